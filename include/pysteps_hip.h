@@ -1,0 +1,94 @@
+/* pysteps_hip.h - C ABI of libpysteps_hip.so (MI355X / gfx950 advection hot path).
+ *
+ * pysteps has no FFI of its own for this path: the operators are plain Python
+ * callables looked up by name in two module-level tables,
+ *     pysteps/motion/interface.py:36-46         (_methods -> dense_lucaskanade)
+ *     pysteps/extrapolation/interface.py:107-111 (_extrapolation_methods -> extrapolate)
+ * The drop-in boundary is therefore "Python callable -> ctypes -> this header".
+ * Every entry point below names the reference interface whose arithmetic it
+ * replaces.  All functions return 0 on success and a negative PSH_E* code on
+ * failure; psh_last_error() then returns a thread-local description.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; images are row-major, x (columns) fastest.
+ *  - "_dev" pointers are device pointers obtained from psh_malloc(); those
+ *    calls are asynchronous on the library's HIP stream (psh_sync() to wait).
+ *    "_host" entry points take host pointers, stage through device memory and
+ *    return synchronously.
+ *  - velocity is (2,m,n): plane 0 = u (px/step along x), plane 1 = v (along y),
+ *    as in semilagrangian.py:44-46.
+ *  - displacement is (2,m,n) float64 on both sides of the boundary, the dtype
+ *    the reference returns (semilagrangian.py:201,264-266).
+ */
+#ifndef PYSTEPS_HIP_H
+#define PYSTEPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSH_OK 0
+#define PSH_EINVAL (-1)   /* bad argument (maps to ValueError in the Python shim) */
+#define PSH_EHIP (-2)     /* HIP runtime error */
+#define PSH_ENOTINIT (-3) /* psh_init() not called */
+#define PSH_ENOMEM (-4)
+#define PSH_ECOMM (-5)    /* RCCL error / librccl.so not loadable */
+#define PSH_EUNSUPPORTED (-6)
+
+/* ---- runtime ----------------------------------------------------------- */
+int psh_init(int device_id);          /* idempotent; binds the calling process to one GPU */
+int psh_shutdown(void);
+const char *psh_last_error(void);
+const char *psh_version(void);
+/* name_len bytes of name are filled (NUL-terminated); any pointer may be NULL */
+int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hbm_free,
+                    char *name, int name_len);
+
+int psh_malloc(void **dev_ptr, size_t nbytes);
+int psh_free(void *dev_ptr);
+int psh_memcpy_h2d(void *dst_dev, const void *src_host, size_t nbytes); /* async; pageable src is staged */
+int psh_memcpy_d2h(void *dst_host, const void *src_dev, size_t nbytes); /* synchronous */
+int psh_memcpy_d2d(void *dst_dev, const void *src_dev, size_t nbytes);  /* async */
+int psh_memset(void *dst_dev, int byte_value, size_t nbytes);           /* async */
+int psh_sync(void);
+
+/* HIP events on the library stream (bench.py times kernels with these) */
+int psh_event_create(void **event);
+int psh_event_destroy(void *event);
+int psh_event_record(void *event);
+int psh_event_elapsed_ms(void *start, void *stop, float *ms); /* waits for stop */
+
+/* ---- semi-Lagrangian extrapolation ------------------------------------- *
+ * Replaces pysteps/extrapolation/semilagrangian.py:21-266 (extrapolate) incl.
+ * its inner interpolate_motion (:181-198) and the scipy.ndimage.map_coordinates
+ * order-0/1 resampling it calls (:185-190 mode="nearest", :225-232
+ * mode="constant").  One fused kernel integrates every pixel's trajectory
+ * through all T lead steps (n_iter midpoint sub-steps each) and writes one
+ * advected plane per lead step.
+ *
+ *  precip      (m,n) float32 or NULL (displacement only; nowcasts/utils.py:498-503)
+ *  velocity    (2,m,n) float32
+ *  steps_host  T doubles, HOST memory: lead-time increments / vel_timestep
+ *              (timestep_diff / vel_timestep of semilagrangian.py:165,198)
+ *  n_iter      >= 0 (0 = no midpoint rule, :215-219)
+ *  interp_order 0 or 1 for the precip resampling (:85-90)
+ *  outval      value for pixels advected from outside the domain (may be NaN)
+ *  disp        (2,m,n) float64 or NULL; if resume != 0 it holds displacement_prev
+ *              on entry (:203-207); if non-NULL it receives the final displacement
+ *  out         (T,m,n) float32, required iff precip != NULL
+ */
+int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
+                    const double *steps_host, int T, int n_iter, int interp_order,
+                    float outval, double *disp_dev, int resume, float *out_dev);
+
+int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
+                     const double *steps, int T, int n_iter, int interp_order, float outval,
+                     const double *disp_prev, double *disp_out, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYSTEPS_HIP_H */

@@ -1,0 +1,230 @@
+"""CPU oracle for the semi-Lagrangian extrapolator.  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker for the HIP path, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it.  ``pysteps_amd`` must never import anything under ``oracle/``.
+
+It restates, in float64 NumPy, the algorithm of the reference
+
+    pysteps/extrapolation/semilagrangian.py:21-266   (``extrapolate``)
+    pysteps/extrapolation/semilagrangian.py:181-198  (``interpolate_motion``)
+
+whose arithmetic lives in the third-party ``scipy.ndimage.map_coordinates``
+(SciPy 1.15.3 here; not under /root/reference).  Two samplers are provided:
+
+* ``backend="numpy"``  - a self-contained restatement of order-0/1
+  ``map_coordinates`` semantics: ``mode="nearest"``
+  clamps the coordinate to ``[0, len-1]``; ``mode="constant"`` returns ``cval``
+  iff a coordinate is ``< 0`` or ``> len-1`` (strict), otherwise the four taps
+  ``floor, floor+1`` are all multiplied (a NaN tap poisons the sample even at
+  weight 0) and a ``floor+1 == len`` tap is index-mirrored to ``len-2``.
+* ``backend="scipy"``  - the same driver calling ``map_coordinates`` itself,
+  i.e. the reference's own third-party kernel (used as the CPU baseline that
+  is closest to the reference, and to validate the NumPy restatement).
+
+Pinning: ``tests/test_oracle_semilag.py`` checks both backends against the two
+known-answer tests of pysteps/tests/test_extrapolation_semilagrangian.py:9-24,
+57-72 and against golden vectors produced by the real reference
+(``tools/make_golden.py``, fixtures under ``tests/golden/``).
+"""
+
+import numpy as np
+
+__all__ = ["extrapolate", "sample_velocity", "sample_field"]
+
+
+# --------------------------------------------------------------------------
+# order-0 / order-1 resampling, restated
+# --------------------------------------------------------------------------
+def _taps(coord, length):
+    """floor index, mirrored upper index and upper weight for in-range coords."""
+    base = np.floor(coord)
+    frac = coord - base
+    lo = base.astype(np.int64)
+    hi = lo + 1
+    # the upper tap can only leave the array when coord == length-1 exactly
+    # (weight 0 there); SciPy mirrors that index back inside.
+    hi = np.where(hi > length - 1, np.maximum(length - 2, 0), hi)
+    lo = np.clip(lo, 0, length - 1)
+    return lo, hi, frac
+
+
+def _bilinear(field, row, col):
+    m, n = field.shape
+    r0, r1, fr = _taps(row, m)
+    c0, c1, fc = _taps(col, n)
+    f = field.astype(np.float64, copy=False)
+    # all four products are formed, so NaN/Inf taps propagate at weight 0
+    return (
+        (1.0 - fr) * (1.0 - fc) * f[r0, c0]
+        + (1.0 - fr) * fc * f[r0, c1]
+        + fr * (1.0 - fc) * f[r1, c0]
+        + fr * fc * f[r1, c1]
+    )
+
+
+def _numpy_sample(field, row, col, mode, cval, order):
+    m, n = field.shape
+    row = np.asarray(row, dtype=np.float64)
+    col = np.asarray(col, dtype=np.float64)
+    if mode == "nearest":
+        rr = np.clip(row, 0.0, m - 1.0)
+        cc = np.clip(col, 0.0, n - 1.0)
+        outside = None
+    elif mode == "constant":
+        outside = (row < 0.0) | (row > m - 1.0) | (col < 0.0) | (col > n - 1.0)
+        rr = np.where(outside, 0.0, row)
+        cc = np.where(outside, 0.0, col)
+    else:
+        raise NotImplementedError("numpy backend restates modes nearest/constant only")
+
+    if order == 1:
+        val = _bilinear(field, rr, cc)
+    elif order == 0:
+        ri = np.floor(rr + 0.5).astype(np.int64)
+        ci = np.floor(cc + 0.5).astype(np.int64)
+        val = field.astype(np.float64, copy=False)[
+            np.clip(ri, 0, m - 1), np.clip(ci, 0, n - 1)
+        ]
+    else:
+        raise NotImplementedError("numpy backend restates interpolation order 0/1 only")
+
+    if outside is not None:
+        val = np.where(outside, cval, val)
+    return val
+
+
+def _scipy_sample(field, row, col, mode, cval, order):
+    from scipy.ndimage import map_coordinates
+
+    return map_coordinates(
+        field, [row, col], mode=mode, cval=cval, order=order, prefilter=order > 1
+    )
+
+
+_BACKENDS = {"numpy": _numpy_sample, "scipy": _scipy_sample}
+
+
+def sample_velocity(velocity, dx, dy, backend="numpy"):
+    """Both velocity components at (x+dx, y+dy), edge-clamped (reference :181-190)."""
+    m, n = velocity.shape[1:]
+    yy, xx = np.mgrid[0:m, 0:n]
+    fn = _BACKENDS[backend]
+    return np.stack(
+        [fn(velocity[c], yy + dy, xx + dx, "nearest", 0.0, 1) for c in range(2)]
+    )
+
+
+def sample_field(field, dx, dy, cval=np.nan, order=1, backend="numpy"):
+    """Scalar field at (x+dx, y+dy); outside -> cval (reference :221-232)."""
+    m, n = field.shape
+    yy, xx = np.mgrid[0:m, 0:n]
+    return _BACKENDS[backend](field, yy + dy, xx + dx, "constant", cval, order)
+
+
+# --------------------------------------------------------------------------
+# driver
+# --------------------------------------------------------------------------
+def _step_sizes(timesteps, vel_timestep):
+    """Lead-time increments in units of the velocity time step (reference :159-165)."""
+    if isinstance(timesteps, (int, np.integer)) and not isinstance(timesteps, bool):
+        return np.ones(int(timesteps), dtype=np.float64)
+    ts = np.asarray(timesteps, dtype=np.float64)
+    if ts.ndim != 1 or ts.size == 0:
+        raise ValueError("timesteps must be an int or a 1-d sequence")
+    if np.any(np.diff(ts) <= 0.0):
+        raise ValueError("the given timestep sequence is not monotonously increasing")
+    return np.concatenate([ts[:1], np.diff(ts)]) / float(vel_timestep)
+
+
+def extrapolate(
+    precip,
+    velocity,
+    timesteps,
+    outval=np.nan,
+    allow_nonfinite_values=False,
+    vel_timestep=1,
+    displacement_prev=None,
+    n_iter=1,
+    return_displacement=False,
+    interp_order=1,
+    backend="numpy",
+):
+    """float64 restatement of semilagrangian.extrapolate (reference :21-266).
+
+    Returns what the reference returns: ``(T,m,n)`` in the dtype of ``precip``
+    (SciPy allocates its output in the input dtype), optionally with the
+    float64 displacement ``(2,m,n)``; ``(None, displacement)`` for precip None.
+    """
+    sampler = _BACKENDS[backend]
+    if precip is not None and precip.ndim != 2:
+        raise ValueError("precip must be a two-dimensional array")
+    if velocity.ndim != 3:
+        raise ValueError("velocity must be a three-dimensional array")
+    if not allow_nonfinite_values:
+        if precip is not None and not np.all(np.isfinite(precip)):
+            raise ValueError("precip contains non-finite values")
+        if not np.all(np.isfinite(velocity)):
+            raise ValueError("velocity contains non-finite values")
+    if precip is not None and not np.any(np.isfinite(precip)):
+        raise ValueError("precip contains only non-finite values")
+    if not np.any(np.isfinite(velocity)):
+        raise ValueError("velocity contains only non-finite values")
+    if isinstance(timesteps, list) and sorted(timesteps) != timesteps:
+        raise ValueError("timesteps is not in ascending order")
+    if precip is None and not return_displacement:
+        raise ValueError("precip is None but return_displacement is False")
+
+    steps = _step_sizes(timesteps, vel_timestep)
+    if isinstance(outval, str):
+        if outval != "min":
+            raise ValueError("outval must be a number or 'min'")
+        outval = np.nanmin(precip) if precip is not None else np.nan
+
+    m, n = velocity.shape[1:]
+    yy, xx = np.mgrid[0:m, 0:n]
+    sub = float(n_iter) if n_iter > 1 else 1.0
+
+    def motion_at(dx, dy, step):
+        # map_coordinates allocates its output in the dtype of the sampled
+        # array, so float32 velocities give float32-rounded samples.
+        v = np.stack(
+            [
+                np.asarray(
+                    sampler(velocity[c], yy + dy, xx + dx, "nearest", 0.0, 1)
+                ).astype(velocity.dtype)
+                for c in range(2)
+            ]
+        ).astype(np.float64)
+        return v / sub * step
+
+    if displacement_prev is None:
+        disp = np.zeros((2, m, n))
+        # NB the very first increment is NOT divided by n_iter (reference :202)
+        inc = velocity.astype(np.float64) * steps[0]
+        resumed = False
+    else:
+        disp = np.array(displacement_prev, dtype=np.float64)
+        inc = motion_at(disp[0], disp[1], steps[0])
+        resumed = True
+
+    frames = []
+    for ti, step in enumerate(steps):
+        if n_iter > 0:
+            for _ in range(n_iter):
+                inc = motion_at(disp[0] - inc[0] / 2.0, disp[1] - inc[1] / 2.0, step)
+                disp = disp - inc
+                inc = motion_at(disp[0], disp[1], step)
+        else:
+            if ti > 0 or resumed:
+                inc = motion_at(disp[0], disp[1], step)
+            disp = disp - inc
+
+        if precip is not None:
+            val = sampler(precip, yy + disp[1], xx + disp[0], "constant", outval, interp_order)
+            frames.append(np.asarray(val).astype(precip.dtype, copy=False))
+
+    if precip is None:
+        return None, disp
+    out = np.stack(frames)
+    return (out, disp) if return_displacement else out

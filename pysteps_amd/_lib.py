@@ -1,0 +1,121 @@
+"""ctypes binding of libpysteps_hip.so (the C ABI declared in include/pysteps_hip.h).
+
+There is deliberately no CPU fallback: if the shared object is missing or the
+GPU cannot be initialised the product path raises, it never computes elsewhere.
+"""
+
+import ctypes
+import os
+import threading
+
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libpysteps_hip.so")
+
+PSH_OK = 0
+PSH_EINVAL = -1
+PSH_EHIP = -2
+PSH_ENOTINIT = -3
+PSH_ENOMEM = -4
+PSH_ECOMM = -5
+PSH_EUNSUPPORTED = -6
+
+
+class HipLibraryError(RuntimeError):
+    """libpysteps_hip.so is missing, failed to load, or a HIP/RCCL call failed."""
+
+
+# name -> (restype, argtypes); kept in step with include/pysteps_hip.h
+# (tests/test_capi_symbols.py parses the header and compares).
+SIGNATURES = {
+    "psh_init": (c_int, [c_int]),
+    "psh_shutdown": (c_int, []),
+    "psh_last_error": (c_char_p, []),
+    "psh_version": (c_char_p, []),
+    "psh_device_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t), c_char_p, c_int]),
+    "psh_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "psh_free": (c_int, [c_void_p]),
+    "psh_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "psh_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "psh_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "psh_memset": (c_int, [c_void_p, c_int, c_size_t]),
+    "psh_sync": (c_int, []),
+    "psh_event_create": (c_int, [POINTER(c_void_p)]),
+    "psh_event_destroy": (c_int, [c_void_p]),
+    "psh_event_record": (c_int, [c_void_p]),
+    "psh_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
+    "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+}
+
+_lock = threading.RLock()
+_lib = None
+_initialised = False
+
+
+def load():
+    """dlopen the library and declare the prototypes (no GPU needed)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                "libpysteps_hip.so not found at %s - build it with "
+                "`python -m pysteps_amd.build` (hipcc, gfx950). pysteps_amd has no CPU fallback."
+                % LIB_PATH
+            )
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise HipLibraryError("cannot load %s: %s" % (LIB_PATH, exc)) from exc
+        for name, (restype, argtypes) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as exc:
+                raise HipLibraryError("%s does not export %s" % (LIB_PATH, name)) from exc
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+        return lib
+
+
+def last_error():
+    msg = load().psh_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, what=""):
+    """Map a C status code onto the exception the reference would raise."""
+    if rc == PSH_OK:
+        return
+    msg = "%s%s" % (what + ": " if what else "", last_error())
+    if rc == PSH_EINVAL:
+        raise ValueError(msg)
+    if rc == PSH_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == PSH_ENOMEM:
+        raise MemoryError(msg)
+    raise HipLibraryError(msg)
+
+
+def default_device():
+    """Device index for this process: PYSTEPS_HIP_DEVICE, else LOCAL_RANK, else 0."""
+    for key in ("PYSTEPS_HIP_DEVICE", "LOCAL_RANK"):
+        val = os.environ.get(key)
+        if val not in (None, ""):
+            return int(val)
+    return 0
+
+
+def lib():
+    """Loaded library with the GPU bound (psh_init done); raises if there is no GPU."""
+    global _initialised
+    handle = load()
+    if not _initialised:
+        with _lock:
+            if not _initialised:
+                check(handle.psh_init(default_device()), "psh_init")
+                _initialised = True
+    return handle

@@ -1,0 +1,62 @@
+// Shared host-side plumbing of libpysteps_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+
+#include "../../include/pysteps_hip.h"
+
+namespace psh {
+
+constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, block b is dispatched to XCD b % 8
+
+struct Context {
+  bool ready = false;
+  int device = -1;
+  int cu_count = 0;
+  hipStream_t stream = nullptr;
+  // small persistent device scratch (per-step scale factors etc.)
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // pinned staging buffer for pageable host copies
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+  std::recursive_mutex mu;
+};
+
+Context &ctx();
+int fail(int code, const char *fmt, ...);
+int ensure_scratch(size_t nbytes);
+
+#define PSH_HIP(expr)                                                            \
+  do {                                                                           \
+    hipError_t _e = (expr);                                                      \
+    if (_e != hipSuccess)                                                        \
+      return ::psh::fail(PSH_EHIP, "%s failed: %s (%s:%d)", #expr,               \
+                         hipGetErrorString(_e), __FILE__, __LINE__);             \
+  } while (0)
+
+#define PSH_REQUIRE_INIT()                                                       \
+  do {                                                                           \
+    if (!::psh::ctx().ready)                                                     \
+      return ::psh::fail(PSH_ENOTINIT, "psh_init() has not been called");        \
+  } while (0)
+
+// ---- kernel launchers (one per .hip translation unit) ----------------------
+struct SemilagArgs {
+  const float *precip;  // (m,n) or nullptr
+  const float *vel;     // (2,m,n)
+  float *out;           // (T,m,n) or nullptr
+  double *disp;         // (2,m,n) in/out or nullptr
+  const float *scale;   // device, T floats: step / vel_timestep
+  int m, n, T, n_iter, order, resume;
+  float outval;
+};
+hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
+
+}  // namespace psh

@@ -1,0 +1,370 @@
+// Runtime half of the C ABI (include/pysteps_hip.h): device binding, memory,
+// events, error reporting.  One process drives one GPU (one rank per device).
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace psh {
+
+Context &ctx() {
+  static Context c;
+  return c;
+}
+
+static thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int ensure_scratch(size_t nbytes) {
+  Context &c = ctx();
+  if (c.scratch_bytes >= nbytes) return PSH_OK;
+  if (c.scratch) {
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    PSH_HIP(hipFree(c.scratch));
+    c.scratch = nullptr;
+    c.scratch_bytes = 0;
+  }
+  size_t want = nbytes < 65536 ? 65536 : nbytes;
+  PSH_HIP(hipMalloc(&c.scratch, want));
+  c.scratch_bytes = want;
+  return PSH_OK;
+}
+
+static int ensure_pinned(size_t nbytes) {
+  Context &c = ctx();
+  if (c.pinned_bytes >= nbytes) return PSH_OK;
+  if (c.pinned) {
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    PSH_HIP(hipHostFree(c.pinned));
+    c.pinned = nullptr;
+    c.pinned_bytes = 0;
+  }
+  PSH_HIP(hipHostMalloc(&c.pinned, nbytes, hipHostMallocDefault));
+  c.pinned_bytes = nbytes;
+  return PSH_OK;
+}
+
+}  // namespace psh
+
+using psh::ctx;
+using psh::fail;
+
+extern "C" {
+
+const char *psh_last_error(void) { return psh::g_err; }
+
+const char *psh_version(void) { return "pysteps_hip 0.1 (gfx950)"; }
+
+int psh_init(int device_id) {
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  if (c.ready) {
+    if (device_id >= 0 && device_id != c.device)
+      return fail(PSH_EINVAL, "already bound to device %d (asked for %d)", c.device, device_id);
+    return PSH_OK;
+  }
+  int count = 0;
+  PSH_HIP(hipGetDeviceCount(&count));
+  if (count <= 0) return fail(PSH_EHIP, "no HIP device visible");
+  if (device_id < 0) device_id = 0;
+  if (device_id >= count)
+    return fail(PSH_EINVAL, "device %d out of range (%d visible)", device_id, count);
+  PSH_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  PSH_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(PSH_EUNSUPPORTED, "device %d is %s; this library is built for gfx950 only",
+                device_id, prop.gcnArchName);
+  c.device = device_id;
+  c.cu_count = prop.multiProcessorCount;
+  PSH_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  c.ready = true;
+  return PSH_OK;
+}
+
+int psh_shutdown(void) {
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  if (!c.ready) return PSH_OK;
+  hipStreamSynchronize(c.stream);
+  if (c.scratch) hipFree(c.scratch);
+  if (c.pinned) hipHostFree(c.pinned);
+  hipStreamDestroy(c.stream);
+  c.scratch = c.pinned = nullptr;
+  c.scratch_bytes = c.pinned_bytes = 0;
+  c.stream = nullptr;
+  c.ready = false;
+  return PSH_OK;
+}
+
+int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hbm_free,
+                    char *name, int name_len) {
+  PSH_REQUIRE_INIT();
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  if (device_id) *device_id = c.device;
+  if (cu_count) *cu_count = c.cu_count;
+  if (hbm_total || hbm_free) {
+    size_t f = 0, t = 0;
+    PSH_HIP(hipMemGetInfo(&f, &t));
+    if (hbm_total) *hbm_total = t;
+    if (hbm_free) *hbm_free = f;
+  }
+  if (name && name_len > 0) {
+    hipDeviceProp_t prop;
+    PSH_HIP(hipGetDeviceProperties(&prop, c.device));
+    std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  return PSH_OK;
+}
+
+int psh_malloc(void **dev_ptr, size_t nbytes) {
+  PSH_REQUIRE_INIT();
+  if (!dev_ptr) return fail(PSH_EINVAL, "psh_malloc: NULL out pointer");
+  std::lock_guard<std::recursive_mutex> lock(ctx().mu);
+  PSH_HIP(hipSetDevice(ctx().device));
+  *dev_ptr = nullptr;
+  if (nbytes == 0) return PSH_OK;
+  hipError_t e = hipMalloc(dev_ptr, nbytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    return fail(PSH_ENOMEM, "hipMalloc(%zu) out of device memory", nbytes);
+  }
+  PSH_HIP(e);
+  return PSH_OK;
+}
+
+int psh_free(void *dev_ptr) {
+  PSH_REQUIRE_INIT();
+  if (!dev_ptr) return PSH_OK;
+  std::lock_guard<std::recursive_mutex> lock(ctx().mu);
+  PSH_HIP(hipSetDevice(ctx().device));
+  PSH_HIP(hipStreamSynchronize(ctx().stream));
+  PSH_HIP(hipFree(dev_ptr));
+  return PSH_OK;
+}
+
+int psh_memcpy_h2d(void *dst_dev, const void *src_host, size_t nbytes) {
+  PSH_REQUIRE_INIT();
+  if (nbytes == 0) return PSH_OK;
+  if (!dst_dev || !src_host) return fail(PSH_EINVAL, "psh_memcpy_h2d: NULL pointer");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  // pageable source: the runtime stages it, after which the host buffer may be reused
+  PSH_HIP(hipMemcpyAsync(dst_dev, src_host, nbytes, hipMemcpyHostToDevice, c.stream));
+  return PSH_OK;
+}
+
+int psh_memcpy_d2h(void *dst_host, const void *src_dev, size_t nbytes) {
+  PSH_REQUIRE_INIT();
+  if (nbytes == 0) return PSH_OK;
+  if (!dst_host || !src_dev) return fail(PSH_EINVAL, "psh_memcpy_d2h: NULL pointer");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  PSH_HIP(hipMemcpyAsync(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipStreamSynchronize(c.stream));
+  return PSH_OK;
+}
+
+int psh_memcpy_d2d(void *dst_dev, const void *src_dev, size_t nbytes) {
+  PSH_REQUIRE_INIT();
+  if (nbytes == 0) return PSH_OK;
+  if (!dst_dev || !src_dev) return fail(PSH_EINVAL, "psh_memcpy_d2d: NULL pointer");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  PSH_HIP(hipMemcpyAsync(dst_dev, src_dev, nbytes, hipMemcpyDeviceToDevice, c.stream));
+  return PSH_OK;
+}
+
+int psh_memset(void *dst_dev, int byte_value, size_t nbytes) {
+  PSH_REQUIRE_INIT();
+  if (nbytes == 0) return PSH_OK;
+  if (!dst_dev) return fail(PSH_EINVAL, "psh_memset: NULL pointer");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  PSH_HIP(hipMemsetAsync(dst_dev, byte_value, nbytes, c.stream));
+  return PSH_OK;
+}
+
+int psh_sync(void) {
+  PSH_REQUIRE_INIT();
+  psh::Context &c = ctx();
+  PSH_HIP(hipSetDevice(c.device));
+  PSH_HIP(hipStreamSynchronize(c.stream));
+  return PSH_OK;
+}
+
+int psh_event_create(void **event) {
+  PSH_REQUIRE_INIT();
+  if (!event) return fail(PSH_EINVAL, "psh_event_create: NULL out pointer");
+  PSH_HIP(hipSetDevice(ctx().device));
+  hipEvent_t e;
+  PSH_HIP(hipEventCreate(&e));
+  *event = e;
+  return PSH_OK;
+}
+
+int psh_event_destroy(void *event) {
+  PSH_REQUIRE_INIT();
+  if (event) PSH_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+  return PSH_OK;
+}
+
+int psh_event_record(void *event) {
+  PSH_REQUIRE_INIT();
+  if (!event) return fail(PSH_EINVAL, "psh_event_record: NULL event");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  PSH_HIP(hipEventRecord(static_cast<hipEvent_t>(event), c.stream));
+  return PSH_OK;
+}
+
+int psh_event_elapsed_ms(void *start, void *stop, float *ms) {
+  PSH_REQUIRE_INIT();
+  if (!start || !stop || !ms) return fail(PSH_EINVAL, "psh_event_elapsed_ms: NULL argument");
+  PSH_HIP(hipSetDevice(ctx().device));
+  PSH_HIP(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+  PSH_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+  return PSH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// semi-Lagrangian extrapolation
+// ---------------------------------------------------------------------------
+static int check_semilag(int m, int n, int T, int n_iter, int order) {
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "semilag: invalid shape (%d,%d)", m, n);
+  if (static_cast<uint64_t>(m) * static_cast<uint64_t>(n) >= (1ull << 30))
+    return fail(PSH_EUNSUPPORTED, "semilag: m*n must be < 2^30 pixels (32-bit byte offsets)");
+  if (T <= 0) return fail(PSH_EINVAL, "semilag: T must be positive (got %d)", T);
+  if (n_iter < 0) return fail(PSH_EINVAL, "semilag: n_iter must be >= 0 (got %d)", n_iter);
+  if (order != 0 && order != 1)
+    return fail(PSH_EUNSUPPORTED, "semilag: interp_order %d not implemented (0 or 1)", order);
+  return PSH_OK;
+}
+
+int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
+                    const double *steps_host, int T, int n_iter, int interp_order,
+                    float outval, double *disp_dev, int resume, float *out_dev) {
+  PSH_REQUIRE_INIT();
+  if (int rc = check_semilag(m, n, T, n_iter, interp_order)) return rc;
+  if (!velocity_dev || !steps_host) return fail(PSH_EINVAL, "semilag: NULL velocity/steps");
+  if (precip_dev && !out_dev) return fail(PSH_EINVAL, "semilag: precip given but out is NULL");
+  if (!precip_dev && !disp_dev)
+    return fail(PSH_EINVAL, "semilag: precip is NULL but no displacement buffer was given");
+  if (resume && !disp_dev) return fail(PSH_EINVAL, "semilag: resume without displacement");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  // per-step scale factors: a fresh slot per call so that back-to-back async
+  // calls never overwrite factors a queued kernel still has to read
+  static size_t slot = 0;
+  const size_t slot_floats = 1024;
+  if (static_cast<size_t>(T) > slot_floats)
+    return fail(PSH_EUNSUPPORTED, "semilag: at most %zu lead steps per call", slot_floats);
+  const size_t n_slots = 64;
+  if (int rc = psh::ensure_scratch(n_slots * slot_floats * sizeof(float))) return rc;
+  if (int rc = psh::ensure_pinned(n_slots * slot_floats * sizeof(float))) return rc;
+  if (slot == n_slots) {  // ring wrapped: make sure the oldest slots are consumed
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    slot = 0;
+  }
+  float *h = static_cast<float *>(c.pinned) + slot * slot_floats;
+  float *d = static_cast<float *>(c.scratch) + slot * slot_floats;
+  ++slot;
+  for (int t = 0; t < T; ++t) h[t] = static_cast<float>(steps_host[t]);
+  PSH_HIP(hipMemcpyAsync(d, h, T * sizeof(float), hipMemcpyHostToDevice, c.stream));
+
+  psh::SemilagArgs a;
+  a.precip = precip_dev;
+  a.vel = velocity_dev;
+  a.out = out_dev;
+  a.disp = disp_dev;
+  a.scale = d;
+  a.m = m;
+  a.n = n;
+  a.T = T;
+  a.n_iter = n_iter;
+  a.order = interp_order;
+  a.resume = resume;
+  a.outval = outval;
+  PSH_HIP(psh::launch_semilag(a, c.stream));
+  return PSH_OK;
+}
+
+int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
+                     const double *steps, int T, int n_iter, int interp_order, float outval,
+                     const double *disp_prev, double *disp_out, float *out) {
+  PSH_REQUIRE_INIT();
+  if (int rc = check_semilag(m, n, T, n_iter, interp_order)) return rc;
+  if (!velocity || !steps) return fail(PSH_EINVAL, "semilag: NULL velocity/steps");
+  if (precip && !out) return fail(PSH_EINVAL, "semilag: precip given but out is NULL");
+  if (!precip && !disp_out)
+    return fail(PSH_EINVAL, "semilag: precip is NULL but no displacement output was given");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t plane = static_cast<size_t>(m) * n;
+  float *d_p = nullptr, *d_v = nullptr, *d_out = nullptr;
+  double *d_disp = nullptr;
+  int rc = PSH_OK;
+  auto cleanup = [&]() {
+    hipStreamSynchronize(c.stream);
+    if (d_p) hipFree(d_p);
+    if (d_v) hipFree(d_v);
+    if (d_out) hipFree(d_out);
+    if (d_disp) hipFree(d_disp);
+  };
+#define PSH_TRY(expr)                                                        \
+  do {                                                                       \
+    hipError_t _e = (expr);                                                  \
+    if (_e != hipSuccess) {                                                  \
+      cleanup();                                                             \
+      return fail(_e == hipErrorOutOfMemory ? PSH_ENOMEM : PSH_EHIP,         \
+                  "%s failed: %s", #expr, hipGetErrorString(_e));            \
+    }                                                                        \
+  } while (0)
+  PSH_TRY(hipMalloc(&d_v, 2 * plane * sizeof(float)));
+  PSH_TRY(hipMemcpyAsync(d_v, velocity, 2 * plane * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  if (precip) {
+    PSH_TRY(hipMalloc(&d_p, plane * sizeof(float)));
+    PSH_TRY(hipMemcpyAsync(d_p, precip, plane * sizeof(float), hipMemcpyHostToDevice, c.stream));
+    PSH_TRY(hipMalloc(&d_out, static_cast<size_t>(T) * plane * sizeof(float)));
+  }
+  if (disp_prev || disp_out) {
+    PSH_TRY(hipMalloc(&d_disp, 2 * plane * sizeof(double)));
+    if (disp_prev)
+      PSH_TRY(hipMemcpyAsync(d_disp, disp_prev, 2 * plane * sizeof(double), hipMemcpyHostToDevice,
+                             c.stream));
+  }
+  rc = psh_semilag_dev(d_p, d_v, m, n, steps, T, n_iter, interp_order, outval, d_disp,
+                       disp_prev != nullptr, d_out);
+  if (rc != PSH_OK) {
+    cleanup();
+    return rc;
+  }
+  if (precip)
+    PSH_TRY(hipMemcpyAsync(out, d_out, static_cast<size_t>(T) * plane * sizeof(float),
+                           hipMemcpyDeviceToHost, c.stream));
+  if (disp_out)
+    PSH_TRY(hipMemcpyAsync(disp_out, d_disp, 2 * plane * sizeof(double), hipMemcpyDeviceToHost,
+                           c.stream));
+  PSH_TRY(hipStreamSynchronize(c.stream));
+#undef PSH_TRY
+  cleanup();
+  return PSH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / at round end)")
+
+
+class GoldenCases:
+    """Cases stored by tools/make_golden.py: inputs, kwargs and reference outputs."""
+
+    def __init__(self, path):
+        self._z = np.load(path, allow_pickle=False)
+        self.names = sorted({k.split("/")[0] for k in self._z.files})
+
+    def case(self, name):
+        z = self._z
+        c = {"kw": {}}
+        for key in z.files:
+            if not key.startswith(name + "/"):
+                continue
+            rest = key[len(name) + 1:]
+            if rest.startswith("kw/"):
+                v = z[key]
+                c["kw"][rest[3:]] = v.item() if v.ndim == 0 else v
+            else:
+                c[rest] = z[key]
+        if "timesteps" in c:
+            if bool(c.pop("timesteps_is_int")):
+                c["timesteps"] = int(c["timesteps"])
+            else:
+                c["timesteps"] = [float(t) for t in np.atleast_1d(c["timesteps"])]
+        return c
+
+
+@pytest.fixture(scope="session")
+def semilag_golden():
+    return GoldenCases(os.path.join(GOLDEN, "semilag_reference.npz"))
+
+
+def rel_l2(a, b):
+    """relative L2 error over jointly finite entries (BASELINE.md section 3 'Parity')."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    ok = np.isfinite(a) & np.isfinite(b)
+    den = np.linalg.norm(b[ok])
+    return float(np.linalg.norm(a[ok] - b[ok]) / (den if den > 0 else 1.0))
+
+
+def nan_mismatch(a, b):
+    return int(np.count_nonzero(np.isnan(np.asarray(a)) != np.isnan(np.asarray(b))))

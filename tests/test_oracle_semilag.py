@@ -1,0 +1,121 @@
+"""Pin the CPU oracles (oracle/semilag.py, oracle/semilag_c.c) to the reference.
+
+* the two known-answer tests of pysteps/tests/test_extrapolation_semilagrangian.py:9-24,57-72
+* golden vectors produced by the unmodified reference (tools/make_golden.py)
+* if /root/reference is present (build container), a live comparison as well
+"""
+
+import numpy as np
+import pytest
+from numpy.testing import assert_array_almost_equal
+
+from oracle import semilag as osl
+from oracle import semilag_cport as ocl
+from tools import ref_loader
+
+from conftest import nan_mismatch
+
+GOLDEN_SL = [
+    "sl_int_T6", "sl_shear_K3", "sl_K0", "sl_list_vt", "sl_nan_min", "sl_nan_nan",
+    "sl_order0", "sl_resume", "sl_resume_K0", "sl_f64",
+]
+
+
+def _kat_inputs(speed):
+    precip = np.zeros((8, 8))
+    precip[0, 0] = 1
+    v = np.ones((8, 8)) * speed
+    expected = np.zeros((1, 8, 8))
+    expected[:, :, 0] = np.nan
+    expected[:, 0, :] = np.nan
+    expected[:, 1, 1] = 1
+    return precip, np.stack([v, v]), expected
+
+
+@pytest.mark.parametrize("backend", ["numpy", "scipy", "c"])
+@pytest.mark.parametrize("speed,timesteps", [(1, 1), (10, [0.1])])
+def test_reference_known_answers(backend, speed, timesteps):
+    precip, velocity, expected = _kat_inputs(speed)
+    if backend == "c":
+        result = ocl.extrapolate(precip, velocity, timesteps)
+    else:
+        result = osl.extrapolate(precip, velocity, timesteps, backend=backend)
+    assert_array_almost_equal(result, expected)
+
+
+def _run(backend, c):
+    kw = dict(c["kw"])
+    kw.pop("allow_nonfinite_values", None)
+    if backend == "c":
+        return ocl.extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **kw)
+    return osl.extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True,
+                           allow_nonfinite_values=True, backend=backend, **kw)
+
+
+@pytest.mark.parametrize("backend", ["numpy", "scipy", "c"])
+@pytest.mark.parametrize("name", GOLDEN_SL)
+def test_oracle_matches_reference_golden(semilag_golden, backend, name):
+    c = semilag_golden.case(name)
+    if backend == "c" and c["precip"].dtype != np.float32:
+        pytest.skip("the C port takes float32 fields")
+    out, disp = _run(backend, c)
+    assert out.shape == c["out"].shape
+    if backend != "c":
+        assert out.dtype == c["out"].dtype
+    assert nan_mismatch(out, c["out"]) == 0
+    np.testing.assert_allclose(disp, c["disp"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out, c["out"], rtol=0, atol=2e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("backend", ["numpy", "c"])
+def test_displacement_only(semilag_golden, backend):
+    c = semilag_golden.case("sl_disp_only")
+    mod = ocl if backend == "c" else osl
+    none, disp = mod.extrapolate(None, c["velocity"], [0.7], return_displacement=True, n_iter=1)
+    assert none is None
+    np.testing.assert_allclose(disp, c["disp"], rtol=0, atol=1e-11)
+
+
+def test_oracle_error_behaviour():
+    p = np.ones((8, 8))
+    v = np.ones((2, 8, 8))
+    with pytest.raises(ValueError):
+        osl.extrapolate(np.ones(8), v, 1)
+    with pytest.raises(ValueError):
+        osl.extrapolate(p, np.ones((8, 8)), 1)
+    with pytest.raises(ValueError):
+        osl.extrapolate(p, v, [1, 2, 3, 5, 4, 6, 7])
+    with pytest.raises(ValueError):
+        osl.extrapolate(None, v, 1)
+
+
+def test_chained_calls_equal_one_call():
+    """displacement_prev chaining is bitwise equal to a multi-step call."""
+    rng = np.random.default_rng(5)
+    p = rng.random((40, 56)).astype(np.float32)
+    y, x = np.mgrid[0:40, 0:56]
+    v = np.stack([2 + 0.05 * y, -1 + 0.04 * x]).astype(np.float32)
+    full, dfull = osl.extrapolate(p, v, 3, return_displacement=True)
+    d = None
+    for t in range(3):
+        out, d = osl.extrapolate(p, v, [1.0], return_displacement=True, displacement_prev=d)
+        assert np.array_equal(out[0], full[t], equal_nan=True)
+    assert np.array_equal(d, dfull)
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
+def test_oracle_matches_live_reference():
+    ref = ref_loader.load("pysteps.extrapolation.semilagrangian")
+    rng = np.random.default_rng(11)
+    m, n = 50, 70
+    p = rng.gamma(1.0, 2.0, (m, n)).astype(np.float32)
+    y, x = np.mgrid[0:m, 0:n]
+    v = np.stack([3 + 0.08 * (y - m / 2), -2 + 0.06 * (x - n / 2)]).astype(np.float32)
+    for k in (0, 1, 2):
+        r, rd = ref.extrapolate(p, v, [0.5, 1.25, 2.0], n_iter=k, vel_timestep=0.5, return_displacement=True)
+        for mod, kw in ((osl, dict(backend="numpy")), (ocl, {})):
+            a, ad = mod.extrapolate(p, v, [0.5, 1.25, 2.0], n_iter=k, vel_timestep=0.5,
+                                    return_displacement=True, **kw)
+            assert nan_mismatch(a, r) == 0
+            np.testing.assert_allclose(ad, rd, rtol=0, atol=1e-11)
+            np.testing.assert_allclose(a, r, rtol=0, atol=2e-6, equal_nan=True)

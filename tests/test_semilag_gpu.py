@@ -1,0 +1,219 @@
+"""HIP semi-Lagrangian extrapolator vs the CPU oracle and the reference's golden vectors.
+
+Tolerance (BASELINE.json north_star): advected field within 1e-4 relative L2 of the
+reference CPU path, identical NaN mask; displacement within 1e-4 px.  The tests
+mirror pysteps/tests/test_extrapolation_semilagrangian.py and go through the
+C ABI (ctypes -> psh_semilag_host / psh_semilag_dev).
+"""
+
+import numpy as np
+import pytest
+from numpy.testing import assert_array_almost_equal
+
+from conftest import nan_mismatch, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+REL_L2_TOL = 1e-4
+DISP_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def extrapolate():
+    from pysteps_amd.extrapolation import get_method
+
+    return get_method("semilagrangian")
+
+
+# ---- mirrors of the reference's own tests --------------------------------
+def test_semilagrangian(extrapolate):
+    precip = np.zeros((8, 8))
+    precip[0, 0] = 1
+    v = np.ones((8, 8))
+    velocity = np.stack([v, v])
+    expected = np.zeros((1, 8, 8))
+    expected[:, :, 0] = np.nan
+    expected[:, 0, :] = np.nan
+    expected[:, 1, 1] = 1
+    result = extrapolate(precip, velocity, 1)
+    assert result.dtype == precip.dtype
+    assert_array_almost_equal(result, expected)
+
+
+def test_wrong_input_dimensions(extrapolate):
+    p_1d, p_2d, p_3d = np.ones(8), np.ones((8, 8)), np.ones((8, 8, 2))
+    v_2d = np.ones((8, 8))
+    v_3d = np.stack([v_2d, v_2d])
+    for precip, velocity in [(p_1d, v_3d), (p_2d, v_2d), (p_3d, v_2d), (p_3d, v_3d)]:
+        with pytest.raises(ValueError):
+            extrapolate(precip, velocity, 1)
+
+
+def test_ascending_time_step(extrapolate):
+    precip = np.ones((8, 8))
+    v = np.ones((8, 8))
+    with pytest.raises(ValueError):
+        extrapolate(precip, np.stack([v, v]), [1, 2, 3, 5, 4, 6, 7])
+
+
+def test_semilagrangian_timesteps(extrapolate):
+    precip = np.zeros((8, 8))
+    precip[0, 0] = 1
+    v = np.ones((8, 8)) * 10
+    expected = np.zeros((1, 8, 8))
+    expected[:, :, 0] = np.nan
+    expected[:, 0, :] = np.nan
+    expected[:, 1, 1] = 1
+    result = extrapolate(precip, np.stack([v, v]), [0.1])
+    assert_array_almost_equal(result, expected)
+
+
+def test_nonfinite_and_none_errors(extrapolate):
+    p = np.ones((8, 8))
+    v = np.ones((2, 8, 8))
+    bad = p.copy()
+    bad[2, 2] = np.nan
+    with pytest.raises(ValueError):
+        extrapolate(bad, v, 1)
+    with pytest.raises(ValueError):
+        extrapolate(np.full((8, 8), np.nan), v, 1, allow_nonfinite_values=True)
+    with pytest.raises(ValueError):
+        extrapolate(None, v, 1)
+    with pytest.raises(ValueError):
+        extrapolate(p, v, np.array([1.0, 1.0]))
+
+
+def test_zero_velocity_identity(extrapolate):
+    """pysteps/tests/test_nowcasts_lagrangian_probability.py: border pixels stay inside."""
+    rng = np.random.default_rng(0)
+    p = rng.random((20, 20))
+    out = extrapolate(p, np.zeros((2, 20, 20)), np.array([1.0, 2.0, 5.0, 12.0]))
+    assert out.shape == (4, 20, 20)
+    for t in range(4):
+        np.testing.assert_allclose(out[t], p.astype(np.float32), rtol=0, atol=0)
+
+
+# ---- golden vectors of the real reference ---------------------------------
+GOLDEN_SL = [
+    "sl_int_T6", "sl_shear_K3", "sl_K0", "sl_list_vt", "sl_nan_min", "sl_nan_nan",
+    "sl_order0", "sl_resume", "sl_resume_K0", "sl_f64",
+]
+
+
+@pytest.mark.parametrize("name", GOLDEN_SL)
+def test_matches_reference_golden(extrapolate, semilag_golden, name):
+    c = semilag_golden.case(name)
+    out, disp = extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **c["kw"])
+    assert out.shape == c["out"].shape and out.dtype == c["out"].dtype
+    assert disp.dtype == np.float64 and disp.shape == c["disp"].shape
+    assert nan_mismatch(out, c["out"]) == 0
+    assert np.max(np.abs(disp - c["disp"])) < DISP_TOL
+    if name == "sl_order0":
+        # nearest-neighbour: a 1e-7 px trajectory difference can pick the other pixel
+        differing = np.count_nonzero(out != c["out"])
+        assert differing <= 1e-4 * out.size
+    else:
+        assert rel_l2(out, c["out"]) < REL_L2_TOL
+
+
+def test_displacement_only_golden(extrapolate, semilag_golden):
+    c = semilag_golden.case("sl_disp_only")
+    none, disp = extrapolate(None, c["velocity"], [0.7], return_displacement=True, n_iter=1)
+    assert none is None
+    assert np.max(np.abs(disp - c["disp"])) < DISP_TOL
+
+
+# ---- against the oracle on seeded synthetic fields -------------------------
+@pytest.mark.parametrize("shape", [(1, 1), (1, 37), (33, 1), (5, 3), (64, 4), (65, 5), (257, 131), (512, 512)])
+@pytest.mark.parametrize("n_iter", [0, 1, 3])
+def test_shapes_vs_oracle(extrapolate, shape, n_iter):
+    from oracle import semilag_cport as ocl
+
+    m, n = shape
+    rng = np.random.default_rng(m * 1000 + n)
+    p = rng.gamma(1.0, 2.0, (m, n)).astype(np.float32)
+    y, x = np.mgrid[0:m, 0:n]
+    v = np.stack([2.5 + 0.03 * (y - m / 2) + np.sin(x / 9.0), -1.5 + 0.02 * (x - n / 2)]).astype(np.float32)
+    want, wdisp = ocl.extrapolate(p, v, 4, n_iter=n_iter, return_displacement=True)
+    got, gdisp = extrapolate(p, v, 4, n_iter=n_iter, return_displacement=True)
+    assert nan_mismatch(got, want) == 0
+    assert np.max(np.abs(gdisp - wdisp)) < DISP_TOL
+    assert rel_l2(got, want) < REL_L2_TOL
+
+
+def test_config2_2048_vs_oracle(extrapolate):
+    """BASELINE config 2 shape: 2048^2, 12 lead times, n_iter=3 (full size, C oracle)."""
+    from oracle import semilag_cport as ocl
+    from tools import synth
+
+    m = n = 2048
+    p = synth.rain_field_db(m, n)
+    v = synth.true_velocity(m, n)
+    want, wdisp = ocl.extrapolate(p, v, 12, n_iter=3, outval=-15.0, return_displacement=True)
+    got, gdisp = extrapolate(p, v, 12, n_iter=3, outval=-15.0, return_displacement=True)
+    assert np.max(np.abs(gdisp - wdisp)) < DISP_TOL
+    err = rel_l2(got, want)
+    assert err < REL_L2_TOL, err
+
+
+def test_nan_border_variant_vs_oracle(extrapolate):
+    from oracle import semilag_cport as ocl
+    from tools import synth
+
+    m, n = 768, 640
+    p = synth.rain_field_db(m, n, seed=5)
+    p[synth.border_nan_mask(m, n, 0.1)] = np.nan
+    v = synth.true_velocity(m, n)
+    want = ocl.extrapolate(p, v, 6)
+    got = extrapolate(p, v, 6, allow_nonfinite_values=True)
+    # a NaN tap poisons a sample even at weight 0, so a 1e-7 px trajectory
+    # difference at an exactly-integer coordinate can move the NaN edge by a pixel
+    assert nan_mismatch(got, want) <= 1e-5 * got.size
+    assert rel_l2(got, want) < REL_L2_TOL
+
+
+def test_chained_calls_match_single_call(extrapolate):
+    """displacement_prev / return_displacement state (nowcasts/utils.py:453-458)."""
+    from tools import synth
+
+    m, n = 300, 260
+    p = synth.rain_field_db(m, n, seed=9)
+    v = synth.true_velocity(m, n)
+    full, dfull = extrapolate(p, v, 3, return_displacement=True)
+    d = None
+    for t in range(3):
+        out, d = extrapolate(p, v, [1.0], return_displacement=True, displacement_prev=d)
+        assert nan_mismatch(out[0], full[t]) == 0
+        assert rel_l2(out[0], full[t]) < 1e-6
+    assert np.max(np.abs(d - dfull)) < 1e-5
+
+
+def test_inputs_not_mutated(extrapolate):
+    rng = np.random.default_rng(1)
+    p = rng.random((32, 48)).astype(np.float32)
+    v = rng.normal(0, 2, (2, 32, 48)).astype(np.float32)
+    d0 = rng.normal(0, 2, (2, 32, 48))
+    p0, v0, d00 = p.copy(), v.copy(), d0.copy()
+    extrapolate(p, v, 2, displacement_prev=d0, return_displacement=True)
+    assert np.array_equal(p, p0) and np.array_equal(v, v0) and np.array_equal(d0, d00)
+
+
+def test_device_resident_path(extrapolate):
+    """DeviceArray in -> DeviceArray out, no host round trip (psh_semilag_dev)."""
+    from pysteps_amd.device import DeviceArray
+    from tools import synth
+
+    m, n = 200, 333
+    p = synth.rain_field_db(m, n, seed=2)
+    v = synth.true_velocity(m, n)
+    host_out, host_disp = extrapolate(p, v, 5, outval=-15.0, return_displacement=True)
+    dp, dv = DeviceArray.from_host(p), DeviceArray.from_host(v)
+    dev_out, dev_disp = extrapolate(dp, dv, 5, outval=-15.0, return_displacement=True)
+    assert isinstance(dev_out, DeviceArray) and dev_out.shape == (5, m, n)
+    assert np.array_equal(dev_out.to_host(), host_out)
+    assert np.array_equal(dev_disp.to_host(), host_disp)
+    # resume on device
+    out2, disp2 = extrapolate(dp, dv, [1.0], outval=-15.0, return_displacement=True, displacement_prev=dev_disp)
+    ref2, rdisp2 = extrapolate(p, v, [1.0], outval=-15.0, return_displacement=True, displacement_prev=host_disp)
+    assert np.array_equal(out2.to_host(), ref2)
+    assert np.array_equal(dev_disp.to_host(), host_disp)  # displacement_prev untouched

@@ -1,0 +1,75 @@
+"""Generate tests/golden/*.npz from the REAL reference (run in the build container only).
+
+    python -m tools.make_golden
+
+Each fixture stores seeded inputs, the keyword arguments and the outputs of the
+unmodified reference function, so the GPU box (which has no /root/reference)
+can check both the oracle and the HIP path against the reference's own results.
+"""
+
+import os
+import sys
+
+import numpy as np
+
+from . import ref_loader, synth
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def semilag_cases():
+    m, n = 72, 96
+    P = synth.rain_field_db(m, n, seed=7, sigma=2.0)
+    V = synth.true_velocity(m, n)
+    y, x = np.mgrid[0:m, 0:n]
+    Vs = V + np.stack([0.04 * (x - n / 2), -0.03 * (y - m / 2)]).astype(np.float32)  # shear, leaves domain
+    Pn = P.copy()
+    Pn[synth.border_nan_mask(m, n, 0.15)] = np.nan
+    rng = np.random.default_rng(3)
+    D0 = rng.normal(0, 3, (2, m, n))
+    return {
+        "sl_int_T6": dict(precip=P, velocity=V, timesteps=6, kw={}),
+        "sl_shear_K3": dict(precip=P, velocity=Vs, timesteps=4, kw=dict(n_iter=3)),
+        "sl_K0": dict(precip=P, velocity=Vs, timesteps=3, kw=dict(n_iter=0)),
+        "sl_list_vt": dict(precip=P, velocity=Vs, timesteps=[0.5, 1.0, 2.5, 3.0], kw=dict(vel_timestep=2.0, n_iter=2)),
+        "sl_nan_min": dict(precip=Pn, velocity=V, timesteps=3, kw=dict(outval="min", allow_nonfinite_values=True)),
+        "sl_nan_nan": dict(precip=Pn, velocity=Vs, timesteps=3, kw=dict(allow_nonfinite_values=True)),
+        "sl_order0": dict(precip=P, velocity=Vs, timesteps=3, kw=dict(interp_order=0, outval=-15.0)),
+        "sl_resume": dict(precip=P, velocity=Vs, timesteps=[1.5], kw=dict(displacement_prev=D0, n_iter=1)),
+        "sl_resume_K0": dict(precip=P, velocity=Vs, timesteps=[0.5, 1.5], kw=dict(displacement_prev=D0, n_iter=0)),
+        "sl_f64": dict(precip=P.astype(np.float64), velocity=Vs.astype(np.float64), timesteps=2, kw={}),
+    }
+
+
+def make_semilag():
+    ref = ref_loader.load("pysteps.extrapolation.semilagrangian")
+    blob = {}
+    for name, c in semilag_cases().items():
+        kw = dict(c["kw"])
+        out, disp = ref.extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **kw)
+        blob[name + "/precip"] = c["precip"]
+        blob[name + "/velocity"] = c["velocity"]
+        blob[name + "/timesteps"] = np.asarray(c["timesteps"])
+        blob[name + "/timesteps_is_int"] = np.asarray(isinstance(c["timesteps"], int))
+        for k, v in kw.items():
+            blob[name + "/kw/" + k] = np.asarray(v)
+        blob[name + "/out"] = out
+        blob[name + "/disp"] = disp
+    # displacement-only call (precip None), reference nowcasts/utils.py:498-503
+    c = semilag_cases()["sl_shear_K3"]
+    _, disp = ref.extrapolate(None, c["velocity"], [0.7], return_displacement=True, n_iter=1)
+    blob["sl_disp_only/velocity"] = c["velocity"]
+    blob["sl_disp_only/disp"] = disp
+    np.savez_compressed(os.path.join(OUT, "semilag_reference.npz"), **blob)
+    print("semilag:", len(semilag_cases()) + 1, "cases")
+
+
+def main():
+    if not ref_loader.available():
+        sys.exit("reference not available")
+    os.makedirs(OUT, exist_ok=True)
+    make_semilag()
+
+
+if __name__ == "__main__":
+    main()
