@@ -61,6 +61,10 @@ int psh_event_destroy(void *event);
 int psh_event_record(void *event);
 int psh_event_elapsed_ms(void *start, void *stop, float *ms); /* waits for stop */
 
+/* Known-traffic streaming copy (vec_width 1 = dword, 4 = dwordx4 per lane) used to
+ * calibrate rocprofv3 FETCH_SIZE/WRITE_SIZE on gfx950; not part of the hot path. */
+int psh_calib_copy(float *dst_dev, const float *src_dev, size_t nfloats, int vec_width);
+
 /* ---- semi-Lagrangian extrapolation ------------------------------------- *
  * Replaces pysteps/extrapolation/semilagrangian.py:21-266 (extrapolate) incl.
  * its inner interpolate_motion (:181-198) and the scipy.ndimage.map_coordinates

@@ -93,10 +93,10 @@ int psh_shutdown(void) {
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   if (!c.ready) return PSH_OK;
-  hipStreamSynchronize(c.stream);
-  if (c.scratch) hipFree(c.scratch);
-  if (c.pinned) hipHostFree(c.pinned);
-  hipStreamDestroy(c.stream);
+  (void)hipStreamSynchronize(c.stream);
+  if (c.scratch) (void)hipFree(c.scratch);
+  if (c.pinned) (void)hipHostFree(c.pinned);
+  (void)hipStreamDestroy(c.stream);
   c.scratch = c.pinned = nullptr;
   c.scratch_bytes = c.pinned_bytes = 0;
   c.stream = nullptr;
@@ -321,11 +321,11 @@ int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
   double *d_disp = nullptr;
   int rc = PSH_OK;
   auto cleanup = [&]() {
-    hipStreamSynchronize(c.stream);
-    if (d_p) hipFree(d_p);
-    if (d_v) hipFree(d_v);
-    if (d_out) hipFree(d_out);
-    if (d_disp) hipFree(d_disp);
+    (void)hipStreamSynchronize(c.stream);
+    if (d_p) (void)hipFree(d_p);
+    if (d_v) (void)hipFree(d_v);
+    if (d_out) (void)hipFree(d_out);
+    if (d_disp) (void)hipFree(d_disp);
   };
 #define PSH_TRY(expr)                                                        \
   do {                                                                       \

@@ -11,7 +11,7 @@
 //    displacement D and the increment Vi in registers.  Nothing but the T output
 //    planes (and optionally the final D) is ever written: algorithmic traffic
 //    is 16*n_iter + 8 bytes per pixel per lead step.
-//  * D is carried as integer + fraction (frac in [0,1]) per axis.  Sub-pixel
+//  * D is carried as integer + fraction (frac in [0,1)) per axis.  Sub-pixel
 //    weights therefore keep full fp32 precision however far the trajectory has
 //    travelled, and the "advected from outside" test of map_coordinates
 //    (coord < 0 or coord > len-1, strict) becomes an integer comparison.
@@ -24,6 +24,12 @@
 //    contraction.  The kernel is bound by HBM/LLC bandwidth.
 #include "common.h"
 
+// No implicit FMA contraction in this file: floor(w) and (w - floor(w)) must see
+// the SAME rounded product w = sample * scale, otherwise a fused w - floor(w)
+// disagrees with the integer part by one ulp of 1.0 and a trajectory that lands
+// exactly on the domain edge is classified as outside.  FMAs are written out.
+#pragma clang fp contract(off)
+
 namespace psh {
 namespace {
 
@@ -35,7 +41,7 @@ __device__ __forceinline__ float ld(const float *base, unsigned byte_off) {
   return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-// (i + f) -= w with f kept in [0,1]; w is split exactly so |rounding| ~ 6e-8 px
+// (i + f) -= w with f kept in [0,1); w is split exactly so |rounding| ~ 6e-8 px
 __device__ __forceinline__ void retreat(int &i, float &f, float w) {
   const float wf = floorf(w);
   i -= static_cast<int>(wf);
@@ -43,6 +49,10 @@ __device__ __forceinline__ void retreat(int &i, float &f, float w) {
   if (f < 0.f) {
     f += 1.f;
     i -= 1;
+  }
+  if (f >= 1.f) {  // -1e-9 + 1 rounds up to 1.0f
+    f = 0.f;
+    i += 1;
   }
 }
 
@@ -62,7 +72,7 @@ __device__ __forceinline__ void weights(Taps &t, float fx, float fy) {
 __device__ __forceinline__ float blend(const Taps &t, float a, float b, float c, float d) {
   // all four products are formed: a NaN tap poisons the sample even at weight 0,
   // exactly like map_coordinates
-  return t.w00 * a + t.w01 * b + t.w10 * c + t.w11 * d;
+  return fmaf(t.w11, d, fmaf(t.w10, c, fmaf(t.w01, b, t.w00 * a)));
 }
 
 // velocity taps, mode="nearest": the coordinate is clamped to [0,len-1]; with
@@ -172,8 +182,16 @@ __global__ __launch_bounds__(kTileX *kTileY) void semilag_fused(SemilagArgs a, i
     const double flx = floor(px), fly = floor(py);
     dix = static_cast<int>(flx);
     diy = static_cast<int>(fly);
-    dfx = static_cast<float>(px - flx);  // may round up to 1.0f: still a valid split
+    dfx = static_cast<float>(px - flx);
     dfy = static_cast<float>(py - fly);
+    if (dfx >= 1.f) {  // fraction rounded up to 1.0f
+      dfx = 0.f;
+      dix += 1;
+    }
+    if (dfy >= 1.f) {
+      dfy = 0.f;
+      diy += 1;
+    }
     motion_at(x + dix, y + diy, dfx, dfy, s0);
   } else {
     // first increment is NOT divided by n_iter (semilagrangian.py:202)
