@@ -53,7 +53,8 @@ struct SemilagArgs {
   const float *vel;     // (2,m,n)
   float *out;           // (T,m,n) or nullptr
   double *disp;         // (2,m,n) in/out or nullptr
-  const float *scale;   // device, T floats: step / vel_timestep
+  const float *scale;   // device, T floats: step / vel_timestep / max(n_iter, 1)
+  float first_scale;    // step[0] / vel_timestep (the very first increment is not divided)
   int m, n, T, n_iter, order, resume;
   float outval;
 };

@@ -284,7 +284,8 @@ int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, i
   float *h = static_cast<float *>(c.pinned) + slot * slot_floats;
   float *d = static_cast<float *>(c.scratch) + slot * slot_floats;
   ++slot;
-  for (int t = 0; t < T; ++t) h[t] = static_cast<float>(steps_host[t]);
+  const double sub = n_iter > 1 ? static_cast<double>(n_iter) : 1.0;
+  for (int t = 0; t < T; ++t) h[t] = static_cast<float>(steps_host[t] / sub);
   PSH_HIP(hipMemcpyAsync(d, h, T * sizeof(float), hipMemcpyHostToDevice, c.stream));
 
   psh::SemilagArgs a;
@@ -293,6 +294,7 @@ int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, i
   a.out = out_dev;
   a.disp = disp_dev;
   a.scale = d;
+  a.first_scale = static_cast<float>(steps_host[0]);
   a.m = m;
   a.n = n;
   a.T = T;

@@ -11,21 +11,27 @@
 //    displacement D and the increment Vi in registers.  Nothing but the T output
 //    planes (and optionally the final D) is ever written: algorithmic traffic
 //    is 16*n_iter + 8 bytes per pixel per lead step.
-//  * D is carried as integer + fraction (frac in [0,1)) per axis.  Sub-pixel
+//  * The trajectory is carried as integer pixel position + fraction in [0,1) per axis.  Sub-pixel
 //    weights therefore keep full fp32 precision however far the trajectory has
 //    travelled, and the "advected from outside" test of map_coordinates
 //    (coord < 0 or coord > len-1, strict) becomes an integer comparison.
-//  * 64x4-pixel workgroups: a wave reads 64 consecutive floats per tap row
-//    (coalesced up to the sub-row shift), vertically adjacent waves share tap
-//    rows through L1/L2.  The block index is remapped so that each XCD (block b
+//  * 64x8-pixel workgroups of 4 waves; a thread owns the SAME column in two
+//    adjacent rows, i.e. two independent trajectories whose loads are all issued
+//    before either is consumed (the kernel is latency/L1 bound: twice the
+//    memory-level parallelism per wave, and the shared middle tap row hits L1).
+//    A wave reads 64 consecutive floats per tap row (coalesced up to the sub-row
+//    shift).  The block index is remapped so that each XCD (block b
 //    runs on XCD b % 8) owns one contiguous horizontal band of the image and
 //    its private 4 MiB L2 sees all the halo reuse of that band.
+//  * Waves whose 64 lanes all have their four taps strictly inside the image (almost
+//    all of them) take a clamp-free path where one lane offset addresses every
+//    plane (+1 column = immediate offset, +1 row = second uniform base).
 //  * No LDS, no MFMA: the gather footprint moves with D and there is no dense
 //    contraction.  The kernel is bound by HBM/LLC bandwidth.
 #include "common.h"
 
-// No implicit FMA contraction in this file: floor(w) and (w - floor(w)) must see
-// the SAME rounded product w = sample * scale, otherwise a fused w - floor(w)
+// No implicit FMA contraction in this file: floor(t) and (t - floor(t)) must see
+// the SAME rounded value t = frac - sample * scale, otherwise a fused form
 // disagrees with the integer part by one ulp of 1.0 and a trajectory that lands
 // exactly on the domain edge is classified as outside.  FMAs are written out.
 #pragma clang fp contract(off)
@@ -34,223 +40,372 @@ namespace psh {
 namespace {
 
 constexpr int kTileX = 64;
-constexpr int kTileY = 4;
+constexpr int kRowsPerThread = 1;           // pixels (rows) owned by one thread
+constexpr int kWavesPerBlock = 4;
+constexpr int kTileY = kWavesPerBlock * kRowsPerThread;
+constexpr float kMaxFrac = 0x1.fffffep-1f;  // largest float below 1
 
-__device__ __forceinline__ float ld(const float *base, unsigned byte_off) {
-  // uniform base + 32-bit lane offset -> global_load_dword v, v_off, s[base:base+1]
-  return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+// uniform base + 32-bit lane byte offset (+ small immediate):
+//   global_load_dword v, v_off, s[base:base+1] offset:imm
+__device__ __forceinline__ float ld(const float *base, unsigned byte_off, int elem = 0) {
+  return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off)[elem];
 }
 
-// (i + f) -= w with f kept in [0,1); w is split exactly so |rounding| ~ 6e-8 px
-__device__ __forceinline__ void retreat(int &i, float &f, float w) {
-  const float wf = floorf(w);
-  i -= static_cast<int>(wf);
-  f -= (w - wf);
-  if (f < 0.f) {
-    f += 1.f;
-    i -= 1;
-  }
-  if (f >= 1.f) {  // -1e-9 + 1 rounds up to 1.0f
-    f = 0.f;
-    i += 1;
-  }
+// Position along one axis is an integer pixel index P plus a fraction f in [0,1).
+// Subtract w: |rounding| <= ulp(|f - w|)/2 ~ 5e-7 px for |w| < 8, independent of
+// how far the trajectory has travelled.
+__device__ __forceinline__ void retreat(int &P, float &f, float w) {
+  const float t = f - w;
+  const float k = floorf(t);
+  P += static_cast<int>(k);
+  f = fminf(t - k, kMaxFrac);  // (-1e-9) - (-1) rounds to 1.0f: keep f < 1
 }
 
-struct Taps {
-  unsigned o00, o01, o10, o11;  // byte offsets inside one plane
+struct Weights {
   float w00, w01, w10, w11;
 };
 
-__device__ __forceinline__ void weights(Taps &t, float fx, float fy) {
+__device__ __forceinline__ Weights make_weights(float fx, float fy) {
   const float gx = 1.f - fx, gy = 1.f - fy;
-  t.w00 = gy * gx;
-  t.w01 = gy * fx;
-  t.w10 = fy * gx;
-  t.w11 = fy * fx;
+  return {gy * gx, gy * fx, fy * gx, fy * fx};
 }
 
-__device__ __forceinline__ float blend(const Taps &t, float a, float b, float c, float d) {
-  // all four products are formed: a NaN tap poisons the sample even at weight 0,
-  // exactly like map_coordinates
-  return fmaf(t.w11, d, fmaf(t.w10, c, fmaf(t.w01, b, t.w00 * a)));
+// all four products are formed: a NaN tap poisons the sample even at weight 0,
+// exactly like map_coordinates
+__device__ __forceinline__ float blend(const Weights &w, float a, float b, float c, float d) {
+  return fmaf(w.w11, d, fmaf(w.w10, c, fmaf(w.w01, b, w.w00 * a)));
 }
 
-// velocity taps, mode="nearest": the coordinate is clamped to [0,len-1]; with
-// clamped indices both taps coincide outside the range, which is the same value.
-__device__ __forceinline__ Taps vel_taps(int X, int Y, float fx, float fy, int m, int n) {
-  Taps t;
-  const int x0 = min(max(X, 0), n - 1), x1 = min(max(X + 1, 0), n - 1);
-  const int y0 = min(max(Y, 0), m - 1), y1 = min(max(Y + 1, 0), m - 1);
-  const unsigned r0 = static_cast<unsigned>(y0) * n, r1 = static_cast<unsigned>(y1) * n;
-  t.o00 = (r0 + x0) * 4u;
-  t.o01 = (r0 + x1) * 4u;
-  t.o10 = (r1 + x0) * 4u;
-  t.o11 = (r1 + x1) * 4u;
-  weights(t, fx, fy);
-  return t;
-}
-
-__device__ __forceinline__ bool interior(int X, int Y, int m, int n) {
+__device__ __forceinline__ bool is_interior(int X, int Y, int m, int n) {
   return static_cast<unsigned>(X) < static_cast<unsigned>(n - 1) &&
          static_cast<unsigned>(Y) < static_cast<unsigned>(m - 1);
 }
 
-__device__ __forceinline__ Taps interior_taps(int X, int Y, float fx, float fy, int n) {
-  Taps t;
-  t.o00 = (static_cast<unsigned>(Y) * n + X) * 4u;
-  t.o01 = t.o00 + 4u;
-  t.o10 = t.o00 + static_cast<unsigned>(n) * 4u;
-  t.o11 = t.o10 + 4u;
-  weights(t, fx, fy);
-  return t;
+struct Fields {
+  const float *u0, *u1, *v0, *v1, *p0, *p1;  // row r and row r+1 bases of each plane
+};
+
+// lane i receives the value of lane i+1 (v_mov_b32_dpp wave_shl:1); lane 63, which
+// has no right neighbour, keeps `fill`
+__device__ __forceinline__ int from_next_lane(int v, int fill) {
+  return __builtin_amdgcn_update_dpp(fill, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float from_next_lane(float v) {
+  return __int_as_float(from_next_lane(__float_as_int(v), 0));
 }
 
-__device__ __forceinline__ void sample_velocity(const float *u, const float *v, const Taps &t,
-                                                float &su, float &sv) {
-  const float a = ld(u, t.o00), b = ld(u, t.o01), c = ld(u, t.o10), d = ld(u, t.o11);
-  const float e = ld(v, t.o00), f = ld(v, t.o01), g = ld(v, t.o10), h = ld(v, t.o11);
-  su = blend(t, a, b, c, d);
-  sv = blend(t, e, f, g, h);
+// ---- fast path: every lane of the wave has all four taps strictly inside ----
+// The L1 (TCP) moves 64 B/clk/CU, so the fast path asks it for as few bytes as
+// possible: each lane loads only the LEFT column of its 2x2 footprint (one lane
+// offset serves all planes, the +1 row is a second uniform base) and takes the
+// RIGHT column from lane i+1 by DPP.  That is valid wherever the neighbour's
+// integer position is exactly one pixel to the right (the rule in a smooth motion
+// field); the few other lanes - trajectory crossing an integer boundary, lane 63 -
+// fetch their right column themselves in an exec-masked branch issued together
+// with the main loads.  All NPX pixels of the thread are loaded before any is used.
+template <int NPX, bool WITH_P>
+__device__ __forceinline__ void sample_interior(const Fields &F, const int (&X)[NPX],
+                                                const int (&Y)[NPX], const float (&fx)[NPX],
+                                                const float (&fy)[NPX], int n, float (&su)[NPX],
+                                                float (&sv)[NPX], float (&sp)[NPX]) {
+  unsigned off[NPX];
+  bool shared[NPX];
+  float a[NPX], c[NPX], e[NPX], g[NPX], pa[NPX], pc[NPX];
+  float b[NPX], d[NPX], f[NPX], h[NPX], pb[NPX], pd[NPX];
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    off[j] = static_cast<unsigned>(__mul24(Y[j], n) + X[j]) << 2;
+    shared[j] = from_next_lane(X[j], -2) == X[j] + 1 && from_next_lane(Y[j], -2) == Y[j];
+    b[j] = d[j] = f[j] = h[j] = pb[j] = pd[j] = 0.f;
+    if (!shared[j]) {
+      b[j] = ld(F.u0, off[j], 1);
+      d[j] = ld(F.u1, off[j], 1);
+      f[j] = ld(F.v0, off[j], 1);
+      h[j] = ld(F.v1, off[j], 1);
+      if (WITH_P) {
+        pb[j] = ld(F.p0, off[j], 1);
+        pd[j] = ld(F.p1, off[j], 1);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    a[j] = ld(F.u0, off[j]);
+    c[j] = ld(F.u1, off[j]);
+    e[j] = ld(F.v0, off[j]);
+    g[j] = ld(F.v1, off[j]);
+    pa[j] = WITH_P ? ld(F.p0, off[j]) : 0.f;
+    pc[j] = WITH_P ? ld(F.p1, off[j]) : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    const Weights w = make_weights(fx[j], fy[j]);
+    const float a1 = from_next_lane(a[j]), c1 = from_next_lane(c[j]);
+    const float e1 = from_next_lane(e[j]), g1 = from_next_lane(g[j]);
+    su[j] = blend(w, a[j], shared[j] ? a1 : b[j], c[j], shared[j] ? c1 : d[j]);
+    sv[j] = blend(w, e[j], shared[j] ? e1 : f[j], g[j], shared[j] ? g1 : h[j]);
+    if (WITH_P) {
+      const float pa1 = from_next_lane(pa[j]), pc1 = from_next_lane(pc[j]);
+      sp[j] = blend(w, pa[j], shared[j] ? pa1 : pb[j], pc[j], shared[j] ? pc1 : pd[j]);
+    }
+  }
 }
 
-// precip sample, mode="constant": outside -> outval; the upper tap at
-// floor+1 == len is index-mirrored (weight 0 there).
+// ---- general path (some lane touches the border) ------------------------------
+// velocity, mode="nearest": the coordinate is clamped to [0,len-1]; with clamped
+// indices both taps coincide outside the range, which gives the same value.
+__device__ __forceinline__ void sample_velocity_border(const Fields &F, int X, int Y, float fx,
+                                                       float fy, int m, int n, float &su,
+                                                       float &sv) {
+  const int x0 = min(max(X, 0), n - 1), x1 = min(max(X + 1, 0), n - 1);
+  const int y0 = min(max(Y, 0), m - 1), y1 = min(max(Y + 1, 0), m - 1);
+  const unsigned r0 = static_cast<unsigned>(__mul24(y0, n)), r1 = static_cast<unsigned>(__mul24(y1, n));
+  const unsigned o00 = (r0 + x0) << 2, o01 = (r0 + x1) << 2, o10 = (r1 + x0) << 2,
+                 o11 = (r1 + x1) << 2;
+  const float a = ld(F.u0, o00), b = ld(F.u0, o01), c = ld(F.u0, o10), d = ld(F.u0, o11);
+  const float e = ld(F.v0, o00), f = ld(F.v0, o01), g = ld(F.v0, o10), h = ld(F.v0, o11);
+  const Weights w = make_weights(fx, fy);
+  su = blend(w, a, b, c, d);
+  sv = blend(w, e, f, g, h);
+}
+
+// precip, mode="constant": outside (coord < 0 or > len-1, strict) -> outval; the
+// upper tap at floor+1 == len is index-mirrored (weight 0 there).  Loads are
+// unconditional (indices clamped) so that they can be issued with the velocity taps.
 template <int ORDER>
-__device__ __forceinline__ float sample_precip(const float *p, int X, int Y, float fx, float fy,
-                                               int m, int n, float outval) {
+__device__ __forceinline__ float sample_precip_border(const float *p, int X, int Y, float fx,
+                                                      float fy, int m, int n, float outval) {
   const bool outside = X < 0 || Y < 0 || X > n - 1 || Y > m - 1 || (X == n - 1 && fx > 0.f) ||
                        (Y == m - 1 && fy > 0.f);
-  if (outside) return outval;
+  const int xc = min(max(X, 0), n - 1), yc = min(max(Y, 0), m - 1);
+  float val;
   if (ORDER == 0) {
     // floor(c + 0.5): half rounds up
-    const int xi = min(X + (fx >= 0.5f ? 1 : 0), n - 1);
-    const int yi = min(Y + (fy >= 0.5f ? 1 : 0), m - 1);
-    return ld(p, (static_cast<unsigned>(yi) * n + xi) * 4u);
+    const int xi = min(xc + (fx >= 0.5f ? 1 : 0), n - 1);
+    const int yi = min(yc + (fy >= 0.5f ? 1 : 0), m - 1);
+    val = ld(p, static_cast<unsigned>(__mul24(yi, n) + xi) << 2);
+  } else {
+    const int x1 = (xc + 1 > n - 1) ? max(n - 2, 0) : xc + 1;
+    const int y1 = (yc + 1 > m - 1) ? max(m - 2, 0) : yc + 1;
+    const unsigned r0 = static_cast<unsigned>(__mul24(yc, n)), r1 = static_cast<unsigned>(__mul24(y1, n));
+    const Weights w = make_weights(fx, fy);
+    val = blend(w, ld(p, (r0 + xc) << 2), ld(p, (r0 + x1) << 2), ld(p, (r1 + xc) << 2),
+                ld(p, (r1 + x1) << 2));
   }
-  Taps t;
-  const int x1 = (X + 1 > n - 1) ? max(n - 2, 0) : X + 1;
-  const int y1 = (Y + 1 > m - 1) ? max(m - 2, 0) : Y + 1;
-  const unsigned r0 = static_cast<unsigned>(Y) * n, r1 = static_cast<unsigned>(y1) * n;
-  t.o00 = (r0 + X) * 4u;
-  t.o01 = (r0 + x1) * 4u;
-  t.o10 = (r1 + X) * 4u;
-  t.o11 = (r1 + x1) * 4u;
-  weights(t, fx, fy);
-  return blend(t, ld(p, t.o00), ld(p, t.o01), ld(p, t.o10), ld(p, t.o11));
+  return outside ? outval : val;
 }
 
-template <int ORDER, bool HAS_PRECIP>
-__global__ __launch_bounds__(kTileX *kTileY) void semilag_fused(SemilagArgs a, int tiles_x,
-                                                                int n_tiles, int tiles_per_xcd) {
+// What to sample at the NPX positions of a thread
+enum : int { kVel = 1, kPrecip = 2 };
+
+template <int NPX, int ORDER, int WHAT>
+__device__ __forceinline__ void sample_at(const Fields &F, const int (&X)[NPX], const int (&Y)[NPX],
+                                          const float (&fx)[NPX], const float (&fy)[NPX], int m,
+                                          int n, float outval, float (&su)[NPX], float (&sv)[NPX],
+                                          float (&sp)[NPX]) {
+  constexpr bool kWithP = (WHAT & kPrecip) != 0;
+  bool inside = true;
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) inside = inside && is_interior(X[j], Y[j], m, n);
+  // wave-uniform branch: interior waves (almost all of them) skip every clamp
+  if (__all(inside)) {
+    sample_interior<NPX, kWithP && ORDER == 1>(F, X, Y, fx, fy, n, su, sv, sp);
+    if (kWithP && ORDER == 0) {
+#pragma unroll
+      for (int j = 0; j < NPX; ++j) {
+        const int xi = X[j] + (fx[j] >= 0.5f ? 1 : 0), yi = Y[j] + (fy[j] >= 0.5f ? 1 : 0);
+        sp[j] = ld(F.p0, static_cast<unsigned>(__mul24(yi, n) + xi) << 2);
+      }
+    }
+    // keep the optimiser from sinking both branches into one load sequence with
+    // selected 64-bit addresses (that would cost the fast path its addressing)
+    asm volatile("" ::: "memory");
+  } else {
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      if (WHAT & kVel) sample_velocity_border(F, X[j], Y[j], fx[j], fy[j], m, n, su[j], sv[j]);
+      if (kWithP) sp[j] = sample_precip_border<ORDER>(F.p0, X[j], Y[j], fx[j], fy[j], m, n, outval);
+    }
+  }
+}
+
+template <int NPX, int ORDER, bool HAS_PRECIP>
+__global__ __launch_bounds__(kTileX *kWavesPerBlock, 8) void semilag_fused(
+    const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out,
+    double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
+    int T, int n_iter, int resume, float outval, int tiles_x, int n_tiles, int tiles_per_xcd) {
   // XCD-aware remap: hardware block b -> XCD b % 8; give XCD k the k-th band of tiles
   const int b = blockIdx.x;
   const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
   if (tile >= n_tiles) return;
-  const int x = (tile % tiles_x) * kTileX + (threadIdx.x & (kTileX - 1));
-  const int y = (tile / tiles_x) * kTileY + (threadIdx.x / kTileX);
-  const int m = a.m, n = a.n;
-  if (x >= n || y >= m) return;
-
+  // threads past the right/bottom edge shadow the edge pixel (all 64 lanes stay
+  // active for the cross-lane exchange); only their stores are masked
+  const int xt = (tile % tiles_x) * kTileX + (threadIdx.x & (kTileX - 1));
+  const int yt = (tile / tiles_x) * (kWavesPerBlock * NPX) + (threadIdx.x / kTileX) * NPX;
+  const int x = min(xt, n - 1);
   const size_t plane = static_cast<size_t>(m) * n;
-  const float *__restrict__ u = a.vel;
-  const float *__restrict__ v = a.vel + plane;
-  const unsigned pix = (static_cast<unsigned>(y) * n + x) * 4u;
-  const float sub = a.n_iter > 1 ? static_cast<float>(a.n_iter) : 1.f;
+  Fields F;
+  F.u0 = vel;
+  F.u1 = vel + n;
+  F.v0 = vel + plane;
+  F.v1 = vel + plane + n;
+  F.p0 = precip;
+  F.p1 = HAS_PRECIP ? precip + n : nullptr;
 
-  int dix = 0, diy = 0;
-  float dfx = 0.f, dfy = 0.f, vix, viy;
-
-  auto motion_at = [&](int X, int Y, float fx, float fy, float s) {
-    float su, sv;
-    if (interior(X, Y, m, n)) {
-      sample_velocity(u, v, interior_taps(X, Y, fx, fy, n), su, sv);
-    } else {
-      sample_velocity(u, v, vel_taps(X, Y, fx, fy, m, n), su, sv);
-    }
-    if (sub != 1.f) {
-      su /= sub;
-      sv /= sub;
-    }
-    vix = su * s;
-    viy = sv * s;
-  };
-
-  const float s0 = a.scale[0];
-  if (a.resume) {
-    const double px = a.disp[static_cast<size_t>(y) * n + x];
-    const double py = a.disp[plane + static_cast<size_t>(y) * n + x];
-    const double flx = floor(px), fly = floor(py);
-    dix = static_cast<int>(flx);
-    diy = static_cast<int>(fly);
-    dfx = static_cast<float>(px - flx);
-    dfy = static_cast<float>(py - fly);
-    if (dfx >= 1.f) {  // fraction rounded up to 1.0f
-      dfx = 0.f;
-      dix += 1;
-    }
-    if (dfy >= 1.f) {
-      dfy = 0.f;
-      diy += 1;
-    }
-    motion_at(x + dix, y + diy, dfx, dfy, s0);
-  } else {
-    // first increment is NOT divided by n_iter (semilagrangian.py:202)
-    vix = ld(u, pix) * s0;
-    viy = ld(v, pix) * s0;
+  // trajectory state per pixel: absolute integer position + fraction, and the increment
+  int y[NPX], px[NPX], py[NPX];
+  float fx[NPX], fy[NPX], vix[NPX], viy[NPX], su[NPX], sv[NPX], sp[NPX];
+  bool live[NPX];
+  unsigned pix[NPX];
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    live[j] = xt < n && yt + j < m;
+    y[j] = min(yt + j, m - 1);
+    pix[j] = static_cast<unsigned>(__mul24(y[j], n) + x) << 2;
+    px[j] = x;
+    py[j] = y[j];
+    fx[j] = fy[j] = sp[j] = 0.f;
   }
 
-  float *__restrict__ out = a.out;
-  for (int t = 0; t < a.T; ++t) {
-    const float s = a.scale[t];
-    if (a.n_iter > 0) {
-      for (int k = 0; k < a.n_iter; ++k) {
-        int mx = dix, my = diy;
-        float gx = dfx, gy = dfy;
-        retreat(mx, gx, 0.5f * vix);
-        retreat(my, gy, 0.5f * viy);
-        motion_at(x + mx, y + my, gx, gy, s);  // midpoint rule (:213)
-        retreat(dix, dfx, vix);
-        retreat(diy, dfy, viy);
-        motion_at(x + dix, y + diy, dfx, dfy, s);
+  if (resume) {
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      const double dx = disp[static_cast<size_t>(y[j]) * n + x];
+      const double dy = disp[plane + static_cast<size_t>(y[j]) * n + x];
+      const double flx = floor(dx), fly = floor(dy);
+      px[j] += static_cast<int>(flx);
+      py[j] += static_cast<int>(fly);
+      fx[j] = fminf(static_cast<float>(dx - flx), kMaxFrac);
+      fy[j] = fminf(static_cast<float>(dy - fly), kMaxFrac);
+    }
+    sample_at<NPX, ORDER, kVel>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
+    const float s0 = scale[0];
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      vix[j] = su[j] * s0;
+      viy[j] = sv[j] * s0;
+    }
+  } else {
+    // first increment is NOT divided by n_iter (semilagrangian.py:202)
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      vix[j] = ld(F.u0, pix[j]) * first_scale;
+      viy[j] = ld(F.v0, pix[j]) * first_scale;
+    }
+  }
+
+  for (int t = 0; t < T; ++t) {
+    const float s = scale[t];  // (lead-time increment / vel_timestep) / max(n_iter, 1)
+    if (n_iter > 0) {
+      for (int k = 0; k < n_iter; ++k) {
+        int mx[NPX], my[NPX];
+        float gx[NPX], gy[NPX];
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+          mx[j] = px[j];
+          my[j] = py[j];
+          gx[j] = fx[j];
+          gy[j] = fy[j];
+          retreat(mx[j], gx[j], 0.5f * vix[j]);  // midpoint rule (:213)
+          retreat(my[j], gy[j], 0.5f * viy[j]);
+        }
+        sample_at<NPX, ORDER, kVel>(F, mx, my, gx, gy, m, n, outval, su, sv, sp);
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+          retreat(px[j], fx[j], su[j] * s);
+          retreat(py[j], fy[j], sv[j] * s);
+        }
+        if (HAS_PRECIP && k == n_iter - 1) {
+          sample_at<NPX, ORDER, kVel | kPrecip>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
+        } else {
+          sample_at<NPX, ORDER, kVel>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
+        }
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+          vix[j] = su[j] * s;
+          viy[j] = sv[j] * s;
+        }
       }
     } else {
-      if (t > 0 || a.resume) motion_at(x + dix, y + diy, dfx, dfy, s);
-      retreat(dix, dfx, vix);
-      retreat(diy, dfy, viy);
+      if (t > 0 || resume) {
+        sample_at<NPX, ORDER, kVel>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) {
+          vix[j] = su[j] * s;
+          viy[j] = sv[j] * s;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NPX; ++j) {
+        retreat(px[j], fx[j], vix[j]);
+        retreat(py[j], fy[j], viy[j]);
+      }
+      if (HAS_PRECIP) {
+        bool inside = true;
+#pragma unroll
+        for (int j = 0; j < NPX; ++j) inside = inside && is_interior(px[j], py[j], m, n);
+        if (ORDER == 1 && __all(inside)) {
+          float v[NPX][4];
+#pragma unroll
+          for (int j = 0; j < NPX; ++j) {
+            const unsigned off = static_cast<unsigned>(__mul24(py[j], n) + px[j]) << 2;
+            v[j][0] = ld(F.p0, off);
+            v[j][1] = ld(F.p0, off, 1);
+            v[j][2] = ld(F.p1, off);
+            v[j][3] = ld(F.p1, off, 1);
+          }
+#pragma unroll
+          for (int j = 0; j < NPX; ++j)
+            sp[j] = blend(make_weights(fx[j], fy[j]), v[j][0], v[j][1], v[j][2], v[j][3]);
+          asm volatile("" ::: "memory");
+        } else {
+#pragma unroll
+          for (int j = 0; j < NPX; ++j)
+            sp[j] = sample_precip_border<ORDER>(F.p0, px[j], py[j], fx[j], fy[j], m, n, outval);
+        }
+      }
     }
     if (HAS_PRECIP) {
-      const float val = sample_precip<ORDER>(a.precip, x + dix, y + diy, dfx, dfy, m, n, a.outval);
-      *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + pix) = val;
+#pragma unroll
+      for (int j = 0; j < NPX; ++j)
+        if (live[j]) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + pix[j]) = sp[j];
       out += plane;
     }
   }
 
-  if (a.disp != nullptr) {
-    a.disp[static_cast<size_t>(y) * n + x] = static_cast<double>(dix) + static_cast<double>(dfx);
-    a.disp[plane + static_cast<size_t>(y) * n + x] =
-        static_cast<double>(diy) + static_cast<double>(dfy);
+  if (disp != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      if (!live[j]) continue;
+      disp[static_cast<size_t>(y[j]) * n + x] =
+          static_cast<double>(px[j] - x) + static_cast<double>(fx[j]);
+      disp[plane + static_cast<size_t>(y[j]) * n + x] =
+          static_cast<double>(py[j] - y[j]) + static_cast<double>(fy[j]);
+    }
   }
 }
 
 }  // namespace
 
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
+  constexpr int NPX = kRowsPerThread;
   const int tiles_x = (a.n + kTileX - 1) / kTileX;
   const int tiles_y = (a.m + kTileY - 1) / kTileY;
   const int n_tiles = tiles_x * tiles_y;
   const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
-  const dim3 grid(tiles_per_xcd * kNumXcd), block(kTileX * kTileY);
-  const bool has_precip = a.precip != nullptr;
-  if (!has_precip) {
-    hipLaunchKernelGGL((semilag_fused<1, false>), grid, block, 0, stream, a, tiles_x, n_tiles,
-                       tiles_per_xcd);
+  const dim3 grid(tiles_per_xcd * kNumXcd), block(kTileX * kWavesPerBlock);
+#define PSH_SL_LAUNCH(ORDER, HASP)                                                             \
+  hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP>), grid, block, 0, stream, a.precip,      \
+                     a.vel, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter,    \
+                     a.resume, a.outval, tiles_x, n_tiles, tiles_per_xcd)
+  if (a.precip == nullptr) {
+    PSH_SL_LAUNCH(1, false);
   } else if (a.order == 0) {
-    hipLaunchKernelGGL((semilag_fused<0, true>), grid, block, 0, stream, a, tiles_x, n_tiles,
-                       tiles_per_xcd);
+    PSH_SL_LAUNCH(0, true);
   } else {
-    hipLaunchKernelGGL((semilag_fused<1, true>), grid, block, 0, stream, a, tiles_x, n_tiles,
-                       tiles_per_xcd);
+    PSH_SL_LAUNCH(1, true);
   }
+#undef PSH_SL_LAUNCH
   return hipGetLastError();
 }
 
