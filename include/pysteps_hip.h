@@ -92,6 +92,26 @@ int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
                      const double *steps, int T, int n_iter, int interp_order, float outval,
                      const double *disp_prev, double *disp_out, float *out);
 
+/* ---- sparse vectors -> dense field: k-NN inverse distance weighting ------ *
+ * Replaces pysteps/utils/interpolate.py:26-114 (idwinterp2d) as called from
+ * pysteps/motion/lucaskanade.py:272-274, including the cKDTree k-NN query it
+ * makes for every grid node (:80-86):
+ *     w_i = (d_i / res + dist_offset)^-power over the k nearest samples,
+ *     out = sum(w_i * values_i) / sum(w_i),  res = mean(|dx|,|dy|)  (:89-109).
+ *  xy      (L,2) sample coordinates (x, y);  values (L,2) e.g. (u, v)
+ *  grid    x_i = x0 + dx*i (i < n),  y_j = y0 + dy*j (j < m)   [np.arange -> 0,1]
+ *  k       neighbours used (k >= L uses every sample; k <= 32 otherwise)
+ *  out     (2,m,n): plane 0 = first value column, plane 1 = second
+ * The _dev form takes float32 device arrays and reach_hint = an upper bound of
+ * the distance between any grid node and any sample (sizes the search bins).
+ * The _host form takes/returns float64 like the reference. */
+int psh_idw_dev(const float *xy_dev, const float *values_dev, int L, int m, int n, double x0,
+                double dx, double y0, double dy, int k, double power, double dist_offset,
+                double reach_hint, float *out_dev);
+int psh_idw_host(const double *xy, const double *values, int L, int m, int n, double x0,
+                 double dx, double y0, double dy, int k, double power, double dist_offset,
+                 double *out);
+
 #ifdef __cplusplus
 }
 #endif

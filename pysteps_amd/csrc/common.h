@@ -60,4 +60,14 @@ struct SemilagArgs {
 };
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
 
+struct IdwArgs {
+  const float *xy;  // (L,2) device: x, y of the sparse vectors
+  const float *uv;  // (L,2) device: values
+  float *out;       // (2,m,n) device
+  int L, k, m, n;
+  float x0, dx, y0, dy;  // target grid: x = x0 + dx*i (i<n), y = y0 + dy*j (j<m)
+  float inv_res, power, offset, dmax;
+};
+hipError_t launch_idw(const IdwArgs &a, hipStream_t stream);
+
 }  // namespace psh

@@ -1,0 +1,379 @@
+// k-nearest-neighbour inverse-distance-weighting of sparse motion vectors onto
+// the full pixel grid, for gfx950.
+//
+// Replaces pysteps/utils/interpolate.py:26-114 (idwinterp2d) as it is called by
+// dense_lucaskanade (pysteps/motion/lucaskanade.py:272-274):
+//     for every pixel, the k nearest vectors (cKDTree.query, :80-86),
+//     w = (d / res + dist_offset)^-power, normalised (:95-103), out = sum w*uv (:106-109).
+// This is the dominant cost of the reference's dense LK (109 s at 4096^2).
+//
+// Design (DESIGN.md "idw_knn"): selection-bound FP32 VALU work, no MFMA, almost no
+// HBM traffic (8 B written per pixel).
+//  * one 256-thread workgroup per 16x16-pixel tile.  A tile-level pre-pass prunes
+//    the L vectors to the candidates that can be among ANY pixel's k nearest:
+//    with c the tile centre, R any radius holding >= k vectors and h the tile's
+//    half diagonal, every pixel's k-NN lie within R + 2h of c.  R comes from an
+//    LDS histogram of centre distances (one pass, LDS atomics), candidates are
+//    compacted in index order (deterministic summation order) into LDS.
+//  * each thread then scans the ~25-40 candidates (LDS broadcast reads) keeping
+//    its k best in registers (unsorted set + running maximum, fully unrolled so
+//    the set never leaves VGPRs), and accumulates the weights.
+//  * k >= L (use everything) and candidate overflow take a brute-force path.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace psh {
+namespace {
+
+constexpr int kTile = 16;
+constexpr int kThreads = kTile * kTile;
+constexpr int kBins = 256;
+constexpr int kCandCap = 1024;  // candidates kept in LDS per tile (16 KiB)
+
+__device__ __forceinline__ float idw_weight(float d, float power, float offset) {
+  const float t = d + offset;
+  // power 0.5 is the reference default: 1/sqrt(t)
+  return power == 0.5f ? 1.0f / sqrtf(t) : powf(t, -power);
+}
+
+template <int KMAX>
+struct TopK {
+  float d2[KMAX];
+  int idx[KMAX];
+  float worst;
+  int worst_pos;
+
+  __device__ __forceinline__ void init(int k) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      // slots beyond k can never be the maximum, so they are never filled
+      d2[j] = j < k ? INFINITY : -INFINITY;
+      idx[j] = -1;
+    }
+    worst = INFINITY;
+    worst_pos = 0;
+  }
+
+  __device__ __forceinline__ void offer(float d, int i) {
+    if (d < worst) {
+      float w = -INFINITY;
+      int wp = 0;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        const bool hit = j == worst_pos;
+        d2[j] = hit ? d : d2[j];
+        idx[j] = hit ? i : idx[j];
+        if (d2[j] > w) {
+          w = d2[j];
+          wp = j;
+        }
+      }
+      worst = w;
+      worst_pos = wp;
+    }
+  }
+};
+
+// Brute force over all L vectors, optional k selection (used for k >= L and overflow).
+template <int KMAX>
+__device__ __forceinline__ void idw_pixel_global(const float2 *__restrict__ xy,
+                                                 const float2 *__restrict__ uv, int L, int k,
+                                                 float px, float py, float inv_res, float power,
+                                                 float offset, float &ou, float &ov) {
+  float sw = 0.f, su = 0.f, sv = 0.f;
+  if (k >= L) {
+    for (int i = 0; i < L; ++i) {
+      const float2 p = xy[i], val = uv[i];
+      const float dx = p.x - px, dy = p.y - py;
+      const float w = idw_weight(sqrtf(dx * dx + dy * dy) * inv_res, power, offset);
+      sw += w;
+      su += w * val.x;
+      sv += w * val.y;
+    }
+  } else {
+    TopK<KMAX> top;
+    top.init(k);
+    for (int i = 0; i < L; ++i) {
+      const float2 p = xy[i];
+      const float dx = p.x - px, dy = p.y - py;
+      top.offer(dx * dx + dy * dy, i);
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (top.idx[j] >= 0) {
+        const float2 val = uv[top.idx[j]];
+        const float w = idw_weight(sqrtf(top.d2[j]) * inv_res, power, offset);
+        sw += w;
+        su += w * val.x;
+        sv += w * val.y;
+      }
+    }
+  }
+  ou = su / sw;
+  ov = sv / sw;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ xy,
+                                                    const float2 *__restrict__ uv, int L, int k,
+                                                    int m, int n, float x0, float dx_grid,
+                                                    float y0, float dy_grid, float inv_res,
+                                                    float power, float offset, float dmax,
+                                                    float *__restrict__ out, int tiles_x,
+                                                    int n_tiles, int tiles_per_xcd) {
+  __shared__ int s_hist[kBins];
+  __shared__ float4 s_cand[kCandCap];  // x, y, u, v
+  __shared__ int s_count;
+  __shared__ float s_radius;
+
+  const int b = blockIdx.x;
+  const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;  // XCD-contiguous tiles
+  if (tile >= n_tiles) return;
+  const int tx = (tile % tiles_x) * kTile, ty = (tile / tiles_x) * kTile;
+  const int tid = threadIdx.x;
+  const int ix = tx + (tid % kTile), iy = ty + (tid / kTile);
+  const bool live = ix < n && iy < m;
+  const float px = x0 + dx_grid * static_cast<float>(min(ix, n - 1));
+  const float py = y0 + dy_grid * static_cast<float>(min(iy, m - 1));
+  const size_t plane = static_cast<size_t>(m) * n;
+
+  float ou, ov;
+  if (k >= L) {  // no selection at all (uniform)
+    idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
+  } else {
+    // ---- tile pre-pass: radius holding >= k vectors around the tile centre --------
+    const int wx = min(kTile, n - tx), wy = min(kTile, m - ty);
+    const float cx = x0 + dx_grid * (static_cast<float>(tx) + 0.5f * static_cast<float>(wx - 1));
+    const float cy = y0 + dy_grid * (static_cast<float>(ty) + 0.5f * static_cast<float>(wy - 1));
+    const float hx = 0.5f * fabsf(dx_grid) * static_cast<float>(wx - 1);
+    const float hy = 0.5f * fabsf(dy_grid) * static_cast<float>(wy - 1);
+    const float half_diag = sqrtf(hx * hx + hy * hy);
+    const float bin_w = dmax / static_cast<float>(kBins);
+
+    for (int i = tid; i < kBins; i += kThreads) s_hist[i] = 0;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for (int i = tid; i < L; i += kThreads) {
+      const float2 p = xy[i];
+      const float ddx = p.x - cx, ddy = p.y - cy;
+      const int bin = min(static_cast<int>(sqrtf(ddx * ddx + ddy * ddy) / bin_w), kBins - 1);
+      atomicAdd(&s_hist[bin], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {  // one wave: prefix over the 256 bins (4 per lane), first bin reaching k
+      int c[4], tot = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        c[q] = s_hist[tid * 4 + q];
+        tot += c[q];
+      }
+      int incl = tot;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (tid >= d) incl += up;
+      }
+      int run = incl - tot;
+      int first = kBins;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        run += c[q];
+        if (run >= k && first == kBins) first = tid * 4 + q;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) first = min(first, __shfl_xor(first, d));
+      // the last bin is open-ended: fall back to "everything"
+      if (tid == 0) s_radius = first >= kBins - 1 ? INFINITY : static_cast<float>(first + 1) * bin_w;
+    }
+    __syncthreads();
+    const float reach = s_radius + 2.f * half_diag + 1e-3f * (s_radius + half_diag);
+    // ---- ordered compaction of the candidates (wave 0, 64 vectors per round) ------
+    if (tid < 64) {
+      int base = 0;
+      for (int i0 = 0; i0 < L; i0 += 64) {
+        const int i = i0 + tid;
+        bool keep = false;
+        float2 p = make_float2(0.f, 0.f);
+        if (i < L) {
+          p = xy[i];
+          const float ddx = p.x - cx, ddy = p.y - cy;
+          keep = sqrtf(ddx * ddx + ddy * ddy) <= reach;
+        }
+        const unsigned long long mask = __ballot(keep);
+        const int pos = base + __popcll(mask & ((1ull << tid) - 1ull));
+        if (keep && pos < kCandCap) {
+          const float2 val = uv[i];
+          s_cand[pos] = make_float4(p.x, p.y, val.x, val.y);
+        }
+        base += __popcll(mask);
+      }
+      if (tid == 0) s_count = base;
+    }
+    __syncthreads();
+    const int n_cand = s_count;
+    if (n_cand > kCandCap) {  // pathological clustering: exact brute force
+      idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
+    } else {
+      TopK<KMAX> top;
+      top.init(k);
+      for (int i = 0; i < n_cand; ++i) {
+        const float4 c = s_cand[i];  // same address in every lane: LDS broadcast
+        const float ddx = c.x - px, ddy = c.y - py;
+        top.offer(ddx * ddx + ddy * ddy, i);
+      }
+      float sw = 0.f, su = 0.f, sv = 0.f;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        if (top.idx[j] >= 0) {
+          const float4 c = s_cand[top.idx[j]];
+          const float w = idw_weight(sqrtf(top.d2[j]) * inv_res, power, offset);
+          sw += w;
+          su += w * c.z;
+          sv += w * c.w;
+        }
+      }
+      ou = su / sw;
+      ov = sv / sw;
+    }
+  }
+  if (live) {
+    out[static_cast<size_t>(iy) * n + ix] = ou;
+    out[plane + static_cast<size_t>(iy) * n + ix] = ov;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
+  const int tiles_x = (a.n + kTile - 1) / kTile;
+  const int tiles_y = (a.m + kTile - 1) / kTile;
+  const int n_tiles = tiles_x * tiles_y;
+  const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
+  const dim3 grid(tiles_per_xcd * kNumXcd), block(kThreads);
+  const float2 *xy = reinterpret_cast<const float2 *>(a.xy);
+  const float2 *uv = reinterpret_cast<const float2 *>(a.uv);
+#define PSH_IDW_LAUNCH(KMAX)                                                                    \
+  hipLaunchKernelGGL((idw_knn<KMAX>), grid, block, 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0, \
+                     a.dx, a.y0, a.dy, a.inv_res, a.power, a.offset, a.dmax, a.out, tiles_x,    \
+                     n_tiles, tiles_per_xcd)
+  const int k_eff = a.k >= a.L ? 1 : a.k;
+  if (k_eff <= 8) {
+    PSH_IDW_LAUNCH(8);
+  } else if (k_eff <= 20) {
+    PSH_IDW_LAUNCH(20);
+  } else {
+    PSH_IDW_LAUNCH(32);
+  }
+#undef PSH_IDW_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace psh
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+static int idw_check(int L, int k, int m, int n, double dx, double dy, double power) {
+  if (L <= 0) return psh::fail(PSH_EINVAL, "idw: need at least one sample (L=%d)", L);
+  if (m <= 0 || n <= 0) return psh::fail(PSH_EINVAL, "idw: invalid grid (%d,%d)", m, n);
+  if (k <= 0) return psh::fail(PSH_EINVAL, "idw: k must be positive (got %d)", k);
+  if (k < L && k > 32)
+    return psh::fail(PSH_EUNSUPPORTED, "idw: k=%d > 32 with k < L is not implemented", k);
+  if (dx == 0.0 || dy == 0.0) return psh::fail(PSH_EINVAL, "idw: zero grid spacing");
+  if (!(power > 0.0)) return psh::fail(PSH_EINVAL, "idw: power must be positive");
+  return PSH_OK;
+}
+
+extern "C" int psh_idw_dev(const float *xy_dev, const float *values_dev, int L, int m, int n,
+                           double x0, double dx, double y0, double dy, int k, double power,
+                           double dist_offset, double reach_hint, float *out_dev) {
+  PSH_REQUIRE_INIT();
+  if (int rc = idw_check(L, k, m, n, dx, dy, power)) return rc;
+  if (!xy_dev || !values_dev || !out_dev) return psh::fail(PSH_EINVAL, "idw: NULL pointer");
+  if (!(reach_hint > 0.0)) return psh::fail(PSH_EINVAL, "idw: reach_hint must be positive");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  psh::IdwArgs a;
+  a.xy = xy_dev;
+  a.uv = values_dev;
+  a.out = out_dev;
+  a.L = L;
+  a.k = k < L ? k : L;
+  a.m = m;
+  a.n = n;
+  a.x0 = static_cast<float>(x0);
+  a.dx = static_cast<float>(dx);
+  a.y0 = static_cast<float>(y0);
+  a.dy = static_cast<float>(dy);
+  // distances are expressed in pixels: mean grid resolution (interpolate.py:89-93)
+  const double res = 0.5 * (fabs(dx) + fabs(dy));
+  a.inv_res = static_cast<float>(1.0 / res);
+  a.power = static_cast<float>(power);
+  a.offset = static_cast<float>(dist_offset);
+  a.dmax = static_cast<float>(reach_hint);
+  PSH_HIP(psh::launch_idw(a, c.stream));
+  return PSH_OK;
+}
+
+extern "C" int psh_idw_host(const double *xy, const double *values, int L, int m, int n, double x0,
+                            double dx, double y0, double dy, int k, double power,
+                            double dist_offset, double *out) {
+  PSH_REQUIRE_INIT();
+  if (int rc = idw_check(L, k, m, n, dx, dy, power)) return rc;
+  if (!xy || !values || !out) return psh::fail(PSH_EINVAL, "idw: NULL pointer");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t plane = static_cast<size_t>(m) * n;
+  std::vector<float> h_xy(2 * static_cast<size_t>(L)), h_uv(2 * static_cast<size_t>(L));
+  // farthest any sample can be from any grid node: diagonal of the joint bounding box
+  double xmin = fmin(x0, x0 + dx * (n - 1)), xmax = fmax(x0, x0 + dx * (n - 1));
+  double ymin = fmin(y0, y0 + dy * (m - 1)), ymax = fmax(y0, y0 + dy * (m - 1));
+  for (int i = 0; i < L; ++i) {
+    h_xy[2 * i] = static_cast<float>(xy[2 * i]);
+    h_xy[2 * i + 1] = static_cast<float>(xy[2 * i + 1]);
+    h_uv[2 * i] = static_cast<float>(values[2 * i]);
+    h_uv[2 * i + 1] = static_cast<float>(values[2 * i + 1]);
+    xmin = fmin(xmin, xy[2 * i]);
+    xmax = fmax(xmax, xy[2 * i]);
+    ymin = fmin(ymin, xy[2 * i + 1]);
+    ymax = fmax(ymax, xy[2 * i + 1]);
+  }
+  const double reach = hypot(xmax - xmin, ymax - ymin) * 1.001 + 1.0;
+  float *d_xy = nullptr, *d_uv = nullptr, *d_out = nullptr;
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(c.stream);
+    if (d_xy) (void)hipFree(d_xy);
+    if (d_uv) (void)hipFree(d_uv);
+    if (d_out) (void)hipFree(d_out);
+  };
+#define PSH_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      cleanup();                                                                       \
+      return psh::fail(_e == hipErrorOutOfMemory ? PSH_ENOMEM : PSH_EHIP, "%s failed: %s", #expr, \
+                       hipGetErrorString(_e));                                         \
+    }                                                                                  \
+  } while (0)
+  PSH_TRY(hipMalloc(&d_xy, h_xy.size() * sizeof(float)));
+  PSH_TRY(hipMalloc(&d_uv, h_uv.size() * sizeof(float)));
+  PSH_TRY(hipMalloc(&d_out, 2 * plane * sizeof(float)));
+  PSH_TRY(hipMemcpyAsync(d_xy, h_xy.data(), h_xy.size() * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  PSH_TRY(hipMemcpyAsync(d_uv, h_uv.data(), h_uv.size() * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  int rc = psh_idw_dev(d_xy, d_uv, L, m, n, x0, dx, y0, dy, k, power, dist_offset, reach, d_out);
+  if (rc != PSH_OK) {
+    cleanup();
+    return rc;
+  }
+  std::vector<float> h_out(2 * plane);
+  PSH_TRY(hipMemcpyAsync(h_out.data(), d_out, 2 * plane * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+  PSH_TRY(hipStreamSynchronize(c.stream));
+#undef PSH_TRY
+  cleanup();
+  for (size_t i = 0; i < 2 * plane; ++i) out[i] = static_cast<double>(h_out[i]);
+  return PSH_OK;
+}

@@ -1,0 +1,129 @@
+"""HIP k-NN IDW interpolation vs the reference's goldens and the cKDTree oracle.
+
+Mirrors pysteps/tests/test_utils_interpolate.py (shapes, finiteness, error cases,
+single sample / uniform values -> uniform field, k=1, k=None).  Tolerance: the
+kernel computes in float32 -> relative L2 <= 1e-5 against the float64 reference,
+max abs <= 1e-4 px/step; pixels whose k-th and (k+1)-th neighbours are exactly
+equidistant are excluded (the tie order is implementation-defined in cKDTree too).
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def idw():
+    from pysteps_amd.utils import idwinterp2d
+
+    return idwinterp2d
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "sparse_reference.npz"))
+
+
+def _tie_mask(xy, m, n, k):
+    """Pixels whose k-th and (k+1)-th nearest samples are (numerically) equidistant: there the
+    selected set is implementation-defined (cKDTree's order is arbitrary as well)."""
+    from scipy.spatial import cKDTree
+
+    if k is None or k >= len(xy):
+        return np.zeros((m, n), dtype=bool)
+    gx, gy = np.meshgrid(np.arange(n), np.arange(m))
+    d, _ = cKDTree(xy).query(np.column_stack([gx.ravel(), gy.ravel()]), k=k + 1)
+    # float32 sample coordinates move distances by up to ~1e-4 px at |x| ~ 1e3
+    return (d[:, k] - d[:, k - 1] <= 2e-4).reshape(m, n)
+
+
+def _close(got, want, ties=None):
+    assert got.shape == want.shape and got.dtype == np.float64
+    assert np.isfinite(got).all()
+    ok = np.ones(got.shape, dtype=bool) if ties is None else np.broadcast_to(~ties, got.shape)
+    assert ok.mean() > 0.98
+    assert np.max(np.abs(got - want)[ok]) <= 1e-4
+    assert rel_l2(got[ok], want[ok]) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_matches_reference_golden(idw, gold, case):
+    m, n = gold[case + "/shape"]
+    dxy, duv = gold[case + "/dxy"], gold[case + "/duv"]
+    _close(idw(dxy, duv, np.arange(n), np.arange(m)), gold[case + "/idw"], _tie_mask(dxy, m, n, 20))
+    _close(idw(dxy, duv, np.arange(n), np.arange(m), power=2.0, k=5, dist_offset=0.1), gold[case + "/idw_k5_p2"],
+           _tie_mask(dxy, m, n, 5))
+
+
+@pytest.mark.parametrize("L,m,n,k", [(2, 17, 33, 20), (19, 40, 50, 20), (21, 40, 50, 20), (300, 333, 257, 20),
+                                     (300, 100, 100, 1), (300, 100, 100, 32), (50, 64, 64, None), (2500, 512, 512, 20)])
+def test_vs_oracle_random_positions(idw, L, m, n, k):
+    from oracle import sparse as osp
+
+    rng = np.random.default_rng(L + m)
+    xy = np.column_stack([rng.uniform(-5, n + 5, L), rng.uniform(-5, m + 5, L)])  # no ties
+    uv = rng.normal(0, 2, (L, 2))
+    want = osp.idw(xy, uv, m, n, k=k)
+    got = idw(xy, uv, np.arange(n), np.arange(m), k=k)
+    _close(got, want, _tie_mask(xy, m, n, k))
+
+
+def test_clustered_samples_overflow_path(idw):
+    """More candidates than the LDS list holds -> exact brute-force path."""
+    from oracle import sparse as osp
+
+    rng = np.random.default_rng(4)
+    L, m, n = 1800, 96, 96
+    xy = np.column_stack([rng.normal(48, 3, L), rng.normal(48, 3, L)])
+    uv = rng.normal(0, 1, (L, 2))
+    _close(idw(xy, uv, np.arange(n), np.arange(m)), osp.idw(xy, uv, m, n), _tie_mask(xy, m, n, 20))
+
+
+def test_trivial_cases_and_shapes(idw):
+    xg, yg = np.arange(30), np.arange(20)
+    one = idw(np.array([[3.0, 4.0]]), np.array([[1.5, -2.0]]), xg, yg)
+    assert one.shape == (2, 20, 30) and np.all(one[0] == 1.5) and np.all(one[1] == -2.0)
+    same = idw(np.array([[3.0, 4.0], [9.0, 1.0]]), np.array([2.0, 2.0]), xg, yg)
+    # decorators.py:207-208 returns this case without squeezing
+    assert same.shape == (1, 20, 30) and np.all(same == 2.0)
+    rng = np.random.default_rng(0)
+    xy = rng.uniform(0, 20, (10, 2))
+    assert idw(xy, rng.normal(size=10), xg, yg).shape == (20, 30)
+    assert idw(xy, rng.normal(size=(10, 1)), xg, yg).shape == (20, 30)
+    assert idw(xy, rng.normal(size=(10, 3)), xg, yg).shape == (3, 20, 30)
+    shifted = idw(xy, rng.normal(size=(10, 2)), np.arange(5, 35) * 2.0, np.arange(20) * 2.0)
+    assert shifted.shape == (2, 20, 30) and np.isfinite(shifted).all()
+
+
+def test_scaled_grid_vs_oracle(idw):
+    """Non-unit grid spacing: distances are divided by the mean resolution (interpolate.py:89-93)."""
+    from scipy.spatial import cKDTree
+
+    rng = np.random.default_rng(3)
+    xy = rng.uniform(0, 100, (40, 2))
+    uv = rng.normal(size=(40, 2))
+    xg, yg = np.arange(0, 100, 2.0), np.arange(0, 60, 2.0)
+    gx, gy = np.meshgrid(xg, yg)
+    d, i = cKDTree(xy).query(np.column_stack([gx.ravel(), gy.ravel()]), k=20)
+    w = 1.0 / np.sqrt(d / 2.0 + 0.5)
+    w /= w.sum(axis=1, keepdims=True)
+    want = np.moveaxis((uv[i] * w[..., None]).sum(axis=1).reshape(yg.size, xg.size, 2), -1, 0)
+    _close(idw(xy, uv, xg, yg), want)
+
+
+def test_errors(idw):
+    xg, yg = np.arange(10), np.arange(10)
+    xy = np.random.default_rng(0).uniform(0, 10, (6, 2))
+    with pytest.raises(ValueError):
+        idw(xy, np.array([1.0, np.nan, 1, 1, 1, 1]), xg, yg)
+    with pytest.raises(ValueError):
+        idw(xy, np.ones((5, 2)), xg, yg)
+    with pytest.raises(ValueError):
+        idw(np.ones(6), np.arange(6.0), xg, yg)
+    with pytest.raises(ValueError):
+        idw(xy, np.ones((6, 2, 2)), xg, yg)

@@ -1,0 +1,122 @@
+"""Sparse-vector QC (host NumPy product code) and its oracle against the reference's goldens.
+
+Mirrors pysteps/tests/test_utils_cleansing.py and pins oracle/sparse.py and
+pysteps_amd.utils.cleansing to outputs of the unmodified reference functions
+(tests/golden/sparse_reference.npz, made by tools/make_golden.py).
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import sparse as osp
+from pysteps_amd.utils import cleansing
+from tools import ref_loader
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "sparse_reference.npz"))
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_outliers_and_decluster_match_reference(gold, case):
+    xy, uv = gold[case + "/xy"], gold[case + "/uv"]
+    for impl in (cleansing, osp):
+        out = impl.detect_outliers(uv, 3, xy, 30)
+        assert np.array_equal(out, gold[case + "/outliers"])
+        dxy, duv = impl.decluster(xy[~out], uv[~out], 20, 1)
+        np.testing.assert_allclose(dxy, gold[case + "/dxy"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(duv, gold[case + "/duv"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_oracle_idw_matches_reference(gold, case):
+    m, n = gold[case + "/shape"]
+    dxy, duv = gold[case + "/dxy"], gold[case + "/duv"]
+    np.testing.assert_allclose(osp.idw(dxy, duv, m, n), gold[case + "/idw"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(
+        osp.idw(dxy, duv, m, n, k=5, power=2.0, dist_offset=0.1), gold[case + "/idw_k5_p2"], rtol=0, atol=1e-12
+    )
+
+
+# ---- mirrors of pysteps/tests/test_utils_cleansing.py ----------------------
+def test_decluster_empty():
+    xy, uv = cleansing.decluster(np.empty((0, 2)), np.empty((0, 2)), 20)
+    assert xy.shape == (0, 2) and uv.shape == (0, 2)
+
+
+def test_decluster_single_and_median():
+    c, v = cleansing.decluster(np.array([[3.0, 4.0]]), np.array([[1.0, 2.0]]), 20)
+    assert np.array_equal(c, [[3.0, 4.0]]) and np.array_equal(v, [[1.0, 2.0]])
+    rng = np.random.default_rng(0)
+    coord = rng.uniform(0, 99, (51, 2))
+    vals = rng.normal(size=(51, 2))
+    c, v = cleansing.decluster(coord, vals, 100)
+    assert np.allclose(v, np.median(vals, axis=0)) and np.allclose(c, np.median(coord, axis=0))
+    c1, v1 = cleansing.decluster(coord, vals[:, 0], 100)
+    assert v1.shape == (1, 1)
+    c, v = cleansing.decluster(coord, vals, 20, min_samples=3)
+    assert c.shape[0] < 25
+
+
+def test_decluster_errors():
+    with pytest.raises(ValueError):
+        cleansing.decluster(np.ones((4, 2)), np.ones((3, 2)), 20)
+    with pytest.raises(ValueError):
+        cleansing.decluster(np.ones(4), np.ones((4, 2)), 20)
+    with pytest.raises(ValueError):
+        cleansing.decluster(np.ones((4, 2)), np.full((4, 2), np.nan), 20)
+    with pytest.raises(ValueError):
+        cleansing.decluster(np.ones((4, 2)), np.ones((4, 2)), np.ones(3))
+
+
+def test_outliers_constant_and_planted():
+    assert not cleansing.detect_outliers(np.zeros(20), 1).any()
+    assert not cleansing.detect_outliers(np.zeros((20, 2)), 1).any()
+    assert cleansing.detect_outliers(np.zeros((1, 2)), 1).shape == (1,)
+    rng = np.random.default_rng(1)
+    data = rng.normal(size=200)
+    data[7] = 40.0
+    flags = cleansing.detect_outliers(data, 4)
+    assert flags[7] and flags.sum() == 1
+    data2 = rng.normal(size=(300, 2))
+    data2[11] = (30.0, -30.0)
+    flags = cleansing.detect_outliers(data2, 5)
+    assert flags[11] and flags.sum() == 1
+    coord = rng.uniform(0, 100, (300, 2))
+    flags = cleansing.detect_outliers(data2, 5, coord, 30)
+    assert flags[11]
+    flags = cleansing.detect_outliers(data, 4, rng.uniform(0, 100, 200), 30)
+    assert flags[7]
+
+
+def test_outliers_errors():
+    with pytest.raises(ValueError):
+        cleansing.detect_outliers(np.ones((3, 2, 2)), 1)
+    with pytest.raises(ValueError):
+        cleansing.detect_outliers(np.array([1.0, np.nan]), 1)
+    with pytest.raises(ValueError):
+        cleansing.detect_outliers(np.ones(5), 1, np.ones((4, 2)), 2)
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
+def test_live_reference_cleansing():
+    cl = ref_loader.load("pysteps.utils.cleansing")
+    rng = np.random.default_rng(8)
+    for L in (2, 5, 31, 32, 700):
+        xy = np.column_stack([rng.integers(0, 300, L), rng.integers(0, 200, L)]).astype(float)
+        uv = rng.normal(0, 1, (L, 2)) + [3, -2]
+        uv[rng.integers(0, L)] += 9
+        want = cl.detect_outliers(uv, 3, xy, 30)
+        assert np.array_equal(cleansing.detect_outliers(uv, 3, xy, 30), want)
+        wc, wv = cl.decluster(xy, uv, 20, 1)
+        gc, gv = cleansing.decluster(xy, uv, 20, 1)
+        np.testing.assert_allclose(gc, wc, atol=1e-12)
+        np.testing.assert_allclose(gv, wv, atol=1e-12)
+        wc, wv = cl.decluster(xy, uv, [20, 35], 2)
+        gc, gv = cleansing.decluster(xy, uv, [20, 35], 2)
+        np.testing.assert_allclose(gc, wc, atol=1e-12)
+        np.testing.assert_allclose(gv, wv, atol=1e-12)

@@ -64,11 +64,45 @@ def make_semilag():
     print("semilag:", len(semilag_cases()) + 1, "cases")
 
 
+def sparse_vectors(L, m, n, seed, outliers=True):
+    """LK-like sparse vectors: integer feature positions, smooth motion + noise (+ planted outliers)."""
+    rng = np.random.default_rng(seed)
+    xy = np.column_stack([rng.integers(0, n, L), rng.integers(0, m, L)]).astype(float)
+    uv = np.column_stack([
+        4 + 2 * np.sin(2 * np.pi * xy[:, 1] / m) + rng.normal(0, 0.15, L),
+        -3 + 1.5 * np.cos(2 * np.pi * xy[:, 0] / n) + rng.normal(0, 0.15, L),
+    ])
+    if outliers:
+        bad = rng.choice(L, max(1, L // 40), replace=False)
+        uv[bad] += rng.choice([-1, 1], (bad.size, 2)) * rng.uniform(4, 9, (bad.size, 2))
+    return xy, uv.astype(np.float32).astype(float)
+
+
+def make_sparse():
+    cl = ref_loader.load("pysteps.utils.cleansing")
+    ip = ref_loader.load("pysteps.utils.interpolate")
+    blob = {}
+    for name, (L, m, n, seed) in {"a": (400, 120, 160, 1), "b": (60, 90, 70, 2), "c": (1500, 256, 256, 3)}.items():
+        xy, uv = sparse_vectors(L, m, n, seed)
+        out = cl.detect_outliers(uv, 3, xy, 30)
+        dxy, duv = cl.decluster(xy[~out], uv[~out], 20, 1)
+        blob["%s/xy" % name], blob["%s/uv" % name] = xy, uv
+        blob["%s/shape" % name] = np.array([m, n])
+        blob["%s/outliers" % name] = out
+        blob["%s/dxy" % name], blob["%s/duv" % name] = dxy, duv
+        if name != "c":
+            blob["%s/idw" % name] = ip.idwinterp2d(dxy, duv, np.arange(n), np.arange(m))
+            blob["%s/idw_k5_p2" % name] = ip.idwinterp2d(dxy, duv, np.arange(n), np.arange(m), power=2.0, k=5, dist_offset=0.1)
+    np.savez_compressed(os.path.join(OUT, "sparse_reference.npz"), **blob)
+    print("sparse: 3 cases")
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference not available")
     os.makedirs(OUT, exist_ok=True)
     make_semilag()
+    make_sparse()
 
 
 if __name__ == "__main__":
