@@ -112,6 +112,42 @@ int psh_idw_host(const double *xy, const double *values, int L, int m, int n, do
                  double dx, double y0, double dy, int k, double power, double dist_offset,
                  double *out);
 
+/* ---- dense Lucas-Kanade: image front end ----------------------------------- *
+ * The NumPy + OpenCV stages of pysteps/motion/lucaskanade.py:205-242, per frame /
+ * frame pair.  OpenCV is a third-party dependency of the reference (not in its
+ * tree); the kernels follow the OpenCV 4.x algorithms restated in
+ * oracle/lk_opencv.py.
+ *
+ * psh_lk_prepare_dev  - one frame (m,n) float32 (NaN/Inf = missing):
+ *     fill + binary opening with the 3x3 cross (pysteps/utils/images.py:58-86,
+ *     cv2.morphologyEx OPEN) -> clean (m,n) float32 (missing pixels stay NaN);
+ *     min-max rescale to uint8 by truncation for the tracker
+ *     (pysteps/tracking/lucaskanade.py:135-160) -> track_u8, and for the feature
+ *     detector (pysteps/feature/shitomasi.py:128-151 incl. the row-0/1 masking of
+ *     :140) -> feature_u8 (may be NULL).  stats_dev: 8 floats of device scratch that
+ *     carry min/max/NaN-count between the kernels (no host round trip).
+ * psh_lk_corners_dev  - cv2.goodFeaturesToTrack(maxCorners, qualityLevel,
+ *     minDistance, blockSize, useHarris=False, mask) of shitomasi.py:153-165 with
+ *     mask = NOT dilate(missing, ones(buffer_mask)) (:135-139,152).  Writes up to
+ *     max_corners (x,y) float32 pairs to HOST memory, strongest first.
+ * psh_lk_track_dev    - cv2.calcOpticalFlowPyrLK(prev, next, points, winSize,
+ *     maxLevel, criteria=(COUNT+EPS, max_count, epsilon), minEigThreshold) of
+ *     tracking/lucaskanade.py:164-171: builds both Gaussian pyramids and the
+ *     Scharr gradients on device, tracks every point in one launch.  points /
+ *     next_points / status are HOST arrays (p,2) float32, (p,2) float32, (p) uint8.
+ * All three are ordered on the library stream; the last two return synchronously. */
+int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, int buffer_mask,
+                       float *clean_dev, unsigned char *track_u8_dev,
+                       unsigned char *feature_u8_dev, float *stats_dev);
+int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
+                       float *stats_dev, int m, int n, int block_size, int buffer_mask,
+                       double quality_level, double min_distance, int max_corners,
+                       float *points_host, int *count_host);
+int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m,
+                     int n, const float *points_host, int npts, int win_w, int win_h,
+                     int max_level, int max_count, double epsilon, double min_eig_threshold,
+                     float *next_points_host, unsigned char *status_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,4 +9,4 @@ pysteps' own method tables.
 
 __version__ = "0.1.0"
 
-from . import extrapolation  # noqa: F401,E402
+from . import extrapolation, motion  # noqa: F401,E402

@@ -48,6 +48,9 @@ SIGNATURES = {
     "psh_calib_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
     "psh_idw_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_double, c_void_p]),
     "psh_idw_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_void_p]),
+    "psh_lk_prepare_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psh_lk_corners_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_void_p, POINTER(c_int)]),
+    "psh_lk_track_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
     "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
 }

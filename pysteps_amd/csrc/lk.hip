@@ -1,0 +1,875 @@
+// Dense-image front end of Lucas-Kanade for gfx950: frame cleaning, uint8
+// quantisation, Shi-Tomasi corner response / selection, Gaussian pyramid, Scharr
+// gradients and the pyramidal LK tracker.
+//
+// Replaces the NumPy + OpenCV stages of pysteps/motion/lucaskanade.py:205-242:
+//   pysteps/utils/images.py:58-86            morph_opening  (cv2.morphologyEx OPEN, 3x3 cross)
+//   pysteps/feature/shitomasi.py:122-171     mask buffering, uint8 rescale, cv2.goodFeaturesToTrack
+//   pysteps/tracking/lucaskanade.py:130-189  uint8 rescale, cv2.calcOpticalFlowPyrLK
+// OpenCV is a third-party dependency that is not part of the reference tree; the
+// kernels follow the published OpenCV 4.x algorithms as restated in
+// oracle/lk_opencv.py (cornerMinEigenVal, goodFeaturesToTrack, pyrDown,
+// calcSharrDeriv, LKTrackerInvoker) - see the notes there and in DESIGN.md.
+//
+// All image passes are HBM-streaming stencils (LDS-staged halos, coalesced rows);
+// reductions are two-stage (per-block partials + one finishing block), so results
+// are deterministic and no statistic ever travels to the host between kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace psh {
+namespace {
+
+// ---- device-side statistics block (floats) ---------------------------------
+enum Stat : int {
+  kMinAll = 0,   // min over finite pixels of the raw frame (= fill value)
+  kNanCount,     // number of non-finite pixels (as float; exact below 2^24, >0 is what matters)
+  kMaxAll,       // max over finite pixels after opening
+  kMinFeat,      // min / max over finite pixels of rows >= first usable row (shitomasi.py:140 quirk)
+  kMaxFeat,
+  kEigMax,       // max corner response over allowed pixels
+  kNumStats = 8
+};
+
+constexpr int kRedBlocks = 1024;
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  if (i < 0) i = -i;
+  if (i >= n) {
+    const int period = 2 * (n - 1);
+    i %= period;
+    if (i >= n) i = period - i;
+  }
+  return i;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// ---- pass 1: min over finite pixels + count of non-finite ones ----------------
+__global__ __launch_bounds__(256) void lk_stats1(const float *__restrict__ img, size_t npx,
+                                                 float *__restrict__ partial) {
+  float mn = INFINITY, bad = 0.f;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < npx; i += stride) {
+    const float v = img[i];
+    if (isfinite(v)) {
+      mn = fminf(mn, v);
+    } else {
+      bad += 1.f;
+    }
+  }
+  __shared__ float s[2][4];
+  mn = wave_min(mn);
+  bad = wave_sum(bad);
+  if ((threadIdx.x & 63) == 0) {
+    s[0][threadIdx.x >> 6] = mn;
+    s[1][threadIdx.x >> 6] = bad;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = fminf(fminf(s[0][0], s[0][1]), fminf(s[0][2], s[0][3]));
+    partial[gridDim.x + blockIdx.x] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+  }
+}
+
+__global__ __launch_bounds__(256) void lk_stats1_final(const float *__restrict__ partial, int nb,
+                                                       float *__restrict__ stats) {
+  float mn = INFINITY, bad = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    mn = fminf(mn, partial[i]);
+    bad += partial[nb + i];
+  }
+  __shared__ float s[2][4];
+  mn = wave_min(mn);
+  bad = wave_sum(bad);
+  if ((threadIdx.x & 63) == 0) {
+    s[0][threadIdx.x >> 6] = mn;
+    s[1][threadIdx.x >> 6] = bad;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[kMinAll] = fminf(fminf(s[0][0], s[0][1]), fminf(s[0][2], s[0][3]));
+    stats[kNanCount] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+  }
+}
+
+// ---- pass 2: binary opening (3x3 cross) + statistics of the cleaned frame ------
+// field = (filled > min).  Opening = erode then dilate with the plus-shaped 3x3
+// element, image border neutral.  Pixels of the field that the opening removes
+// are set to the minimum (images.py:78-81).  64x4 tile + 2-pixel halo in LDS.
+constexpr int kOpenTX = 64, kOpenTY = 4;
+
+__global__ __launch_bounds__(256) void lk_open(const float *__restrict__ img, int m, int n,
+                                               int size_opening, int buffer_mask,
+                                               const float *__restrict__ stats,
+                                               float *__restrict__ clean,
+                                               float *__restrict__ partial) {
+  __shared__ unsigned char fld[kOpenTY + 4][kOpenTX + 4];  // 1 = in field, 2 = outside the image
+  __shared__ unsigned char ero[kOpenTY + 2][kOpenTX + 2];
+  __shared__ float red[3][4];
+  const float mn = stats[kMinAll];
+  const int x0 = blockIdx.x * kOpenTX, y0 = blockIdx.y * kOpenTY;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (kOpenTY + 4) * (kOpenTX + 4); i += 256) {
+    const int ly = i / (kOpenTX + 4), lx = i % (kOpenTX + 4);
+    const int y = y0 + ly - 2, x = x0 + lx - 2;
+    unsigned char f = 2;
+    if (x >= 0 && x < n && y >= 0 && y < m) {
+      const float v = img[static_cast<size_t>(y) * n + x];
+      f = (isfinite(v) && v > mn) ? 1 : 0;  // masked pixels are filled with the minimum
+    }
+    fld[ly][lx] = f;
+  }
+  __syncthreads();
+  for (int i = tid; i < (kOpenTY + 2) * (kOpenTX + 2); i += 256) {
+    const int ly = i / (kOpenTX + 2), lx = i % (kOpenTX + 2);
+    // erosion at (y0+ly-1, x0+lx-1); outside-image taps are neutral (count as set);
+    // the eroded value of an outside-image pixel is never used by the dilation
+    const int cy = ly + 1, cx = lx + 1;
+    const bool e = fld[cy][cx] == 1 && fld[cy - 1][cx] != 0 && fld[cy + 1][cx] != 0 &&
+                   fld[cy][cx - 1] != 0 && fld[cy][cx + 1] != 0;
+    ero[ly][lx] = e ? 1 : 0;
+  }
+  __syncthreads();
+  const int lx = tid % kOpenTX, ly = tid / kOpenTX;
+  const int x = x0 + lx, y = y0 + ly;
+  float mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
+  if (x < n && y < m) {
+    float v = img[static_cast<size_t>(y) * n + x];
+    if (size_opening > 0 && isfinite(v) && v > mn) {
+      const int cy = ly + 1, cx = lx + 1;
+      const bool opened = ero[cy][cx] | ero[cy - 1][cx] | ero[cy + 1][cx] | ero[cy][cx - 1] |
+                          ero[cy][cx + 1];
+      if (!opened) v = mn;
+    }
+    clean[static_cast<size_t>(y) * n + x] = v;
+    if (isfinite(v)) {
+      mx_all = v;
+      // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
+      const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+      if (y >= first_row) mn_feat = mx_feat = v;
+    }
+  }
+  mx_all = wave_max(mx_all);
+  mn_feat = wave_min(mn_feat);
+  mx_feat = wave_max(mx_feat);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = mx_all;
+    red[1][tid >> 6] = mn_feat;
+    red[2][tid >> 6] = mx_feat;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
+    partial[b] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    partial[nb + b] = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+    partial[2 * nb + b] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void lk_open_final(const float *__restrict__ partial, int nb,
+                                                     float *__restrict__ stats) {
+  float a = -INFINITY, b = INFINITY, c = -INFINITY;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    a = fmaxf(a, partial[i]);
+    b = fminf(b, partial[nb + i]);
+    c = fmaxf(c, partial[2 * nb + i]);
+  }
+  __shared__ float s[3][4];
+  a = wave_max(a);
+  b = wave_min(b);
+  c = wave_max(c);
+  if ((threadIdx.x & 63) == 0) {
+    s[0][threadIdx.x >> 6] = a;
+    s[1][threadIdx.x >> 6] = b;
+    s[2][threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[kMaxAll] = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+    stats[kMinFeat] = fminf(fminf(s[1][0], s[1][1]), fminf(s[1][2], s[1][3]));
+    stats[kMaxFeat] = fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3]));
+  }
+}
+
+// ---- pass 3: min-max rescale to uint8 by truncation ----------------------------
+// tracking/lucaskanade.py:143-160 (all finite pixels) and shitomasi.py:143-151
+// (rows hidden by the :140 quirk are filled with the minimum first).
+__device__ __forceinline__ unsigned char quantise(float v, float lo, float hi) {
+  float s = (hi - lo) > 1e-8f ? (v - lo) / (hi - lo) * 255.f : v - lo;
+  // astype(uint8) truncates toward zero; out-of-range values cannot occur for lo <= v <= hi
+  return static_cast<unsigned char>(static_cast<int>(s));
+}
+
+__global__ __launch_bounds__(256) void lk_to_u8(const float *__restrict__ clean, int m, int n,
+                                                int buffer_mask, const float *__restrict__ stats,
+                                                unsigned char *__restrict__ trk,
+                                                unsigned char *__restrict__ feat) {
+  const float fill = stats[kMinAll], hi = stats[kMaxAll];
+  const float flo = stats[kMinFeat], fhi = stats[kMaxFeat];
+  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+  const size_t npx = static_cast<size_t>(m) * n;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
+  for (size_t i = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i < npx;
+       i += stride) {
+    unsigned char t[4], f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t p = i + j;
+      float v = p < npx ? clean[p] : fill;
+      const bool ok = isfinite(v);
+      if (!ok) v = fill;
+      t[j] = quantise(v, fill, hi);
+      const int row = static_cast<int>(p / n);
+      f[j] = quantise((ok && row >= first_row) ? v : fill, flo, fhi);
+    }
+    if (i + 3 < npx && (npx & 3) == 0) {
+      *reinterpret_cast<uchar4 *>(trk + i) = make_uchar4(t[0], t[1], t[2], t[3]);
+      if (feat) *reinterpret_cast<uchar4 *>(feat + i) = make_uchar4(f[0], f[1], f[2], f[3]);
+    } else {
+      for (int j = 0; j < 4 && i + j < npx; ++j) {
+        trk[i + j] = t[j];
+        if (feat) feat[i + j] = f[j];
+      }
+    }
+  }
+}
+
+// ---- Shi-Tomasi response: cv::cornerMinEigenVal(8U, blockSize, ksize=3) --------
+constexpr int kCrnTX = 32, kCrnTY = 8, kMaxBlockR = 3;  // block_size <= 7
+
+__device__ __forceinline__ bool px_allowed(const float *__restrict__ clean, int m, int n, int x,
+                                           int y, int bm, bool any_nan) {
+  // allowed = NOT dilate(nan_mask, ones(bm,bm)) (shitomasi.py:135-139,152)
+  if (!any_nan) return true;
+  if (bm <= 0) return isfinite(clean[static_cast<size_t>(y) * n + x]);
+  const int a = bm / 2;
+  for (int j = 0; j < bm; ++j) {
+    const int yy = y + j - a;
+    if (yy < 0 || yy >= m) continue;
+    for (int i = 0; i < bm; ++i) {
+      const int xx = x + i - a;
+      if (xx < 0 || xx >= n) continue;
+      if (!isfinite(clean[static_cast<size_t>(yy) * n + xx])) return false;
+    }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void lk_corner_response(
+    const unsigned char *__restrict__ u8, const float *__restrict__ clean, int m, int n,
+    int block_size, int buffer_mask, const float *__restrict__ stats, float *__restrict__ eig,
+    float *__restrict__ partial) {
+  constexpr int H = kMaxBlockR + 1;  // Sobel (1) + box radius (<= 3)
+  __shared__ float tile[kCrnTY + 2 * H][kCrnTX + 2 * H];
+  __shared__ float cxx[kCrnTY + 2 * kMaxBlockR][kCrnTX + 2 * kMaxBlockR];
+  __shared__ float cxy[kCrnTY + 2 * kMaxBlockR][kCrnTX + 2 * kMaxBlockR];
+  __shared__ float cyy[kCrnTY + 2 * kMaxBlockR][kCrnTX + 2 * kMaxBlockR];
+  __shared__ float red[4];
+  const int r = block_size / 2;
+  const int x0 = blockIdx.x * kCrnTX, y0 = blockIdx.y * kCrnTY;
+  const int tid = threadIdx.x;
+  const float s = 1.0f / (4.0f * static_cast<float>(block_size) * 255.0f);
+  // u8 tile with reflect-101 image border; covers [x0-H, x0+TX+H)
+  for (int i = tid; i < (kCrnTY + 2 * H) * (kCrnTX + 2 * H); i += 256) {
+    const int ly = i / (kCrnTX + 2 * H), lx = i % (kCrnTX + 2 * H);
+    const int y = reflect101(y0 + ly - H, m), x = reflect101(x0 + lx - H, n);
+    tile[ly][lx] = static_cast<float>(u8[static_cast<size_t>(y) * n + x]);
+  }
+  __syncthreads();
+  // gradient products on [x0-r, x0+TX+r): positions outside the image take the
+  // value of their reflect-101 mirror pixel (boxFilter border), not a mirrored stencil
+  const int rw = kCrnTX + 2 * r, rh = kCrnTY + 2 * r;
+  for (int i = tid; i < rw * rh; i += 256) {
+    const int ry = i / rw, rx = i % rw;
+    // rows/columns more than r beyond the image are never summed by a live pixel
+    if (y0 + ry - r > m - 1 + r || x0 + rx - r > n - 1 + r) continue;
+    const int y = reflect101(y0 + ry - r, m), x = reflect101(x0 + rx - r, n);
+    const int ly = y - y0 + H, lx = x - x0 + H;
+    const float hx0 = tile[ly - 1][lx + 1] - tile[ly - 1][lx - 1];
+    const float hx1 = tile[ly][lx + 1] - tile[ly][lx - 1];
+    const float hx2 = tile[ly + 1][lx + 1] - tile[ly + 1][lx - 1];
+    const float dx = (hx0 + hx2) * s + hx1 * (2.f * s);
+    const float hy0 = (tile[ly - 1][lx - 1] + tile[ly - 1][lx + 1]) * s + tile[ly - 1][lx] * (2.f * s);
+    const float hy2 = (tile[ly + 1][lx - 1] + tile[ly + 1][lx + 1]) * s + tile[ly + 1][lx] * (2.f * s);
+    const float dy = hy2 - hy0;
+    cxx[ry][rx] = dx * dx;
+    cxy[ry][rx] = dx * dy;
+    cyy[ry][rx] = dy * dy;
+  }
+  __syncthreads();
+  const int lx = tid % kCrnTX, ly = tid / kCrnTX;
+  const int x = x0 + lx, y = y0 + ly;
+  float best = 0.f;
+  if (x < n && y < m) {
+    double sxx = 0.0, sxy = 0.0, syy = 0.0;  // boxFilter sums 32F data in double
+    for (int j = 0; j < block_size; ++j) {
+      for (int i = 0; i < block_size; ++i) {
+        sxx += cxx[ly + j][lx + i];
+        sxy += cxy[ly + j][lx + i];
+        syy += cyy[ly + j][lx + i];
+      }
+    }
+    const float a = static_cast<float>(sxx) * 0.5f, b = static_cast<float>(sxy);
+    const float c = static_cast<float>(syy) * 0.5f;
+    const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+    eig[static_cast<size_t>(y) * n + x] = e;
+    if (px_allowed(clean, m, n, x, y, buffer_mask, stats[kNanCount] > 0.f)) best = fmaxf(e, 0.f);
+  }
+  best = wave_max(best);
+  if ((tid & 63) == 0) red[tid >> 6] = best;
+  __syncthreads();
+  if (tid == 0)
+    partial[blockIdx.y * gridDim.x + blockIdx.x] =
+        fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void lk_max_final(const float *__restrict__ partial, int nb,
+                                                    float *__restrict__ stats, int slot) {
+  float a = -INFINITY;
+  for (int i = threadIdx.x; i < nb; i += 256) a = fmaxf(a, partial[i]);
+  __shared__ float s[4];
+  a = wave_max(a);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) stats[slot] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+}
+
+// ---- corner candidates: threshold, 3x3 non-maximum suppression, compaction ------
+struct Corner {
+  float val;
+  int x, y;
+};
+
+__global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict__ eig,
+                                                        const float *__restrict__ clean, int m,
+                                                        int n, int buffer_mask, float quality,
+                                                        const float *__restrict__ stats,
+                                                        Corner *__restrict__ out, int cap,
+                                                        int *__restrict__ count) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  bool keep = false;
+  float v = 0.f;
+  if (x >= 1 && x < n - 1 && y >= 1 && y < m - 1) {
+    const float thr = stats[kEigMax] * quality;  // THRESH_TOZERO: keep values > thr
+    v = eig[static_cast<size_t>(y) * n + x];
+    if (v > thr && v != 0.f) {
+      keep = true;
+#pragma unroll
+      for (int j = -1; j <= 1; ++j)
+#pragma unroll
+        for (int i = -1; i <= 1; ++i) {
+          const float q = eig[static_cast<size_t>(y + j) * n + (x + i)];
+          if (q > v) keep = false;  // v == max of the thresholded 3x3 neighbourhood
+        }
+      if (keep) keep = px_allowed(clean, m, n, x, y, buffer_mask, stats[kNanCount] > 0.f);
+    }
+  }
+  const unsigned long long mask = __ballot(keep);
+  if (mask) {
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(mask));
+    base = __shfl(base, 0);
+    if (keep) {
+      const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < cap) out[pos] = Corner{v, x, y};
+    }
+  }
+}
+
+// ---- Gaussian pyramid level: cv::pyrDown for 8U ---------------------------------
+__global__ __launch_bounds__(256) void lk_pyrdown(const unsigned char *__restrict__ src, int m,
+                                                  int n, unsigned char *__restrict__ dst, int om,
+                                                  int on) {
+  // 32x8 output tile <- (67 x 19) input window
+  constexpr int TX = 32, TY = 8;
+  __shared__ unsigned short rows[2 * TY + 3][TX];  // horizontally filtered, decimated rows
+  const int ox0 = blockIdx.x * TX, oy0 = blockIdx.y * TY;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (2 * TY + 3) * TX; i += 256) {
+    const int ry = i / TX, ox = ox0 + (i % TX);
+    const int y = reflect101(2 * oy0 + ry - 2, m);
+    const unsigned char *row = src + static_cast<size_t>(y) * n;
+    const int xc = 2 * min(ox, on - 1);
+    const int v = row[reflect101(xc - 2, n)] + 4 * row[reflect101(xc - 1, n)] + 6 * row[xc] +
+                  4 * row[reflect101(xc + 1, n)] + row[reflect101(xc + 2, n)];
+    rows[ry][i % TX] = static_cast<unsigned short>(v);
+  }
+  __syncthreads();
+  const int lx = tid % TX, ly = tid / TX;
+  const int ox = ox0 + lx, oy = oy0 + ly;
+  if (ox < on && oy < om) {
+    const int r = 2 * ly;
+    const int v = rows[r][lx] + 4 * rows[r + 1][lx] + 6 * rows[r + 2][lx] + 4 * rows[r + 3][lx] +
+                  rows[r + 4][lx];
+    dst[static_cast<size_t>(oy) * on + ox] = static_cast<unsigned char>((v + 128) >> 8);
+  }
+}
+
+// ---- Scharr gradients: calcSharrDeriv, int16 (Ix, Iy) interleaved ----------------
+__global__ __launch_bounds__(256) void lk_scharr(const unsigned char *__restrict__ src, int m,
+                                                 int n, short2 *__restrict__ dst) {
+  constexpr int TX = 64, TY = 4;
+  __shared__ short tile[TY + 2][TX + 2];
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (TY + 2) * (TX + 2); i += 256) {
+    const int ly = i / (TX + 2), lx = i % (TX + 2);
+    const int y = reflect101(y0 + ly - 1, m), x = reflect101(x0 + lx - 1, n);
+    tile[ly][lx] = src[static_cast<size_t>(y) * n + x];
+  }
+  __syncthreads();
+  const int lx = tid % TX + 1, ly = tid / TX + 1;
+  const int x = x0 + lx - 1, y = y0 + ly - 1;
+  if (x < n && y < m) {
+    const int t0l = (tile[ly - 1][lx - 1] + tile[ly + 1][lx - 1]) * 3 + tile[ly][lx - 1] * 10;
+    const int t0r = (tile[ly - 1][lx + 1] + tile[ly + 1][lx + 1]) * 3 + tile[ly][lx + 1] * 10;
+    const int t1l = tile[ly + 1][lx - 1] - tile[ly - 1][lx - 1];
+    const int t1c = tile[ly + 1][lx] - tile[ly - 1][lx];
+    const int t1r = tile[ly + 1][lx + 1] - tile[ly - 1][lx + 1];
+    dst[static_cast<size_t>(y) * n + x] =
+        make_short2(static_cast<short>(t0r - t0l), static_cast<short>((t1r + t1l) * 3 + t1c * 10));
+  }
+}
+
+// ---- pyramidal LK tracker: LKTrackerInvoker, one workgroup per feature ------------
+constexpr int kMaxLevels = 8;
+constexpr int kMaxWin = 64;
+
+struct PyrLevel {
+  const unsigned char *I, *J;  // previous / next frame at this level
+  const short2 *dI;            // Scharr gradients of I
+  int rows, cols;
+};
+struct Pyramid {
+  PyrLevel lv[kMaxLevels];
+  int top;  // index of the coarsest level
+};
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+__device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11) {
+  const float s = 16384.f;  // 1 << W_BITS
+  w00 = static_cast<int>(rintf((1.f - a) * (1.f - b) * s));  // cvRound: half to even
+  w01 = static_cast<int>(rintf(a * (1.f - b) * s));
+  w10 = static_cast<int>(rintf((1.f - a) * b * s));
+  w11 = 16384 - w00 - w01 - w10;
+}
+
+__device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+
+__global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__restrict__ pts,
+                                                int npts, int win_w, int win_h, int max_count,
+                                                float eps2, float min_eig_thr,
+                                                float2 *__restrict__ next_pts,
+                                                unsigned char *__restrict__ status) {
+  __shared__ short sI[kMaxWin * kMaxWin];
+  __shared__ short sGx[kMaxWin * kMaxWin];
+  __shared__ short sGy[kMaxWin * kMaxWin];
+  __shared__ long long red[3][4];
+  const int p = blockIdx.x;
+  if (p >= npts) return;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int area = win_w * win_h;
+  const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
+  const float2 pt = pts[p];
+  float nx = 0.f, ny = 0.f;  // tracked position (with half window added back)
+  bool ok = true;
+
+  for (int level = pyr.top; level >= 0; --level) {
+    const PyrLevel L = pyr.lv[level];
+    const float scale = 1.f / static_cast<float>(1 << level);
+    float px = pt.x * scale, py = pt.y * scale;
+    if (level == pyr.top) {
+      nx = px;
+      ny = py;
+    } else {
+      nx *= 2.f;
+      ny *= 2.f;
+    }
+    px -= half_x;
+    py -= half_y;
+    const int ipx = static_cast<int>(floorf(px)), ipy = static_cast<int>(floorf(py));
+    if (ipx < -win_w || ipx >= L.cols || ipy < -win_h || ipy >= L.rows) {
+      if (level == 0) ok = false;
+      continue;
+    }
+    int w00, w01, w10, w11;
+    lk_weights(px - static_cast<float>(ipx), py - static_cast<float>(ipy), w00, w01, w10, w11);
+    // ---- template patch + spatial gradient matrix -------------------------------
+    long long a11 = 0, a12 = 0, a22 = 0;
+    __syncthreads();  // previous level's readers are done with the LDS patch
+    for (int i = tid; i < area; i += 256) {
+      const int wy = i / win_w, wx = i - wy * win_w;
+      const int x = ipx + wx, y = ipy + wy;
+      // image taps: reflect-101 padding; gradient taps: zero outside the image
+      const int xa = reflect101(x, L.cols), xb = reflect101(x + 1, L.cols);
+      const int ya = reflect101(y, L.rows), yb = reflect101(y + 1, L.rows);
+      const unsigned char *ra = L.I + static_cast<size_t>(ya) * L.cols;
+      const unsigned char *rb = L.I + static_cast<size_t>(yb) * L.cols;
+      const int ival = descale(ra[xa] * w00 + ra[xb] * w01 + rb[xa] * w10 + rb[xb] * w11, 14 - 5);
+      const bool x_in0 = x >= 0 && x < L.cols, x_in1 = x + 1 >= 0 && x + 1 < L.cols;
+      const bool y_in0 = y >= 0 && y < L.rows, y_in1 = y + 1 >= 0 && y + 1 < L.rows;
+      const short2 z = make_short2(0, 0);
+      const short2 g00 = (x_in0 && y_in0) ? L.dI[static_cast<size_t>(y) * L.cols + x] : z;
+      const short2 g01 = (x_in1 && y_in0) ? L.dI[static_cast<size_t>(y) * L.cols + x + 1] : z;
+      const short2 g10 = (x_in0 && y_in1) ? L.dI[static_cast<size_t>(y + 1) * L.cols + x] : z;
+      const short2 g11 = (x_in1 && y_in1) ? L.dI[static_cast<size_t>(y + 1) * L.cols + x + 1] : z;
+      const int gx = descale(g00.x * w00 + g01.x * w01 + g10.x * w10 + g11.x * w11, 14);
+      const int gy = descale(g00.y * w00 + g01.y * w01 + g10.y * w10 + g11.y * w11, 14);
+      sI[i] = static_cast<short>(ival);
+      sGx[i] = static_cast<short>(gx);
+      sGy[i] = static_cast<short>(gy);
+      a11 += static_cast<long long>(gx) * gx;
+      a12 += static_cast<long long>(gx) * gy;
+      a22 += static_cast<long long>(gy) * gy;
+    }
+    a11 = wave_sum_i64(a11);
+    a12 = wave_sum_i64(a12);
+    a22 = wave_sum_i64(a22);
+    if (lane == 0) {
+      red[0][wave] = a11;
+      red[1][wave] = a12;
+      red[2][wave] = a22;
+    }
+    __syncthreads();
+    const float flt_scale = 1.f / 1048576.f;  // 2^-20
+    const float A11 = static_cast<float>(red[0][0] + red[0][1] + red[0][2] + red[0][3]) * flt_scale;
+    const float A12 = static_cast<float>(red[1][0] + red[1][1] + red[1][2] + red[1][3]) * flt_scale;
+    const float A22 = static_cast<float>(red[2][0] + red[2][1] + red[2][2] + red[2][3]) * flt_scale;
+    float D = A11 * A22 - A12 * A12;
+    const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
+                          static_cast<float>(2 * win_w * win_h);
+    if (min_eig < min_eig_thr || D < 1.1920929e-07f) {
+      if (level == 0) ok = false;
+      continue;
+    }
+    D = 1.f / D;
+    float qx = nx - half_x, qy = ny - half_y;
+    float prev_dx = 0.f, prev_dy = 0.f;
+    for (int j = 0; j < max_count; ++j) {
+      const int inx = static_cast<int>(floorf(qx)), iny = static_cast<int>(floorf(qy));
+      if (inx < -win_w || inx >= L.cols || iny < -win_h || iny >= L.rows) {
+        if (level == 0) ok = false;
+        break;
+      }
+      lk_weights(qx - static_cast<float>(inx), qy - static_cast<float>(iny), w00, w01, w10, w11);
+      long long b1 = 0, b2 = 0;
+      for (int i = tid; i < area; i += 256) {
+        const int wy = i / win_w, wx = i - wy * win_w;
+        const int x = inx + wx, y = iny + wy;
+        const int xa = reflect101(x, L.cols), xb = reflect101(x + 1, L.cols);
+        const int ya = reflect101(y, L.rows), yb = reflect101(y + 1, L.rows);
+        const unsigned char *ra = L.J + static_cast<size_t>(ya) * L.cols;
+        const unsigned char *rb = L.J + static_cast<size_t>(yb) * L.cols;
+        const int diff =
+            descale(ra[xa] * w00 + ra[xb] * w01 + rb[xa] * w10 + rb[xb] * w11, 14 - 5) - sI[i];
+        b1 += static_cast<long long>(diff) * sGx[i];
+        b2 += static_cast<long long>(diff) * sGy[i];
+      }
+      b1 = wave_sum_i64(b1);
+      b2 = wave_sum_i64(b2);
+      __syncthreads();  // everyone has consumed the previous reduction
+      if (lane == 0) {
+        red[0][wave] = b1;
+        red[1][wave] = b2;
+      }
+      __syncthreads();
+      const float B1 = static_cast<float>(red[0][0] + red[0][1] + red[0][2] + red[0][3]) * flt_scale;
+      const float B2 = static_cast<float>(red[1][0] + red[1][1] + red[1][2] + red[1][3]) * flt_scale;
+      const float dx = (A12 * B2 - A22 * B1) * D;
+      const float dy = (A12 * B1 - A11 * B2) * D;
+      qx += dx;
+      qy += dy;
+      nx = qx + half_x;
+      ny = qy + half_y;
+      if (dx * dx + dy * dy <= eps2) break;
+      if (j > 0 && fabsf(dx + prev_dx) < 0.01f && fabsf(dy + prev_dy) < 0.01f) {
+        nx -= dx * 0.5f;
+        ny -= dy * 0.5f;
+        break;
+      }
+      prev_dx = dx;
+      prev_dy = dy;
+    }
+    if (level == 0 && ok) {
+      // the Python binding always asks for the error output: the final window must
+      // start inside the (padded) image, else the feature is dropped
+      const int rx = static_cast<int>(rintf(nx - half_x)), ry = static_cast<int>(rintf(ny - half_y));
+      if (rx < -win_w || rx >= L.cols || ry < -win_h || ry >= L.rows) ok = false;
+    }
+  }
+  if (tid == 0) {
+    next_pts[p] = make_float2(nx, ny);
+    status[p] = ok ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int ensure_lk_ws(size_t nbytes, void **ptr) {
+  Context &c = ctx();
+  static void *ws = nullptr;
+  static size_t ws_bytes = 0;
+  if (ws_bytes < nbytes) {
+    if (ws) {
+      PSH_HIP(hipStreamSynchronize(c.stream));
+      PSH_HIP(hipFree(ws));
+      ws = nullptr;
+      ws_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ws, nbytes);
+    if (e == hipErrorOutOfMemory) {
+      (void)hipGetLastError();
+      return fail(PSH_ENOMEM, "LK workspace of %zu bytes does not fit in device memory", nbytes);
+    }
+    PSH_HIP(e);
+    ws_bytes = nbytes;
+  }
+  *ptr = ws;
+  return PSH_OK;
+}
+
+}  // namespace psh
+
+using psh::ctx;
+using psh::fail;
+
+extern "C" {
+
+int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, int buffer_mask,
+                       float *clean_dev, unsigned char *track_u8_dev,
+                       unsigned char *feature_u8_dev, float *stats_dev) {
+  PSH_REQUIRE_INIT();
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_prepare: invalid shape (%d,%d)", m, n);
+  if (!frame_dev || !clean_dev || !track_u8_dev || !stats_dev)
+    return fail(PSH_EINVAL, "lk_prepare: NULL pointer");
+  if (size_opening != 0 && size_opening != 3)
+    return fail(PSH_EUNSUPPORTED, "lk_prepare: size_opening %d not implemented (0 or 3)", size_opening);
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t npx = static_cast<size_t>(m) * n;
+  const dim3 ogrid((n + psh::kOpenTX - 1) / psh::kOpenTX, (m + psh::kOpenTY - 1) / psh::kOpenTY);
+  const int nb_open = ogrid.x * ogrid.y;
+  void *ws = nullptr;
+  const size_t need = sizeof(float) * (2 * static_cast<size_t>(psh::kRedBlocks) + 3 * static_cast<size_t>(nb_open));
+  if (int rc = psh::ensure_lk_ws(need, &ws)) return rc;
+  float *part1 = static_cast<float *>(ws);
+  float *part2 = part1 + 2 * psh::kRedBlocks;
+  hipLaunchKernelGGL(psh::lk_stats1, dim3(psh::kRedBlocks), dim3(256), 0, c.stream, frame_dev, npx, part1);
+  hipLaunchKernelGGL(psh::lk_stats1_final, dim3(1), dim3(256), 0, c.stream, part1, psh::kRedBlocks, stats_dev);
+  hipLaunchKernelGGL(psh::lk_open, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening,
+                     buffer_mask, stats_dev, clean_dev, part2);
+  hipLaunchKernelGGL(psh::lk_open_final, dim3(1), dim3(256), 0, c.stream, part2, nb_open, stats_dev);
+  const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
+  hipLaunchKernelGGL(psh::lk_to_u8, dim3(qgrid), dim3(256), 0, c.stream, clean_dev, m, n, buffer_mask,
+                     stats_dev, track_u8_dev, feature_u8_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
+                       float *stats_dev, int m, int n, int block_size, int buffer_mask,
+                       double quality_level, double min_distance, int max_corners,
+                       float *points_host, int *count_host) {
+  PSH_REQUIRE_INIT();
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_corners: invalid shape (%d,%d)", m, n);
+  if (!feature_u8_dev || !clean_dev || !stats_dev || !points_host || !count_host)
+    return fail(PSH_EINVAL, "lk_corners: NULL pointer");
+  if (block_size < 1 || block_size > 2 * psh::kMaxBlockR + 1 || (block_size & 1) == 0)
+    return fail(PSH_EUNSUPPORTED, "lk_corners: block_size %d not implemented (odd, <= 7)", block_size);
+  if (max_corners <= 0) return fail(PSH_EINVAL, "lk_corners: max_corners must be positive");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t npx = static_cast<size_t>(m) * n;
+  const dim3 rgrid((n + psh::kCrnTX - 1) / psh::kCrnTX, (m + psh::kCrnTY - 1) / psh::kCrnTY);
+  const int nb = rgrid.x * rgrid.y;
+  const int cap = static_cast<int>(std::min<size_t>(npx / 6 + 4096, 1u << 26));
+  const size_t off_eig = 0, off_part = off_eig + npx * sizeof(float);
+  const size_t off_cnt = off_part + static_cast<size_t>(nb) * sizeof(float);
+  const size_t off_out = (off_cnt + 256) & ~static_cast<size_t>(255);
+  void *ws = nullptr;
+  if (int rc = psh::ensure_lk_ws(off_out + static_cast<size_t>(cap) * sizeof(psh::Corner), &ws)) return rc;
+  char *base = static_cast<char *>(ws);
+  float *eig = reinterpret_cast<float *>(base + off_eig);
+  float *part = reinterpret_cast<float *>(base + off_part);
+  int *cnt = reinterpret_cast<int *>(base + off_cnt);
+  psh::Corner *cand = reinterpret_cast<psh::Corner *>(base + off_out);
+  hipLaunchKernelGGL(psh::lk_corner_response, rgrid, dim3(256), 0, c.stream, feature_u8_dev, clean_dev,
+                     m, n, block_size, buffer_mask, stats_dev, eig, part);
+  hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(256), 0, c.stream, part, nb, stats_dev,
+                     static_cast<int>(psh::kEigMax));
+  PSH_HIP(hipMemsetAsync(cnt, 0, sizeof(int), c.stream));
+  const dim3 sgrid((n + 63) / 64, (m + 3) / 4);
+  hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n,
+                     buffer_mask, static_cast<float>(quality_level), stats_dev, cand, cap, cnt);
+  PSH_HIP(hipGetLastError());
+  int count = 0;
+  PSH_HIP(hipMemcpyAsync(&count, cnt, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipStreamSynchronize(c.stream));
+  if (count > cap)
+    return fail(PSH_EUNSUPPORTED, "lk_corners: %d corner candidates exceed the buffer of %d", count, cap);
+  std::vector<psh::Corner> h(static_cast<size_t>(count));
+  if (count > 0) {
+    PSH_HIP(hipMemcpyAsync(h.data(), cand, h.size() * sizeof(psh::Corner), hipMemcpyDeviceToHost, c.stream));
+    PSH_HIP(hipStreamSynchronize(c.stream));
+  }
+  // goodFeaturesToTrack: strongest first (ties: higher address first), then greedy
+  // acceptance on a min_distance grid (featureselect.cpp)
+  std::sort(h.begin(), h.end(), [n](const psh::Corner &a, const psh::Corner &b) {
+    if (a.val != b.val) return a.val > b.val;
+    return static_cast<long long>(a.y) * n + a.x > static_cast<long long>(b.y) * n + b.x;
+  });
+  int accepted = 0;
+  if (min_distance >= 1.0) {
+    const int cell = static_cast<int>(std::lrint(min_distance));
+    const int gw = (n + cell - 1) / cell, gh = (m + cell - 1) / cell;
+    std::vector<std::vector<std::pair<int, int>>> grid(static_cast<size_t>(gw) * gh);
+    const double md2 = min_distance * min_distance;
+    for (const psh::Corner &k : h) {
+      const int xc = k.x / cell, yc = k.y / cell;
+      bool good = true;
+      for (int yy = std::max(0, yc - 1); yy <= std::min(gh - 1, yc + 1) && good; ++yy)
+        for (int xx = std::max(0, xc - 1); xx <= std::min(gw - 1, xc + 1) && good; ++xx)
+          for (const auto &q : grid[static_cast<size_t>(yy) * gw + xx]) {
+            const double dx = k.x - q.first, dy = k.y - q.second;
+            if (dx * dx + dy * dy < md2) {
+              good = false;
+              break;
+            }
+          }
+      if (!good) continue;
+      grid[static_cast<size_t>(yc) * gw + xc].emplace_back(k.x, k.y);
+      points_host[2 * accepted] = static_cast<float>(k.x);
+      points_host[2 * accepted + 1] = static_cast<float>(k.y);
+      if (++accepted == max_corners) break;
+    }
+  } else {
+    for (const psh::Corner &k : h) {
+      points_host[2 * accepted] = static_cast<float>(k.x);
+      points_host[2 * accepted + 1] = static_cast<float>(k.y);
+      if (++accepted == max_corners) break;
+    }
+  }
+  *count_host = accepted;
+  return PSH_OK;
+}
+
+int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m,
+                     int n, const float *points_host, int npts, int win_w, int win_h,
+                     int max_level, int max_count, double epsilon, double min_eig_threshold,
+                     float *next_points_host, unsigned char *status_host) {
+  PSH_REQUIRE_INIT();
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_track: invalid shape (%d,%d)", m, n);
+  if (npts < 0) return fail(PSH_EINVAL, "lk_track: negative point count");
+  if (npts == 0) return PSH_OK;
+  if (!prev_u8_dev || !next_u8_dev || !points_host || !next_points_host || !status_host)
+    return fail(PSH_EINVAL, "lk_track: NULL pointer");
+  if (win_w <= 2 || win_h <= 2 || win_w > psh::kMaxWin || win_h > psh::kMaxWin)
+    return fail(PSH_EUNSUPPORTED, "lk_track: window (%d,%d) not implemented (3..%d)", win_w, win_h, psh::kMaxWin);
+  if (max_level < 0) return fail(PSH_EINVAL, "lk_track: max_level must be >= 0");
+  if (max_level >= psh::kMaxLevels) max_level = psh::kMaxLevels - 1;
+  max_count = std::min(std::max(max_count, 0), 100);  // calcOpticalFlowPyrLK clamps the criteria
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  // level geometry (buildOpticalFlowPyramid stops before a level is not larger than the window)
+  int rows[psh::kMaxLevels], cols[psh::kMaxLevels], top = 0;
+  rows[0] = m;
+  cols[0] = n;
+  for (int l = 1; l <= max_level; ++l) {
+    const int r = (rows[l - 1] + 1) / 2, q = (cols[l - 1] + 1) / 2;
+    if (q <= win_w || r <= win_h) break;
+    rows[l] = r;
+    cols[l] = q;
+    top = l;
+  }
+  size_t bytes = 0;
+  auto take = [&bytes](size_t nb) {
+    const size_t at = bytes;
+    bytes += (nb + 255) & ~static_cast<size_t>(255);
+    return at;
+  };
+  size_t off_i[psh::kMaxLevels], off_j[psh::kMaxLevels], off_d[psh::kMaxLevels];
+  for (int l = 0; l <= top; ++l) {
+    const size_t px = static_cast<size_t>(rows[l]) * cols[l];
+    off_i[l] = l ? take(px) : 0;
+    off_j[l] = l ? take(px) : 0;
+    off_d[l] = take(px * sizeof(short2));
+  }
+  const size_t off_pts = take(static_cast<size_t>(npts) * sizeof(float2));
+  const size_t off_next = take(static_cast<size_t>(npts) * sizeof(float2));
+  const size_t off_st = take(static_cast<size_t>(npts));
+  void *ws = nullptr;
+  if (int rc = psh::ensure_lk_ws(bytes, &ws)) return rc;
+  char *base = static_cast<char *>(ws);
+  psh::Pyramid pyr;
+  pyr.top = top;
+  for (int l = 0; l <= top; ++l) {
+    unsigned char *Il = l ? reinterpret_cast<unsigned char *>(base + off_i[l]) : const_cast<unsigned char *>(prev_u8_dev);
+    unsigned char *Jl = l ? reinterpret_cast<unsigned char *>(base + off_j[l]) : const_cast<unsigned char *>(next_u8_dev);
+    short2 *dl = reinterpret_cast<short2 *>(base + off_d[l]);
+    if (l) {
+      const dim3 g((cols[l] + 31) / 32, (rows[l] + 7) / 8);
+      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, pyr.lv[l - 1].I, rows[l - 1],
+                         cols[l - 1], Il, rows[l], cols[l]);
+      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, pyr.lv[l - 1].J, rows[l - 1],
+                         cols[l - 1], Jl, rows[l], cols[l]);
+    }
+    const dim3 sg((cols[l] + 63) / 64, (rows[l] + 3) / 4);
+    hipLaunchKernelGGL(psh::lk_scharr, sg, dim3(256), 0, c.stream, Il, rows[l], cols[l], dl);
+    pyr.lv[l].I = Il;
+    pyr.lv[l].J = Jl;
+    pyr.lv[l].dI = dl;
+    pyr.lv[l].rows = rows[l];
+    pyr.lv[l].cols = cols[l];
+  }
+  float2 *d_pts = reinterpret_cast<float2 *>(base + off_pts);
+  float2 *d_next = reinterpret_cast<float2 *>(base + off_next);
+  unsigned char *d_st = reinterpret_cast<unsigned char *>(base + off_st);
+  PSH_HIP(hipMemcpyAsync(d_pts, points_host, static_cast<size_t>(npts) * sizeof(float2),
+                         hipMemcpyHostToDevice, c.stream));
+  const float eps = static_cast<float>(epsilon);
+  hipLaunchKernelGGL(psh::lk_track, dim3(npts), dim3(256), 0, c.stream, pyr, d_pts, npts, win_w, win_h,
+                     max_count, eps * eps, static_cast<float>(min_eig_threshold), d_next, d_st);
+  PSH_HIP(hipGetLastError());
+  PSH_HIP(hipMemcpyAsync(next_points_host, d_next, static_cast<size_t>(npts) * sizeof(float2),
+                         hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipMemcpyAsync(status_host, d_st, static_cast<size_t>(npts), hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipStreamSynchronize(c.stream));
+  return PSH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,245 @@
+"""Dense Lucas-Kanade optical flow on MI355X (HIP), drop-in for
+``pysteps.motion.lucaskanade.dense_lucaskanade`` (reference:
+pysteps/motion/lucaskanade.py:38-279).
+
+Same signature, return values and exceptions.  Per frame the cleaning (NaN fill,
+3x3 opening), the uint8 rescaling, the Shi-Tomasi response / selection, the
+Gaussian pyramids, the Scharr gradients and the pyramidal tracker run as HIP
+kernels (``csrc/lk.hip``, C ABI ``psh_lk_*``); the pooled sparse vectors (a few
+thousand) are quality-controlled on the host exactly like the reference
+(``pysteps_amd.utils.cleansing``) and interpolated to the grid by the IDW kernel
+(``csrc/idw.hip``).  ``input_images`` may be a NumPy array / MaskedArray (result:
+float64 ndarray like the reference) or a float32
+:class:`pysteps_amd.device.DeviceArray` (result stays in HBM as float32).
+
+Only the reference's default detector/interpolator pair is implemented natively
+(``fd_method="shitomasi"``, ``interp_method="idwinterp2d"``); other choices are
+delegated to the reference when pysteps is importable, else NotImplementedError.
+"""
+
+import ctypes
+import time
+import warnings
+
+import numpy as np
+
+from .. import _lib
+from ..device import DeviceArray
+from ..utils.cleansing import decluster, detect_outliers
+from ..utils.interpolate import idw_to_device, idwinterp2d
+
+__all__ = ["dense_lucaskanade", "PreparedFrame", "detect_corners", "track_points"]
+
+_N_STATS = 8
+
+
+class PreparedFrame:
+    """Device-side products of one input frame: cleaned float32 field, the two
+    uint8 renderings (tracker / feature detector) and the statistics block."""
+
+    def __init__(self, frame_dev, size_opening, buffer_mask, want_features):
+        lib = _lib.lib()
+        m, n = frame_dev.shape
+        self.shape = (m, n)
+        self.buffer_mask = int(buffer_mask)
+        self.clean = DeviceArray((m, n), np.float32)
+        self.track_u8 = DeviceArray((m, n), np.uint8)
+        self.feature_u8 = DeviceArray((m, n), np.uint8) if want_features else None
+        self.stats = DeviceArray((_N_STATS,), np.float32)
+        _lib.check(
+            lib.psh_lk_prepare_dev(
+                frame_dev.ptr, m, n, int(size_opening), self.buffer_mask, self.clean.ptr,
+                self.track_u8.ptr, None if self.feature_u8 is None else self.feature_u8.ptr,
+                self.stats.ptr,
+            ),
+            "psh_lk_prepare_dev",
+        )
+
+
+def detect_corners(prep, max_corners=1000, quality_level=0.01, min_distance=10, block_size=5):
+    """Shi-Tomasi corners of a prepared frame -> (p,2) float32 (x,y) (shitomasi.py:153-171)."""
+    lib = _lib.lib()
+    m, n = prep.shape
+    pts = np.empty((int(max_corners), 2), dtype=np.float32)
+    count = ctypes.c_int(0)
+    _lib.check(
+        lib.psh_lk_corners_dev(
+            prep.feature_u8.ptr, prep.clean.ptr, prep.stats.ptr, m, n, int(block_size),
+            prep.buffer_mask, float(quality_level), float(min_distance), int(max_corners),
+            pts.ctypes.data, ctypes.byref(count),
+        ),
+        "psh_lk_corners_dev",
+    )
+    return pts[: count.value].copy()
+
+
+def track_points(prev, nxt, points, winsize=(50, 50), nr_levels=3, criteria=(3, 10, 0),
+                 min_eig_thr=1e-4):
+    """Pyramidal LK between two prepared frames -> (next_points (p,2) f32, status (p,) bool)."""
+    lib = _lib.lib()
+    m, n = prev.shape
+    p0 = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
+    p1 = np.empty_like(p0)
+    st = np.zeros(p0.shape[0], dtype=np.uint8)
+    ctype, max_count, eps = criteria
+    if not (ctype & 1):  # no COUNT bit: OpenCV substitutes 30 iterations
+        max_count = 30
+    if not (ctype & 2):  # no EPS bit: OpenCV substitutes 0.01
+        eps = 0.01
+    _lib.check(
+        lib.psh_lk_track_dev(
+            prev.track_u8.ptr, nxt.track_u8.ptr, m, n, p0.ctypes.data, p0.shape[0],
+            int(winsize[0]), int(winsize[1]), int(nr_levels), int(max_count), float(eps),
+            float(min_eig_thr), p1.ctypes.data, st.ctypes.data,
+        ),
+        "psh_lk_track_dev",
+    )
+    return p1, st.astype(bool)
+
+
+def _reference_dense_lk():
+    try:
+        from pysteps.motion.lucaskanade import dense_lucaskanade as ref  # noqa: PLC0415
+    except Exception:
+        return None
+    return None if ref is dense_lucaskanade else ref
+
+
+def _frames_to_device(input_images):
+    if isinstance(input_images, DeviceArray):
+        if input_images.dtype != np.float32:
+            raise ValueError("device-resident input_images must be float32")
+        return input_images, True
+    arr = input_images
+    if isinstance(arr, np.ma.MaskedArray):
+        arr = np.ma.filled(arr.astype(np.float32, copy=True), np.nan)
+    return DeviceArray.from_host(np.asarray(arr), dtype=np.float32), False
+
+
+def dense_lucaskanade(
+    input_images,
+    lk_kwargs=None,
+    fd_method="shitomasi",
+    fd_kwargs=None,
+    interp_method="idwinterp2d",
+    interp_kwargs=None,
+    dense=True,
+    nr_std_outlier=3,
+    k_outlier=30,
+    size_opening=3,
+    decl_scale=20,
+    verbose=False,
+):
+    """Run the Lucas-Kanade optical flow routine and interpolate the motion vectors.
+
+    Parameters and returns as documented for the reference
+    (pysteps/motion/lucaskanade.py:53-180): ``(2,m,n)`` motion field
+    (x- and y-components, pixels per time step) or, with ``dense=False``, the
+    sparse ``(xy, uv)`` arrays after outlier removal.
+    """
+    if input_images.ndim != 3:
+        # check_input_frames (decorators.py:121-146)
+        raise ValueError(
+            "input_images dimension mismatch.\n"
+            f"input_images.shape: {tuple(input_images.shape)}\n"
+            "(t, x, y ) dimensions expected"
+        )
+    lk_kwargs = dict(lk_kwargs or {})
+    fd_kwargs = dict(fd_kwargs or {})
+    interp_kwargs = dict(interp_kwargs or {})
+
+    unsupported = None
+    if fd_method != "shitomasi":
+        unsupported = "fd_method=%r" % (fd_method,)
+    elif interp_method != "idwinterp2d":
+        unsupported = "interp_method=%r" % (interp_method,)
+    elif fd_kwargs.get("use_harris", False):
+        unsupported = "use_harris=True"
+    elif lk_kwargs.get("flags", 0) != 0:
+        unsupported = "flags=%r" % (lk_kwargs.get("flags"),)
+    elif size_opening not in (0, 3):
+        unsupported = "size_opening=%r" % (size_opening,)
+    if unsupported is not None:
+        ref = _reference_dense_lk()
+        if ref is None or isinstance(input_images, DeviceArray):
+            raise NotImplementedError(
+                "pysteps_amd dense_lucaskanade: %s is not implemented on the HIP path" % unsupported
+            )
+        warnings.warn("pysteps_amd dense_lucaskanade: %s -> delegating to the reference CPU path" % unsupported)
+        return ref(input_images, lk_kwargs, fd_method, fd_kwargs, interp_method, interp_kwargs,
+                   dense, nr_std_outlier, k_outlier, size_opening, decl_scale, verbose)
+
+    if verbose:
+        print("Computing the motion field with the Lucas-Kanade method.")
+        t0 = time.time()
+
+    frames, on_device = _frames_to_device(input_images)
+    nr_fields, m, n = frames.shape
+
+    max_corners = fd_kwargs.get("max_num_features") or fd_kwargs.get("max_corners", 1000)
+    quality_level = fd_kwargs.get("quality_level", 0.01)
+    min_distance = fd_kwargs.get("min_distance", 10)
+    block_size = fd_kwargs.get("block_size", 5)
+    buffer_mask = fd_kwargs.get("buffer_mask", 5)
+    winsize = lk_kwargs.get("winsize", (50, 50))
+    nr_levels = lk_kwargs.get("nr_levels", 3)
+    criteria = lk_kwargs.get("criteria", (3, 10, 0))
+    min_eig_thr = lk_kwargs.get("min_eig_thr", 1e-4)
+
+    prepared = [
+        PreparedFrame(frames.view(t), size_opening, buffer_mask, want_features=t < nr_fields - 1)
+        for t in range(nr_fields)
+    ]
+
+    xy = np.empty(shape=(0, 2))
+    uv = np.empty(shape=(0, 2))
+    for t in range(nr_fields - 1):
+        points = detect_corners(prepared[t], max_corners, quality_level, min_distance, block_size)
+        if fd_kwargs.get("verbose", False):
+            print(f"--- {points.shape[0]} good features to track detected ---")
+        if points.shape[0] == 0:
+            continue
+        p1, st = track_points(prepared[t], prepared[t + 1], points, winsize, nr_levels, criteria, min_eig_thr)
+        if lk_kwargs.get("verbose", False):
+            print(f"--- {int(st.sum())} sparse vectors found ---")
+        if not st.any():
+            continue
+        xy = np.append(xy, points[st], axis=0)
+        uv = np.append(uv, p1[st] - points[st], axis=0)
+
+    def zero_field():
+        if on_device:
+            return DeviceArray((2, m, n), np.float32).fill_bytes(0)
+        return np.zeros((2, m, n))
+
+    if xy.shape[0] == 0:
+        return zero_field() if dense else (xy, uv)
+
+    outliers = detect_outliers(uv, nr_std_outlier, xy, k_outlier, verbose)
+    xy, uv = xy[~outliers, :], uv[~outliers, :]
+    if verbose:
+        print("--- LK found %i sparse vectors ---" % xy.shape[0])
+    if not dense:
+        return xy, uv
+
+    if decl_scale > 1:
+        xy, uv = decluster(xy, uv, decl_scale, 1, verbose)
+    if xy.shape[0] == 0:
+        return zero_field()
+
+    if on_device:
+        nsamples = xy.shape[0]
+        if nsamples == 1 or uv.max() == uv.min():  # trivial cases of the interpolator
+            host = np.ones((2, m, n), dtype=np.float32) * uv[0].astype(np.float32)[:, None, None]
+            uvgrid = DeviceArray.from_host(host)
+        else:
+            uvgrid = idw_to_device(
+                xy, uv, m, n, power=interp_kwargs.get("power", 0.5), k=interp_kwargs.get("k", 20),
+                dist_offset=interp_kwargs.get("dist_offset", 0.5),
+            )
+    else:
+        uvgrid = idwinterp2d(xy, uv, np.arange(n), np.arange(m), **interp_kwargs)
+
+    if verbose:
+        print("--- total time: %.2f seconds ---" % (time.time() - t0))
+    return uvgrid
