@@ -148,6 +148,21 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
                      int max_level, int max_count, double epsilon, double min_eig_threshold,
                      float *next_points_host, unsigned char *status_host);
 
+/* ---- multi-GPU: RCCL over xGMI, one rank (process) per GPU ------------------ *
+ * The reference has no communication layer (single process, optional dask threads:
+ * pysteps/nowcasts/utils.py:464-471); members / fields shard across GPUs with ONE
+ * broadcast of the input fields.  librccl.so is dlopen'ed on first use.
+ *  psh_comm_unique_id   rank 0: 128-byte ncclUniqueId to hand to every rank (any host channel)
+ *  psh_comm_init        collective: ncclCommInitRank on the GPU bound by psh_init()
+ *  psh_comm_broadcast   in-place ncclBroadcast of nbytes from root, on the library stream
+ *  psh_comm_allgather   ncclAllGather of nbytes_per_rank (sparse vector lists), library stream */
+int psh_comm_unique_id_bytes(void);
+int psh_comm_unique_id(void *id_out);
+int psh_comm_init(const void *id, int nranks, int rank);
+int psh_comm_broadcast(void *buf_dev, size_t nbytes, int root);
+int psh_comm_allgather(const void *send_dev, void *recv_dev, size_t nbytes_per_rank);
+int psh_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

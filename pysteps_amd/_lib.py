@@ -51,6 +51,12 @@ SIGNATURES = {
     "psh_lk_prepare_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "psh_lk_corners_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_void_p, POINTER(c_int)]),
     "psh_lk_track_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
+    "psh_comm_unique_id_bytes": (c_int, []),
+    "psh_comm_unique_id": (c_int, [c_void_p]),
+    "psh_comm_init": (c_int, [c_void_p, c_int, c_int]),
+    "psh_comm_broadcast": (c_int, [c_void_p, c_size_t, c_int]),
+    "psh_comm_allgather": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "psh_comm_destroy": (c_int, []),
     "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
 }

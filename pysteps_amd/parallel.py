@@ -1,0 +1,92 @@
+"""Multi-GPU plumbing: one process (rank) per GPU, RCCL over xGMI.
+
+The advection path shards embarrassingly (ensemble members, independent fields or
+lead-time batches, output tiles): every rank advects its own share and the only
+data-path collective is one broadcast of the input fields from the rank that
+produced them (``Communicator.broadcast``).  The reference has nothing to mirror
+here - its only parallelism is dask threads over members
+(pysteps/nowcasts/utils.py:464-471, nowcasts/steps.py:705-720).
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray
+
+
+def partition(n_items, world_size, rank):
+    """Contiguous share of ``n_items`` for ``rank`` (members j -> rank j // ceil(n/world);
+    48 members on 8 GPUs -> 6 each).  Returns a ``range``."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank %r of %r" % (rank, world_size))
+    if n_items < 0:
+        raise ValueError("n_items must be >= 0")
+    base, extra = divmod(n_items, world_size)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def owner_of(item, n_items, world_size):
+    """Rank that owns ``item`` under :func:`partition`."""
+    if not (0 <= item < n_items):
+        raise ValueError("item out of range")
+    base, extra = divmod(n_items, world_size)
+    boundary = extra * (base + 1)
+    if item < boundary:
+        return item // (base + 1)
+    return extra + (item - boundary) // base
+
+
+class Communicator:
+    """RCCL communicator on the GPU this process is bound to.
+
+    ``exchange(payload_or_None) -> payload`` must broadcast a small bytes object
+    from rank 0 to all ranks over any host channel (torch.distributed object
+    broadcast, MPI, a file, ...); it carries the 128-byte ncclUniqueId.
+    """
+
+    def __init__(self, rank, world_size, exchange):
+        self.rank, self.world_size = int(rank), int(world_size)
+        lib = _lib.lib()
+        nbytes = lib.psh_comm_unique_id_bytes()
+        uid = None
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(nbytes)
+            _lib.check(lib.psh_comm_unique_id(buf), "psh_comm_unique_id")
+            uid = buf.raw
+        uid = exchange(uid)
+        if not isinstance(uid, (bytes, bytearray)) or len(uid) != nbytes:
+            raise ValueError("exchange() must return the %d-byte unique id of rank 0" % nbytes)
+        _lib.check(lib.psh_comm_init(bytes(uid), self.world_size, self.rank), "psh_comm_init")
+
+    def broadcast(self, array, root=0):
+        """In-place broadcast of a DeviceArray (asynchronous on the library stream)."""
+        if not isinstance(array, DeviceArray):
+            raise TypeError("broadcast expects a DeviceArray")
+        _lib.check(_lib.lib().psh_comm_broadcast(array.ptr, array.nbytes, int(root)), "psh_comm_broadcast")
+        return array
+
+    def allgather(self, array):
+        """Gather equally sized DeviceArrays from all ranks -> (world_size,) + shape."""
+        out = DeviceArray((self.world_size,) + array.shape, array.dtype)
+        _lib.check(_lib.lib().psh_comm_allgather(array.ptr, out.ptr, array.nbytes), "psh_comm_allgather")
+        return out
+
+    def close(self):
+        _lib.check(_lib.lib().psh_comm_destroy(), "psh_comm_destroy")
+
+
+def sharded_extrapolate(precip_members, velocity, timesteps, rank, world_size, **kwargs):
+    """Advect this rank's share of an ensemble (list of (m,n) fields, same velocity).
+
+    Inputs must already be present on every rank (see :meth:`Communicator.broadcast`);
+    returns ``{member_index: result}`` for the members this rank owns.  No
+    communication happens here - members are independent.
+    """
+    from .extrapolation import get_method
+
+    extrapolate = get_method("semilagrangian")
+    mine = partition(len(precip_members), world_size, rank)
+    return {j: extrapolate(precip_members[j], velocity, timesteps, **kwargs) for j in mine}

@@ -1,0 +1,43 @@
+"""Plug the HIP operators into pysteps' own method tables.
+
+pysteps looks the two hot-path operators up by name in module-level dicts
+(pysteps/motion/interface.py:36-46 ``_methods``;
+pysteps/extrapolation/interface.py:107-111 ``_extrapolation_methods``); there is
+no entry-point discovery for them.  ``register()`` inserts the HIP callables under
+new names, so that every caller that takes a method *name* - ``nowcasts.extrapolation``,
+``nowcasts.steps`` (``extrap_method=``), sprog/anvil/linda/sseps, the blending
+module, user scripts calling ``motion.get_method("LK_hip")`` - picks them up
+unchanged.  With ``override=True`` the stock names ("semilagrangian", "lk",
+"lucaskanade") are replaced as well (the reference's own identity tests
+pysteps/tests/test_interfaces.py:69-78,220-233 then fail by design).
+"""
+
+EXTRAPOLATION_NAMES = ("semilagrangian_hip",)
+MOTION_NAMES = ("lk_hip", "lucaskanade_hip")
+_STOCK_EXTRAPOLATION = ("semilagrangian",)
+_STOCK_MOTION = ("lk", "lucaskanade")
+
+
+def register_into(motion_methods, extrapolation_methods, override=False):
+    """Insert the callables into the given dicts (either may be None). Returns the names added."""
+    from .extrapolation.semilagrangian import extrapolate
+    from .motion.lucaskanade import dense_lucaskanade
+
+    added = []
+    if extrapolation_methods is not None:
+        for name in EXTRAPOLATION_NAMES + (_STOCK_EXTRAPOLATION if override else ()):
+            extrapolation_methods[name] = extrapolate
+            added.append("extrapolation:" + name)
+    if motion_methods is not None:
+        for name in MOTION_NAMES + (_STOCK_MOTION if override else ()):
+            motion_methods[name] = dense_lucaskanade
+            added.append("motion:" + name)
+    return added
+
+
+def register(override=False):
+    """Register with an importable pysteps; raises ImportError if pysteps is absent."""
+    import pysteps.extrapolation.interface as ext_if  # noqa: PLC0415
+    import pysteps.motion.interface as mot_if  # noqa: PLC0415
+
+    return register_into(mot_if._methods, ext_if._extrapolation_methods, override=override)

@@ -1,0 +1,32 @@
+"""World-size-2 CPU worker (gloo) for tests/test_parallel_cpu.py - launched by torch.distributed.run."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from pysteps_amd import parallel  # noqa: E402
+
+
+def main():
+    out_dir = sys.argv[1]
+    dist = bench.Dist(want=2)
+    assert dist.world == 2
+    # control plane used by bench.py: barrier, max over ranks, unique-id style broadcast
+    dist.barrier()
+    slowest = dist.max(1.0 + dist.rank)
+    token = dist.broadcast_bytes(b"x" * 128 if dist.rank == 0 else None)
+    # member sharding: 48 members, 2 ranks -> 24 each, disjoint and complete
+    mine = list(parallel.partition(48, dist.world, dist.rank))
+    owners = [parallel.owner_of(j, 48, dist.world) for j in mine]
+    with open(os.path.join(out_dir, "rank%d.json" % dist.rank), "w") as fh:
+        json.dump({"rank": dist.rank, "max": slowest, "token_len": len(token), "mine": mine,
+                   "owners": owners}, fh)
+    dist.barrier()
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

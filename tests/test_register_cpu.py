@@ -1,0 +1,54 @@
+"""Registration into pysteps' method tables (no GPU: nothing is computed)."""
+
+import pytest
+
+from pysteps_amd import register
+from pysteps_amd.extrapolation.semilagrangian import extrapolate
+from pysteps_amd.motion.lucaskanade import dense_lucaskanade
+from tools import ref_loader
+
+
+def test_register_into_plain_dicts():
+    motion, extrap = {"lk": object()}, {"semilagrangian": object()}
+    stock_lk, stock_sl = motion["lk"], extrap["semilagrangian"]
+    added = register.register_into(motion, extrap)
+    assert motion["lk_hip"] is dense_lucaskanade and motion["lucaskanade_hip"] is dense_lucaskanade
+    assert extrap["semilagrangian_hip"] is extrapolate
+    assert motion["lk"] is stock_lk and extrap["semilagrangian"] is stock_sl  # default: non-overriding
+    assert "motion:lk_hip" in added and "extrapolation:semilagrangian_hip" in added
+    register.register_into(motion, extrap, override=True)
+    assert motion["lk"] is dense_lucaskanade and motion["lucaskanade"] is dense_lucaskanade
+    assert extrap["semilagrangian"] is extrapolate
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
+def test_reference_get_method_serves_the_hip_extrapolator():
+    """The real pysteps.extrapolation.interface.get_method returns our callable by name."""
+    iface = ref_loader.load("pysteps.extrapolation.interface")
+    saved = dict(iface._extrapolation_methods)
+    try:
+        register.register_into(None, iface._extrapolation_methods)
+        assert iface.get_method("semilagrangian_hip") is extrapolate
+        assert iface.get_method("SEMILAGRANGIAN_HIP") is extrapolate  # names are case-insensitive
+        assert iface.get_method("semilagrangian") is saved["semilagrangian"]
+        assert iface.get_method(None) is saved[None]
+        with pytest.raises(ValueError):
+            iface.get_method("nonexistent")
+    finally:
+        iface._extrapolation_methods.clear()
+        iface._extrapolation_methods.update(saved)
+
+
+def test_own_interfaces_mirror_the_reference_contract():
+    from pysteps_amd import extrapolation, motion
+
+    assert extrapolation.get_method("semilagrangian") is extrapolate
+    assert extrapolation.get_method("SemiLagrangian") is extrapolate
+    assert extrapolation.get_method(None)(None, None, 1) is None
+    assert extrapolation.get_method("eulerian") is not None
+    assert motion.get_method("LK") is dense_lucaskanade
+    assert motion.get_method("lucaskanade") is dense_lucaskanade
+    with pytest.raises(ValueError):
+        extrapolation.get_method("unknown")
+    with pytest.raises(ValueError):
+        motion.get_method("unknown")
