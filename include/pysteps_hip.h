@@ -148,6 +148,16 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
                      int max_level, int max_count, double epsilon, double min_eig_threshold,
                      float *next_points_host, unsigned char *status_host);
 
+/* ---- sparse vector QC: local Mahalanobis outlier test ----------------------- *
+ * The form of pysteps/utils/cleansing.py:124-249 (detect_outliers) used by dense LK
+ * (pysteps/motion/lucaskanade.py:252): for every 2-vector the k nearest OTHER
+ * samples by coordinate (the reference: cKDTree k+1 query minus the first hit),
+ * Mahalanobis distance to their mean with their covariance (ddof=1); flag = 1 iff
+ * > thr; singular covariance -> 0.  HOST arrays: xy (n,2) f64, values (n,2) f64,
+ * flags (n) uint8.  float64 on device; equidistant neighbours: lower index first. */
+int psh_outliers_local_host(const double *xy, const double *values, int n, int k, double thr,
+                            unsigned char *flags);
+
 /* ---- multi-GPU: RCCL over xGMI, one rank (process) per GPU ------------------ *
  * The reference has no communication layer (single process, optional dask threads:
  * pysteps/nowcasts/utils.py:464-471); members / fields shard across GPUs with ONE

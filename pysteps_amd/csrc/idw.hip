@@ -56,6 +56,21 @@ struct TopK {
     worst_pos = 0;
   }
 
+  // recompute the running maximum after slots were written directly
+  __device__ __forceinline__ void refresh() {
+    float w = -INFINITY;
+    int wp = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (d2[j] > w) {
+        w = d2[j];
+        wp = j;
+      }
+    }
+    worst = w;
+    worst_pos = wp;
+  }
+
   __device__ __forceinline__ void offer(float d, int i) {
     if (d < worst) {
       float w = -INFINITY;
@@ -218,8 +233,21 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
     } else {
       TopK<KMAX> top;
       top.init(k);
-      for (int i = 0; i < n_cand; ++i) {
-        const float4 c = s_cand[i];  // same address in every lane: LDS broadcast
+      // the first k candidates go straight into their slots (no selection needed:
+      // n_cand >= k by construction of the radius), then one maximum scan
+      const int n_fill = min(k, n_cand);
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        if (j < n_fill) {
+          const float4 c = s_cand[j];  // same address in every lane: LDS broadcast
+          const float ddx = c.x - px, ddy = c.y - py;
+          top.d2[j] = ddx * ddx + ddy * ddy;
+          top.idx[j] = j;
+        }
+      }
+      top.refresh();
+      for (int i = n_fill; i < n_cand; ++i) {
+        const float4 c = s_cand[i];
         const float ddx = c.x - px, ddy = c.y - py;
         top.offer(ddx * ddx + ddy * ddy, i);
       }

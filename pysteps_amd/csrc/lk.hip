@@ -66,6 +66,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// block-wide reductions for the single-block finishing kernels (up to 16 waves)
+constexpr int kFinalThreads = 1024;
+enum class Red { kMin, kMax, kSum };
+template <Red OP>
+__device__ __forceinline__ float block_reduce(float v, float *smem /* [16] */) {
+  v = OP == Red::kMin ? wave_min(v) : OP == Red::kMax ? wave_max(v) : wave_sum(v);
+  const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+  __syncthreads();  // smem may still be read from a previous reduction
+  if ((threadIdx.x & 63) == 0) smem[wave] = v;
+  __syncthreads();
+  float r = smem[0];
+  for (int w = 1; w < nwaves; ++w)
+    r = OP == Red::kMin ? fminf(r, smem[w]) : OP == Red::kMax ? fmaxf(r, smem[w]) : r + smem[w];
+  return r;
+}
+
 // ---- pass 1: min over finite pixels + count of non-finite ones ----------------
 __global__ __launch_bounds__(256) void lk_stats1(const float *__restrict__ img, size_t npx,
                                                  float *__restrict__ partial) {
@@ -93,24 +109,20 @@ __global__ __launch_bounds__(256) void lk_stats1(const float *__restrict__ img, 
   }
 }
 
-__global__ __launch_bounds__(256) void lk_stats1_final(const float *__restrict__ partial, int nb,
-                                                       float *__restrict__ stats) {
+__global__ __launch_bounds__(kFinalThreads) void lk_stats1_final(const float *__restrict__ partial,
+                                                                 int nb,
+                                                                 float *__restrict__ stats) {
+  __shared__ float smem[16];
   float mn = INFINITY, bad = 0.f;
-  for (int i = threadIdx.x; i < nb; i += 256) {
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) {
     mn = fminf(mn, partial[i]);
     bad += partial[nb + i];
   }
-  __shared__ float s[2][4];
-  mn = wave_min(mn);
-  bad = wave_sum(bad);
-  if ((threadIdx.x & 63) == 0) {
-    s[0][threadIdx.x >> 6] = mn;
-    s[1][threadIdx.x >> 6] = bad;
-  }
-  __syncthreads();
+  mn = block_reduce<Red::kMin>(mn, smem);
+  bad = block_reduce<Red::kSum>(bad, smem);
   if (threadIdx.x == 0) {
-    stats[kMinAll] = fminf(fminf(s[0][0], s[0][1]), fminf(s[0][2], s[0][3]));
-    stats[kNanCount] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+    stats[kMinAll] = mn;
+    stats[kNanCount] = bad;
   }
 }
 
@@ -188,28 +200,22 @@ __global__ __launch_bounds__(256) void lk_open(const float *__restrict__ img, in
   }
 }
 
-__global__ __launch_bounds__(256) void lk_open_final(const float *__restrict__ partial, int nb,
-                                                     float *__restrict__ stats) {
+__global__ __launch_bounds__(kFinalThreads) void lk_open_final(const float *__restrict__ partial,
+                                                               int nb, float *__restrict__ stats) {
+  __shared__ float smem[16];
   float a = -INFINITY, b = INFINITY, c = -INFINITY;
-  for (int i = threadIdx.x; i < nb; i += 256) {
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) {
     a = fmaxf(a, partial[i]);
     b = fminf(b, partial[nb + i]);
     c = fmaxf(c, partial[2 * nb + i]);
   }
-  __shared__ float s[3][4];
-  a = wave_max(a);
-  b = wave_min(b);
-  c = wave_max(c);
-  if ((threadIdx.x & 63) == 0) {
-    s[0][threadIdx.x >> 6] = a;
-    s[1][threadIdx.x >> 6] = b;
-    s[2][threadIdx.x >> 6] = c;
-  }
-  __syncthreads();
+  a = block_reduce<Red::kMax>(a, smem);
+  b = block_reduce<Red::kMin>(b, smem);
+  c = block_reduce<Red::kMax>(c, smem);
   if (threadIdx.x == 0) {
-    stats[kMaxAll] = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
-    stats[kMinFeat] = fminf(fminf(s[1][0], s[1][1]), fminf(s[1][2], s[1][3]));
-    stats[kMaxFeat] = fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3]));
+    stats[kMaxAll] = a;
+    stats[kMinFeat] = b;
+    stats[kMaxFeat] = c;
   }
 }
 
@@ -345,15 +351,14 @@ __global__ __launch_bounds__(256) void lk_corner_response(
         fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-__global__ __launch_bounds__(256) void lk_max_final(const float *__restrict__ partial, int nb,
-                                                    float *__restrict__ stats, int slot) {
+__global__ __launch_bounds__(kFinalThreads) void lk_max_final(const float *__restrict__ partial,
+                                                              int nb, float *__restrict__ stats,
+                                                              int slot) {
+  __shared__ float smem[16];
   float a = -INFINITY;
-  for (int i = threadIdx.x; i < nb; i += 256) a = fmaxf(a, partial[i]);
-  __shared__ float s[4];
-  a = wave_max(a);
-  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) stats[slot] = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) a = fmaxf(a, partial[i]);
+  a = block_reduce<Red::kMax>(a, smem);
+  if (threadIdx.x == 0) stats[slot] = a;
 }
 
 // ---- corner candidates: threshold, 3x3 non-maximum suppression, compaction ------
@@ -688,10 +693,10 @@ int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, i
   float *part1 = static_cast<float *>(ws);
   float *part2 = part1 + 2 * psh::kRedBlocks;
   hipLaunchKernelGGL(psh::lk_stats1, dim3(psh::kRedBlocks), dim3(256), 0, c.stream, frame_dev, npx, part1);
-  hipLaunchKernelGGL(psh::lk_stats1_final, dim3(1), dim3(256), 0, c.stream, part1, psh::kRedBlocks, stats_dev);
+  hipLaunchKernelGGL(psh::lk_stats1_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part1, psh::kRedBlocks, stats_dev);
   hipLaunchKernelGGL(psh::lk_open, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening,
                      buffer_mask, stats_dev, clean_dev, part2);
-  hipLaunchKernelGGL(psh::lk_open_final, dim3(1), dim3(256), 0, c.stream, part2, nb_open, stats_dev);
+  hipLaunchKernelGGL(psh::lk_open_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part2, nb_open, stats_dev);
   const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
   hipLaunchKernelGGL(psh::lk_to_u8, dim3(qgrid), dim3(256), 0, c.stream, clean_dev, m, n, buffer_mask,
                      stats_dev, track_u8_dev, feature_u8_dev);
@@ -729,7 +734,7 @@ int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_d
   psh::Corner *cand = reinterpret_cast<psh::Corner *>(base + off_out);
   hipLaunchKernelGGL(psh::lk_corner_response, rgrid, dim3(256), 0, c.stream, feature_u8_dev, clean_dev,
                      m, n, block_size, buffer_mask, stats_dev, eig, part);
-  hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(256), 0, c.stream, part, nb, stats_dev,
+  hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb, stats_dev,
                      static_cast<int>(psh::kEigMax));
   PSH_HIP(hipMemsetAsync(cnt, 0, sizeof(int), c.stream));
   const dim3 sgrid((n + 63) / 64, (m + 3) / 4);
@@ -748,17 +753,31 @@ int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_d
   }
   // goodFeaturesToTrack: strongest first (ties: higher address first), then greedy
   // acceptance on a min_distance grid (featureselect.cpp)
-  std::sort(h.begin(), h.end(), [n](const psh::Corner &a, const psh::Corner &b) {
+  auto stronger = [n](const psh::Corner &a, const psh::Corner &b) {
     if (a.val != b.val) return a.val > b.val;
     return static_cast<long long>(a.y) * n + a.x > static_cast<long long>(b.y) * n + b.x;
-  });
+  };
+  // the greedy pass below rarely looks beyond a few thousand of the strongest
+  // candidates: order them chunk by chunk (nth_element + sort) instead of all at once
+  const size_t chunk = static_cast<size_t>(max_corners) * 4 + 1024;
+  size_t sorted_upto = 0;
+  auto ensure_sorted = [&](size_t upto) {
+    while (sorted_upto < upto && sorted_upto < h.size()) {
+      const size_t end = std::min(h.size(), sorted_upto + chunk);
+      if (end < h.size()) std::nth_element(h.begin() + sorted_upto, h.begin() + end, h.end(), stronger);
+      std::sort(h.begin() + sorted_upto, h.begin() + end, stronger);
+      sorted_upto = end;
+    }
+  };
   int accepted = 0;
   if (min_distance >= 1.0) {
     const int cell = static_cast<int>(std::lrint(min_distance));
     const int gw = (n + cell - 1) / cell, gh = (m + cell - 1) / cell;
     std::vector<std::vector<std::pair<int, int>>> grid(static_cast<size_t>(gw) * gh);
     const double md2 = min_distance * min_distance;
-    for (const psh::Corner &k : h) {
+    for (size_t ci = 0; ci < h.size(); ++ci) {
+      ensure_sorted(ci + 1);
+      const psh::Corner &k = h[ci];
       const int xc = k.x / cell, yc = k.y / cell;
       bool good = true;
       for (int yy = std::max(0, yc - 1); yy <= std::min(gh - 1, yc + 1) && good; ++yy)
@@ -777,6 +796,7 @@ int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_d
       if (++accepted == max_corners) break;
     }
   } else {
+    ensure_sorted(static_cast<size_t>(max_corners));
     for (const psh::Corner &k : h) {
       points_host[2 * accepted] = static_cast<float>(k.x);
       points_host[2 * accepted + 1] = static_cast<float>(k.y);

@@ -25,7 +25,7 @@ import numpy as np
 
 from .. import _lib
 from ..device import DeviceArray
-from ..utils.cleansing import decluster, detect_outliers
+from ..utils.cleansing import decluster, detect_outliers_device
 from ..utils.interpolate import idw_to_device, idwinterp2d
 
 __all__ = ["dense_lucaskanade", "PreparedFrame", "detect_corners", "track_points"]
@@ -215,7 +215,7 @@ def dense_lucaskanade(
     if xy.shape[0] == 0:
         return zero_field() if dense else (xy, uv)
 
-    outliers = detect_outliers(uv, nr_std_outlier, xy, k_outlier, verbose)
+    outliers = detect_outliers_device(uv, nr_std_outlier, xy, k_outlier, verbose)
     xy, uv = xy[~outliers, :], uv[~outliers, :]
     if verbose:
         print("--- LK found %i sparse vectors ---" % xy.shape[0])

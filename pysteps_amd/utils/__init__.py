@@ -1,4 +1,4 @@
 """Sparse-vector utilities on the dense-LK path (mirrors of pysteps.utils.cleansing / interpolate)."""
 
-from .cleansing import decluster, detect_outliers  # noqa: F401
+from .cleansing import decluster, detect_outliers, detect_outliers_device  # noqa: F401
 from .interpolate import idwinterp2d  # noqa: F401

@@ -127,3 +127,35 @@ def test_errors(idw):
         idw(np.ones(6), np.arange(6.0), xg, yg)
     with pytest.raises(ValueError):
         idw(xy, np.ones((6, 2, 2)), xg, yg)
+
+
+# ---- device outlier test (csrc/sparse_qc.hip) ------------------------------------
+@pytest.mark.parametrize("n,k", [(2, 30), (5, 30), (31, 30), (32, 30), (900, 30), (400, 5), (300, 60)])
+def test_device_outliers_match_host(n, k):
+    from pysteps_amd.utils import detect_outliers, detect_outliers_device
+
+    rng = np.random.default_rng(n + k)
+    xy = rng.uniform(0, 4096, (n, 2))  # continuous positions: no equidistant neighbours
+    uv = rng.normal(0, 1, (n, 2)) + [3, -2]
+    uv[rng.integers(0, n, max(1, n // 30))] += rng.uniform(4, 9, 2)
+    want = detect_outliers(uv, 3, xy, k)
+    got = detect_outliers_device(uv, 3, xy, k)
+    assert got.dtype == bool and np.array_equal(got, want)
+
+
+def test_device_outliers_reference_golden(gold):
+    """integer feature positions (ties possible): at most a handful of borderline flips."""
+    from pysteps_amd.utils import detect_outliers_device
+
+    for case in ("a", "b", "c"):
+        got = detect_outliers_device(gold[case + "/uv"], 3, gold[case + "/xy"], 30)
+        want = gold[case + "/outliers"]
+        assert np.count_nonzero(got != want) <= max(1, 0.01 * want.size)
+
+
+def test_device_outliers_degenerate():
+    from pysteps_amd.utils import detect_outliers_device
+
+    assert not detect_outliers_device(np.zeros((20, 2)), 1, np.random.default_rng(0).uniform(0, 9, (20, 2)), 5).any()
+    assert detect_outliers_device(np.zeros((1, 2)), 1, np.zeros((1, 2)), 5).shape == (1,)
+    assert detect_outliers_device(np.zeros((0, 2)), 1, np.zeros((0, 2)), 5).shape == (0,)
