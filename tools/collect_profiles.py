@@ -1,0 +1,44 @@
+"""Copy the judged summaries of a gpurun_out/<tag> session into profiles/<round>/ and refresh
+profiles/pmc_traffic.json (HBM bytes per launch of semilag_fused; FETCH_SIZE is doubled: gfx950
+reports exactly half of a coalesced read stream, see tools/calib_copy.py / DESIGN.md section 6)."""
+import csv, glob, json, os, shutil, sys
+
+tag, rnd, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
+src = os.path.join("gpurun_out", tag)
+dst = os.path.join("profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+for name in ("bench.json", "pytest_gpu.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (prefix, name)))
+for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, "%s_rocprofv3_kernel_stats.csv" % prefix))
+
+def mean_counter(sub, counter, kernel):
+    vals = []
+    for f in glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                vals.append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    vals = [v for v in vals if v[1] > 500000]  # full-size launches only (not the input synthesis)
+    return (sum(v[0] for v in vals) / len(vals), sum(v[1] for v in vals) / len(vals) / 1e6, len(vals)) if vals else None
+
+fetch = mean_counter("pmc_fetch", "FETCH_SIZE", "semilag_fused")
+write = mean_counter("pmc_write", "WRITE_SIZE", "semilag_fused")
+if fetch and write:
+    bench = json.load(open(os.path.join(src, "bench.json")))
+    key = "semilag_4096x4096_T24_K1"
+    rec = {
+        "kernel": "semilag_fused", "launches_averaged": fetch[2],
+        "FETCH_SIZE_KiB": fetch[0], "WRITE_SIZE_KiB": write[0],
+        "fetch_correction": 2.0,
+        "hbm_bytes_per_launch": (2.0 * fetch[0] + write[0]) * 1024.0,
+        "kernel_ms_under_pmc": fetch[1],
+        "alg_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
+        "source": "gpurun_out/%s pmc_fetch + pmc_write (rocprofv3 --pmc, separate passes)" % tag,
+    }
+    path = os.path.join("profiles", "pmc_traffic.json")
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    table[key] = rec
+    json.dump(table, open(path, "w"), indent=1)
+    json.dump(rec, open(os.path.join(dst, "%s_pmc_semilag.json" % prefix), "w"), indent=1)
+    print(rec)
