@@ -47,6 +47,9 @@ const char *psh_version(void);
 int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hbm_free,
                     char *name, int name_len);
 
+/* tuning knobs; "semilag_variant": 0 direct gathers (default), 2 / 4 LDS-staged tiles */
+int psh_set_option(const char *key, int value);
+
 int psh_malloc(void **dev_ptr, size_t nbytes);
 int psh_free(void *dev_ptr);
 int psh_memcpy_h2d(void *dst_dev, const void *src_host, size_t nbytes); /* async; pageable src is staged */

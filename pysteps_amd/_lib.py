@@ -34,6 +34,7 @@ SIGNATURES = {
     "psh_last_error": (c_char_p, []),
     "psh_version": (c_char_p, []),
     "psh_device_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t), POINTER(c_size_t), c_char_p, c_int]),
+    "psh_set_option": (c_int, [c_char_p, c_int]),
     "psh_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "psh_free": (c_int, [c_void_p]),
     "psh_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),

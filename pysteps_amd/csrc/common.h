@@ -59,6 +59,7 @@ struct SemilagArgs {
   float outval;
 };
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
+void set_semilag_variant(int v);
 
 struct IdwArgs {
   const float *xy;  // (L,2) device: x, y of the sparse vectors

@@ -138,6 +138,17 @@ int psh_shutdown(void) {
   return PSH_OK;
 }
 
+int psh_set_option(const char *key, int value) {
+  if (!key) return fail(PSH_EINVAL, "psh_set_option: NULL key");
+  if (std::strcmp(key, "semilag_variant") == 0) {
+    if (value != 0 && value != 2 && value != 4)
+      return fail(PSH_EINVAL, "semilag_variant must be 0 (direct), 2 or 4 (LDS-staged rows per thread)");
+    psh::set_semilag_variant(value);
+    return PSH_OK;
+  }
+  return fail(PSH_EINVAL, "psh_set_option: unknown option '%s'", key);
+}
+
 int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hbm_free,
                     char *name, int name_len) {
   PSH_REQUIRE_INIT();

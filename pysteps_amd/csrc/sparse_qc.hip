@@ -7,11 +7,14 @@
 // C = cov(neighbours, ddof=1), outlier iff sqrt(z^T C^-1 z) > thr; singular C ->
 // not an outlier (:239-243).
 //
-// N is a few thousand at most: one thread owns one vector, scans all N in LDS-
-// staged chunks and keeps its k+1 nearest in registers; everything is float64
-// (coordinates are exact, ties are broken by the lower index - cKDTree's own tie
-// order is unspecified).  Runtime ~ tens of microseconds; it exists to keep the
-// 2-4 ms host k-d tree query off the critical path of a nowcast step.
+// N is a few thousand at most.  One WAVE owns one vector: the 64 lanes compute the
+// N squared distances into an LDS key array (distance bits << 32 | index, so that a
+// single 64-bit minimum also breaks ties by the lower index - cKDTree's own tie
+// order is unspecified), then the k+1 nearest are extracted one by one with a wave
+// minimum; the owner lane retires the key and rescans its N/64 entries.  Sums for
+// mean / covariance are accumulated in float64 relative to the vector itself.
+// Runtime ~ 10 us; it exists to keep the 2-4 ms host k-d tree query off the critical
+// path of a nowcast step.
 #include <vector>
 
 #include "common.h"
@@ -19,100 +22,67 @@
 namespace psh {
 namespace {
 
-constexpr int kQcMaxK = 64;   // k + 1 <= 64
-constexpr int kQcChunk = 256;
+constexpr int kQcMaxN = 8192;  // LDS keys: 8 B per vector (64 KiB)
 
-template <int KMAX>
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(v, d);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(64) void outliers_local(const double2 *__restrict__ xy,
                                                      const double2 *__restrict__ uv, int n, int k,
                                                      double thr,
                                                      unsigned char *__restrict__ flags) {
-  __shared__ double2 s_xy[kQcChunk];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < n;
-  const double2 me = xy[live ? i : 0];
-  const int kk = min(n, k + 1);  // neighbours incl. the vector itself
-  double d2[KMAX];
-  int idx[KMAX];
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) {
-    d2[j] = j < kk ? INFINITY : -INFINITY;
-    idx[j] = -1;
+  extern __shared__ unsigned long long keys[];
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const double2 me = xy[i], mine = uv[i];
+  constexpr unsigned long long kGone = ~0ull;
+  unsigned long long best = kGone;
+  for (int j = lane; j < n; j += 64) {
+    const double dx = xy[j].x - me.x, dy = xy[j].y - me.y;
+    const float d = static_cast<float>(dx * dx + dy * dy);
+    const unsigned long long key =
+        (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | static_cast<unsigned>(j);
+    keys[j] = key;
+    best = key < best ? key : best;
   }
-  double worst = INFINITY;
-  int worst_pos = 0;
-  for (int base = 0; base < n; base += kQcChunk) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < kQcChunk && base + t < n; t += blockDim.x) s_xy[t] = xy[base + t];
-    __syncthreads();
-    const int lim = min(kQcChunk, n - base);
-    for (int t = 0; t < lim; ++t) {
-      const double dx = s_xy[t].x - me.x, dy = s_xy[t].y - me.y;
-      const double d = dx * dx + dy * dy;
-      if (d < worst) {  // strict: among equal distances the lower index stays
-        double w = -INFINITY;
-        int wp = 0;
-#pragma unroll
-        for (int j = 0; j < KMAX; ++j) {
-          const bool hit = j == worst_pos;
-          d2[j] = hit ? d : d2[j];
-          idx[j] = hit ? base + t : idx[j];
-          if (d2[j] > w) {
-            w = d2[j];
-            wp = j;
-          }
-        }
-        worst = w;
-        worst_pos = wp;
-      }
-    }
-  }
-  if (!live) return;
-  // drop the nearest hit (the vector itself, or a duplicate position with a lower index)
-  double best = INFINITY;
-  int best_idx = 0x7fffffff, best_pos = 0;
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) {
-    if (idx[j] >= 0 && (d2[j] < best || (d2[j] == best && idx[j] < best_idx))) {
-      best = d2[j];
-      best_idx = idx[j];
-      best_pos = j;
-    }
-  }
-  double su = 0.0, sv = 0.0;
+  const int kk = min(n, k + 1);  // nearest hits incl. the vector itself
+  double sa = 0.0, sb = 0.0, saa = 0.0, sab = 0.0, sbb = 0.0;
   int cnt = 0;
-#pragma unroll
-  for (int j = 0; j < KMAX; ++j) {
-    if (idx[j] >= 0 && j != best_pos) {
-      const double2 q = uv[idx[j]];
-      su += q.x;
-      sv += q.y;
+  for (int t = 0; t < kk; ++t) {
+    const unsigned long long g = wave_min_u64(best);
+    const int j = static_cast<int>(g & 0xffffffffull);
+    if (t > 0) {  // the first hit is the vector itself (or a duplicate position): dropped
+      const double2 q = uv[j];
+      const double a = q.x - mine.x, b = q.y - mine.y;
+      sa += a;
+      sb += b;
+      saa += a * a;
+      sab += a * b;
+      sbb += b * b;
       ++cnt;
     }
+    if ((j & 63) == lane) {  // owner retires the key and rescans its entries
+      keys[j] = kGone;
+      best = kGone;
+      for (int q = lane; q < n; q += 64) best = keys[q] < best ? keys[q] : best;
+    }
   }
+  if (lane != 0) return;
   bool out = false;
   if (cnt >= 2) {
-    const double mu = su / cnt, mv = sv / cnt;
-    double cuu = 0.0, cuv = 0.0, cvv = 0.0;
-#pragma unroll
-    for (int j = 0; j < KMAX; ++j) {
-      if (idx[j] >= 0 && j != best_pos) {
-        const double2 q = uv[idx[j]];
-        const double a = q.x - mu, b = q.y - mv;
-        cuu += a * a;
-        cuv += a * b;
-        cvv += b * b;
-      }
-    }
+    const double ma = sa / cnt, mb = sb / cnt;  // neighbour mean relative to this vector
     const double dof = cnt - 1;
-    cuu /= dof;
-    cuv /= dof;
-    cvv /= dof;
-    const double det = cuu * cvv - cuv * cuv;
+    const double caa = (saa - sa * ma) / dof, cab = (sab - sa * mb) / dof,
+                 cbb = (sbb - sb * mb) / dof;
+    const double det = caa * cbb - cab * cab;
     if (det != 0.0 && isfinite(det)) {
-      const double2 mine = uv[i];
-      const double zu = mine.x - mu, zv = mine.y - mv;
-      const double md2 = (zu * zu * cvv - 2.0 * zu * zv * cuv + zv * zv * cuu) / det;
+      const double zu = -ma, zv = -mb;  // this vector minus the neighbour mean
+      const double md2 = (zu * zu * cbb - 2.0 * zu * zv * cab + zv * zv * caa) / det;
       out = sqrt(md2) > thr;
     }
   }
@@ -129,9 +99,9 @@ extern "C" int psh_outliers_local_host(const double *xy, const double *values, i
   if (n == 0) return PSH_OK;
   if (!xy || !values || !flags) return psh::fail(PSH_EINVAL, "outliers: NULL pointer");
   if (k < 1) return psh::fail(PSH_EINVAL, "outliers: k must be >= 1");
-  if (k + 1 > psh::kQcMaxK && n > psh::kQcMaxK)
-    return psh::fail(PSH_EUNSUPPORTED, "outliers: k=%d > %d not implemented on the device", k,
-                     psh::kQcMaxK - 1);
+  if (n > psh::kQcMaxN)
+    return psh::fail(PSH_EUNSUPPORTED, "outliers: more than %d vectors not implemented on the device",
+                     psh::kQcMaxN);
   if (n < 2) {
     flags[0] = 0;
     return PSH_OK;
@@ -150,12 +120,8 @@ extern "C" int psh_outliers_local_host(const double *xy, const double *values, i
   auto run = [&]() -> int {
     PSH_HIP(hipMemcpyAsync(d_xy, xy, vec_bytes, hipMemcpyHostToDevice, c.stream));
     PSH_HIP(hipMemcpyAsync(d_uv, values, vec_bytes, hipMemcpyHostToDevice, c.stream));
-    const dim3 grid((n + 63) / 64), block(64);
-    if (std::min(n, k + 1) <= 32) {
-      hipLaunchKernelGGL((psh::outliers_local<32>), grid, block, 0, c.stream, d_xy, d_uv, n, k, thr, d_fl);
-    } else {
-      hipLaunchKernelGGL((psh::outliers_local<psh::kQcMaxK>), grid, block, 0, c.stream, d_xy, d_uv, n, k, thr, d_fl);
-    }
+    const size_t lds = static_cast<size_t>(n) * sizeof(unsigned long long);
+    hipLaunchKernelGGL(psh::outliers_local, dim3(n), dim3(64), lds, c.stream, d_xy, d_uv, n, k, thr, d_fl);
     PSH_HIP(hipGetLastError());
     PSH_HIP(hipMemcpyAsync(flags, d_fl, static_cast<size_t>(n), hipMemcpyDeviceToHost, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));

@@ -217,7 +217,7 @@ def detect_outliers_device(input_array, thr, coord, k, verbose=False):
     xy = None if coord is None else np.ascontiguousarray(coord, dtype=np.float64)
     if (
         values.ndim != 2 or values.shape[1] != 2 or xy is None or k is None
-        or xy.shape != values.shape or int(k) + 1 > 64
+        or xy.shape != values.shape or values.shape[0] > 8192
     ):
         return detect_outliers(input_array, thr, coord, k, verbose)
     if np.any(~np.isfinite(values)):

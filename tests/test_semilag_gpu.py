@@ -217,3 +217,41 @@ def test_device_resident_path(extrapolate):
     ref2, rdisp2 = extrapolate(p, v, [1.0], outval=-15.0, return_displacement=True, displacement_prev=host_disp)
     assert np.array_equal(out2.to_host(), ref2)
     assert np.array_equal(dev_disp.to_host(), host_disp)  # displacement_prev untouched
+
+
+@pytest.mark.parametrize("variant", [2, 4])
+def test_lds_staged_variants_match_default(extrapolate, semilag_golden, variant):
+    """The LDS-staged kernels (psh_set_option semilag_variant) give the default kernel's result."""
+    from pysteps_amd import _lib
+    from tools import synth
+
+    lib = _lib.lib()
+    cases = []
+    m, n = 200, 256
+    p = synth.rain_field_db(m, n, seed=21)
+    y, x = np.mgrid[0:m, 0:n]
+    v = synth.true_velocity(m, n) + np.stack([0.03 * (x - n / 2), -0.02 * (y - m / 2)]).astype(np.float32)
+    pn = p.copy()
+    pn[synth.border_nan_mask(m, n, 0.1)] = np.nan
+    cases.append((p, v, 6, dict(n_iter=1)))
+    cases.append((p, v, 3, dict(n_iter=3, outval=-15.0)))
+    cases.append((p, v, 3, dict(n_iter=0)))
+    cases.append((pn, v, 3, dict(allow_nonfinite_values=True)))
+    cases.append((p, v, 2, dict(interp_order=0, outval=-15.0)))
+    base = [extrapolate(a, b, t, return_displacement=True, **kw) for a, b, t, kw in cases]
+    _lib.check(lib.psh_set_option(b"semilag_variant", variant))
+    try:
+        for (a, b, t, kw), (want, wdisp) in zip(cases, base):
+            got, gdisp = extrapolate(a, b, t, return_displacement=True, **kw)
+            assert nan_mismatch(got, want) == 0
+            assert np.max(np.abs(gdisp - wdisp)) < 1e-5
+            if kw.get("interp_order", 1) == 0:
+                assert np.count_nonzero(got != want) <= 1e-4 * got.size
+            else:
+                assert rel_l2(got, want) < 1e-6
+        for name in ("sl_int_T6", "sl_shear_K3", "sl_nan_nan", "sl_resume"):
+            c = semilag_golden.case(name)
+            out, disp = extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **c["kw"])
+            assert nan_mismatch(out, c["out"]) == 0 and rel_l2(out, c["out"]) < REL_L2_TOL
+    finally:
+        _lib.check(lib.psh_set_option(b"semilag_variant", 0))
