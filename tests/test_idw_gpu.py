@@ -159,3 +159,31 @@ def test_device_outliers_degenerate():
     assert not detect_outliers_device(np.zeros((20, 2)), 1, np.random.default_rng(0).uniform(0, 9, (20, 2)), 5).any()
     assert detect_outliers_device(np.zeros((1, 2)), 1, np.zeros((1, 2)), 5).shape == (1,)
     assert detect_outliers_device(np.zeros((0, 2)), 1, np.zeros((0, 2)), 5).shape == (0,)
+
+
+def test_idw_4096_sampled_pixels_vs_oracle():
+    """Full-size field (4096^2, ~1000 declustered vectors): the cKDTree oracle is evaluated on a
+    random sample of pixels only (it needs 100 s for the whole grid)."""
+    from scipy.spatial import cKDTree
+
+    from pysteps_amd.utils.interpolate import idw_to_device
+
+    m = n = 4096
+    rng = np.random.default_rng(12)
+    L = 1000
+    xy = np.column_stack([rng.integers(0, n, L), rng.integers(0, m, L)]).astype(float) + 0.5 * rng.integers(0, 2, (L, 2))
+    uv = np.column_stack([4 + 2 * np.sin(2 * np.pi * xy[:, 1] / m), -3 + 1.5 * np.cos(2 * np.pi * xy[:, 0] / n)])
+    uv += rng.normal(0, 0.1, uv.shape)
+    field = idw_to_device(xy, uv, m, n).to_host()
+    assert field.shape == (2, m, n) and np.isfinite(field).all()
+    sx, sy = rng.integers(0, n, 4000), rng.integers(0, m, 4000)
+    # corners and edges as well
+    sx[:4], sy[:4] = [0, n - 1, 0, n - 1], [0, 0, m - 1, m - 1]
+    d, i = cKDTree(xy).query(np.column_stack([sx, sy]).astype(float), k=21)
+    ties = d[:, 20] - d[:, 19] <= 2e-4
+    d, i = d[:, :20], i[:, :20]
+    w = 1.0 / np.sqrt(d + 0.5)
+    w /= w.sum(axis=1, keepdims=True)
+    want = (uv[i] * w[..., None]).sum(axis=1)
+    got = field[:, sy, sx].T
+    assert np.max(np.abs(got - want)[~ties]) < 1e-4

@@ -228,3 +228,30 @@ def test_device_resident_frames(dense_lk):
     dev = dense_lk(DeviceArray.from_host(frames))
     assert isinstance(dev, DeviceArray) and dev.shape == (2, 256, 256) and dev.dtype == np.float32
     assert np.abs(dev.to_host() - host).max() < 1e-4
+
+
+def test_dense_lk_4096_recovers_true_motion(dense_lk):
+    """Bench workload (config 3) at full size, device resident: the frames are the base field
+    advected by the known motion; dense LK must give that motion back away from the inflow edges."""
+    from pysteps_amd import _lib, extrapolation
+    from pysteps_amd.device import DeviceArray
+    from tools import synth
+
+    m = n = 4096
+    base = synth.rain_field_db(m, n)
+    vel = synth.true_velocity(m, n)
+    vel_d = DeviceArray.from_host(vel)
+    frames = DeviceArray((2, m, n), np.float32)
+    lib = _lib.lib()
+    _lib.check(lib.psh_memcpy_h2d(frames.ptr, base.ctypes.data, base.nbytes))
+    adv = extrapolation.get_method("semilagrangian")(frames.view(0), vel_d, 1, outval=-15.0)
+    _lib.check(lib.psh_memcpy_d2d(frames.view(1).ptr, adv.ptr, adv.nbytes))
+    field = dense_lk(frames)
+    assert isinstance(field, DeviceArray) and field.shape == (2, m, n)
+    got = field.to_host()
+    assert np.isfinite(got).all()
+    inner = (slice(None), slice(512, m - 512), slice(512, n - 512))
+    rmse = np.sqrt(np.mean((got - vel)[inner] ** 2))
+    assert rmse < 0.25, rmse
+    xy, uv = dense_lk(frames.to_host(), dense=False)
+    assert 500 < len(xy) <= 1000

@@ -255,3 +255,32 @@ def test_lds_staged_variants_match_default(extrapolate, semilag_golden, variant)
             assert nan_mismatch(out, c["out"]) == 0 and rel_l2(out, c["out"]) < REL_L2_TOL
     finally:
         _lib.check(lib.psh_set_option(b"semilag_variant", 0))
+
+
+def test_config3_4096_full_size_vs_oracle(extrapolate):
+    """BASELINE config 3 (the bench workload): 4096^2, 24 lead times, n_iter=1, against the
+    multi-threaded C oracle at full size; device-resident so only the results cross PCIe."""
+    from oracle import semilag_cport as ocl
+    from pysteps_amd.device import DeviceArray
+    from tools import synth
+
+    m = n = 4096
+    p = synth.rain_field_db(m, n)
+    v = synth.true_velocity(m, n)
+    want, wdisp = ocl.extrapolate(p, v, 24, outval=-15.0, return_displacement=True)
+    out, disp = extrapolate(DeviceArray.from_host(p), DeviceArray.from_host(v), 24, outval=-15.0,
+                            return_displacement=True)
+    gdisp = disp.to_host()
+    assert np.max(np.abs(gdisp - wdisp)) < DISP_TOL
+    for t in (0, 11, 23):  # three of the 24 planes come back (64 MiB each)
+        got = out.view(t).to_host()
+        err = rel_l2(got, want[t])
+        assert err < REL_L2_TOL, (t, err)
+    # size-independent property on all planes: chained single steps == one 24-step call
+    d = None
+    dp, dv = DeviceArray.from_host(p), DeviceArray.from_host(v)
+    for t in range(24):
+        o1, d = extrapolate(dp, dv, [1.0], outval=-15.0, return_displacement=True, displacement_prev=d)
+        if t in (0, 11, 23):
+            assert rel_l2(o1.view(0).to_host(), want[t]) < REL_L2_TOL
+    assert np.max(np.abs(d.to_host() - wdisp)) < DISP_TOL
