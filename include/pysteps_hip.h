@@ -161,6 +161,13 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
 int psh_outliers_local_host(const double *xy, const double *values, int n, int k, double thr,
                             unsigned char *flags);
 
+/* decluster of pysteps/utils/cleansing.py:21-121 for (n,2) coordinates, (n,2) values and a
+ * scalar scale: per scale-sized cell (lexicographic cell order) the component-wise medians.
+ * Pure host code (no device needed).  out_xy / out_values must hold n rows; *out_count rows
+ * are written. */
+int psh_decluster_host(const double *xy, const double *values, int n, double scale,
+                       int min_samples, double *out_xy, double *out_values, int *out_count);
+
 /* ---- multi-GPU: RCCL over xGMI, one rank (process) per GPU ------------------ *
  * The reference has no communication layer (single process, optional dask threads:
  * pysteps/nowcasts/utils.py:464-471); members / fields shard across GPUs with ONE

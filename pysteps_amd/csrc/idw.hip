@@ -34,9 +34,54 @@ constexpr int kCandCap = 1024;  // candidates kept in LDS per tile (16 KiB)
 
 __device__ __forceinline__ float idw_weight(float d, float power, float offset) {
   const float t = d + offset;
-  // power 0.5 is the reference default: 1/sqrt(t)
-  return power == 0.5f ? 1.0f / sqrtf(t) : powf(t, -power);
+  // power 0.5 is the reference default: 1/sqrt(t) as one v_rsq_f32 (1 ulp)
+  return power == 0.5f ? __builtin_amdgcn_rsqf(t) : powf(t, -power);
 }
+
+// distance from its square: one v_sqrt_f32 (1 ulp) instead of the IEEE sequence
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// The k smallest squared distances seen so far, as an unsorted register set with a
+// running maximum.  Only VALUES are kept: the maximum of the final set is the k-th
+// smallest distance, and a second sweep over the (LDS-resident) candidates collects
+// every candidate below it - half the registers and selects of an index-carrying set.
+template <int KMAX>
+struct KSmallest {
+  float d2[KMAX];
+  float worst;
+  int worst_pos;
+
+  __device__ __forceinline__ void refresh() {
+    float w = -INFINITY;
+    int wp = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (d2[j] > w) {
+        w = d2[j];
+        wp = j;
+      }
+    }
+    worst = w;
+    worst_pos = wp;
+  }
+
+  __device__ __forceinline__ void offer(float d) {
+    if (d < worst) {
+      float w = -INFINITY;
+      int wp = 0;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        d2[j] = j == worst_pos ? d : d2[j];
+        if (d2[j] > w) {
+          w = d2[j];
+          wp = j;
+        }
+      }
+      worst = w;
+      worst_pos = wp;
+    }
+  }
+};
 
 template <int KMAX>
 struct TopK {
@@ -231,32 +276,44 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
     if (n_cand > kCandCap) {  // pathological clustering: exact brute force
       idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
     } else {
-      TopK<KMAX> top;
-      top.init(k);
-      // the first k candidates go straight into their slots (no selection needed:
-      // n_cand >= k by construction of the radius), then one maximum scan
+      KSmallest<KMAX> top;
+      // the first k candidates go straight into their slots (n_cand >= k by construction
+      // of the radius; unused slots can never be the maximum), then one maximum scan
       const int n_fill = min(k, n_cand);
 #pragma unroll
       for (int j = 0; j < KMAX; ++j) {
+        top.d2[j] = -INFINITY;
         if (j < n_fill) {
           const float4 c = s_cand[j];  // same address in every lane: LDS broadcast
           const float ddx = c.x - px, ddy = c.y - py;
           top.d2[j] = ddx * ddx + ddy * ddy;
-          top.idx[j] = j;
         }
       }
       top.refresh();
       for (int i = n_fill; i < n_cand; ++i) {
         const float4 c = s_cand[i];
         const float ddx = c.x - px, ddy = c.y - py;
-        top.offer(ddx * ddx + ddy * ddy, i);
+        top.offer(ddx * ddx + ddy * ddy);
       }
-      float sw = 0.f, su = 0.f, sv = 0.f;
+      // second sweep: everything strictly below the k-th smallest distance, plus as many
+      // of the candidates AT that distance (in index order) as are needed to reach k
+      const float tau = top.worst;
+      int below = 0;
 #pragma unroll
-      for (int j = 0; j < KMAX; ++j) {
-        if (top.idx[j] >= 0) {
-          const float4 c = s_cand[top.idx[j]];
-          const float w = idw_weight(sqrtf(top.d2[j]) * inv_res, power, offset);
+      for (int j = 0; j < KMAX; ++j) below += (top.d2[j] > -INFINITY && top.d2[j] < tau) ? 1 : 0;
+      int ties_wanted = n_fill - below;
+      float sw = 0.f, su = 0.f, sv = 0.f;
+      for (int i = 0; i < n_cand; ++i) {
+        const float4 c = s_cand[i];
+        const float ddx = c.x - px, ddy = c.y - py;
+        const float d2 = ddx * ddx + ddy * ddy;
+        bool take = d2 < tau;
+        if (d2 == tau && ties_wanted > 0) {
+          take = true;
+          --ties_wanted;
+        }
+        if (take) {
+          const float w = idw_weight(fast_sqrt(d2) * inv_res, power, offset);
           sw += w;
           su += w * c.z;
           sv += w * c.w;

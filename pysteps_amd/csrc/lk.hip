@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kFinalThreads) void lk_stats1_final(const float *__
 // field = (filled > min).  Opening = erode then dilate with the plus-shaped 3x3
 // element, image border neutral.  Pixels of the field that the opening removes
 // are set to the minimum (images.py:78-81).  64x4 tile + 2-pixel halo in LDS.
-constexpr int kOpenTX = 64, kOpenTY = 4;
+constexpr int kOpenTX = 64, kOpenTY = 16;  // 4 pixels per thread: halo overhead 1.33x
 
 __global__ __launch_bounds__(256) void lk_open(const float *__restrict__ img, int m, int n,
                                                int size_opening, int buffer_mask,
@@ -164,10 +164,13 @@ __global__ __launch_bounds__(256) void lk_open(const float *__restrict__ img, in
     ero[ly][lx] = e ? 1 : 0;
   }
   __syncthreads();
-  const int lx = tid % kOpenTX, ly = tid / kOpenTX;
-  const int x = x0 + lx, y = y0 + ly;
   float mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
-  if (x < n && y < m) {
+  // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
+  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+  for (int i = tid; i < kOpenTX * kOpenTY; i += 256) {
+    const int lx = i % kOpenTX, ly = i / kOpenTX;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= n || y >= m) continue;
     float v = img[static_cast<size_t>(y) * n + x];
     if (size_opening > 0 && isfinite(v) && v > mn) {
       const int cy = ly + 1, cx = lx + 1;
@@ -177,10 +180,11 @@ __global__ __launch_bounds__(256) void lk_open(const float *__restrict__ img, in
     }
     clean[static_cast<size_t>(y) * n + x] = v;
     if (isfinite(v)) {
-      mx_all = v;
-      // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
-      const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
-      if (y >= first_row) mn_feat = mx_feat = v;
+      mx_all = fmaxf(mx_all, v);
+      if (y >= first_row) {
+        mn_feat = fminf(mn_feat, v);
+        mx_feat = fmaxf(mx_feat, v);
+      }
     }
   }
   mx_all = wave_max(mx_all);
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void lk_to_u8(const float *__restrict__ clean,
 }
 
 // ---- Shi-Tomasi response: cv::cornerMinEigenVal(8U, blockSize, ksize=3) --------
-constexpr int kCrnTX = 32, kCrnTY = 8, kMaxBlockR = 3;  // block_size <= 7
+constexpr int kCrnTX = 32, kCrnTY = 32, kMaxBlockR = 3;  // block_size <= 7; 4 px per thread
 
 __device__ __forceinline__ bool px_allowed(const float *__restrict__ clean, int m, int n, int x,
                                            int y, int bm, bool any_nan) {
@@ -325,10 +329,12 @@ __global__ __launch_bounds__(256) void lk_corner_response(
     cyy[ry][rx] = dy * dy;
   }
   __syncthreads();
-  const int lx = tid % kCrnTX, ly = tid / kCrnTX;
-  const int x = x0 + lx, y = y0 + ly;
   float best = 0.f;
-  if (x < n && y < m) {
+  const bool any_nan = stats[kNanCount] > 0.f;
+  for (int p = tid; p < kCrnTX * kCrnTY; p += 256) {
+    const int lx = p % kCrnTX, ly = p / kCrnTX;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= n || y >= m) continue;
     double sxx = 0.0, sxy = 0.0, syy = 0.0;  // boxFilter sums 32F data in double
     for (int j = 0; j < block_size; ++j) {
       for (int i = 0; i < block_size; ++i) {
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256) void lk_corner_response(
     const float c = static_cast<float>(syy) * 0.5f;
     const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
     eig[static_cast<size_t>(y) * n + x] = e;
-    if (px_allowed(clean, m, n, x, y, buffer_mask, stats[kNanCount] > 0.f)) best = fmaxf(e, 0.f);
+    if (px_allowed(clean, m, n, x, y, buffer_mask, any_nan)) best = fmaxf(best, fmaxf(e, 0.f));
   }
   best = wave_max(best);
   if ((tid & 63) == 0) red[tid >> 6] = best;
@@ -367,41 +373,65 @@ struct Corner {
   int x, y;
 };
 
+constexpr int kSelRows = 64;  // rows per workgroup (16 per wave): one counter atomic per 64x64 pixels
+
+__device__ __forceinline__ bool corner_keep(const float *__restrict__ eig,
+                                            const float *__restrict__ clean, int m, int n, int x,
+                                            int y, int buffer_mask, float thr, bool any_nan,
+                                            float &v) {
+  v = 0.f;
+  if (!(x >= 1 && x < n - 1 && y >= 1 && y < m - 1)) return false;
+  v = eig[static_cast<size_t>(y) * n + x];
+  if (!(v > thr) || v == 0.f) return false;  // THRESH_TOZERO keeps values > thr
+#pragma unroll
+  for (int j = -1; j <= 1; ++j)
+#pragma unroll
+    for (int i = -1; i <= 1; ++i)
+      if (eig[static_cast<size_t>(y + j) * n + (x + i)] > v) return false;  // not the 3x3 maximum
+  return px_allowed(clean, m, n, x, y, buffer_mask, any_nan);
+}
+
 __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict__ eig,
                                                         const float *__restrict__ clean, int m,
                                                         int n, int buffer_mask, float quality,
                                                         const float *__restrict__ stats,
                                                         Corner *__restrict__ out, int cap,
                                                         int *__restrict__ count) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  bool keep = false;
-  float v = 0.f;
-  if (x >= 1 && x < n - 1 && y >= 1 && y < m - 1) {
-    const float thr = stats[kEigMax] * quality;  // THRESH_TOZERO: keep values > thr
-    v = eig[static_cast<size_t>(y) * n + x];
-    if (v > thr && v != 0.f) {
-      keep = true;
-#pragma unroll
-      for (int j = -1; j <= 1; ++j)
-#pragma unroll
-        for (int i = -1; i <= 1; ++i) {
-          const float q = eig[static_cast<size_t>(y + j) * n + (x + i)];
-          if (q > v) keep = false;  // v == max of the thresholded 3x3 neighbourhood
-        }
-      if (keep) keep = px_allowed(clean, m, n, x, y, buffer_mask, stats[kNanCount] > 0.f);
-    }
+  __shared__ int wave_count[4];
+  __shared__ int block_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 64 + lane;
+  const int y_first = blockIdx.y * kSelRows + wave * (kSelRows / 4);
+  const float thr = stats[kEigMax] * quality;
+  const bool any_nan = stats[kNanCount] > 0.f;
+  // pass 1: how many candidates does this wave hold (a single global counter saturates at
+  // ~90 atomics/us, so the workgroup reserves its output range with ONE atomic)
+  int mine = 0;
+  for (int r = 0; r < kSelRows / 4; ++r) {
+    float v;
+    mine += __popcll(__ballot(corner_keep(eig, clean, m, n, x, y_first + r, buffer_mask, thr, any_nan, v)));
   }
-  const unsigned long long mask = __ballot(keep);
-  if (mask) {
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(count, __popcll(mask));
-    base = __shfl(base, 0);
+  if (lane == 0) wave_count[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    block_base = total > 0 ? atomicAdd(count, total) : 0;
+  }
+  __syncthreads();
+  int pos = block_base;
+  for (int w = 0; w < wave; ++w) pos += wave_count[w];
+  if (mine == 0) return;
+  // pass 2: same predicate, now with a destination
+  for (int r = 0; r < kSelRows / 4; ++r) {
+    float v;
+    const int y = y_first + r;
+    const bool keep = corner_keep(eig, clean, m, n, x, y, buffer_mask, thr, any_nan, v);
+    const unsigned long long mask = __ballot(keep);
     if (keep) {
-      const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-      if (pos < cap) out[pos] = Corner{v, x, y};
+      const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
+      if (at < cap) out[at] = Corner{v, x, y};
     }
+    pos += __popcll(mask);
   }
 }
 
@@ -737,7 +767,7 @@ int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_d
   hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb, stats_dev,
                      static_cast<int>(psh::kEigMax));
   PSH_HIP(hipMemsetAsync(cnt, 0, sizeof(int), c.stream));
-  const dim3 sgrid((n + 63) / 64, (m + 3) / 4);
+  const dim3 sgrid((n + 63) / 64, (m + psh::kSelRows - 1) / psh::kSelRows);
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n,
                      buffer_mask, static_cast<float>(quality_level), stats_dev, cand, cap, cnt);
   PSH_HIP(hipGetLastError());

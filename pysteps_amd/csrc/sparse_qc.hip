@@ -131,3 +131,70 @@ extern "C" int psh_outliers_local_host(const double *xy, const double *values, i
   (void)psh_free(blk);
   return rc;
 }
+
+// ---------------------------------------------------------------------------
+// decluster (host): pysteps/utils/cleansing.py:21-121 for 2-d coordinates and
+// 2-vectors with a scalar scale - cell = floor(xy / scale), cells in lexicographic
+// (x_cell, y_cell) order (np.unique(axis=0), :101), per cell the component-wise
+// median of the coordinates and of the vectors (:107-116).  A few thousand samples:
+// plain C++ on the host (no device needed), ~20 us instead of ~0.4 ms of NumPy.
+// ---------------------------------------------------------------------------
+#include <algorithm>
+#include <cmath>
+
+namespace {
+double median_of(std::vector<double> &v) {
+  std::sort(v.begin(), v.end());
+  const size_t c = v.size();
+  return 0.5 * (v[(c - 1) / 2] + v[c / 2]);
+}
+}  // namespace
+
+extern "C" int psh_decluster_host(const double *xy, const double *values, int n, double scale,
+                                  int min_samples, double *out_xy, double *out_values,
+                                  int *out_count) {
+  if (n < 0) return psh::fail(PSH_EINVAL, "decluster: negative sample count");
+  if (!out_count) return psh::fail(PSH_EINVAL, "decluster: NULL out_count");
+  *out_count = 0;
+  if (n == 0) return PSH_OK;
+  if (!xy || !values || !out_xy || !out_values) return psh::fail(PSH_EINVAL, "decluster: NULL pointer");
+  if (!(scale > 0.0) || !std::isfinite(scale)) return psh::fail(PSH_EINVAL, "decluster: scale must be positive");
+  struct Item {
+    double cx, cy;
+    int idx;
+  };
+  std::vector<Item> items(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) {
+    items[i].cx = std::floor(xy[2 * i] / scale);
+    items[i].cy = std::floor(xy[2 * i + 1] / scale);
+    items[i].idx = i;
+  }
+  std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
+    return a.cx != b.cx ? a.cx < b.cx : a.cy < b.cy;
+  });
+  std::vector<double> col;
+  int written = 0;
+  for (size_t s = 0; s < items.size();) {
+    size_t e = s + 1;
+    while (e < items.size() && items[e].cx == items[s].cx && items[e].cy == items[s].cy) ++e;
+    if (static_cast<int>(e - s) >= min_samples) {
+      for (int c = 0; c < 4; ++c) {
+        col.clear();
+        for (size_t t = s; t < e; ++t) {
+          const int i = items[t].idx;
+          col.push_back(c < 2 ? xy[2 * i + c] : values[2 * i + (c - 2)]);
+        }
+        const double med = median_of(col);
+        if (c < 2) {
+          out_xy[2 * written + c] = med;
+        } else {
+          out_values[2 * written + (c - 2)] = med;
+        }
+      }
+      ++written;
+    }
+    s = e;
+  }
+  *out_count = written;
+  return PSH_OK;
+}

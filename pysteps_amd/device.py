@@ -13,11 +13,12 @@ from . import _lib
 
 
 class DeviceArray:
-    __slots__ = ("ptr", "shape", "dtype", "_owner", "__weakref__")
+    __slots__ = ("ptr", "shape", "dtype", "_owner", "_keep", "__weakref__")
 
     def __init__(self, shape, dtype=np.float32, ptr=None, owner=None):
         self.shape = tuple(int(s) for s in np.atleast_1d(shape))
         self.dtype = np.dtype(dtype)
+        self._keep = None  # objects that must outlive work queued on this array
         if ptr is None:
             p = ctypes.c_void_p()
             _lib.check(_lib.lib().psh_malloc(ctypes.byref(p), self.nbytes), "psh_malloc")
@@ -42,13 +43,16 @@ class DeviceArray:
 
     # -- construction / transfer ---------------------------------------
     @classmethod
-    def from_host(cls, array, dtype=None):
+    def from_host(cls, array, dtype=None, sync=True):
         arr = np.ascontiguousarray(array, dtype=dtype)
         out = cls(arr.shape, arr.dtype)
         if arr.nbytes:
             _lib.check(_lib.lib().psh_memcpy_h2d(out.ptr, arr.ctypes.data, arr.nbytes), "h2d")
-            # pageable source: make sure the copy is complete before `arr` can die
-            _lib.check(_lib.lib().psh_sync(), "sync")
+            if sync:
+                # pageable source: make sure the copy is complete before `arr` can die
+                _lib.check(_lib.lib().psh_sync(), "sync")
+            else:
+                out._keep = arr  # the host buffer lives as long as the device array
         return out
 
     def to_host(self, out=None):

@@ -55,6 +55,14 @@ def decluster(coord, input_array, scale, min_samples=1, verbose=False):
     if coord.shape[0] == 0:
         return np.empty((0, ndim)), np.empty((0, nvar))
 
+    if nvar == 2 and ndim == 2 and isinstance(scale, float) and np.all(np.isfinite(coord)):
+        # the shape dense LK uses: native host routine of the C ABI (psh_decluster_host)
+        native = _decluster_native(coord, input_array, scale, min_samples)
+        if native is not None:
+            if verbose:
+                print("--- %i samples left after declustering ---" % native[1].shape[0])
+            return native
+
     cells = np.floor(coord / scale)
     group, counts = _group_rows(cells)
     starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
@@ -74,6 +82,27 @@ def decluster(coord, input_array, scale, min_samples=1, verbose=False):
     if verbose:
         print("--- %i samples left after declustering ---" % dinput.shape[0])
     return dcoord, dinput
+
+
+def _decluster_native(coord, values, scale, min_samples):
+    """psh_decluster_host (pure host C++, no GPU needed); None if the library is not built."""
+    import ctypes  # noqa: PLC0415
+
+    from .. import _lib  # noqa: PLC0415
+
+    try:
+        lib = _lib.load()
+    except _lib.HipLibraryError:
+        return None
+    n = coord.shape[0]
+    xy = np.ascontiguousarray(coord, dtype=np.float64)
+    uv = np.ascontiguousarray(values, dtype=np.float64)
+    oxy, ouv = np.empty((n, 2)), np.empty((n, 2))
+    count = ctypes.c_int(0)
+    rc = lib.psh_decluster_host(xy.ctypes.data, uv.ctypes.data, n, float(scale), int(min_samples),
+                                oxy.ctypes.data, ouv.ctypes.data, ctypes.byref(count))
+    _lib.check(rc, "psh_decluster_host")
+    return oxy[: count.value].copy(), ouv[: count.value].copy()
 
 
 def _group_rows(cells):

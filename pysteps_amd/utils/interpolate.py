@@ -74,15 +74,14 @@ def idw_to_device(xy_coord, values2, m, n, x0=0.0, dx=1.0, y0=0.0, dy=1.0, power
     xs = (x0, x0 + dx * (n - 1), float(xy_coord[:, 0].min()), float(xy_coord[:, 0].max()))
     ys = (y0, y0 + dy * (m - 1), float(xy_coord[:, 1].min()), float(xy_coord[:, 1].max()))
     reach = float(np.hypot(max(xs) - min(xs), max(ys) - min(ys))) * 1.001 + 1.0
-    d_xy, d_uv = DeviceArray.from_host(xy32), DeviceArray.from_host(uv32)
+    d_xy, d_uv = DeviceArray.from_host(xy32, sync=False), DeviceArray.from_host(uv32, sync=False)
     out = DeviceArray((2, m, n), np.float32)
     _lib.check(
         lib.psh_idw_dev(d_xy.ptr, d_uv.ptr, L, m, n, x0, dx, y0, dy, k_eff, float(power),
                         float(dist_offset), reach, out.ptr),
         "psh_idw_dev",
     )
-    # the sample buffers must outlive the queued kernel
-    _lib.check(lib.psh_sync(), "psh_sync")
+    out._keep = (d_xy, d_uv)  # the sample buffers must outlive the queued kernel
     return out
 
 
