@@ -24,11 +24,23 @@
 
 #include "common.h"
 
+// The selection compares squared distances computed at several places of the kernel
+// for EXACT equality (k-th smallest distance vs the candidates in the second sweep):
+// every site must round identically, so implicit FMA contraction is off and the one
+// fused form is written out in dist2().
+#pragma clang fp contract(off)
+
 namespace psh {
 namespace {
 
-constexpr int kTile = 16;
-constexpr int kThreads = kTile * kTile;
+__device__ __forceinline__ float dist2(float ax, float ay, float bx, float by) {
+  const float dx = ax - bx, dy = ay - by;
+  return fmaf(dx, dx, dy * dy);
+}
+
+constexpr int kTile = 16;      // 16x16 pixels per workgroup (32x32 measured slower: the wider halo
+constexpr int kThreads = 256;  // adds ~35 % candidates per pixel, more than the pre-pass costs)
+constexpr int kRowsPerPass = kThreads / kTile;
 constexpr int kBins = 256;
 constexpr int kCandCap = 1024;  // candidates kept in LDS per tile (16 KiB)
 
@@ -146,8 +158,7 @@ __device__ __forceinline__ void idw_pixel_global(const float2 *__restrict__ xy,
   if (k >= L) {
     for (int i = 0; i < L; ++i) {
       const float2 p = xy[i], val = uv[i];
-      const float dx = p.x - px, dy = p.y - py;
-      const float w = idw_weight(sqrtf(dx * dx + dy * dy) * inv_res, power, offset);
+      const float w = idw_weight(sqrtf(dist2(p.x, p.y, px, py)) * inv_res, power, offset);
       sw += w;
       su += w * val.x;
       sv += w * val.y;
@@ -157,8 +168,7 @@ __device__ __forceinline__ void idw_pixel_global(const float2 *__restrict__ xy,
     top.init(k);
     for (int i = 0; i < L; ++i) {
       const float2 p = xy[i];
-      const float dx = p.x - px, dy = p.y - py;
-      top.offer(dx * dx + dy * dy, i);
+      top.offer(dist2(p.x, p.y, px, py), i);
     }
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
@@ -185,7 +195,6 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
                                                     int n_tiles, int tiles_per_xcd) {
   __shared__ int s_hist[kBins];
   __shared__ float4 s_cand[kCandCap];  // x, y, u, v
-  __shared__ int s_count;
   __shared__ float s_radius;
 
   const int b = blockIdx.x;
@@ -193,16 +202,11 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
   if (tile >= n_tiles) return;
   const int tx = (tile % tiles_x) * kTile, ty = (tile / tiles_x) * kTile;
   const int tid = threadIdx.x;
-  const int ix = tx + (tid % kTile), iy = ty + (tid / kTile);
-  const bool live = ix < n && iy < m;
-  const float px = x0 + dx_grid * static_cast<float>(min(ix, n - 1));
-  const float py = y0 + dy_grid * static_cast<float>(min(iy, m - 1));
   const size_t plane = static_cast<size_t>(m) * n;
+  __shared__ int s_wave_count[4];
 
-  float ou, ov;
-  if (k >= L) {  // no selection at all (uniform)
-    idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
-  } else {
+  int n_cand = 0;
+  if (k < L) {
     // ---- tile pre-pass: radius holding >= k vectors around the tile centre --------
     const int wx = min(kTile, n - tx), wy = min(kTile, m - ty);
     const float cx = x0 + dx_grid * (static_cast<float>(tx) + 0.5f * static_cast<float>(wx - 1));
@@ -213,7 +217,6 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
     const float bin_w = dmax / static_cast<float>(kBins);
 
     for (int i = tid; i < kBins; i += kThreads) s_hist[i] = 0;
-    if (tid == 0) s_count = 0;
     __syncthreads();
     for (int i = tid; i < L; i += kThreads) {
       const float2 p = xy[i];
@@ -249,31 +252,51 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
     }
     __syncthreads();
     const float reach = s_radius + 2.f * half_diag + 1e-3f * (s_radius + half_diag);
-    // ---- ordered compaction of the candidates (wave 0, 64 vectors per round) ------
-    if (tid < 64) {
-      int base = 0;
-      for (int i0 = 0; i0 < L; i0 += 64) {
-        const int i = i0 + tid;
-        bool keep = false;
+    // ---- ordered compaction of the candidates: each wave owns a contiguous quarter of
+    // the vectors, counts first, then writes behind the waves before it (index order is
+    // kept, so the summation order is deterministic)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int per_wave = (L + 3) / 4;
+    const int i_begin = wave * per_wave, i_end = min(L, i_begin + per_wave);
+    auto wanted = [&](int i, float2 &p) {
+      if (i >= i_end) return false;
+      p = xy[i];
+      const float ddx = p.x - cx, ddy = p.y - cy;
+      return sqrtf(ddx * ddx + ddy * ddy) <= reach;
+    };
+    int mine = 0;
+    for (int i0 = i_begin; i0 < i_end; i0 += 64) {
+      float2 p;
+      mine += __popcll(__ballot(wanted(i0 + lane, p)));
+    }
+    if (lane == 0) s_wave_count[wave] = mine;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_wave_count[w];
+    n_cand = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
+    if (n_cand <= kCandCap) {
+      for (int i0 = i_begin; i0 < i_end; i0 += 64) {
         float2 p = make_float2(0.f, 0.f);
-        if (i < L) {
-          p = xy[i];
-          const float ddx = p.x - cx, ddy = p.y - cy;
-          keep = sqrtf(ddx * ddx + ddy * ddy) <= reach;
-        }
+        const bool keep = wanted(i0 + lane, p);
         const unsigned long long mask = __ballot(keep);
-        const int pos = base + __popcll(mask & ((1ull << tid) - 1ull));
-        if (keep && pos < kCandCap) {
-          const float2 val = uv[i];
-          s_cand[pos] = make_float4(p.x, p.y, val.x, val.y);
+        if (keep) {
+          const float2 val = uv[i0 + lane];
+          s_cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_float4(p.x, p.y, val.x, val.y);
         }
         base += __popcll(mask);
       }
-      if (tid == 0) s_count = base;
     }
     __syncthreads();
-    const int n_cand = s_count;
-    if (n_cand > kCandCap) {  // pathological clustering: exact brute force
+  }
+
+  for (int q = 0; q < kTile / kRowsPerPass; ++q) {
+    const int ix = tx + (tid % kTile), iy = ty + (tid / kTile) + q * kRowsPerPass;
+    if (ix >= n || iy >= m) continue;
+    const float px = x0 + dx_grid * static_cast<float>(ix);
+    const float py = y0 + dy_grid * static_cast<float>(iy);
+    float ou, ov;
+    if (k >= L || n_cand > kCandCap) {
+      // no selection at all, or pathological clustering: exact brute force
       idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
     } else {
       KSmallest<KMAX> top;
@@ -285,15 +308,13 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
         top.d2[j] = -INFINITY;
         if (j < n_fill) {
           const float4 c = s_cand[j];  // same address in every lane: LDS broadcast
-          const float ddx = c.x - px, ddy = c.y - py;
-          top.d2[j] = ddx * ddx + ddy * ddy;
+          top.d2[j] = dist2(c.x, c.y, px, py);
         }
       }
       top.refresh();
       for (int i = n_fill; i < n_cand; ++i) {
         const float4 c = s_cand[i];
-        const float ddx = c.x - px, ddy = c.y - py;
-        top.offer(ddx * ddx + ddy * ddy);
+        top.offer(dist2(c.x, c.y, px, py));
       }
       // second sweep: everything strictly below the k-th smallest distance, plus as many
       // of the candidates AT that distance (in index order) as are needed to reach k
@@ -305,8 +326,7 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
       float sw = 0.f, su = 0.f, sv = 0.f;
       for (int i = 0; i < n_cand; ++i) {
         const float4 c = s_cand[i];
-        const float ddx = c.x - px, ddy = c.y - py;
-        const float d2 = ddx * ddx + ddy * ddy;
+        const float d2 = dist2(c.x, c.y, px, py);
         bool take = d2 < tau;
         if (d2 == tau && ties_wanted > 0) {
           take = true;
@@ -322,8 +342,6 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
       ou = su / sw;
       ov = sv / sw;
     }
-  }
-  if (live) {
     out[static_cast<size_t>(iy) * n + ix] = ou;
     out[plane + static_cast<size_t>(iy) * n + ix] = ov;
   }

@@ -83,7 +83,16 @@ __device__ __forceinline__ bool is_interior(int X, int Y, int m, int n) {
 
 struct Fields {
   const float *u0, *u1, *v0, *v1, *p0, *p1;  // row r and row r+1 bases of each plane
+  // buffer descriptors of the three planes for the fast path: addressing is then
+  // descriptor (SGPR) + one 32-bit lane offset + immediate (+1 column) + scalar
+  // offset (+1 row) - no per-load 64-bit VALU address arithmetic
+  __amdgpu_buffer_rsrc_t ru, rv, rp;
+  int row_bytes;
 };
+
+__device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, static_cast<int>(byte_off), soff, 0));
+}
 
 // lane i receives the value of lane i+1 (v_mov_b32_dpp wave_shl:1); lane 63, which
 // has no right neighbour, keeps `fill`
@@ -112,30 +121,31 @@ __device__ __forceinline__ void sample_interior(const Fields &F, const int (&X)[
   bool shared[NPX];
   float a[NPX], c[NPX], e[NPX], g[NPX], pa[NPX], pc[NPX];
   float b[NPX], d[NPX], f[NPX], h[NPX], pb[NPX], pd[NPX];
+  const int rb = F.row_bytes;
 #pragma unroll
   for (int j = 0; j < NPX; ++j) {
     off[j] = static_cast<unsigned>(__mul24(Y[j], n) + X[j]) << 2;
     shared[j] = from_next_lane(X[j], -2) == X[j] + 1 && from_next_lane(Y[j], -2) == Y[j];
     b[j] = d[j] = f[j] = h[j] = pb[j] = pd[j] = 0.f;
     if (!shared[j]) {
-      b[j] = ld(F.u0, off[j], 1);
-      d[j] = ld(F.u1, off[j], 1);
-      f[j] = ld(F.v0, off[j], 1);
-      h[j] = ld(F.v1, off[j], 1);
+      b[j] = bld(F.ru, off[j] + 4u, 0);
+      d[j] = bld(F.ru, off[j] + 4u, rb);
+      f[j] = bld(F.rv, off[j] + 4u, 0);
+      h[j] = bld(F.rv, off[j] + 4u, rb);
       if (WITH_P) {
-        pb[j] = ld(F.p0, off[j], 1);
-        pd[j] = ld(F.p1, off[j], 1);
+        pb[j] = bld(F.rp, off[j] + 4u, 0);
+        pd[j] = bld(F.rp, off[j] + 4u, rb);
       }
     }
   }
 #pragma unroll
   for (int j = 0; j < NPX; ++j) {
-    a[j] = ld(F.u0, off[j]);
-    c[j] = ld(F.u1, off[j]);
-    e[j] = ld(F.v0, off[j]);
-    g[j] = ld(F.v1, off[j]);
-    pa[j] = WITH_P ? ld(F.p0, off[j]) : 0.f;
-    pc[j] = WITH_P ? ld(F.p1, off[j]) : 0.f;
+    a[j] = bld(F.ru, off[j], 0);
+    c[j] = bld(F.ru, off[j], rb);
+    e[j] = bld(F.rv, off[j], 0);
+    g[j] = bld(F.rv, off[j], rb);
+    pa[j] = WITH_P ? bld(F.rp, off[j], 0) : 0.f;
+    pc[j] = WITH_P ? bld(F.rp, off[j], rb) : 0.f;
   }
 #pragma unroll
   for (int j = 0; j < NPX; ++j) {
@@ -384,6 +394,12 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
   F.v1 = vel + plane + n;
   F.p0 = precip;
   F.p1 = HAS_PRECIP ? precip + n : nullptr;
+  const int plane_bytes = static_cast<int>(plane * sizeof(float));
+  F.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel), 0, plane_bytes, 0x00020000);
+  F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
+  F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_PRECIP ? precip : vel), 0, plane_bytes,
+                                           0x00020000);
+  F.row_bytes = n * static_cast<int>(sizeof(float));
 
   __shared__ float stage_buf[LDS ? 3 * kStageCap : 1];
   __shared__ int stage_red[16];
