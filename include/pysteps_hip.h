@@ -95,6 +95,23 @@ int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
                      const double *steps, int T, int n_iter, int interp_order, float outval,
                      const double *disp_prev, double *disp_out, float *out);
 
+/* Member-batched, stateful step for ensemble nowcasts: the worker of the generic nowcast
+ * loop, pysteps/nowcasts/utils.py:441-462, for ALL members in one launch:
+ *     velocity_j = V + par_j * V_par + perp_j * V_perp            (utils.py:448-451 with the BPS
+ *                  perturbation of pysteps/noise/motion.py:146-180; V_par = V/|V|,
+ *                  V_perp = (-V_par_y, V_par_x); par_j = g_par(t) eps_par_j / vsf, perp_j likewise)
+ *     precip_j, D_j = extrapolate(precip_j, velocity_j, steps, displacement_prev=D_j)  (:453-458)
+ *  precip (B,m,n) f32 or NULL; velocity (2,m,n); vhat = V_par (2,m,n) from
+ *  psh_velocity_unit_dev, or NULL for "no perturbation"; pert_par/pert_perp: B doubles in HOST
+ *  memory; disp (B,2,m,n) f64 in/out, stays resident between calls (resume=0: start from zero
+ *  displacement); out (B,T,m,n) f32. */
+int psh_velocity_unit_dev(const float *velocity_dev, int m, int n, float *vhat_dev);
+int psh_semilag_members_dev(const float *precip_dev, const float *velocity_dev,
+                            const float *vhat_dev, const double *pert_par_host,
+                            const double *pert_perp_host, int n_members, int m, int n,
+                            const double *steps_host, int T, int n_iter, int interp_order,
+                            float outval, double *disp_dev, int resume, float *out_dev);
+
 /* ---- sparse vectors -> dense field: k-NN inverse distance weighting ------ *
  * Replaces pysteps/utils/interpolate.py:26-114 (idwinterp2d) as called from
  * pysteps/motion/lucaskanade.py:272-274, including the cKDTree k-NN query it

@@ -1,0 +1,279 @@
+// Member-batched, stateful semi-Lagrangian step for ensemble nowcasts (gfx950).
+//
+// Serves the calling convention of the generic nowcast loop,
+// pysteps/nowcasts/utils.py:441-462 (worker1): for every ensemble member j
+//     velocity_j = velocity + velocity_pert_gen[j](t)                     (:448-451)
+//     precip_j, D_j = extrapolator(precip_j, velocity_j, [dt], displacement_prev=D_j,
+//                                  return_displacement=True)               (:453-458)
+// in ONE launch for all members, with every D_j resident in HBM between calls.
+// The BPS motion perturbation (pysteps/noise/motion.py:146-180, generate_bps) is
+//     velocity_j = V + a_j * V_par + b_j * V_perp,   V_par = V/|V|, V_perp = (-V_par_y, V_par_x)
+// with two scalars per member (a_j = g_par(t) eps_par_j / vsf, b_j likewise), so the 48
+// perturbed velocity fields are never materialised: the kernel samples V and the
+// unit field V_par at the same taps (bilinear interpolation is linear) and combines
+// them with the member's scalars held in SGPRs.
+//
+// One thread = one pixel of one member (grid.y = member); same trajectory
+// arithmetic and resampling rules as semilag.hip (shared header), direct gathers
+// through buffer descriptors; roofline = HBM, 48 B/pixel/step algorithmic at
+// n_iter=1 (D read+write 32, precip in/out 8, velocity passes amortised by L2).
+#include <vector>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+#include "semilag_device.h"
+
+namespace psh {
+namespace {
+
+using namespace sl;
+
+struct Planes {
+  __amdgpu_buffer_rsrc_t u, v, hu, hv, p;  // velocity, unit velocity, this member's precip
+  const float *pu, *pv, *phu, *phv, *pp;   // the same as raw pointers (border path)
+  int row_bytes;
+};
+
+__device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, static_cast<int>(byte_off), soff, 0));
+}
+
+__device__ __forceinline__ float tap4(__amdgpu_buffer_rsrc_t r, unsigned off, int rb, const Weights &w) {
+  return blend(w, bld(r, off, 0), bld(r, off + 4u, 0), bld(r, off, rb), bld(r, off + 4u, rb));
+}
+
+__device__ __forceinline__ float tap4_clamped(const float *p, int X, int Y, const Weights &w, int m, int n) {
+  const int x0 = min(max(X, 0), n - 1), x1 = min(max(X + 1, 0), n - 1);
+  const int y0 = min(max(Y, 0), m - 1), y1 = min(max(Y + 1, 0), m - 1);
+  const unsigned r0 = static_cast<unsigned>(__mul24(y0, n)), r1 = static_cast<unsigned>(__mul24(y1, n));
+  return blend(w, ld(p, (r0 + x0) << 2), ld(p, (r0 + x1) << 2), ld(p, (r1 + x0) << 2), ld(p, (r1 + x1) << 2));
+}
+
+// velocity of this member at (X + fx, Y + fy), mode="nearest"; optionally the precip sample too
+template <int ORDER, bool PERT, bool WITH_P>
+__device__ __forceinline__ void sample_member(const Planes &F, int X, int Y, float fx, float fy, int m,
+                                              int n, float a, float b, float outval, float &su,
+                                              float &sv, float &sp) {
+  const Weights w = make_weights(fx, fy);
+  float hu = 0.f, hv = 0.f;
+  if (__all(is_interior(X, Y, m, n))) {
+    const unsigned off = static_cast<unsigned>(__mul24(Y, n) + X) << 2;
+    su = tap4(F.u, off, F.row_bytes, w);
+    sv = tap4(F.v, off, F.row_bytes, w);
+    if (PERT) {
+      hu = tap4(F.hu, off, F.row_bytes, w);
+      hv = tap4(F.hv, off, F.row_bytes, w);
+    }
+    if (WITH_P) {
+      if (ORDER == 1) {
+        sp = tap4(F.p, off, F.row_bytes, w);
+      } else {
+        const int xi = X + (fx >= 0.5f ? 1 : 0), yi = Y + (fy >= 0.5f ? 1 : 0);
+        sp = bld(F.p, static_cast<unsigned>(__mul24(yi, n) + xi) << 2, 0);
+      }
+    }
+    asm volatile("" ::: "memory");  // keep the two paths from being merged (see semilag.hip)
+  } else {
+    su = tap4_clamped(F.pu, X, Y, w, m, n);
+    sv = tap4_clamped(F.pv, X, Y, w, m, n);
+    if (PERT) {
+      hu = tap4_clamped(F.phu, X, Y, w, m, n);
+      hv = tap4_clamped(F.phv, X, Y, w, m, n);
+    }
+    if (WITH_P) sp = sample_precip_border<ORDER>(F.pp, X, Y, fx, fy, m, n, outval);
+  }
+  if (PERT) {
+    // V + a * V_par + b * V_perp with V_perp = (-V_par_y, V_par_x)
+    su = su + (a * hu - b * hv);
+    sv = sv + (a * hv + b * hu);
+  }
+}
+
+template <int ORDER, bool PERT, bool HAS_PRECIP>
+__global__ __launch_bounds__(256) void semilag_members(
+    const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vhat,
+    const float *__restrict__ pert_ab, float *__restrict__ out, double *__restrict__ disp,
+    const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume,
+    float outval, int tiles_x, int n_tiles, int tiles_per_xcd) {
+  const int blk = blockIdx.x;
+  const int tile = (blk % kNumXcd) * tiles_per_xcd + blk / kNumXcd;  // XCD-contiguous bands
+  if (tile >= n_tiles) return;
+  const int member = blockIdx.y;
+  const int x = (tile % tiles_x) * 64 + (threadIdx.x & 63);
+  const int y = (tile / tiles_x) * 4 + (threadIdx.x >> 6);
+  const bool live = x < n && y < m;
+  const int xc = min(x, n - 1), yc = min(y, m - 1);
+  const size_t plane = static_cast<size_t>(m) * n;
+  const int plane_bytes = static_cast<int>(plane * sizeof(float));
+
+  Planes F;
+  F.pu = vel;
+  F.pv = vel + plane;
+  F.phu = PERT ? vhat : vel;
+  F.phv = PERT ? vhat + plane : vel;
+  F.pp = HAS_PRECIP ? precip + static_cast<size_t>(member) * plane : vel;
+  F.u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F.pu), 0, plane_bytes, 0x00020000);
+  F.v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F.pv), 0, plane_bytes, 0x00020000);
+  F.hu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F.phu), 0, plane_bytes, 0x00020000);
+  F.hv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F.phv), 0, plane_bytes, 0x00020000);
+  F.p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F.pp), 0, plane_bytes, 0x00020000);
+  F.row_bytes = n * static_cast<int>(sizeof(float));
+  const float a = PERT ? pert_ab[2 * member] : 0.f, b = PERT ? pert_ab[2 * member + 1] : 0.f;
+
+  double *dplane = disp + static_cast<size_t>(member) * 2 * plane;
+  const size_t pix = static_cast<size_t>(yc) * n + xc;
+  int px = xc, py = yc;
+  float fx = 0.f, fy = 0.f, vix, viy, su, sv, sp = 0.f;
+  if (resume) {
+    const double dx = dplane[pix], dy = dplane[plane + pix];
+    const double flx = floor(dx), fly = floor(dy);
+    px += static_cast<int>(flx);
+    py += static_cast<int>(fly);
+    fx = fminf(static_cast<float>(dx - flx), kMaxFrac);
+    fy = fminf(static_cast<float>(dy - fly), kMaxFrac);
+    sample_member<ORDER, PERT, false>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+    vix = su * scale[0];
+    viy = sv * scale[0];
+  } else {
+    sample_member<ORDER, PERT, false>(F, px, py, 0.f, 0.f, m, n, a, b, outval, su, sv, sp);
+    vix = su * first_scale;  // the very first increment is not divided by n_iter (:202)
+    viy = sv * first_scale;
+  }
+  float *optr = out + (static_cast<size_t>(member) * T) * plane + pix;
+  for (int t = 0; t < T; ++t) {
+    const float s = scale[t];
+    if (n_iter > 0) {
+      for (int k = 0; k < n_iter; ++k) {
+        int mx = px, my = py;
+        float gx = fx, gy = fy;
+        retreat(mx, gx, 0.5f * vix);
+        retreat(my, gy, 0.5f * viy);
+        sample_member<ORDER, PERT, false>(F, mx, my, gx, gy, m, n, a, b, outval, su, sv, sp);
+        retreat(px, fx, su * s);
+        retreat(py, fy, sv * s);
+        if (HAS_PRECIP && k == n_iter - 1) {
+          sample_member<ORDER, PERT, true>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+        } else {
+          sample_member<ORDER, PERT, false>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+        }
+        vix = su * s;
+        viy = sv * s;
+      }
+    } else {
+      if (t > 0 || resume) {
+        sample_member<ORDER, PERT, false>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+        vix = su * s;
+        viy = sv * s;
+      }
+      retreat(px, fx, vix);
+      retreat(py, fy, viy);
+      if (HAS_PRECIP) {
+        float du, dv;
+        sample_member<ORDER, false, true>(F, px, py, fx, fy, m, n, 0.f, 0.f, outval, du, dv, sp);
+      }
+    }
+    if (HAS_PRECIP) {
+      if (live) *optr = sp;
+      optr += plane;
+    }
+  }
+  if (live) {
+    dplane[pix] = static_cast<double>(px - xc) + static_cast<double>(fx);
+    dplane[plane + pix] = static_cast<double>(py - yc) + static_cast<double>(fy);
+  }
+}
+
+// V / |V| with zeros where |V| <= 1e-12 (noise/motion.py:127-131)
+__global__ __launch_bounds__(256) void velocity_unit(const float *__restrict__ vel, size_t plane,
+                                                     float *__restrict__ vhat) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < plane; i += stride) {
+    const float u = vel[i], v = vel[plane + i];
+    const float nrm = sqrtf(u * u + v * v);
+    const bool ok = nrm > 1e-12f;
+    vhat[i] = ok ? u / nrm : 0.f;
+    vhat[plane + i] = ok ? v / nrm : 0.f;
+  }
+}
+
+}  // namespace
+}  // namespace psh
+
+extern "C" int psh_velocity_unit_dev(const float *velocity_dev, int m, int n, float *vhat_dev) {
+  PSH_REQUIRE_INIT();
+  if (m <= 0 || n <= 0 || !velocity_dev || !vhat_dev)
+    return psh::fail(PSH_EINVAL, "velocity_unit: invalid argument");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t plane = static_cast<size_t>(m) * n;
+  hipLaunchKernelGGL(psh::velocity_unit, dim3(2048), dim3(256), 0, c.stream, velocity_dev, plane, vhat_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+extern "C" int psh_semilag_members_dev(const float *precip_dev, const float *velocity_dev,
+                                       const float *vhat_dev, const double *pert_par_host,
+                                       const double *pert_perp_host, int n_members, int m, int n,
+                                       const double *steps_host, int T, int n_iter, int interp_order,
+                                       float outval, double *disp_dev, int resume, float *out_dev) {
+  PSH_REQUIRE_INIT();
+  if (n_members <= 0 || n_members > 65535)
+    return psh::fail(PSH_EINVAL, "semilag_members: member count %d out of range", n_members);
+  if (m <= 0 || n <= 0 || static_cast<uint64_t>(m) * n >= (1ull << 29))
+    return psh::fail(PSH_EINVAL, "semilag_members: invalid shape (%d,%d)", m, n);
+  if (T <= 0 || T > 1024) return psh::fail(PSH_EINVAL, "semilag_members: T must be in 1..1024");
+  if (n_iter < 0) return psh::fail(PSH_EINVAL, "semilag_members: n_iter must be >= 0");
+  if (interp_order != 0 && interp_order != 1)
+    return psh::fail(PSH_EUNSUPPORTED, "semilag_members: interp_order %d not implemented", interp_order);
+  if (!velocity_dev || !steps_host || !disp_dev)
+    return psh::fail(PSH_EINVAL, "semilag_members: NULL velocity/steps/displacement");
+  if (precip_dev && !out_dev) return psh::fail(PSH_EINVAL, "semilag_members: precip given but out is NULL");
+  const bool pert = vhat_dev != nullptr;
+  if (pert && (!pert_par_host || !pert_perp_host))
+    return psh::fail(PSH_EINVAL, "semilag_members: unit velocity given without member scalars");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  // per-call constants: T scale factors + 2 scalars per member, staged through pinned memory
+  const size_t n_const = static_cast<size_t>(T) + 2 * static_cast<size_t>(n_members);
+  void *blk = nullptr;
+  if (int rc = psh_malloc(&blk, n_const * sizeof(float))) return rc;
+  std::vector<float> h(n_const);
+  const double sub = n_iter > 1 ? static_cast<double>(n_iter) : 1.0;
+  for (int t = 0; t < T; ++t) h[t] = static_cast<float>(steps_host[t] / sub);
+  for (int j = 0; j < n_members; ++j) {
+    h[T + 2 * j] = pert ? static_cast<float>(pert_par_host[j]) : 0.f;
+    h[T + 2 * j + 1] = pert ? static_cast<float>(pert_perp_host[j]) : 0.f;
+  }
+  float *d_const = static_cast<float *>(blk);
+  hipError_t e = hipMemcpyAsync(d_const, h.data(), n_const * sizeof(float), hipMemcpyHostToDevice, c.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c.stream);  // h is a stack-lifetime staging buffer
+  if (e != hipSuccess) {
+    (void)psh_free(blk);
+    return psh::fail(PSH_EHIP, "semilag_members: constant upload failed: %s", hipGetErrorString(e));
+  }
+  const int tiles_x = (n + 63) / 64, tiles_y = (m + 3) / 4;
+  const int n_tiles = tiles_x * tiles_y;
+  const int tiles_per_xcd = (n_tiles + psh::kNumXcd - 1) / psh::kNumXcd;
+  const dim3 grid(tiles_per_xcd * psh::kNumXcd, n_members), block(256);
+  const float first_scale = static_cast<float>(steps_host[0]);
+#define PSH_MEMBERS(ORDER, PERT, HASP)                                                             \
+  hipLaunchKernelGGL((psh::semilag_members<ORDER, PERT, HASP>), grid, block, 0, c.stream, precip_dev, \
+                     velocity_dev, vhat_dev, d_const + T, out_dev, disp_dev, d_const, first_scale, m, \
+                     n, T, n_iter, resume, outval, tiles_x, n_tiles, tiles_per_xcd)
+  if (!precip_dev) {
+    if (pert) PSH_MEMBERS(1, true, false); else PSH_MEMBERS(1, false, false);
+  } else if (interp_order == 0) {
+    if (pert) PSH_MEMBERS(0, true, true); else PSH_MEMBERS(0, false, true);
+  } else {
+    if (pert) PSH_MEMBERS(1, true, true); else PSH_MEMBERS(1, false, true);
+  }
+#undef PSH_MEMBERS
+  e = hipGetLastError();
+  (void)psh_free(blk);  // stream-ordered: the kernel above is queued before any reuse
+  if (e != hipSuccess) return psh::fail(PSH_EHIP, "semilag_members launch failed: %s", hipGetErrorString(e));
+  return PSH_OK;
+}

@@ -1,0 +1,91 @@
+"""Device-resident ensemble advection (member-batched semi-Lagrangian steps).
+
+The generic nowcast loop of the reference advects every ensemble member once per
+time step with its own (optionally perturbed) velocity and threads the
+displacement through as state (pysteps/nowcasts/utils.py:441-462).
+:class:`EnsembleAdvector` does that for all members in one kernel launch
+(``psh_semilag_members_dev``): the displacements of all members stay in HBM, the
+BPS velocity perturbation (pysteps/noise/motion.py:146-180) is applied in-kernel
+from two scalars per member.
+"""
+
+import numpy as np
+
+from .. import _lib
+from ..device import DeviceArray
+
+__all__ = ["EnsembleAdvector", "bps_scalars"]
+
+
+def bps_scalars(perturbators, t):
+    """Per-member scalars of ``generate_bps(perturbator, t)`` (noise/motion.py:146-180):
+    the perturbation field is ``par * V_par + perp * V_perp``."""
+    par, perp = [], []
+    for p in perturbators:
+        g_par = p["p_par"][0] * pow(t, p["p_par"][1]) + p["p_par"][2]
+        g_perp = p["p_perp"][0] * pow(t, p["p_perp"][1]) + p["p_perp"][2]
+        par.append(g_par * p["eps_par"] / p["vsf"])
+        perp.append(g_perp * p["eps_perp"] / p["vsf"])
+    return np.asarray(par, dtype=np.float64), np.asarray(perp, dtype=np.float64)
+
+
+class EnsembleAdvector:
+    """Stateful advection of ``n_members`` fields with a common motion field.
+
+    ``perturbators``: optional list (one per member) of dicts with the scalar entries
+    of ``pysteps.noise.motion.initialize_bps`` (``eps_par``, ``eps_perp``, ``p_par``,
+    ``p_perp``, ``vsf``); the unit fields ``V_par``/``V_perp`` are rebuilt on the device.
+    """
+
+    def __init__(self, velocity, n_members, perturbators=None, n_iter=1, interp_order=1, outval=np.nan):
+        self._lib = _lib.lib()
+        self.velocity = velocity if isinstance(velocity, DeviceArray) else DeviceArray.from_host(velocity, np.float32)
+        if self.velocity.ndim != 3 or self.velocity.shape[0] != 2 or self.velocity.dtype != np.float32:
+            raise ValueError("velocity must be a (2,m,n) float32 field")
+        self.n_members = int(n_members)
+        self.m, self.n = self.velocity.shape[1:]
+        if perturbators is not None and len(perturbators) != self.n_members:
+            raise ValueError("one perturbator per member is required")
+        self.perturbators = perturbators
+        self.n_iter, self.interp_order, self.outval = int(n_iter), int(interp_order), float(outval)
+        self.displacement = DeviceArray((self.n_members, 2, self.m, self.n), np.float64)
+        self._started = False
+        self.vhat = None
+        if perturbators is not None:
+            self.vhat = DeviceArray((2, self.m, self.n), np.float32)
+            _lib.check(self._lib.psh_velocity_unit_dev(self.velocity.ptr, self.m, self.n, self.vhat.ptr),
+                       "psh_velocity_unit_dev")
+
+    def step(self, precip_members, t_diff, t_total=None):
+        """Advect all members by ``t_diff`` (velocity time steps); ``t_total`` is the lead time
+        handed to the perturbators (minutes, as in the reference).  ``precip_members``:
+        (B,m,n) ndarray or float32 DeviceArray, or None for displacement only.
+        Returns the advected members (B,m,n) in the container type of the input."""
+        on_device = isinstance(precip_members, DeviceArray)
+        pm = None
+        if precip_members is not None:
+            pm = precip_members if on_device else DeviceArray.from_host(precip_members, np.float32)
+            if pm.shape != (self.n_members, self.m, self.n) or pm.dtype != np.float32:
+                raise ValueError("precip_members must have shape (n_members, m, n)")
+        steps = np.atleast_1d(np.asarray(t_diff, dtype=np.float64))
+        par = perp = None
+        if self.perturbators is not None:
+            if t_total is None:
+                raise ValueError("t_total is required with velocity perturbations")
+            par, perp = bps_scalars(self.perturbators, t_total)
+        out = None if pm is None else DeviceArray((self.n_members, steps.size, self.m, self.n), np.float32)
+        rc = self._lib.psh_semilag_members_dev(
+            None if pm is None else pm.ptr, self.velocity.ptr,
+            None if self.vhat is None else self.vhat.ptr,
+            None if par is None else par.ctypes.data, None if perp is None else perp.ctypes.data,
+            self.n_members, self.m, self.n, steps.ctypes.data, int(steps.size), self.n_iter,
+            self.interp_order, self.outval, self.displacement.ptr, int(self._started),
+            None if out is None else out.ptr,
+        )
+        _lib.check(rc, "psh_semilag_members_dev")
+        self._started = True
+        if out is None:
+            return None
+        if steps.size == 1:
+            out = DeviceArray((self.n_members, self.m, self.n), np.float32, ptr=out.ptr, owner=out)
+        return out if on_device else out.to_host()
