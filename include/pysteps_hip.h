@@ -167,6 +167,21 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
                      int n, const float *points_host, int npts, int win_w, int win_h,
                      int max_level, int max_count, double epsilon, double min_eig_threshold,
                      float *next_points_host, unsigned char *status_host);
+/* The same two operations in halves, so that independent device work overlaps the host's
+ * ordered pass over the corner candidates: corners_launch queues the kernels and the copy of
+ * the candidates, pyramids builds the Gaussian pyramids + Scharr gradients of a frame pair
+ * (opaque handle, release with psh_lk_pyramids_free), corners_finish waits only for the
+ * candidates, track_pyr tracks points through a prebuilt pyramid set. */
+int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
+                              float *stats_dev, int m, int n, int block_size, int buffer_mask,
+                              double quality_level, double min_distance, int max_corners);
+int psh_lk_corners_finish(float *points_host, int *count_host);
+int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m,
+                        int n, int win_w, int win_h, int max_level, void **handle_out);
+int psh_lk_pyramids_free(void *handle);
+int psh_lk_track_pyr_dev(void *handle, const float *points_host, int npts, int max_count,
+                         double epsilon, double min_eig_threshold, float *next_points_host,
+                         unsigned char *status_host);
 
 /* ---- sparse vector QC: local Mahalanobis outlier test ----------------------- *
  * The form of pysteps/utils/cleansing.py:124-249 (detect_outliers) used by dense LK

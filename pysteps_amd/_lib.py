@@ -62,6 +62,11 @@ SIGNATURES = {
     "psh_decluster_host": (c_int, [c_void_p, c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, POINTER(c_int)]),
     "psh_velocity_unit_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "psh_semilag_members_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
+    "psh_lk_corners_launch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_int]),
+    "psh_lk_corners_finish": (c_int, [c_void_p, POINTER(c_int)]),
+    "psh_lk_pyramids_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "psh_lk_pyramids_free": (c_int, [c_void_p]),
+    "psh_lk_track_pyr_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
     "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
 }

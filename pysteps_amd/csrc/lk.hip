@@ -734,20 +734,38 @@ int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, i
   return PSH_OK;
 }
 
-int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
-                       float *stats_dev, int m, int n, int block_size, int buffer_mask,
-                       double quality_level, double min_distance, int max_corners,
-                       float *points_host, int *count_host) {
+namespace {
+// state of the corner request in flight (launch -> finish), guarded by the context mutex
+struct CornerJob {
+  bool active = false;
+  int m = 0, n = 0, cap = 0, max_corners = 0;
+  double min_distance = 0.0;
+  psh::Corner *cand_dev = nullptr;
+  hipEvent_t ready = nullptr;
+  void *pinned = nullptr;  // [int count | pad | first kFirstChunk candidates]
+};
+constexpr int kFirstChunk = 65536;
+constexpr size_t kPinnedHeader = 64;
+CornerJob g_corner_job;
+}  // namespace
+
+int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
+                              float *stats_dev, int m, int n, int block_size, int buffer_mask,
+                              double quality_level, double min_distance, int max_corners) {
   PSH_REQUIRE_INIT();
   if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_corners: invalid shape (%d,%d)", m, n);
-  if (!feature_u8_dev || !clean_dev || !stats_dev || !points_host || !count_host)
-    return fail(PSH_EINVAL, "lk_corners: NULL pointer");
+  if (!feature_u8_dev || !clean_dev || !stats_dev) return fail(PSH_EINVAL, "lk_corners: NULL pointer");
   if (block_size < 1 || block_size > 2 * psh::kMaxBlockR + 1 || (block_size & 1) == 0)
     return fail(PSH_EUNSUPPORTED, "lk_corners: block_size %d not implemented (odd, <= 7)", block_size);
   if (max_corners <= 0) return fail(PSH_EINVAL, "lk_corners: max_corners must be positive");
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
+  CornerJob &job = g_corner_job;
+  if (job.active) return fail(PSH_EINVAL, "lk_corners: a corner request is already in flight");
+  if (!job.ready) PSH_HIP(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
+  if (!job.pinned)
+    PSH_HIP(hipHostMalloc(&job.pinned, kPinnedHeader + kFirstChunk * sizeof(psh::Corner), hipHostMallocDefault));
   const size_t npx = static_cast<size_t>(m) * n;
   const dim3 rgrid((n + psh::kCrnTX - 1) / psh::kCrnTX, (m + psh::kCrnTY - 1) / psh::kCrnTY);
   const int nb = rgrid.x * rgrid.y;
@@ -771,14 +789,46 @@ int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_d
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n,
                      buffer_mask, static_cast<float>(quality_level), stats_dev, cand, cap, cnt);
   PSH_HIP(hipGetLastError());
-  int count = 0;
-  PSH_HIP(hipMemcpyAsync(&count, cnt, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-  PSH_HIP(hipStreamSynchronize(c.stream));
+  // the count and the first chunk of candidates go to pinned memory right behind the
+  // kernel, so that work queued afterwards (pyramids) does not delay the host's pass
+  char *pin = static_cast<char *>(job.pinned);
+  PSH_HIP(hipMemcpyAsync(pin, cnt, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  const size_t first = std::min<size_t>(static_cast<size_t>(cap), kFirstChunk);
+  PSH_HIP(hipMemcpyAsync(pin + kPinnedHeader, cand, first * sizeof(psh::Corner), hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipEventRecord(job.ready, c.stream));
+  job.active = true;
+  job.m = m;
+  job.n = n;
+  job.cap = cap;
+  job.max_corners = max_corners;
+  job.min_distance = min_distance;
+  job.cand_dev = cand;
+  return PSH_OK;
+}
+
+int psh_lk_corners_finish(float *points_host, int *count_host) {
+  PSH_REQUIRE_INIT();
+  if (!points_host || !count_host) return fail(PSH_EINVAL, "lk_corners: NULL pointer");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  CornerJob &job = g_corner_job;
+  if (!job.active) return fail(PSH_EINVAL, "lk_corners: no corner request in flight");
+  job.active = false;
+  PSH_HIP(hipEventSynchronize(job.ready));
+  const int m = job.m, n = job.n, cap = job.cap, max_corners = job.max_corners;
+  const double min_distance = job.min_distance;
+  (void)m;
+  const char *pin = static_cast<const char *>(job.pinned);
+  const int count = *reinterpret_cast<const int *>(pin);
   if (count > cap)
     return fail(PSH_EUNSUPPORTED, "lk_corners: %d corner candidates exceed the buffer of %d", count, cap);
   std::vector<psh::Corner> h(static_cast<size_t>(count));
-  if (count > 0) {
-    PSH_HIP(hipMemcpyAsync(h.data(), cand, h.size() * sizeof(psh::Corner), hipMemcpyDeviceToHost, c.stream));
+  const size_t first = std::min<size_t>(h.size(), kFirstChunk);
+  if (first) std::memcpy(h.data(), pin + kPinnedHeader, first * sizeof(psh::Corner));
+  if (h.size() > first) {  // rare: more candidates than the first chunk holds
+    PSH_HIP(hipMemcpyAsync(h.data() + first, job.cand_dev + first, (h.size() - first) * sizeof(psh::Corner),
+                           hipMemcpyDeviceToHost, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));
   }
   // goodFeaturesToTrack: strongest first (ties: higher address first), then greedy
@@ -837,21 +887,38 @@ int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_d
   return PSH_OK;
 }
 
-int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m,
-                     int n, const float *points_host, int npts, int win_w, int win_h,
-                     int max_level, int max_count, double epsilon, double min_eig_threshold,
-                     float *next_points_host, unsigned char *status_host) {
+int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
+                       float *stats_dev, int m, int n, int block_size, int buffer_mask,
+                       double quality_level, double min_distance, int max_corners,
+                       float *points_host, int *count_host) {
+  if (!points_host || !count_host) return fail(PSH_EINVAL, "lk_corners: NULL pointer");
+  if (int rc = psh_lk_corners_launch_dev(feature_u8_dev, clean_dev, stats_dev, m, n, block_size,
+                                         buffer_mask, quality_level, min_distance, max_corners))
+    return rc;
+  return psh_lk_corners_finish(points_host, count_host);
+}
+
+namespace {
+// Gaussian pyramids + Scharr gradients of one frame pair, in a block of its own so that they
+// can be built while the host is still ordering the corner candidates
+struct PyramidSet {
+  psh::Pyramid pyr;
+  void *block = nullptr;
+  int win_w = 0, win_h = 0;
+};
+}  // namespace
+
+int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m,
+                        int n, int win_w, int win_h, int max_level, void **handle_out) {
   PSH_REQUIRE_INIT();
-  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_track: invalid shape (%d,%d)", m, n);
-  if (npts < 0) return fail(PSH_EINVAL, "lk_track: negative point count");
-  if (npts == 0) return PSH_OK;
-  if (!prev_u8_dev || !next_u8_dev || !points_host || !next_points_host || !status_host)
-    return fail(PSH_EINVAL, "lk_track: NULL pointer");
+  if (!handle_out) return fail(PSH_EINVAL, "lk_pyramids: NULL handle pointer");
+  *handle_out = nullptr;
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_pyramids: invalid shape (%d,%d)", m, n);
+  if (!prev_u8_dev || !next_u8_dev) return fail(PSH_EINVAL, "lk_pyramids: NULL pointer");
   if (win_w <= 2 || win_h <= 2 || win_w > psh::kMaxWin || win_h > psh::kMaxWin)
     return fail(PSH_EUNSUPPORTED, "lk_track: window (%d,%d) not implemented (3..%d)", win_w, win_h, psh::kMaxWin);
-  if (max_level < 0) return fail(PSH_EINVAL, "lk_track: max_level must be >= 0");
+  if (max_level < 0) return fail(PSH_EINVAL, "lk_pyramids: max_level must be >= 0");
   if (max_level >= psh::kMaxLevels) max_level = psh::kMaxLevels - 1;
-  max_count = std::min(std::max(max_count, 0), 100);  // calcOpticalFlowPyrLK clamps the criteria
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
@@ -879,47 +946,102 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
     off_j[l] = l ? take(px) : 0;
     off_d[l] = take(px * sizeof(short2));
   }
-  const size_t off_pts = take(static_cast<size_t>(npts) * sizeof(float2));
-  const size_t off_next = take(static_cast<size_t>(npts) * sizeof(float2));
-  const size_t off_st = take(static_cast<size_t>(npts));
-  void *ws = nullptr;
-  if (int rc = psh::ensure_lk_ws(bytes, &ws)) return rc;
-  char *base = static_cast<char *>(ws);
-  psh::Pyramid pyr;
-  pyr.top = top;
+  PyramidSet *ps = new PyramidSet();
+  if (int rc = psh_malloc(&ps->block, bytes)) {
+    delete ps;
+    return rc;
+  }
+  char *base = static_cast<char *>(ps->block);
+  ps->pyr.top = top;
+  ps->win_w = win_w;
+  ps->win_h = win_h;
   for (int l = 0; l <= top; ++l) {
     unsigned char *Il = l ? reinterpret_cast<unsigned char *>(base + off_i[l]) : const_cast<unsigned char *>(prev_u8_dev);
     unsigned char *Jl = l ? reinterpret_cast<unsigned char *>(base + off_j[l]) : const_cast<unsigned char *>(next_u8_dev);
     short2 *dl = reinterpret_cast<short2 *>(base + off_d[l]);
     if (l) {
       const dim3 g((cols[l] + 31) / 32, (rows[l] + 7) / 8);
-      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, pyr.lv[l - 1].I, rows[l - 1],
+      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, ps->pyr.lv[l - 1].I, rows[l - 1],
                          cols[l - 1], Il, rows[l], cols[l]);
-      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, pyr.lv[l - 1].J, rows[l - 1],
+      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, ps->pyr.lv[l - 1].J, rows[l - 1],
                          cols[l - 1], Jl, rows[l], cols[l]);
     }
     const dim3 sg((cols[l] + 63) / 64, (rows[l] + 3) / 4);
     hipLaunchKernelGGL(psh::lk_scharr, sg, dim3(256), 0, c.stream, Il, rows[l], cols[l], dl);
-    pyr.lv[l].I = Il;
-    pyr.lv[l].J = Jl;
-    pyr.lv[l].dI = dl;
-    pyr.lv[l].rows = rows[l];
-    pyr.lv[l].cols = cols[l];
+    ps->pyr.lv[l].I = Il;
+    ps->pyr.lv[l].J = Jl;
+    ps->pyr.lv[l].dI = dl;
+    ps->pyr.lv[l].rows = rows[l];
+    ps->pyr.lv[l].cols = cols[l];
   }
-  float2 *d_pts = reinterpret_cast<float2 *>(base + off_pts);
-  float2 *d_next = reinterpret_cast<float2 *>(base + off_next);
-  unsigned char *d_st = reinterpret_cast<unsigned char *>(base + off_st);
-  PSH_HIP(hipMemcpyAsync(d_pts, points_host, static_cast<size_t>(npts) * sizeof(float2),
-                         hipMemcpyHostToDevice, c.stream));
-  const float eps = static_cast<float>(epsilon);
-  hipLaunchKernelGGL(psh::lk_track, dim3(npts), dim3(256), 0, c.stream, pyr, d_pts, npts, win_w, win_h,
-                     max_count, eps * eps, static_cast<float>(min_eig_threshold), d_next, d_st);
-  PSH_HIP(hipGetLastError());
-  PSH_HIP(hipMemcpyAsync(next_points_host, d_next, static_cast<size_t>(npts) * sizeof(float2),
-                         hipMemcpyDeviceToHost, c.stream));
-  PSH_HIP(hipMemcpyAsync(status_host, d_st, static_cast<size_t>(npts), hipMemcpyDeviceToHost, c.stream));
-  PSH_HIP(hipStreamSynchronize(c.stream));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    (void)psh_free(ps->block);
+    delete ps;
+    return fail(PSH_EHIP, "lk_pyramids launch failed: %s", hipGetErrorString(e));
+  }
+  *handle_out = ps;
   return PSH_OK;
+}
+
+int psh_lk_pyramids_free(void *handle) {
+  if (!handle) return PSH_OK;
+  PyramidSet *ps = static_cast<PyramidSet *>(handle);
+  int rc = PSH_OK;
+  if (ps->block && ctx().ready) rc = psh_free(ps->block);  // stream-ordered reuse
+  delete ps;
+  return rc;
+}
+
+int psh_lk_track_pyr_dev(void *handle, const float *points_host, int npts, int max_count,
+                         double epsilon, double min_eig_threshold, float *next_points_host,
+                         unsigned char *status_host) {
+  PSH_REQUIRE_INIT();
+  if (!handle) return fail(PSH_EINVAL, "lk_track: NULL pyramid handle");
+  if (npts < 0) return fail(PSH_EINVAL, "lk_track: negative point count");
+  if (npts == 0) return PSH_OK;
+  if (!points_host || !next_points_host || !status_host) return fail(PSH_EINVAL, "lk_track: NULL pointer");
+  PyramidSet *ps = static_cast<PyramidSet *>(handle);
+  max_count = std::min(std::max(max_count, 0), 100);  // calcOpticalFlowPyrLK clamps the criteria
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t pts_bytes = (static_cast<size_t>(npts) * sizeof(float2) + 255) & ~static_cast<size_t>(255);
+  void *blk = nullptr;
+  if (int rc = psh_malloc(&blk, 2 * pts_bytes + static_cast<size_t>(npts))) return rc;
+  char *base = static_cast<char *>(blk);
+  float2 *d_pts = reinterpret_cast<float2 *>(base);
+  float2 *d_next = reinterpret_cast<float2 *>(base + pts_bytes);
+  unsigned char *d_st = reinterpret_cast<unsigned char *>(base + 2 * pts_bytes);
+  const float eps = static_cast<float>(epsilon);
+  auto run = [&]() -> int {
+    PSH_HIP(hipMemcpyAsync(d_pts, points_host, static_cast<size_t>(npts) * sizeof(float2),
+                           hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(psh::lk_track, dim3(npts), dim3(256), 0, c.stream, ps->pyr, d_pts, npts, ps->win_w,
+                       ps->win_h, max_count, eps * eps, static_cast<float>(min_eig_threshold), d_next, d_st);
+    PSH_HIP(hipGetLastError());
+    PSH_HIP(hipMemcpyAsync(next_points_host, d_next, static_cast<size_t>(npts) * sizeof(float2),
+                           hipMemcpyDeviceToHost, c.stream));
+    PSH_HIP(hipMemcpyAsync(status_host, d_st, static_cast<size_t>(npts), hipMemcpyDeviceToHost, c.stream));
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    return PSH_OK;
+  };
+  const int rc = run();
+  (void)psh_free(blk);
+  return rc;
+}
+
+int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m,
+                     int n, const float *points_host, int npts, int win_w, int win_h,
+                     int max_level, int max_count, double epsilon, double min_eig_threshold,
+                     float *next_points_host, unsigned char *status_host) {
+  if (npts == 0) return PSH_OK;
+  void *h = nullptr;
+  if (int rc = psh_lk_pyramids_dev(prev_u8_dev, next_u8_dev, m, n, win_w, win_h, max_level, &h)) return rc;
+  const int rc = psh_lk_track_pyr_dev(h, points_host, npts, max_count, epsilon, min_eig_threshold,
+                                      next_points_host, status_host);
+  const int rc2 = psh_lk_pyramids_free(h);
+  return rc ? rc : rc2;
 }
 
 }  // extern "C"

@@ -73,6 +73,74 @@ def detect_corners(prep, max_corners=1000, quality_level=0.01, min_distance=10, 
     return pts[: count.value].copy()
 
 
+def _criteria(criteria):
+    ctype, max_count, eps = criteria
+    if not (ctype & 1):  # no COUNT bit: OpenCV substitutes 30 iterations
+        max_count = 30
+    if not (ctype & 2):  # no EPS bit: OpenCV substitutes 0.01
+        eps = 0.01
+    return int(max_count), float(eps)
+
+
+def launch_corners(prep, max_corners=1000, quality_level=0.01, min_distance=10, block_size=5):
+    """Queue the corner kernels of a prepared frame (asynchronous); pair with finish_corners."""
+    m, n = prep.shape
+    _lib.check(
+        _lib.lib().psh_lk_corners_launch_dev(
+            prep.feature_u8.ptr, prep.clean.ptr, prep.stats.ptr, m, n, int(block_size),
+            prep.buffer_mask, float(quality_level), float(min_distance), int(max_corners),
+        ),
+        "psh_lk_corners_launch_dev",
+    )
+    return int(max_corners)
+
+
+def finish_corners(max_corners):
+    """Wait for the candidates, run the ordered min-distance pass -> (p,2) float32 (x,y)."""
+    pts = np.empty((int(max_corners), 2), dtype=np.float32)
+    count = ctypes.c_int(0)
+    _lib.check(_lib.lib().psh_lk_corners_finish(pts.ctypes.data, ctypes.byref(count)), "psh_lk_corners_finish")
+    return pts[: count.value].copy()
+
+
+class PyramidPair:
+    """Gaussian pyramids + Scharr gradients of a frame pair on the device (asynchronous build)."""
+
+    def __init__(self, prev, nxt, winsize=(50, 50), nr_levels=3):
+        m, n = prev.shape
+        handle = ctypes.c_void_p()
+        _lib.check(
+            _lib.lib().psh_lk_pyramids_dev(prev.track_u8.ptr, nxt.track_u8.ptr, m, n, int(winsize[0]),
+                                           int(winsize[1]), int(nr_levels), ctypes.byref(handle)),
+            "psh_lk_pyramids_dev",
+        )
+        self._h = handle
+        self._frames = (prev, nxt)  # level 0 lives in the prepared frames
+
+    def track(self, points, criteria=(3, 10, 0), min_eig_thr=1e-4):
+        p0 = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
+        p1 = np.empty_like(p0)
+        st = np.zeros(p0.shape[0], dtype=np.uint8)
+        max_count, eps = _criteria(criteria)
+        _lib.check(
+            _lib.lib().psh_lk_track_pyr_dev(self._h, p0.ctypes.data, p0.shape[0], max_count, eps,
+                                            float(min_eig_thr), p1.ctypes.data, st.ctypes.data),
+            "psh_lk_track_pyr_dev",
+        )
+        return p1, st.astype(bool)
+
+    def close(self):
+        if self._h:
+            _lib.load().psh_lk_pyramids_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def track_points(prev, nxt, points, winsize=(50, 50), nr_levels=3, criteria=(3, 10, 0),
                  min_eig_thr=1e-4):
     """Pyramidal LK between two prepared frames -> (next_points (p,2) f32, status (p,) bool)."""
@@ -81,11 +149,7 @@ def track_points(prev, nxt, points, winsize=(50, 50), nr_levels=3, criteria=(3, 
     p0 = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
     p1 = np.empty_like(p0)
     st = np.zeros(p0.shape[0], dtype=np.uint8)
-    ctype, max_count, eps = criteria
-    if not (ctype & 1):  # no COUNT bit: OpenCV substitutes 30 iterations
-        max_count = 30
-    if not (ctype & 2):  # no EPS bit: OpenCV substitutes 0.01
-        eps = 0.01
+    max_count, eps = _criteria(criteria)
     _lib.check(
         lib.psh_lk_track_dev(
             prev.track_u8.ptr, nxt.track_u8.ptr, m, n, p0.ctypes.data, p0.shape[0],
@@ -194,12 +258,18 @@ def dense_lucaskanade(
     xy = np.empty(shape=(0, 2))
     uv = np.empty(shape=(0, 2))
     for t in range(nr_fields - 1):
-        points = detect_corners(prepared[t], max_corners, quality_level, min_distance, block_size)
+        # corner kernels first, then the pyramids of the pair: the device builds them while
+        # the host runs the ordered min-distance pass over the candidates
+        token = launch_corners(prepared[t], max_corners, quality_level, min_distance, block_size)
+        pyramids = PyramidPair(prepared[t], prepared[t + 1], winsize, nr_levels)
+        points = finish_corners(token)
         if fd_kwargs.get("verbose", False):
             print(f"--- {points.shape[0]} good features to track detected ---")
         if points.shape[0] == 0:
+            pyramids.close()
             continue
-        p1, st = track_points(prepared[t], prepared[t + 1], points, winsize, nr_levels, criteria, min_eig_thr)
+        p1, st = pyramids.track(points, criteria, min_eig_thr)
+        pyramids.close()
         if lk_kwargs.get("verbose", False):
             print(f"--- {int(st.sum())} sparse vectors found ---")
         if not st.any():
