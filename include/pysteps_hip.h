@@ -91,6 +91,15 @@ int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, i
                     const double *steps_host, int T, int n_iter, int interp_order,
                     float outval, double *disp_dev, int resume, float *out_dev);
 
+/* Row-band form for output tiling across GPUs (BASELINE config 5: every rank holds the whole
+ * input - it is tiny next to 288 GB - and advects only its band): pixels of rows
+ * [row_begin, row_begin + row_count) are integrated and written to out (T,row_count,n);
+ * disp, if given, stays full size (2,m,n) and only the band's rows are read/written. */
+int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
+                         const double *steps_host, int T, int n_iter, int interp_order,
+                         float outval, double *disp_dev, int resume, int row_begin, int row_count,
+                         float *out_dev);
+
 int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
                      const double *steps, int T, int n_iter, int interp_order, float outval,
                      const double *disp_prev, double *disp_out, float *out);

@@ -56,6 +56,7 @@ struct SemilagArgs {
   const float *scale;   // device, T floats: step / vel_timestep / max(n_iter, 1)
   float first_scale;    // step[0] / vel_timestep (the very first increment is not divided)
   int m, n, T, n_iter, order, resume;
+  int row0, rows;       // output row band [row0, row0+rows); out is (T,rows,n)
   float outval;
 };
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);

@@ -329,10 +329,26 @@ static int check_semilag(int m, int n, int T, int n_iter, int order) {
   return PSH_OK;
 }
 
+int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
+                         const double *steps_host, int T, int n_iter, int interp_order,
+                         float outval, double *disp_dev, int resume, int row_begin, int row_count,
+                         float *out_dev);
+
 int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
                     const double *steps_host, int T, int n_iter, int interp_order,
                     float outval, double *disp_dev, int resume, float *out_dev) {
+  return psh_semilag_rows_dev(precip_dev, velocity_dev, m, n, steps_host, T, n_iter, interp_order,
+                              outval, disp_dev, resume, 0, m, out_dev);
+}
+
+int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
+                         const double *steps_host, int T, int n_iter, int interp_order,
+                         float outval, double *disp_dev, int resume, int row_begin, int row_count,
+                         float *out_dev) {
   PSH_REQUIRE_INIT();
+  if (row_begin < 0 || row_count <= 0 || row_begin + row_count > m)
+    return fail(PSH_EINVAL, "semilag: row band [%d, %d) outside the %d-row image", row_begin,
+                row_begin + row_count, m);
   if (int rc = check_semilag(m, n, T, n_iter, interp_order)) return rc;
   if (!velocity_dev || !steps_host) return fail(PSH_EINVAL, "semilag: NULL velocity/steps");
   if (precip_dev && !out_dev) return fail(PSH_EINVAL, "semilag: precip given but out is NULL");
@@ -375,6 +391,8 @@ int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, i
   a.n_iter = n_iter;
   a.order = interp_order;
   a.resume = resume;
+  a.row0 = row_begin;
+  a.rows = row_count;
   a.outval = outval;
   PSH_HIP(psh::launch_semilag(a, c.stream));
   return PSH_OK;

@@ -316,7 +316,8 @@ template <int NPX, int ORDER, bool HAS_PRECIP, bool LDS>
 __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
     const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
-    int T, int n_iter, int resume, float outval, int tiles_x, int n_tiles, int tiles_per_xcd) {
+    int T, int n_iter, int resume, float outval, int row0, int rows, int tiles_x, int n_tiles,
+    int tiles_per_xcd) {
   // XCD-aware remap: hardware block b -> XCD b % 8; give XCD k the k-th band of tiles
   const int b = blockIdx.x;
   const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
@@ -324,7 +325,8 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
   // threads past the right/bottom edge shadow the edge pixel (all 64 lanes stay
   // active for the cross-lane exchange); only their stores are masked
   const int xt = (tile % tiles_x) * kTileX + (threadIdx.x & (kTileX - 1));
-  const int yt = (tile / tiles_x) * (kWavesPerBlock * NPX) + (threadIdx.x / kTileX) * NPX;
+  // row band [row0, row0 + rows) of the image (the whole image unless the output is tiled)
+  const int yt = row0 + (tile / tiles_x) * (kWavesPerBlock * NPX) + (threadIdx.x / kTileX) * NPX;
   const int x = min(xt, n - 1);
   const size_t plane = static_cast<size_t>(m) * n;
   Fields F;
@@ -347,19 +349,20 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
   S.buf = stage_buf;
   S.red = stage_red;
   S.x0 = (tile % tiles_x) * kTileX;
-  S.y0 = (tile / tiles_x) * (kWavesPerBlock * NPX);
+  S.y0 = row0 + (tile / tiles_x) * (kWavesPerBlock * NPX);
   S.parity = 0;
 
   // trajectory state per pixel: absolute integer position + fraction, and the increment
   int y[NPX], px[NPX], py[NPX];
   float fx[NPX], fy[NPX], vix[NPX], viy[NPX], su[NPX], sv[NPX], sp[NPX];
   bool live[NPX];
-  unsigned pix[NPX];
+  unsigned pix[NPX], opix[NPX];
 #pragma unroll
   for (int j = 0; j < NPX; ++j) {
-    live[j] = xt < n && yt + j < m;
+    live[j] = xt < n && yt + j < row0 + rows;
     y[j] = min(yt + j, m - 1);
     pix[j] = static_cast<unsigned>(__mul24(y[j], n) + x) << 2;
+    opix[j] = static_cast<unsigned>(__mul24(y[j] - row0, n) + x) << 2;  // output is band-local
     px[j] = x;
     py[j] = y[j];
     fx[j] = fy[j] = sp[j] = 0.f;
@@ -466,8 +469,8 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
     if (HAS_PRECIP) {
 #pragma unroll
       for (int j = 0; j < NPX; ++j)
-        if (live[j]) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + pix[j]) = sp[j];
-      out += plane;
+        if (live[j]) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]) = sp[j];
+      out += static_cast<size_t>(rows) * n;
     }
   }
 
@@ -487,14 +490,14 @@ template <int NPX, bool LDS>
 static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   const int tile_y = kWavesPerBlock * NPX;
   const int tiles_x = (a.n + kTileX - 1) / kTileX;
-  const int tiles_y = (a.m + tile_y - 1) / tile_y;
+  const int tiles_y = (a.rows + tile_y - 1) / tile_y;
   const int n_tiles = tiles_x * tiles_y;
   const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
   const dim3 grid(tiles_per_xcd * kNumXcd), block(kTileX * kWavesPerBlock);
 #define PSH_SL_LAUNCH(ORDER, HASP)                                                              \
   hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, LDS>), grid, block, 0, stream, a.precip,   \
                      a.vel, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter,     \
-                     a.resume, a.outval, tiles_x, n_tiles, tiles_per_xcd)
+                     a.resume, a.outval, a.row0, a.rows, tiles_x, n_tiles, tiles_per_xcd)
   if (a.precip == nullptr) {
     PSH_SL_LAUNCH(1, false);
   } else if (a.order == 0) {

@@ -90,3 +90,32 @@ def sharded_extrapolate(precip_members, velocity, timesteps, rank, world_size, *
     extrapolate = get_method("semilagrangian")
     mine = partition(len(precip_members), world_size, rank)
     return {j: extrapolate(precip_members[j], velocity, timesteps, **kwargs) for j in mine}
+
+
+def tiled_extrapolate(precip, velocity, timesteps, rank, world_size, outval=float("nan"), n_iter=1,
+                      interp_order=1):
+    """Output-tiled nowcast for domains shared by several GPUs (BASELINE config 5).
+
+    Every rank holds the whole (broadcast) ``precip`` (m,n) and ``velocity`` (2,m,n)
+    DeviceArrays - they are tiny next to 288 GB of HBM - and integrates only the pixels of
+    its row band ``partition(m, world_size, rank)``; the semi-Lagrangian scheme has no
+    inter-pixel dependency, so no halo exchange is needed and the bands of all ranks
+    concatenate to the single-GPU result bit for bit.  Returns ``(rows, out)`` with
+    ``out`` a float32 DeviceArray ``(T, len(rows), n)``.
+    """
+    from .extrapolation.semilagrangian import _step_increments
+
+    if not isinstance(precip, DeviceArray) or not isinstance(velocity, DeviceArray):
+        raise TypeError("tiled_extrapolate works on device-resident fields")
+    m, n = precip.shape
+    rows = partition(m, world_size, rank)
+    steps = _step_increments(timesteps, 1)
+    out = DeviceArray((steps.size, max(len(rows), 1), n), np.float32)
+    if len(rows) == 0:
+        return rows, out
+    rc = _lib.lib().psh_semilag_rows_dev(
+        precip.ptr, velocity.ptr, m, n, steps.ctypes.data, int(steps.size), int(n_iter), int(interp_order),
+        float(outval), None, 0, rows.start, len(rows), out.ptr,
+    )
+    _lib.check(rc, "psh_semilag_rows_dev")
+    return rows, out

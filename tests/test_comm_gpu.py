@@ -35,3 +35,37 @@ def test_sharded_extrapolate_single_rank():
     assert sorted(got) == [0, 1, 2]
     want = get_method("semilagrangian")(members[1], vel, 2, outval=-15.0)
     assert np.array_equal(got[1], want)
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_row_band_tiling_equals_single_gpu(world):
+    """Config-5 style output tiling with 'virtual ranks' on one GPU: the bands concatenate to the
+    full-image result bit for bit (no halo exchange needed: inputs are replicated)."""
+    from pysteps_amd import _lib, parallel
+    from pysteps_amd.device import DeviceArray
+    from pysteps_amd.extrapolation import get_method
+    from tools import synth
+
+    m, n = 515, 384
+    p = synth.rain_field_db(m, n, seed=8)
+    y, x = np.mgrid[0:m, 0:n]
+    v = synth.true_velocity(m, n) + np.stack([0.02 * (x - n / 2), -0.02 * (y - m / 2)]).astype(np.float32)
+    dp, dv = DeviceArray.from_host(p), DeviceArray.from_host(v)
+    full = get_method("semilagrangian")(dp, dv, 5, n_iter=2).to_host()
+    for variant in (0, 4):
+        _lib.check(_lib.lib().psh_set_option(b"semilag_variant", variant))
+        try:
+            bands = []
+            for rank in range(world):
+                rows, out = parallel.tiled_extrapolate(dp, dv, 5, rank, world, n_iter=2)
+                assert out.shape == (5, len(rows), n)
+                bands.append(out.to_host())
+            tiled = np.concatenate(bands, axis=1)
+        finally:
+            _lib.check(_lib.lib().psh_set_option(b"semilag_variant", 0))
+        assert tiled.shape == full.shape
+        if variant == 0:
+            assert np.array_equal(tiled, full, equal_nan=True)
+        else:
+            assert np.array_equal(np.isnan(tiled), np.isnan(full))
+            assert np.nanmax(np.abs(tiled - full)) < 1e-4
