@@ -47,7 +47,8 @@ const char *psh_version(void);
 int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hbm_free,
                     char *name, int name_len);
 
-/* tuning knobs; "semilag_variant": 0 direct gathers (default), 2 / 4 LDS-staged tiles */
+/* knobs; "semilag_variant": 0 direct gathers (default), 2 / 4 LDS-staged tiles;
+ * "trim_cache": release the device blocks cached by psh_free (value ignored) */
 int psh_set_option(const char *key, int value);
 
 int psh_malloc(void **dev_ptr, size_t nbytes);

@@ -449,9 +449,9 @@ extern "C" int psh_idw_host(const double *xy, const double *values, int L, int m
   float *d_xy = nullptr, *d_uv = nullptr, *d_out = nullptr;
   auto cleanup = [&]() {
     (void)hipStreamSynchronize(c.stream);
-    if (d_xy) (void)hipFree(d_xy);
-    if (d_uv) (void)hipFree(d_uv);
-    if (d_out) (void)hipFree(d_out);
+    if (d_xy) (void)psh_free(d_xy);
+    if (d_uv) (void)psh_free(d_uv);
+    if (d_out) (void)psh_free(d_out);
   };
 #define PSH_TRY(expr)                                                                  \
   do {                                                                                 \
@@ -462,9 +462,19 @@ extern "C" int psh_idw_host(const double *xy, const double *values, int L, int m
                        hipGetErrorString(_e));                                         \
     }                                                                                  \
   } while (0)
-  PSH_TRY(hipMalloc(&d_xy, h_xy.size() * sizeof(float)));
-  PSH_TRY(hipMalloc(&d_uv, h_uv.size() * sizeof(float)));
-  PSH_TRY(hipMalloc(&d_out, 2 * plane * sizeof(float)));
+  {
+    void *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;
+    int arc = psh_malloc(&p0, h_xy.size() * sizeof(float));
+    if (!arc) arc = psh_malloc(&p1, h_uv.size() * sizeof(float));
+    if (!arc) arc = psh_malloc(&p2, 2 * plane * sizeof(float));
+    d_xy = static_cast<float *>(p0);
+    d_uv = static_cast<float *>(p1);
+    d_out = static_cast<float *>(p2);
+    if (arc) {
+      cleanup();
+      return arc;
+    }
+  }
   PSH_TRY(hipMemcpyAsync(d_xy, h_xy.data(), h_xy.size() * sizeof(float), hipMemcpyHostToDevice, c.stream));
   PSH_TRY(hipMemcpyAsync(d_uv, h_uv.data(), h_uv.size() * sizeof(float), hipMemcpyHostToDevice, c.stream));
   int rc = psh_idw_dev(d_xy, d_uv, L, m, n, x0, dx, y0, dy, k, power, dist_offset, reach, d_out);

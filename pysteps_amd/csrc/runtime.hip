@@ -146,6 +146,16 @@ int psh_set_option(const char *key, int value) {
     psh::set_semilag_variant(value);
     return PSH_OK;
   }
+  if (std::strcmp(key, "trim_cache") == 0) {  // give the cached device blocks back to the driver
+    psh::Context &c = ctx();
+    std::lock_guard<std::recursive_mutex> lock(c.mu);
+    if (c.ready) {
+      PSH_HIP(hipSetDevice(c.device));
+      PSH_HIP(hipStreamSynchronize(c.stream));
+      psh::release_cache();
+    }
+    return PSH_OK;
+  }
   return fail(PSH_EINVAL, "psh_set_option: unknown option '%s'", key);
 }
 
@@ -414,12 +424,14 @@ int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
   float *d_p = nullptr, *d_v = nullptr, *d_out = nullptr;
   double *d_disp = nullptr;
   int rc = PSH_OK;
+  // blocks come from the stream-ordered cache: a nowcast loop that calls this entry point
+  // once per member and time step does not pay hipMalloc/hipFree each time
   auto cleanup = [&]() {
     (void)hipStreamSynchronize(c.stream);
-    if (d_p) (void)hipFree(d_p);
-    if (d_v) (void)hipFree(d_v);
-    if (d_out) (void)hipFree(d_out);
-    if (d_disp) (void)hipFree(d_disp);
+    if (d_p) (void)psh_free(d_p);
+    if (d_v) (void)psh_free(d_v);
+    if (d_out) (void)psh_free(d_out);
+    if (d_disp) (void)psh_free(d_disp);
   };
 #define PSH_TRY(expr)                                                        \
   do {                                                                       \
@@ -430,15 +442,24 @@ int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
                   "%s failed: %s", #expr, hipGetErrorString(_e));            \
     }                                                                        \
   } while (0)
-  PSH_TRY(hipMalloc(&d_v, 2 * plane * sizeof(float)));
+#define PSH_ALLOC(ptr, bytes)                                             \
+  do {                                                                    \
+    void *_p = nullptr;                                                   \
+    if (int _rc = psh_malloc(&_p, (bytes))) {                             \
+      cleanup();                                                          \
+      return _rc;                                                         \
+    }                                                                     \
+    ptr = static_cast<decltype(ptr)>(_p);                                 \
+  } while (0)
+  PSH_ALLOC(d_v, 2 * plane * sizeof(float));
   PSH_TRY(hipMemcpyAsync(d_v, velocity, 2 * plane * sizeof(float), hipMemcpyHostToDevice, c.stream));
   if (precip) {
-    PSH_TRY(hipMalloc(&d_p, plane * sizeof(float)));
+    PSH_ALLOC(d_p, plane * sizeof(float));
     PSH_TRY(hipMemcpyAsync(d_p, precip, plane * sizeof(float), hipMemcpyHostToDevice, c.stream));
-    PSH_TRY(hipMalloc(&d_out, static_cast<size_t>(T) * plane * sizeof(float)));
+    PSH_ALLOC(d_out, static_cast<size_t>(T) * plane * sizeof(float));
   }
   if (disp_prev || disp_out) {
-    PSH_TRY(hipMalloc(&d_disp, 2 * plane * sizeof(double)));
+    PSH_ALLOC(d_disp, 2 * plane * sizeof(double));
     if (disp_prev)
       PSH_TRY(hipMemcpyAsync(d_disp, disp_prev, 2 * plane * sizeof(double), hipMemcpyHostToDevice,
                              c.stream));
@@ -457,6 +478,7 @@ int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
                            c.stream));
   PSH_TRY(hipStreamSynchronize(c.stream));
 #undef PSH_TRY
+#undef PSH_ALLOC
   cleanup();
   return PSH_OK;
 }

@@ -18,6 +18,7 @@ delegated to the reference when pysteps is importable, else NotImplementedError.
 """
 
 import ctypes
+import threading
 import time
 import warnings
 
@@ -31,6 +32,9 @@ from ..utils.interpolate import idw_to_device, idwinterp2d
 __all__ = ["dense_lucaskanade", "PreparedFrame", "detect_corners", "track_points"]
 
 _N_STATS = 8
+# one corner request (launch -> finish) is in flight per process: callers on several threads
+# (the reference is re-entrant and gets called from dask workers) take turns here
+_corner_lock = threading.Lock()
 
 
 class PreparedFrame:
@@ -62,14 +66,13 @@ def detect_corners(prep, max_corners=1000, quality_level=0.01, min_distance=10, 
     m, n = prep.shape
     pts = np.empty((int(max_corners), 2), dtype=np.float32)
     count = ctypes.c_int(0)
-    _lib.check(
-        lib.psh_lk_corners_dev(
+    with _corner_lock:
+        rc = lib.psh_lk_corners_dev(
             prep.feature_u8.ptr, prep.clean.ptr, prep.stats.ptr, m, n, int(block_size),
             prep.buffer_mask, float(quality_level), float(min_distance), int(max_corners),
             pts.ctypes.data, ctypes.byref(count),
-        ),
-        "psh_lk_corners_dev",
-    )
+        )
+    _lib.check(rc, "psh_lk_corners_dev")
     return pts[: count.value].copy()
 
 
@@ -260,9 +263,10 @@ def dense_lucaskanade(
     for t in range(nr_fields - 1):
         # corner kernels first, then the pyramids of the pair: the device builds them while
         # the host runs the ordered min-distance pass over the candidates
-        token = launch_corners(prepared[t], max_corners, quality_level, min_distance, block_size)
-        pyramids = PyramidPair(prepared[t], prepared[t + 1], winsize, nr_levels)
-        points = finish_corners(token)
+        with _corner_lock:
+            token = launch_corners(prepared[t], max_corners, quality_level, min_distance, block_size)
+            pyramids = PyramidPair(prepared[t], prepared[t + 1], winsize, nr_levels)
+            points = finish_corners(token)
         if fd_kwargs.get("verbose", False):
             print(f"--- {points.shape[0]} good features to track detected ---")
         if points.shape[0] == 0:
