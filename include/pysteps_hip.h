@@ -69,6 +69,18 @@ int psh_event_elapsed_ms(void *start, void *stop, float *ms); /* waits for stop 
  * calibrate rocprofv3 FETCH_SIZE/WRITE_SIZE on gfx950; not part of the hot path. */
 int psh_calib_copy(float *dst_dev, const float *src_dev, size_t nfloats, int vec_width);
 
+/* ---- element-wise passes either side of the path (keep a nowcast chain in HBM) ------ *
+ * psh_db_transform_dev: pysteps/utils/transformation.py:150-232 (dB_transform).  Forward:
+ *   out = R < threshold ? zerovalue : 10 log10(R)  (threshold in the units of R);  inverse:
+ *   out = 10^(R/10) < 10^(threshold/10) ? zerovalue : 10^(R/10)  (threshold in dB).  n floats,
+ *   in place allowed, NaN stays NaN.
+ * psh_field_stats_dev: min / max over the finite values and the number of non-finite values
+ *   (the NumPy scans of nowcasts/extrapolation.py:76 and semilagrangian.py:171-172). Synchronous. */
+int psh_db_transform_dev(const float *in_dev, float *out_dev, size_t n, double threshold,
+                         double zerovalue, int inverse);
+int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *max_out,
+                        double *nonfinite_out);
+
 /* ---- semi-Lagrangian extrapolation ------------------------------------- *
  * Replaces pysteps/extrapolation/semilagrangian.py:21-266 (extrapolate) incl.
  * its inner interpolate_motion (:181-198) and the scipy.ndimage.map_coordinates

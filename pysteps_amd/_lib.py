@@ -67,6 +67,8 @@ SIGNATURES = {
     "psh_lk_pyramids_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "psh_lk_pyramids_free": (c_int, [c_void_p]),
     "psh_lk_track_pyr_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
+    "psh_db_transform_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_double, c_double, c_int]),
+    "psh_field_stats_dev": (c_int, [c_void_p, c_size_t, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_semilag_rows_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -216,7 +216,11 @@ def _run_device(lib, precip, velocity, steps, outval, displacement_prev, n_iter,
     if precip is not None and not isinstance(precip, DeviceArray):
         raise ValueError("precip must be a DeviceArray when velocity is one")
     if isinstance(outval, str):
-        raise ValueError("outval='min' needs a host precip array; pass the minimum explicitly")
+        if outval != "min":
+            raise ValueError("outval must be a number or 'min'")
+        from ..utils.transformation import field_stats  # noqa: PLC0415
+
+        outval = field_stats(precip)[0] if precip is not None else float("nan")  # device reduction
     disp = None
     resume = 0
     if displacement_prev is not None:
