@@ -94,7 +94,8 @@ int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *
  *  steps_host  T doubles, HOST memory: lead-time increments / vel_timestep
  *              (timestep_diff / vel_timestep of semilagrangian.py:165,198)
  *  n_iter      >= 0 (0 = no midpoint rule, :215-219)
- *  interp_order 0 or 1 for the precip resampling (:85-90)
+ *  interp_order 0, 1 or 3 for the precip resampling (:85-90); 3 = cubic B-spline incl. the
+ *              spline prefilter and the two mask warps of :146-157,234-253 (outside -> NaN)
  *  outval      value for pixels advected from outside the domain (may be NaN)
  *  disp        (2,m,n) float64 or NULL; if resume != 0 it holds displacement_prev
  *              on entry (:203-207); if non-NULL it receives the final displacement

@@ -63,6 +63,61 @@ def _bilinear(field, row, col):
     )
 
 
+def _spline_prefilter_mirror(field):
+    """Cubic B-spline coefficients with mirror boundaries along both axes, float64
+    (scipy.ndimage.spline_filter(order=3, mode="constant"|"mirror"); ni_splines.c:
+    gain 6, pole z = sqrt(3) - 2, _init_causal_mirror / _init_anticausal_mirror)."""
+    z = np.sqrt(3.0) - 2.0
+    c = np.array(field, dtype=np.float64)
+    for axis in (0, 1):
+        c = np.moveaxis(c, axis, 0).copy()
+        n = c.shape[0]
+        if n > 1:
+            c *= 6.0
+            zn1 = z ** (n - 1)
+            acc = c[0] + zn1 * c[n - 1]
+            zi = z
+            for i in range(1, n - 1):
+                acc = acc + zi * (c[i] + zn1 * c[n - 1 - i])
+                zi *= z
+            c[0] = acc / (1.0 - zn1 * zn1)
+            for i in range(1, n):
+                c[i] += z * c[i - 1]
+            c[n - 1] = (z * c[n - 2] + c[n - 1]) * z / (z * z - 1.0)
+            for i in range(n - 2, -1, -1):
+                c[i] = z * (c[i + 1] - c[i])
+        c = np.moveaxis(c, 0, axis)
+    return c
+
+
+def _mirror_index(i, n):
+    if n == 1:
+        return np.zeros_like(i)
+    period = 2 * (n - 1)
+    i = np.mod(i, period)
+    return np.where(i >= n, period - i, i)
+
+
+def _bspline3_weights(t):
+    return [(1 - t) ** 3 / 6, (3 * t**3 - 6 * t**2 + 4) / 6, (-3 * t**3 + 3 * t**2 + 3 * t + 1) / 6, t**3 / 6]
+
+
+def _cubic(field, row, col, cval):
+    """order-3 map_coordinates, mode="constant": strict inside test on the coordinate, 4x4 taps
+    around floor(c) with mirrored indices, coefficients from the mirror prefilter."""
+    m, n = field.shape
+    coef = _spline_prefilter_mirror(field)
+    outside = (row < 0.0) | (row > m - 1.0) | (col < 0.0) | (col > n - 1.0)
+    rr, cc = np.where(outside, 0.0, row), np.where(outside, 0.0, col)
+    iy, ix = np.floor(rr).astype(np.int64), np.floor(cc).astype(np.int64)
+    wy, wx = _bspline3_weights(rr - iy), _bspline3_weights(cc - ix)
+    acc = np.zeros(row.shape)
+    for a in range(4):
+        for b in range(4):
+            acc += wy[a] * wx[b] * coef[_mirror_index(iy - 1 + a, m), _mirror_index(ix - 1 + b, n)]
+    return np.where(outside, cval, acc)
+
+
 def _numpy_sample(field, row, col, mode, cval, order):
     m, n = field.shape
     row = np.asarray(row, dtype=np.float64)
@@ -78,6 +133,10 @@ def _numpy_sample(field, row, col, mode, cval, order):
     else:
         raise NotImplementedError("numpy backend restates modes nearest/constant only")
 
+    if order == 3:
+        if mode != "constant":
+            raise NotImplementedError("numpy backend restates order 3 for mode constant only")
+        return _cubic(field.astype(np.float64), row, col, cval)
     if order == 1:
         val = _bilinear(field, rr, cc)
     elif order == 0:
@@ -87,7 +146,7 @@ def _numpy_sample(field, row, col, mode, cval, order):
             np.clip(ri, 0, m - 1), np.clip(ci, 0, n - 1)
         ]
     else:
-        raise NotImplementedError("numpy backend restates interpolation order 0/1 only")
+        raise NotImplementedError("numpy backend restates interpolation order 0/1/3 only")
 
     if outside is not None:
         val = np.where(outside, cval, val)
@@ -185,6 +244,19 @@ def extrapolate(
     yy, xx = np.mgrid[0:m, 0:n]
     sub = float(n_iter) if n_iter > 1 else 1.0
 
+    # interp_order > 1: the field is interpolated with NaNs zeroed and two order-1 mask warps
+    # restore the no-rain minimum and the missing values (reference :146-157, :234-253)
+    if precip is not None and interp_order > 1:
+        minval = np.nanmin(precip)
+        mask_min = (precip > minval).astype(float)
+        if allow_nonfinite_values:
+            mask_finite = np.isfinite(precip)
+            precip = precip.copy()
+            precip[~mask_finite] = 0.0
+            mask_finite = mask_finite.astype(float)
+        else:
+            mask_finite = np.ones(precip.shape)
+
     def motion_at(dx, dy, step):
         # map_coordinates allocates its output in the dtype of the sampled
         # array, so float32 velocities give float32-rounded samples.
@@ -221,8 +293,14 @@ def extrapolate(
             disp = disp - inc
 
         if precip is not None:
-            val = sampler(precip, yy + disp[1], xx + disp[0], "constant", outval, interp_order)
-            frames.append(np.asarray(val).astype(precip.dtype, copy=False))
+            val = np.asarray(sampler(precip, yy + disp[1], xx + disp[0], "constant", outval, interp_order))
+            val = val.astype(precip.dtype, copy=True)
+            if interp_order > 1:
+                warped = sampler(mask_min, yy + disp[1], xx + disp[0], "constant", 0, 1)
+                val[np.asarray(warped) < 0.5] = minval
+                warped = sampler(mask_finite, yy + disp[1], xx + disp[0], "constant", 0, 1)
+                val[np.asarray(warped) < 0.5] = np.nan
+            frames.append(val)
 
     if precip is None:
         return None, disp

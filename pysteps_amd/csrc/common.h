@@ -58,9 +58,12 @@ struct SemilagArgs {
   int m, n, T, n_iter, order, resume;
   int row0, rows;       // output row band [row0, row0+rows); out is (T,rows,n)
   float outval;
+  const float *coef;    // interp_order 3: cubic B-spline coefficients of precip (m,n)
+  float minval;         // interp_order 3: minimum over the finite values of precip
 };
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
 void set_semilag_variant(int v);
+hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream);
 
 struct IdwArgs {
   const float *xy;  // (L,2) device: x, y of the sparse vectors

@@ -159,6 +159,9 @@ int psh_set_option(const char *key, int value) {
   return fail(PSH_EINVAL, "psh_set_option: unknown option '%s'", key);
 }
 
+int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *max_out,
+                        double *nonfinite_out);
+
 int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hbm_free,
                     char *name, int name_len) {
   PSH_REQUIRE_INIT();
@@ -334,8 +337,8 @@ static int check_semilag(int m, int n, int T, int n_iter, int order) {
     return fail(PSH_EUNSUPPORTED, "semilag: m*n must be < 2^30 pixels (32-bit byte offsets)");
   if (T <= 0) return fail(PSH_EINVAL, "semilag: T must be positive (got %d)", T);
   if (n_iter < 0) return fail(PSH_EINVAL, "semilag: n_iter must be >= 0 (got %d)", n_iter);
-  if (order != 0 && order != 1)
-    return fail(PSH_EUNSUPPORTED, "semilag: interp_order %d not implemented (0 or 1)", order);
+  if (order != 0 && order != 1 && order != 3)
+    return fail(PSH_EUNSUPPORTED, "semilag: interp_order %d not implemented (0, 1 or 3)", order);
   return PSH_OK;
 }
 
@@ -404,7 +407,29 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
   a.row0 = row_begin;
   a.rows = row_count;
   a.outval = outval;
-  PSH_HIP(psh::launch_semilag(a, c.stream));
+  a.coef = nullptr;
+  a.minval = 0.f;
+  void *spline_blk = nullptr;
+  if (interp_order == 3 && precip_dev) {
+    // cubic B-spline coefficients (spline.hip) + the minimum the mask logic restores (:146-147)
+    const size_t plane_bytes = static_cast<size_t>(m) * n * sizeof(float);
+    if (int rc = psh_malloc(&spline_blk, 2 * plane_bytes)) return rc;
+    float *coef = static_cast<float *>(spline_blk);
+    float *tmp = coef + static_cast<size_t>(m) * n;
+    hipError_t e = psh::spline_prefilter(precip_dev, coef, tmp, m, n, c.stream);
+    double mn = 0.0;
+    int rc = e == hipSuccess ? psh_field_stats_dev(precip_dev, static_cast<size_t>(m) * n, &mn, nullptr, nullptr)
+                             : fail(PSH_EHIP, "spline prefilter failed: %s", hipGetErrorString(e));
+    if (rc) {
+      (void)psh_free(spline_blk);
+      return rc;
+    }
+    a.coef = coef;
+    a.minval = static_cast<float>(mn);
+  }
+  const hipError_t le = psh::launch_semilag(a, c.stream);
+  if (spline_blk) (void)psh_free(spline_blk);  // stream-ordered: the launch above is queued first
+  PSH_HIP(le);
   return PSH_OK;
 }
 

@@ -54,6 +54,8 @@ struct Fields {
   // offset (+1 row) - no per-load 64-bit VALU address arithmetic
   __amdgpu_buffer_rsrc_t ru, rv, rp;
   int row_bytes;
+  const float *coef;  // cubic B-spline coefficients of the field (interp_order 3 only)
+  float minval;       // minimum over its finite values (interp_order 3 only)
 };
 
 __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soff) {
@@ -300,6 +302,11 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
         sp[j] = ld(F.p0, static_cast<unsigned>(__mul24(yi, n) + xi) << 2);
       }
     }
+    if (kWithP && ORDER == 3) {
+#pragma unroll
+      for (int j = 0; j < NPX; ++j)
+        sp[j] = sample_precip_cubic(F.coef, F.p0, X[j], Y[j], fx[j], fy[j], m, n, F.minval);
+    }
     // keep the optimiser from sinking both branches into one load sequence with
     // selected 64-bit addresses (that would cost the fast path its addressing)
     asm volatile("" ::: "memory");
@@ -307,7 +314,11 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
       if (WHAT & kVel) sample_velocity_border(F, X[j], Y[j], fx[j], fy[j], m, n, su[j], sv[j]);
-      if (kWithP) sp[j] = sample_precip_border<ORDER>(F.p0, X[j], Y[j], fx[j], fy[j], m, n, outval);
+      if (kWithP) {
+        sp[j] = ORDER == 3 ? sample_precip_cubic(F.coef, F.p0, X[j], Y[j], fx[j], fy[j], m, n, F.minval)
+                           : sample_precip_border<(ORDER == 3 ? 1 : ORDER)>(F.p0, X[j], Y[j], fx[j],
+                                                                            fy[j], m, n, outval);
+      }
     }
   }
 }
@@ -316,8 +327,8 @@ template <int NPX, int ORDER, bool HAS_PRECIP, bool LDS>
 __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
     const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
-    int T, int n_iter, int resume, float outval, int row0, int rows, int tiles_x, int n_tiles,
-    int tiles_per_xcd) {
+    int T, int n_iter, int resume, float outval, int row0, int rows, const float *__restrict__ coef,
+    float minval, int tiles_x, int n_tiles, int tiles_per_xcd) {
   // XCD-aware remap: hardware block b -> XCD b % 8; give XCD k the k-th band of tiles
   const int b = blockIdx.x;
   const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
@@ -342,6 +353,8 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
   F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_PRECIP ? precip : vel), 0, plane_bytes,
                                            0x00020000);
   F.row_bytes = n * static_cast<int>(sizeof(float));
+  F.coef = coef;
+  F.minval = minval;
 
   __shared__ float stage_buf[LDS ? 3 * kStageCap : 1];
   __shared__ int stage_red[16];
@@ -462,7 +475,10 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
         } else {
 #pragma unroll
           for (int j = 0; j < NPX; ++j)
-            sp[j] = sample_precip_border<ORDER>(F.p0, px[j], py[j], fx[j], fy[j], m, n, outval);
+            sp[j] = ORDER == 3
+                        ? sample_precip_cubic(F.coef, F.p0, px[j], py[j], fx[j], fy[j], m, n, F.minval)
+                        : sample_precip_border<(ORDER == 3 ? 1 : ORDER)>(F.p0, px[j], py[j], fx[j], fy[j],
+                                                                         m, n, outval);
         }
       }
     }
@@ -497,11 +513,18 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
 #define PSH_SL_LAUNCH(ORDER, HASP)                                                              \
   hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, LDS>), grid, block, 0, stream, a.precip,   \
                      a.vel, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter,     \
-                     a.resume, a.outval, a.row0, a.rows, tiles_x, n_tiles, tiles_per_xcd)
+                     a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, tiles_x, n_tiles,           \
+                     tiles_per_xcd)
   if (a.precip == nullptr) {
     PSH_SL_LAUNCH(1, false);
   } else if (a.order == 0) {
     PSH_SL_LAUNCH(0, true);
+  } else if (a.order == 3) {
+    if constexpr (!LDS) {
+      PSH_SL_LAUNCH(3, true);
+    } else {
+      return hipErrorInvalidValue;  // the staged variants are built for order 0/1
+    }
   } else {
     PSH_SL_LAUNCH(1, true);
   }
@@ -525,7 +548,7 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
   // LDS staging needs 16-byte aligned rows (n % 4 == 0)
   const bool aligned = (a.n % 4 == 0) && (reinterpret_cast<uintptr_t>(a.vel) % 16 == 0) &&
                        (a.precip == nullptr || reinterpret_cast<uintptr_t>(a.precip) % 16 == 0);
-  if (g_semilag_variant != 0 && aligned && a.n >= 64 && a.m >= 16) {
+  if (g_semilag_variant != 0 && aligned && a.n >= 64 && a.m >= 16 && a.order != 3) {
     if (g_semilag_variant == 2) return launch_variant<2, true>(a, stream);
     return launch_variant<4, true>(a, stream);
   }

@@ -75,5 +75,64 @@ __device__ __forceinline__ float sample_precip_border(const float *p, int X, int
 }
 
 
+// ---- interp_order = 3 -------------------------------------------------------------------
+// map_coordinates(order=3, mode="constant") on the prefiltered coefficients (csrc/spline.hip)
+// plus the two order-1 mask warps of pysteps/extrapolation/semilagrangian.py:234-253: pixels
+// whose warped "finite" mask is < 0.5 become NaN (this includes everything advected from
+// outside, whatever outval is), pixels whose warped "above the minimum" mask is < 0.5 become
+// the minimum.  Both masks are functions of the original field, so they are evaluated from its
+// four order-1 taps instead of from two extra planes.
+__device__ __forceinline__ int mirror101(int i, int n) {
+  if (n == 1) return 0;
+  if (i < 0) i = -i;
+  if (i >= n) {
+    const int period = 2 * (n - 1);
+    i %= period;
+    if (i >= n) i = period - i;
+  }
+  return i;
+}
+
+__device__ __forceinline__ void bspline3(float t, float (&w)[4]) {
+  const float u = 1.f - t;
+  w[0] = u * u * u * (1.f / 6.f);
+  w[1] = (3.f * t * t * t - 6.f * t * t + 4.f) * (1.f / 6.f);
+  w[2] = (-3.f * t * t * t + 3.f * t * t + 3.f * t + 1.f) * (1.f / 6.f);
+  w[3] = t * t * t * (1.f / 6.f);
+}
+
+__device__ __forceinline__ float sample_precip_cubic(const float *coef, const float *p, int X, int Y,
+                                                     float fx, float fy, int m, int n,
+                                                     float minval) {
+  const bool outside = X < 0 || Y < 0 || X > n - 1 || Y > m - 1 || (X == n - 1 && fx > 0.f) ||
+                       (Y == m - 1 && fy > 0.f);
+  if (outside) return __builtin_nanf("");
+  const int x1 = (X + 1 > n - 1) ? max(n - 2, 0) : X + 1;
+  const int y1 = (Y + 1 > m - 1) ? max(m - 2, 0) : Y + 1;
+  const unsigned r0 = static_cast<unsigned>(__mul24(Y, n)), r1 = static_cast<unsigned>(__mul24(y1, n));
+  const float v00 = ld(p, (r0 + X) << 2), v01 = ld(p, (r0 + x1) << 2);
+  const float v10 = ld(p, (r1 + X) << 2), v11 = ld(p, (r1 + x1) << 2);
+  const Weights w = make_weights(fx, fy);
+  const float finite = blend(w, isfinite(v00) ? 1.f : 0.f, isfinite(v01) ? 1.f : 0.f,
+                             isfinite(v10) ? 1.f : 0.f, isfinite(v11) ? 1.f : 0.f);
+  if (finite < 0.5f) return __builtin_nanf("");
+  const float above = blend(w, v00 > minval ? 1.f : 0.f, v01 > minval ? 1.f : 0.f,
+                            v10 > minval ? 1.f : 0.f, v11 > minval ? 1.f : 0.f);
+  if (above < 0.5f) return minval;
+  float wx[4], wy[4];
+  bspline3(fx, wx);
+  bspline3(fy, wy);
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const unsigned row = static_cast<unsigned>(__mul24(mirror101(Y - 1 + a, m), n));
+    float line = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) line = fmaf(wx[b], ld(coef, (row + mirror101(X - 1 + b, n)) << 2), line);
+    acc = fmaf(wy[a], line, acc);
+  }
+  return acc;
+}
+
 }  // namespace sl
 }  // namespace psh

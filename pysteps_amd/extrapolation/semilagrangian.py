@@ -12,7 +12,7 @@ Differences, all documented in DESIGN.md:
 * arithmetic is float32 on device (the reference computes in float64 inside
   SciPy); the advected field is within 1e-4 relative L2 of the reference (measured
   ~1e-6) and the returned displacement is float64 like the reference's;
-* options the kernel does not implement (``interp_order > 1``,
+* options the kernel does not implement (``interp_order`` other than 0/1/3,
   ``map_coordinates_mode != "constant"``, custom ``xy_coords``, non-finite
   velocities) are delegated to the reference implementation when pysteps is
   importable and raise ``NotImplementedError`` otherwise;
@@ -147,7 +147,7 @@ def extrapolate(
         raise ValueError("precip and velocity have incompatible shapes")
 
     # ---- options outside the kernel's contract -------------------------
-    if interp_order not in (0, 1):
+    if interp_order not in (0, 1, 3):
         return _unsupported("interp_order=%r" % (interp_order,), call_args, call_kwargs)
     if map_coordinates_mode != "constant":
         return _unsupported("map_coordinates_mode=%r" % (map_coordinates_mode,), call_args, call_kwargs)

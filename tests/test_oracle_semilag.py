@@ -17,7 +17,7 @@ from conftest import nan_mismatch
 
 GOLDEN_SL = [
     "sl_int_T6", "sl_shear_K3", "sl_K0", "sl_list_vt", "sl_nan_min", "sl_nan_nan",
-    "sl_order0", "sl_resume", "sl_resume_K0", "sl_f64",
+    "sl_order0", "sl_resume", "sl_resume_K0", "sl_f64", "sl_order3", "sl_order3_nan",
 ]
 
 
@@ -45,11 +45,11 @@ def test_reference_known_answers(backend, speed, timesteps):
 
 def _run(backend, c):
     kw = dict(c["kw"])
-    kw.pop("allow_nonfinite_values", None)
+    allow = bool(kw.pop("allow_nonfinite_values", False)) or not np.all(np.isfinite(c["precip"]))
     if backend == "c":
         return ocl.extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **kw)
     return osl.extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True,
-                           allow_nonfinite_values=True, backend=backend, **kw)
+                           allow_nonfinite_values=allow, backend=backend, **kw)
 
 
 @pytest.mark.parametrize("backend", ["numpy", "scipy", "c"])
@@ -58,6 +58,8 @@ def test_oracle_matches_reference_golden(semilag_golden, backend, name):
     c = semilag_golden.case(name)
     if backend == "c" and c["precip"].dtype != np.float32:
         pytest.skip("the C port takes float32 fields")
+    if backend == "c" and c["kw"].get("interp_order", 1) > 1:
+        pytest.skip("the C port restates interpolation order 0/1")
     out, disp = _run(backend, c)
     assert out.shape == c["out"].shape
     if backend != "c":

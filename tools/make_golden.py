@@ -37,6 +37,8 @@ def semilag_cases():
         "sl_order0": dict(precip=P, velocity=Vs, timesteps=3, kw=dict(interp_order=0, outval=-15.0)),
         "sl_resume": dict(precip=P, velocity=Vs, timesteps=[1.5], kw=dict(displacement_prev=D0, n_iter=1)),
         "sl_resume_K0": dict(precip=P, velocity=Vs, timesteps=[0.5, 1.5], kw=dict(displacement_prev=D0, n_iter=0)),
+        "sl_order3": dict(precip=P, velocity=Vs, timesteps=3, kw=dict(interp_order=3, outval=-15.0)),
+        "sl_order3_nan": dict(precip=Pn, velocity=V, timesteps=2, kw=dict(interp_order=3, allow_nonfinite_values=True)),
         "sl_f64": dict(precip=P.astype(np.float64), velocity=Vs.astype(np.float64), timesteps=2, kw={}),
     }
 
