@@ -206,6 +206,34 @@ int psh_lk_track_pyr_dev(void *handle, const float *points_host, int npts, int m
                          double epsilon, double min_eig_threshold, float *next_points_host,
                          unsigned char *status_host);
 
+/* Whole dense_lucaskanade (pysteps/motion/lucaskanade.py:182-279, default detector and
+ * interpolator) in one call, composed of the stage entry points above/below; keeps the
+ * interpreter out of the four device->host hand-offs of the sparse stage.
+ *  frames (nframes,m,n) f32 device (NaN/Inf = missing).  field_dev (2,m,n) f32 or NULL; with
+ *  NULL the sparse vectors after outlier removal are returned instead (dense=False):
+ *  xy_host / uv_host (capacity,2) f64, *count_out rows.  Fields of psh_lk_params follow the
+ *  reference's keyword arguments (lk_kwargs / fd_kwargs / interp_kwargs and the function's own). */
+typedef struct psh_lk_params {
+  int size_opening;          /* 0 or 3 (lucaskanade.py:48, images.py:27) */
+  int buffer_mask;           /* shitomasi.py:33 */
+  int max_corners;           /* max_corners / max_num_features */
+  int block_size;            /* odd, <= 7 */
+  double quality_level, min_distance;
+  int win_w, win_h;          /* winsize */
+  int max_level;             /* nr_levels */
+  int max_count;             /* criteria: iteration count */
+  double epsilon;            /* criteria: epsilon */
+  double min_eig_threshold;  /* min_eig_thr */
+  double nr_std_outlier;
+  int k_outlier;
+  double decl_scale;
+  int idw_k;                 /* <= 0: use every vector (k=None) */
+  double idw_power, idw_dist_offset;
+} psh_lk_params;
+int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int n, const psh_lk_params *params,
+                     float *field_dev, double *xy_host, double *uv_host, int capacity,
+                     int *count_out);
+
 /* ---- sparse vector QC: local Mahalanobis outlier test ----------------------- *
  * The form of pysteps/utils/cleansing.py:124-249 (detect_outliers) used by dense LK
  * (pysteps/motion/lucaskanade.py:252): for every 2-vector the k nearest OTHER

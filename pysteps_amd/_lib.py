@@ -22,6 +22,20 @@ PSH_ECOMM = -5
 PSH_EUNSUPPORTED = -6
 
 
+class LkParams(ctypes.Structure):
+    """struct psh_lk_params of include/pysteps_hip.h."""
+
+    _fields_ = [
+        ("size_opening", c_int), ("buffer_mask", c_int), ("max_corners", c_int), ("block_size", c_int),
+        ("quality_level", c_double), ("min_distance", c_double),
+        ("win_w", c_int), ("win_h", c_int), ("max_level", c_int), ("max_count", c_int),
+        ("epsilon", c_double), ("min_eig_threshold", c_double),
+        ("nr_std_outlier", c_double), ("k_outlier", c_int),
+        ("decl_scale", c_double),
+        ("idw_k", c_int), ("idw_power", c_double), ("idw_dist_offset", c_double),
+    ]
+
+
 class HipLibraryError(RuntimeError):
     """libpysteps_hip.so is missing, failed to load, or a HIP/RCCL call failed."""
 
@@ -69,6 +83,7 @@ SIGNATURES = {
     "psh_lk_track_pyr_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
     "psh_db_transform_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_double, c_double, c_int]),
     "psh_field_stats_dev": (c_int, [c_void_p, c_size_t, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "psh_dense_lk_dev": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(LkParams), c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_semilag_rows_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,180 @@
+// Whole dense Lucas-Kanade estimate in one C-ABI call.
+//
+// Orchestration of pysteps/motion/lucaskanade.py:182-279 (dense_lucaskanade) for the default
+// detector / interpolator pair, built from the stage entry points of this library
+// (psh_lk_*, psh_outliers_local_host, psh_decluster_host, psh_idw_dev).  It exists to keep the
+// interpreter out of the critical path: between the four device->host hand-offs of the sparse
+// stage only a few microseconds of C++ run instead of ~0.3 ms of Python and ctypes marshalling
+// per estimate.  The Python shim (pysteps_amd/motion/lucaskanade.py) remains the reference
+// mirror and falls back to its own stage-by-stage loop for anything this call does not take.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+// RAII for psh_malloc blocks (stream-ordered free)
+struct DevBlock {
+  void *p = nullptr;
+  ~DevBlock() {
+    if (p) (void)psh_free(p);
+  }
+  int alloc(size_t bytes) { return psh_malloc(&p, bytes); }
+  template <class T>
+  T *as() const {
+    return static_cast<T *>(p);
+  }
+};
+
+__global__ __launch_bounds__(256) void fill_two_planes(float *out, size_t plane, float a, float b) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < 2 * plane; i += stride)
+    out[i] = i < plane ? a : b;
+}
+
+int fill_field(float *out_dev, size_t plane, float a, float b) {
+  psh::Context &c = psh::ctx();
+  hipLaunchKernelGGL(fill_two_planes, dim3(2048), dim3(256), 0, c.stream, out_dev, plane, a, b);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+}  // namespace
+
+extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int n,
+                                const psh_lk_params *prm, float *field_dev, double *xy_host,
+                                double *uv_host, int capacity, int *count_out) {
+  PSH_REQUIRE_INIT();
+  if (!frames_dev || !prm) return psh::fail(PSH_EINVAL, "dense_lk: NULL pointer");
+  if (nframes < 1 || m <= 0 || n <= 0) return psh::fail(PSH_EINVAL, "dense_lk: invalid shape");
+  if (!field_dev && !(xy_host && uv_host && count_out))
+    return psh::fail(PSH_EINVAL, "dense_lk: neither a dense output nor sparse output buffers given");
+  if (prm->max_corners <= 0) return psh::fail(PSH_EINVAL, "dense_lk: max_corners must be positive");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t plane = static_cast<size_t>(m) * n;
+
+  // ---- per frame: cleaning + uint8 renderings (lucaskanade.py:213-224) -----------------
+  std::vector<DevBlock> clean(nframes), trk(nframes), feat(nframes), stats(nframes);
+  for (int t = 0; t < nframes; ++t) {
+    const bool want_feat = t < nframes - 1;
+    if (int rc = clean[t].alloc(plane * sizeof(float))) return rc;
+    if (int rc = trk[t].alloc(plane)) return rc;
+    if (want_feat)
+      if (int rc = feat[t].alloc(plane)) return rc;
+    if (int rc = stats[t].alloc(8 * sizeof(float))) return rc;
+    if (int rc = psh_lk_prepare_dev(frames_dev + static_cast<size_t>(t) * plane, m, n, prm->size_opening,
+                                    prm->buffer_mask, clean[t].as<float>(), trk[t].as<unsigned char>(),
+                                    want_feat ? feat[t].as<unsigned char>() : nullptr, stats[t].as<float>()))
+      return rc;
+  }
+
+  // ---- per frame pair: features, tracking, pooling (:207-242) ---------------------------
+  std::vector<double> xy, uv;
+  std::vector<float> pts(static_cast<size_t>(prm->max_corners) * 2), nxt(pts.size());
+  std::vector<unsigned char> st(static_cast<size_t>(prm->max_corners));
+  for (int t = 0; t + 1 < nframes; ++t) {
+    if (int rc = psh_lk_corners_launch_dev(feat[t].as<unsigned char>(), clean[t].as<float>(),
+                                           stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
+                                           prm->quality_level, prm->min_distance, prm->max_corners))
+      return rc;
+    void *pyr = nullptr;  // built on the device while the host orders the corner candidates
+    int rc = psh_lk_pyramids_dev(trk[t].as<unsigned char>(), trk[t + 1].as<unsigned char>(), m, n, prm->win_w,
+                                 prm->win_h, prm->max_level, &pyr);
+    int npts = 0;
+    const int rc2 = psh_lk_corners_finish(pts.data(), &npts);
+    if (rc || rc2) {
+      (void)psh_lk_pyramids_free(pyr);
+      return rc ? rc : rc2;
+    }
+    if (npts > 0)
+      rc = psh_lk_track_pyr_dev(pyr, pts.data(), npts, prm->max_count, prm->epsilon, prm->min_eig_threshold,
+                                nxt.data(), st.data());
+    const int rc3 = psh_lk_pyramids_free(pyr);
+    if (rc || rc3) return rc ? rc : rc3;
+    for (int i = 0; i < npts; ++i) {
+      if (!st[i]) continue;
+      xy.push_back(pts[2 * i]);
+      xy.push_back(pts[2 * i + 1]);
+      // float32 difference, like p1 - p0 of the float32 OpenCV arrays (tracking/lucaskanade.py:181)
+      uv.push_back(static_cast<double>(nxt[2 * i] - pts[2 * i]));
+      uv.push_back(static_cast<double>(nxt[2 * i + 1] - pts[2 * i + 1]));
+    }
+  }
+  int count = static_cast<int>(xy.size() / 2);
+
+  // ---- outlier removal (:252-254) ----------------------------------------------------------
+  if (count > 0) {
+    std::vector<unsigned char> flags(static_cast<size_t>(count), 0);
+    if (int rc = psh_outliers_local_host(xy.data(), uv.data(), count, prm->k_outlier, prm->nr_std_outlier,
+                                         flags.data()))
+      return rc;
+    int kept = 0;
+    for (int i = 0; i < count; ++i) {
+      if (flags[i]) continue;
+      xy[2 * kept] = xy[2 * i];
+      xy[2 * kept + 1] = xy[2 * i + 1];
+      uv[2 * kept] = uv[2 * i];
+      uv[2 * kept + 1] = uv[2 * i + 1];
+      ++kept;
+    }
+    count = kept;
+  }
+  if (!field_dev) {  // sparse vectors requested (dense=False, :260-261)
+    if (count > capacity) return psh::fail(PSH_EINVAL, "dense_lk: %d vectors exceed the output capacity %d", count, capacity);
+    for (int i = 0; i < 2 * count; ++i) {
+      xy_host[i] = xy[i];
+      uv_host[i] = uv[i];
+    }
+    *count_out = count;
+    return PSH_OK;
+  }
+
+  // ---- declustering (:264-265) and interpolation (:272-274) ----------------------------------
+  if (count > 0 && prm->decl_scale > 1.0) {
+    std::vector<double> dxy(static_cast<size_t>(count) * 2), duv(static_cast<size_t>(count) * 2);
+    int kept = 0;
+    if (int rc = psh_decluster_host(xy.data(), uv.data(), count, prm->decl_scale, 1, dxy.data(), duv.data(), &kept))
+      return rc;
+    xy.assign(dxy.begin(), dxy.begin() + 2 * kept);
+    uv.assign(duv.begin(), duv.begin() + 2 * kept);
+    count = kept;
+  }
+  if (count_out) *count_out = count;
+  if (count == 0) return fill_field(field_dev, plane, 0.f, 0.f);  // :245-249, :268-269
+  double vmin = uv[0], vmax = uv[0];
+  for (int i = 1; i < 2 * count; ++i) {
+    vmin = std::fmin(vmin, uv[i]);
+    vmax = std::fmax(vmax, uv[i]);
+  }
+  if (count == 1) return fill_field(field_dev, plane, static_cast<float>(uv[0]), static_cast<float>(uv[1]));
+  if (vmin == vmax)  // "all equal elements" of the interpolator preamble (decorators.py:207-208)
+    return fill_field(field_dev, plane, static_cast<float>(uv[0]), static_cast<float>(uv[0]));
+
+  std::vector<float> fxy(static_cast<size_t>(count) * 2), fuv(fxy.size());
+  double xmin = 0.0, xmax = n - 1.0, ymin = 0.0, ymax = m - 1.0;
+  for (int i = 0; i < count; ++i) {
+    fxy[2 * i] = static_cast<float>(xy[2 * i]);
+    fxy[2 * i + 1] = static_cast<float>(xy[2 * i + 1]);
+    fuv[2 * i] = static_cast<float>(uv[2 * i]);
+    fuv[2 * i + 1] = static_cast<float>(uv[2 * i + 1]);
+    xmin = std::fmin(xmin, xy[2 * i]);
+    xmax = std::fmax(xmax, xy[2 * i]);
+    ymin = std::fmin(ymin, xy[2 * i + 1]);
+    ymax = std::fmax(ymax, xy[2 * i + 1]);
+  }
+  DevBlock samples;
+  const size_t sbytes = fxy.size() * sizeof(float);
+  if (int rc = samples.alloc(2 * sbytes)) return rc;
+  float *d_xy = samples.as<float>(), *d_uv = d_xy + fxy.size();
+  PSH_HIP(hipMemcpyAsync(d_xy, fxy.data(), sbytes, hipMemcpyHostToDevice, c.stream));
+  PSH_HIP(hipMemcpyAsync(d_uv, fuv.data(), sbytes, hipMemcpyHostToDevice, c.stream));
+  // the staging vectors die with this call: wait for the (tiny) uploads, not for the kernel
+  PSH_HIP(hipStreamSynchronize(c.stream));
+  const double reach = std::hypot(xmax - xmin, ymax - ymin) * 1.001 + 1.0;
+  const int k = prm->idw_k <= 0 ? count : prm->idw_k;
+  return psh_idw_dev(d_xy, d_uv, count, m, n, 0.0, 1.0, 0.0, 1.0, k, prm->idw_power, prm->idw_dist_offset, reach,
+                     field_dev);
+}

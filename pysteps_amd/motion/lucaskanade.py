@@ -32,6 +32,9 @@ from ..utils.interpolate import idw_to_device, idwinterp2d
 __all__ = ["dense_lucaskanade", "PreparedFrame", "detect_corners", "track_points"]
 
 _N_STATS = 8
+# set to False to run the stage-by-stage Python loop instead of psh_dense_lk_dev (same results;
+# used by the tests to keep both orchestrations honest)
+USE_NATIVE_ORCHESTRATION = True
 # one corner request (launch -> finish) is in flight per process: callers on several threads
 # (the reference is re-entrant and gets called from dask workers) take turns here
 _corner_lock = threading.Lock()
@@ -164,6 +167,50 @@ def track_points(prev, nxt, points, winsize=(50, 50), nr_levels=3, criteria=(3, 
     return p1, st.astype(bool)
 
 
+def _dense_lk_native(frames, on_device, dense, size_opening, buffer_mask, max_corners, quality_level,
+                     min_distance, block_size, winsize, nr_levels, criteria, min_eig_thr,
+                     nr_std_outlier, k_outlier, decl_scale, interp_kwargs):
+    """psh_dense_lk_dev; None if the request is outside what that call takes (the stage-by-stage
+    loop below then handles it)."""
+    if not USE_NATIVE_ORCHESTRATION or set(interp_kwargs) - {"power", "k", "dist_offset", "nchunks", "hkey"}:
+        return None
+    if k_outlier is None or np.ndim(decl_scale) != 0:
+        return None
+    nr_fields, m, n = frames.shape
+    max_count, eps = _criteria(criteria)
+    k_idw = interp_kwargs.get("k", 20)
+    prm = _lib.LkParams(
+        int(size_opening), int(buffer_mask), int(max_corners), int(block_size),
+        float(quality_level), float(min_distance), int(winsize[0]), int(winsize[1]), int(nr_levels),
+        max_count, eps, float(min_eig_thr), float(nr_std_outlier), int(k_outlier), float(decl_scale),
+        0 if k_idw is None else int(k_idw), float(interp_kwargs.get("power", 0.5)),
+        float(interp_kwargs.get("dist_offset", 0.5)),
+    )
+    lib = _lib.lib()
+    count = ctypes.c_int(0)
+    if dense:
+        field = DeviceArray((2, m, n), np.float32)
+        rc = lib.psh_dense_lk_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), field.ptr, None, None, 0,
+                                  ctypes.byref(count))
+        if rc == _lib.PSH_EUNSUPPORTED:
+            return None
+        _lib.check(rc, "psh_dense_lk_dev")
+        if on_device:
+            return field
+        if count.value == 0:
+            return np.zeros((2, m, n))
+        return field.to_host().astype(np.float64)
+    capacity = int(max_corners) * max(nr_fields - 1, 1)
+    xy = np.empty((capacity, 2), dtype=np.float64)
+    uv = np.empty((capacity, 2), dtype=np.float64)
+    rc = lib.psh_dense_lk_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), None, xy.ctypes.data,
+                              uv.ctypes.data, capacity, ctypes.byref(count))
+    if rc == _lib.PSH_EUNSUPPORTED:
+        return None
+    _lib.check(rc, "psh_dense_lk_dev")
+    return xy[: count.value].copy(), uv[: count.value].copy()
+
+
 def _reference_dense_lk():
     try:
         from pysteps.motion.lucaskanade import dense_lucaskanade as ref  # noqa: PLC0415
@@ -252,6 +299,17 @@ def dense_lucaskanade(
     nr_levels = lk_kwargs.get("nr_levels", 3)
     criteria = lk_kwargs.get("criteria", (3, 10, 0))
     min_eig_thr = lk_kwargs.get("min_eig_thr", 1e-4)
+
+    # ---- fast path: the whole estimate in one C-ABI call (csrc/dense_lk.hip) ----------------
+    native = _dense_lk_native(
+        frames, on_device, dense, size_opening, buffer_mask, max_corners, quality_level, min_distance,
+        block_size, winsize, nr_levels, criteria, min_eig_thr, nr_std_outlier, k_outlier, decl_scale,
+        interp_kwargs,
+    )
+    if native is not None:
+        if verbose:
+            print("--- total time: %.2f seconds ---" % (time.time() - t0))
+        return native
 
     prepared = [
         PreparedFrame(frames.view(t), size_opening, buffer_mask, want_features=t < nr_fields - 1)

@@ -255,3 +255,23 @@ def test_dense_lk_4096_recovers_true_motion(dense_lk):
     assert rmse < 0.25, rmse
     xy, uv = dense_lk(frames.to_host(), dense=False)
     assert 500 < len(xy) <= 1000
+
+
+def test_native_and_python_orchestration_agree(lkmod, dense_lk):
+    """psh_dense_lk_dev (one C call) and the stage-by-stage Python loop give the same results."""
+    frames, _ = _advected_frames(320, 288, 3, seed=17, nan=True)
+    try:
+        lkmod.USE_NATIVE_ORCHESTRATION = False
+        py_field = dense_lk(frames)
+        py_xy, py_uv = dense_lk(frames, dense=False)
+        py_opts = dense_lk(frames, fd_kwargs={"max_num_features": 40, "buffer_mask": 0}, decl_scale=0,
+                           interp_kwargs={"k": 5, "power": 2.0})
+    finally:
+        lkmod.USE_NATIVE_ORCHESTRATION = True
+    field = dense_lk(frames)
+    xy, uv = dense_lk(frames, dense=False)
+    opts = dense_lk(frames, fd_kwargs={"max_num_features": 40, "buffer_mask": 0}, decl_scale=0,
+                    interp_kwargs={"k": 5, "power": 2.0})
+    assert np.array_equal(xy, py_xy) and np.array_equal(uv, py_uv)
+    assert np.array_equal(field, py_field)
+    assert np.array_equal(opts, py_opts)
