@@ -57,7 +57,9 @@ class EnsembleAdvector:
                        "psh_velocity_unit_dev")
 
     def step(self, precip_members, t_diff, t_total=None):
-        """Advect all members by ``t_diff`` (velocity time steps); ``t_total`` is the lead time
+        """Advect all members by ``t_diff`` (lead-time increment(s) in velocity time steps, i.e.
+        the ``timestep_diff`` of the reference - a sequence gives several steps in one call);
+        ``t_total`` is the lead time
         handed to the perturbators (minutes, as in the reference).  ``precip_members``:
         (B,m,n) ndarray or float32 DeviceArray, or None for displacement only.
         Returns the advected members (B,m,n) in the container type of the input."""

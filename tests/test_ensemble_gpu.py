@@ -71,3 +71,18 @@ def test_members_equal_single_member_calls():
             want, d[j] = ex(members[j], V, [1.0], outval=-15.0, return_displacement=True, displacement_prev=d[j])
             assert np.max(np.abs(got[j] - want[0])) < 1e-5
     assert adv.step(None, 1.0) is None  # displacement-only call (utils.py:498-503)
+
+
+def test_single_member_and_nearest_order():
+    from pysteps_amd.extrapolation import get_method
+    from pysteps_amd.extrapolation.ensemble import EnsembleAdvector
+    from tools import synth
+
+    m, n = 70, 130
+    p = synth.rain_field_db(m, n, seed=2)[None]
+    V = synth.true_velocity(m, n)
+    adv = EnsembleAdvector(V, 1, interp_order=0, outval=-15.0)
+    got = adv.step(p, [1.0, 1.0])  # two lead-time INCREMENTS in one call -> (B, T, m, n)
+    want = get_method("semilagrangian")(p[0], V, [1.0, 2.0], outval=-15.0, interp_order=0)
+    assert got.shape == (1, 2, m, n)
+    assert np.count_nonzero(got[0] != want) <= 1e-4 * want.size

@@ -275,3 +275,30 @@ def test_native_and_python_orchestration_agree(lkmod, dense_lk):
     assert np.array_equal(xy, py_xy) and np.array_equal(uv, py_uv)
     assert np.array_equal(field, py_field)
     assert np.array_equal(opts, py_opts)
+
+
+@pytest.mark.parametrize("shape", [(30, 30), (51, 64), (64, 200), (7, 300)])
+def test_small_images_do_not_break(dense_lk, shape):
+    """Images smaller than / comparable to the 50x50 tracking window: same behaviour as the
+    restatement (features whose window cannot be placed are dropped), never a crash."""
+    from oracle import lk_opencv as olk
+
+    m, n = shape
+    tex = _texture(max(m, 64), max(n, 64), seed=m + n)[:m, :n]
+    frames = np.stack([tex, np.roll(tex, 1, axis=1)])
+    got = dense_lk(frames)
+    want = olk.dense_lucaskanade(frames)
+    assert got.shape == (2, m, n) and np.isfinite(got).all()
+    gxy, guv = dense_lk(frames, dense=False)
+    wxy, wuv = olk.dense_lucaskanade(frames, dense=False)
+    assert abs(len(gxy) - len(wxy)) <= max(2, 0.05 * len(wxy))
+    if len(wxy) and len(gxy) == len(wxy):
+        assert np.abs(got - want).max() < 1e-2
+
+
+def test_flat_and_constant_frames(dense_lk):
+    flat = np.full((2, 96, 96), 3.25, dtype=np.float32)
+    assert np.all(dense_lk(flat) == 0)
+    half = flat.copy()
+    half[:, :, :40] = np.nan
+    assert np.all(dense_lk(half) == 0)
