@@ -75,4 +75,13 @@ struct IdwArgs {
 };
 hipError_t launch_idw(const IdwArgs &a, hipStream_t stream);
 
+hipError_t launch_outliers_pooled(const double *xy_dev, const double *uv_dev, const int *count_dev,
+                                  int capacity, int k, double thr, unsigned char *flags_dev,
+                                  hipStream_t stream);
+// tracker with device-side pooling of the successful vectors (lk.hip); asynchronous, the host
+// points are staged in a pinned slot that stays valid until the stream has consumed it
+int lk_track_pool(void *pyramid_handle, const float *points_host, int npts, int max_count, double epsilon,
+                  double min_eig_threshold, double *pool_xy_dev, double *pool_uv_dev, int *pool_count_dev,
+                  int pool_capacity);
+
 }  // namespace psh

@@ -7,7 +7,9 @@
 // stage only a few microseconds of C++ run instead of ~0.3 ms of Python and ctypes marshalling
 // per estimate.  The Python shim (pysteps_amd/motion/lucaskanade.py) remains the reference
 // mirror and falls back to its own stage-by-stage loop for anything this call does not take.
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "common.h"
@@ -72,9 +74,23 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   }
 
   // ---- per frame pair: features, tracking, pooling (:207-242) ---------------------------
-  std::vector<double> xy, uv;
-  std::vector<float> pts(static_cast<size_t>(prm->max_corners) * 2), nxt(pts.size());
-  std::vector<unsigned char> st(static_cast<size_t>(prm->max_corners));
+  // The successful tracks of all pairs are pooled ON THE DEVICE (lk_pool_append) and the outlier
+  // test reads its sample count from device memory, so the only host hand-offs left are the
+  // ordered corner pass of each pair and ONE copy of (count, xy, uv, flags) at the end.
+  const int pairs = nframes - 1;
+  const int capacity_dev = prm->max_corners * (pairs > 0 ? pairs : 1);
+  if (capacity_dev > 8192)
+    return psh::fail(PSH_EUNSUPPORTED, "dense_lk: more than 8192 pooled vectors (max_corners x frame pairs)");
+  const size_t cap = static_cast<size_t>(capacity_dev);
+  const size_t off_uv = cap * 16, off_cnt = 2 * cap * 16, off_fl = off_cnt + 256;
+  DevBlock pool;
+  if (int rc = pool.alloc(off_fl + cap)) return rc;
+  char *pbase = pool.as<char>();
+  double *d_pxy = reinterpret_cast<double *>(pbase), *d_puv = reinterpret_cast<double *>(pbase + off_uv);
+  int *d_pcnt = reinterpret_cast<int *>(pbase + off_cnt);
+  unsigned char *d_pfl = reinterpret_cast<unsigned char *>(pbase + off_fl);
+  PSH_HIP(hipMemsetAsync(d_pcnt, 0, sizeof(int), c.stream));
+  std::vector<float> pts(static_cast<size_t>(prm->max_corners) * 2);
   for (int t = 0; t + 1 < nframes; ++t) {
     if (int rc = psh_lk_corners_launch_dev(feat[t].as<unsigned char>(), clean[t].as<float>(),
                                            stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
@@ -90,38 +106,38 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
       return rc ? rc : rc2;
     }
     if (npts > 0)
-      rc = psh_lk_track_pyr_dev(pyr, pts.data(), npts, prm->max_count, prm->epsilon, prm->min_eig_threshold,
-                                nxt.data(), st.data());
-    const int rc3 = psh_lk_pyramids_free(pyr);
+      rc = psh::lk_track_pool(pyr, pts.data(), npts, prm->max_count, prm->epsilon, prm->min_eig_threshold,
+                              d_pxy, d_puv, d_pcnt, capacity_dev);
+    const int rc3 = psh_lk_pyramids_free(pyr);  // stream-ordered: the tracker above is queued first
     if (rc || rc3) return rc ? rc : rc3;
-    for (int i = 0; i < npts; ++i) {
-      if (!st[i]) continue;
-      xy.push_back(pts[2 * i]);
-      xy.push_back(pts[2 * i + 1]);
-      // float32 difference, like p1 - p0 of the float32 OpenCV arrays (tracking/lucaskanade.py:181)
-      uv.push_back(static_cast<double>(nxt[2 * i] - pts[2 * i]));
-      uv.push_back(static_cast<double>(nxt[2 * i + 1] - pts[2 * i + 1]));
-    }
+  }
+  // ---- outlier removal (:252-254) on the pooled vectors, then one hand-off to the host ------
+  PSH_HIP(psh::launch_outliers_pooled(d_pxy, d_puv, d_pcnt, capacity_dev, prm->k_outlier, prm->nr_std_outlier,
+                                      d_pfl, c.stream));
+  static void *pinned = nullptr;  // (count | xy | uv | flags) staging, sized for 8192 vectors
+  constexpr size_t kPinXy = 256, kPinUv = kPinXy + 8192 * 16, kPinFl = kPinUv + 8192 * 16, kPinBytes = kPinFl + 8192;
+  if (!pinned) PSH_HIP(hipHostMalloc(&pinned, kPinBytes, hipHostMallocDefault));
+  char *pin = static_cast<char *>(pinned);
+  PSH_HIP(hipMemcpyAsync(pin, d_pcnt, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipMemcpyAsync(pin + kPinXy, d_pxy, cap * 16, hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipMemcpyAsync(pin + kPinUv, d_puv, cap * 16, hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipMemcpyAsync(pin + kPinFl, d_pfl, cap, hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipStreamSynchronize(c.stream));
+  const int pooled = std::min(*reinterpret_cast<const int *>(pin), capacity_dev);
+  const double *hxy = reinterpret_cast<const double *>(pin + kPinXy);
+  const double *huv = reinterpret_cast<const double *>(pin + kPinUv);
+  const unsigned char *hfl = reinterpret_cast<const unsigned char *>(pin + kPinFl);
+  std::vector<double> xy, uv;
+  xy.reserve(2 * static_cast<size_t>(pooled));
+  uv.reserve(2 * static_cast<size_t>(pooled));
+  for (int i = 0; i < pooled; ++i) {
+    if (pooled >= 2 && hfl[i]) continue;  // fewer than two samples: nothing is an outlier (:178-179)
+    xy.push_back(hxy[2 * i]);
+    xy.push_back(hxy[2 * i + 1]);
+    uv.push_back(huv[2 * i]);
+    uv.push_back(huv[2 * i + 1]);
   }
   int count = static_cast<int>(xy.size() / 2);
-
-  // ---- outlier removal (:252-254) ----------------------------------------------------------
-  if (count > 0) {
-    std::vector<unsigned char> flags(static_cast<size_t>(count), 0);
-    if (int rc = psh_outliers_local_host(xy.data(), uv.data(), count, prm->k_outlier, prm->nr_std_outlier,
-                                         flags.data()))
-      return rc;
-    int kept = 0;
-    for (int i = 0; i < count; ++i) {
-      if (flags[i]) continue;
-      xy[2 * kept] = xy[2 * i];
-      xy[2 * kept + 1] = xy[2 * i + 1];
-      uv[2 * kept] = uv[2 * i];
-      uv[2 * kept + 1] = uv[2 * i + 1];
-      ++kept;
-    }
-    count = kept;
-  }
   if (!field_dev) {  // sparse vectors requested (dense=False, :260-261)
     if (count > capacity) return psh::fail(PSH_EINVAL, "dense_lk: %d vectors exceed the output capacity %d", count, capacity);
     for (int i = 0; i < 2 * count; ++i) {
@@ -169,10 +185,19 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   const size_t sbytes = fxy.size() * sizeof(float);
   if (int rc = samples.alloc(2 * sbytes)) return rc;
   float *d_xy = samples.as<float>(), *d_uv = d_xy + fxy.size();
-  PSH_HIP(hipMemcpyAsync(d_xy, fxy.data(), sbytes, hipMemcpyHostToDevice, c.stream));
-  PSH_HIP(hipMemcpyAsync(d_uv, fuv.data(), sbytes, hipMemcpyHostToDevice, c.stream));
-  // the staging vectors die with this call: wait for the (tiny) uploads, not for the kernel
-  PSH_HIP(hipStreamSynchronize(c.stream));
+  // pinned staging ring: the uploads are asynchronous and outlive this call's vectors
+  static void *up_ring = nullptr;
+  static size_t up_slot = 0;
+  constexpr size_t kUpSlots = 8, kUpSlotBytes = 2 * 8192 * 2 * sizeof(float);
+  if (!up_ring) PSH_HIP(hipHostMalloc(&up_ring, kUpSlots * kUpSlotBytes, hipHostMallocDefault));
+  if (up_slot == kUpSlots) {
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    up_slot = 0;
+  }
+  char *up = static_cast<char *>(up_ring) + (up_slot++) * kUpSlotBytes;
+  std::memcpy(up, fxy.data(), sbytes);
+  std::memcpy(up + sbytes, fuv.data(), sbytes);
+  PSH_HIP(hipMemcpyAsync(d_xy, up, 2 * sbytes, hipMemcpyHostToDevice, c.stream));
   const double reach = std::hypot(xmax - xmin, ymax - ymin) * 1.001 + 1.0;
   const int k = prm->idw_k <= 0 ? count : prm->idw_k;
   return psh_idw_dev(d_xy, d_uv, count, m, n, 0.0, 1.0, 0.0, 1.0, k, prm->idw_power, prm->idw_dist_offset, reach,

@@ -667,6 +667,41 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
   }
 }
 
+// successful tracks -> pooled (xy, uv) float64 pairs in tracking order, appended behind the
+// vectors of earlier frame pairs (lucaskanade.py:241-242); one workgroup, ordered compaction
+__global__ __launch_bounds__(256) void lk_pool_append(const float2 *__restrict__ pts,
+                                                      const float2 *__restrict__ next_pts,
+                                                      const unsigned char *__restrict__ status, int npts,
+                                                      double2 *__restrict__ pool_xy,
+                                                      double2 *__restrict__ pool_uv,
+                                                      int *__restrict__ pool_count, int capacity) {
+  __shared__ int wave_total[4];
+  __shared__ int running;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) running = *pool_count;
+  __syncthreads();
+  for (int i0 = 0; i0 < npts; i0 += 256) {
+    const int i = i0 + tid;
+    const bool keep = i < npts && status[i] != 0;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) wave_total[wave] = __popcll(mask);
+    __syncthreads();
+    int pos = running;
+    for (int w = 0; w < wave; ++w) pos += wave_total[w];
+    pos += __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep && pos < capacity) {
+      const float2 p = pts[i], q = next_pts[i];
+      pool_xy[pos] = make_double2(p.x, p.y);
+      // float32 difference, like p1 - p0 of the float32 OpenCV arrays (tracking/lucaskanade.py:181)
+      pool_uv[pos] = make_double2(static_cast<double>(q.x - p.x), static_cast<double>(q.y - p.y));
+    }
+    __syncthreads();
+    if (tid == 0) running += wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+    __syncthreads();
+  }
+  if (tid == 0) *pool_count = running;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -1045,3 +1080,58 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
 }
 
 }  // extern "C"
+
+namespace psh {
+
+int lk_track_pool(void *pyramid_handle, const float *points_host, int npts, int max_count, double epsilon,
+                  double min_eig_threshold, double *pool_xy_dev, double *pool_uv_dev, int *pool_count_dev,
+                  int pool_capacity) {
+  if (!pyramid_handle || !points_host || !pool_xy_dev || !pool_uv_dev || !pool_count_dev)
+    return fail(PSH_EINVAL, "lk_track_pool: NULL pointer");
+  if (npts <= 0) return PSH_OK;
+  PyramidSet *ps = static_cast<PyramidSet *>(pyramid_handle);
+  max_count = std::min(std::max(max_count, 0), 100);
+  Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t pts_bytes = (static_cast<size_t>(npts) * sizeof(float2) + 255) & ~static_cast<size_t>(255);
+  void *blk = nullptr;
+  if (int rc = psh_malloc(&blk, 2 * pts_bytes + static_cast<size_t>(npts))) return rc;
+  char *base = static_cast<char *>(blk);
+  float2 *d_pts = reinterpret_cast<float2 *>(base);
+  float2 *d_next = reinterpret_cast<float2 *>(base + pts_bytes);
+  unsigned char *d_st = reinterpret_cast<unsigned char *>(base + 2 * pts_bytes);
+  // pinned staging slot per call (ring): the copy is asynchronous and the caller's buffer may
+  // be reused at once
+  static void *ring = nullptr;
+  static size_t ring_slot = 0;
+  constexpr size_t kSlots = 8, kSlotBytes = 1 << 16;
+  if (static_cast<size_t>(npts) * sizeof(float2) > kSlotBytes) {
+    (void)psh_free(blk);
+    return fail(PSH_EUNSUPPORTED, "lk_track_pool: more than %zu points", kSlotBytes / sizeof(float2));
+  }
+  if (!ring) PSH_HIP(hipHostMalloc(&ring, kSlots * kSlotBytes, hipHostMallocDefault));
+  if (ring_slot == kSlots) {
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    ring_slot = 0;
+  }
+  char *slot = static_cast<char *>(ring) + (ring_slot++) * kSlotBytes;
+  std::memcpy(slot, points_host, static_cast<size_t>(npts) * sizeof(float2));
+  const float eps = static_cast<float>(epsilon);
+  auto run = [&]() -> int {
+    PSH_HIP(hipMemcpyAsync(d_pts, slot, static_cast<size_t>(npts) * sizeof(float2), hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(lk_track, dim3(npts), dim3(256), 0, c.stream, ps->pyr, d_pts, npts, ps->win_w, ps->win_h,
+                       max_count, eps * eps, static_cast<float>(min_eig_threshold), d_next, d_st);
+    hipLaunchKernelGGL(lk_pool_append, dim3(1), dim3(256), 0, c.stream, d_pts, d_next, d_st, npts,
+                       reinterpret_cast<double2 *>(pool_xy_dev), reinterpret_cast<double2 *>(pool_uv_dev),
+                       pool_count_dev, pool_capacity);
+    PSH_HIP(hipGetLastError());
+    return PSH_OK;
+  };
+  const int rc = run();
+  (void)psh_free(blk);  // stream-ordered
+  return rc;
+}
+
+}  // namespace psh
+

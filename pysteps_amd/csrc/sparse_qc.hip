@@ -34,11 +34,21 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 }
 
 __global__ __launch_bounds__(64) void outliers_local(const double2 *__restrict__ xy,
-                                                     const double2 *__restrict__ uv, int n, int k,
+                                                     const double2 *__restrict__ uv, int n_host,
+                                                     const int *__restrict__ n_dev, int k,
                                                      double thr,
                                                      unsigned char *__restrict__ flags) {
   extern __shared__ unsigned long long keys[];
+  // the sample count is either known on the host or still sitting in device memory (the
+  // pooled tracker output); in the latter case the grid covers the capacity and extra
+  // workgroups leave at once
+  const int n = n_dev ? *n_dev : n_host;
   const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= n) return;
+  if (n < 2) {
+    if (lane == 0) flags[i] = 0;
+    return;
+  }
   const double2 me = xy[i], mine = uv[i];
   constexpr unsigned long long kGone = ~0ull;
   unsigned long long best = kGone;
@@ -92,6 +102,19 @@ __global__ __launch_bounds__(64) void outliers_local(const double2 *__restrict__
 }  // namespace
 }  // namespace psh
 
+namespace psh {
+// device-resident form used by the one-call dense LK: count in device memory, capacity rows
+hipError_t launch_outliers_pooled(const double *xy_dev, const double *uv_dev, const int *count_dev,
+                                  int capacity, int k, double thr, unsigned char *flags_dev,
+                                  hipStream_t stream) {
+  const size_t lds = static_cast<size_t>(capacity) * sizeof(unsigned long long);
+  hipLaunchKernelGGL(outliers_local, dim3(capacity), dim3(64), lds, stream,
+                     reinterpret_cast<const double2 *>(xy_dev), reinterpret_cast<const double2 *>(uv_dev), 0,
+                     count_dev, k, thr, flags_dev);
+  return hipGetLastError();
+}
+}  // namespace psh
+
 extern "C" int psh_outliers_local_host(const double *xy, const double *values, int n, int k,
                                        double thr, unsigned char *flags) {
   PSH_REQUIRE_INIT();
@@ -121,7 +144,8 @@ extern "C" int psh_outliers_local_host(const double *xy, const double *values, i
     PSH_HIP(hipMemcpyAsync(d_xy, xy, vec_bytes, hipMemcpyHostToDevice, c.stream));
     PSH_HIP(hipMemcpyAsync(d_uv, values, vec_bytes, hipMemcpyHostToDevice, c.stream));
     const size_t lds = static_cast<size_t>(n) * sizeof(unsigned long long);
-    hipLaunchKernelGGL(psh::outliers_local, dim3(n), dim3(64), lds, c.stream, d_xy, d_uv, n, k, thr, d_fl);
+    hipLaunchKernelGGL(psh::outliers_local, dim3(n), dim3(64), lds, c.stream, d_xy, d_uv, n, nullptr, k, thr,
+                       d_fl);
     PSH_HIP(hipGetLastError());
     PSH_HIP(hipMemcpyAsync(flags, d_fl, static_cast<size_t>(n), hipMemcpyDeviceToHost, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));
