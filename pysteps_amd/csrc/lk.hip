@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -368,10 +369,19 @@ __global__ __launch_bounds__(kFinalThreads) void lk_max_final(const float *__res
 }
 
 // ---- corner candidates: threshold, 3x3 non-maximum suppression, compaction ------
-struct Corner {
-  float val;
-  int x, y;
-};
+// candidate key: response bits in the high word (responses are positive, so the bit pattern
+// orders like the value), pixel address y*n + x in the low word; descending key order is the
+// order goodFeaturesToTrack walks the corners in (strongest first, ties: higher address first)
+using CornerKey = unsigned long long;
+__host__ __device__ inline CornerKey make_corner_key(float val, unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned bits = __float_as_uint(val);
+#else
+  unsigned bits;
+  std::memcpy(&bits, &val, sizeof(bits));
+#endif
+  return (static_cast<CornerKey>(bits) << 32) | addr;
+}
 
 constexpr int kSelRows = 64;  // rows per workgroup (16 per wave): one counter atomic per 64x64 pixels
 
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
                                                         const float *__restrict__ clean, int m,
                                                         int n, int buffer_mask, float quality,
                                                         const float *__restrict__ stats,
-                                                        Corner *__restrict__ out, int cap,
+                                                        CornerKey *__restrict__ out, int cap,
                                                         int *__restrict__ count) {
   __shared__ int wave_count[4];
   __shared__ int block_base;
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
     const unsigned long long mask = __ballot(keep);
     if (keep) {
       const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
-      if (at < cap) out[at] = Corner{v, x, y};
+      if (at < cap) out[at] = make_corner_key(v, static_cast<unsigned>(y) * n + x);
     }
     pos += __popcll(mask);
   }
@@ -775,13 +785,49 @@ struct CornerJob {
   bool active = false;
   int m = 0, n = 0, cap = 0, max_corners = 0;
   double min_distance = 0.0;
-  psh::Corner *cand_dev = nullptr;
+  psh::CornerKey *sorted_dev = nullptr;  // candidates in walking order (device)
+  psh::CornerKey *raw_dev = nullptr;     // unsorted candidates (overflow path)
   hipEvent_t ready = nullptr;
-  void *pinned = nullptr;  // [int count | pad | first kFirstChunk candidates]
+  void *pinned = nullptr;  // [int count | pad | first kFirstChunk sorted keys]
 };
-constexpr int kFirstChunk = 65536;
+constexpr int kSortSpan = 1 << 17;   // candidates ordered on the device (zero padded)
+constexpr int kFirstChunk = 1 << 13; // sorted keys that travel with the count (64 KiB)
 constexpr size_t kPinnedHeader = 64;
 CornerJob g_corner_job;
+
+// Greedy acceptance of goodFeaturesToTrack on a min_distance grid (featureselect.cpp): walk the
+// candidates strongest first, accept one unless an accepted corner lies closer than min_distance.
+// Accepted corners are chained per grid cell in flat arrays (no per-cell containers).
+struct GreedyGrid {
+  int cell, gw, gh, n;
+  double md2;
+  std::vector<int> head, next, px, py;
+  GreedyGrid(int m, int n_, double min_distance, int max_corners)
+      : cell(std::max(1, static_cast<int>(std::lrint(min_distance)))), n(n_),
+        md2(min_distance * min_distance) {
+    gw = (n + cell - 1) / cell;
+    gh = (m + cell - 1) / cell;
+    head.assign(static_cast<size_t>(gw) * gh, -1);
+    next.reserve(max_corners);
+    px.reserve(max_corners);
+    py.reserve(max_corners);
+  }
+  bool offer(int x, int y) {
+    const int xc = x / cell, yc = y / cell;
+    for (int yy = std::max(0, yc - 1); yy <= std::min(gh - 1, yc + 1); ++yy)
+      for (int xx = std::max(0, xc - 1); xx <= std::min(gw - 1, xc + 1); ++xx)
+        for (int q = head[static_cast<size_t>(yy) * gw + xx]; q >= 0; q = next[q]) {
+          const double dx = x - px[q], dy = y - py[q];
+          if (dx * dx + dy * dy < md2) return false;
+        }
+    const int id = static_cast<int>(px.size());
+    px.push_back(x);
+    py.push_back(y);
+    next.push_back(head[static_cast<size_t>(yc) * gw + xc]);
+    head[static_cast<size_t>(yc) * gw + xc] = id;
+    return true;
+  }
+};
 }  // namespace
 
 int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
@@ -793,6 +839,8 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
   if (block_size < 1 || block_size > 2 * psh::kMaxBlockR + 1 || (block_size & 1) == 0)
     return fail(PSH_EUNSUPPORTED, "lk_corners: block_size %d not implemented (odd, <= 7)", block_size);
   if (max_corners <= 0) return fail(PSH_EINVAL, "lk_corners: max_corners must be positive");
+  if (static_cast<uint64_t>(m) * static_cast<uint64_t>(n) >= (1ull << 32))
+    return fail(PSH_EUNSUPPORTED, "lk_corners: more than 2^32 pixels");
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
@@ -800,36 +848,45 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
   if (job.active) return fail(PSH_EINVAL, "lk_corners: a corner request is already in flight");
   if (!job.ready) PSH_HIP(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
   if (!job.pinned)
-    PSH_HIP(hipHostMalloc(&job.pinned, kPinnedHeader + kFirstChunk * sizeof(psh::Corner), hipHostMallocDefault));
+    PSH_HIP(hipHostMalloc(&job.pinned, kPinnedHeader + kFirstChunk * sizeof(psh::CornerKey), hipHostMallocDefault));
   const size_t npx = static_cast<size_t>(m) * n;
   const dim3 rgrid((n + psh::kCrnTX - 1) / psh::kCrnTX, (m + psh::kCrnTY - 1) / psh::kCrnTY);
   const int nb = rgrid.x * rgrid.y;
-  const int cap = static_cast<int>(std::min<size_t>(npx / 6 + 4096, 1u << 26));
-  const size_t off_eig = 0, off_part = off_eig + npx * sizeof(float);
-  const size_t off_cnt = off_part + static_cast<size_t>(nb) * sizeof(float);
-  const size_t off_out = (off_cnt + 256) & ~static_cast<size_t>(255);
+  const int cap = static_cast<int>(std::max<size_t>(std::min<size_t>(npx / 6 + 4096, 1u << 26), kSortSpan));
+  size_t sort_temp = 0;
+  PSH_HIP(psh::sort_keys_desc(nullptr, nullptr, kSortSpan, nullptr, &sort_temp, c.stream));
+  auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  const size_t off_eig = 0, off_part = up(off_eig + npx * sizeof(float));
+  const size_t off_cnt = up(off_part + static_cast<size_t>(nb) * sizeof(float));
+  const size_t off_raw = up(off_cnt + sizeof(int));
+  const size_t off_sorted = up(off_raw + static_cast<size_t>(cap) * sizeof(psh::CornerKey));
+  const size_t off_temp = up(off_sorted + static_cast<size_t>(kSortSpan) * sizeof(psh::CornerKey));
   void *ws = nullptr;
-  if (int rc = psh::ensure_lk_ws(off_out + static_cast<size_t>(cap) * sizeof(psh::Corner), &ws)) return rc;
+  if (int rc = psh::ensure_lk_ws(off_temp + sort_temp, &ws)) return rc;
   char *base = static_cast<char *>(ws);
   float *eig = reinterpret_cast<float *>(base + off_eig);
   float *part = reinterpret_cast<float *>(base + off_part);
   int *cnt = reinterpret_cast<int *>(base + off_cnt);
-  psh::Corner *cand = reinterpret_cast<psh::Corner *>(base + off_out);
+  psh::CornerKey *raw = reinterpret_cast<psh::CornerKey *>(base + off_raw);
+  psh::CornerKey *sorted = reinterpret_cast<psh::CornerKey *>(base + off_sorted);
   hipLaunchKernelGGL(psh::lk_corner_response, rgrid, dim3(256), 0, c.stream, feature_u8_dev, clean_dev,
                      m, n, block_size, buffer_mask, stats_dev, eig, part);
   hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb, stats_dev,
                      static_cast<int>(psh::kEigMax));
   PSH_HIP(hipMemsetAsync(cnt, 0, sizeof(int), c.stream));
+  // the first kSortSpan slots are zeroed: unused ones sort behind every real (positive) key
+  PSH_HIP(hipMemsetAsync(raw, 0, static_cast<size_t>(kSortSpan) * sizeof(psh::CornerKey), c.stream));
   const dim3 sgrid((n + 63) / 64, (m + psh::kSelRows - 1) / psh::kSelRows);
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n,
-                     buffer_mask, static_cast<float>(quality_level), stats_dev, cand, cap, cnt);
+                     buffer_mask, static_cast<float>(quality_level), stats_dev, raw, cap, cnt);
   PSH_HIP(hipGetLastError());
-  // the count and the first chunk of candidates go to pinned memory right behind the
-  // kernel, so that work queued afterwards (pyramids) does not delay the host's pass
+  PSH_HIP(psh::sort_keys_desc(raw, sorted, kSortSpan, base + off_temp, &sort_temp, c.stream));
+  // the count and the head of the ordered list go to pinned memory right behind the sort,
+  // so that work queued afterwards (pyramids) does not delay the host's pass
   char *pin = static_cast<char *>(job.pinned);
   PSH_HIP(hipMemcpyAsync(pin, cnt, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-  const size_t first = std::min<size_t>(static_cast<size_t>(cap), kFirstChunk);
-  PSH_HIP(hipMemcpyAsync(pin + kPinnedHeader, cand, first * sizeof(psh::Corner), hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipMemcpyAsync(pin + kPinnedHeader, sorted, kFirstChunk * sizeof(psh::CornerKey),
+                         hipMemcpyDeviceToHost, c.stream));
   PSH_HIP(hipEventRecord(job.ready, c.stream));
   job.active = true;
   job.m = m;
@@ -837,7 +894,8 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
   job.cap = cap;
   job.max_corners = max_corners;
   job.min_distance = min_distance;
-  job.cand_dev = cand;
+  job.sorted_dev = sorted;
+  job.raw_dev = raw;
   return PSH_OK;
 }
 
@@ -853,70 +911,43 @@ int psh_lk_corners_finish(float *points_host, int *count_host) {
   PSH_HIP(hipEventSynchronize(job.ready));
   const int m = job.m, n = job.n, cap = job.cap, max_corners = job.max_corners;
   const double min_distance = job.min_distance;
-  (void)m;
   const char *pin = static_cast<const char *>(job.pinned);
   const int count = *reinterpret_cast<const int *>(pin);
   if (count > cap)
     return fail(PSH_EUNSUPPORTED, "lk_corners: %d corner candidates exceed the buffer of %d", count, cap);
-  std::vector<psh::Corner> h(static_cast<size_t>(count));
-  const size_t first = std::min<size_t>(h.size(), kFirstChunk);
-  if (first) std::memcpy(h.data(), pin + kPinnedHeader, first * sizeof(psh::Corner));
-  if (h.size() > first) {  // rare: more candidates than the first chunk holds
-    PSH_HIP(hipMemcpyAsync(h.data() + first, job.cand_dev + first, (h.size() - first) * sizeof(psh::Corner),
-                           hipMemcpyDeviceToHost, c.stream));
+  // ordered candidates: the device-sorted head first; the tail (rare) is fetched on demand; more
+  // candidates than the device ordered (very rare) are ordered here
+  std::vector<psh::CornerKey> keys;
+  const psh::CornerKey *head = reinterpret_cast<const psh::CornerKey *>(pin + kPinnedHeader);
+  size_t have = std::min<size_t>(static_cast<size_t>(count), kFirstChunk);
+  const bool device_sorted = count <= kSortSpan;
+  if (!device_sorted) {
+    keys.resize(static_cast<size_t>(count));
+    PSH_HIP(hipMemcpyAsync(keys.data(), job.raw_dev, keys.size() * sizeof(psh::CornerKey), hipMemcpyDeviceToHost,
+                           c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));
+    std::sort(keys.begin(), keys.end(), std::greater<psh::CornerKey>());
+    head = keys.data();
+    have = keys.size();
   }
-  // goodFeaturesToTrack: strongest first (ties: higher address first), then greedy
-  // acceptance on a min_distance grid (featureselect.cpp)
-  auto stronger = [n](const psh::Corner &a, const psh::Corner &b) {
-    if (a.val != b.val) return a.val > b.val;
-    return static_cast<long long>(a.y) * n + a.x > static_cast<long long>(b.y) * n + b.x;
-  };
-  // the greedy pass below rarely looks beyond a few thousand of the strongest
-  // candidates: order them chunk by chunk (nth_element + sort) instead of all at once
-  const size_t chunk = static_cast<size_t>(max_corners) * 4 + 1024;
-  size_t sorted_upto = 0;
-  auto ensure_sorted = [&](size_t upto) {
-    while (sorted_upto < upto && sorted_upto < h.size()) {
-      const size_t end = std::min(h.size(), sorted_upto + chunk);
-      if (end < h.size()) std::nth_element(h.begin() + sorted_upto, h.begin() + end, h.end(), stronger);
-      std::sort(h.begin() + sorted_upto, h.begin() + end, stronger);
-      sorted_upto = end;
-    }
-  };
+  GreedyGrid grid(m, n, min_distance, max_corners);
   int accepted = 0;
-  if (min_distance >= 1.0) {
-    const int cell = static_cast<int>(std::lrint(min_distance));
-    const int gw = (n + cell - 1) / cell, gh = (m + cell - 1) / cell;
-    std::vector<std::vector<std::pair<int, int>>> grid(static_cast<size_t>(gw) * gh);
-    const double md2 = min_distance * min_distance;
-    for (size_t ci = 0; ci < h.size(); ++ci) {
-      ensure_sorted(ci + 1);
-      const psh::Corner &k = h[ci];
-      const int xc = k.x / cell, yc = k.y / cell;
-      bool good = true;
-      for (int yy = std::max(0, yc - 1); yy <= std::min(gh - 1, yc + 1) && good; ++yy)
-        for (int xx = std::max(0, xc - 1); xx <= std::min(gw - 1, xc + 1) && good; ++xx)
-          for (const auto &q : grid[static_cast<size_t>(yy) * gw + xx]) {
-            const double dx = k.x - q.first, dy = k.y - q.second;
-            if (dx * dx + dy * dy < md2) {
-              good = false;
-              break;
-            }
-          }
-      if (!good) continue;
-      grid[static_cast<size_t>(yc) * gw + xc].emplace_back(k.x, k.y);
-      points_host[2 * accepted] = static_cast<float>(k.x);
-      points_host[2 * accepted + 1] = static_cast<float>(k.y);
-      if (++accepted == max_corners) break;
+  for (size_t ci = 0; ci < static_cast<size_t>(count) && accepted < max_corners; ++ci) {
+    if (ci == have) {  // the head is used up: bring the rest of the device-sorted list
+      keys.resize(static_cast<size_t>(count));
+      std::memcpy(keys.data(), head, have * sizeof(psh::CornerKey));
+      PSH_HIP(hipMemcpyAsync(keys.data() + have, job.sorted_dev + have, (keys.size() - have) * sizeof(psh::CornerKey),
+                             hipMemcpyDeviceToHost, c.stream));
+      PSH_HIP(hipStreamSynchronize(c.stream));
+      head = keys.data();
+      have = keys.size();
     }
-  } else {
-    ensure_sorted(static_cast<size_t>(max_corners));
-    for (const psh::Corner &k : h) {
-      points_host[2 * accepted] = static_cast<float>(k.x);
-      points_host[2 * accepted + 1] = static_cast<float>(k.y);
-      if (++accepted == max_corners) break;
-    }
+    const unsigned addr = static_cast<unsigned>(head[ci] & 0xffffffffull);
+    const int x = static_cast<int>(addr % static_cast<unsigned>(n)), y = static_cast<int>(addr / static_cast<unsigned>(n));
+    if (min_distance >= 1.0 && !grid.offer(x, y)) continue;
+    points_host[2 * accepted] = static_cast<float>(x);
+    points_host[2 * accepted + 1] = static_cast<float>(y);
+    ++accepted;
   }
   *count_host = accepted;
   return PSH_OK;
