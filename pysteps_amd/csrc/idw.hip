@@ -9,15 +9,18 @@
 //
 // Design (DESIGN.md "idw_knn"): selection-bound FP32 VALU work, no MFMA, almost no
 // HBM traffic (8 B written per pixel).
-//  * one 256-thread workgroup per 16x16-pixel tile.  A tile-level pre-pass prunes
-//    the L vectors to the candidates that can be among ANY pixel's k nearest:
-//    with c the tile centre, R any radius holding >= k vectors and h the tile's
-//    half diagonal, every pixel's k-NN lie within R + 2h of c.  R comes from an
-//    LDS histogram of centre distances (one pass, LDS atomics), candidates are
-//    compacted in index order (deterministic summation order) into LDS.
-//  * each thread then scans the ~25-40 candidates (LDS broadcast reads) keeping
-//    its k best in registers (unsorted set + running maximum, fully unrolled so
-//    the set never leaves VGPRs), and accumulates the weights.
+//  * one 256-thread workgroup per 16x16-pixel tile.  A tile-level pre-pass brackets the
+//    k-th nearest distance R of the tile centre c from an LDS histogram of centre
+//    distances (R_lo < R <= R_hi, one pass, LDS atomics).  With h the tile's half
+//    diagonal every pixel's k-th neighbour distance lies in [R-h, R+h], hence vectors
+//    beyond R_hi + 2h are pruned, vectors within R_lo - 2h are CERTAIN members of every
+//    pixel's neighbourhood, and only the ring in between is undecided.  Candidates are
+//    compacted in index order (deterministic summation order) into LDS as
+//    [certain | undecided].
+//  * each thread adds the certain vectors without any selection, then picks the
+//    k - n_certain nearest of the ~10-15 undecided ones (LDS broadcast reads; unsorted
+//    register set + running maximum, fully unrolled so it never leaves VGPRs; a
+//    tile-uniform branch uses an 8-slot set when that suffices) and adds them.
 //  * k >= L (use everything) and candidate overflow take a brute-force path.
 #include <cmath>
 #include <vector>
@@ -41,8 +44,8 @@ __device__ __forceinline__ float dist2(float ax, float ay, float bx, float by) {
 constexpr int kTile = 16;      // 16x16 pixels per workgroup (32x32 measured slower: the wider halo
 constexpr int kThreads = 256;  // adds ~35 % candidates per pixel, more than the pre-pass costs)
 constexpr int kRowsPerPass = kThreads / kTile;
-constexpr int kBins = 256;
-constexpr int kCandCap = 1024;  // candidates kept in LDS per tile (16 KiB)
+constexpr int kBins = 1024;  // centre-distance histogram: bin width = reach / 1024
+constexpr int kCandCap = 512;  // candidates kept in LDS per tile (8 KiB, twice: raw + classified)
 
 __device__ __forceinline__ float idw_weight(float d, float power, float offset) {
   const float t = d + offset;
@@ -148,6 +151,52 @@ struct TopK {
   }
 };
 
+// Pick the `need` nearest of the candidates cand[first .. first+count) for the pixel (px,py) and add
+// their weighted values to the running sums.  Two sweeps over the (LDS-resident, broadcast-read)
+// candidates: the first keeps the `need` smallest squared distances, the second collects every
+// candidate strictly below the largest of them plus as many AT that distance (index order) as
+// are needed.
+template <int KS>
+__device__ __forceinline__ void add_nearest(const float4 *cand, int first, int count, int need, float px,
+                                            float py, float inv_res, float power, float offset,
+                                            float &sw, float &su, float &sv) {
+  KSmallest<KS> top;
+  const int n_fill = min(need, count);
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    top.d2[j] = -INFINITY;  // unused slots can never be the maximum
+    if (j < n_fill) {
+      const float4 c = cand[first + j];
+      top.d2[j] = dist2(c.x, c.y, px, py);
+    }
+  }
+  top.refresh();
+  for (int i = n_fill; i < count; ++i) {
+    const float4 c = cand[first + i];
+    top.offer(dist2(c.x, c.y, px, py));
+  }
+  const float tau = top.worst;
+  int below = 0;
+#pragma unroll
+  for (int j = 0; j < KS; ++j) below += (top.d2[j] > -INFINITY && top.d2[j] < tau) ? 1 : 0;
+  int ties_wanted = n_fill - below;
+  for (int i = 0; i < count; ++i) {
+    const float4 c = cand[first + i];
+    const float d2 = dist2(c.x, c.y, px, py);
+    bool take = d2 < tau;
+    if (d2 == tau && ties_wanted > 0) {
+      take = true;
+      --ties_wanted;
+    }
+    if (take) {
+      const float w = idw_weight(fast_sqrt(d2) * inv_res, power, offset);
+      sw += w;
+      su += w * c.z;
+      sv += w * c.w;
+    }
+  }
+}
+
 // Brute force over all L vectors, optional k selection (used for k >= L and overflow).
 template <int KMAX>
 __device__ __forceinline__ void idw_pixel_global(const float2 *__restrict__ xy,
@@ -194,8 +243,10 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
                                                     float *__restrict__ out, int tiles_x,
                                                     int n_tiles, int tiles_per_xcd) {
   __shared__ int s_hist[kBins];
-  __shared__ float4 s_cand[kCandCap];  // x, y, u, v
-  __shared__ float s_radius;
+  __shared__ float4 s_raw[kCandCap];   // x, y, u, v of the pruned vectors, index order
+  __shared__ float4 s_cand[kCandCap];  // the same, classified: [certain | undecided]
+  __shared__ float s_radius, s_radius_lo;
+  __shared__ int s_split[2];  // number of certain / undecided candidates
 
   const int b = blockIdx.x;
   const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;  // XCD-contiguous tiles
@@ -225,13 +276,10 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
       atomicAdd(&s_hist[bin], 1);
     }
     __syncthreads();
-    if (tid < 64) {  // one wave: prefix over the 256 bins (4 per lane), first bin reaching k
-      int c[4], tot = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        c[q] = s_hist[tid * 4 + q];
-        tot += c[q];
-      }
+    if (tid < 64) {  // one wave: prefix over the bins (kBins/64 per lane), first bin reaching k
+      constexpr int kPer = kBins / 64;
+      int tot = 0;
+      for (int q = 0; q < kPer; ++q) tot += s_hist[tid * kPer + q];
       int incl = tot;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -240,15 +288,17 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
       }
       int run = incl - tot;
       int first = kBins;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        run += c[q];
-        if (run >= k && first == kBins) first = tid * 4 + q;
+      for (int q = 0; q < kPer; ++q) {
+        run += s_hist[tid * kPer + q];
+        if (run >= k && first == kBins) first = tid * kPer + q;
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) first = min(first, __shfl_xor(first, d));
-      // the last bin is open-ended: fall back to "everything"
-      if (tid == 0) s_radius = first >= kBins - 1 ? INFINITY : static_cast<float>(first + 1) * bin_w;
+      // R_lo < (k-th smallest centre distance) <= R_hi; the last bin is open-ended
+      if (tid == 0) {
+        s_radius = first >= kBins - 1 ? INFINITY : static_cast<float>(first + 1) * bin_w;
+        s_radius_lo = static_cast<float>(min(first, kBins - 1)) * bin_w;
+      }
     }
     __syncthreads();
     const float reach = s_radius + 2.f * half_diag + 1e-3f * (s_radius + half_diag);
@@ -281,13 +331,49 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
         const unsigned long long mask = __ballot(keep);
         if (keep) {
           const float2 val = uv[i0 + lane];
-          s_cand[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_float4(p.x, p.y, val.x, val.y);
+          s_raw[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_float4(p.x, p.y, val.x, val.y);
         }
         base += __popcll(mask);
       }
     }
     __syncthreads();
+    // ---- classification against the bracket R_lo < R <= R_hi of the k-th centre distance ------
+    // For a pixel p of the tile (|p - c| <= h) its k-th neighbour distance lies in [R-h, R+h], so a
+    // candidate with centre distance <= R_lo - 2h belongs to every pixel's k nearest ("certain")
+    // and one beyond R_hi + 2h (already pruned) to none; only the ring in between needs a
+    // per-pixel selection, of k - n_certain vectors.  Wave 0 orders the candidates
+    // [certain | undecided], each group in index order.
+    if (n_cand <= kCandCap) {
+      if (tid < 64) {
+        const float sure_below = s_radius_lo - 2.f * half_diag - 1e-3f * (s_radius_lo + half_diag);
+        int n_sure = 0, n_ring = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+          int at = pass == 0 ? 0 : n_sure;
+          for (int i0 = 0; i0 < n_cand; i0 += 64) {
+            const int i = i0 + tid;
+            bool keep = false;
+            float4 cnd = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n_cand) {
+              cnd = s_raw[i];
+              const float ddx = cnd.x - cx, ddy = cnd.y - cy;
+              const bool sure = sqrtf(ddx * ddx + ddy * ddy) <= sure_below;
+              keep = pass == 0 ? sure : !sure;
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (keep) s_cand[at + __popcll(mask & ((1ull << tid) - 1ull))] = cnd;
+            at += __popcll(mask);
+          }
+          if (pass == 0) n_sure = at; else n_ring = at - n_sure;
+        }
+        if (tid == 0) {
+          s_split[0] = n_sure;
+          s_split[1] = n_ring;
+        }
+      }
+      __syncthreads();
+    }
   }
+  const int n_sure = s_split[0], n_ring = s_split[1];
 
   for (int q = 0; q < kTile / kRowsPerPass; ++q) {
     const int ix = tx + (tid % kTile), iy = ty + (tid / kTile) + q * kRowsPerPass;
@@ -299,45 +385,19 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
       // no selection at all, or pathological clustering: exact brute force
       idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
     } else {
-      KSmallest<KMAX> top;
-      // the first k candidates go straight into their slots (n_cand >= k by construction
-      // of the radius; unused slots can never be the maximum), then one maximum scan
-      const int n_fill = min(k, n_cand);
-#pragma unroll
-      for (int j = 0; j < KMAX; ++j) {
-        top.d2[j] = -INFINITY;
-        if (j < n_fill) {
-          const float4 c = s_cand[j];  // same address in every lane: LDS broadcast
-          top.d2[j] = dist2(c.x, c.y, px, py);
-        }
-      }
-      top.refresh();
-      for (int i = n_fill; i < n_cand; ++i) {
-        const float4 c = s_cand[i];
-        top.offer(dist2(c.x, c.y, px, py));
-      }
-      // second sweep: everything strictly below the k-th smallest distance, plus as many
-      // of the candidates AT that distance (in index order) as are needed to reach k
-      const float tau = top.worst;
-      int below = 0;
-#pragma unroll
-      for (int j = 0; j < KMAX; ++j) below += (top.d2[j] > -INFINITY && top.d2[j] < tau) ? 1 : 0;
-      int ties_wanted = n_fill - below;
       float sw = 0.f, su = 0.f, sv = 0.f;
-      for (int i = 0; i < n_cand; ++i) {
-        const float4 c = s_cand[i];
-        const float d2 = dist2(c.x, c.y, px, py);
-        bool take = d2 < tau;
-        if (d2 == tau && ties_wanted > 0) {
-          take = true;
-          --ties_wanted;
-        }
-        if (take) {
-          const float w = idw_weight(fast_sqrt(d2) * inv_res, power, offset);
-          sw += w;
-          su += w * c.z;
-          sv += w * c.w;
-        }
+      for (int i = 0; i < n_sure; ++i) {  // in every pixel's neighbourhood: no selection
+        const float4 c = s_cand[i];    // same address in every lane: LDS broadcast
+        const float w = idw_weight(fast_sqrt(dist2(c.x, c.y, px, py)) * inv_res, power, offset);
+        sw += w;
+        su += w * c.z;
+        sv += w * c.w;
+      }
+      const int need = k - n_sure;  // >= 1: fewer than k vectors lie strictly inside R
+      if (need <= 8) {              // tile-uniform branch: small selection sets are much cheaper
+        add_nearest<8>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
+      } else {
+        add_nearest<KMAX>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
       }
       ou = su / sw;
       ov = sv / sw;
