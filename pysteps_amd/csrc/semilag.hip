@@ -46,6 +46,9 @@ namespace {
 using namespace sl;
 
 constexpr int kTileX = 64;
+// kernel flavours: direct gathers (one pixel per lane), LDS-staged tiles, direct gathers with
+// two horizontally adjacent pixels per lane
+enum : int { kModeDirect = 0, kModeStaged = 1, kModePairX = 2 };
 constexpr int kWavesPerBlock = 4;
 struct Fields {
   const float *u0, *u1, *v0, *v1, *p0, *p1;  // row r and row r+1 bases of each plane
@@ -62,14 +65,43 @@ __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned byte_off
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, static_cast<int>(byte_off), soff, 0));
 }
 
-// lane i receives the value of lane i+1 (v_mov_b32_dpp wave_shl:1); lane 63, which
-// has no right neighbour, keeps `fill`
-__device__ __forceinline__ int from_next_lane(int v, int fill) {
-  return __builtin_amdgcn_update_dpp(fill, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+// ---- cross-lane helpers ---------------------------------------------------------------
+// lane i receives the value of lane i+1 (v_mov_b32_dpp wave_shl:1); lane 63, which has no
+// right neighbour, reads 0 (bound_ctrl)
+__device__ __forceinline__ unsigned from_next_lane_or_zero(unsigned v) {
+  return static_cast<unsigned>(
+      __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float from_next_lane(float v) {
-  return __int_as_float(from_next_lane(__float_as_int(v), 0));
+
+// a VGPR whose content does not matter (lanes that are overwritten before use): spares the
+// zero-initialisation the compiler would otherwise emit in front of exec-masked loads
+__device__ __forceinline__ float any_value() {
+  float v;
+  asm volatile("" : "=v"(v));
+  return v;
 }
+
+// right[i] = own[i] ? right[i] : left[i + 1] for two / three planes x two tap rows, one VALU
+// instruction per value: v_cndmask_b32_dpp selects between the lane's own register and the
+// DPP-shifted left column of its neighbour.  Lane 63 has no neighbour: its write is
+// disabled by the DPP rule for invalid source lanes, and it is in `own` anyway.
+// s_nop 1 covers the two wait states a DPP read needs after a VALU write of its source.
+#define PSH_TAKE(R, L) "v_cndmask_b32_dpp %[" #R "], %[" #L "], %[" #R "], vcc wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void take_right_columns(unsigned long long own, float a, float c, float e,
+                                                   float g, float &b, float &d, float &f, float &h) {
+  asm("s_mov_b64 vcc, %[own]\n\ts_nop 1\n\t" PSH_TAKE(b, a) PSH_TAKE(d, c) PSH_TAKE(f, e) PSH_TAKE(h, g)
+      : [b] "+v"(b), [d] "+v"(d), [f] "+v"(f), [h] "+v"(h)
+      : [a] "v"(a), [c] "v"(c), [e] "v"(e), [g] "v"(g), [own] "s"(own)
+      : "vcc");
+}
+__device__ __forceinline__ void take_right_columns(unsigned long long own, float a, float c, float &b,
+                                                   float &d) {
+  asm("s_mov_b64 vcc, %[own]\n\ts_nop 1\n\t" PSH_TAKE(b, a) PSH_TAKE(d, c)
+      : [b] "+v"(b), [d] "+v"(d)
+      : [a] "v"(a), [c] "v"(c), [own] "s"(own)
+      : "vcc");
+}
+#undef PSH_TAKE
 
 // ---- fast path: every lane of the wave has all four taps strictly inside ----
 // The L1 (TCP) moves 64 B/clk/CU, so the fast path asks it for as few bytes as
@@ -86,16 +118,20 @@ __device__ __forceinline__ void sample_interior(const Fields &F, const int (&X)[
                                                 const float (&fy)[NPX], int n, float (&su)[NPX],
                                                 float (&sv)[NPX], float (&sp)[NPX]) {
   unsigned off[NPX];
-  bool shared[NPX];
+  unsigned long long own[NPX];
   float a[NPX], c[NPX], e[NPX], g[NPX], pa[NPX], pc[NPX];
   float b[NPX], d[NPX], f[NPX], h[NPX], pb[NPX], pd[NPX];
   const int rb = F.row_bytes;
 #pragma unroll
   for (int j = 0; j < NPX; ++j) {
     off[j] = static_cast<unsigned>(__mul24(Y[j], n) + X[j]) << 2;
-    shared[j] = from_next_lane(X[j], -2) == X[j] + 1 && from_next_lane(Y[j], -2) == Y[j];
-    b[j] = d[j] = f[j] = h[j] = pb[j] = pd[j] = 0.f;
-    if (!shared[j]) {
+    // interior positions have X + 1 <= n - 1, so "the neighbour's linear offset is mine + 1"
+    // is the same statement as "same row, next column"
+    const bool own_right = from_next_lane_or_zero(off[j]) != off[j] + 4u;
+    own[j] = __builtin_amdgcn_ballot_w64(own_right);
+    b[j] = any_value(), d[j] = any_value(), f[j] = any_value(), h[j] = any_value();
+    if (WITH_P) pb[j] = any_value(), pd[j] = any_value();
+    if (own_right) {
       b[j] = bld(F.ru, off[j] + 4u, 0);
       d[j] = bld(F.ru, off[j] + 4u, rb);
       f[j] = bld(F.rv, off[j] + 4u, 0);
@@ -112,19 +148,20 @@ __device__ __forceinline__ void sample_interior(const Fields &F, const int (&X)[
     c[j] = bld(F.ru, off[j], rb);
     e[j] = bld(F.rv, off[j], 0);
     g[j] = bld(F.rv, off[j], rb);
-    pa[j] = WITH_P ? bld(F.rp, off[j], 0) : 0.f;
-    pc[j] = WITH_P ? bld(F.rp, off[j], rb) : 0.f;
+    if (WITH_P) {
+      pa[j] = bld(F.rp, off[j], 0);
+      pc[j] = bld(F.rp, off[j], rb);
+    }
   }
 #pragma unroll
   for (int j = 0; j < NPX; ++j) {
     const Weights w = make_weights(fx[j], fy[j]);
-    const float a1 = from_next_lane(a[j]), c1 = from_next_lane(c[j]);
-    const float e1 = from_next_lane(e[j]), g1 = from_next_lane(g[j]);
-    su[j] = blend(w, a[j], shared[j] ? a1 : b[j], c[j], shared[j] ? c1 : d[j]);
-    sv[j] = blend(w, e[j], shared[j] ? e1 : f[j], g[j], shared[j] ? g1 : h[j]);
+    take_right_columns(own[j], a[j], c[j], e[j], g[j], b[j], d[j], f[j], h[j]);
+    su[j] = blend(w, a[j], b[j], c[j], d[j]);
+    sv[j] = blend(w, e[j], f[j], g[j], h[j]);
     if (WITH_P) {
-      const float pa1 = from_next_lane(pa[j]), pc1 = from_next_lane(pc[j]);
-      sp[j] = blend(w, pa[j], shared[j] ? pa1 : pb[j], pc[j], shared[j] ? pc1 : pd[j]);
+      take_right_columns(own[j], pa[j], pc[j], pb[j], pd[j]);
+      sp[j] = blend(w, pa[j], pb[j], pc[j], pd[j]);
     }
   }
 }
@@ -272,13 +309,13 @@ __device__ __forceinline__ bool sample_staged(const Fields &F, Stage &S, const i
 // What to sample at the NPX positions of a thread
 enum : int { kVel = 1, kPrecip = 2 };
 
-template <int NPX, int ORDER, int WHAT, bool LDS>
+template <int NPX, int ORDER, int WHAT, int MODE>
 __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (&X)[NPX],
                                           const int (&Y)[NPX], const float (&fx)[NPX],
                                           const float (&fy)[NPX], int m, int n, float outval,
                                           float (&su)[NPX], float (&sv)[NPX], float (&sp)[NPX]) {
   constexpr bool kWithP = (WHAT & kPrecip) != 0;
-  if (LDS) {
+  if (MODE == kModeStaged) {
     // every thread of the workgroup reaches this call (uniform loop structure)
     if (sample_staged<NPX, ORDER, kWithP>(F, S, X, Y, fx, fy, m, n, su, sv, sp)) return;
     // rare (border tiles, extreme deformation): plain clamped gathers, pixel by pixel
@@ -291,9 +328,9 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
   }
   bool inside = true;
 #pragma unroll
-  for (int j = 0; j < NPX; ++j) inside = inside && is_interior(X[j], Y[j], m, n);
+  for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(X[j], Y[j], m, n);
   // wave-uniform branch: interior waves (almost all of them) skip every clamp
-  if (__all(inside)) {
+  if (inside) {
     sample_interior<NPX, kWithP && ORDER == 1>(F, X, Y, fx, fy, n, su, sv, sp);
     if (kWithP && ORDER == 0) {
 #pragma unroll
@@ -323,7 +360,7 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
   }
 }
 
-template <int NPX, int ORDER, bool HAS_PRECIP, bool LDS>
+template <int NPX, int ORDER, bool HAS_PRECIP, int MODE>
 __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
     const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
@@ -356,7 +393,7 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
   F.coef = coef;
   F.minval = minval;
 
-  __shared__ float stage_buf[LDS ? 3 * kStageCap : 1];
+  __shared__ float stage_buf[MODE == kModeStaged ? 3 * kStageCap : 1];
   __shared__ int stage_red[16];
   Stage S;
   S.buf = stage_buf;
@@ -392,7 +429,7 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
       fx[j] = fminf(static_cast<float>(dx - flx), kMaxFrac);
       fy[j] = fminf(static_cast<float>(dy - fly), kMaxFrac);
     }
-    sample_at<NPX, ORDER, kVel, LDS>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+    sample_at<NPX, ORDER, kVel, MODE>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
     const float s0 = scale[0];
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
@@ -408,9 +445,20 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
     }
   }
 
+  // with n_iter > 0 the increment is only ever used halved (midpoint rule): carry Vi / 2,
+  // which is the same number as halving at the point of use (scaling by 2 is exact)
+  if (n_iter > 0) {
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) {
+      vix[j] *= 0.5f;
+      viy[j] *= 0.5f;
+    }
+  }
+
   for (int t = 0; t < T; ++t) {
     const float s = scale[t];  // (lead-time increment / vel_timestep) / max(n_iter, 1)
     if (n_iter > 0) {
+      const float half_s = 0.5f * s;
       for (int k = 0; k < n_iter; ++k) {
         int mx[NPX], my[NPX];
         float gx[NPX], gy[NPX];
@@ -420,29 +468,29 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
           my[j] = py[j];
           gx[j] = fx[j];
           gy[j] = fy[j];
-          retreat(mx[j], gx[j], 0.5f * vix[j]);  // midpoint rule (:213)
-          retreat(my[j], gy[j], 0.5f * viy[j]);
+          retreat(mx[j], gx[j], vix[j]);  // midpoint rule (:213), vix = Vi / 2
+          retreat(my[j], gy[j], viy[j]);
         }
-        sample_at<NPX, ORDER, kVel, LDS>(F, S, mx, my, gx, gy, m, n, outval, su, sv, sp);
+        sample_at<NPX, ORDER, kVel, MODE>(F, S, mx, my, gx, gy, m, n, outval, su, sv, sp);
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
           retreat(px[j], fx[j], su[j] * s);
           retreat(py[j], fy[j], sv[j] * s);
         }
         if (HAS_PRECIP && k == n_iter - 1) {
-          sample_at<NPX, ORDER, kVel | kPrecip, LDS>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+          sample_at<NPX, ORDER, kVel | kPrecip, MODE>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
         } else {
-          sample_at<NPX, ORDER, kVel, LDS>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+          sample_at<NPX, ORDER, kVel, MODE>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
         }
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
-          vix[j] = su[j] * s;
-          viy[j] = sv[j] * s;
+          vix[j] = su[j] * half_s;
+          viy[j] = sv[j] * half_s;
         }
       }
     } else {
       if (t > 0 || resume) {
-        sample_at<NPX, ORDER, kVel, LDS>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+        sample_at<NPX, ORDER, kVel, MODE>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
           vix[j] = su[j] * s;
@@ -457,8 +505,8 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
       if (HAS_PRECIP) {
         bool inside = true;
 #pragma unroll
-        for (int j = 0; j < NPX; ++j) inside = inside && is_interior(px[j], py[j], m, n);
-        if (ORDER == 1 && __all(inside)) {
+        for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(px[j], py[j], m, n);
+        if (ORDER == 1 && inside) {
           float v[NPX][4];
 #pragma unroll
           for (int j = 0; j < NPX; ++j) {
@@ -485,7 +533,9 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
     if (HAS_PRECIP) {
 #pragma unroll
       for (int j = 0; j < NPX; ++j)
-        if (live[j]) *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]) = sp[j];
+        // streamed once, never re-read: keep the output out of the L2 ways the input planes live in
+        if (live[j])
+          __builtin_nontemporal_store(sp[j], reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
       out += static_cast<size_t>(rows) * n;
     }
   }
@@ -502,7 +552,7 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
   }
 }
 
-template <int NPX, bool LDS>
+template <int NPX, int MODE>
 static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   const int tile_y = kWavesPerBlock * NPX;
   const int tiles_x = (a.n + kTileX - 1) / kTileX;
@@ -511,7 +561,7 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
   const dim3 grid(tiles_per_xcd * kNumXcd), block(kTileX * kWavesPerBlock);
 #define PSH_SL_LAUNCH(ORDER, HASP)                                                              \
-  hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, LDS>), grid, block, 0, stream, a.precip,   \
+  hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, MODE>), grid, block, 0, stream, a.precip,   \
                      a.vel, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter,     \
                      a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, tiles_x, n_tiles,           \
                      tiles_per_xcd)
@@ -520,7 +570,7 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   } else if (a.order == 0) {
     PSH_SL_LAUNCH(0, true);
   } else if (a.order == 3) {
-    if constexpr (!LDS) {
+    if constexpr (MODE != kModeStaged) {
       PSH_SL_LAUNCH(3, true);
     } else {
       return hipErrorInvalidValue;  // the staged variants are built for order 0/1
@@ -549,10 +599,10 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
   const bool aligned = (a.n % 4 == 0) && (reinterpret_cast<uintptr_t>(a.vel) % 16 == 0) &&
                        (a.precip == nullptr || reinterpret_cast<uintptr_t>(a.precip) % 16 == 0);
   if (g_semilag_variant != 0 && aligned && a.n >= 64 && a.m >= 16 && a.order != 3) {
-    if (g_semilag_variant == 2) return launch_variant<2, true>(a, stream);
-    return launch_variant<4, true>(a, stream);
+    if (g_semilag_variant == 2) return launch_variant<2, kModeStaged>(a, stream);
+    return launch_variant<4, kModeStaged>(a, stream);
   }
-  return launch_variant<1, false>(a, stream);
+  return launch_variant<1, kModeDirect>(a, stream);
 }
 
 }  // namespace psh

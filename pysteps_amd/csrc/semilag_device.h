@@ -23,9 +23,19 @@ __device__ __forceinline__ float ld(const float *base, unsigned byte_off, int el
 // how far the trajectory has travelled.
 __device__ __forceinline__ void retreat(int &P, float &f, float w) {
   const float t = f - w;
-  const float k = floorf(t);
-  P += static_cast<int>(k);
-  f = fminf(t - k, kMaxFrac);  // (-1e-9) - (-1) rounds to 1.0f: keep f < 1
+  int k;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k) : "v"(t));  // (int)floor(t), one instruction
+  P += k;
+  // v_fract_f32 = min(t - floor(t), 0x1.fffffep-1): (-1e-9) - (-1) would round to 1.0f, the
+  // instruction keeps f < 1 (checked on the device by tests/test_semilag_gpu.py::test_fraction_clamp)
+  f = __builtin_amdgcn_fractf(t);
+}
+
+// true when every active lane of the wave has all four taps strictly inside the image
+__device__ __forceinline__ bool wave_all_interior(int X, int Y, int m, int n) {
+  const unsigned long long bx = __builtin_amdgcn_ballot_w64(static_cast<unsigned>(X) < static_cast<unsigned>(n - 1));
+  const unsigned long long by = __builtin_amdgcn_ballot_w64(static_cast<unsigned>(Y) < static_cast<unsigned>(m - 1));
+  return (bx & by) == __builtin_amdgcn_ballot_w64(true);
 }
 
 struct Weights {

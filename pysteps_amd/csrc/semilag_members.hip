@@ -58,7 +58,7 @@ __device__ __forceinline__ void sample_member(const Planes &F, int X, int Y, flo
                                               float &sv, float &sp) {
   const Weights w = make_weights(fx, fy);
   float hu = 0.f, hv = 0.f;
-  if (__all(is_interior(X, Y, m, n))) {
+  if (wave_all_interior(X, Y, m, n)) {
     const unsigned off = static_cast<unsigned>(__mul24(Y, n) + X) << 2;
     su = tap4(F.u, off, F.row_bytes, w);
     sv = tap4(F.v, off, F.row_bytes, w);

@@ -314,3 +314,15 @@ def test_cubic_interpolation_vs_oracle(extrapolate):
         assert rel_l2(np.where(both, got, 0)[..., :][both][~flips], want[both][~flips]) < REL_L2_TOL
     dev = extrapolate(DeviceArray.from_host(p), DeviceArray.from_host(v), 3, interp_order=3)
     assert np.array_equal(dev.to_host(), extrapolate(p, v, 3, interp_order=3), equal_nan=True)
+
+
+def test_fraction_clamp(extrapolate):
+    """A tiny negative fraction (0 - 1e-9) must become (pixel - 1, largest float below 1), not
+    (pixel - 1, 1.0): the kernel relies on v_fract_f32 clamping its result below 1."""
+    m, n = 70, 130  # interior waves (DPP path) and border waves
+    precip = np.zeros((m, n), dtype=np.float32)
+    velocity = np.full((2, m, n), 1e-9, dtype=np.float32)
+    for n_iter in (0, 1):
+        _, disp = extrapolate(precip, velocity, 1, n_iter=n_iter, return_displacement=True)
+        # D = (P - x) + f = -1 + 0x1.fffffep-1 = -2^-24 (0 if the fraction were 1.0)
+        assert np.all(disp == np.float64(-(2.0**-24))), (n_iter, np.unique(disp))
