@@ -63,6 +63,9 @@ struct SemilagArgs {
 };
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
 void set_semilag_variant(int v);
+// three-pixels-per-lane kernel (semilag_wide.hip): interp_order 0/1, images >= 192 columns
+bool semilag_wide_eligible(const SemilagArgs &a);
+hipError_t launch_semilag_wide(const SemilagArgs &a, hipStream_t stream);
 hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream);
 
 struct IdwArgs {

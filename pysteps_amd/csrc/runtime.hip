@@ -141,8 +141,10 @@ int psh_shutdown(void) {
 int psh_set_option(const char *key, int value) {
   if (!key) return fail(PSH_EINVAL, "psh_set_option: NULL key");
   if (std::strcmp(key, "semilag_variant") == 0) {
-    if (value != 0 && value != 2 && value != 4)
-      return fail(PSH_EINVAL, "semilag_variant must be 0 (direct), 2 or 4 (LDS-staged rows per thread)");
+    if (value != 0 && value != 2 && value != 3 && value != 4)
+      return fail(PSH_EINVAL,
+                  "semilag_variant must be 0 (one pixel per lane), 3 (three pixels per lane), 2 or 4 "
+                  "(LDS-staged rows per thread)");
     psh::set_semilag_variant(value);
     return PSH_OK;
   }

@@ -584,9 +584,11 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
 
 }  // namespace
 
-// 0 = direct gathers + DPP column sharing (default), 4 / 2 = LDS-staged tiles with 4 / 2
-// rows per thread.  Measured equal at 4096^2 x 24 (1.85 vs 1.86 / 1.93 ms):
-// staging cuts the L1 traffic but adds two barriers per sampling pass and LDS traffic.
+// 0 = one pixel per lane, direct gathers + DPP column sharing (default); 4 / 2 = LDS-staged
+// tiles with 4 / 2 rows per thread (measured equal at 4096^2 x 24, DESIGN.md 3.1: staging cuts
+// the L1 traffic but adds two barriers per sampling pass); 3 = three pixels per lane with
+// dwordx4 gathers (semilag_wide.hip: faster in near-uniform motion, slower once most waves
+// carry a trajectory split).
 static int g_semilag_variant = [] {
   const char *e = std::getenv("PYSTEPS_HIP_SL_VARIANT");
   return e ? std::atoi(e) : 0;
@@ -598,7 +600,8 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
   // LDS staging needs 16-byte aligned rows (n % 4 == 0)
   const bool aligned = (a.n % 4 == 0) && (reinterpret_cast<uintptr_t>(a.vel) % 16 == 0) &&
                        (a.precip == nullptr || reinterpret_cast<uintptr_t>(a.precip) % 16 == 0);
-  if (g_semilag_variant != 0 && aligned && a.n >= 64 && a.m >= 16 && a.order != 3) {
+  if (g_semilag_variant == 3 && semilag_wide_eligible(a)) return launch_semilag_wide(a, stream);
+  if ((g_semilag_variant == 2 || g_semilag_variant == 4) && aligned && a.n >= 64 && a.m >= 16 && a.order != 3) {
     if (g_semilag_variant == 2) return launch_variant<2, kModeStaged>(a, stream);
     return launch_variant<4, kModeStaged>(a, stream);
   }

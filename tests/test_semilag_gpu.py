@@ -223,9 +223,10 @@ def test_device_resident_path(extrapolate):
     assert np.array_equal(dev_disp.to_host(), host_disp)  # displacement_prev untouched
 
 
-@pytest.mark.parametrize("variant", [2, 4])
-def test_lds_staged_variants_match_default(extrapolate, semilag_golden, variant):
-    """The LDS-staged kernels (psh_set_option semilag_variant) give the default kernel's result."""
+@pytest.mark.parametrize("variant", [3, 2, 4])
+def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
+    """The three-pixels-per-lane kernel (variant 3) is bit-identical to the default
+    one-pixel-per-lane kernel; the LDS-staged kernels (2, 4) agree to rounding."""
     from pysteps_amd import _lib
     from tools import synth
 
@@ -249,7 +250,9 @@ def test_lds_staged_variants_match_default(extrapolate, semilag_golden, variant)
             got, gdisp = extrapolate(a, b, t, return_displacement=True, **kw)
             assert nan_mismatch(got, want) == 0
             assert np.max(np.abs(gdisp - wdisp)) < 1e-5
-            if kw.get("interp_order", 1) == 0:
+            if variant == 3:
+                assert np.array_equal(got, want, equal_nan=True) and np.array_equal(gdisp, wdisp)
+            elif kw.get("interp_order", 1) == 0:
                 assert np.count_nonzero(got != want) <= 1e-4 * got.size
             else:
                 assert rel_l2(got, want) < 1e-6

@@ -8,20 +8,32 @@ from tools import synth
 
 def main():
     m = n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    if len(sys.argv) > 5:  # fewer rows, same columns (keeps the planes inside the L2s)
+        m = int(sys.argv[5])
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 24
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     print(device_info())
     ex = get_method("semilagrangian")
     p = DeviceArray.from_host(synth.rain_field_db(m, n))
-    v = DeviceArray.from_host(synth.true_velocity(m, n))
+    vel = synth.true_velocity(m, n)
+    if len(sys.argv) > 4 and sys.argv[4] == "uniform":  # rigid translation: no integer crossings inside a wave
+        vel[0], vel[1] = 4.3, -3.1
+    if len(sys.argv) > 5:
+        vel *= 24.0 / T  # same total displacement as the 24-step workload
+    v = DeviceArray.from_host(vel)
+    if len(sys.argv) > 6 and sys.argv[6] == "noprecip":  # trajectories only: no field taps, no stores
+        p = None
+        kw = dict(return_displacement=True)
+    else:
+        kw = {}
     for _ in range(2):
-        out = ex(p, v, T, outval=-15.0, n_iter=K)
+        out = ex(p, v, T, outval=-15.0, n_iter=K, **kw)
     synchronize()
     reps = 5
     e0, e1 = Event(), Event()
     e0.record()
     for _ in range(reps):
-        out = ex(p, v, T, outval=-15.0, n_iter=K)
+        out = ex(p, v, T, outval=-15.0, n_iter=K, **kw)
     e1.record()
     ms = e0.elapsed_ms(e1) / reps
     balg = (16 * K + 8) * m * n * T
