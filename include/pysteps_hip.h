@@ -103,12 +103,22 @@ int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *
  *              (timestep_diff / vel_timestep of semilagrangian.py:165,198)
  *  n_iter      >= 0 (0 = no midpoint rule, :215-219)
  *  interp_order 0, 1 or 3 for the precip resampling (:85-90); 3 = cubic B-spline incl. the
- *              spline prefilter and the two mask warps of :146-157,234-253 (outside -> NaN)
+ *              spline prefilter and the two mask warps of :146-157,234-253 (outside -> NaN).
+ *              The boundary mode of that resampling (map_coordinates_mode, :91-96,225-232) rides in
+ *              the second byte: interp_order | PSH_MODE_* << 8; modes other than "constant" need
+ *              interp_order 0 or 1 (outval is then the cval of "grid-constant").
  *  outval      value for pixels advected from outside the domain (may be NaN)
  *  disp        (2,m,n) float64 or NULL; if resume != 0 it holds displacement_prev
  *              on entry (:203-207); if non-NULL it receives the final displacement
  *  out         (T,m,n) float32, required iff precip != NULL
  */
+#define PSH_MODE_CONSTANT 0      /* scipy.ndimage mode names: "constant" (the default) */
+#define PSH_MODE_NEAREST 1
+#define PSH_MODE_REFLECT 2
+#define PSH_MODE_MIRROR 3
+#define PSH_MODE_WRAP 4
+#define PSH_MODE_GRID_CONSTANT 5
+#define PSH_MODE_GRID_WRAP 6
 int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
                     const double *steps_host, int T, int n_iter, int interp_order,
                     float outval, double *disp_dev, int resume, float *out_dev);

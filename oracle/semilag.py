@@ -118,11 +118,108 @@ def _cubic(field, row, col, cval):
     return np.where(outside, cval, acc)
 
 
+# ---- boundary modes other than "constant" (map_coordinates_mode, reference :91-96, :225-232) ----
+# Restated from the behaviour of SciPy 1.15.3 and pinned against it on dense probes with NaNs
+# planted at every index (tests/test_oracle_semilag.py::test_boundary_modes_*):
+#  1. the coordinate is folded into the array for "mirror", "reflect", "wrap", "grid-wrap"
+#     ("nearest" and "grid-constant" leave it alone; "constant" only decides inside/outside);
+#  2. taps are floor(c), floor(c)+1 (order 1) or floor(c+0.5) (order 0);
+#  3. a tap outside [0,len) is clamped ("nearest"), reflected ("reflect"), taken modulo len
+#     ("grid-wrap"), replaced by cval ("grid-constant"), and MIRRORED for "mirror", "wrap", "constant".
+def _trunc_div(a, b):
+    """C-style (npy_intp)(a / b) for float a, int b."""
+    return np.trunc(a / b)
+
+
+def _fold_coordinate(x, length, mode):
+    x = np.array(x, dtype=np.float64, copy=True)
+    if mode in ("nearest", "grid-constant", "constant"):
+        return x
+    if length <= 1:
+        return np.where((x < 0) | (x > length - 1), 0.0, x)
+    lo, hi = x < 0, x > length - 1
+    out = x.copy()
+    if mode == "mirror":
+        s2 = 2 * length - 2
+        t = s2 * _trunc_div(-x, s2) + x
+        out = np.where(lo, np.where(t <= 1 - length, t + s2, -t), out)
+        t = x - s2 * _trunc_div(x, s2)
+        out = np.where(hi, np.where(t >= length, s2 - t, t), out)
+    elif mode == "reflect":
+        s2 = 2 * length
+        t = np.where(x < -s2, s2 * _trunc_div(-x, s2) + x, x)
+        out = np.where(lo, np.where(t < -length, t + s2, -t - 1), out)
+        t = x - s2 * _trunc_div(x, s2)
+        out = np.where(hi, np.where(t >= length, s2 - t - 1, t), out)
+    elif mode == "wrap":
+        s1 = length - 1
+        out = np.where(lo, x + s1 * (_trunc_div(-x, s1) + 1), out)
+        out = np.where(hi, x - s1 * _trunc_div(x, s1), out)
+    elif mode == "grid-wrap":
+        out = np.where(lo, x + length * (_trunc_div(-1 - x, length) + 1), out)
+        out = np.where(hi, x - length * _trunc_div(x + 1, length), out)
+    else:
+        raise RuntimeError("boundary mode not supported")
+    return out
+
+
+def _fold_tap(i, length, mode):
+    """(index, is_cval) of integer taps ``i`` that may lie outside [0, length)."""
+    i = np.array(i, dtype=np.int64, copy=True)
+    outside = (i < 0) | (i >= length)
+    if mode == "grid-constant":
+        return np.where(outside, 0, i), outside
+    no = np.zeros(i.shape, dtype=bool)
+    if length <= 1:
+        return np.zeros_like(i), no
+    if mode == "nearest":
+        return np.clip(i, 0, length - 1), no
+    if mode == "grid-wrap":
+        return np.mod(i, length), no
+    if mode == "reflect":
+        s2 = 2 * length
+        t = np.where(i < -s2, i + s2 * ((-i) // s2), i)
+        neg = np.where(t < -length, t + s2, -t - 1)
+        t = i - s2 * (np.maximum(i, 0) // s2)
+        pos = np.where(t >= length, s2 - t - 1, t)
+    else:  # mirror, wrap, constant
+        s2 = 2 * length - 2
+        t = i + s2 * ((-i) // s2)
+        neg = np.where(t <= 1 - length, t + s2, -t)
+        t = i - s2 * (np.maximum(i, 0) // s2)
+        pos = np.where(t >= length, s2 - t, t)
+    return np.where(i < 0, neg, np.where(i >= length, pos, i)), no
+
+
+def _numpy_sample_mode(field, row, col, mode, cval, order):
+    m, n = field.shape
+    f = field.astype(np.float64, copy=False)
+    rr = _fold_coordinate(row, m, mode)
+    cc = _fold_coordinate(col, n, mode)
+    if order == 0:
+        ri, rc = _fold_tap(np.floor(rr + 0.5).astype(np.int64), m, mode)
+        ci, cv = _fold_tap(np.floor(cc + 0.5).astype(np.int64), n, mode)
+        return np.where(rc | cv, cval, f[ri, ci])
+    r0 = np.floor(rr)
+    c0 = np.floor(cc)
+    fr, fc = rr - r0, cc - c0
+    acc = 0.0
+    for dr, wr in ((0, 1.0 - fr), (1, fr)):
+        ri, rcv = _fold_tap(r0.astype(np.int64) + dr, m, mode)
+        for dc, wc in ((0, 1.0 - fc), (1, fc)):
+            ci, ccv = _fold_tap(c0.astype(np.int64) + dc, n, mode)
+            acc = acc + wr * wc * np.where(rcv | ccv, cval, f[ri, ci])
+    return acc
+
+
 def _numpy_sample(field, row, col, mode, cval, order):
     m, n = field.shape
     row = np.asarray(row, dtype=np.float64)
     col = np.asarray(col, dtype=np.float64)
+    if mode != "constant" and order in (0, 1) and not (mode == "nearest" and np.all(np.isfinite(field))):
+        return _numpy_sample_mode(field, row, col, mode, cval, order)
     if mode == "nearest":
+        # finite data: clamping the coordinate gives the same values as clamping the taps
         rr = np.clip(row, 0.0, m - 1.0)
         cc = np.clip(col, 0.0, n - 1.0)
         outside = None
@@ -131,7 +228,7 @@ def _numpy_sample(field, row, col, mode, cval, order):
         rr = np.where(outside, 0.0, row)
         cc = np.where(outside, 0.0, col)
     else:
-        raise NotImplementedError("numpy backend restates modes nearest/constant only")
+        raise NotImplementedError("numpy backend restates order 3 for mode constant only")
 
     if order == 3:
         if mode != "constant":
@@ -174,11 +271,11 @@ def sample_velocity(velocity, dx, dy, backend="numpy"):
     )
 
 
-def sample_field(field, dx, dy, cval=np.nan, order=1, backend="numpy"):
+def sample_field(field, dx, dy, cval=np.nan, order=1, backend="numpy", mode="constant"):
     """Scalar field at (x+dx, y+dy); outside -> cval (reference :221-232)."""
     m, n = field.shape
     yy, xx = np.mgrid[0:m, 0:n]
-    return _BACKENDS[backend](field, yy + dy, xx + dx, "constant", cval, order)
+    return _BACKENDS[backend](field, yy + dy, xx + dx, mode, cval, order)
 
 
 # --------------------------------------------------------------------------
@@ -208,6 +305,7 @@ def extrapolate(
     return_displacement=False,
     interp_order=1,
     backend="numpy",
+    map_coordinates_mode="constant",
 ):
     """float64 restatement of semilagrangian.extrapolate (reference :21-266).
 
@@ -293,7 +391,9 @@ def extrapolate(
             disp = disp - inc
 
         if precip is not None:
-            val = np.asarray(sampler(precip, yy + disp[1], xx + disp[0], "constant", outval, interp_order))
+            val = np.asarray(
+                sampler(precip, yy + disp[1], xx + disp[0], map_coordinates_mode, outval, interp_order)
+            )
             val = val.astype(precip.dtype, copy=True)
             if interp_order > 1:
                 warped = sampler(mask_min, yy + disp[1], xx + disp[0], "constant", 0, 1)

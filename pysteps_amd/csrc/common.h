@@ -60,6 +60,7 @@ struct SemilagArgs {
   float outval;
   const float *coef;    // interp_order 3: cubic B-spline coefficients of precip (m,n)
   float minval;         // interp_order 3: minimum over the finite values of precip
+  int bmode = 0;        // boundary mode of the field resampling (PSH_MODE_*), interp_order 0/1
 };
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
 void set_semilag_variant(int v);

@@ -333,7 +333,12 @@ int psh_event_elapsed_ms(void *start, void *stop, float *ms) {
 // ---------------------------------------------------------------------------
 // semi-Lagrangian extrapolation
 // ---------------------------------------------------------------------------
-static int check_semilag(int m, int n, int T, int n_iter, int order) {
+static int check_semilag(int m, int n, int T, int n_iter, int order_and_mode) {
+  const int order = order_and_mode & 0xff, bmode = (order_and_mode >> 8) & 0xff;
+  if (order_and_mode < 0 || (order_and_mode >> 16) != 0 || bmode > PSH_MODE_GRID_WRAP)
+    return fail(PSH_EINVAL, "semilag: invalid interp_order / boundary mode word 0x%x", order_and_mode);
+  if (bmode != PSH_MODE_CONSTANT && order == 3)
+    return fail(PSH_EUNSUPPORTED, "semilag: interp_order 3 is implemented for mode \"constant\" only");
   if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "semilag: invalid shape (%d,%d)", m, n);
   if (static_cast<uint64_t>(m) * static_cast<uint64_t>(n) >= (1ull << 30))
     return fail(PSH_EUNSUPPORTED, "semilag: m*n must be < 2^30 pixels (32-bit byte offsets)");
@@ -404,7 +409,9 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
   a.n = n;
   a.T = T;
   a.n_iter = n_iter;
-  a.order = interp_order;
+  a.order = interp_order & 0xff;
+  a.bmode = (interp_order >> 8) & 0xff;
+  interp_order &= 0xff;
   a.resume = resume;
   a.row0 = row_begin;
   a.rows = row_count;

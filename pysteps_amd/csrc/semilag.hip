@@ -59,6 +59,7 @@ struct Fields {
   int row_bytes;
   const float *coef;  // cubic B-spline coefficients of the field (interp_order 3 only)
   float minval;       // minimum over its finite values (interp_order 3 only)
+  int bmode;          // boundary mode of the field resampling (semilag_device.h kMode*)
 };
 
 __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soff) {
@@ -322,7 +323,7 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
       if (WHAT & kVel) sample_velocity_border(F, X[j], Y[j], fx[j], fy[j], m, n, su[j], sv[j]);
-      if (kWithP) sp[j] = sample_precip_border<ORDER>(F.p0, X[j], Y[j], fx[j], fy[j], m, n, outval);
+      if (kWithP) sp[j] = sample_precip_edge<ORDER>(F.p0, X[j], Y[j], fx[j], fy[j], m, n, outval, F.bmode);
     }
     return;
   }
@@ -353,8 +354,8 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
       if (WHAT & kVel) sample_velocity_border(F, X[j], Y[j], fx[j], fy[j], m, n, su[j], sv[j]);
       if (kWithP) {
         sp[j] = ORDER == 3 ? sample_precip_cubic(F.coef, F.p0, X[j], Y[j], fx[j], fy[j], m, n, F.minval)
-                           : sample_precip_border<(ORDER == 3 ? 1 : ORDER)>(F.p0, X[j], Y[j], fx[j],
-                                                                            fy[j], m, n, outval);
+                           : sample_precip_edge<(ORDER == 3 ? 1 : ORDER)>(F.p0, X[j], Y[j], fx[j], fy[j],
+                                                                          m, n, outval, F.bmode);
       }
     }
   }
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
     const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
     int T, int n_iter, int resume, float outval, int row0, int rows, const float *__restrict__ coef,
-    float minval, int tiles_x, int n_tiles, int tiles_per_xcd) {
+    float minval, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd) {
   // XCD-aware remap: hardware block b -> XCD b % 8; give XCD k the k-th band of tiles
   const int b = blockIdx.x;
   const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
   F.row_bytes = n * static_cast<int>(sizeof(float));
   F.coef = coef;
   F.minval = minval;
+  F.bmode = bmode;
 
   __shared__ float stage_buf[MODE == kModeStaged ? 3 * kStageCap : 1];
   __shared__ int stage_red[16];
@@ -525,8 +527,8 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
           for (int j = 0; j < NPX; ++j)
             sp[j] = ORDER == 3
                         ? sample_precip_cubic(F.coef, F.p0, px[j], py[j], fx[j], fy[j], m, n, F.minval)
-                        : sample_precip_border<(ORDER == 3 ? 1 : ORDER)>(F.p0, px[j], py[j], fx[j], fy[j],
-                                                                         m, n, outval);
+                        : sample_precip_edge<(ORDER == 3 ? 1 : ORDER)>(F.p0, px[j], py[j], fx[j], fy[j], m,
+                                                                       n, outval, F.bmode);
         }
       }
     }
@@ -563,7 +565,7 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
 #define PSH_SL_LAUNCH(ORDER, HASP)                                                              \
   hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, MODE>), grid, block, 0, stream, a.precip,   \
                      a.vel, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter,     \
-                     a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, tiles_x, n_tiles,           \
+                     a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, a.bmode, tiles_x, n_tiles,  \
                      tiles_per_xcd)
   if (a.precip == nullptr) {
     PSH_SL_LAUNCH(1, false);
@@ -601,7 +603,7 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
   const bool aligned = (a.n % 4 == 0) && (reinterpret_cast<uintptr_t>(a.vel) % 16 == 0) &&
                        (a.precip == nullptr || reinterpret_cast<uintptr_t>(a.precip) % 16 == 0);
   if (g_semilag_variant == 3 && semilag_wide_eligible(a)) return launch_semilag_wide(a, stream);
-  if ((g_semilag_variant == 2 || g_semilag_variant == 4) && aligned && a.n >= 64 && a.m >= 16 && a.order != 3) {
+  if ((g_semilag_variant == 2 || g_semilag_variant == 4) && a.bmode == 0 && aligned && a.n >= 64 && a.m >= 16 && a.order != 3) {
     if (g_semilag_variant == 2) return launch_variant<2, kModeStaged>(a, stream);
     return launch_variant<4, kModeStaged>(a, stream);
   }

@@ -85,6 +85,133 @@ __device__ __forceinline__ float sample_precip_border(const float *p, int X, int
 }
 
 
+// ---- map_coordinates_mode other than "constant" (interp_order 0 / 1) ------------------------------
+// scipy.ndimage.map_coordinates (SciPy 1.15, the reference's resampler at
+// pysteps/extrapolation/semilagrangian.py:225-232) restated on the split coordinate c = P + f,
+// f in [0,1): first the coordinate is folded into the array by the mode ("mirror", "reflect",
+// "wrap", "grid-wrap"; "nearest" and "grid-constant" leave it alone), then the taps floor(c),
+// floor(c)+1 (order 1) or floor(c+0.5) (order 0) that fall outside [0,len) are folded index by
+// index: clamped ("nearest"), reflected ("reflect"), taken modulo len ("grid-wrap"), replaced by
+// cval ("grid-constant") and MIRRORED for "mirror", "wrap" and "constant".  The rules were pinned
+// against SciPy itself on dense probes with NaNs planted at every index (oracle/semilag.py,
+// tests/test_oracle_semilag.py); the integer conditions below are the exact images of SciPy's
+// double comparisons because f < 1.
+enum : int {
+  kModeConstant = 0, kModeNearest = 1, kModeReflect = 2, kModeMirror = 3, kModeWrap = 4,
+  kModeGridConstant = 5, kModeGridWrap = 6
+};
+
+// c -> -c
+__device__ __forceinline__ void negate_coord(int &P, float &f) {
+  if (f > 0.f) {
+    P = -P - 1;
+    f = fminf(1.f - f, kMaxFrac);
+  } else {
+    P = -P;
+  }
+}
+
+// (npy_intp)(-c / s) for c < 0: truncation of a positive quotient
+__device__ __forceinline__ int trunc_neg_over(int P, float f, int s) { return (f > 0.f ? -P - 1 : -P) / s; }
+
+__device__ __forceinline__ void fold_coord(int &P, float &f, int len, int mode) {
+  const bool below = P < 0, above = P > len - 1 || (P == len - 1 && f > 0.f);
+  if (!(below || above) || mode == kModeNearest || mode == kModeGridConstant || mode == kModeConstant) return;
+  if (len <= 1) {
+    P = 0;
+    f = 0.f;
+    return;
+  }
+  if (mode == kModeMirror) {
+    const int s2 = 2 * len - 2;
+    if (below) {
+      P += s2 * trunc_neg_over(P, f, s2);
+      if (P < 1 - len || (P == 1 - len && f == 0.f)) P += s2; else negate_coord(P, f);
+    } else {
+      P -= s2 * (P / s2);
+      if (P >= len) { negate_coord(P, f); P += s2; }
+    }
+  } else if (mode == kModeReflect) {
+    const int s2 = 2 * len;
+    if (below) {
+      if (P < -s2) P += s2 * trunc_neg_over(P, f, s2);
+      if (P < -len) P += s2; else { negate_coord(P, f); P -= 1; }
+    } else {
+      P -= s2 * (P / s2);
+      if (P >= len) { negate_coord(P, f); P += s2 - 1; }
+    }
+  } else if (mode == kModeWrap) {
+    const int s = len - 1;
+    if (below) P += s * (trunc_neg_over(P, f, s) + 1); else P -= s * (P / s);
+  } else {  // grid-wrap
+    if (below) P += len * ((f > 0.f ? -P - 2 : -P - 1) / len + 1); else P -= len * ((P + 1) / len);
+  }
+}
+
+// index of a tap that fell outside [0,len); *is_cval is set for "grid-constant"
+__device__ __forceinline__ int fold_tap(int i, int len, int mode, bool *is_cval) {
+  if (static_cast<unsigned>(i) < static_cast<unsigned>(len)) return i;
+  if (mode == kModeGridConstant) {
+    *is_cval = true;
+    return 0;
+  }
+  if (len <= 1) return 0;
+  if (mode == kModeNearest) return min(max(i, 0), len - 1);
+  if (mode == kModeGridWrap) {
+    const int r = i % len;
+    return r < 0 ? r + len : r;
+  }
+  if (mode == kModeReflect) {
+    const int s2 = 2 * len;
+    if (i < 0) {
+      if (i < -s2) i += s2 * (-i / s2);
+      return i < -len ? i + s2 : -i - 1;
+    }
+    i -= s2 * (i / s2);
+    return i >= len ? s2 - i - 1 : i;
+  }
+  const int s2 = 2 * len - 2;  // mirror, wrap, constant
+  if (i < 0) {
+    i += s2 * (-i / s2);
+    return i <= 1 - len ? i + s2 : -i;
+  }
+  i -= s2 * (i / s2);
+  return i >= len ? s2 - i : i;
+}
+
+template <int ORDER>
+__device__ __forceinline__ float sample_precip_mode(const float *p, int X, int Y, float fx, float fy, int m,
+                                                    int n, float cval, int mode) {
+  fold_coord(X, fx, n, mode);
+  fold_coord(Y, fy, m, mode);
+  if (ORDER == 0) {
+    bool cv = false;
+    const int xi = fold_tap(X + (fx >= 0.5f ? 1 : 0), n, mode, &cv);
+    const int yi = fold_tap(Y + (fy >= 0.5f ? 1 : 0), m, mode, &cv);
+    const float v = ld(p, static_cast<unsigned>(__mul24(yi, n) + xi) << 2);
+    return cv ? cval : v;
+  }
+  bool cx0 = false, cx1 = false, cy0 = false, cy1 = false;
+  const int x0 = fold_tap(X, n, mode, &cx0), x1 = fold_tap(X + 1, n, mode, &cx1);
+  const int y0 = fold_tap(Y, m, mode, &cy0), y1 = fold_tap(Y + 1, m, mode, &cy1);
+  const unsigned r0 = static_cast<unsigned>(__mul24(y0, n)), r1 = static_cast<unsigned>(__mul24(y1, n));
+  float a = ld(p, (r0 + x0) << 2), b = ld(p, (r0 + x1) << 2);
+  float c = ld(p, (r1 + x0) << 2), d = ld(p, (r1 + x1) << 2);
+  a = (cx0 || cy0) ? cval : a;
+  b = (cx1 || cy0) ? cval : b;
+  c = (cx0 || cy1) ? cval : c;
+  d = (cx1 || cy1) ? cval : d;
+  return blend(make_weights(fx, fy), a, b, c, d);
+}
+
+// the advected field off the clamp-free interior path, any boundary mode
+template <int ORDER>
+__device__ __forceinline__ float sample_precip_edge(const float *p, int X, int Y, float fx, float fy, int m,
+                                                    int n, float outval, int mode) {
+  return mode == kModeConstant ? sample_precip_border<ORDER>(p, X, Y, fx, fy, m, n, outval)
+                               : sample_precip_mode<ORDER>(p, X, Y, fx, fy, m, n, outval, mode);
+}
+
 // ---- interp_order = 3 -------------------------------------------------------------------
 // map_coordinates(order=3, mode="constant") on the prefiltered coefficients (csrc/spline.hip)
 // plus the two order-1 mask warps of pysteps/extrapolation/semilagrangian.py:234-253: pixels

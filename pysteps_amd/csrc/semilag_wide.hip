@@ -346,7 +346,9 @@ __global__ __launch_bounds__(64 * kWideRows) void semilag_wide(
 }  // namespace
 
 // interp_order 0 / 1 on images at least one tile wide; everything else stays with semilag_fused
-bool semilag_wide_eligible(const SemilagArgs &a) { return a.order != 3 && a.n >= kWideTileX && a.m >= 2; }
+bool semilag_wide_eligible(const SemilagArgs &a) {
+  return a.order != 3 && a.bmode == 0 && a.n >= kWideTileX && a.m >= 2;
+}
 
 hipError_t launch_semilag_wide(const SemilagArgs &a, hipStream_t stream) {
   const int tiles_x = (a.n + kWideTileX - 1) / kWideTileX;

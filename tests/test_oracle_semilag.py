@@ -18,7 +18,10 @@ from conftest import nan_mismatch
 GOLDEN_SL = [
     "sl_int_T6", "sl_shear_K3", "sl_K0", "sl_list_vt", "sl_nan_min", "sl_nan_nan",
     "sl_order0", "sl_resume", "sl_resume_K0", "sl_f64", "sl_order3", "sl_order3_nan",
+    "sl_mode_nearest", "sl_mode_reflect_nan", "sl_mode_mirror", "sl_mode_wrap", "sl_mode_gridwrap",
+    "sl_mode_gridconst", "sl_mode_reflect_o0", "sl_mode_gridwrap_o0",
 ]
+BOUNDARY_MODES = ["constant", "nearest", "reflect", "mirror", "wrap", "grid-constant", "grid-wrap"]
 
 
 def _kat_inputs(speed):
@@ -60,6 +63,8 @@ def test_oracle_matches_reference_golden(semilag_golden, backend, name):
         pytest.skip("the C port takes float32 fields")
     if backend == "c" and c["kw"].get("interp_order", 1) > 1:
         pytest.skip("the C port restates interpolation order 0/1")
+    if backend == "c" and "map_coordinates_mode" in c["kw"]:
+        pytest.skip("the C port restates mode constant")
     out, disp = _run(backend, c)
     assert out.shape == c["out"].shape
     if backend != "c":
@@ -121,3 +126,47 @@ def test_oracle_matches_live_reference():
             assert nan_mismatch(a, r) == 0
             np.testing.assert_allclose(ad, rd, rtol=0, atol=1e-11)
             np.testing.assert_allclose(a, r, rtol=0, atol=2e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("mode", BOUNDARY_MODES)
+def test_boundary_modes_pinned_against_scipy(mode, order):
+    """The restated folding rules of oracle.semilag (coordinate, then tap by tap) against
+    scipy.ndimage.map_coordinates itself: lattice and random coordinates several periods outside
+    the array, NaN planted at every index in turn (a NaN tap poisons the sample even at weight 0,
+    so the NaN pattern reveals WHICH index an out-of-range tap was folded to)."""
+    from scipy.ndimage import map_coordinates
+
+    rng = np.random.default_rng(17)
+    for m, n in ((1, 1), (1, 4), (2, 2), (3, 5), (5, 3)):
+        lat_r = np.arange(-3 * m - 2, 3 * m + 2.01, 0.25)
+        lat_c = np.arange(-3 * n - 2, 3 * n + 2.01, 0.25)
+        rows = np.concatenate([np.repeat(lat_r, lat_c.size), rng.uniform(-3 * m - 2, 3 * m + 2, 300)])
+        cols = np.concatenate([np.tile(lat_c, lat_r.size), rng.uniform(-3 * n - 2, 3 * n + 2, 300)])
+        for nan_at in [None] + list(range(m * n)):
+            field = rng.uniform(1.0, 9.0, (m, n))
+            if nan_at is not None:
+                field.flat[nan_at] = np.nan
+            want = map_coordinates(field, [rows, cols], order=order, mode=mode, cval=-7.0, prefilter=False)
+            got = osl._numpy_sample(field, rows, cols, mode, -7.0, order)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (mode, order, m, n, nan_at)
+            np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="reference tree not present")
+@pytest.mark.parametrize("mode", BOUNDARY_MODES[1:])
+def test_oracle_boundary_modes_match_live_reference(mode):
+    ref = ref_loader.load("pysteps.extrapolation.semilagrangian")
+    rng = np.random.default_rng(23)
+    m, n = 40, 56
+    p = rng.gamma(1.0, 2.0, (m, n)).astype(np.float32)
+    p[rng.uniform(size=(m, n)) < 0.03] = np.nan
+    y, x = np.mgrid[0:m, 0:n]
+    v = np.stack([3 + 0.08 * (y - m / 2), -2 + 0.06 * (x - n / 2)]).astype(np.float32)
+    for order in (0, 1):
+        r = ref.extrapolate(p, v, [2.0, 9.0, 31.0], interp_order=order, map_coordinates_mode=mode, outval=-3.0,
+                            allow_nonfinite_values=True)
+        a = osl.extrapolate(p, v, [2.0, 9.0, 31.0], interp_order=order, map_coordinates_mode=mode, outval=-3.0,
+                            allow_nonfinite_values=True)
+        assert nan_mismatch(a, r) == 0
+        np.testing.assert_allclose(a, r, rtol=0, atol=2e-6, equal_nan=True)

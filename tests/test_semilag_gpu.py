@@ -120,6 +120,62 @@ def test_matches_reference_golden(extrapolate, semilag_golden, name):
         assert rel_l2(out, c["out"]) < REL_L2_TOL
 
 
+GOLDEN_SL_MODES = [
+    "sl_mode_nearest", "sl_mode_reflect_nan", "sl_mode_mirror", "sl_mode_wrap", "sl_mode_gridwrap",
+    "sl_mode_gridconst", "sl_mode_reflect_o0", "sl_mode_gridwrap_o0",
+]
+
+
+def _assert_mostly_close(out, want, max_outliers=5e-4):
+    """Folded boundaries make the resampled field discontinuous along a few lines ("wrap", order 0,
+    NaN neighbourhoods): a 1e-6 px trajectory difference may put isolated pixels on the other
+    side.  Everything else agrees pixel by pixel to the displacement tolerance times the field's
+    gradient (a few 1e-4 px x ~10 units/px) and to 1e-4 in relative L2."""
+    both_nan = np.isnan(out) & np.isnan(want)
+    close = np.isclose(out, want, rtol=1e-3, atol=3e-3) | both_nan
+    assert np.count_nonzero(~close) <= max_outliers * out.size, np.count_nonzero(~close)
+    ok = close & ~both_nan
+    assert rel_l2(out[ok], want[ok]) < REL_L2_TOL
+
+
+@pytest.mark.parametrize("name", GOLDEN_SL_MODES)
+def test_boundary_modes_match_reference_golden(extrapolate, semilag_golden, name):
+    """map_coordinates_mode variants (semilagrangian.py:91-96, 225-232) against the reference's
+    own outputs; lead times long enough to wrap the 72 x 96 domain more than once."""
+    c = semilag_golden.case(name)
+    out, disp = extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **c["kw"])
+    assert out.shape == c["out"].shape and out.dtype == c["out"].dtype
+    assert np.max(np.abs(disp - c["disp"])) < DISP_TOL
+    _assert_mostly_close(out, c["out"])
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("mode", ["nearest", "reflect", "mirror", "wrap", "grid-constant", "grid-wrap"])
+def test_boundary_modes_vs_oracle(extrapolate, mode, order):
+    """Small and odd shapes (length-1 axes, periods shorter than the displacement), NaNs in the field."""
+    from oracle import semilag as osl
+
+    rng = np.random.default_rng(29)
+    for m, n in ((1, 1), (1, 9), (7, 1), (2, 2), (5, 3), (40, 70), (130, 257)):
+        p = rng.gamma(1.0, 2.0, (m, n)).astype(np.float32)
+        p[rng.uniform(size=(m, n)) < 0.04] = np.nan
+        if not np.isfinite(p).any():
+            p[0, 0] = 1.0
+        y, x = np.mgrid[0:m, 0:n]
+        v = np.stack([2.6 + 0.05 * (y - m / 2), -1.7 + 0.04 * (x - n / 2)]).astype(np.float32)
+        kw = dict(interp_order=order, map_coordinates_mode=mode, outval=-3.0, allow_nonfinite_values=True)
+        want = osl.extrapolate(p, v, [1.0, 6.0, 29.0], **kw)
+        got = extrapolate(p, v, [1.0, 6.0, 29.0], **kw)
+        assert got.shape == want.shape
+        _assert_mostly_close(got, want, max_outliers=2e-3 if m * n > 100 else 0.05)
+
+
+def test_unknown_boundary_mode(extrapolate):
+    p = np.ones((8, 8), dtype=np.float32)
+    with pytest.raises(RuntimeError):
+        extrapolate(p, np.ones((2, 8, 8), dtype=np.float32), 1, map_coordinates_mode="bogus")
+
+
 def test_displacement_only_golden(extrapolate, semilag_golden):
     c = semilag_golden.case("sl_disp_only")
     none, disp = extrapolate(None, c["velocity"], [0.7], return_displacement=True, n_iter=1)

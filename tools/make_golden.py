@@ -40,6 +40,21 @@ def semilag_cases():
         "sl_order3": dict(precip=P, velocity=Vs, timesteps=3, kw=dict(interp_order=3, outval=-15.0)),
         "sl_order3_nan": dict(precip=Pn, velocity=V, timesteps=2, kw=dict(interp_order=3, allow_nonfinite_values=True)),
         "sl_f64": dict(precip=P.astype(np.float64), velocity=Vs.astype(np.float64), timesteps=2, kw={}),
+        # map_coordinates_mode variants (reference :91-96, :225-232); long lead times wrap the
+        # 72 x 96 domain more than once
+        "sl_mode_nearest": dict(precip=P, velocity=Vs, timesteps=[4.0, 10.0], kw=dict(map_coordinates_mode="nearest")),
+        "sl_mode_reflect_nan": dict(precip=Pn, velocity=Vs, timesteps=[4.0, 10.0, 40.0],
+                                    kw=dict(map_coordinates_mode="reflect", allow_nonfinite_values=True)),
+        "sl_mode_mirror": dict(precip=P, velocity=Vs, timesteps=[4.0, 10.0, 40.0], kw=dict(map_coordinates_mode="mirror")),
+        "sl_mode_wrap": dict(precip=P, velocity=Vs, timesteps=[4.0, 10.0, 40.0], kw=dict(map_coordinates_mode="wrap")),
+        "sl_mode_gridwrap": dict(precip=P, velocity=Vs, timesteps=[4.0, 10.0, 40.0],
+                                 kw=dict(map_coordinates_mode="grid-wrap", n_iter=2)),
+        "sl_mode_gridconst": dict(precip=P, velocity=Vs, timesteps=[4.0, 10.0],
+                                  kw=dict(map_coordinates_mode="grid-constant", outval=-15.0)),
+        "sl_mode_reflect_o0": dict(precip=P, velocity=Vs, timesteps=[4.0, 10.0],
+                                   kw=dict(map_coordinates_mode="reflect", interp_order=0)),
+        "sl_mode_gridwrap_o0": dict(precip=P, velocity=Vs, timesteps=[4.0, 10.0],
+                                    kw=dict(map_coordinates_mode="grid-wrap", interp_order=0)),
     }
 
 
