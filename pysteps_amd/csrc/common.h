@@ -76,8 +76,11 @@ struct IdwArgs {
   int L, k, m, n;
   float x0, dx, y0, dy;  // target grid: x = x0 + dx*i (i<n), y = y0 + dy*j (j<m)
   float inv_res, power, offset, dmax;
+  void *scratch = nullptr;  // idw_scratch_bytes(m, n) of device memory: supertile candidate lists
 };
 hipError_t launch_idw(const IdwArgs &a, hipStream_t stream);
+size_t idw_scratch_bytes(int m, int n);
+void set_idw_variant(int v);
 
 hipError_t launch_outliers_pooled(const double *xy_dev, const double *uv_dev, const int *count_dev,
                                   int capacity, int k, double thr, unsigned char *flags_dev,

@@ -23,6 +23,7 @@
 //    tile-uniform branch uses an 8-slot set when that suffices) and adds them.
 //  * k >= L (use everything) and candidate overflow take a brute-force path.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -407,21 +408,302 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
   }
 }
 
+// ---- two-level variant (default) ----------------------------------------------------------
+// The per-tile pre-pass above scans all L vectors for every 16x16 tile: at L ~ 1000 that is a
+// third of the kernel, and the ring of undecided vectors is as thick as four half-diagonals of
+// the tile.  Here the scan over all L is done once per 64x64 SUPERTILE (idw_coarse: the same
+// bracket and ordered compaction, into a global list of typically 30-60 vectors), and the
+// fine pass runs one WAVE per 8x8 tile (one pixel per lane, no workgroup barriers that span
+// waves): it brackets the k-th centre distance of its own tile from the supertile's list, so
+// the ring is 2.7 times thinner and fewer vectors need the per-pixel selection.
+// Exactness: a pixel q of a supertile with centre c and half-diagonal H has its k-th neighbour
+// within R_hi + H of q, hence within R_hi + 2H of c - the supertile list holds every vector any
+// of its pixels can need, and a fine tile's k-th centre distance computed from the list is the
+// true one (vectors outside the list are farther than R_hi + H from any fine centre).
+constexpr int kSuper = 64;      // supertile edge in pixels
+constexpr int kSuperCap = 256;  // vectors kept per supertile (4 KiB of float4)
+constexpr int kFine = 8;        // fine tile edge: 64 pixels, one per lane
+constexpr int kFineCap = 96;    // vectors per fine tile in LDS
+constexpr int kFineBins = 256;
+
+struct SuperHeader {
+  int count;        // vectors in the list, or > kSuperCap: overflow (brute force in the fine pass)
+  float reach;      // the list holds every vector within `reach` of the supertile centre
+  float half_diag;  // of the supertile
+  float pad;
+};
+
+__global__ __launch_bounds__(kThreads) void idw_coarse(const float2 *__restrict__ xy,
+                                                       const float2 *__restrict__ uv, int L, int k, int m,
+                                                       int n, float x0, float dx_grid, float y0,
+                                                       float dy_grid, float dmax, int supers_x,
+                                                       SuperHeader *__restrict__ headers,
+                                                       float4 *__restrict__ lists) {
+  __shared__ int s_hist[kBins];
+  __shared__ float s_radius;
+  __shared__ int s_wave_count[4];
+  const int sup = blockIdx.x;
+  const int tx = (sup % supers_x) * kSuper, ty = (sup / supers_x) * kSuper;
+  const int tid = threadIdx.x;
+  const int wx = min(kSuper, n - tx), wy = min(kSuper, m - ty);
+  const float cx = x0 + dx_grid * (static_cast<float>(tx) + 0.5f * static_cast<float>(wx - 1));
+  const float cy = y0 + dy_grid * (static_cast<float>(ty) + 0.5f * static_cast<float>(wy - 1));
+  const float hx = 0.5f * fabsf(dx_grid) * static_cast<float>(wx - 1);
+  const float hy = 0.5f * fabsf(dy_grid) * static_cast<float>(wy - 1);
+  const float half_diag = sqrtf(hx * hx + hy * hy);
+  const float bin_w = dmax / static_cast<float>(kBins);
+  for (int i = tid; i < kBins; i += kThreads) s_hist[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < L; i += kThreads) {
+    const float2 p = xy[i];
+    const float ddx = p.x - cx, ddy = p.y - cy;
+    const int bin = min(static_cast<int>(sqrtf(ddx * ddx + ddy * ddy) / bin_w), kBins - 1);
+    atomicAdd(&s_hist[bin], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    constexpr int kPer = kBins / 64;
+    int tot = 0;
+    for (int q = 0; q < kPer; ++q) tot += s_hist[tid * kPer + q];
+    int incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (tid >= d) incl += up;
+    }
+    int run = incl - tot;
+    int first = kBins;
+    for (int q = 0; q < kPer; ++q) {
+      run += s_hist[tid * kPer + q];
+      if (run >= k && first == kBins) first = tid * kPer + q;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) first = min(first, __shfl_xor(first, d));
+    if (tid == 0) s_radius = first >= kBins - 1 ? INFINITY : static_cast<float>(first + 1) * bin_w;
+  }
+  __syncthreads();
+  const float reach = s_radius + 2.f * half_diag + 1e-3f * (s_radius + half_diag);
+  // ordered compaction, as in idw_knn: each wave owns a contiguous quarter of the vectors
+  const int wave = tid >> 6, lane = tid & 63;
+  const int per_wave = (L + 3) / 4;
+  const int i_begin = wave * per_wave, i_end = min(L, i_begin + per_wave);
+  auto wanted = [&](int i, float2 &p) {
+    if (i >= i_end) return false;
+    p = xy[i];
+    const float ddx = p.x - cx, ddy = p.y - cy;
+    return sqrtf(ddx * ddx + ddy * ddy) <= reach;
+  };
+  int mine = 0;
+  for (int i0 = i_begin; i0 < i_end; i0 += 64) {
+    float2 p;
+    mine += __popcll(__ballot(wanted(i0 + lane, p)));
+  }
+  if (lane == 0) s_wave_count[wave] = mine;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wave_count[w];
+  const int n_cand = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
+  if (tid == 0) {
+    SuperHeader h;
+    h.count = n_cand;
+    h.reach = reach;
+    h.half_diag = half_diag;
+    h.pad = 0.f;
+    headers[sup] = h;
+  }
+  if (n_cand > kSuperCap) return;
+  float4 *dst = lists + static_cast<size_t>(sup) * kSuperCap;
+  for (int i0 = i_begin; i0 < i_end; i0 += 64) {
+    float2 p = make_float2(0.f, 0.f);
+    const bool keep = wanted(i0 + lane, p);
+    const unsigned long long mask = __ballot(keep);
+    if (keep) {
+      const float2 val = uv[i0 + lane];
+      dst[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_float4(p.x, p.y, val.x, val.y);
+    }
+    base += __popcll(mask);
+  }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(64) void idw_fine(const float2 *__restrict__ xy, const float2 *__restrict__ uv,
+                                               int L, int k, int m, int n, float x0, float dx_grid,
+                                               float y0, float dy_grid, float inv_res, float power,
+                                               float offset, float *__restrict__ out, int supers_x,
+                                               const SuperHeader *__restrict__ headers,
+                                               const float4 *__restrict__ lists, int tiles_x, int n_tiles,
+                                               int tiles_per_xcd) {
+  __shared__ int s_hist[kFineBins];
+  __shared__ float4 s_cand[kFineCap];  // [certain | undecided], each group in index order
+  const int b = blockIdx.x;
+  const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;  // XCD-contiguous tiles
+  if (tile >= n_tiles) return;
+  const int tx = (tile % tiles_x) * kFine, ty = (tile / tiles_x) * kFine;
+  const int lane = threadIdx.x;
+  const int ix = tx + (lane % kFine), iy = ty + (lane / kFine);
+  const bool live = ix < n && iy < m;
+  const float px = x0 + dx_grid * static_cast<float>(ix);
+  const float py = y0 + dy_grid * static_cast<float>(iy);
+  const size_t plane = static_cast<size_t>(m) * n;
+  const int sup = (ty / kSuper) * supers_x + tx / kSuper;
+  const SuperHeader hdr = headers[sup];
+  const float4 *list = lists + static_cast<size_t>(sup) * kSuperCap;
+  const int n_s = hdr.count;
+
+  bool brute = k >= L || n_s > kSuperCap;
+  int n_sure = 0, n_ring = 0;
+  if (!brute) {
+    const int wx = min(kFine, n - tx), wy = min(kFine, m - ty);
+    const float cx = x0 + dx_grid * (static_cast<float>(tx) + 0.5f * static_cast<float>(wx - 1));
+    const float cy = y0 + dy_grid * (static_cast<float>(ty) + 0.5f * static_cast<float>(wy - 1));
+    const float hx = 0.5f * fabsf(dx_grid) * static_cast<float>(wx - 1);
+    const float hy = 0.5f * fabsf(dy_grid) * static_cast<float>(wy - 1);
+    const float half_diag = sqrtf(hx * hx + hy * hy);
+    // every listed vector is within reach + H of any point of the supertile
+    const float bin_w = (hdr.reach + hdr.half_diag) * (1.001f / static_cast<float>(kFineBins));
+    constexpr int kPerLane = kSuperCap / 64;
+    float dc[kPerLane];
+#pragma unroll
+    for (int q = 0; q < kFineBins / 64; ++q) s_hist[q * 64 + lane] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j) {
+      const int i = j * 64 + lane;
+      dc[j] = INFINITY;
+      if (i < n_s) {
+        const float4 c = list[i];
+        const float ddx = c.x - cx, ddy = c.y - cy;
+        dc[j] = sqrtf(ddx * ddx + ddy * ddy);
+        atomicAdd(&s_hist[min(static_cast<int>(dc[j] / bin_w), kFineBins - 1)], 1);
+      }
+    }
+    __syncthreads();
+    constexpr int kPer = kFineBins / 64;
+    int tot = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) tot += s_hist[lane * kPer + q];
+    int incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    int run = incl - tot;
+    int first = kFineBins;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      run += s_hist[lane * kPer + q];
+      if (run >= k && first == kFineBins) first = lane * kPer + q;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) first = min(first, __shfl_xor(first, d));
+    // R_lo < (k-th smallest centre distance) <= R_hi; the last bin is open-ended
+    const float r_hi = first >= kFineBins - 1 ? INFINITY : static_cast<float>(first + 1) * bin_w;
+    const float r_lo = static_cast<float>(min(first, kFineBins - 1)) * bin_w;
+    const float reach = r_hi + 2.f * half_diag + 1e-3f * (r_hi + half_diag);
+    const float sure_below = r_lo - 2.f * half_diag - 1e-3f * (r_lo + half_diag);
+    int at = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int j = 0; j < kPerLane; ++j) {
+        if (j * 64 >= n_s) break;
+        const bool sure = dc[j] <= sure_below;
+        const bool keep = pass == 0 ? sure : (!sure && dc[j] <= reach);
+        const unsigned long long mask = __ballot(keep);
+        const int slot = at + __popcll(mask & ((1ull << lane) - 1ull));
+        if (keep && slot < kFineCap) s_cand[slot] = list[j * 64 + lane];
+        at += __popcll(mask);
+      }
+      if (pass == 0) n_sure = at;
+    }
+    n_ring = at - n_sure;
+    brute = at > kFineCap;  // pathological clustering: exact brute force
+    __syncthreads();
+  }
+  if (!live) return;
+  float ou, ov;
+  if (brute) {
+    idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
+  } else {
+    float sw = 0.f, su = 0.f, sv = 0.f;
+    for (int i = 0; i < n_sure; ++i) {  // in every pixel's neighbourhood: no selection
+      const float4 c = s_cand[i];       // same address in every lane: LDS broadcast
+      const float w = idw_weight(fast_sqrt(dist2(c.x, c.y, px, py)) * inv_res, power, offset);
+      sw += w;
+      su += w * c.z;
+      sv += w * c.w;
+    }
+    const int need = k - n_sure;  // >= 1: fewer than k vectors lie strictly inside R_lo
+    if (need <= 8) {              // tile-uniform branch: small selection sets are much cheaper
+      add_nearest<8>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
+    } else {
+      add_nearest<KMAX>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
+    }
+    ou = su / sw;
+    ov = sv / sw;
+  }
+  out[static_cast<size_t>(iy) * n + ix] = ou;
+  out[plane + static_cast<size_t>(iy) * n + ix] = ov;
+}
+
 }  // namespace
 
+// 0 = two-level (default), 1 = one pre-pass per 16x16 tile
+static int g_idw_variant = [] {
+  const char *e = std::getenv("PYSTEPS_HIP_IDW_VARIANT");
+  return e ? std::atoi(e) : 0;
+}();
+void set_idw_variant(int v) { g_idw_variant = v; }
+
+size_t idw_scratch_bytes(int m, int n) {
+  const size_t supers = static_cast<size_t>((n + kSuper - 1) / kSuper) * ((m + kSuper - 1) / kSuper);
+  return supers * (sizeof(SuperHeader) + kSuperCap * sizeof(float4));
+}
+
 hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
+  const float2 *xy = reinterpret_cast<const float2 *>(a.xy);
+  const float2 *uv = reinterpret_cast<const float2 *>(a.uv);
+  const int k_eff = a.k >= a.L ? 1 : a.k;
+  if (g_idw_variant == 0 && a.scratch != nullptr) {
+    const int supers_x = (a.n + kSuper - 1) / kSuper, supers_y = (a.m + kSuper - 1) / kSuper;
+    const int n_super = supers_x * supers_y;
+    SuperHeader *headers = static_cast<SuperHeader *>(a.scratch);
+    float4 *lists = reinterpret_cast<float4 *>(headers + n_super);
+    if (a.k < a.L) {
+      hipLaunchKernelGGL(idw_coarse, dim3(n_super), dim3(kThreads), 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0,
+                         a.dx, a.y0, a.dy, a.dmax, supers_x, headers, lists);
+    } else {
+      hipError_t e = hipMemsetAsync(headers, 0, n_super * sizeof(SuperHeader), stream);
+      if (e != hipSuccess) return e;
+    }
+    const int tiles_x = (a.n + kFine - 1) / kFine, tiles_y = (a.m + kFine - 1) / kFine;
+    const int n_tiles = tiles_x * tiles_y;
+    const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
+    const dim3 grid(tiles_per_xcd * kNumXcd), block(64);
+#define PSH_IDW_FINE(KMAX)                                                                            \
+  hipLaunchKernelGGL((idw_fine<KMAX>), grid, block, 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0, a.dx, \
+                     a.y0, a.dy, a.inv_res, a.power, a.offset, a.out, supers_x, headers, lists,       \
+                     tiles_x, n_tiles, tiles_per_xcd)
+    if (k_eff <= 8) {
+      PSH_IDW_FINE(8);
+    } else if (k_eff <= 20) {
+      PSH_IDW_FINE(20);
+    } else {
+      PSH_IDW_FINE(32);
+    }
+#undef PSH_IDW_FINE
+    return hipGetLastError();
+  }
   const int tiles_x = (a.n + kTile - 1) / kTile;
   const int tiles_y = (a.m + kTile - 1) / kTile;
   const int n_tiles = tiles_x * tiles_y;
   const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
   const dim3 grid(tiles_per_xcd * kNumXcd), block(kThreads);
-  const float2 *xy = reinterpret_cast<const float2 *>(a.xy);
-  const float2 *uv = reinterpret_cast<const float2 *>(a.uv);
 #define PSH_IDW_LAUNCH(KMAX)                                                                    \
   hipLaunchKernelGGL((idw_knn<KMAX>), grid, block, 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0, \
                      a.dx, a.y0, a.dy, a.inv_res, a.power, a.offset, a.dmax, a.out, tiles_x,    \
                      n_tiles, tiles_per_xcd)
-  const int k_eff = a.k >= a.L ? 1 : a.k;
   if (k_eff <= 8) {
     PSH_IDW_LAUNCH(8);
   } else if (k_eff <= 20) {
@@ -477,7 +759,13 @@ extern "C" int psh_idw_dev(const float *xy_dev, const float *values_dev, int L, 
   a.power = static_cast<float>(power);
   a.offset = static_cast<float>(dist_offset);
   a.dmax = static_cast<float>(reach_hint);
-  PSH_HIP(psh::launch_idw(a, c.stream));
+  // supertile candidate lists of the two-level kernel (stream-ordered caching allocator)
+  void *scratch = nullptr;
+  if (int rc = psh_malloc(&scratch, psh::idw_scratch_bytes(m, n))) return rc;
+  a.scratch = scratch;
+  const hipError_t le = psh::launch_idw(a, c.stream);
+  (void)psh_free(scratch);
+  if (le != hipSuccess) return psh::fail(PSH_EHIP, "idw launch failed: %s", hipGetErrorString(le));
   return PSH_OK;
 }
 

@@ -148,6 +148,12 @@ int psh_set_option(const char *key, int value) {
     psh::set_semilag_variant(value);
     return PSH_OK;
   }
+  if (std::strcmp(key, "idw_variant") == 0) {
+    if (value != 0 && value != 1)
+      return fail(PSH_EINVAL, "idw_variant must be 0 (two-level pre-pass) or 1 (pre-pass per 16x16 tile)");
+    psh::set_idw_variant(value);
+    return PSH_OK;
+  }
   if (std::strcmp(key, "trim_cache") == 0) {  // give the cached device blocks back to the driver
     psh::Context &c = ctx();
     std::lock_guard<std::recursive_mutex> lock(c.mu);

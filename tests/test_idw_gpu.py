@@ -84,6 +84,31 @@ def test_clustered_samples_overflow_path(idw):
     _close(idw(xy, uv, np.arange(n), np.arange(m)), osp.idw(xy, uv, m, n), _tie_mask(xy, m, n, 20))
 
 
+def test_fine_tile_overflow_and_variants_agree(idw):
+    """Moderately clustered samples: the supertile lists fit, some 8x8 tiles overflow their LDS list
+    (brute-force path per tile); and the one-level kernel (idw_variant 1) gives the same field."""
+    from oracle import sparse as osp
+    from pysteps_amd import _lib
+
+    rng = np.random.default_rng(9)
+    m, n = 200, 260
+    xy = np.concatenate([np.column_stack([rng.normal(60, 6, 150), rng.normal(70, 6, 150)]),
+                         np.column_stack([rng.uniform(0, n, 400), rng.uniform(0, m, 400)])])
+    uv = rng.normal(0, 1, (xy.shape[0], 2))
+    want = osp.idw(xy, uv, m, n)
+    got = idw(xy, uv, np.arange(n), np.arange(m))
+    _close(got, want, _tie_mask(xy, m, n, 20))
+    lib = _lib.lib()
+    _lib.check(lib.psh_set_option(b"idw_variant", 1))
+    try:
+        old = idw(xy, uv, np.arange(n), np.arange(m))
+    finally:
+        _lib.check(lib.psh_set_option(b"idw_variant", 0))
+    _close(old, want, _tie_mask(xy, m, n, 20))
+    keep = ~_tie_mask(xy, m, n, 20)
+    assert np.max(np.abs(old - got)[:, keep]) < 1e-5
+
+
 def test_trivial_cases_and_shapes(idw):
     xg, yg = np.arange(30), np.arange(20)
     one = idw(np.array([[3.0, 4.0]]), np.array([[1.5, -2.0]]), xg, yg)
