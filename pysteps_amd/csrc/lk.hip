@@ -288,17 +288,23 @@ __device__ __forceinline__ bool px_allowed(const float *__restrict__ clean, int 
   return true;
 }
 
+// row pitch of the product arrays: a multiple of 4 floats, so that the 4-column strips of the
+// box stage start 16-byte aligned (ds_read_b128)
+constexpr int kCrnPitch = (kCrnTX + 2 * kMaxBlockR + 3) & ~3;
+
+template <int BS>
 __global__ __launch_bounds__(256) void lk_corner_response(
     const unsigned char *__restrict__ u8, const float *__restrict__ clean, int m, int n,
-    int block_size, int buffer_mask, const float *__restrict__ stats, float *__restrict__ eig,
+    int buffer_mask, const float *__restrict__ stats, float *__restrict__ eig,
     float *__restrict__ partial) {
   constexpr int H = kMaxBlockR + 1;  // Sobel (1) + box radius (<= 3)
+  constexpr int block_size = BS;
   __shared__ float tile[kCrnTY + 2 * H][kCrnTX + 2 * H];
-  __shared__ float cxx[kCrnTY + 2 * kMaxBlockR][kCrnTX + 2 * kMaxBlockR];
-  __shared__ float cxy[kCrnTY + 2 * kMaxBlockR][kCrnTX + 2 * kMaxBlockR];
-  __shared__ float cyy[kCrnTY + 2 * kMaxBlockR][kCrnTX + 2 * kMaxBlockR];
+  __shared__ __attribute__((aligned(16))) float cxx[kCrnTY + 2 * kMaxBlockR][kCrnPitch];
+  __shared__ __attribute__((aligned(16))) float cxy[kCrnTY + 2 * kMaxBlockR][kCrnPitch];
+  __shared__ __attribute__((aligned(16))) float cyy[kCrnTY + 2 * kMaxBlockR][kCrnPitch];
   __shared__ float red[4];
-  const int r = block_size / 2;
+  constexpr int r = block_size / 2;
   const int x0 = blockIdx.x * kCrnTX, y0 = blockIdx.y * kCrnTY;
   const int tid = threadIdx.x;
   const float s = 1.0f / (4.0f * static_cast<float>(block_size) * 255.0f);
@@ -332,23 +338,48 @@ __global__ __launch_bounds__(256) void lk_corner_response(
   __syncthreads();
   float best = 0.f;
   const bool any_nan = stats[kNanCount] > 0.f;
-  for (int p = tid; p < kCrnTX * kCrnTY; p += 256) {
-    const int lx = p % kCrnTX, ly = p / kCrnTX;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x >= n || y >= m) continue;
-    double sxx = 0.0, sxy = 0.0, syy = 0.0;  // boxFilter sums 32F data in double
-    for (int j = 0; j < block_size; ++j) {
-      for (int i = 0; i < block_size; ++i) {
-        sxx += cxx[ly + j][lx + i];
-        sxy += cxy[ly + j][lx + i];
-        syy += cyy[ly + j][lx + i];
+  // Box sums.  boxFilter accumulates the float products in double; the products span 20 binary
+  // orders of magnitude with 24-bit mantissas, so every partial sum of a 7x7 window is EXACT in
+  // double and the order of summation is free: each thread owns a strip of four neighbouring
+  // pixels, sums the BS rows of its 4 + 2r columns once and slides the window along the strip
+  // (12 instead of 25 additions per pixel and array, rows read as 16-byte LDS loads).
+  {
+    constexpr int kStrip = 4, kCols = kStrip + 2 * r;
+    const int ly = tid / (kCrnTX / kStrip), lx0 = (tid % (kCrnTX / kStrip)) * kStrip;
+    double cs[3][kCols];
+#pragma unroll
+    for (int c = 0; c < kCols; ++c) cs[0][c] = cs[1][c] = cs[2][c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < BS; ++j) {
+#pragma unroll
+      for (int c = 0; c < kCols; ++c) {
+        cs[0][c] += cxx[ly + j][lx0 + c];
+        cs[1][c] += cxy[ly + j][lx0 + c];
+        cs[2][c] += cyy[ly + j][lx0 + c];
       }
     }
-    const float a = static_cast<float>(sxx) * 0.5f, b = static_cast<float>(sxy);
-    const float c = static_cast<float>(syy) * 0.5f;
-    const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-    eig[static_cast<size_t>(y) * n + x] = e;
-    if (px_allowed(clean, m, n, x, y, buffer_mask, any_nan)) best = fmaxf(best, fmaxf(e, 0.f));
+    double win[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < BS; ++c) {
+      win[0] += cs[0][c];
+      win[1] += cs[1][c];
+      win[2] += cs[2][c];
+    }
+#pragma unroll
+    for (int i = 0; i < kStrip; ++i) {
+      if (i > 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) win[q] = win[q] - cs[q][i - 1] + cs[q][i - 1 + BS];
+      }
+      const int x = x0 + lx0 + i, y = y0 + ly;
+      if (x < n && y < m) {
+        const float a = static_cast<float>(win[0]) * 0.5f, b = static_cast<float>(win[1]);
+        const float c = static_cast<float>(win[2]) * 0.5f;
+        const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+        eig[static_cast<size_t>(y) * n + x] = e;
+        if (px_allowed(clean, m, n, x, y, buffer_mask, any_nan)) best = fmaxf(best, fmaxf(e, 0.f));
+      }
+    }
   }
   best = wave_max(best);
   if ((tid & 63) == 0) red[tid >> 6] = best;
@@ -869,8 +900,19 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
   int *cnt = reinterpret_cast<int *>(base + off_cnt);
   psh::CornerKey *raw = reinterpret_cast<psh::CornerKey *>(base + off_raw);
   psh::CornerKey *sorted = reinterpret_cast<psh::CornerKey *>(base + off_sorted);
-  hipLaunchKernelGGL(psh::lk_corner_response, rgrid, dim3(256), 0, c.stream, feature_u8_dev, clean_dev,
-                     m, n, block_size, buffer_mask, stats_dev, eig, part);
+#define PSH_CRN_LAUNCH(BS)                                                                            \
+  hipLaunchKernelGGL(psh::lk_corner_response<BS>, rgrid, dim3(256), 0, c.stream, feature_u8_dev, clean_dev, \
+                     m, n, buffer_mask, stats_dev, eig, part)
+  if (block_size == 1) {
+    PSH_CRN_LAUNCH(1);
+  } else if (block_size == 3) {
+    PSH_CRN_LAUNCH(3);
+  } else if (block_size == 5) {
+    PSH_CRN_LAUNCH(5);
+  } else {
+    PSH_CRN_LAUNCH(7);
+  }
+#undef PSH_CRN_LAUNCH
   hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb, stats_dev,
                      static_cast<int>(psh::kEigMax));
   PSH_HIP(hipMemsetAsync(cnt, 0, sizeof(int), c.stream));
