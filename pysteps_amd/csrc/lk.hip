@@ -561,6 +561,8 @@ __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01,
 
 __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
 
+// kPer: window samples per thread, >= ceil(win_w * win_h / 256) (4, 10 or 16: 32x32, 50x50, 64x64)
+template <int kPer>
 __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__restrict__ pts,
                                                 int npts, int win_w, int win_h, int max_count,
                                                 float eps2, float min_eig_thr,
@@ -578,6 +580,14 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
   const float2 pt = pts[p];
   float nx = 0.f, ny = 0.f;  // tracked position (with half window added back)
   bool ok = true;
+  // window samples of this thread (the same on every level and iteration): sample i = tid + 256 q
+  int wxs[kPer], wys[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const int i = min(tid + 256 * q, area - 1);
+    wys[q] = i / win_w;
+    wxs[q] = i - wys[q] * win_w;
+  }
 
   for (int level = pyr.top; level >= 0; --level) {
     const PyrLevel L = pyr.lv[level];
@@ -600,33 +610,38 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
     int w00, w01, w10, w11;
     lk_weights(px - static_cast<float>(ipx), py - static_cast<float>(ipy), w00, w01, w10, w11);
     // ---- template patch + spatial gradient matrix -------------------------------
-    long long a11 = 0, a12 = 0, a22 = 0;
+    // per-thread partial sums fit 32 bits: |g| <= 16 * 255, <= 16 samples per thread
+    int s11 = 0, s12 = 0, s22 = 0;
     __syncthreads();  // previous level's readers are done with the LDS patch
-    for (int i = tid; i < area; i += 256) {
-      const int wy = i / win_w, wx = i - wy * win_w;
-      const int x = ipx + wx, y = ipy + wy;
-      // image taps: reflect-101 padding; gradient taps: zero outside the image
-      const int xa = reflect101(x, L.cols), xb = reflect101(x + 1, L.cols);
-      const int ya = reflect101(y, L.rows), yb = reflect101(y + 1, L.rows);
-      const unsigned char *ra = L.I + static_cast<size_t>(ya) * L.cols;
-      const unsigned char *rb = L.I + static_cast<size_t>(yb) * L.cols;
-      const int ival = descale(ra[xa] * w00 + ra[xb] * w01 + rb[xa] * w10 + rb[xb] * w11, 14 - 5);
-      const bool x_in0 = x >= 0 && x < L.cols, x_in1 = x + 1 >= 0 && x + 1 < L.cols;
-      const bool y_in0 = y >= 0 && y < L.rows, y_in1 = y + 1 >= 0 && y + 1 < L.rows;
-      const short2 z = make_short2(0, 0);
-      const short2 g00 = (x_in0 && y_in0) ? L.dI[static_cast<size_t>(y) * L.cols + x] : z;
-      const short2 g01 = (x_in1 && y_in0) ? L.dI[static_cast<size_t>(y) * L.cols + x + 1] : z;
-      const short2 g10 = (x_in0 && y_in1) ? L.dI[static_cast<size_t>(y + 1) * L.cols + x] : z;
-      const short2 g11 = (x_in1 && y_in1) ? L.dI[static_cast<size_t>(y + 1) * L.cols + x + 1] : z;
-      const int gx = descale(g00.x * w00 + g01.x * w01 + g10.x * w10 + g11.x * w11, 14);
-      const int gy = descale(g00.y * w00 + g01.y * w01 + g10.y * w10 + g11.y * w11, 14);
-      sI[i] = static_cast<short>(ival);
-      sGx[i] = static_cast<short>(gx);
-      sGy[i] = static_cast<short>(gy);
-      a11 += static_cast<long long>(gx) * gx;
-      a12 += static_cast<long long>(gx) * gy;
-      a22 += static_cast<long long>(gy) * gy;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int i = tid + 256 * q;
+      if (i < area) {
+        const int x = ipx + wxs[q], y = ipy + wys[q];
+        // image taps: reflect-101 padding; gradient taps: zero outside the image
+        const int xa = reflect101(x, L.cols), xb = reflect101(x + 1, L.cols);
+        const int ya = reflect101(y, L.rows), yb = reflect101(y + 1, L.rows);
+        const unsigned char *ra = L.I + static_cast<size_t>(ya) * L.cols;
+        const unsigned char *rb = L.I + static_cast<size_t>(yb) * L.cols;
+        const int ival = descale(ra[xa] * w00 + ra[xb] * w01 + rb[xa] * w10 + rb[xb] * w11, 14 - 5);
+        const bool x_in0 = x >= 0 && x < L.cols, x_in1 = x + 1 >= 0 && x + 1 < L.cols;
+        const bool y_in0 = y >= 0 && y < L.rows, y_in1 = y + 1 >= 0 && y + 1 < L.rows;
+        const short2 z = make_short2(0, 0);
+        const short2 g00 = (x_in0 && y_in0) ? L.dI[static_cast<size_t>(y) * L.cols + x] : z;
+        const short2 g01 = (x_in1 && y_in0) ? L.dI[static_cast<size_t>(y) * L.cols + x + 1] : z;
+        const short2 g10 = (x_in0 && y_in1) ? L.dI[static_cast<size_t>(y + 1) * L.cols + x] : z;
+        const short2 g11 = (x_in1 && y_in1) ? L.dI[static_cast<size_t>(y + 1) * L.cols + x + 1] : z;
+        const int gx = descale(g00.x * w00 + g01.x * w01 + g10.x * w10 + g11.x * w11, 14);
+        const int gy = descale(g00.y * w00 + g01.y * w01 + g10.y * w10 + g11.y * w11, 14);
+        sI[i] = static_cast<short>(ival);
+        sGx[i] = static_cast<short>(gx);
+        sGy[i] = static_cast<short>(gy);
+        s11 += gx * gx;
+        s12 += gx * gy;
+        s22 += gy * gy;
+      }
     }
+    long long a11 = s11, a12 = s12, a22 = s22;
     a11 = wave_sum_i64(a11);
     a12 = wave_sum_i64(a12);
     a22 = wave_sum_i64(a22);
@@ -657,19 +672,32 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
         break;
       }
       lk_weights(qx - static_cast<float>(inx), qy - static_cast<float>(iny), w00, w01, w10, w11);
-      long long b1 = 0, b2 = 0;
-      for (int i = tid; i < area; i += 256) {
-        const int wy = i / win_w, wx = i - wy * win_w;
-        const int x = inx + wx, y = iny + wy;
+      // all taps of the thread's samples are requested before any is used: one memory round
+      // trip per iteration instead of one per sample
+      int t00[kPer], t01[kPer], t10[kPer], t11[kPer];
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {  // (samples past the window repeat its last one, unused)
+        const int x = inx + wxs[q], y = iny + wys[q];
         const int xa = reflect101(x, L.cols), xb = reflect101(x + 1, L.cols);
         const int ya = reflect101(y, L.rows), yb = reflect101(y + 1, L.rows);
         const unsigned char *ra = L.J + static_cast<size_t>(ya) * L.cols;
         const unsigned char *rb = L.J + static_cast<size_t>(yb) * L.cols;
-        const int diff =
-            descale(ra[xa] * w00 + ra[xb] * w01 + rb[xa] * w10 + rb[xb] * w11, 14 - 5) - sI[i];
-        b1 += static_cast<long long>(diff) * sGx[i];
-        b2 += static_cast<long long>(diff) * sGy[i];
+        t00[q] = ra[xa];
+        t01[q] = ra[xb];
+        t10[q] = rb[xa];
+        t11[q] = rb[xb];
       }
+      int c1 = 0, c2 = 0;  // |diff * g| < 2^26, <= 16 samples per thread
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int i = tid + 256 * q;
+        if (i < area) {
+          const int diff = descale(t00[q] * w00 + t01[q] * w01 + t10[q] * w10 + t11[q] * w11, 14 - 5) - sI[i];
+          c1 += diff * sGx[i];
+          c2 += diff * sGy[i];
+        }
+      }
+      long long b1 = c1, b2 = c2;
       b1 = wave_sum_i64(b1);
       b2 = wave_sum_i64(b2);
       __syncthreads();  // everyone has consumed the previous reduction
@@ -1101,6 +1129,23 @@ int psh_lk_pyramids_free(void *handle) {
   return rc;
 }
 
+// picks the instantiation with the fewest window samples per thread
+static void launch_lk_track(int npts, hipStream_t stream, const psh::Pyramid &pyr, const float2 *pts, int win_w,
+                            int win_h, int max_count, float eps2, float min_eig_thr, float2 *next_pts,
+                            unsigned char *status) {
+  const int per = (win_w * win_h + 255) / 256;
+  if (per <= 4) {
+    hipLaunchKernelGGL(psh::lk_track<4>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h, max_count,
+                       eps2, min_eig_thr, next_pts, status);
+  } else if (per <= 10) {
+    hipLaunchKernelGGL(psh::lk_track<10>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h,
+                       max_count, eps2, min_eig_thr, next_pts, status);
+  } else {
+    hipLaunchKernelGGL(psh::lk_track<16>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h,
+                       max_count, eps2, min_eig_thr, next_pts, status);
+  }
+}
+
 int psh_lk_track_pyr_dev(void *handle, const float *points_host, int npts, int max_count,
                          double epsilon, double min_eig_threshold, float *next_points_host,
                          unsigned char *status_host) {
@@ -1125,8 +1170,8 @@ int psh_lk_track_pyr_dev(void *handle, const float *points_host, int npts, int m
   auto run = [&]() -> int {
     PSH_HIP(hipMemcpyAsync(d_pts, points_host, static_cast<size_t>(npts) * sizeof(float2),
                            hipMemcpyHostToDevice, c.stream));
-    hipLaunchKernelGGL(psh::lk_track, dim3(npts), dim3(256), 0, c.stream, ps->pyr, d_pts, npts, ps->win_w,
-                       ps->win_h, max_count, eps * eps, static_cast<float>(min_eig_threshold), d_next, d_st);
+    launch_lk_track(npts, c.stream, ps->pyr, d_pts, ps->win_w, ps->win_h, max_count, eps * eps,
+                    static_cast<float>(min_eig_threshold), d_next, d_st);
     PSH_HIP(hipGetLastError());
     PSH_HIP(hipMemcpyAsync(next_points_host, d_next, static_cast<size_t>(npts) * sizeof(float2),
                            hipMemcpyDeviceToHost, c.stream));
@@ -1193,8 +1238,8 @@ int lk_track_pool(void *pyramid_handle, const float *points_host, int npts, int 
   const float eps = static_cast<float>(epsilon);
   auto run = [&]() -> int {
     PSH_HIP(hipMemcpyAsync(d_pts, slot, static_cast<size_t>(npts) * sizeof(float2), hipMemcpyHostToDevice, c.stream));
-    hipLaunchKernelGGL(lk_track, dim3(npts), dim3(256), 0, c.stream, ps->pyr, d_pts, npts, ps->win_w, ps->win_h,
-                       max_count, eps * eps, static_cast<float>(min_eig_threshold), d_next, d_st);
+    launch_lk_track(npts, c.stream, ps->pyr, d_pts, ps->win_w, ps->win_h, max_count, eps * eps,
+                    static_cast<float>(min_eig_threshold), d_next, d_st);
     hipLaunchKernelGGL(lk_pool_append, dim3(1), dim3(256), 0, c.stream, d_pts, d_next, d_st, npts,
                        reinterpret_cast<double2 *>(pool_xy_dev), reinterpret_cast<double2 *>(pool_uv_dev),
                        pool_count_dev, pool_capacity);
