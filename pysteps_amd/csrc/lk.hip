@@ -736,6 +736,189 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
   }
 }
 
+// ---- row-structured tracker (windows up to 63 columns) ---------------------------------------
+// Same arithmetic as lk_track; what changes is how the window reaches the registers.  A vector
+// memory instruction costs the CU's address pipeline the same whether it gathers bytes or
+// dwords, and lk_track issues four byte gathers per window sample and pass.
+// Here a lane owns a window COLUMN and a wave a band of ROWS window rows: every image row of
+// the band is loaded once (column x by lane x - x0; lane win_w fetches the extra column), the
+// right-hand tap comes from the next lane by DPP and the lower tap row is the next row's upper
+// one - (ROWS + 1) loads per wave and pass instead of 4 * ROWS.
+__device__ __forceinline__ int from_next_lane(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+
+template <int ROWS>
+__global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *__restrict__ pts, int npts,
+                                                     int win_w, int win_h, int max_count, float eps2,
+                                                     float min_eig_thr, float2 *__restrict__ next_pts,
+                                                     unsigned char *__restrict__ status) {
+  __shared__ short sI[kMaxWin * kMaxWin];
+  __shared__ short sGx[kMaxWin * kMaxWin];
+  __shared__ short sGy[kMaxWin * kMaxWin];
+  __shared__ long long red[3][4];
+  const int p = blockIdx.x;
+  if (p >= npts) return;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
+  const float2 pt = pts[p];
+  float nx = 0.f, ny = 0.f;  // tracked position (with half window added back)
+  bool ok = true;
+  const int row_first = wave * ROWS;                          // window rows of this wave
+  const int row_count = min(ROWS, win_h - row_first);         // may be <= 0 for the last waves
+  const bool sample_lane = lane < win_w, load_lane = lane <= win_w;
+
+  for (int level = pyr.top; level >= 0; --level) {
+    const PyrLevel L = pyr.lv[level];
+    const float scale = 1.f / static_cast<float>(1 << level);
+    float px = pt.x * scale, py = pt.y * scale;
+    if (level == pyr.top) {
+      nx = px;
+      ny = py;
+    } else {
+      nx *= 2.f;
+      ny *= 2.f;
+    }
+    px -= half_x;
+    py -= half_y;
+    const int ipx = static_cast<int>(floorf(px)), ipy = static_cast<int>(floorf(py));
+    if (ipx < -win_w || ipx >= L.cols || ipy < -win_h || ipy >= L.rows) {
+      if (level == 0) ok = false;
+      continue;
+    }
+    int w00, w01, w10, w11;
+    lk_weights(px - static_cast<float>(ipx), py - static_cast<float>(ipy), w00, w01, w10, w11);
+    // ---- template patch + spatial gradient matrix -------------------------------
+    int s11 = 0, s12 = 0, s22 = 0;  // per-thread partial sums fit 32 bits (|g| <= 16 * 255)
+    __syncthreads();  // previous level's readers are done with the LDS patch
+    {
+      const int x = ipx + lane;
+      // image taps: reflect-101 padding; gradient taps: zero outside the image
+      const int xa = reflect101(x, L.cols);
+      const bool x_in = x >= 0 && x < L.cols;
+      int ti[ROWS + 1], tg[ROWS + 1];
+#pragma unroll
+      for (int r = 0; r <= ROWS; ++r) {
+        ti[r] = 0;
+        tg[r] = 0;
+        if (r <= row_count && load_lane) {
+          const int y = ipy + row_first + r;
+          ti[r] = L.I[static_cast<size_t>(reflect101(y, L.rows)) * L.cols + xa];
+          if (x_in && y >= 0 && y < L.rows)
+            tg[r] = *reinterpret_cast<const int *>(&L.dI[static_cast<size_t>(y) * L.cols + x]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        if (r < row_count) {
+          const int i00 = ti[r], i01 = from_next_lane(ti[r]), i10 = ti[r + 1], i11 = from_next_lane(ti[r + 1]);
+          const int g00 = tg[r], g01 = from_next_lane(tg[r]), g10 = tg[r + 1], g11 = from_next_lane(tg[r + 1]);
+          if (sample_lane) {
+            const int ival = descale(i00 * w00 + i01 * w01 + i10 * w10 + i11 * w11, 14 - 5);
+            // short2 (x, y) packed in one dword: x in the low half
+            const int gx = descale(static_cast<short>(g00) * w00 + static_cast<short>(g01) * w01 +
+                                       static_cast<short>(g10) * w10 + static_cast<short>(g11) * w11, 14);
+            const int gy = descale((g00 >> 16) * w00 + (g01 >> 16) * w01 + (g10 >> 16) * w10 + (g11 >> 16) * w11, 14);
+            const int i = (row_first + r) * win_w + lane;
+            sI[i] = static_cast<short>(ival);
+            sGx[i] = static_cast<short>(gx);
+            sGy[i] = static_cast<short>(gy);
+            s11 += gx * gx;
+            s12 += gx * gy;
+            s22 += gy * gy;
+          }
+        }
+      }
+    }
+    long long a11 = s11, a12 = s12, a22 = s22;
+    a11 = wave_sum_i64(a11);
+    a12 = wave_sum_i64(a12);
+    a22 = wave_sum_i64(a22);
+    if (lane == 0) {
+      red[0][wave] = a11;
+      red[1][wave] = a12;
+      red[2][wave] = a22;
+    }
+    __syncthreads();
+    const float flt_scale = 1.f / 1048576.f;  // 2^-20
+    const float A11 = static_cast<float>(red[0][0] + red[0][1] + red[0][2] + red[0][3]) * flt_scale;
+    const float A12 = static_cast<float>(red[1][0] + red[1][1] + red[1][2] + red[1][3]) * flt_scale;
+    const float A22 = static_cast<float>(red[2][0] + red[2][1] + red[2][2] + red[2][3]) * flt_scale;
+    float D = A11 * A22 - A12 * A12;
+    const float min_eig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
+                          static_cast<float>(2 * win_w * win_h);
+    if (min_eig < min_eig_thr || D < 1.1920929e-07f) {
+      if (level == 0) ok = false;
+      continue;
+    }
+    D = 1.f / D;
+    float qx = nx - half_x, qy = ny - half_y;
+    float prev_dx = 0.f, prev_dy = 0.f;
+    for (int j = 0; j < max_count; ++j) {
+      const int inx = static_cast<int>(floorf(qx)), iny = static_cast<int>(floorf(qy));
+      if (inx < -win_w || inx >= L.cols || iny < -win_h || iny >= L.rows) {
+        if (level == 0) ok = false;
+        break;
+      }
+      lk_weights(qx - static_cast<float>(inx), qy - static_cast<float>(iny), w00, w01, w10, w11);
+      const int xa = reflect101(inx + lane, L.cols);
+      int tj[ROWS + 1];
+#pragma unroll
+      for (int r = 0; r <= ROWS; ++r) {
+        tj[r] = 0;
+        if (r <= row_count && load_lane)
+          tj[r] = L.J[static_cast<size_t>(reflect101(iny + row_first + r, L.rows)) * L.cols + xa];
+      }
+      int c1 = 0, c2 = 0;  // |diff * g| < 2^26, <= 16 samples per thread
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) {
+        if (r < row_count) {
+          const int j01 = from_next_lane(tj[r]), j11 = from_next_lane(tj[r + 1]);
+          if (sample_lane) {
+            const int i = (row_first + r) * win_w + lane;
+            const int diff = descale(tj[r] * w00 + j01 * w01 + tj[r + 1] * w10 + j11 * w11, 14 - 5) - sI[i];
+            c1 += diff * sGx[i];
+            c2 += diff * sGy[i];
+          }
+        }
+      }
+      long long b1 = c1, b2 = c2;
+      b1 = wave_sum_i64(b1);
+      b2 = wave_sum_i64(b2);
+      __syncthreads();  // everyone has consumed the previous reduction
+      if (lane == 0) {
+        red[0][wave] = b1;
+        red[1][wave] = b2;
+      }
+      __syncthreads();
+      const float B1 = static_cast<float>(red[0][0] + red[0][1] + red[0][2] + red[0][3]) * flt_scale;
+      const float B2 = static_cast<float>(red[1][0] + red[1][1] + red[1][2] + red[1][3]) * flt_scale;
+      const float dx = (A12 * B2 - A22 * B1) * D;
+      const float dy = (A12 * B1 - A11 * B2) * D;
+      qx += dx;
+      qy += dy;
+      nx = qx + half_x;
+      ny = qy + half_y;
+      if (dx * dx + dy * dy <= eps2) break;
+      if (j > 0 && fabsf(dx + prev_dx) < 0.01f && fabsf(dy + prev_dy) < 0.01f) {
+        nx -= dx * 0.5f;
+        ny -= dy * 0.5f;
+        break;
+      }
+      prev_dx = dx;
+      prev_dy = dy;
+    }
+    if (level == 0 && ok) {
+      const int rx = static_cast<int>(rintf(nx - half_x)), ry = static_cast<int>(rintf(ny - half_y));
+      if (rx < -win_w || rx >= L.cols || ry < -win_h || ry >= L.rows) ok = false;
+    }
+  }
+  if (tid == 0) {
+    next_pts[p] = make_float2(nx, ny);
+    status[p] = ok ? 1 : 0;
+  }
+}
+
 // successful tracks -> pooled (xy, uv) float64 pairs in tracking order, appended behind the
 // vectors of earlier frame pairs (lucaskanade.py:241-242); one workgroup, ordered compaction
 __global__ __launch_bounds__(256) void lk_pool_append(const float2 *__restrict__ pts,
@@ -1134,6 +1317,21 @@ static void launch_lk_track(int npts, hipStream_t stream, const psh::Pyramid &py
                             int win_h, int max_count, float eps2, float min_eig_thr, float2 *next_pts,
                             unsigned char *status) {
   const int per = (win_w * win_h + 255) / 256;
+  if (win_w <= 63) {  // one lane per window column, ceil(win_h / 4) rows per wave
+#define PSH_TRACK_ROWS(R)                                                                               \
+  hipLaunchKernelGGL(psh::lk_track_rows<R>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h, \
+                     max_count, eps2, min_eig_thr, next_pts, status)
+    const int rows = (win_h + 3) / 4;
+    if (rows <= 8) {
+      PSH_TRACK_ROWS(8);
+    } else if (rows <= 13) {
+      PSH_TRACK_ROWS(13);
+    } else {
+      PSH_TRACK_ROWS(16);
+    }
+#undef PSH_TRACK_ROWS
+    return;
+  }
   if (per <= 4) {
     hipLaunchKernelGGL(psh::lk_track<4>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h, max_count,
                        eps2, min_eig_thr, next_pts, status);

@@ -124,6 +124,27 @@ def test_tracker_matches_oracle(lkmod, shape, shift):
         assert np.abs((got - pts)[inner] - shift).max() < 0.05
 
 
+@pytest.mark.parametrize("win", [(21, 21), (15, 31), (63, 40), (64, 64), (37, 64)])
+def test_tracker_window_sizes(lkmod, win):
+    """Every tracker instantiation (row-structured 8 / 13 / 16 rows per wave, and the gather kernel
+    that takes 64-column windows) against the oracle."""
+    from oracle import lk_opencv as olk
+
+    m, n = 260, 300
+    a = _texture(m, n, seed=win[0])
+    b = np.roll(a, (1, -2), axis=(0, 1)) + _texture(m, n, seed=win[1] + 7) * 0.02
+    pa, pb = _prep(lkmod, a, 0, 0), _prep(lkmod, b, 0, 0)
+    ones = np.ones((m, n), bool)
+    a8 = olk.to_uint8(a, ones, a.min(), a.max(), a.min())
+    b8 = olk.to_uint8(b, ones, b.min(), b.max(), b.min())
+    pts = olk.good_features_to_track(a8, ones, max_corners=150)
+    pts = np.vstack([pts, [[0.0, 0.0], [n - 1.0, m - 1.0], [2.5, m / 2.0]]]).astype(np.float32)
+    want, wst = olk.calc_optical_flow_pyr_lk(a8, b8, pts, win=win)
+    got, gst = lkmod.track_points(pa, pb, pts, winsize=win)
+    assert np.array_equal(gst, wst)
+    assert np.abs(got[wst] - want[wst]).max() < 1e-2
+
+
 def test_tracker_small_image_fewer_levels(lkmod):
     """levels are dropped until the image is larger than the window (buildOpticalFlowPyramid)."""
     from oracle import lk_opencv as olk
