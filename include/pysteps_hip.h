@@ -71,6 +71,10 @@ int psh_event_elapsed_ms(void *start, void *stop, float *ms); /* waits for stop 
 /* Known-traffic streaming copy (vec_width 1 = dword, 4 = dwordx4 per lane) used to
  * calibrate rocprofv3 FETCH_SIZE/WRITE_SIZE on gfx950; not part of the hot path. */
 int psh_calib_copy(float *dst_dev, const float *src_dev, size_t nfloats, int vec_width);
+/* which source lane the wavefront / row shift DPP controls deliver on this device
+ * (tools/dpp_probe.py): out_dev receives 6 x 64 ints (wave_shl:1, wave_shr:1, wave_rol:1,
+ * wave_ror:1, row_shl:1, row_shr:1), -1 where no lane was delivered. */
+int psh_calib_dpp(int *out_dev);
 /* gather microbenchmark (tools/gather_probe.py): blocks_per_cu * CUs workgroups of 4 waves, each
  * wave issues iters * 8 buffer loads of `width` (1, 2, 4) dwords per lane, lane i at column
  * i * width + shift, walking cyclically over `n_rows` rows (power of two, `pitch_bytes` apart;

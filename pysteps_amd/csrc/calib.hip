@@ -59,8 +59,30 @@ __global__ __launch_bounds__(256) void calib_gather(const float *__restrict__ sr
   if (acc == 123.456f) sink[threadIdx.x] = acc;
 }
 
+// which lane does each DPP control deliver?  out[c * 64 + lane] = lane id received (-1: none)
+__global__ __launch_bounds__(64) void calib_dpp(int *__restrict__ out) {
+  const int lane = threadIdx.x;
+  out[0 * 64 + lane] = __builtin_amdgcn_update_dpp(-1, lane, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  out[1 * 64 + lane] = __builtin_amdgcn_update_dpp(-1, lane, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  out[2 * 64 + lane] = __builtin_amdgcn_update_dpp(-1, lane, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+  out[3 * 64 + lane] = __builtin_amdgcn_update_dpp(-1, lane, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
+  out[4 * 64 + lane] = __builtin_amdgcn_update_dpp(-1, lane, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+  out[5 * 64 + lane] = __builtin_amdgcn_update_dpp(-1, lane, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+}
+
 }  // namespace
 }  // namespace psh
+
+extern "C" int psh_calib_dpp(int *out_dev) {
+  PSH_REQUIRE_INIT();
+  if (!out_dev) return psh::fail(PSH_EINVAL, "psh_calib_dpp: NULL pointer");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  hipLaunchKernelGGL(psh::calib_dpp, dim3(1), dim3(64), 0, c.stream, out_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
 
 extern "C" int psh_calib_gather(const float *src_dev, float *sink_dev, int pitch_bytes, int width, int shift,
                                 int iters, int blocks_per_cu, int n_rows, int active_lanes) {

@@ -88,14 +88,26 @@ __global__ __launch_bounds__(256) void lk_stats1(const float *__restrict__ img, 
                                                  float *__restrict__ partial) {
   float mn = INFINITY, bad = 0.f;
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < npx; i += stride) {
-    const float v = img[i];
-    if (isfinite(v)) {
-      mn = fminf(mn, v);
-    } else {
-      bad += 1.f;
-    }
+  const size_t first = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  auto take = [&](float v) {
+    const bool fin = isfinite(v);
+    mn = fminf(mn, fin ? v : INFINITY);
+    bad += fin ? 0.f : 1.f;
+  };
+  // 16-byte loads, two in flight per thread (a streaming read is bound by bytes in flight)
+  const size_t n4 = (reinterpret_cast<uintptr_t>(img) % 16 == 0) ? npx / 4 : 0;
+  const float4 *img4 = reinterpret_cast<const float4 *>(img);
+  size_t i = first;
+  for (; i + stride < n4; i += 2 * stride) {
+    const float4 a = img4[i], b = img4[i + stride];
+    take(a.x), take(a.y), take(a.z), take(a.w);
+    take(b.x), take(b.y), take(b.z), take(b.w);
   }
+  for (; i < n4; i += stride) {
+    const float4 a = img4[i];
+    take(a.x), take(a.y), take(a.z), take(a.w);
+  }
+  for (size_t j = 4 * n4 + first; j < npx; j += stride) take(img[j]);
   __shared__ float s[2][4];
   mn = wave_min(mn);
   bad = wave_sum(bad);
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(256) void lk_to_u8(const float *__restrict__ clean,
   const float flo = stats[kMinFeat], fhi = stats[kMaxFeat];
   const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
   const size_t npx = static_cast<size_t>(m) * n;
+  const size_t first_feature_px = static_cast<size_t>(first_row) * n;
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
   for (size_t i = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i < npx;
        i += stride) {
@@ -252,8 +265,7 @@ __global__ __launch_bounds__(256) void lk_to_u8(const float *__restrict__ clean,
       const bool ok = isfinite(v);
       if (!ok) v = fill;
       t[j] = quantise(v, fill, hi);
-      const int row = static_cast<int>(p / n);
-      f[j] = quantise((ok && row >= first_row) ? v : fill, flo, fhi);
+      f[j] = quantise((ok && p >= first_feature_px) ? v : fill, flo, fhi);  // rows >= first_row
     }
     if (i + 3 < npx && (npx & 3) == 0) {
       *reinterpret_cast<uchar4 *>(trk + i) = make_uchar4(t[0], t[1], t[2], t[3]);
@@ -744,9 +756,14 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
 // the band is loaded once (column x by lane x - x0; lane win_w fetches the extra column), the
 // right-hand tap comes from the next lane by DPP and the lower tap row is the next row's upper
 // one - (ROWS + 1) loads per wave and pass instead of 4 * ROWS.
+// The Scharr gradients of the template window (calcSharrDeriv: reflect-101 stencil inside the
+// image, zero outside) are computed here from the same rows, so no gradient image is built at
+// all: the tracker touches ~1000 windows, the full-image Scharr pass wrote 5 bytes per pixel of
+// every level.
 __device__ __forceinline__ int from_next_lane(int v) {
   return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
+constexpr int kRowsMaxWin = 61;  // window columns + 3 (Scharr halo, right tap) have to fit a wave
 
 template <int ROWS>
 __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *__restrict__ pts, int npts,
@@ -792,30 +809,49 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
     int s11 = 0, s12 = 0, s22 = 0;  // per-thread partial sums fit 32 bits (|g| <= 16 * 255)
     __syncthreads();  // previous level's readers are done with the LDS patch
     {
-      const int x = ipx + lane;
-      // image taps: reflect-101 padding; gradient taps: zero outside the image
+      // lanes 0 .. win_w + 2 LOAD image columns ipx - 1 .. ipx + win_w + 1; everything a lane then
+      // works on belongs to the column one to the right, xd = ipx + lane, assembled from lanes
+      // l, l + 1, l + 2 with wave_shl DPP only (a centred form with wave_shr folded into the
+      // subtraction came out with zero x-gradients on the device, although a plain
+      // v_mov_b32_dpp wave_shr:1 does deliver lane l - 1: tools/dpp_probe.py)
+      const int x = ipx - 1 + lane;
       const int xa = reflect101(x, L.cols);
-      const bool x_in = x >= 0 && x < L.cols;
-      int ti[ROWS + 1], tg[ROWS + 1];
+      const int xd = ipx + lane;
+      const bool xd_in = xd >= 0 && xd < L.cols;
+      const bool tpl_load = lane <= win_w + 2;
+      // image rows ipy + row_first - 1 ... + row_count + 1 (reflect-101), one byte per lane
+      int ti[ROWS + 3];
+#pragma unroll
+      for (int r = 0; r < ROWS + 3; ++r) {
+        ti[r] = 0;
+        if (r < row_count + 3 && tpl_load)
+          ti[r] = L.I[static_cast<size_t>(reflect101(ipy + row_first - 1 + r, L.rows)) * L.cols + xa];
+      }
+      // Scharr gradients of column xd at rows ipy + row_first ... + row_count: (Ix, Iy) packed
+      int tg[ROWS + 1];
 #pragma unroll
       for (int r = 0; r <= ROWS; ++r) {
-        ti[r] = 0;
         tg[r] = 0;
-        if (r <= row_count && load_lane) {
+        if (r <= row_count) {
+          const int up = ti[r], mid = ti[r + 1], dn = ti[r + 2];
+          const int t0 = (up + dn) * 3 + mid * 10, t1 = dn - up;  // column xd - 1
+          const int t0_r = from_next_lane(from_next_lane(t0));     // column xd + 1
+          const int t1_c = from_next_lane(t1), t1_r = from_next_lane(t1_c);
+          const int gx = t0_r - t0;
+          const int gy = (t1 + t1_r) * 3 + t1_c * 10;
           const int y = ipy + row_first + r;
-          ti[r] = L.I[static_cast<size_t>(reflect101(y, L.rows)) * L.cols + xa];
-          if (x_in && y >= 0 && y < L.rows)
-            tg[r] = *reinterpret_cast<const int *>(&L.dI[static_cast<size_t>(y) * L.cols + x]);
+          const bool in = xd_in && y >= 0 && y < L.rows;  // the gradient image is zero-padded
+          tg[r] = in ? ((gy << 16) | (gx & 0xffff)) : 0;
         }
       }
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
         if (r < row_count) {
-          const int i00 = ti[r], i01 = from_next_lane(ti[r]), i10 = ti[r + 1], i11 = from_next_lane(ti[r + 1]);
+          const int i00 = from_next_lane(ti[r + 1]), i01 = from_next_lane(i00);
+          const int i10 = from_next_lane(ti[r + 2]), i11 = from_next_lane(i10);
           const int g00 = tg[r], g01 = from_next_lane(tg[r]), g10 = tg[r + 1], g11 = from_next_lane(tg[r + 1]);
           if (sample_lane) {
             const int ival = descale(i00 * w00 + i01 * w01 + i10 * w10 + i11 * w11, 14 - 5);
-            // short2 (x, y) packed in one dword: x in the low half
             const int gx = descale(static_cast<short>(g00) * w00 + static_cast<short>(g01) * w01 +
                                        static_cast<short>(g10) * w10 + static_cast<short>(g11) * w11, 14);
             const int gy = descale((g00 >> 16) * w00 + (g01 >> 16) * w01 + (g10 >> 16) * w10 + (g11 >> 16) * w11, 14);
@@ -1258,13 +1294,17 @@ int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *n
     bytes += (nb + 255) & ~static_cast<size_t>(255);
     return at;
   };
+  // the row-structured tracker computes the Scharr gradients of its windows itself; only the
+  // gather kernel for wider windows reads a gradient image
+  const bool need_deriv = win_w > psh::kRowsMaxWin;
   size_t off_i[psh::kMaxLevels], off_j[psh::kMaxLevels], off_d[psh::kMaxLevels];
   for (int l = 0; l <= top; ++l) {
     const size_t px = static_cast<size_t>(rows[l]) * cols[l];
     off_i[l] = l ? take(px) : 0;
     off_j[l] = l ? take(px) : 0;
-    off_d[l] = take(px * sizeof(short2));
+    off_d[l] = need_deriv ? take(px * sizeof(short2)) : 0;
   }
+  if (bytes == 0) bytes = 256;  // single level, no gradient image: nothing to store
   PyramidSet *ps = new PyramidSet();
   if (int rc = psh_malloc(&ps->block, bytes)) {
     delete ps;
@@ -1277,7 +1317,7 @@ int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *n
   for (int l = 0; l <= top; ++l) {
     unsigned char *Il = l ? reinterpret_cast<unsigned char *>(base + off_i[l]) : const_cast<unsigned char *>(prev_u8_dev);
     unsigned char *Jl = l ? reinterpret_cast<unsigned char *>(base + off_j[l]) : const_cast<unsigned char *>(next_u8_dev);
-    short2 *dl = reinterpret_cast<short2 *>(base + off_d[l]);
+    short2 *dl = need_deriv ? reinterpret_cast<short2 *>(base + off_d[l]) : nullptr;
     if (l) {
       const dim3 g((cols[l] + 31) / 32, (rows[l] + 7) / 8);
       hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, ps->pyr.lv[l - 1].I, rows[l - 1],
@@ -1285,8 +1325,10 @@ int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *n
       hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, ps->pyr.lv[l - 1].J, rows[l - 1],
                          cols[l - 1], Jl, rows[l], cols[l]);
     }
-    const dim3 sg((cols[l] + 63) / 64, (rows[l] + 3) / 4);
-    hipLaunchKernelGGL(psh::lk_scharr, sg, dim3(256), 0, c.stream, Il, rows[l], cols[l], dl);
+    if (need_deriv) {
+      const dim3 sg((cols[l] + 63) / 64, (rows[l] + 3) / 4);
+      hipLaunchKernelGGL(psh::lk_scharr, sg, dim3(256), 0, c.stream, Il, rows[l], cols[l], dl);
+    }
     ps->pyr.lv[l].I = Il;
     ps->pyr.lv[l].J = Jl;
     ps->pyr.lv[l].dI = dl;
@@ -1317,7 +1359,7 @@ static void launch_lk_track(int npts, hipStream_t stream, const psh::Pyramid &py
                             int win_h, int max_count, float eps2, float min_eig_thr, float2 *next_pts,
                             unsigned char *status) {
   const int per = (win_w * win_h + 255) / 256;
-  if (win_w <= 63) {  // one lane per window column, ceil(win_h / 4) rows per wave
+  if (win_w <= psh::kRowsMaxWin) {  // one lane per window column, ceil(win_h / 4) rows per wave
 #define PSH_TRACK_ROWS(R)                                                                               \
   hipLaunchKernelGGL(psh::lk_track_rows<R>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h, \
                      max_count, eps2, min_eig_thr, next_pts, status)
