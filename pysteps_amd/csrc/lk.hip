@@ -217,6 +217,89 @@ __global__ __launch_bounds__(256) void lk_open(const float *__restrict__ img, in
   }
 }
 
+// The same pass with 16-byte accesses (n a multiple of 4, 16-byte aligned planes): the haloed
+// field tile is fetched as float4 columns [x0 - 4, x0 + 68) and each thread opens and stores
+// four neighbouring pixels - a quarter of the vector memory instructions of lk_open.
+__global__ __launch_bounds__(256) void lk_open_vec(const float *__restrict__ img, int m, int n,
+                                                   int size_opening, int buffer_mask,
+                                                   const float *__restrict__ stats,
+                                                   float *__restrict__ clean,
+                                                   float *__restrict__ partial) {
+  constexpr int kW4 = kOpenTX / 4 + 2;  // float4 columns of the haloed tile
+  __shared__ unsigned char fld[kOpenTY + 4][kW4 * 4];  // column c <-> image x0 - 4 + c
+  __shared__ unsigned char ero[kOpenTY + 2][kOpenTX + 2];
+  __shared__ float red[3][4];
+  const float mn = stats[kMinAll];
+  const int x0 = blockIdx.x * kOpenTX, y0 = blockIdx.y * kOpenTY;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < (kOpenTY + 4) * kW4; i += 256) {
+    const int ly = i / kW4, c4 = i % kW4;
+    const int y = y0 + ly - 2, x = x0 - 4 + 4 * c4;
+    uchar4 f = make_uchar4(2, 2, 2, 2);
+    if (x >= 0 && x < n && y >= 0 && y < m) {  // n % 4 == 0: a float4 is inside or outside as a whole
+      const float4 v = *reinterpret_cast<const float4 *>(img + static_cast<size_t>(y) * n + x);
+      f.x = (isfinite(v.x) && v.x > mn) ? 1 : 0;  // masked pixels are filled with the minimum
+      f.y = (isfinite(v.y) && v.y > mn) ? 1 : 0;
+      f.z = (isfinite(v.z) && v.z > mn) ? 1 : 0;
+      f.w = (isfinite(v.w) && v.w > mn) ? 1 : 0;
+    }
+    *reinterpret_cast<uchar4 *>(&fld[ly][4 * c4]) = f;
+  }
+  __syncthreads();
+  for (int i = tid; i < (kOpenTY + 2) * (kOpenTX + 2); i += 256) {
+    const int ly = i / (kOpenTX + 2), lx = i % (kOpenTX + 2);
+    // erosion at (y0+ly-1, x0+lx-1); outside-image taps are neutral (count as set)
+    const int cy = ly + 1, cx = lx + 3;
+    const bool e = fld[cy][cx] == 1 && fld[cy - 1][cx] != 0 && fld[cy + 1][cx] != 0 &&
+                   fld[cy][cx - 1] != 0 && fld[cy][cx + 1] != 0;
+    ero[ly][lx] = e ? 1 : 0;
+  }
+  __syncthreads();
+  float mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
+  // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
+  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+  {
+    const int lx = (tid % (kOpenTX / 4)) * 4, ly = tid / (kOpenTX / 4);
+    const int x = x0 + lx, y = y0 + ly;
+    if (x < n && y < m) {
+      float4 v4 = *reinterpret_cast<const float4 *>(img + static_cast<size_t>(y) * n + x);
+      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (size_opening > 0 && isfinite(v[j]) && v[j] > mn) {
+          const int cy = ly + 1, cx = lx + j + 1;
+          const bool opened = ero[cy][cx] | ero[cy - 1][cx] | ero[cy + 1][cx] | ero[cy][cx - 1] |
+                              ero[cy][cx + 1];
+          if (!opened) v[j] = mn;
+        }
+        if (isfinite(v[j])) {
+          mx_all = fmaxf(mx_all, v[j]);
+          if (y >= first_row) {
+            mn_feat = fminf(mn_feat, v[j]);
+            mx_feat = fmaxf(mx_feat, v[j]);
+          }
+        }
+      }
+      *reinterpret_cast<float4 *>(clean + static_cast<size_t>(y) * n + x) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  mx_all = wave_max(mx_all);
+  mn_feat = wave_min(mn_feat);
+  mx_feat = wave_max(mx_feat);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = mx_all;
+    red[1][tid >> 6] = mn_feat;
+    red[2][tid >> 6] = mx_feat;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
+    partial[b] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    partial[nb + b] = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+    partial[2 * nb + b] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+  }
+}
+
 __global__ __launch_bounds__(kFinalThreads) void lk_open_final(const float *__restrict__ partial,
                                                                int nb, float *__restrict__ stats) {
   __shared__ float smem[16];
@@ -1047,8 +1130,15 @@ int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, i
   float *part2 = part1 + 2 * psh::kRedBlocks;
   hipLaunchKernelGGL(psh::lk_stats1, dim3(psh::kRedBlocks), dim3(256), 0, c.stream, frame_dev, npx, part1);
   hipLaunchKernelGGL(psh::lk_stats1_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part1, psh::kRedBlocks, stats_dev);
-  hipLaunchKernelGGL(psh::lk_open, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening,
-                     buffer_mask, stats_dev, clean_dev, part2);
+  const bool vec_ok = n % 4 == 0 && reinterpret_cast<uintptr_t>(frame_dev) % 16 == 0 &&
+                      reinterpret_cast<uintptr_t>(clean_dev) % 16 == 0;
+  if (vec_ok) {
+    hipLaunchKernelGGL(psh::lk_open_vec, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening,
+                       buffer_mask, stats_dev, clean_dev, part2);
+  } else {
+    hipLaunchKernelGGL(psh::lk_open, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening,
+                       buffer_mask, stats_dev, clean_dev, part2);
+  }
   hipLaunchKernelGGL(psh::lk_open_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part2, nb_open, stats_dev);
   const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
   hipLaunchKernelGGL(psh::lk_to_u8, dim3(qgrid), dim3(256), 0, c.stream, clean_dev, m, n, buffer_mask,
