@@ -15,19 +15,17 @@
 //    weights therefore keep full fp32 precision however far the trajectory has
 //    travelled, and the "advected from outside" test of map_coordinates
 //    (coord < 0 or coord > len-1, strict) becomes an integer comparison.
-//  * 64x8-pixel workgroups of 4 waves; a thread owns the SAME column in two
-//    adjacent rows, i.e. two independent trajectories whose loads are all issued
-//    before either is consumed (the kernel is latency/L1 bound: twice the
-//    memory-level parallelism per wave, and the shared middle tap row hits L1).
-//    A wave reads 64 consecutive floats per tap row (coalesced up to the sub-row
-//    shift).  The block index is remapped so that each XCD (block b
-//    runs on XCD b % 8) owns one contiguous horizontal band of the image and
-//    its private 4 MiB L2 sees all the halo reuse of that band.
-//  * Waves whose 64 lanes all have their four taps strictly inside the image (almost
-//    all of them) take a clamp-free path where one lane offset addresses every
-//    plane (+1 column = immediate offset, +1 row = second uniform base).
-//  * No LDS, no MFMA: the gather footprint moves with D and there is no dense
-//    contraction.  The kernel is bound by HBM/LLC bandwidth.
+//  * 64x4-pixel workgroups of 4 waves, one image row per wave, one pixel per lane (two rows
+//    per thread were measured equal).  A wave reads 64 consecutive floats per tap row
+//    (coalesced up to the sub-row shift).  The block index is remapped so that each XCD
+//    (block b runs on XCD b % 8) owns one contiguous horizontal band of the image and its
+//    private 4 MiB L2 sees all the halo reuse of that band.
+//  * Waves whose 64 lanes all have their four taps strictly inside the image (almost all of
+//    them) take a clamp-free path: buffer loads with one lane offset for every plane (+1 row
+//    = scalar offset), the right-hand column of each lane's 2x2 footprint taken from lane
+//    i+1 by DPP (v_cndmask_b32_dpp) unless the neighbour's trajectory sits elsewhere.
+//  * No LDS (default variant), no MFMA: the gather footprint moves with D and there is no
+//    dense contraction.  The kernel is bound by the CU's vector-memory pipeline.
 #include <cstdlib>
 
 #include "common.h"
@@ -122,17 +120,32 @@ __device__ __forceinline__ void sample_interior(const Fields &F, const int (&X)[
   unsigned long long own[NPX];
   float a[NPX], c[NPX], e[NPX], g[NPX], pa[NPX], pc[NPX];
   float b[NPX], d[NPX], f[NPX], h[NPX], pb[NPX], pd[NPX];
+  float lb[NPX], ld_[NPX], lf[NPX], lh[NPX], lpb[NPX], lpd[NPX];  // lane 63's right column (SGPRs)
   const int rb = F.row_bytes;
+  const bool last_lane = (threadIdx.x & 63) == 63;
 #pragma unroll
   for (int j = 0; j < NPX; ++j) {
     off[j] = static_cast<unsigned>(__mul24(Y[j], n) + X[j]) << 2;
+    // Lane 63 has no right neighbour.  Its right column is one address per wave: fetched with
+    // SCALAR loads (s_load_dword through the scalar cache), it costs the vector memory pipeline
+    // nothing - an exec-masked vector load for one lane would cost it as much as a full one
+    // (tools/gather_probe.py), and in smooth motion lane 63 is the only lane that needs one.
+    const unsigned off63 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(off[j]), 63)) + 4u;
+    lb[j] = ld(F.u0, off63);
+    ld_[j] = ld(F.u1, off63);
+    lf[j] = ld(F.v0, off63);
+    lh[j] = ld(F.v1, off63);
+    if (WITH_P) {
+      lpb[j] = ld(F.p0, off63);
+      lpd[j] = ld(F.p1, off63);
+    }
     // interior positions have X + 1 <= n - 1, so "the neighbour's linear offset is mine + 1"
     // is the same statement as "same row, next column"
-    const bool own_right = from_next_lane_or_zero(off[j]) != off[j] + 4u;
-    own[j] = __builtin_amdgcn_ballot_w64(own_right);
+    const bool own_right = from_next_lane_or_zero(off[j]) != off[j] + 4u && !last_lane;
+    own[j] = __builtin_amdgcn_ballot_w64(own_right) | (1ull << 63);
     b[j] = any_value(), d[j] = any_value(), f[j] = any_value(), h[j] = any_value();
     if (WITH_P) pb[j] = any_value(), pd[j] = any_value();
-    if (own_right) {
+    if (own_right) {  // skipped by the whole wave (s_cbranch_execz) when no trajectory crossed
       b[j] = bld(F.ru, off[j] + 4u, 0);
       d[j] = bld(F.ru, off[j] + 4u, rb);
       f[j] = bld(F.rv, off[j] + 4u, 0);
@@ -157,10 +170,16 @@ __device__ __forceinline__ void sample_interior(const Fields &F, const int (&X)[
 #pragma unroll
   for (int j = 0; j < NPX; ++j) {
     const Weights w = make_weights(fx[j], fy[j]);
+    b[j] = last_lane ? lb[j] : b[j];
+    d[j] = last_lane ? ld_[j] : d[j];
+    f[j] = last_lane ? lf[j] : f[j];
+    h[j] = last_lane ? lh[j] : h[j];
     take_right_columns(own[j], a[j], c[j], e[j], g[j], b[j], d[j], f[j], h[j]);
     su[j] = blend(w, a[j], b[j], c[j], d[j]);
     sv[j] = blend(w, e[j], f[j], g[j], h[j]);
     if (WITH_P) {
+      pb[j] = last_lane ? lpb[j] : pb[j];
+      pd[j] = last_lane ? lpd[j] : pd[j];
       take_right_columns(own[j], pa[j], pc[j], pb[j], pd[j]);
       sp[j] = blend(w, pa[j], pb[j], pc[j], pd[j]);
     }
