@@ -540,12 +540,17 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
   const int y_first = blockIdx.y * kSelRows + wave * (kSelRows / 4);
   const float thr = stats[kEigMax] * quality;
   const bool any_nan = stats[kNanCount] > 0.f;
-  // pass 1: how many candidates does this wave hold (a single global counter saturates at
-  // ~90 atomics/us, so the workgroup reserves its output range with ONE atomic)
+  // pass 1: which pixels of the wave's 16 rows are candidates (a single global counter saturates
+  // at ~90 atomics/us, so the workgroup reserves its output range with ONE atomic); the ballots
+  // are kept, the response image is streamed once
+  constexpr int kRows = kSelRows / 4;
+  unsigned long long masks[kRows];
   int mine = 0;
-  for (int r = 0; r < kSelRows / 4; ++r) {
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
     float v;
-    mine += __popcll(__ballot(corner_keep(eig, clean, m, n, x, y_first + r, buffer_mask, thr, any_nan, v)));
+    masks[r] = __ballot(corner_keep(eig, clean, m, n, x, y_first + r, buffer_mask, thr, any_nan, v));
+    mine += __popcll(masks[r]);
   }
   if (lane == 0) wave_count[wave] = mine;
   __syncthreads();
@@ -557,15 +562,16 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
   int pos = block_base;
   for (int w = 0; w < wave; ++w) pos += wave_count[w];
   if (mine == 0) return;
-  // pass 2: same predicate, now with a destination
-  for (int r = 0; r < kSelRows / 4; ++r) {
-    float v;
+  // pass 2: the kept pixels get their destination
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    const unsigned long long mask = masks[r];
+    if (mask == 0) continue;
     const int y = y_first + r;
-    const bool keep = corner_keep(eig, clean, m, n, x, y, buffer_mask, thr, any_nan, v);
-    const unsigned long long mask = __ballot(keep);
-    if (keep) {
+    if ((mask >> lane) & 1ull) {
       const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
-      if (at < cap) out[at] = make_corner_key(v, static_cast<unsigned>(y) * n + x);
+      if (at < cap)
+        out[at] = make_corner_key(eig[static_cast<size_t>(y) * n + x], static_cast<unsigned>(y) * n + x);
     }
     pos += __popcll(mask);
   }
