@@ -323,3 +323,29 @@ def test_flat_and_constant_frames(dense_lk):
     half = flat.copy()
     half[:, :, :40] = np.nan
     assert np.all(dense_lk(half) == 0)
+
+
+def test_config2_2048_three_frames(dense_lk):
+    """BASELINE config 2: 2048^2, 3 input frames (two frame pairs pooled), device resident: the
+    estimate gives the known motion back and equals the estimate from host arrays."""
+    from pysteps_amd import _lib, extrapolation
+    from pysteps_amd.device import DeviceArray
+    from tools import synth
+
+    m = n = 2048
+    base = synth.rain_field_db(m, n)
+    vel = synth.true_velocity(m, n)
+    vel_d = DeviceArray.from_host(vel)
+    frames = DeviceArray((3, m, n), np.float32)
+    lib = _lib.lib()
+    _lib.check(lib.psh_memcpy_h2d(frames.ptr, base.ctypes.data, base.nbytes))
+    adv = extrapolation.get_method("semilagrangian")(frames.view(0), vel_d, 2, outval=-15.0)
+    _lib.check(lib.psh_memcpy_d2d(frames.view(1).ptr, adv.ptr, 2 * base.nbytes))
+    field = dense_lk(frames).to_host()
+    inner = (slice(None), slice(256, m - 256), slice(256, n - 256))
+    rmse = np.sqrt(np.mean((field - vel)[inner] ** 2))
+    assert rmse < 0.25, rmse
+    host = dense_lk(frames.to_host())
+    assert host.dtype == np.float64 and np.max(np.abs(host - field)) < 1e-5
+    xy, uv = dense_lk(frames.to_host(), dense=False)
+    assert 1000 < len(xy) <= 2000  # two pairs x <= 1000 corners

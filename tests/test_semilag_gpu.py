@@ -385,3 +385,46 @@ def test_fraction_clamp(extrapolate):
         _, disp = extrapolate(precip, velocity, 1, n_iter=n_iter, return_displacement=True)
         # D = (P - x) + f = -1 + 0x1.fffffep-1 = -2^-24 (0 if the fraction were 1.0)
         assert np.all(disp == np.float64(-(2.0**-24))), (n_iter, np.unique(disp))
+
+
+def test_config5_8192_tiled_and_last_plane(extrapolate):
+    """BASELINE config 5: 8192^2, 36 lead times.  (a) the row bands of 8 virtual ranks
+    (parallel.tiled_extrapolate, what each GPU of the node would integrate) concatenate to the
+    single-device result bit for bit; (b) the displacement after 36 steps matches the C oracle
+    (displacement-only call) and the last plane matches the oracle's resampling at that
+    displacement; (c) chained single steps land on the same last plane."""
+    from oracle import semilag as osl
+    from oracle import semilag_cport as ocl
+    from pysteps_amd import parallel
+    from pysteps_amd.device import DeviceArray
+    from tools import synth
+
+    m = n = 8192
+    T = 36
+    p = synth.rain_field_db(m, n, sigma=32.0)
+    v = synth.true_velocity(m, n)
+    dp, dv = DeviceArray.from_host(p), DeviceArray.from_host(v)
+    out, disp = extrapolate(dp, dv, T, outval=-15.0, return_displacement=True)
+    last = out.view(T - 1).to_host()
+    mid = out.view(17).to_host()
+    # (a) output tiling
+    for rank in (0, 3, 7):
+        rows, band = parallel.tiled_extrapolate(dp, dv, T, rank, 8, outval=-15.0)
+        assert band.shape == (T, len(rows), n)
+        assert np.array_equal(band.view(T - 1).to_host(), last[rows.start:rows.stop], equal_nan=True)
+        assert np.array_equal(band.view(17).to_host(), mid[rows.start:rows.stop], equal_nan=True)
+        del band
+    # (b) oracle: trajectories for all 36 steps, resampling of the last plane only
+    _, wdisp = ocl.extrapolate(None, v, T, return_displacement=True)
+    gdisp = disp.to_host()
+    assert np.max(np.abs(gdisp - wdisp)) < DISP_TOL
+    want_last = osl.sample_field(p, wdisp[0], wdisp[1], cval=-15.0, order=1, backend="scipy")
+    assert nan_mismatch(last, want_last) == 0
+    assert rel_l2(last, want_last) < REL_L2_TOL
+    # (c) chained single steps
+    del out
+    d = None
+    for t in range(T):
+        o1, d = extrapolate(dp, dv, [1.0], outval=-15.0, return_displacement=True, displacement_prev=d)
+    assert rel_l2(o1.view(0).to_host(), want_last) < REL_L2_TOL
+    assert np.max(np.abs(d.to_host() - wdisp)) < DISP_TOL
