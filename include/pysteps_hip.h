@@ -158,6 +158,17 @@ int psh_semilag_members_dev(const float *precip_dev, const float *velocity_dev,
                             const double *pert_perp_host, int n_members, int m, int n,
                             const double *steps_host, int T, int n_iter, int interp_order,
                             float outval, double *disp_dev, int resume, float *out_dev);
+/* The same step with the trajectories kept in the kernel's own representation between calls:
+ * state (B,m,n) records of 16 bytes {int32 P-x, int32 P-y, float32 frac_x, float32 frac_y} - half the
+ * HBM traffic of the float64 displacement pair.  The converters translate to / from the
+ * reference's displacement (B,2,m,n) float64 (D = (P - x) + frac). */
+int psh_semilag_members_state_dev(const float *precip_dev, const float *velocity_dev,
+                                  const float *vhat_dev, const double *pert_par_host,
+                                  const double *pert_perp_host, int n_members, int m, int n,
+                                  const double *steps_host, int T, int n_iter, int interp_order,
+                                  float outval, void *state_dev, int resume, float *out_dev);
+int psh_members_state_to_disp_dev(const void *state_dev, int n_members, int m, int n, double *disp_dev);
+int psh_members_disp_to_state_dev(const double *disp_dev, int n_members, int m, int n, void *state_dev);
 
 /* ---- sparse vectors -> dense field: k-NN inverse distance weighting ------ *
  * Replaces pysteps/utils/interpolate.py:26-114 (idwinterp2d) as called from

@@ -78,6 +78,9 @@ SIGNATURES = {
     "psh_decluster_host": (c_int, [c_void_p, c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, POINTER(c_int)]),
     "psh_velocity_unit_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "psh_semilag_members_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
+    "psh_semilag_members_state_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
+    "psh_members_state_to_disp_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "psh_members_disp_to_state_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_lk_corners_launch_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_int]),
     "psh_lk_corners_finish": (c_int, [c_void_p, POINTER(c_int)]),
     "psh_lk_pyramids_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),

@@ -32,6 +32,10 @@ struct Context {
 Context &ctx();
 int fail(int code, const char *fmt, ...);
 int ensure_scratch(size_t nbytes);
+// pinned staging slot (kConstSlotFloats floats) and its device twin for small per-call constants;
+// the caller fills *host and queues the copy to *dev on the library stream (lock held)
+constexpr size_t kConstSlotFloats = 1024;
+int const_slot(float **host, const float **dev);
 
 #define PSH_HIP(expr)                                                            \
   do {                                                                           \

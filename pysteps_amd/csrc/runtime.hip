@@ -84,6 +84,25 @@ static int ensure_pinned(size_t nbytes) {
   return PSH_OK;
 }
 
+// A fresh 4 KiB pinned slot + its device twin per call, so that back-to-back asynchronous calls
+// never overwrite constants a queued kernel still has to read; the ring synchronises with the
+// stream only when it wraps (every 64 calls).
+int const_slot(float **host, const float **dev) {
+  Context &c = ctx();
+  static size_t slot = 0;
+  const size_t n_slots = 64;
+  if (int rc = ensure_scratch(n_slots * kConstSlotFloats * sizeof(float))) return rc;
+  if (int rc = ensure_pinned(n_slots * kConstSlotFloats * sizeof(float))) return rc;
+  if (slot == n_slots) {  // ring wrapped: make sure the oldest slots are consumed
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    slot = 0;
+  }
+  *host = static_cast<float *>(c.pinned) + slot * kConstSlotFloats;
+  *dev = static_cast<float *>(c.scratch) + slot * kConstSlotFloats;
+  ++slot;
+  return PSH_OK;
+}
+
 }  // namespace psh
 
 using psh::ctx;
@@ -384,25 +403,15 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  // per-step scale factors: a fresh slot per call so that back-to-back async
-  // calls never overwrite factors a queued kernel still has to read
-  static size_t slot = 0;
-  const size_t slot_floats = 1024;
-  if (static_cast<size_t>(T) > slot_floats)
-    return fail(PSH_EUNSUPPORTED, "semilag: at most %zu lead steps per call", slot_floats);
-  const size_t n_slots = 64;
-  if (int rc = psh::ensure_scratch(n_slots * slot_floats * sizeof(float))) return rc;
-  if (int rc = psh::ensure_pinned(n_slots * slot_floats * sizeof(float))) return rc;
-  if (slot == n_slots) {  // ring wrapped: make sure the oldest slots are consumed
-    PSH_HIP(hipStreamSynchronize(c.stream));
-    slot = 0;
-  }
-  float *h = static_cast<float *>(c.pinned) + slot * slot_floats;
-  float *d = static_cast<float *>(c.scratch) + slot * slot_floats;
-  ++slot;
+  // per-step scale factors through the pinned slot ring (no host synchronisation)
+  if (static_cast<size_t>(T) > psh::kConstSlotFloats)
+    return fail(PSH_EUNSUPPORTED, "semilag: at most %zu lead steps per call", psh::kConstSlotFloats);
+  float *h = nullptr;
+  const float *d = nullptr;
+  if (int rc = psh::const_slot(&h, &d)) return rc;
   const double sub = n_iter > 1 ? static_cast<double>(n_iter) : 1.0;
   for (int t = 0; t < T; ++t) h[t] = static_cast<float>(steps_host[t] / sub);
-  PSH_HIP(hipMemcpyAsync(d, h, T * sizeof(float), hipMemcpyHostToDevice, c.stream));
+  PSH_HIP(hipMemcpyAsync(const_cast<float *>(d), h, T * sizeof(float), hipMemcpyHostToDevice, c.stream));
 
   psh::SemilagArgs a;
   a.precip = precip_dev;

@@ -17,7 +17,7 @@
 // arithmetic and resampling rules as semilag.hip (shared header), direct gathers
 // through buffer descriptors; roofline = HBM, 48 B/pixel/step algorithmic at
 // n_iter=1 (D read+write 32, precip in/out 8, velocity passes amortised by L2).
-#include <vector>
+#include <algorithm>
 
 #include "common.h"
 
@@ -91,10 +91,14 @@ __device__ __forceinline__ void sample_member(const Planes &F, int X, int Y, flo
   }
 }
 
-template <int ORDER, bool PERT, bool HAS_PRECIP>
+// State of a trajectory between calls.  COMPACT = the kernel's own representation, one 16-byte
+// record per pixel and member: integer pixel offsets (P - x, P - y) and the two fractions as
+// float32 - half the bytes of the float64 displacement pair of the reference, read and written
+// with one dwordx4 access each, and no float64 conversions in the kernel.
+template <int ORDER, bool PERT, bool HAS_PRECIP, bool COMPACT>
 __global__ __launch_bounds__(256) void semilag_members(
     const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vhat,
-    const float *__restrict__ pert_ab, float *__restrict__ out, double *__restrict__ disp,
+    const float *__restrict__ pert_ab, float *__restrict__ out, void *__restrict__ state,
     const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume,
     float outval, int tiles_x, int n_tiles, int tiles_per_xcd) {
   const int blk = blockIdx.x;
@@ -122,17 +126,26 @@ __global__ __launch_bounds__(256) void semilag_members(
   F.row_bytes = n * static_cast<int>(sizeof(float));
   const float a = PERT ? pert_ab[2 * member] : 0.f, b = PERT ? pert_ab[2 * member + 1] : 0.f;
 
-  double *dplane = disp + static_cast<size_t>(member) * 2 * plane;
+  double *dplane = static_cast<double *>(state) + static_cast<size_t>(member) * 2 * plane;
   const size_t pix = static_cast<size_t>(yc) * n + xc;
+  uint4 *record = static_cast<uint4 *>(state) + static_cast<size_t>(member) * plane + pix;
   int px = xc, py = yc;
   float fx = 0.f, fy = 0.f, vix, viy, su, sv, sp = 0.f;
   if (resume) {
-    const double dx = dplane[pix], dy = dplane[plane + pix];
-    const double flx = floor(dx), fly = floor(dy);
-    px += static_cast<int>(flx);
-    py += static_cast<int>(fly);
-    fx = fminf(static_cast<float>(dx - flx), kMaxFrac);
-    fy = fminf(static_cast<float>(dy - fly), kMaxFrac);
+    if (COMPACT) {
+      const uint4 r = *record;
+      px += static_cast<int>(r.x);
+      py += static_cast<int>(r.y);
+      fx = __uint_as_float(r.z);
+      fy = __uint_as_float(r.w);
+    } else {
+      const double dx = dplane[pix], dy = dplane[plane + pix];
+      const double flx = floor(dx), fly = floor(dy);
+      px += static_cast<int>(flx);
+      py += static_cast<int>(fly);
+      fx = fminf(static_cast<float>(dx - flx), kMaxFrac);
+      fy = fminf(static_cast<float>(dy - fly), kMaxFrac);
+    }
     sample_member<ORDER, PERT, false>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
     vix = su * scale[0];
     viy = sv * scale[0];
@@ -180,8 +193,39 @@ __global__ __launch_bounds__(256) void semilag_members(
     }
   }
   if (live) {
-    dplane[pix] = static_cast<double>(px - xc) + static_cast<double>(fx);
-    dplane[plane + pix] = static_cast<double>(py - yc) + static_cast<double>(fy);
+    if (COMPACT) {
+      *record = make_uint4(static_cast<unsigned>(px - xc), static_cast<unsigned>(py - yc), __float_as_uint(fx),
+                           __float_as_uint(fy));
+    } else {
+      dplane[pix] = static_cast<double>(px - xc) + static_cast<double>(fx);
+      dplane[plane + pix] = static_cast<double>(py - yc) + static_cast<double>(fy);
+    }
+  }
+}
+
+// compact trajectory records <-> float64 displacement (B,2,m,n)
+__global__ __launch_bounds__(256) void members_state_to_disp(const uint4 *__restrict__ state, size_t plane,
+                                                             double *__restrict__ disp) {
+  const size_t member = blockIdx.y;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < plane; i += stride) {
+    const uint4 r = state[member * plane + i];
+    disp[(2 * member) * plane + i] = static_cast<double>(static_cast<int>(r.x)) + static_cast<double>(__uint_as_float(r.z));
+    disp[(2 * member + 1) * plane + i] = static_cast<double>(static_cast<int>(r.y)) + static_cast<double>(__uint_as_float(r.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void members_disp_to_state(const double *__restrict__ disp, size_t plane,
+                                                             uint4 *__restrict__ state) {
+  const size_t member = blockIdx.y;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < plane; i += stride) {
+    const double dx = disp[(2 * member) * plane + i], dy = disp[(2 * member + 1) * plane + i];
+    const double flx = floor(dx), fly = floor(dy);
+    state[member * plane + i] =
+        make_uint4(static_cast<unsigned>(static_cast<int>(flx)), static_cast<unsigned>(static_cast<int>(fly)),
+                   __float_as_uint(fminf(static_cast<float>(dx - flx), kMaxFrac)),
+                   __float_as_uint(fminf(static_cast<float>(dy - fly), kMaxFrac)));
   }
 }
 
@@ -214,11 +258,10 @@ extern "C" int psh_velocity_unit_dev(const float *velocity_dev, int m, int n, fl
   return PSH_OK;
 }
 
-extern "C" int psh_semilag_members_dev(const float *precip_dev, const float *velocity_dev,
-                                       const float *vhat_dev, const double *pert_par_host,
-                                       const double *pert_perp_host, int n_members, int m, int n,
-                                       const double *steps_host, int T, int n_iter, int interp_order,
-                                       float outval, double *disp_dev, int resume, float *out_dev) {
+static int members_step(const float *precip_dev, const float *velocity_dev, const float *vhat_dev,
+                        const double *pert_par_host, const double *pert_perp_host, int n_members, int m,
+                        int n, const double *steps_host, int T, int n_iter, int interp_order, float outval,
+                        void *disp_dev, bool compact, int resume, float *out_dev) {
   PSH_REQUIRE_INIT();
   if (n_members <= 0 || n_members > 65535)
     return psh::fail(PSH_EINVAL, "semilag_members: member count %d out of range", n_members);
@@ -237,33 +280,38 @@ extern "C" int psh_semilag_members_dev(const float *precip_dev, const float *vel
   psh::Context &c = psh::ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  // per-call constants: T scale factors + 2 scalars per member, staged through pinned memory
+  // per-call constants: T scale factors + 2 scalars per member, through the pinned slot ring
+  // (asynchronous: back-to-back member steps queue up without a host round trip)
   const size_t n_const = static_cast<size_t>(T) + 2 * static_cast<size_t>(n_members);
-  void *blk = nullptr;
-  if (int rc = psh_malloc(&blk, n_const * sizeof(float))) return rc;
-  std::vector<float> h(n_const);
+  if (n_const > psh::kConstSlotFloats)
+    return psh::fail(PSH_EUNSUPPORTED, "semilag_members: T + 2 * members must be <= %zu", psh::kConstSlotFloats);
+  float *h = nullptr;
+  const float *d_const = nullptr;
+  if (int rc = psh::const_slot(&h, &d_const)) return rc;
   const double sub = n_iter > 1 ? static_cast<double>(n_iter) : 1.0;
   for (int t = 0; t < T; ++t) h[t] = static_cast<float>(steps_host[t] / sub);
   for (int j = 0; j < n_members; ++j) {
     h[T + 2 * j] = pert ? static_cast<float>(pert_par_host[j]) : 0.f;
     h[T + 2 * j + 1] = pert ? static_cast<float>(pert_perp_host[j]) : 0.f;
   }
-  float *d_const = static_cast<float *>(blk);
-  hipError_t e = hipMemcpyAsync(d_const, h.data(), n_const * sizeof(float), hipMemcpyHostToDevice, c.stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c.stream);  // h is a stack-lifetime staging buffer
-  if (e != hipSuccess) {
-    (void)psh_free(blk);
-    return psh::fail(PSH_EHIP, "semilag_members: constant upload failed: %s", hipGetErrorString(e));
-  }
+  PSH_HIP(hipMemcpyAsync(const_cast<float *>(d_const), h, n_const * sizeof(float), hipMemcpyHostToDevice, c.stream));
   const int tiles_x = (n + 63) / 64, tiles_y = (m + 3) / 4;
   const int n_tiles = tiles_x * tiles_y;
   const int tiles_per_xcd = (n_tiles + psh::kNumXcd - 1) / psh::kNumXcd;
   const dim3 grid(tiles_per_xcd * psh::kNumXcd, n_members), block(256);
   const float first_scale = static_cast<float>(steps_host[0]);
-#define PSH_MEMBERS(ORDER, PERT, HASP)                                                             \
-  hipLaunchKernelGGL((psh::semilag_members<ORDER, PERT, HASP>), grid, block, 0, c.stream, precip_dev, \
-                     velocity_dev, vhat_dev, d_const + T, out_dev, disp_dev, d_const, first_scale, m, \
-                     n, T, n_iter, resume, outval, tiles_x, n_tiles, tiles_per_xcd)
+#define PSH_MEMBERS_C(ORDER, PERT, HASP, COMPACT)                                                     \
+  hipLaunchKernelGGL((psh::semilag_members<ORDER, PERT, HASP, COMPACT>), grid, block, 0, c.stream,    \
+                     precip_dev, velocity_dev, vhat_dev, d_const + T, out_dev, disp_dev, d_const,     \
+                     first_scale, m, n, T, n_iter, resume, outval, tiles_x, n_tiles, tiles_per_xcd)
+#define PSH_MEMBERS(ORDER, PERT, HASP)                  \
+  do {                                                  \
+    if (compact) {                                      \
+      PSH_MEMBERS_C(ORDER, PERT, HASP, true);           \
+    } else {                                            \
+      PSH_MEMBERS_C(ORDER, PERT, HASP, false);          \
+    }                                                   \
+  } while (0)
   if (!precip_dev) {
     if (pert) PSH_MEMBERS(1, true, false); else PSH_MEMBERS(1, false, false);
   } else if (interp_order == 0) {
@@ -271,9 +319,55 @@ extern "C" int psh_semilag_members_dev(const float *precip_dev, const float *vel
   } else {
     if (pert) PSH_MEMBERS(1, true, true); else PSH_MEMBERS(1, false, true);
   }
+#undef PSH_MEMBERS_C
 #undef PSH_MEMBERS
-  e = hipGetLastError();
-  (void)psh_free(blk);  // stream-ordered: the kernel above is queued before any reuse
+  const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return psh::fail(PSH_EHIP, "semilag_members launch failed: %s", hipGetErrorString(e));
   return PSH_OK;
+}
+
+extern "C" int psh_semilag_members_dev(const float *precip_dev, const float *velocity_dev,
+                                       const float *vhat_dev, const double *pert_par_host,
+                                       const double *pert_perp_host, int n_members, int m, int n,
+                                       const double *steps_host, int T, int n_iter, int interp_order,
+                                       float outval, double *disp_dev, int resume, float *out_dev) {
+  return members_step(precip_dev, velocity_dev, vhat_dev, pert_par_host, pert_perp_host, n_members, m, n,
+                      steps_host, T, n_iter, interp_order, outval, disp_dev, false, resume, out_dev);
+}
+
+extern "C" int psh_semilag_members_state_dev(const float *precip_dev, const float *velocity_dev,
+                                             const float *vhat_dev, const double *pert_par_host,
+                                             const double *pert_perp_host, int n_members, int m, int n,
+                                             const double *steps_host, int T, int n_iter, int interp_order,
+                                             float outval, void *state_dev, int resume, float *out_dev) {
+  return members_step(precip_dev, velocity_dev, vhat_dev, pert_par_host, pert_perp_host, n_members, m, n,
+                      steps_host, T, n_iter, interp_order, outval, state_dev, true, resume, out_dev);
+}
+
+static int members_convert(const void *src, void *dst, int n_members, int m, int n, bool to_disp) {
+  PSH_REQUIRE_INIT();
+  if (!src || !dst || n_members <= 0 || n_members > 65535 || m <= 0 || n <= 0)
+    return psh::fail(PSH_EINVAL, "members state conversion: invalid argument");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t plane = static_cast<size_t>(m) * n;
+  const dim3 grid(static_cast<unsigned>(std::min<size_t>((plane + 255) / 256, 4096)), n_members), block(256);
+  if (to_disp) {
+    hipLaunchKernelGGL(psh::members_state_to_disp, grid, block, 0, c.stream, static_cast<const uint4 *>(src), plane,
+                       static_cast<double *>(dst));
+  } else {
+    hipLaunchKernelGGL(psh::members_disp_to_state, grid, block, 0, c.stream, static_cast<const double *>(src), plane,
+                       static_cast<uint4 *>(dst));
+  }
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+extern "C" int psh_members_state_to_disp_dev(const void *state_dev, int n_members, int m, int n, double *disp_dev) {
+  return members_convert(state_dev, disp_dev, n_members, m, n, true);
+}
+
+extern "C" int psh_members_disp_to_state_dev(const double *disp_dev, int n_members, int m, int n, void *state_dev) {
+  return members_convert(disp_dev, state_dev, n_members, m, n, false);
 }

@@ -4,7 +4,7 @@ The generic nowcast loop of the reference advects every ensemble member once per
 time step with its own (optionally perturbed) velocity and threads the
 displacement through as state (pysteps/nowcasts/utils.py:441-462).
 :class:`EnsembleAdvector` does that for all members in one kernel launch
-(``psh_semilag_members_dev``): the displacements of all members stay in HBM, the
+(``psh_semilag_members_state_dev``): the trajectories of all members stay in HBM, the
 BPS velocity perturbation (pysteps/noise/motion.py:146-180) is applied in-kernel
 from two scalars per member.
 """
@@ -48,13 +48,38 @@ class EnsembleAdvector:
             raise ValueError("one perturbator per member is required")
         self.perturbators = perturbators
         self.n_iter, self.interp_order, self.outval = int(n_iter), int(interp_order), float(outval)
-        self.displacement = DeviceArray((self.n_members, 2, self.m, self.n), np.float64)
+        # trajectories between calls, in the kernel's own representation: one 16-byte record per
+        # member and pixel {int32 P-x, int32 P-y, float32 frac_x, float32 frac_y} (half the HBM
+        # traffic of the float64 displacement pair; see ``displacement``)
+        self._state = DeviceArray((self.n_members, self.m, self.n, 4), np.uint32)
         self._started = False
         self.vhat = None
         if perturbators is not None:
             self.vhat = DeviceArray((2, self.m, self.n), np.float32)
             _lib.check(self._lib.psh_velocity_unit_dev(self.velocity.ptr, self.m, self.n, self.vhat.ptr),
                        "psh_velocity_unit_dev")
+
+    @property
+    def displacement(self):
+        """The displacements ``D_j`` of all members as the reference carries them: a float64
+        DeviceArray ``(n_members, 2, m, n)`` (zeros before the first step), converted from the
+        resident trajectory records on demand."""
+        disp = DeviceArray((self.n_members, 2, self.m, self.n), np.float64)
+        if not self._started:
+            return disp.fill_bytes(0)
+        _lib.check(self._lib.psh_members_state_to_disp_dev(self._state.ptr, self.n_members, self.m, self.n,
+                                                           disp.ptr), "psh_members_state_to_disp_dev")
+        return disp
+
+    @displacement.setter
+    def displacement(self, value):
+        """Restart from given displacements ((n_members, 2, m, n) float64, host or device)."""
+        disp = value if isinstance(value, DeviceArray) else DeviceArray.from_host(value, np.float64)
+        if disp.shape != (self.n_members, 2, self.m, self.n) or disp.dtype != np.float64:
+            raise ValueError("displacement must have shape (n_members, 2, m, n) and dtype float64")
+        _lib.check(self._lib.psh_members_disp_to_state_dev(disp.ptr, self.n_members, self.m, self.n,
+                                                           self._state.ptr), "psh_members_disp_to_state_dev")
+        self._started = True
 
     def step(self, precip_members, t_diff, t_total=None):
         """Advect all members by ``t_diff`` (lead-time increment(s) in velocity time steps, i.e.
@@ -76,15 +101,15 @@ class EnsembleAdvector:
                 raise ValueError("t_total is required with velocity perturbations")
             par, perp = bps_scalars(self.perturbators, t_total)
         out = None if pm is None else DeviceArray((self.n_members, steps.size, self.m, self.n), np.float32)
-        rc = self._lib.psh_semilag_members_dev(
+        rc = self._lib.psh_semilag_members_state_dev(
             None if pm is None else pm.ptr, self.velocity.ptr,
             None if self.vhat is None else self.vhat.ptr,
             None if par is None else par.ctypes.data, None if perp is None else perp.ctypes.data,
             self.n_members, self.m, self.n, steps.ctypes.data, int(steps.size), self.n_iter,
-            self.interp_order, self.outval, self.displacement.ptr, int(self._started),
+            self.interp_order, self.outval, self._state.ptr, int(self._started),
             None if out is None else out.ptr,
         )
-        _lib.check(rc, "psh_semilag_members_dev")
+        _lib.check(rc, "psh_semilag_members_state_dev")
         self._started = True
         if out is None:
             return None

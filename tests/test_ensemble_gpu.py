@@ -86,3 +86,42 @@ def test_single_member_and_nearest_order():
     want = get_method("semilagrangian")(p[0], V, [1.0, 2.0], outval=-15.0, interp_order=0)
     assert got.shape == (1, 2, m, n)
     assert np.count_nonzero(got[0] != want) <= 1e-4 * want.size
+
+
+def test_compact_state_float64_entry_and_restart():
+    """The resident 16-byte trajectory records and the float64 displacement of the reference are
+    two views of the same state: the float64 entry point (psh_semilag_members_dev) continues from
+    ``adv.displacement`` exactly like the advector itself, and an advector restarted from a
+    displacement array reproduces the original one."""
+    from pysteps_amd import _lib
+    from pysteps_amd.device import DeviceArray
+    from pysteps_amd.extrapolation.ensemble import EnsembleAdvector
+    from tools import synth
+
+    B, m, n = 3, 70, 200
+    members = np.stack([synth.rain_field_db(m, n, seed=60 + j, sigma=2.0) for j in range(B)])
+    V = synth.true_velocity(m, n) * 2.5
+    adv = EnsembleAdvector(V, B, n_iter=1)
+    assert not adv.displacement.to_host().any()  # zeros before the first step
+    adv.step(members, [1.0, 1.0])
+    disp = adv.displacement  # float64 (B,2,m,n) on the device
+    assert disp.dtype == np.float64 and disp.shape == (B, 2, m, n)
+    d_host = disp.to_host()
+    # the records hold D = (P - x) + frac with frac in [0, 1)
+    assert np.all(d_host - np.floor(d_host) < 1.0)
+    want = adv.step(members, 0.5)
+    # (a) float64 entry point, continuing from the converted displacement
+    lib = _lib.lib()
+    pm, dv = DeviceArray.from_host(members, np.float32), DeviceArray.from_host(V, np.float32)
+    out = DeviceArray((B, 1, m, n), np.float32)
+    steps = np.array([0.5])
+    _lib.check(lib.psh_semilag_members_dev(pm.ptr, dv.ptr, None, None, None, B, m, n, steps.ctypes.data, 1, 1, 1,
+                                           float("nan"), disp.ptr, 1, out.ptr), "psh_semilag_members_dev")
+    assert np.array_equal(out.to_host()[:, 0], want, equal_nan=True)
+    assert np.array_equal(disp.to_host(), adv.displacement.to_host())
+    # (b) restart from a host displacement array
+    again = EnsembleAdvector(V, B, n_iter=1)
+    again.displacement = d_host
+    assert np.array_equal(again.step(members, 0.5), want, equal_nan=True)
+    with pytest.raises(ValueError):
+        again.displacement = d_host[:, :1]
