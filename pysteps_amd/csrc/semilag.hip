@@ -49,7 +49,7 @@ constexpr int kTileX = 64;
 enum : int { kModeDirect = 0, kModeStaged = 1, kModePairX = 2 };
 constexpr int kWavesPerBlock = 4;
 struct Fields {
-  const float *u0, *u1, *v0, *v1, *p0, *p1;  // row r and row r+1 bases of each plane
+  const float *u0, *v0, *p0;  // plane bases (border path, scalar loads)
   // buffer descriptors of the three planes for the fast path: addressing is then
   // descriptor (SGPR) + one 32-bit lane offset + immediate (+1 column) + scalar
   // offset (+1 row) - no per-load 64-bit VALU address arithmetic
@@ -131,13 +131,14 @@ __device__ __forceinline__ void sample_interior(const Fields &F, const int (&X)[
     // nothing - an exec-masked vector load for one lane would cost it as much as a full one
     // (tools/gather_probe.py), and in smooth motion lane 63 is the only lane that needs one.
     const unsigned off63 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(off[j]), 63)) + 4u;
+    const unsigned off63_below = off63 + static_cast<unsigned>(rb);
     lb[j] = ld(F.u0, off63);
-    ld_[j] = ld(F.u1, off63);
+    ld_[j] = ld(F.u0, off63_below);
     lf[j] = ld(F.v0, off63);
-    lh[j] = ld(F.v1, off63);
+    lh[j] = ld(F.v0, off63_below);
     if (WITH_P) {
       lpb[j] = ld(F.p0, off63);
-      lpd[j] = ld(F.p1, off63);
+      lpd[j] = ld(F.p0, off63_below);
     }
     // interior positions have X + 1 <= n - 1, so "the neighbour's linear offset is mine + 1"
     // is the same statement as "same row, next column"
@@ -399,11 +400,8 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
   const size_t plane = static_cast<size_t>(m) * n;
   Fields F;
   F.u0 = vel;
-  F.u1 = vel + n;
   F.v0 = vel + plane;
-  F.v1 = vel + plane + n;
   F.p0 = precip;
-  F.p1 = HAS_PRECIP ? precip + n : nullptr;
   const int plane_bytes = static_cast<int>(plane * sizeof(float));
   F.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel), 0, plane_bytes, 0x00020000);
   F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
@@ -534,8 +532,8 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
             const unsigned off = static_cast<unsigned>(__mul24(py[j], n) + px[j]) << 2;
             v[j][0] = ld(F.p0, off);
             v[j][1] = ld(F.p0, off, 1);
-            v[j][2] = ld(F.p1, off);
-            v[j][3] = ld(F.p1, off, 1);
+            v[j][2] = ld(F.p0, off + static_cast<unsigned>(F.row_bytes));
+            v[j][3] = ld(F.p0, off + static_cast<unsigned>(F.row_bytes), 1);
           }
 #pragma unroll
           for (int j = 0; j < NPX; ++j)
