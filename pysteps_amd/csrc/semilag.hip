@@ -327,10 +327,17 @@ __device__ __forceinline__ bool sample_staged(const Fields &F, Stage &S, const i
   return true;
 }
 
+template <int ORDER, bool GEN>
+__device__ __forceinline__ float sample_precip_off_fast(const float *p, int X, int Y, float fx, float fy, int m,
+                                                        int n, float outval, int bmode) {
+  if (GEN) return sample_precip_edge<ORDER>(p, X, Y, fx, fy, m, n, outval, bmode);
+  return sample_precip_border<ORDER>(p, X, Y, fx, fy, m, n, outval);
+}
+
 // What to sample at the NPX positions of a thread
 enum : int { kVel = 1, kPrecip = 2 };
 
-template <int NPX, int ORDER, int WHAT, int MODE>
+template <int NPX, int ORDER, int WHAT, int MODE, bool GEN>
 __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (&X)[NPX],
                                           const int (&Y)[NPX], const float (&fx)[NPX],
                                           const float (&fy)[NPX], int m, int n, float outval,
@@ -343,7 +350,7 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
       if (WHAT & kVel) sample_velocity_border(F, X[j], Y[j], fx[j], fy[j], m, n, su[j], sv[j]);
-      if (kWithP) sp[j] = sample_precip_edge<ORDER>(F.p0, X[j], Y[j], fx[j], fy[j], m, n, outval, F.bmode);
+      if (kWithP) sp[j] = sample_precip_off_fast<ORDER, GEN>(F.p0, X[j], Y[j], fx[j], fy[j], m, n, outval, F.bmode);
     }
     return;
   }
@@ -374,14 +381,16 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
       if (WHAT & kVel) sample_velocity_border(F, X[j], Y[j], fx[j], fy[j], m, n, su[j], sv[j]);
       if (kWithP) {
         sp[j] = ORDER == 3 ? sample_precip_cubic(F.coef, F.p0, X[j], Y[j], fx[j], fy[j], m, n, F.minval)
-                           : sample_precip_edge<(ORDER == 3 ? 1 : ORDER)>(F.p0, X[j], Y[j], fx[j], fy[j],
+                           : sample_precip_off_fast<(ORDER == 3 ? 1 : ORDER), GEN>(F.p0, X[j], Y[j], fx[j], fy[j],
                                                                           m, n, outval, F.bmode);
       }
     }
   }
 }
 
-template <int NPX, int ORDER, bool HAS_PRECIP, int MODE>
+// GEN: the field resampling honours F.bmode (any scipy boundary mode); otherwise the kernel only
+// contains the "constant" rule and none of the folding code
+template <int NPX, int ORDER, bool HAS_PRECIP, int MODE, bool GEN>
 __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
     const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
       fx[j] = fminf(static_cast<float>(dx - flx), kMaxFrac);
       fy[j] = fminf(static_cast<float>(dy - fly), kMaxFrac);
     }
-    sample_at<NPX, ORDER, kVel, MODE>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+    sample_at<NPX, ORDER, kVel, MODE, GEN>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
     const float s0 = scale[0];
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
@@ -490,16 +499,16 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
           retreat(mx[j], gx[j], vix[j]);  // midpoint rule (:213), vix = Vi / 2
           retreat(my[j], gy[j], viy[j]);
         }
-        sample_at<NPX, ORDER, kVel, MODE>(F, S, mx, my, gx, gy, m, n, outval, su, sv, sp);
+        sample_at<NPX, ORDER, kVel, MODE, GEN>(F, S, mx, my, gx, gy, m, n, outval, su, sv, sp);
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
           retreat(px[j], fx[j], su[j] * s);
           retreat(py[j], fy[j], sv[j] * s);
         }
         if (HAS_PRECIP && k == n_iter - 1) {
-          sample_at<NPX, ORDER, kVel | kPrecip, MODE>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+          sample_at<NPX, ORDER, kVel | kPrecip, MODE, GEN>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
         } else {
-          sample_at<NPX, ORDER, kVel, MODE>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+          sample_at<NPX, ORDER, kVel, MODE, GEN>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
         }
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
@@ -509,7 +518,7 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
       }
     } else {
       if (t > 0 || resume) {
-        sample_at<NPX, ORDER, kVel, MODE>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+        sample_at<NPX, ORDER, kVel, MODE, GEN>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
           vix[j] = su[j] * s;
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(kTileX *kWavesPerBlock) void semilag_fused(
           for (int j = 0; j < NPX; ++j)
             sp[j] = ORDER == 3
                         ? sample_precip_cubic(F.coef, F.p0, px[j], py[j], fx[j], fy[j], m, n, F.minval)
-                        : sample_precip_edge<(ORDER == 3 ? 1 : ORDER)>(F.p0, px[j], py[j], fx[j], fy[j], m,
+                        : sample_precip_off_fast<(ORDER == 3 ? 1 : ORDER), GEN>(F.p0, px[j], py[j], fx[j], fy[j], m,
                                                                        n, outval, F.bmode);
         }
       }
@@ -579,23 +588,29 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   const int n_tiles = tiles_x * tiles_y;
   const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
   const dim3 grid(tiles_per_xcd * kNumXcd), block(kTileX * kWavesPerBlock);
-#define PSH_SL_LAUNCH(ORDER, HASP)                                                              \
-  hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, MODE>), grid, block, 0, stream, a.precip,   \
-                     a.vel, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter,     \
-                     a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, a.bmode, tiles_x, n_tiles,  \
-                     tiles_per_xcd)
+#define PSH_SL_LAUNCH(ORDER, HASP, GEN)                                                         \
+  hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, MODE, GEN>), grid, block, 0, stream,      \
+                     a.precip, a.vel, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T,     \
+                     a.n_iter, a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, a.bmode,   \
+                     tiles_x, n_tiles, tiles_per_xcd)
   if (a.precip == nullptr) {
-    PSH_SL_LAUNCH(1, false);
+    PSH_SL_LAUNCH(1, false, false);
   } else if (a.order == 0) {
-    PSH_SL_LAUNCH(0, true);
+    if (a.bmode != 0) {
+      PSH_SL_LAUNCH(0, true, true);
+    } else {
+      PSH_SL_LAUNCH(0, true, false);
+    }
   } else if (a.order == 3) {
     if constexpr (MODE != kModeStaged) {
-      PSH_SL_LAUNCH(3, true);
+      PSH_SL_LAUNCH(3, true, false);
     } else {
       return hipErrorInvalidValue;  // the staged variants are built for order 0/1
     }
+  } else if (a.bmode != 0) {
+    PSH_SL_LAUNCH(1, true, true);
   } else {
-    PSH_SL_LAUNCH(1, true);
+    PSH_SL_LAUNCH(1, true, false);
   }
 #undef PSH_SL_LAUNCH
   return hipGetLastError();
