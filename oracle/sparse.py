@@ -16,11 +16,22 @@ from scipy.spatial import cKDTree
 
 
 def detect_outliers(values, thr, coord, k):
-    """Local multivariate / univariate test (the form dense LK uses)."""
+    """Local multivariate / univariate test (the form dense LK uses); ``k=None`` or ``coord=None``:
+    the global test against the mean and covariance of all samples (cleansing.py:202-217)."""
     values = np.asarray(values, dtype=float)
     n = values.shape[0]
     if n < 2:
         return np.zeros(n, dtype=bool)
+    if k is None or coord is None:
+        if values.ndim == 1:
+            return np.abs(values - values.mean()) / values.std() > thr
+        z = values - values.mean(axis=0)
+        try:
+            vi = np.linalg.inv(np.cov(z.T))
+            md = np.sqrt(np.einsum("ij,jk,ik->i", z, vi, z))
+        except np.linalg.LinAlgError:
+            md = np.zeros(n)
+        return md > thr
     coord = np.asarray(coord, dtype=float)
     kk = min(n, k + 1)
     _, inds = cKDTree(coord).query(coord, k=kk)

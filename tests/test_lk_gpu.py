@@ -349,3 +349,63 @@ def test_config2_2048_three_frames(dense_lk):
     assert host.dtype == np.float64 and np.max(np.abs(host - field)) < 1e-5
     xy, uv = dense_lk(frames.to_host(), dense=False)
     assert 1000 < len(xy) <= 2000  # two pairs x <= 1000 corners
+
+
+# the option matrix of pysteps/tests/test_motion_lk.py:20-40 (fd_method "shitomasi" rows)
+LK_ARG_VALUES = [
+    (True, 3, 30, 3, 20, False),   # defaults
+    (False, 3, 30, 3, 20, True),   # sparse output, verbose
+    (False, 0, 30, 3, 20, False),  # sparse output, all outliers
+    (True, 3, None, 0, 0, False),  # global outlier detection, no filtering, no declustering
+    (True, 0, 30, 3, 20, False),   # all outliers
+]
+
+
+@pytest.mark.parametrize("dense,nr_std_outlier,k_outlier,size_opening,decl_scale,verbose", LK_ARG_VALUES)
+def test_lk_option_matrix(dense_lk, dense, nr_std_outlier, k_outlier, size_opening, decl_scale, verbose, capsys):
+    """Formats as asserted by the reference's test_lk, and values against the oracle with the same
+    options (three frames, two pooled pairs)."""
+    from oracle import lk_opencv as olk
+
+    frames, _ = _advected_frames(240, 272, 3, seed=23)
+    out = dense_lk(frames, dense=dense, nr_std_outlier=nr_std_outlier, k_outlier=k_outlier,
+                   size_opening=size_opening, decl_scale=decl_scale, verbose=verbose)
+    want = olk.dense_lucaskanade(frames, dense=dense, nr_std_outlier=nr_std_outlier, k_outlier=k_outlier,
+                                 size_opening=size_opening, decl_scale=decl_scale)
+    if verbose:
+        assert "Lucas-Kanade" in capsys.readouterr().out  # the reference prints its banner
+    if dense:
+        assert isinstance(out, np.ndarray) and out.ndim == 3 and out.shape == (2,) + frames.shape[1:]
+        if nr_std_outlier == 0:
+            assert out.sum() == 0
+        else:
+            # pixels whose k-th and (k+1)-th nearest vectors are equidistant pick either one (the
+            # reference's cKDTree too): field-level agreement, pixel-level for all but those
+            # (without declustering the same feature position appears once per frame pair: exact
+            # distance ties between its copies, broken either way)
+            loose = decl_scale == 0
+            assert rel_l2(out, want) < (3e-3 if loose else 1e-3)
+            assert np.mean(np.abs(out - want) > 1e-3) < (0.05 if loose else 0.01)
+    else:
+        assert isinstance(out, tuple) and len(out) == 2
+        xy, uv = out
+        assert xy.ndim == 2 and uv.ndim == 2 and xy.shape[1] == 2 and uv.shape == xy.shape
+        if nr_std_outlier == 0:
+            assert xy.shape[0] == 0
+        else:
+            assert abs(len(xy) - len(want[0])) <= max(3, 0.03 * len(want[0]))  # outlier test at 3 sigma
+            wmap = {}
+            for p, v in zip(want[0].astype(int), want[1]):
+                wmap.setdefault(tuple(p), []).append(v)
+            d = [min(np.abs(v - w).max() for w in wmap[tuple(p)]) for p, v in zip(xy.astype(int), uv)
+                 if tuple(p) in wmap]
+            assert len(d) >= 0.95 * len(want[0]) and max(d) < 1e-2
+
+
+@pytest.mark.parametrize("fd_method", ["blob", "tstorm"])
+def test_other_feature_detectors_are_delegated(dense_lk, fd_method):
+    """Detectors other than Shi-Tomasi are not part of the path: they go to the reference when it
+    is importable and fail loudly otherwise (no silent substitution)."""
+    frames, _ = _advected_frames(128, 128, 2, seed=5)
+    with pytest.raises((NotImplementedError, ImportError, ModuleNotFoundError)):
+        dense_lk(frames, fd_method=fd_method)

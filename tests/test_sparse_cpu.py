@@ -112,6 +112,14 @@ def test_live_reference_cleansing():
         uv[rng.integers(0, L)] += 9
         want = cl.detect_outliers(uv, 3, xy, 30)
         assert np.array_equal(cleansing.detect_outliers(uv, 3, xy, 30), want)
+        if L > 2:  # the global test (k=None), both the product's host mirror and the oracle
+            from oracle import sparse as osp
+
+            want_g = cl.detect_outliers(uv, 2.5, xy, None)
+            assert np.array_equal(cleansing.detect_outliers(uv, 2.5, xy, None), want_g)
+            assert np.array_equal(osp.detect_outliers(uv, 2.5, xy, None), want_g)
+            assert np.array_equal(osp.detect_outliers(uv[:, 0], 2.5, None, None),
+                                  cl.detect_outliers(uv[:, 0], 2.5))
         wc, wv = cl.decluster(xy, uv, 20, 1)
         gc, gv = cleansing.decluster(xy, uv, 20, 1)
         np.testing.assert_allclose(gc, wc, atol=1e-12)
