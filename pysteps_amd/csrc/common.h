@@ -95,6 +95,10 @@ int lk_track_pool(void *pyramid_handle, const float *points_host, int npts, int 
                   double min_eig_threshold, double *pool_xy_dev, double *pool_uv_dev, int *pool_count_dev,
                   int pool_capacity);
 
+// corner requests (lk.hip): drop everything in flight; how many may be in flight at once
+void lk_corners_drain();
+int lk_corners_in_flight_limit();
+
 // rocPRIM descending radix sort of 64-bit keys (lk_sort.hip); temp == nullptr queries *temp_bytes
 hipError_t sort_keys_desc(const unsigned long long *in, unsigned long long *out, unsigned int n,
                           void *temp, size_t *temp_bytes, hipStream_t stream);

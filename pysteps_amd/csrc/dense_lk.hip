@@ -91,25 +91,41 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   unsigned char *d_pfl = reinterpret_cast<unsigned char *>(pbase + off_fl);
   PSH_HIP(hipMemsetAsync(d_pcnt, 0, sizeof(int), c.stream));
   std::vector<float> pts(static_cast<size_t>(prm->max_corners) * 2);
-  for (int t = 0; t + 1 < nframes; ++t) {
-    if (int rc = psh_lk_corners_launch_dev(feat[t].as<unsigned char>(), clean[t].as<float>(),
-                                           stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
-                                           prm->quality_level, prm->min_distance, prm->max_corners))
-      return rc;
-    void *pyr = nullptr;  // built on the device while the host orders the corner candidates
-    int rc = psh_lk_pyramids_dev(trk[t].as<unsigned char>(), trk[t + 1].as<unsigned char>(), m, n, prm->win_w,
-                                 prm->win_h, prm->max_level, &pyr);
-    int npts = 0;
-    const int rc2 = psh_lk_corners_finish(pts.data(), &npts);
-    if (rc || rc2) {
-      (void)psh_lk_pyramids_free(pyr);
-      return rc ? rc : rc2;
+  // Frame pairs in groups: the corner requests and pyramids of a whole group are queued first,
+  // then each pair's ordered host pass overlaps the device work of the pairs behind it.
+  const int group = psh::lk_corners_in_flight_limit();
+  psh::lk_corners_drain();  // nothing stale from an earlier failure
+  for (int t0 = 0; t0 + 1 < nframes; t0 += group) {
+    const int t1 = std::min(nframes - 1, t0 + group);
+    std::vector<void *> pyrs(static_cast<size_t>(t1 - t0), nullptr);
+    auto fail_out = [&](int code) {
+      psh::lk_corners_drain();
+      for (void *h : pyrs) (void)psh_lk_pyramids_free(h);
+      return code;
+    };
+    for (int t = t0; t < t1; ++t) {
+      if (int rc = psh_lk_corners_launch_dev(feat[t].as<unsigned char>(), clean[t].as<float>(),
+                                             stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
+                                             prm->quality_level, prm->min_distance, prm->max_corners))
+        return fail_out(rc);
     }
-    if (npts > 0)
-      rc = psh::lk_track_pool(pyr, pts.data(), npts, prm->max_count, prm->epsilon, prm->min_eig_threshold,
-                              d_pxy, d_puv, d_pcnt, capacity_dev);
-    const int rc3 = psh_lk_pyramids_free(pyr);  // stream-ordered: the tracker above is queued first
-    if (rc || rc3) return rc ? rc : rc3;
+    for (int t = t0; t < t1; ++t) {  // built on the device while the host orders the corner candidates
+      if (int rc = psh_lk_pyramids_dev(trk[t].as<unsigned char>(), trk[t + 1].as<unsigned char>(), m, n,
+                                       prm->win_w, prm->win_h, prm->max_level, &pyrs[t - t0]))
+        return fail_out(rc);
+    }
+    for (int t = t0; t < t1; ++t) {
+      int npts = 0;
+      if (int rc = psh_lk_corners_finish(pts.data(), &npts)) return fail_out(rc);
+      if (npts > 0) {
+        if (int rc = psh::lk_track_pool(pyrs[t - t0], pts.data(), npts, prm->max_count, prm->epsilon,
+                                        prm->min_eig_threshold, d_pxy, d_puv, d_pcnt, capacity_dev))
+          return fail_out(rc);
+      }
+      const int rc3 = psh_lk_pyramids_free(pyrs[t - t0]);  // stream-ordered: the tracker above is queued first
+      pyrs[t - t0] = nullptr;
+      if (rc3) return fail_out(rc3);
+    }
   }
   // ---- outlier removal (:252-254) on the pooled vectors, then one hand-off to the host ------
   PSH_HIP(psh::launch_outliers_pooled(d_pxy, d_puv, d_pcnt, capacity_dev, prm->k_outlier, prm->nr_std_outlier,

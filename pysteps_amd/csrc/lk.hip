@@ -1163,11 +1163,16 @@ struct CornerJob {
   psh::CornerKey *raw_dev = nullptr;     // unsorted candidates (overflow path)
   hipEvent_t ready = nullptr;
   void *pinned = nullptr;  // [int count | pad | first kFirstChunk sorted keys]
+  void *ws = nullptr;      // device block of this request (response image, keys, sort scratch)
 };
 constexpr int kSortSpan = 1 << 17;   // candidates ordered on the device (zero padded)
 constexpr int kFirstChunk = 1 << 13; // sorted keys that travel with the count (64 KiB)
 constexpr size_t kPinnedHeader = 64;
-CornerJob g_corner_job;
+// requests in flight, first in first out: the frame pairs of one estimate are launched back to
+// back so that the host's ordered pass over pair t overlaps the device work of pair t + 1
+constexpr int kMaxCornerJobs = 4;
+CornerJob g_corner_jobs[kMaxCornerJobs];
+int g_corner_head = 0, g_corner_count = 0;
 
 // Greedy acceptance of goodFeaturesToTrack on a min_distance grid (featureselect.cpp): walk the
 // candidates strongest first, accept one unless an accepted corner lies closer than min_distance.
@@ -1218,8 +1223,9 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  CornerJob &job = g_corner_job;
-  if (job.active) return fail(PSH_EINVAL, "lk_corners: a corner request is already in flight");
+  if (g_corner_count == kMaxCornerJobs)
+    return fail(PSH_EINVAL, "lk_corners: %d corner requests are already in flight", kMaxCornerJobs);
+  CornerJob &job = g_corner_jobs[(g_corner_head + g_corner_count) % kMaxCornerJobs];
   if (!job.ready) PSH_HIP(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
   if (!job.pinned)
     PSH_HIP(hipHostMalloc(&job.pinned, kPinnedHeader + kFirstChunk * sizeof(psh::CornerKey), hipHostMallocDefault));
@@ -1236,7 +1242,12 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
   const size_t off_sorted = up(off_raw + static_cast<size_t>(cap) * sizeof(psh::CornerKey));
   const size_t off_temp = up(off_sorted + static_cast<size_t>(kSortSpan) * sizeof(psh::CornerKey));
   void *ws = nullptr;
-  if (int rc = psh::ensure_lk_ws(off_temp + sort_temp, &ws)) return rc;
+  if (int rc = psh_malloc(&ws, off_temp + sort_temp)) return rc;  // stream-ordered caching allocator
+  struct Guard {  // the block goes back unless the request gets registered below
+    void *p;
+    ~Guard() { if (p) (void)psh_free(p); }
+  } guard{ws};
+  job.ws = ws;
   char *base = static_cast<char *>(ws);
   float *eig = reinterpret_cast<float *>(base + off_eig);
   float *part = reinterpret_cast<float *>(base + off_part);
@@ -1274,6 +1285,8 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
                          hipMemcpyDeviceToHost, c.stream));
   PSH_HIP(hipEventRecord(job.ready, c.stream));
   job.active = true;
+  ++g_corner_count;
+  guard.p = nullptr;
   job.m = m;
   job.n = n;
   job.cap = cap;
@@ -1290,9 +1303,17 @@ int psh_lk_corners_finish(float *points_host, int *count_host) {
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  CornerJob &job = g_corner_job;
-  if (!job.active) return fail(PSH_EINVAL, "lk_corners: no corner request in flight");
+  if (g_corner_count == 0) return fail(PSH_EINVAL, "lk_corners: no corner request in flight");
+  CornerJob &job = g_corner_jobs[g_corner_head];
+  g_corner_head = (g_corner_head + 1) % kMaxCornerJobs;
+  --g_corner_count;
   job.active = false;
+  // whatever happens below, the request's device block goes back to the allocator
+  struct Release {
+    void *p;
+    ~Release() { (void)psh_free(p); }
+  } release{job.ws};
+  job.ws = nullptr;
   PSH_HIP(hipEventSynchronize(job.ready));
   const int m = job.m, n = job.n, cap = job.cap, max_corners = job.max_corners;
   const double min_distance = job.min_distance;
@@ -1337,6 +1358,26 @@ int psh_lk_corners_finish(float *points_host, int *count_host) {
   *count_host = accepted;
   return PSH_OK;
 }
+
+extern "C++" {
+namespace psh {
+// drop every request still in flight (after an error between launch and finish)
+void lk_corners_drain() {
+  Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  while (g_corner_count > 0) {
+    CornerJob &job = g_corner_jobs[g_corner_head];
+    g_corner_head = (g_corner_head + 1) % kMaxCornerJobs;
+    --g_corner_count;
+    job.active = false;
+    if (job.ready) (void)hipEventSynchronize(job.ready);
+    if (job.ws) (void)psh_free(job.ws);
+    job.ws = nullptr;
+  }
+}
+int lk_corners_in_flight_limit() { return kMaxCornerJobs; }
+}  // namespace psh
+}  // extern "C++"
 
 int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
                        float *stats_dev, int m, int n, int block_size, int buffer_mask,
