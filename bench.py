@@ -34,7 +34,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096, help="grid is size x size")
     ap.add_argument("--leadtimes", type=int, default=24)
     ap.add_argument("--n-iter", type=int, default=1)

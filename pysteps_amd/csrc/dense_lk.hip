@@ -130,19 +130,17 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   // ---- outlier removal (:252-254) on the pooled vectors, then one hand-off to the host ------
   PSH_HIP(psh::launch_outliers_pooled(d_pxy, d_puv, d_pcnt, capacity_dev, prm->k_outlier, prm->nr_std_outlier,
                                       d_pfl, c.stream));
-  static void *pinned = nullptr;  // (count | xy | uv | flags) staging, sized for 8192 vectors
-  constexpr size_t kPinXy = 256, kPinUv = kPinXy + 8192 * 16, kPinFl = kPinUv + 8192 * 16, kPinBytes = kPinFl + 8192;
+  // one copy of the whole pool block (xy | uv | count | flags), same layout on both sides
+  static void *pinned = nullptr;  // sized for 8192 vectors
+  constexpr size_t kPinBytes = 2 * 8192 * 16 + 256 + 8192;
   if (!pinned) PSH_HIP(hipHostMalloc(&pinned, kPinBytes, hipHostMallocDefault));
   char *pin = static_cast<char *>(pinned);
-  PSH_HIP(hipMemcpyAsync(pin, d_pcnt, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-  PSH_HIP(hipMemcpyAsync(pin + kPinXy, d_pxy, cap * 16, hipMemcpyDeviceToHost, c.stream));
-  PSH_HIP(hipMemcpyAsync(pin + kPinUv, d_puv, cap * 16, hipMemcpyDeviceToHost, c.stream));
-  PSH_HIP(hipMemcpyAsync(pin + kPinFl, d_pfl, cap, hipMemcpyDeviceToHost, c.stream));
+  PSH_HIP(hipMemcpyAsync(pin, pbase, off_fl + cap, hipMemcpyDeviceToHost, c.stream));
   PSH_HIP(hipStreamSynchronize(c.stream));
-  const int pooled = std::min(*reinterpret_cast<const int *>(pin), capacity_dev);
-  const double *hxy = reinterpret_cast<const double *>(pin + kPinXy);
-  const double *huv = reinterpret_cast<const double *>(pin + kPinUv);
-  const unsigned char *hfl = reinterpret_cast<const unsigned char *>(pin + kPinFl);
+  const int pooled = std::min(*reinterpret_cast<const int *>(pin + off_cnt), capacity_dev);
+  const double *hxy = reinterpret_cast<const double *>(pin);
+  const double *huv = reinterpret_cast<const double *>(pin + off_uv);
+  const unsigned char *hfl = reinterpret_cast<const unsigned char *>(pin + off_fl);
   std::vector<double> xy, uv;
   xy.reserve(2 * static_cast<size_t>(pooled));
   uv.reserve(2 * static_cast<size_t>(pooled));

@@ -183,41 +183,82 @@ extern "C" int psh_decluster_host(const double *xy, const double *values, int n,
   if (n == 0) return PSH_OK;
   if (!xy || !values || !out_xy || !out_values) return psh::fail(PSH_EINVAL, "decluster: NULL pointer");
   if (!(scale > 0.0) || !std::isfinite(scale)) return psh::fail(PSH_EINVAL, "decluster: scale must be positive");
-  struct Item {
-    double cx, cy;
-    int idx;
-  };
-  std::vector<Item> items(static_cast<size_t>(n));
+  // Cells in lexicographic (x cell, y cell) order, samples of a cell in input order.
+  static thread_local std::vector<long long> cx, cy;
+  static thread_local std::vector<int> order;
+  cx.resize(n);
+  cy.resize(n);
+  long long cx_lo = 0, cx_hi = 0, cy_lo = 0, cy_hi = 0;
   for (int i = 0; i < n; ++i) {
-    items[i].cx = std::floor(xy[2 * i] / scale);
-    items[i].cy = std::floor(xy[2 * i + 1] / scale);
-    items[i].idx = i;
+    const double fx = std::floor(xy[2 * i] / scale), fy = std::floor(xy[2 * i + 1] / scale);
+    if (!(std::fabs(fx) < 4e15) || !(std::fabs(fy) < 4e15))
+      return psh::fail(PSH_EINVAL, "decluster: coordinate / scale out of range");
+    cx[i] = static_cast<long long>(fx);
+    cy[i] = static_cast<long long>(fy);
+    if (i == 0 || cx[i] < cx_lo) cx_lo = cx[i];
+    if (i == 0 || cx[i] > cx_hi) cx_hi = cx[i];
+    if (i == 0 || cy[i] < cy_lo) cy_lo = cy[i];
+    if (i == 0 || cy[i] > cy_hi) cy_hi = cy[i];
   }
-  std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
-    return a.cx != b.cx ? a.cx < b.cx : a.cy < b.cy;
-  });
+  order.resize(n);
+  const unsigned long long nx = static_cast<unsigned long long>(cx_hi - cx_lo) + 1ull;
+  const unsigned long long ny = static_cast<unsigned long long>(cy_hi - cy_lo) + 1ull;
+  for (int i = 0; i < n; ++i) order[i] = i;
+  if (nx <= 65536ull && ny <= 65536ull) {
+    // stable LSD radix sort on the bytes of (y cell, then x cell) relative to the bounding box
+    static thread_local std::vector<int> other;
+    other.resize(n);
+    int *src = order.data(), *dst = other.data();
+    for (int pass = 0; pass < 4; ++pass) {
+      const bool on_x = pass >= 2;
+      const int shift = (pass & 1) * 8;
+      if ((on_x ? nx : ny) <= (1ull << shift) && shift > 0) continue;  // the high byte is zero everywhere
+      int count[257] = {0};
+      auto digit = [&](int i) {
+        return static_cast<int>(((on_x ? cx[i] - cx_lo : cy[i] - cy_lo) >> shift) & 0xff);
+      };
+      for (int t = 0; t < n; ++t) ++count[digit(src[t]) + 1];
+      for (int d = 0; d < 256; ++d) count[d + 1] += count[d];
+      for (int t = 0; t < n; ++t) dst[count[digit(src[t])]++] = src[t];
+      std::swap(src, dst);
+    }
+    if (src != order.data()) std::copy(src, src + n, order.data());
+  } else {
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      return cx[a] != cx[b] ? cx[a] < cx[b] : cy[a] < cy[b];
+    });
+  }
   std::vector<double> col;
   int written = 0;
-  for (size_t s = 0; s < items.size();) {
-    size_t e = s + 1;
-    while (e < items.size() && items[e].cx == items[s].cx && items[e].cy == items[s].cy) ++e;
-    if (static_cast<int>(e - s) >= min_samples) {
-      for (int c = 0; c < 4; ++c) {
-        col.clear();
-        for (size_t t = s; t < e; ++t) {
-          const int i = items[t].idx;
-          col.push_back(c < 2 ? xy[2 * i + c] : values[2 * i + (c - 2)]);
-        }
-        const double med = median_of(col);
-        if (c < 2) {
-          out_xy[2 * written + c] = med;
-        } else {
-          out_values[2 * written + (c - 2)] = med;
+  for (int s0 = 0; s0 < n;) {
+    int e = s0 + 1;
+    while (e < n && cx[order[e]] == cx[order[s0]] && cy[order[e]] == cy[order[s0]]) ++e;
+    const int members = e - s0;
+    if (members >= min_samples) {
+      if (members == 1) {  // the median of one sample
+        const int i = order[s0];
+        out_xy[2 * written] = xy[2 * i];
+        out_xy[2 * written + 1] = xy[2 * i + 1];
+        out_values[2 * written] = values[2 * i];
+        out_values[2 * written + 1] = values[2 * i + 1];
+      } else {
+        for (int c = 0; c < 4; ++c) {
+          col.clear();
+          for (int t = s0; t < e; ++t) {
+            const int i = order[t];
+            col.push_back(c < 2 ? xy[2 * i + c] : values[2 * i + (c - 2)]);
+          }
+          const double med = median_of(col);
+          if (c < 2) {
+            out_xy[2 * written + c] = med;
+          } else {
+            out_values[2 * written + (c - 2)] = med;
+          }
         }
       }
       ++written;
     }
-    s = e;
+    s0 = e;
   }
   *out_count = written;
   return PSH_OK;
