@@ -227,9 +227,11 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
                      float *next_points_host, unsigned char *status_host);
 /* The same two operations in halves, so that independent device work overlaps the host's
  * ordered pass over the corner candidates: corners_launch queues the kernels and the copy of
- * the candidates, pyramids builds the Gaussian pyramids + Scharr gradients of a frame pair
- * (opaque handle, release with psh_lk_pyramids_free), corners_finish waits only for the
- * candidates, track_pyr tracks points through a prebuilt pyramid set. */
+ * the candidates, pyramids builds the Gaussian pyramids of a frame pair (plus a Scharr gradient
+ * image for windows wider than 61 columns; opaque handle, release with psh_lk_pyramids_free),
+ * corners_finish waits only for the candidates, track_pyr tracks points through a prebuilt
+ * pyramid set.  Up to four corner requests may be in flight; corners_finish answers them first
+ * in, first out. */
 int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
                               float *stats_dev, int m, int n, int block_size, int buffer_mask,
                               double quality_level, double min_distance, int max_corners);
