@@ -128,3 +128,26 @@ def test_live_reference_cleansing():
         gc, gv = cleansing.decluster(xy, uv, [20, 35], 2)
         np.testing.assert_allclose(gc, wc, atol=1e-12)
         np.testing.assert_allclose(gv, wv, atol=1e-12)
+
+
+def test_decluster_native_orderings():
+    """psh_decluster_host orders the cells with a byte-wise radix sort over their bounding box and
+    falls back to a comparison sort when the box is huge; both must give the oracle's
+    lexicographic cell order, medians and min_samples filtering, also for negative and
+    fractional coordinates."""
+    from oracle import sparse as osp
+
+    rng = np.random.default_rng(12)
+    cases = [
+        (rng.uniform(-500, 4000, (1500, 2)), 20.0, 1),       # radix path, negative cells
+        (rng.uniform(0, 300, (800, 2)), 7.5, 2),             # dense cells, min_samples filter
+        (rng.uniform(0, 100, (64, 2)), 0.01, 1),             # > 255 cells per axis: both byte passes
+        (rng.uniform(-3e9, 3e9, (200, 2)), 3.0, 1),          # box wider than 65536 cells: fallback
+        (np.repeat(rng.uniform(0, 50, (5, 2)), 4, axis=0), 20.0, 1),  # duplicates: medians of equal values
+    ]
+    for xy, scale, min_samples in cases:
+        uv = rng.normal(0, 1, xy.shape)
+        gc, gv = cleansing.decluster(xy, uv, scale, min_samples)
+        wc, wv = osp.decluster(xy, uv, scale, min_samples)
+        assert gc.shape == wc.shape
+        assert np.array_equal(gc, wc) and np.array_equal(gv, wv)
