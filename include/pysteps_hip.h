@@ -232,6 +232,11 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
  * corners_finish waits only for the candidates, track_pyr tracks points through a prebuilt
  * pyramid set.  Up to four corner requests may be in flight; corners_finish answers them first
  * in, first out. */
+/* The ordered min-distance pass of goodFeaturesToTrack alone (featureselect.cpp; pure host
+ * code): keys = candidates in walking order, (response bits << 32) | (y * n + x), strongest first,
+ * ties by higher address first; accepted corners -> points_host (x, y) float32, at most max_corners. */
+int psh_lk_greedy_host(const unsigned long long *keys, int count, int m, int n, double min_distance,
+                       int max_corners, float *points_host, int *count_host);
 int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
                               float *stats_dev, int m, int n, int block_size, int buffer_mask,
                               double quality_level, double min_distance, int max_corners);

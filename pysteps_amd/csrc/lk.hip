@@ -1180,17 +1180,32 @@ int g_corner_head = 0, g_corner_count = 0;
 struct GreedyGrid {
   int cell, gw, gh, n;
   double md2;
-  std::vector<int> head, next, px, py;
+  // cell heads live in a per-thread array that is kept between calls: a 4096^2 image has 168 k
+  // cells, clearing them costs more than the whole pass, so only the cells an estimate touched
+  // are reset when it is done
+  std::vector<int> &head;
+  std::vector<int> next, px, py, touched;
+  static std::vector<int> &head_store() {
+    static thread_local std::vector<int> store;
+    return store;
+  }
   GreedyGrid(int m, int n_, double min_distance, int max_corners)
       : cell(std::max(1, static_cast<int>(std::lrint(min_distance)))), n(n_),
-        md2(min_distance * min_distance) {
+        md2(min_distance * min_distance), head(head_store()) {
     gw = (n + cell - 1) / cell;
     gh = (m + cell - 1) / cell;
-    head.assign(static_cast<size_t>(gw) * gh, -1);
+    const size_t cells = static_cast<size_t>(gw) * gh;
+    if (head.size() < cells) head.assign(cells, -1);  // (all entries are -1 between calls)
     next.reserve(max_corners);
     px.reserve(max_corners);
     py.reserve(max_corners);
+    touched.reserve(max_corners);
   }
+  ~GreedyGrid() {
+    for (int cidx : touched) head[cidx] = -1;
+  }
+  GreedyGrid(const GreedyGrid &) = delete;
+  GreedyGrid &operator=(const GreedyGrid &) = delete;
   bool offer(int x, int y) {
     const int xc = x / cell, yc = y / cell;
     for (int yy = std::max(0, yc - 1); yy <= std::min(gh - 1, yc + 1); ++yy)
@@ -1202,8 +1217,10 @@ struct GreedyGrid {
     const int id = static_cast<int>(px.size());
     px.push_back(x);
     py.push_back(y);
-    next.push_back(head[static_cast<size_t>(yc) * gw + xc]);
-    head[static_cast<size_t>(yc) * gw + xc] = id;
+    const int cidx = yc * gw + xc;
+    if (head[cidx] < 0) touched.push_back(cidx);
+    next.push_back(head[cidx]);
+    head[cidx] = id;
     return true;
   }
 };
@@ -1350,6 +1367,28 @@ int psh_lk_corners_finish(float *points_host, int *count_host) {
     }
     const unsigned addr = static_cast<unsigned>(head[ci] & 0xffffffffull);
     const int x = static_cast<int>(addr % static_cast<unsigned>(n)), y = static_cast<int>(addr / static_cast<unsigned>(n));
+    if (min_distance >= 1.0 && !grid.offer(x, y)) continue;
+    points_host[2 * accepted] = static_cast<float>(x);
+    points_host[2 * accepted + 1] = static_cast<float>(y);
+    ++accepted;
+  }
+  *count_host = accepted;
+  return PSH_OK;
+}
+
+// The ordered min-distance pass of goodFeaturesToTrack on its own (pure host code, no device):
+// `keys` = candidates in walking order (response bits << 32 | y * n + x, strongest first), the
+// form psh_lk_corners_finish consumes; accepted corners -> points (x, y) float32.
+int psh_lk_greedy_host(const unsigned long long *keys, int count, int m, int n, double min_distance,
+                       int max_corners, float *points_host, int *count_host) {
+  if (!points_host || !count_host || (count > 0 && !keys)) return fail(PSH_EINVAL, "lk_greedy: NULL pointer");
+  if (count < 0 || m <= 0 || n <= 0 || max_corners <= 0) return fail(PSH_EINVAL, "lk_greedy: invalid argument");
+  GreedyGrid grid(m, n, min_distance, max_corners);
+  int accepted = 0;
+  for (int ci = 0; ci < count && accepted < max_corners; ++ci) {
+    const unsigned addr = static_cast<unsigned>(keys[ci] & 0xffffffffull);
+    const int x = static_cast<int>(addr % static_cast<unsigned>(n)), y = static_cast<int>(addr / static_cast<unsigned>(n));
+    if (y >= m) return fail(PSH_EINVAL, "lk_greedy: candidate address outside the image");
     if (min_distance >= 1.0 && !grid.offer(x, y)) continue;
     points_host[2 * accepted] = static_cast<float>(x);
     points_host[2 * accepted + 1] = static_cast<float>(y);

@@ -104,3 +104,45 @@ def test_zeros_give_zero_motion_and_formats():
     assert np.all(lk.dense_lucaskanade(frames, nr_std_outlier=0) == 0)
     xy, uv = lk.dense_lucaskanade(frames, dense=False)
     assert xy.ndim == 2 and xy.shape[1] == 2 and uv.shape == xy.shape
+
+
+@pytest.mark.parametrize("min_distance,max_corners", [(10, 1000), (3.5, 200), (0.5, 50), (25, 40)])
+def test_native_greedy_pass_matches_oracle(min_distance, max_corners):
+    """psh_lk_greedy_host (the host half of psh_lk_corners_*: ordered min-distance acceptance on a
+    cell grid, pure C++) walks the candidates exactly like the oracle's goodFeaturesToTrack."""
+    import ctypes
+
+    from pysteps_amd import _lib
+
+    lib = _lib.load()  # dlopen only: no GPU needed
+    rng = np.random.default_rng(int(min_distance * 10) + max_corners)
+    m, n = 180, 240
+    from scipy.ndimage import gaussian_filter
+
+    img = gaussian_filter(rng.standard_normal((m, n)), 1.5)
+    u8 = np.clip((img - img.min()) / (img.max() - img.min()) * 255, 0, 255).astype(np.uint8)
+    allowed = np.ones((m, n), bool)
+    want = lk.good_features_to_track(u8, allowed, max_corners=max_corners, min_distance=min_distance)
+    # the candidate list the device hands over: thresholded 3x3 maxima, strongest first,
+    # ties by higher address first (response bits << 32 | address, descending)
+    eig = lk.corner_min_eigenval(u8, 5)
+    thr = np.float32(eig.max() * 0.01)
+    e = np.where(eig > thr, eig, np.float32(0))
+    pad = np.full((m + 2, n + 2), -np.inf, dtype=np.float32)
+    pad[1:-1, 1:-1] = e
+    dil = np.max([pad[i:i + m, j:j + n] for i in range(3) for j in range(3)], axis=0)
+    cand = (e != 0) & (e == dil)
+    cand[0, :] = cand[-1, :] = False
+    cand[:, 0] = cand[:, -1] = False
+    ys, xs = np.nonzero(cand)
+    keys = (e[ys, xs].view(np.uint32).astype(np.uint64) << np.uint64(32)) | (ys * n + xs).astype(np.uint64)
+    keys = np.sort(keys)[::-1].copy()
+    pts = np.empty((max_corners, 2), dtype=np.float32)
+    count = ctypes.c_int(0)
+    rc = lib.psh_lk_greedy_host(keys.ctypes.data, int(keys.size), m, n, float(min_distance), int(max_corners),
+                                pts.ctypes.data, ctypes.byref(count))
+    assert rc == 0
+    assert count.value == len(want)
+    assert np.array_equal(pts[: count.value], want)
+    # argument errors do not touch the device either
+    assert lib.psh_lk_greedy_host(keys.ctypes.data, -1, m, n, 10.0, 10, pts.ctypes.data, ctypes.byref(count)) != 0
