@@ -8,7 +8,10 @@
 // per estimate.  The Python shim (pysteps_amd/motion/lucaskanade.py) remains the reference
 // mirror and falls back to its own stage-by-stage loop for anything this call does not take.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -57,6 +60,14 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
   const size_t plane = static_cast<size_t>(m) * n;
+  // PYSTEPS_HIP_TRACE=1: host-side timeline of the call on stderr (where the host waits and works)
+  static const bool trace = std::getenv("PYSTEPS_HIP_TRACE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) {
+    if (trace)
+      std::fprintf(stderr, "dense_lk %-28s +%8.1f us\n", what,
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count());
+  };
 
   // ---- per frame: cleaning + uint8 renderings (lucaskanade.py:213-224) -----------------
   std::vector<DevBlock> clean(nframes), trk(nframes), feat(nframes), stats(nframes);
@@ -114,9 +125,11 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
                                        prm->win_w, prm->win_h, prm->max_level, &pyrs[t - t0]))
         return fail_out(rc);
     }
+    mark("pairs queued");
     for (int t = t0; t < t1; ++t) {
       int npts = 0;
       if (int rc = psh_lk_corners_finish(pts.data(), &npts)) return fail_out(rc);
+      mark("corners ordered");
       if (npts > 0) {
         if (int rc = psh::lk_track_pool(pyrs[t - t0], pts.data(), npts, prm->max_count, prm->epsilon,
                                         prm->min_eig_threshold, d_pxy, d_puv, d_pcnt, capacity_dev))
@@ -136,7 +149,9 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   if (!pinned) PSH_HIP(hipHostMalloc(&pinned, kPinBytes, hipHostMallocDefault));
   char *pin = static_cast<char *>(pinned);
   PSH_HIP(hipMemcpyAsync(pin, pbase, off_fl + cap, hipMemcpyDeviceToHost, c.stream));
+  mark("tracking queued");
   PSH_HIP(hipStreamSynchronize(c.stream));
+  mark("pooled vectors on the host");
   const int pooled = std::min(*reinterpret_cast<const int *>(pin + off_cnt), capacity_dev);
   const double *hxy = reinterpret_cast<const double *>(pin);
   const double *huv = reinterpret_cast<const double *>(pin + off_uv);
@@ -214,6 +229,7 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   PSH_HIP(hipMemcpyAsync(d_xy, up, 2 * sbytes, hipMemcpyHostToDevice, c.stream));
   const double reach = std::hypot(xmax - xmin, ymax - ymin) * 1.001 + 1.0;
   const int k = prm->idw_k <= 0 ? count : prm->idw_k;
+  mark("vectors declustered, uploaded");
   return psh_idw_dev(d_xy, d_uv, count, m, n, 0.0, 1.0, 0.0, 1.0, k, prm->idw_power, prm->idw_dist_offset, reach,
                      field_dev);
 }
