@@ -280,6 +280,10 @@ def main():
                 if dist.world > 1 else "single GPU",
                 "broadcast_s": bcast_s,
                 "broadcast_note": bcast_note,
+                # the two legs of the step (rank 0): the extrapolation kernel by HIP events,
+                # the motion estimate (kernels + its two host hand-overs) as the rest of the step
+                "semilag_only_mpx_leadsteps_s": m * n * T / (sl_ms * 1e-3) / 1e6,
+                "lk_ms_per_step": (ms_per_step - sl_ms) if have_lk else None,
             },
             "roofline": {
                 "kernel": "semilag_fused",
