@@ -298,6 +298,7 @@ def extrapolate(
     velocity,
     timesteps,
     outval=np.nan,
+    xy_coords=None,
     allow_nonfinite_values=False,
     vel_timestep=1,
     displacement_prev=None,
@@ -306,8 +307,14 @@ def extrapolate(
     interp_order=1,
     backend="numpy",
     map_coordinates_mode="constant",
+    verbose=False,
+    D_prev=None,
 ):
     """float64 restatement of semilagrangian.extrapolate (reference :21-266).
+
+    Positional order as the reference's (``outval`` 4th, ``xy_coords`` 5th - steps.py:697-703
+    passes "min" positionally and ``xy_coords=`` by name); ``xy_coords`` replaces the default
+    integer meshgrid (:174-179); ``verbose`` / deprecated ``D_prev`` are accepted and ignored.
 
     Returns what the reference returns: ``(T,m,n)`` in the dtype of ``precip``
     (SciPy allocates its output in the input dtype), optionally with the
@@ -339,7 +346,10 @@ def extrapolate(
         outval = np.nanmin(precip) if precip is not None else np.nan
 
     m, n = velocity.shape[1:]
-    yy, xx = np.mgrid[0:m, 0:n]
+    if xy_coords is None:
+        yy, xx = np.mgrid[0:m, 0:n]
+    else:
+        xx, yy = np.asarray(xy_coords)[0], np.asarray(xy_coords)[1]  # [0] = x/cols, [1] = y/rows (:256-258)
     sub = float(n_iter) if n_iter > 1 else 1.0
 
     # interp_order > 1: the field is interpolated with NaNs zeroed and two order-1 mask warps

@@ -47,6 +47,17 @@ def semilag_golden():
     return GoldenCases(os.path.join(GOLDEN, "semilag_reference.npz"))
 
 
+@pytest.fixture(scope="session")
+def ref_pysteps():
+    """The REAL reference package, imported from oracle/_ref (built by ``python -m oracle.build_ref``
+    from /root/reference; ships to the GPU box with the snapshot).  Test infrastructure only."""
+    from oracle import build_ref
+
+    if not build_ref.available() and build_ref.build() is None:
+        pytest.skip("oracle/_ref is not built and /root/reference is absent")
+    return build_ref.activate()
+
+
 def rel_l2(a, b):
     """relative L2 error over jointly finite entries (BASELINE.md section 3 'Parity')."""
     a = np.asarray(a, dtype=np.float64)
