@@ -47,7 +47,8 @@ const char *psh_version(void);
 int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hbm_free,
                     char *name, int name_len);
 
-/* knobs; "semilag_variant": 0 one pixel per lane, direct gathers (default), 3 three pixels per
+/* knobs; "semilag_variant": 0 one pixel per lane, velocity gathered from a packed {u,v} plane with
+ * dwordx4 loads (default), 1 one plane per component with DPP column sharing, 3 three pixels per
  * lane with dwordx4 gathers (interp_order 0/1, >= 192 columns), 2 / 4 LDS-staged tiles;
  * "idw_variant": 0 two-level pre-pass (64x64 supertile lists, one wave per 8x8 tile; default),
  * 1 one pre-pass per 16x16 tile;
@@ -67,21 +68,6 @@ int psh_event_create(void **event);
 int psh_event_destroy(void *event);
 int psh_event_record(void *event);
 int psh_event_elapsed_ms(void *start, void *stop, float *ms); /* waits for stop */
-
-/* Known-traffic streaming copy (vec_width 1 = dword, 4 = dwordx4 per lane) used to
- * calibrate rocprofv3 FETCH_SIZE/WRITE_SIZE on gfx950; not part of the hot path. */
-int psh_calib_copy(float *dst_dev, const float *src_dev, size_t nfloats, int vec_width);
-/* which source lane the wavefront / row shift DPP controls deliver on this device
- * (tools/dpp_probe.py): out_dev receives 6 x 64 ints (wave_shl:1, wave_shr:1, wave_rol:1,
- * wave_ror:1, row_shl:1, row_shr:1), -1 where no lane was delivered. */
-int psh_calib_dpp(int *out_dev);
-/* gather microbenchmark (tools/gather_probe.py): blocks_per_cu * CUs workgroups of 4 waves, each
- * wave issues iters * 8 buffer loads of `width` (1, 2, 4) dwords per lane, lane i at column
- * i * width + shift, walking cyclically over `n_rows` rows (power of two, `pitch_bytes` apart;
- * 8 rows stay L1-resident, thousands stream from L2 / HBM); only the last `active_lanes` lanes of
- * each wave take part (exec-masked loads). */
-int psh_calib_gather(const float *src_dev, float *sink_dev, int pitch_bytes, int width, int shift, int iters,
-                     int blocks_per_cu, int n_rows, int active_lanes /* the last k lanes of each wave */);
 
 /* ---- element-wise passes either side of the path (keep a nowcast chain in HBM) ------ *
  * psh_db_transform_dev: pysteps/utils/transformation.py:150-232 (dB_transform).  Forward:

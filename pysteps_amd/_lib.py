@@ -60,10 +60,7 @@ SIGNATURES = {
     "psh_event_destroy": (c_int, [c_void_p]),
     "psh_event_record": (c_int, [c_void_p]),
     "psh_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
-    "psh_calib_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
-    "psh_calib_dpp": (c_int, [c_void_p]),
     "psh_lk_greedy_host": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),
-    "psh_calib_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "psh_idw_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_double, c_void_p]),
     "psh_idw_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_void_p]),
     "psh_lk_prepare_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -160,10 +160,10 @@ int psh_shutdown(void) {
 int psh_set_option(const char *key, int value) {
   if (!key) return fail(PSH_EINVAL, "psh_set_option: NULL key");
   if (std::strcmp(key, "semilag_variant") == 0) {
-    if (value != 0 && value != 2 && value != 3 && value != 4)
+    if (value < 0 || value > 4)
       return fail(PSH_EINVAL,
-                  "semilag_variant must be 0 (one pixel per lane), 3 (three pixels per lane), 2 or 4 "
-                  "(LDS-staged rows per thread)");
+                  "semilag_variant must be 0 (packed {u,v} plane, dwordx4 gathers), 1 (one plane per component, "
+                  "DPP column sharing), 3 (three pixels per lane), 2 or 4 (LDS-staged rows per thread)");
     psh::set_semilag_variant(value);
     return PSH_OK;
   }
@@ -451,8 +451,25 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
     a.coef = coef;
     a.minval = static_cast<float>(mn);
   }
+  void *packed_blk = nullptr;
+  if (psh::semilag_wants_packed(a)) {
+    // {u,v} interleaved copy of the velocity for the dwordx4 gathers (semilag.hip); cached block
+    const size_t plane = static_cast<size_t>(m) * n;
+    int rc = psh_malloc(&packed_blk, 2 * plane * sizeof(float));
+    if (rc == PSH_OK) {
+      const hipError_t pe = psh::launch_pack_velocity(velocity_dev, static_cast<float *>(packed_blk), plane, c.stream);
+      if (pe != hipSuccess) rc = fail(PSH_EHIP, "pack_velocity failed: %s", hipGetErrorString(pe));
+    }
+    if (rc) {
+      if (packed_blk) (void)psh_free(packed_blk);
+      if (spline_blk) (void)psh_free(spline_blk);
+      return rc;
+    }
+    a.vel_packed = static_cast<const float *>(packed_blk);
+  }
   const hipError_t le = psh::launch_semilag(a, c.stream);
   if (spline_blk) (void)psh_free(spline_blk);  // stream-ordered: the launch above is queued first
+  if (packed_blk) (void)psh_free(packed_blk);
   PSH_HIP(le);
   return PSH_OK;
 }

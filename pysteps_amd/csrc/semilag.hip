@@ -46,7 +46,7 @@ using namespace sl;
 constexpr int kTileX = 64;
 // kernel flavours: direct gathers (one pixel per lane), LDS-staged tiles, direct gathers with
 // two horizontally adjacent pixels per lane
-enum : int { kModeDirect = 0, kModeStaged = 1, kModePairX = 2 };
+enum : int { kModeDirect = 0, kModeStaged = 1, kModePairX = 2, kModePacked = 3 };
 constexpr int kWavesPerBlock = 4;   // LDS-staged variants: 4 waves (rows) per workgroup
 // the direct kernel runs 8 rows per workgroup: the tap row below a wave's pixels is the row the next
 // wave samples, more rows per workgroup = more of that reuse in the CU's L1 (1.55 -> 1.50 ms)
@@ -57,6 +57,7 @@ struct Fields {
   // descriptor (SGPR) + one 32-bit lane offset + immediate (+1 column) + scalar
   // offset (+1 row) - no per-load 64-bit VALU address arithmetic
   __amdgpu_buffer_rsrc_t ru, rv, rp;
+  __amdgpu_buffer_rsrc_t ruv;  // packed {u,v} float2 plane (kModePacked)
   int row_bytes;
   const float *coef;  // cubic B-spline coefficients of the field (interp_order 3 only)
   float minval;       // minimum over its finite values (interp_order 3 only)
@@ -186,6 +187,68 @@ __device__ __forceinline__ void sample_interior(const Fields &F, const int (&X)[
       pd[j] = last_lane ? lpd[j] : pd[j];
       take_right_columns(own[j], pa[j], pc[j], pb[j], pd[j]);
       sp[j] = blend(w, pa[j], pb[j], pc[j], pd[j]);
+    }
+  }
+}
+
+// ---- fast path over the packed velocity plane ---------------------------------------------
+// What a gather costs the vector memory pipeline depends on the instruction, not on the bytes
+// (tools/gather_probe.py): a wave64 dword load ~8-9.5 clk, dwordx2 and dwordx4 both ~16.5 clk,
+// any alignment.  With the two velocity components interleaved ({u,v} float2 per pixel,
+// pack_velocity below) ONE dwordx4 at the lane's own position returns u and v of BOTH columns of
+// a tap row, so a velocity sampling pass is 2 loads and the field adds one dwordx2 per tap row
+// ({p(X), p(X+1)}): 6 loads per pixel and lead step instead of 10 + 10 - and no lane depends on
+// its neighbour, so sheared motion costs the same as uniform motion (no DPP exchange, no
+// exec-masked second round, no scalar loads for lane 63).  The (u,v) pairs arrive in aligned
+// register pairs: the bilinear blend runs as v_pk_mul_f32 / v_pk_fma_f32 on both components at
+// once, same operation order per component as blend() - results are bit-identical to the
+// one-plane-per-component path.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool WITH_P>
+__device__ __forceinline__ void sample_interior_packed(const Fields &F, int X, int Y, float fx, float fy,
+                                                       int n, float &su, float &sv, float &sp) {
+  const unsigned offp = static_cast<unsigned>(__mul24(Y, n) + X) << 2;
+  const unsigned offuv = offp << 1;
+  const int rb = F.row_bytes;
+  const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(F.ruv, static_cast<int>(offuv), 0, 0);
+  const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(F.ruv, static_cast<int>(offuv), 2 * rb, 0);
+  u32x2 pt, pb;  // {p(X), p(X+1)} of the two tap rows
+  if (WITH_P) {
+    pt = __builtin_amdgcn_raw_buffer_load_b64(F.rp, static_cast<int>(offp), 0, 0);
+    pb = __builtin_amdgcn_raw_buffer_load_b64(F.rp, static_cast<int>(offp), rb, 0);
+  }
+  const Weights w = make_weights(fx, fy);
+  const f32x4 T = __builtin_bit_cast(f32x4, t), B = __builtin_bit_cast(f32x4, b);
+  f32x2 acc = T.xy * w.w00;
+  acc = __builtin_elementwise_fma(f32x2{w.w01, w.w01}, T.zw, acc);
+  acc = __builtin_elementwise_fma(f32x2{w.w10, w.w10}, B.xy, acc);
+  acc = __builtin_elementwise_fma(f32x2{w.w11, w.w11}, B.zw, acc);
+  su = acc.x;
+  sv = acc.y;
+  if (WITH_P) {
+    const f32x2 PT = __builtin_bit_cast(f32x2, pt), PB = __builtin_bit_cast(f32x2, pb);
+    sp = blend(w, PT.x, PT.y, PB.x, PB.y);
+  }
+}
+
+// {u,v} interleaved copy of the velocity planes: 4 pixels per thread, dwordx4 in and out
+__global__ __launch_bounds__(256) void pack_velocity(const float *__restrict__ vel, float *__restrict__ uv,
+                                                     size_t plane) {
+  const size_t i = (static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+  if (i + 3 < plane) {
+    const f32x4 u = *reinterpret_cast<const f32x4 *>(vel + i);
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(vel + plane + i);
+    f32x4 *o = reinterpret_cast<f32x4 *>(uv + 2 * i);
+    o[0] = f32x4{u.x, v.x, u.y, v.y};
+    o[1] = f32x4{u.z, v.z, u.w, v.w};
+  } else {
+    for (size_t k = i; k < plane; ++k) {
+      uv[2 * k] = vel[k];
+      uv[2 * k + 1] = vel[plane + k];
     }
   }
 }
@@ -362,7 +425,13 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
   for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(X[j], Y[j], m, n);
   // wave-uniform branch: interior waves (almost all of them) skip every clamp
   if (inside) {
-    sample_interior<NPX, kWithP && ORDER == 1>(F, X, Y, fx, fy, n, su, sv, sp);
+    if (MODE == kModePacked) {
+#pragma unroll
+      for (int j = 0; j < NPX; ++j)
+        sample_interior_packed<kWithP && ORDER == 1>(F, X[j], Y[j], fx[j], fy[j], n, su[j], sv[j], sp[j]);
+    } else {
+      sample_interior<NPX, kWithP && ORDER == 1>(F, X, Y, fx, fy, n, su, sv, sp);
+    }
     if (kWithP && ORDER == 0) {
 #pragma unroll
       for (int j = 0; j < NPX; ++j) {
@@ -394,11 +463,12 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
 // GEN: the field resampling honours F.bmode (any scipy boundary mode); otherwise the kernel only
 // contains the "constant" rule and none of the folding code
 template <int MODE>
-constexpr int waves_of() { return MODE == kModeDirect ? kDirectWaves : kWavesPerBlock; }
+constexpr int waves_of() { return (MODE == kModeDirect || MODE == kModePacked) ? kDirectWaves : kWavesPerBlock; }
 
 template <int NPX, int ORDER, bool HAS_PRECIP, int MODE, bool GEN>
 __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
-    const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out,
+    const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vel_packed,
+    float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
     int T, int n_iter, int resume, float outval, int row0, int rows, const float *__restrict__ coef,
     float minval, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd) {
@@ -423,6 +493,8 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
   F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
   F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_PRECIP ? precip : vel), 0, plane_bytes,
                                            0x00020000);
+  F.ruv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == kModePacked ? vel_packed : vel), 0,
+                                            2 * plane_bytes, 0x00020000);
   F.row_bytes = n * static_cast<int>(sizeof(float));
   F.coef = coef;
   F.minval = minval;
@@ -598,7 +670,7 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   const dim3 grid(tiles_per_xcd * kNumXcd), block(kTileX * kWaves);
 #define PSH_SL_LAUNCH(ORDER, HASP, GEN)                                                         \
   hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, MODE, GEN>), grid, block, 0, stream,      \
-                     a.precip, a.vel, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T,     \
+                     a.precip, a.vel, a.vel_packed, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T, \
                      a.n_iter, a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, a.bmode,   \
                      tiles_x, n_tiles, tiles_per_xcd)
   if (a.precip == nullptr) {
@@ -647,7 +719,23 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
     if (g_semilag_variant == 2) return launch_variant<2, kModeStaged>(a, stream);
     return launch_variant<4, kModeStaged>(a, stream);
   }
+  // one or two rows per thread measured equal (1.45 ms at 4096^2 x 24): the kernel is not short of
+  // loads in flight
+  if (a.vel_packed != nullptr) return launch_variant<1, kModePacked>(a, stream);
   return launch_variant<1, kModeDirect>(a, stream);
+}
+
+// variant 0 (default) samples the velocity from a packed {u,v} plane when the caller provides one;
+// variant 1 = the one-plane-per-component kernel with DPP column sharing (round 1 default)
+bool semilag_wants_packed(const SemilagArgs &a) {
+  return g_semilag_variant == 0 && static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29);
+}
+
+hipError_t launch_pack_velocity(const float *vel, float *uv, size_t plane, hipStream_t stream) {
+  const size_t threads = (plane + 3) / 4;
+  hipLaunchKernelGGL(pack_velocity, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, stream, vel, uv,
+                     plane);
+  return hipGetLastError();
 }
 
 }  // namespace psh

@@ -279,10 +279,11 @@ def test_device_resident_path(extrapolate):
     assert np.array_equal(dev_disp.to_host(), host_disp)  # displacement_prev untouched
 
 
-@pytest.mark.parametrize("variant", [3, 2, 4])
+@pytest.mark.parametrize("variant", [1, 3, 2, 4])
 def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
-    """The three-pixels-per-lane kernel (variant 3) is bit-identical to the default
-    one-pixel-per-lane kernel; the LDS-staged kernels (2, 4) agree to rounding."""
+    """The one-plane-per-component kernel with DPP column sharing (variant 1, the round-1 default)
+    and the three-pixels-per-lane kernel (variant 3) are bit-identical to the default kernel (packed
+    {u,v} plane, dwordx4 gathers); the LDS-staged kernels (2, 4) agree to rounding."""
     from pysteps_amd import _lib
     from tools import synth
 
@@ -306,7 +307,7 @@ def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
             got, gdisp = extrapolate(a, b, t, return_displacement=True, **kw)
             assert nan_mismatch(got, want) == 0
             assert np.max(np.abs(gdisp - wdisp)) < 1e-5
-            if variant == 3:
+            if variant in (1, 3):
                 assert np.array_equal(got, want, equal_nan=True) and np.array_equal(gdisp, wdisp)
             elif kw.get("interp_order", 1) == 0:
                 assert np.count_nonzero(got != want) <= 1e-4 * got.size

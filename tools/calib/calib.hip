@@ -1,8 +1,12 @@
 // Known-traffic streaming copies used to calibrate rocprofv3's FETCH_SIZE /
 // WRITE_SIZE on gfx950 (MI355X_MICROARCH.md "HBM": FETCH_SIZE under-reads wide
 // coalesced streams by 2x; other widths must be calibrated in the access
-// pattern of the kernel under study).  Not part of the hot path.
-#include "common.h"
+// pattern of the kernel under study).  Measurement aids only: built into tools/calib/libpsh_calib.so
+// (python -m tools.calib.build), NOT into the product library.  Self-contained: launches go to the
+// null stream of the current device and synchronise; device pointers come from psh_malloc.
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
 
 namespace psh {
 namespace {
@@ -28,12 +32,12 @@ __global__ __launch_bounds__(256) void calib_copy_dwordx4(float4 *__restrict__ d
 template <int W>
 __global__ __launch_bounds__(256) void calib_gather(const float *__restrict__ src, float *__restrict__ sink,
                                                     int pitch_bytes, int shift, int iters, int row_mask, int row_step,
-                                                    int first_lane) {
+                                                    int first_lane, int lane_stride) {
   typedef float vec __attribute__((ext_vector_type(W)));
   __amdgpu_buffer_rsrc_t r =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, pitch_bytes * (row_mask + 1), 0x00020000);
   const int lane = threadIdx.x & 63;
-  const unsigned off = static_cast<unsigned>((blockIdx.x & 1) * 2048 + lane * W + shift) * 4u;
+  const unsigned off = static_cast<unsigned>((blockIdx.x & 1) * 2048 + lane * lane_stride + shift) * 4u;
   // every wave starts somewhere else in the row cycle: no L1 sharing between waves beyond 8 rows
   const int phase = row_step == 1 ? 0 : static_cast<int>((blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 * 37);
   float acc = 0.f;
@@ -73,59 +77,69 @@ __global__ __launch_bounds__(64) void calib_dpp(int *__restrict__ out) {
 }  // namespace
 }  // namespace psh
 
-extern "C" int psh_calib_dpp(int *out_dev) {
-  PSH_REQUIRE_INIT();
-  if (!out_dev) return psh::fail(PSH_EINVAL, "psh_calib_dpp: NULL pointer");
-  psh::Context &c = psh::ctx();
-  std::lock_guard<std::recursive_mutex> lock(c.mu);
-  PSH_HIP(hipSetDevice(c.device));
-  hipLaunchKernelGGL(psh::calib_dpp, dim3(1), dim3(64), 0, c.stream, out_dev);
-  PSH_HIP(hipGetLastError());
-  return PSH_OK;
+#define CALIB_HIP(expr)            \
+  do {                             \
+    hipError_t _e = (expr);        \
+    if (_e != hipSuccess) return static_cast<int>(_e); \
+  } while (0)
+
+extern "C" int calib_dpp(int *out_dev) {
+  hipLaunchKernelGGL(psh::calib_dpp, dim3(1), dim3(64), 0, nullptr, out_dev);
+  CALIB_HIP(hipGetLastError());
+  CALIB_HIP(hipDeviceSynchronize());
+  return 0;
 }
 
-extern "C" int psh_calib_gather(const float *src_dev, float *sink_dev, int pitch_bytes, int width, int shift,
-                                int iters, int blocks_per_cu, int n_rows, int active_lanes) {
-  PSH_REQUIRE_INIT();
-  if (!src_dev || !sink_dev) return psh::fail(PSH_EINVAL, "psh_calib_gather: NULL pointer");
-  if (n_rows < 8 || (n_rows & (n_rows - 1))) return psh::fail(PSH_EINVAL, "psh_calib_gather: n_rows must be a power of two >= 8");
-  psh::Context &c = psh::ctx();
-  std::lock_guard<std::recursive_mutex> lock(c.mu);
-  PSH_HIP(hipSetDevice(c.device));
-  const dim3 grid(c.cu_count * blocks_per_cu), block(256);
+// lane i reads `width` dwords at column x0 + i * lane_stride + shift (lane_stride < width: the
+// lanes' footprints overlap, as in the packed semi-Lagrangian gathers); returns milliseconds in *ms
+extern "C" int calib_gather(const float *src_dev, float *sink_dev, int pitch_bytes, int width, int lane_stride,
+                            int shift, int iters, int blocks_per_cu, int n_rows, int active_lanes, float *ms) {
+  if (!src_dev || !sink_dev || n_rows < 8 || (n_rows & (n_rows - 1))) return -1;
+  int dev = 0, cus = 0;
+  CALIB_HIP(hipGetDevice(&dev));
+  CALIB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const dim3 grid(cus * blocks_per_cu), block(256);
+  hipEvent_t e0, e1;
+  CALIB_HIP(hipEventCreate(&e0));
+  CALIB_HIP(hipEventCreate(&e1));
+  CALIB_HIP(hipEventRecord(e0, nullptr));
+  const int row_step = n_rows > 8 ? 8 : 1, first = 64 - active_lanes;
   if (width == 1)
-    hipLaunchKernelGGL(psh::calib_gather<1>, grid, block, 0, c.stream, src_dev, sink_dev, pitch_bytes, shift, iters, n_rows - 1, n_rows > 8 ? 8 : 1,
-                       64 - active_lanes);
+    hipLaunchKernelGGL(psh::calib_gather<1>, grid, block, 0, nullptr, src_dev, sink_dev, pitch_bytes, shift, iters,
+                       n_rows - 1, row_step, first, lane_stride);
   else if (width == 2)
-    hipLaunchKernelGGL(psh::calib_gather<2>, grid, block, 0, c.stream, src_dev, sink_dev, pitch_bytes, shift, iters, n_rows - 1, n_rows > 8 ? 8 : 1,
-                       64 - active_lanes);
+    hipLaunchKernelGGL(psh::calib_gather<2>, grid, block, 0, nullptr, src_dev, sink_dev, pitch_bytes, shift, iters,
+                       n_rows - 1, row_step, first, lane_stride);
   else if (width == 4)
-    hipLaunchKernelGGL(psh::calib_gather<4>, grid, block, 0, c.stream, src_dev, sink_dev, pitch_bytes, shift, iters, n_rows - 1, n_rows > 8 ? 8 : 1,
-                       64 - active_lanes);
+    hipLaunchKernelGGL(psh::calib_gather<4>, grid, block, 0, nullptr, src_dev, sink_dev, pitch_bytes, shift, iters,
+                       n_rows - 1, row_step, first, lane_stride);
   else
-    return psh::fail(PSH_EINVAL, "psh_calib_gather: width must be 1, 2 or 4");
-  PSH_HIP(hipGetLastError());
-  return PSH_OK;
+    return -1;
+  CALIB_HIP(hipGetLastError());
+  CALIB_HIP(hipEventRecord(e1, nullptr));
+  CALIB_HIP(hipEventSynchronize(e1));
+  if (ms) CALIB_HIP(hipEventElapsedTime(ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return 0;
 }
 
-extern "C" int psh_calib_copy(float *dst_dev, const float *src_dev, size_t nfloats, int vec_width) {
-  PSH_REQUIRE_INIT();
-  if (!dst_dev || !src_dev) return psh::fail(PSH_EINVAL, "psh_calib_copy: NULL pointer");
-  psh::Context &c = psh::ctx();
-  std::lock_guard<std::recursive_mutex> lock(c.mu);
-  PSH_HIP(hipSetDevice(c.device));
-  const int grid = c.cu_count * 8;
+extern "C" int calib_copy(float *dst_dev, const float *src_dev, size_t nfloats, int vec_width) {
+  if (!dst_dev || !src_dev) return -1;
+  int dev = 0, cus = 0;
+  CALIB_HIP(hipGetDevice(&dev));
+  CALIB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int grid = cus * 8;
   if (vec_width == 4) {
-    if (nfloats % 4) return psh::fail(PSH_EINVAL, "psh_calib_copy: nfloats must be a multiple of 4");
-    hipLaunchKernelGGL(psh::calib_copy_dwordx4, dim3(grid), dim3(256), 0, c.stream,
-                       reinterpret_cast<float4 *>(dst_dev),
+    if (nfloats % 4) return -1;
+    hipLaunchKernelGGL(psh::calib_copy_dwordx4, dim3(grid), dim3(256), 0, nullptr, reinterpret_cast<float4 *>(dst_dev),
                        reinterpret_cast<const float4 *>(src_dev), nfloats / 4);
   } else if (vec_width == 1) {
-    hipLaunchKernelGGL(psh::calib_copy_dword, dim3(grid), dim3(256), 0, c.stream, dst_dev, src_dev,
-                       nfloats);
+    hipLaunchKernelGGL(psh::calib_copy_dword, dim3(grid), dim3(256), 0, nullptr, dst_dev, src_dev, nfloats);
   } else {
-    return psh::fail(PSH_EINVAL, "psh_calib_copy: vec_width must be 1 or 4");
+    return -1;
   }
-  PSH_HIP(hipGetLastError());
-  return PSH_OK;
+  CALIB_HIP(hipGetLastError());
+  CALIB_HIP(hipDeviceSynchronize());
+  return 0;
 }
