@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=2, help="LK input frames")
     ap.add_argument("--no-lk", action="store_true", help="time the extrapolator only (true velocity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the NumPy-in / NumPy-out leg")
     ap.add_argument("--cpu-sample-steps", type=int, default=2)
     return ap.parse_args()
 
@@ -130,15 +131,53 @@ def cpu_baseline(frames_d, vel_d, n_iter, sample_steps, leadtimes, with_lk):
     vel_h = vel_d.to_host()
     frames_h = frames_d.to_host()
     m, n = vel_h.shape[1:]
+    # the UNMODIFIED reference function where oracle/_ref travelled with the snapshot
+    # (oracle/build_ref.py); otherwise the restated driver over the same SciPy kernel
+    ref_extrapolate = None
+    try:
+        from oracle import build_ref
+
+        if build_ref.available():
+            build_ref.activate()
+            from pysteps.extrapolation.semilagrangian import extrapolate as ref_extrapolate
+    except Exception:
+        ref_extrapolate = None
     t0 = time.perf_counter()
-    osl.extrapolate(frames_h[-1], vel_h, sample_steps, outval=-15.0, n_iter=n_iter, backend="scipy")
+    if ref_extrapolate is not None:
+        ref_extrapolate(frames_h[-1], vel_h, sample_steps, outval=-15.0, n_iter=n_iter)
+    else:
+        osl.extrapolate(frames_h[-1], vel_h, sample_steps, outval=-15.0, n_iter=n_iter, backend="scipy")
     dt = time.perf_counter() - t0
     t0 = time.perf_counter()
     ocl.extrapolate(frames_h[-1], vel_h, sample_steps, outval=-15.0, n_iter=n_iter)
     dtc = time.perf_counter() - t0
     t_sl_full = dt / sample_steps * leadtimes
-    sample = "semi-Lagrangian: %dx%d, %d of %d lead steps, n_iter=%d, scipy map_coordinates driver, %.1f s" % (
-        m, n, sample_steps, leadtimes, n_iter, dt)
+    sample = "semi-Lagrangian: %dx%d, %d of %d lead steps, n_iter=%d, %s, %.1f s" % (
+        m, n, sample_steps, leadtimes, n_iter,
+        "pysteps.extrapolation.semilagrangian.extrapolate (oracle/_ref, unmodified reference)"
+        if ref_extrapolate is not None else "restated driver over scipy map_coordinates", dt)
+    # member-parallel figure: the reference is single-threaded, a host would run one
+    # process per core - P processes advect one lead step each on the full grid
+    multi = None
+    if ref_extrapolate is not None:
+        import multiprocessing as mp
+
+        procs = min(8, len(os.sched_getaffinity(0)))
+        try:
+            ctx = mp.get_context("fork")
+            t0 = time.perf_counter()
+            workers = [ctx.Process(target=ref_extrapolate, args=(frames_h[-1], vel_h, 1),
+                                   kwargs=dict(outval=-15.0, n_iter=n_iter)) for _ in range(procs)]
+            for w in workers:
+                w.start()
+            for w in workers:
+                w.join()
+            dtp = time.perf_counter() - t0
+            if all(w.exitcode == 0 for w in workers):
+                multi = {"value": procs * m * n / dtp / 1e6, "cores": procs,
+                         "note": "%d processes x 1 lead step each, reference function, %.1f s" % (procs, dtp)}
+        except Exception:
+            multi = None
     t_lk_full = 0.0
     if with_lk:
         cm, cn = max(m // 4, 64), max(n // 4, 64)
@@ -156,12 +195,37 @@ def cpu_baseline(frames_d, vel_d, n_iter, sample_steps, leadtimes, with_lk):
         "value": m * n * leadtimes / (t_sl_full + t_lk_full) / 1e6,
         "unit": "Mpx*leadsteps/s",
         "cores": 1,
-        "kind": "port",
+        # semi-Lagrangian leg: the reference itself when oracle/_ref is present; LK leg: always the
+        # restatement (OpenCV is absent from this image and from the GPU box, profiles/r02/a_cv2_probe.txt)
+        "kind": "reference" if ref_extrapolate is not None else "port",
         "sample": sample,
         "semilag_only": {"value": m * n * sample_steps / dt / 1e6, "cores": 1},
+        "semilag_reference_multiprocess": multi,
         "semilag_port_c_openmp": {"value": m * n * sample_steps / dtc / 1e6, "cores": ocl.num_threads(),
                                   "note": "oracle/semilag_c.c, fused per-pixel float64 port"},
     }
+
+
+def host_path(frames_d, vel_d, T, K, reps=3):
+    """The plugin boundary itself: NumPy arrays in, NumPy arrays out through
+    extrapolation.get_method("semilagrangian") (psh_semilag_host) - PCIe included.  Never `value`."""
+    from pysteps_amd import extrapolation
+
+    ex = extrapolation.get_method("semilagrangian")
+    p, v = frames_d.view(frames_d.shape[0] - 1).to_host(), vel_d.to_host()
+    m, n = p.shape
+    ex(p, v, T, outval=-15.0, n_iter=K)  # warm-up: pins the result block, fills the block caches
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = ex(p, v, T, outval=-15.0, n_iter=K)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        del out
+    moved = (3 + T) * m * n * 4.0
+    return {"host_path_ms": best * 1e3, "host_path_pcie_gbs": moved / best / 1e9,
+            "host_path_note": "numpy in / numpy out, %d x %d x %d lead times, best of %d; %.2f GB over PCIe" % (
+                m, n, T, reps, moved / 1e9)}
 
 
 def pmc_traffic(workload):
@@ -173,6 +237,12 @@ def pmc_traffic(workload):
         return table.get(workload, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def compulsory_bytes(m, n, T, K):
+    """What one launch cannot avoid moving to / from HBM: the T output planes once, the three
+    input planes once."""
+    return (T + 3.0) * m * n * 4.0
 
 
 def main():
@@ -297,6 +367,14 @@ def main():
                 "traffic": pmc_traffic("semilag_%dx%d_T%d_K%d" % (m, n, T, K)),
             },
         }
+        # the contract's `frac` prices ALGORITHMIC bytes; the inputs are served from L2/MALL, so the
+        # DRAM-side picture is given beside it: counter traffic over the same duration, and the time
+        # the compulsory stream alone would need at peak
+        rf = line["roofline"]
+        rf["hbm_frac"] = (rf["traffic"] / (sl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rf["traffic"] else None
+        rf["floor_ms"] = compulsory_bytes(m, n, T, K) / (HBM_PEAK_GBS * 1e9) * 1e3
+        if dist.world == 1 and not args.no_host_path:
+            line["config"].update(host_path(frames_d, vel_d, T, K))
         if not args.no_cpu_baseline and dist.world == 1:
             line["cpu_baseline"] = cpu_baseline(frames_d, vel_d, K, args.cpu_sample_steps, T, have_lk)
         print(json.dumps(line))

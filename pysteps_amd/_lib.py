@@ -53,6 +53,8 @@ SIGNATURES = {
     "psh_free": (c_int, [c_void_p]),
     "psh_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "psh_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "psh_host_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "psh_host_free": (c_int, [c_void_p]),
     "psh_memcpy_d2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "psh_memset": (c_int, [c_void_p, c_int, c_size_t]),
     "psh_sync": (c_int, []),

@@ -51,6 +51,14 @@ int const_slot(float **host, const float **dev);
       return ::psh::fail(PSH_ENOTINIT, "psh_init() has not been called");        \
   } while (0)
 
+int check_semilag(int m, int n, int T, int n_iter, int order_and_mode);
+
+// ---- host-buffer path (hostpath.hip): pinned block pool, staged transfers ---
+// pinned host blocks, cached like the device blocks; PSH_ENOMEM beyond PYSTEPS_HIP_PINNED_BYTES
+int pinned_alloc(void **host_ptr, size_t nbytes);
+int pinned_free(void *host_ptr);
+void pinned_release_cache();
+
 // ---- kernel launchers (one per .hip translation unit) ----------------------
 struct SemilagArgs {
   const float *precip;  // (m,n) or nullptr

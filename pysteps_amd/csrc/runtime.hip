@@ -103,6 +103,22 @@ int const_slot(float **host, const float **dev) {
   return PSH_OK;
 }
 
+int check_semilag(int m, int n, int T, int n_iter, int order_and_mode) {
+  const int order = order_and_mode & 0xff, bmode = (order_and_mode >> 8) & 0xff;
+  if (order_and_mode < 0 || (order_and_mode >> 16) != 0 || bmode > PSH_MODE_GRID_WRAP)
+    return fail(PSH_EINVAL, "semilag: invalid interp_order / boundary mode word 0x%x", order_and_mode);
+  if (bmode != PSH_MODE_CONSTANT && order == 3)
+    return fail(PSH_EUNSUPPORTED, "semilag: interp_order 3 is implemented for mode \"constant\" only");
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "semilag: invalid shape (%d,%d)", m, n);
+  if (static_cast<uint64_t>(m) * static_cast<uint64_t>(n) >= (1ull << 30))
+    return fail(PSH_EUNSUPPORTED, "semilag: m*n must be < 2^30 pixels (32-bit byte offsets)");
+  if (T <= 0) return fail(PSH_EINVAL, "semilag: T must be positive (got %d)", T);
+  if (n_iter < 0) return fail(PSH_EINVAL, "semilag: n_iter must be >= 0 (got %d)", n_iter);
+  if (order != 0 && order != 1 && order != 3)
+    return fail(PSH_EUNSUPPORTED, "semilag: interp_order %d not implemented (0, 1 or 3)", order);
+  return PSH_OK;
+}
+
 }  // namespace psh
 
 using psh::ctx;
@@ -147,6 +163,7 @@ int psh_shutdown(void) {
   if (!c.ready) return PSH_OK;
   (void)hipStreamSynchronize(c.stream);
   psh::release_cache();
+  psh::pinned_release_cache();
   if (c.scratch) (void)hipFree(c.scratch);
   if (c.pinned) (void)hipHostFree(c.pinned);
   (void)hipStreamDestroy(c.stream);
@@ -180,6 +197,7 @@ int psh_set_option(const char *key, int value) {
       PSH_HIP(hipSetDevice(c.device));
       PSH_HIP(hipStreamSynchronize(c.stream));
       psh::release_cache();
+      psh::pinned_release_cache();
     }
     return PSH_OK;
   }
@@ -358,21 +376,6 @@ int psh_event_elapsed_ms(void *start, void *stop, float *ms) {
 // ---------------------------------------------------------------------------
 // semi-Lagrangian extrapolation
 // ---------------------------------------------------------------------------
-static int check_semilag(int m, int n, int T, int n_iter, int order_and_mode) {
-  const int order = order_and_mode & 0xff, bmode = (order_and_mode >> 8) & 0xff;
-  if (order_and_mode < 0 || (order_and_mode >> 16) != 0 || bmode > PSH_MODE_GRID_WRAP)
-    return fail(PSH_EINVAL, "semilag: invalid interp_order / boundary mode word 0x%x", order_and_mode);
-  if (bmode != PSH_MODE_CONSTANT && order == 3)
-    return fail(PSH_EUNSUPPORTED, "semilag: interp_order 3 is implemented for mode \"constant\" only");
-  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "semilag: invalid shape (%d,%d)", m, n);
-  if (static_cast<uint64_t>(m) * static_cast<uint64_t>(n) >= (1ull << 30))
-    return fail(PSH_EUNSUPPORTED, "semilag: m*n must be < 2^30 pixels (32-bit byte offsets)");
-  if (T <= 0) return fail(PSH_EINVAL, "semilag: T must be positive (got %d)", T);
-  if (n_iter < 0) return fail(PSH_EINVAL, "semilag: n_iter must be >= 0 (got %d)", n_iter);
-  if (order != 0 && order != 1 && order != 3)
-    return fail(PSH_EUNSUPPORTED, "semilag: interp_order %d not implemented (0, 1 or 3)", order);
-  return PSH_OK;
-}
 
 int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
                          const double *steps_host, int T, int n_iter, int interp_order,
@@ -394,7 +397,7 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
   if (row_begin < 0 || row_count <= 0 || row_begin + row_count > m)
     return fail(PSH_EINVAL, "semilag: row band [%d, %d) outside the %d-row image", row_begin,
                 row_begin + row_count, m);
-  if (int rc = check_semilag(m, n, T, n_iter, interp_order)) return rc;
+  if (int rc = psh::check_semilag(m, n, T, n_iter, interp_order)) return rc;
   if (!velocity_dev || !steps_host) return fail(PSH_EINVAL, "semilag: NULL velocity/steps");
   if (precip_dev && !out_dev) return fail(PSH_EINVAL, "semilag: precip given but out is NULL");
   if (!precip_dev && !disp_dev)
@@ -471,81 +474,6 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
   if (spline_blk) (void)psh_free(spline_blk);  // stream-ordered: the launch above is queued first
   if (packed_blk) (void)psh_free(packed_blk);
   PSH_HIP(le);
-  return PSH_OK;
-}
-
-int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
-                     const double *steps, int T, int n_iter, int interp_order, float outval,
-                     const double *disp_prev, double *disp_out, float *out) {
-  PSH_REQUIRE_INIT();
-  if (int rc = check_semilag(m, n, T, n_iter, interp_order)) return rc;
-  if (!velocity || !steps) return fail(PSH_EINVAL, "semilag: NULL velocity/steps");
-  if (precip && !out) return fail(PSH_EINVAL, "semilag: precip given but out is NULL");
-  if (!precip && !disp_out)
-    return fail(PSH_EINVAL, "semilag: precip is NULL but no displacement output was given");
-  psh::Context &c = ctx();
-  std::lock_guard<std::recursive_mutex> lock(c.mu);
-  PSH_HIP(hipSetDevice(c.device));
-  const size_t plane = static_cast<size_t>(m) * n;
-  float *d_p = nullptr, *d_v = nullptr, *d_out = nullptr;
-  double *d_disp = nullptr;
-  int rc = PSH_OK;
-  // blocks come from the stream-ordered cache: a nowcast loop that calls this entry point
-  // once per member and time step does not pay hipMalloc/hipFree each time
-  auto cleanup = [&]() {
-    (void)hipStreamSynchronize(c.stream);
-    if (d_p) (void)psh_free(d_p);
-    if (d_v) (void)psh_free(d_v);
-    if (d_out) (void)psh_free(d_out);
-    if (d_disp) (void)psh_free(d_disp);
-  };
-#define PSH_TRY(expr)                                                        \
-  do {                                                                       \
-    hipError_t _e = (expr);                                                  \
-    if (_e != hipSuccess) {                                                  \
-      cleanup();                                                             \
-      return fail(_e == hipErrorOutOfMemory ? PSH_ENOMEM : PSH_EHIP,         \
-                  "%s failed: %s", #expr, hipGetErrorString(_e));            \
-    }                                                                        \
-  } while (0)
-#define PSH_ALLOC(ptr, bytes)                                             \
-  do {                                                                    \
-    void *_p = nullptr;                                                   \
-    if (int _rc = psh_malloc(&_p, (bytes))) {                             \
-      cleanup();                                                          \
-      return _rc;                                                         \
-    }                                                                     \
-    ptr = static_cast<decltype(ptr)>(_p);                                 \
-  } while (0)
-  PSH_ALLOC(d_v, 2 * plane * sizeof(float));
-  PSH_TRY(hipMemcpyAsync(d_v, velocity, 2 * plane * sizeof(float), hipMemcpyHostToDevice, c.stream));
-  if (precip) {
-    PSH_ALLOC(d_p, plane * sizeof(float));
-    PSH_TRY(hipMemcpyAsync(d_p, precip, plane * sizeof(float), hipMemcpyHostToDevice, c.stream));
-    PSH_ALLOC(d_out, static_cast<size_t>(T) * plane * sizeof(float));
-  }
-  if (disp_prev || disp_out) {
-    PSH_ALLOC(d_disp, 2 * plane * sizeof(double));
-    if (disp_prev)
-      PSH_TRY(hipMemcpyAsync(d_disp, disp_prev, 2 * plane * sizeof(double), hipMemcpyHostToDevice,
-                             c.stream));
-  }
-  rc = psh_semilag_dev(d_p, d_v, m, n, steps, T, n_iter, interp_order, outval, d_disp,
-                       disp_prev != nullptr, d_out);
-  if (rc != PSH_OK) {
-    cleanup();
-    return rc;
-  }
-  if (precip)
-    PSH_TRY(hipMemcpyAsync(out, d_out, static_cast<size_t>(T) * plane * sizeof(float),
-                           hipMemcpyDeviceToHost, c.stream));
-  if (disp_out)
-    PSH_TRY(hipMemcpyAsync(disp_out, d_disp, 2 * plane * sizeof(double), hipMemcpyDeviceToHost,
-                           c.stream));
-  PSH_TRY(hipStreamSynchronize(c.stream));
-#undef PSH_TRY
-#undef PSH_ALLOC
-  cleanup();
   return PSH_OK;
 }
 

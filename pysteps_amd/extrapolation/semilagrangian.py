@@ -26,7 +26,7 @@ import warnings
 
 import numpy as np
 
-from .. import _lib
+from .. import _lib, _pinned
 from ..device import DeviceArray
 
 __all__ = ["extrapolate"]
@@ -191,8 +191,10 @@ def extrapolate(
             dprev = np.ascontiguousarray(displacement_prev, dtype=np.float64)
             if dprev.shape != (2, m, n):
                 raise ValueError("displacement_prev must have shape (2, m, n)")
-        out = None if precip is None else np.empty((T, m, n), dtype=np.float32)
-        disp = np.empty((2, m, n), dtype=np.float64) if return_displacement else None
+        # results on pinned blocks of the library's pool: the device-to-host copies land in the
+        # arrays the caller receives (csrc/hostpath.hip)
+        out = None if precip is None else _pinned.empty((T, m, n), np.float32)
+        disp = _pinned.empty((2, m, n), np.float64) if return_displacement else None
         rc = lib.psh_semilag_host(
             None if p32 is None else p32.ctypes.data, v32.ctypes.data, m, n,
             steps.ctypes.data, T, n_iter, int(interp_order),

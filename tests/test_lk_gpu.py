@@ -91,13 +91,10 @@ def test_corners_match_oracle(lkmod, shape, nan):
     clean = olk.morph_opening(img, valid, img[valid].min())
     want = olk.shitomasi_detection(clean, valid)
     got = lkmod.detect_corners(_prep(lkmod, img))
-    assert got.dtype == np.float32 and got.shape[1] == 2
-    assert got.shape[0] > 0 and abs(got.shape[0] - want.shape[0]) <= max(2, 0.02 * want.shape[0])
-    a = {tuple(p) for p in got.astype(int)}
-    b = {tuple(p) for p in want.astype(int)}
-    assert len(a & b) >= 0.98 * len(b)
-    k = min(20, len(want), len(got))
-    assert np.array_equal(got[:k], want[:k])  # strongest corners in the same order
+    assert got.dtype == np.float32 and got.shape[1] == 2 and got.shape[0] > 0
+    # corner selection is index work (response ordering + greedy min-distance pass): the same
+    # corners in the same order, no slack
+    assert np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("shape,shift", [((192, 192), (2, -1)), ((300, 260), (-3, 2)), ((130, 520), (1, 1))])
@@ -198,6 +195,66 @@ def test_dense_lk_matches_oracle(dense_lk, m, n, count, nan):
     # and the motion it was made with is recovered (away from the inflow border)
     inner = (slice(None), slice(m // 4, 3 * m // 4), slice(n // 4, 3 * n // 4))
     assert np.sqrt(np.mean((got - vel)[inner] ** 2)) < 0.5
+
+
+@pytest.mark.parametrize("size,count,nr_levels", [(1024, 2, 3), (1024, 2, 2), (2048, 3, 3), (2048, 3, 2)])
+def test_lk_parity_at_baseline_sizes(lkmod, dense_lk, size, count, nr_levels):
+    """LK against the restatement where the 1000-corner cap, the 4-level pyramid and the
+    min-distance grid bind (>= 1024^2; BASELINE config 2 = 2048^2, 3 frames): the reference default
+    ``nr_levels=3`` (maxLevel 3 = 4 pyramid levels) and config 2's "3-level" pyramid
+    (``nr_levels=2``, SURVEY 8d "run both").  Integer stages bit-exact (opening, uint8 renderings,
+    corner list incl. order, tracking status), vectors <= 1e-2 px, dense field <= 1e-3 rel-L2 on a
+    pixel lattice (the float64 k-d tree IDW of the oracle on 4M pixels takes half a minute)."""
+    from oracle import lk_opencv as olk
+    from oracle import sparse as osp
+
+    m = n = size
+    frames, vel = _advected_frames(m, n, count, seed=size + nr_levels)
+    lk_kwargs = {"nr_levels": nr_levels}
+    # --- stage by stage on the first pair ------------------------------------------------
+    valid = np.ones((m, n), bool)
+    prev, nxt = frames[0], frames[1]
+    cprev = olk.morph_opening(prev, valid, prev.min())
+    cnxt = olk.morph_opening(nxt, valid, nxt.min())
+    pa, pb = _prep(lkmod, prev), _prep(lkmod, nxt)
+    assert np.array_equal(pa.clean.to_host(), cprev) and np.array_equal(pb.clean.to_host(), cnxt)
+    a8 = olk.to_uint8(cprev, valid, cprev.min(), cprev.max(), cprev.min())
+    b8 = olk.to_uint8(cnxt, valid, cnxt.min(), cnxt.max(), cnxt.min())
+    assert np.array_equal(pa.track_u8.to_host(), a8) and np.array_equal(pb.track_u8.to_host(), b8)
+    want_pts = olk.shitomasi_detection(cprev, valid)
+    got_pts = lkmod.detect_corners(pa)
+    assert len(want_pts) == 1000  # the cap binds at these sizes
+    assert np.array_equal(got_pts, want_pts)
+    want_p1, wst = olk.calc_optical_flow_pyr_lk(a8, b8, want_pts, max_level=nr_levels)
+    got_p1, gst = lkmod.track_points(pa, pb, got_pts, nr_levels=nr_levels)
+    assert np.array_equal(gst, wst)
+    assert np.abs(got_p1[wst] - want_p1[wst]).max() < 1e-2
+    # --- end to end: pooled, outlier-filtered vectors and the dense field -----------------
+    wxy, wuv = olk.dense_lucaskanade(frames, dense=False, nr_levels=nr_levels)
+    gxy, guv = dense_lk(frames, dense=False, lk_kwargs=lk_kwargs)
+    assert np.array_equal(gxy, wxy)  # same features survive, same order
+    assert np.abs(guv - wuv).max() < 1e-2
+    got = dense_lk(frames, lk_kwargs=lk_kwargs)
+    dxy, duv = osp.decluster(wxy, wuv, 20, 1)
+    step = 5 if size <= 1024 else 9
+    ys, xs = np.arange(2, m, step), np.arange(3, n, step)
+    want = _idw_lattice(dxy, duv, xs, ys)
+    sub = got[:, ys[:, None], xs[None, :]]
+    assert rel_l2(sub, want) < 1e-3
+    inner = (slice(None), slice(m // 4, 3 * m // 4), slice(n // 4, 3 * n // 4))
+    assert np.sqrt(np.mean((got - vel)[inner] ** 2)) < 0.3
+
+
+def _idw_lattice(xy, values, xs, ys, k=20, power=0.5, dist_offset=0.5):
+    """interpolate.py:80-109 on the lattice xs x ys (float64 k-d tree, as oracle.sparse.idw)."""
+    from scipy.spatial import cKDTree
+
+    gx, gy = np.meshgrid(xs, ys)
+    dist, inds = cKDTree(xy).query(np.column_stack([gx.ravel(), gy.ravel()]), k=min(k, len(xy)))
+    w = 1.0 / np.power(dist + dist_offset, power)
+    w /= w.sum(axis=1, keepdims=True)
+    out = np.sum(values[inds, :] * w[..., None], axis=1)
+    return np.moveaxis(out.reshape(len(ys), len(xs), 2), -1, 0)
 
 
 def test_uniform_shift_recovered(dense_lk):

@@ -429,3 +429,48 @@ def test_config5_8192_tiled_and_last_plane(extrapolate):
         o1, d = extrapolate(dp, dv, [1.0], outval=-15.0, return_displacement=True, displacement_prev=d)
     assert rel_l2(o1.view(0).to_host(), want_last) < REL_L2_TOL
     assert np.max(np.abs(d.to_host() - wdisp)) < DISP_TOL
+
+
+def test_host_path_pinned_and_staged_transfers_agree(extrapolate):
+    """psh_semilag_host (csrc/hostpath.hip): results written straight into pinned result arrays
+    (what the shim hands out) == results staged chunk by chunk into ordinary memory == the
+    device-resident path; inputs from ordinary and from pinned memory; > 1 staging chunk (32 MiB)
+    in either direction, displacement in and out."""
+    from pysteps_amd import _lib, _pinned
+    from pysteps_amd.device import DeviceArray
+    from tools import synth
+
+    m, n, T = 1100, 1024, 9  # 4.3 MiB planes: 39 MiB of output, 17 MiB displacement
+    p = synth.rain_field_db(m, n, seed=31)
+    v = synth.true_velocity(m, n)
+    steps = np.ones(T)
+    dev_out, dev_disp = extrapolate(DeviceArray.from_host(p), DeviceArray.from_host(v), T, outval=-15.0,
+                                    return_displacement=True)
+    dev_out, dev_disp = dev_out.to_host(), dev_disp.to_host()
+    got, gdisp = extrapolate(p, v, T, outval=-15.0, return_displacement=True)  # pinned result arrays
+    assert isinstance(got, np.ndarray) and got.flags.writeable and got.dtype == np.float32
+    assert np.array_equal(got, dev_out) and np.array_equal(gdisp, dev_disp)
+    lib = _lib.lib()
+    for pinned_in in (False, True):
+        pp, vv = (p, v)
+        if pinned_in:
+            pp, vv = _pinned.empty(p.shape, np.float32), _pinned.empty(v.shape, np.float32)
+            pp[...] = p
+            vv[...] = v
+        out = np.empty((T, m, n), np.float32)  # ordinary memory: staged download
+        disp = np.empty((2, m, n), np.float64)
+        _lib.check(lib.psh_semilag_host(pp.ctypes.data, vv.ctypes.data, m, n, steps.ctypes.data, T, 1, 1, -15.0,
+                                        None, disp.ctypes.data, out.ctypes.data), "psh_semilag_host")
+        assert np.array_equal(out, dev_out) and np.array_equal(disp, dev_disp)
+    # resumed call, displacement uploaded from ordinary memory (staged upload of 17 MiB)
+    more = np.empty((2, m, n), np.float32)
+    d2 = np.empty((2, m, n), np.float64)
+    two = np.ones(2)
+    _lib.check(lib.psh_semilag_host(p.ctypes.data, v.ctypes.data, m, n, two.ctypes.data, 2, 1, 1, -15.0,
+                                    dev_disp.ctypes.data, d2.ctypes.data, more.ctypes.data), "psh_semilag_host")
+    want, wd = extrapolate(p, v, 2, outval=-15.0, return_displacement=True, displacement_prev=dev_disp)
+    assert np.array_equal(more, want) and np.array_equal(d2, wd)
+    # the result arrays are the caller's: dropping them returns the blocks, new calls reuse them
+    del got, gdisp, want, wd
+    again = extrapolate(p, v, T, outval=-15.0)
+    assert np.array_equal(again, dev_out)
