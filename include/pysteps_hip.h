@@ -37,6 +37,7 @@ extern "C" {
 #define PSH_ENOMEM (-4)
 #define PSH_ECOMM (-5)    /* RCCL error / librccl.so not loadable */
 #define PSH_EUNSUPPORTED (-6)
+#define PSH_EINPUT (-7)   /* input values the reference rejects (non-finite fields); see psh_semilag_host */
 
 /* ---- runtime ----------------------------------------------------------- */
 int psh_init(int device_id);          /* idempotent; binds the calling process to one GPU */
@@ -128,10 +129,27 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
  * Transfer bound (4096^2 x 24: 1.4 ms of kernel, ~30 ms of PCIe): buffers allocated with
  * psh_host_alloc are copied directly at pinned-memory speed; any other host pointer is staged
  * through a ring of pinned chunks filled / drained by several host threads while the DMA engine
- * moves the previous chunk.  Thread-safe; the library mutex is released while the call waits. */
-int psh_semilag_host(const float *precip, const float *velocity, int m, int n,
+ * moves the previous chunk.  Thread-safe; the library mutex is released while the call waits.
+ *
+ * flags: PSH_SL_ALLOW_NONFINITE = allow_nonfinite_values (semilagrangian.py:106-137);
+ *   PSH_SL_OUTVAL_MIN = outval "min": nanmin of precip (:171-172), the outval argument is ignored;
+ *   PSH_SL_PRECIP_F64 / PSH_SL_VELOCITY_F64: the array holds float64 (narrowed on the device);
+ *   PSH_SL_OUT_F64: out receives float64 (SciPy returns the dtype of its input).
+ * The reference's input checks run as device reductions after the upload: *input_status (may be
+ * NULL) receives PSH_SL_ST_* bits; if a condition the flags do not allow holds, nothing is computed
+ * and PSH_EINPUT is returned (the shim raises the reference's ValueError). */
+#define PSH_SL_ALLOW_NONFINITE 1
+#define PSH_SL_OUTVAL_MIN 2
+#define PSH_SL_PRECIP_F64 4
+#define PSH_SL_VELOCITY_F64 8
+#define PSH_SL_OUT_F64 16
+#define PSH_SL_ST_PRECIP_NONFINITE 1
+#define PSH_SL_ST_PRECIP_ALL_NONFINITE 2
+#define PSH_SL_ST_VELOCITY_NONFINITE 4
+#define PSH_SL_ST_VELOCITY_ALL_NONFINITE 8
+int psh_semilag_host(const void *precip, const void *velocity, int m, int n,
                      const double *steps, int T, int n_iter, int interp_order, float outval,
-                     const double *disp_prev, double *disp_out, float *out);
+                     const double *disp_prev, double *disp_out, void *out, int flags, int *input_status);
 
 /* Pinned host blocks from a cached pool (limit: env PYSTEPS_HIP_PINNED_BYTES, default 16 GiB;
  * PSH_ENOMEM beyond it - callers then fall back to ordinary memory).  The Python shims build their

@@ -55,6 +55,12 @@ static inline double clampd(double v, double lo, double hi) {
 static inline void motion_at(const float *vel, long m, long n, long x, long y,
                              double dx, double dy, double scale, double sub,
                              double *ix, double *iy) {
+  /* a non-finite coordinate (the trajectory met a non-finite velocity): SciPy interpolates
+   * across it to NaN in mode "nearest" (sl_velnan* goldens of the reference) */
+  if (!isfinite(dx) || !isfinite(dy)) {
+    *ix = *iy = NAN;
+    return;
+  }
   const tap_t r = taps(clampd((double)y + dy, 0.0, (double)(m - 1)), m);
   const tap_t c = taps(clampd((double)x + dx, 0.0, (double)(n - 1)), n);
   const float u = (float)bilinear(vel, n, r, c);
@@ -107,7 +113,9 @@ int oracle_semilag_f32(const float *precip, const float *vel, int m_, int n_,
         if (precip) {
           const double cy = (double)y + dy, cx = (double)x + dx;
           double val;
-          if (cy < 0.0 || cy > (double)(m - 1) || cx < 0.0 || cx > (double)(n - 1)) {
+          /* non-finite coordinates count as outside (cval), like SciPy's mode "constant" */
+          if (!isfinite(cy) || !isfinite(cx) || cy < 0.0 || cy > (double)(m - 1) || cx < 0.0 ||
+              cx > (double)(n - 1)) {
             val = outval;
           } else if (order == 0) {
             long r = (long)floor(cy + 0.5), c = (long)floor(cx + 0.5);

@@ -20,6 +20,7 @@ PSH_ENOTINIT = -3
 PSH_ENOMEM = -4
 PSH_ECOMM = -5
 PSH_EUNSUPPORTED = -6
+PSH_EINPUT = -7
 
 
 class LkParams(ctypes.Structure):
@@ -91,7 +92,7 @@ SIGNATURES = {
     "psh_dense_lk_dev": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(LkParams), c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_semilag_rows_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),
 }
 
 _lock = threading.RLock()
@@ -136,7 +137,7 @@ def check(rc, what=""):
     if rc == PSH_OK:
         return
     msg = "%s%s" % (what + ": " if what else "", last_error())
-    if rc == PSH_EINVAL:
+    if rc in (PSH_EINVAL, PSH_EINPUT):
         raise ValueError(msg)
     if rc == PSH_EUNSUPPORTED:
         raise NotImplementedError(msg)

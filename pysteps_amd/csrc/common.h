@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstddef>
 #include <cstdint>
@@ -52,6 +53,21 @@ int const_slot(float **host, const float **dev);
   } while (0)
 
 int check_semilag(int m, int n, int T, int n_iter, int order_and_mode);
+
+// ---- element-wise helpers (elementwise.hip) ---------------------------------
+struct FieldStats {
+  double min_finite = INFINITY, max_finite = -INFINITY;  // over finite values
+  double nonfinite = 0, neg_inf = 0, pos_inf = 0, count = 0;
+  // np.nanmin: NaNs ignored, infinities are values
+  double nanmin() const {
+    if (neg_inf > 0) return -INFINITY;
+    if (nonfinite < count) return min_finite;
+    return pos_inf > 0 ? INFINITY : NAN;
+  }
+};
+int field_stats_full(const float *in_dev, size_t n, FieldStats *st);  // waits for the library stream; lock held
+hipError_t launch_convert_f64_f32(const double *in, float *out, size_t n, hipStream_t stream);
+hipError_t launch_convert_f32_f64(const float *in, double *out, size_t n, hipStream_t stream);
 
 // ---- host-buffer path (hostpath.hip): pinned block pool, staged transfers ---
 // pinned host blocks, cached like the device blocks; PSH_ENOMEM beyond PYSTEPS_HIP_PINNED_BYTES

@@ -5,6 +5,9 @@
 //   reference gets from NumPy scans: nowcasts/extrapolation.py:76 (allow_nonfinite_values),
 //   semilagrangian.py:171-172 (outval="min").
 // HBM-streaming, dwordx4 where the size allows; NaN stays NaN like in NumPy.
+#include <algorithm>
+#include <cmath>
+
 #include "common.h"
 
 namespace psh {
@@ -39,9 +42,13 @@ __global__ __launch_bounds__(256) void db_transform(const float *__restrict__ in
     out[i] = INVERSE ? from_db(in[i], thr, zerovalue) : to_db(in[i], thr, zerovalue);
 }
 
+constexpr int kStatFields = 5;
+
 __global__ __launch_bounds__(256) void field_stats(const float *__restrict__ in, size_t n,
                                                    float *__restrict__ partial) {
-  float mn = INFINITY, mx = -INFINITY, bad = 0.f;
+  // per block: min / max over finite values, counts of non-finite values, of -inf and of +inf
+  // (counts < 2^24 per block: exact in float)
+  float mn = INFINITY, mx = -INFINITY, bad = 0.f, ninf = 0.f, pinf = 0.f;
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float v = in[i];
@@ -50,25 +57,48 @@ __global__ __launch_bounds__(256) void field_stats(const float *__restrict__ in,
       mx = fmaxf(mx, v);
     } else {
       bad += 1.f;
+      ninf += v == -INFINITY ? 1.f : 0.f;
+      pinf += v == INFINITY ? 1.f : 0.f;
     }
   }
-  __shared__ float s[3][4];
+  __shared__ float s[kStatFields][4];
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     mn = fminf(mn, __shfl_xor(mn, d));
     mx = fmaxf(mx, __shfl_xor(mx, d));
     bad += __shfl_xor(bad, d);
+    ninf += __shfl_xor(ninf, d);
+    pinf += __shfl_xor(pinf, d);
   }
   if ((threadIdx.x & 63) == 0) {
     s[0][threadIdx.x >> 6] = mn;
     s[1][threadIdx.x >> 6] = mx;
     s[2][threadIdx.x >> 6] = bad;
+    s[3][threadIdx.x >> 6] = ninf;
+    s[4][threadIdx.x >> 6] = pinf;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    partial[3 * blockIdx.x] = fminf(fminf(s[0][0], s[0][1]), fminf(s[0][2], s[0][3]));
-    partial[3 * blockIdx.x + 1] = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
-    partial[3 * blockIdx.x + 2] = s[2][0] + s[2][1] + s[2][2] + s[2][3];
+    float *o = partial + kStatFields * blockIdx.x;
+    o[0] = fminf(fminf(s[0][0], s[0][1]), fminf(s[0][2], s[0][3]));
+    o[1] = fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3]));
+    for (int k = 2; k < kStatFields; ++k) o[k] = s[k][0] + s[k][1] + s[k][2] + s[k][3];
+  }
+}
+
+template <typename Tin, typename Tout>
+__global__ __launch_bounds__(256) void convert_elements(const Tin *__restrict__ in, Tout *__restrict__ out, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
+  for (size_t i = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      Tin v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = in[i + j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[i + j] = static_cast<Tout>(v[j]);
+    } else {
+      for (size_t k = i; k < n; ++k) out[k] = static_cast<Tout>(in[k]);
+    }
   }
 }
 
@@ -99,20 +129,29 @@ extern "C" int psh_db_transform_dev(const float *in_dev, float *out_dev, size_t 
   return PSH_OK;
 }
 
-extern "C" int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *max_out,
-                                   double *nonfinite_out) {
-  PSH_REQUIRE_INIT();
-  if (!in_dev && n) return psh::fail(PSH_EINVAL, "field_stats: NULL pointer");
-  psh::Context &c = psh::ctx();
-  std::lock_guard<std::recursive_mutex> lock(c.mu);
-  PSH_HIP(hipSetDevice(c.device));
+namespace psh {
+
+hipError_t launch_convert_f64_f32(const double *in, float *out, size_t n, hipStream_t stream) {
+  const unsigned grid = static_cast<unsigned>(std::min<size_t>((n / 4 + 255) / 256 + 1, 65535));
+  hipLaunchKernelGGL((convert_elements<double, float>), dim3(grid), dim3(256), 0, stream, in, out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_convert_f32_f64(const float *in, double *out, size_t n, hipStream_t stream) {
+  const unsigned grid = static_cast<unsigned>(std::min<size_t>((n / 4 + 255) / 256 + 1, 65535));
+  hipLaunchKernelGGL((convert_elements<float, double>), dim3(grid), dim3(256), 0, stream, in, out, n);
+  return hipGetLastError();
+}
+
+// synchronous: waits for the library stream
+int field_stats_full(const float *in_dev, size_t n, FieldStats *st) {
+  Context &c = ctx();
   constexpr int kBlocks = 1024;
   void *blk = nullptr;
-  if (int rc = psh_malloc(&blk, 3 * kBlocks * sizeof(float))) return rc;
-  float h[3 * kBlocks];
+  if (int rc = psh_malloc(&blk, kStatFields * kBlocks * sizeof(float))) return rc;
+  static thread_local float h[kStatFields * kBlocks];
   auto run = [&]() -> int {
-    hipLaunchKernelGGL(psh::field_stats, dim3(kBlocks), dim3(256), 0, c.stream, in_dev, n,
-                       static_cast<float *>(blk));
+    hipLaunchKernelGGL(field_stats, dim3(kBlocks), dim3(256), 0, c.stream, in_dev, n, static_cast<float *>(blk));
     PSH_HIP(hipGetLastError());
     PSH_HIP(hipMemcpyAsync(h, blk, sizeof(h), hipMemcpyDeviceToHost, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));
@@ -121,14 +160,33 @@ extern "C" int psh_field_stats_dev(const float *in_dev, size_t n, double *min_ou
   const int rc = run();
   (void)psh_free(blk);
   if (rc) return rc;
-  double mn = INFINITY, mx = -INFINITY, bad = 0.0;
+  FieldStats r;
   for (int b = 0; b < kBlocks; ++b) {
-    mn = fmin(mn, h[3 * b]);
-    mx = fmax(mx, h[3 * b + 1]);
-    bad += h[3 * b + 2];
+    const float *o = h + kStatFields * b;
+    r.min_finite = fmin(r.min_finite, o[0]);
+    r.max_finite = fmax(r.max_finite, o[1]);
+    r.nonfinite += o[2];
+    r.neg_inf += o[3];
+    r.pos_inf += o[4];
   }
-  if (min_out) *min_out = mn;   // +inf if there is no finite value
-  if (max_out) *max_out = mx;   // -inf if there is no finite value
-  if (nonfinite_out) *nonfinite_out = bad;
+  r.count = static_cast<double>(n);
+  *st = r;
+  return PSH_OK;
+}
+
+}  // namespace psh
+
+extern "C" int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *max_out,
+                                   double *nonfinite_out) {
+  PSH_REQUIRE_INIT();
+  if (!in_dev && n) return psh::fail(PSH_EINVAL, "field_stats: NULL pointer");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  psh::FieldStats st;
+  if (int rc = psh::field_stats_full(in_dev, n, &st)) return rc;
+  if (min_out) *min_out = st.min_finite;   // +inf if there is no finite value
+  if (max_out) *max_out = st.max_finite;   // -inf if there is no finite value
+  if (nonfinite_out) *nonfinite_out = st.nonfinite;
   return PSH_OK;
 }

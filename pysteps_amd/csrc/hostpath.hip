@@ -249,14 +249,17 @@ int psh_host_free(void *host_ptr) {
   return psh::pinned_free(host_ptr);
 }
 
-int psh_semilag_host(const float *precip, const float *velocity, int m, int n, const double *steps, int T,
+int psh_semilag_host(const void *precip, const void *velocity, int m, int n, const double *steps, int T,
                      int n_iter, int interp_order, float outval, const double *disp_prev, double *disp_out,
-                     float *out) {
+                     void *out, int flags, int *input_status) {
   PSH_REQUIRE_INIT();
+  if (input_status) *input_status = 0;
   if (int rc = psh::check_semilag(m, n, T, n_iter, interp_order)) return rc;
   if (!velocity || !steps) return fail(PSH_EINVAL, "semilag: NULL velocity/steps");
   if (precip && !out) return fail(PSH_EINVAL, "semilag: precip given but out is NULL");
   if (!precip && !disp_out) return fail(PSH_EINVAL, "semilag: precip is NULL but no displacement output was given");
+  const bool p64 = (flags & PSH_SL_PRECIP_F64) != 0, v64 = (flags & PSH_SL_VELOCITY_F64) != 0;
+  const bool o64 = (flags & PSH_SL_OUT_F64) != 0;
   psh::Context &c = ctx();
   psh::Lock lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
@@ -264,6 +267,7 @@ int psh_semilag_host(const float *precip, const float *velocity, int m, int n, c
   const size_t plane = static_cast<size_t>(m) * n;
   float *d_p = nullptr, *d_v = nullptr, *d_out = nullptr;
   double *d_disp = nullptr;
+  void *d_raw = nullptr, *d_out64 = nullptr;  // float64 inputs as uploaded / float64 results before the download
   psh::Ring ring;
   hipEvent_t done = nullptr;
   // device blocks come from the stream-ordered cache: a nowcast loop that calls this entry point
@@ -278,10 +282,9 @@ int psh_semilag_host(const float *precip, const float *velocity, int m, int n, c
     }
     if (done) (void)hipEventDestroy(done);
     ring.destroy();
-    if (d_p) (void)psh_free(d_p);
-    if (d_v) (void)psh_free(d_v);
-    if (d_out) (void)psh_free(d_out);
-    if (d_disp) (void)psh_free(d_disp);
+    for (void *q : {static_cast<void *>(d_p), static_cast<void *>(d_v), static_cast<void *>(d_out),
+                    static_cast<void *>(d_disp), d_raw, d_out64})
+      if (q) (void)psh_free(q);
   };
 #define PSH_TRY_RC(expr)       \
   do {                         \
@@ -304,17 +307,57 @@ int psh_semilag_host(const float *precip, const float *velocity, int m, int n, c
   if (precip) {
     PSH_TRY_RC(psh_malloc(reinterpret_cast<void **>(&d_p), plane * sizeof(float)));
     PSH_TRY_RC(psh_malloc(reinterpret_cast<void **>(&d_out), static_cast<size_t>(T) * plane * sizeof(float)));
+    if (o64) PSH_TRY_RC(psh_malloc(&d_out64, static_cast<size_t>(T) * plane * sizeof(double)));
   }
   if (disp_prev || disp_out) PSH_TRY_RC(psh_malloc(reinterpret_cast<void **>(&d_disp), 2 * plane * sizeof(double)));
-  PSH_TRY_RC(psh::upload(d_v, velocity, 2 * plane * sizeof(float), c.stream, ring, lock));
-  if (precip) PSH_TRY_RC(psh::upload(d_p, precip, plane * sizeof(float), c.stream, ring, lock));
+  // float64 arrays (what pysteps' importers produce) cross the bus as they are and are narrowed on
+  // the device: a host-side astype(float32) of three 4096^2 planes costs more than the whole call
+  if (p64 || v64) PSH_TRY_RC(psh_malloc(&d_raw, 2 * plane * sizeof(double)));
+  if (v64) {
+    PSH_TRY_RC(psh::upload(d_raw, velocity, 2 * plane * sizeof(double), c.stream, ring, lock));
+    PSH_TRY_HIP(psh::launch_convert_f64_f32(static_cast<const double *>(d_raw), d_v, 2 * plane, c.stream));
+  } else {
+    PSH_TRY_RC(psh::upload(d_v, velocity, 2 * plane * sizeof(float), c.stream, ring, lock));
+  }
+  if (precip && p64) {
+    PSH_TRY_RC(psh::upload(d_raw, precip, plane * sizeof(double), c.stream, ring, lock));
+    PSH_TRY_HIP(psh::launch_convert_f64_f32(static_cast<const double *>(d_raw), d_p, plane, c.stream));
+  } else if (precip) {
+    PSH_TRY_RC(psh::upload(d_p, precip, plane * sizeof(float), c.stream, ring, lock));
+  }
   if (disp_prev) PSH_TRY_RC(psh::upload(d_disp, disp_prev, 2 * plane * sizeof(double), c.stream, ring, lock));
+  // the input checks of semilagrangian.py:106-137 as device reductions (a NumPy isfinite scan of
+  // the three planes costs ~10 ms at 4096^2, these two reductions ~40 us + one stream sync)
+  {
+    psh::FieldStats sv, sp;
+    PSH_TRY_RC(psh::field_stats_full(d_v, 2 * plane, &sv));
+    int status = 0;
+    if (sv.nonfinite > 0) status |= PSH_SL_ST_VELOCITY_NONFINITE;
+    if (sv.nonfinite >= sv.count) status |= PSH_SL_ST_VELOCITY_ALL_NONFINITE;
+    if (precip) {
+      PSH_TRY_RC(psh::field_stats_full(d_p, plane, &sp));
+      if (sp.nonfinite > 0) status |= PSH_SL_ST_PRECIP_NONFINITE;
+      if (sp.nonfinite >= sp.count) status |= PSH_SL_ST_PRECIP_ALL_NONFINITE;
+      if (flags & PSH_SL_OUTVAL_MIN) outval = static_cast<float>(sp.nanmin());  // :171-172
+    }
+    if (input_status) *input_status = status;
+    const int fatal = PSH_SL_ST_VELOCITY_ALL_NONFINITE | PSH_SL_ST_PRECIP_ALL_NONFINITE |
+                      ((flags & PSH_SL_ALLOW_NONFINITE) ? 0 : (PSH_SL_ST_VELOCITY_NONFINITE | PSH_SL_ST_PRECIP_NONFINITE));
+    if (status & fatal) {
+      cleanup(true);
+      return fail(PSH_EINPUT, "semilag: non-finite input values (status 0x%x)", status);
+    }
+  }
   PSH_TRY_RC(psh_semilag_dev(d_p, d_v, m, n, steps, T, n_iter, interp_order, outval, d_disp, disp_prev != nullptr,
                              d_out));
+  const size_t out_elems = static_cast<size_t>(T) * plane;
+  if (precip && o64)
+    PSH_TRY_HIP(psh::launch_convert_f32_f64(d_out, static_cast<double *>(d_out64), out_elems, c.stream));
   PSH_TRY_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
   PSH_TRY_HIP(hipEventRecord(done, c.stream));
   PSH_TRY_HIP(hipStreamWaitEvent(psh::g_down_stream, done, 0));
-  if (precip) PSH_TRY_RC(psh::download(out, d_out, static_cast<size_t>(T) * plane * sizeof(float), ring, lock));
+  if (precip)
+    PSH_TRY_RC(psh::download(out, o64 ? d_out64 : static_cast<void *>(d_out), out_elems * (o64 ? 8 : 4), ring, lock));
   if (disp_out) PSH_TRY_RC(psh::download(disp_out, d_disp, 2 * plane * sizeof(double), ring, lock));
 #undef PSH_TRY_RC
 #undef PSH_TRY_HIP

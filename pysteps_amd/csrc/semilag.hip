@@ -530,11 +530,8 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
     for (int j = 0; j < NPX; ++j) {
       const double dx = disp[static_cast<size_t>(y[j]) * n + x];
       const double dy = disp[plane + static_cast<size_t>(y[j]) * n + x];
-      const double flx = floor(dx), fly = floor(dy);
-      px[j] += static_cast<int>(flx);
-      py[j] += static_cast<int>(fly);
-      fx[j] = fminf(static_cast<float>(dx - flx), kMaxFrac);
-      fy[j] = fminf(static_cast<float>(dy - fly), kMaxFrac);
+      split_displacement(dx, px[j], fx[j]);
+      split_displacement(dy, py[j], fy[j]);
     }
     sample_at<NPX, ORDER, kVel, MODE, GEN>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
     const float s0 = scale[0];
@@ -552,6 +549,11 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
     }
   }
 
+  // what a lost trajectory (NaN coordinate) samples: scipy gives cval except where it interpolates
+  // across the NaN ("nearest", "grid-constant" with order >= 1; order 3 masks it to NaN anyway)
+  const float lostval = (ORDER == 3 || bmode == kModeNearest || (ORDER == 1 && bmode == kModeGridConstant))
+                            ? __builtin_nanf("")
+                            : outval;
   // with n_iter > 0 the increment is only ever used halved (midpoint rule): carry Vi / 2,
   // which is the same number as halving at the point of use (scaling by 2 is exact)
   if (n_iter > 0) {
@@ -639,10 +641,16 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
     }
     if (HAS_PRECIP) {
 #pragma unroll
-      for (int j = 0; j < NPX; ++j)
+      for (int j = 0; j < NPX; ++j) {
+        // Non-finite velocities (allow_nonfinite_values, semilagrangian.py:106-137): a trajectory that
+        // sampled one carries a NaN fraction from then on (v_cvt_flr(NaN) = 0 keeps the integer part in
+        // range, every later sample is NaN).  map_coordinates answers a NaN coordinate with cval in
+        // the "constant" mode (and the folding modes), with NaN where it interpolates across it.
+        sp[j] = lost(fx[j], fy[j]) ? lostval : sp[j];
         // streamed once, never re-read: keep the output out of the L2 ways the input planes live in
         if (live[j])
           __builtin_nontemporal_store(sp[j], reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
+      }
       out += static_cast<size_t>(rows) * n;
     }
   }

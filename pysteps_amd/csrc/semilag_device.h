@@ -31,6 +31,19 @@ __device__ __forceinline__ void retreat(int &P, float &f, float w) {
   f = __builtin_amdgcn_fractf(t);
 }
 
+// float64 displacement of the reference -> split coordinate (P += floor(d), f = d - floor(d)).
+// A non-finite displacement - a trajectory that met a non-finite velocity value
+// (allow_nonfinite_values, semilagrangian.py:106-137) - gives a NaN fraction and leaves P alone:
+// v_cvt_flr(NaN) = 0 keeps the integer part inside the image, every later sample is NaN, and the
+// field sample is replaced by what map_coordinates returns for a NaN coordinate (`lost`).
+__device__ __forceinline__ void split_displacement(double d, int &P, float &f) {
+  const bool ok = fabs(d) < 1e300;  // false for NaN and +-inf
+  const double fl = ok ? floor(d) : 0.0;
+  P += static_cast<int>(fl);
+  f = ok ? fminf(static_cast<float>(d - fl), kMaxFrac) : __builtin_nanf("");
+}
+__device__ __forceinline__ bool lost(float fx, float fy) { return fx != fx || fy != fy; }
+
 // true when every active lane of the wave has all four taps strictly inside the image
 __device__ __forceinline__ bool wave_all_interior(int X, int Y, int m, int n) {
   const unsigned long long bx = __builtin_amdgcn_ballot_w64(static_cast<unsigned>(X) < static_cast<unsigned>(n - 1));

@@ -139,12 +139,8 @@ __global__ __launch_bounds__(256) void semilag_members(
       fx = __uint_as_float(r.z);
       fy = __uint_as_float(r.w);
     } else {
-      const double dx = dplane[pix], dy = dplane[plane + pix];
-      const double flx = floor(dx), fly = floor(dy);
-      px += static_cast<int>(flx);
-      py += static_cast<int>(fly);
-      fx = fminf(static_cast<float>(dx - flx), kMaxFrac);
-      fy = fminf(static_cast<float>(dy - fly), kMaxFrac);
+      split_displacement(dplane[pix], px, fx);
+      split_displacement(dplane[plane + pix], py, fy);
     }
     sample_member<ORDER, PERT, false>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
     vix = su * scale[0];
@@ -188,7 +184,8 @@ __global__ __launch_bounds__(256) void semilag_members(
       }
     }
     if (HAS_PRECIP) {
-      if (live) *optr = sp;
+      // trajectories that met a non-finite velocity sample cval, like map_coordinates at a NaN coordinate
+      if (live) *optr = lost(fx, fy) ? outval : sp;
       optr += plane;
     }
   }
@@ -220,12 +217,12 @@ __global__ __launch_bounds__(256) void members_disp_to_state(const double *__res
   const size_t member = blockIdx.y;
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < plane; i += stride) {
-    const double dx = disp[(2 * member) * plane + i], dy = disp[(2 * member + 1) * plane + i];
-    const double flx = floor(dx), fly = floor(dy);
+    int ox = 0, oy = 0;
+    float fx, fy;
+    split_displacement(disp[(2 * member) * plane + i], ox, fx);
+    split_displacement(disp[(2 * member + 1) * plane + i], oy, fy);
     state[member * plane + i] =
-        make_uint4(static_cast<unsigned>(static_cast<int>(flx)), static_cast<unsigned>(static_cast<int>(fly)),
-                   __float_as_uint(fminf(static_cast<float>(dx - flx), kMaxFrac)),
-                   __float_as_uint(fminf(static_cast<float>(dy - fly), kMaxFrac)));
+        make_uint4(static_cast<unsigned>(ox), static_cast<unsigned>(oy), __float_as_uint(fx), __float_as_uint(fy));
   }
 }
 

@@ -14,15 +14,17 @@ Differences, all documented in DESIGN.md:
   ~1e-6) and the returned displacement is float64 like the reference's;
 * options the kernel does not implement (``interp_order`` other than 0/1/3,
   ``interp_order=3`` together with a ``map_coordinates_mode`` other than
-  ``"constant"``, custom ``xy_coords``, non-finite velocities) are delegated to the reference implementation when pysteps is
+  ``"constant"``, custom ``xy_coords``) are delegated to the reference implementation when pysteps is
   importable and raise ``NotImplementedError`` otherwise;
 * ``precip``/``velocity``/``displacement_prev`` may also be
   :class:`pysteps_amd.device.DeviceArray` objects; then nothing crosses PCIe and
   the results are DeviceArrays too (used by the resident nowcast loop and bench).
 """
 
+import ctypes
 import time
 import warnings
+import weakref
 
 import numpy as np
 
@@ -31,6 +33,10 @@ from ..device import DeviceArray
 
 __all__ = ["extrapolate"]
 
+
+# psh_semilag_host flags / input status bits (include/pysteps_hip.h PSH_SL_*)
+_FLAG_ALLOW_NONFINITE, _FLAG_OUTVAL_MIN, _FLAG_PRECIP_F64, _FLAG_VELOCITY_F64, _FLAG_OUT_F64 = 1, 2, 4, 8, 16
+_ST_PRECIP_NONFINITE, _ST_PRECIP_ALL_NONFINITE, _ST_VELOCITY_NONFINITE, _ST_VELOCITY_ALL_NONFINITE = 1, 2, 4, 8
 
 # scipy.ndimage boundary modes of the field resampling -> PSH_MODE_* (include/pysteps_hip.h)
 _BOUNDARY_MODES = {"constant": 0, "nearest": 1, "reflect": 2, "mirror": 3, "wrap": 4,
@@ -56,19 +62,33 @@ def _unsupported(what, args, kwargs):
     return ref(*args, **kwargs)
 
 
+_verified_grids = []  # [(weakref to the array, data pointer, shape)]: grids already compared in full
+
+
 def _is_default_grid(xy_coords, m, n):
-    """True if xy_coords is the integer meshgrid the reference builds itself (:174-179)."""
+    """True if xy_coords is the integer meshgrid the reference builds itself (:174-179).
+
+    The whole array is compared (every element, not a sample).  The callers that pass
+    ``xy_coords`` (nowcasts/utils.py:361-365, steps.py:661-662) build it once and hand the SAME
+    array to every call, so an array that has been verified is remembered by identity (weak
+    reference + data pointer + shape) and not rescanned - the scan of a (2, 4096, 4096) int64 grid
+    costs more than the advection itself."""
     xy = np.asarray(xy_coords)
     if xy.shape != (2, m, n):
         return False
-    ys = np.unique(np.linspace(0, m - 1, num=min(m, 7)).astype(int))
-    xs = np.unique(np.linspace(0, n - 1, num=min(n, 7)).astype(int))
-    return bool(
-        np.array_equal(xy[0][np.ix_(ys, xs)], np.broadcast_to(xs, (ys.size, xs.size)))
-        and np.array_equal(xy[1][np.ix_(ys, xs)], np.broadcast_to(ys[:, None], (ys.size, xs.size)))
-        and np.array_equal(xy[0, 0, :], np.arange(n))
-        and np.array_equal(xy[1, :, 0], np.arange(m))
-    )
+    key = (xy.__array_interface__["data"][0], xy.shape, xy.dtype.str)
+    for ref, k in _verified_grids:
+        if ref() is xy_coords and k == key:
+            return True
+    ok = bool(np.array_equal(xy[0], np.broadcast_to(np.arange(n), (m, n)))
+              and np.array_equal(xy[1], np.broadcast_to(np.arange(m)[:, None], (m, n))))
+    if ok:
+        try:
+            _verified_grids.append((weakref.ref(xy_coords), key))
+            del _verified_grids[:-8]
+        except TypeError:
+            pass  # not weak-referenceable (a list): verified every time
+    return ok
 
 
 def _step_increments(timesteps, vel_timestep):
@@ -110,24 +130,19 @@ def extrapolate(
         vel_timestep=vel_timestep, **kwargs,
     )
     on_device = isinstance(velocity, DeviceArray)
+    if (precip is not None and isinstance(precip, DeviceArray) != on_device) or (
+            kwargs.get("displacement_prev") is not None
+            and isinstance(kwargs["displacement_prev"], DeviceArray) != on_device):
+        raise ValueError("precip, velocity and displacement_prev must all be NumPy arrays or all be DeviceArrays")
 
     if precip is not None and precip.ndim != 2:
         raise ValueError("precip must be a two-dimensional array")
     if velocity.ndim != 3:
         raise ValueError("velocity must be a three-dimensional array")
 
-    if not on_device:
-        precip_finite = None if precip is None else np.isfinite(precip)
-        velocity_finite = np.isfinite(velocity)
-        if not allow_nonfinite_values:
-            if precip is not None and not precip_finite.all():
-                raise ValueError("precip contains non-finite values")
-            if not velocity_finite.all():
-                raise ValueError("velocity contains non-finite values")
-        if precip is not None and not precip_finite.any():
-            raise ValueError("precip contains only non-finite values")
-        if not velocity_finite.any():
-            raise ValueError("velocity contains only non-finite values")
+    # the non-finite checks of the reference (:106-137) run as device reductions inside
+    # psh_semilag_host, after the upload (a NumPy isfinite scan of three 4096^2 planes costs more
+    # than the whole kernel); same exceptions, raised below
     if isinstance(timesteps, list) and not sorted(timesteps) == timesteps:
         raise ValueError("timesteps is not in ascending order")
 
@@ -163,8 +178,6 @@ def extrapolate(
     interp_order = int(interp_order) | (_BOUNDARY_MODES[map_coordinates_mode] << 8)
     if xy_coords is not None and not _is_default_grid(xy_coords, m, n):
         return _unsupported("a non-default xy_coords grid", call_args, call_kwargs)
-    if not on_device and not velocity_finite.all():
-        return _unsupported("non-finite velocity values", call_args, call_kwargs)
     if n_iter < 0:
         n_iter = 0  # the reference treats any n_iter <= 0 as "no midpoint rule" (:211-219)
 
@@ -179,13 +192,31 @@ def extrapolate(
         result = _run_device(lib, precip, velocity, steps, outval, displacement_prev, n_iter,
                              return_displacement, interp_order)
     else:
-        if precip is not None and isinstance(outval, str):
+        flags = _FLAG_ALLOW_NONFINITE if allow_nonfinite_values else 0
+        if isinstance(outval, str):
             if outval != "min":
                 raise ValueError("outval must be a number or 'min'")
-            outval = np.nanmin(precip)
-        out_dtype = None if precip is None else np.asarray(precip).dtype
-        p32 = None if precip is None else np.ascontiguousarray(precip, dtype=np.float32)
-        v32 = np.ascontiguousarray(velocity, dtype=np.float32)
+            flags |= _FLAG_OUTVAL_MIN  # np.nanmin(precip), as a device reduction (:171-172)
+            outval = float("nan")
+        # float32 and float64 arrays go to the device as they are (float64 is narrowed there);
+        # the advected field comes back in the dtype of precip, like SciPy's output (:225-232)
+        def _as_input(a):
+            a = np.asarray(a)
+            if a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float64 if a.dtype.itemsize > 4 else np.float32)
+            return np.ascontiguousarray(a)
+
+        vin = _as_input(velocity)
+        pin = None if precip is None else _as_input(np.ma.getdata(precip) if np.ma.isMaskedArray(precip) else precip)
+        if vin.dtype == np.float64:
+            flags |= _FLAG_VELOCITY_F64
+        out_dtype = None
+        if pin is not None:
+            out_dtype = np.asarray(precip).dtype
+            if pin.dtype == np.float64:
+                flags |= _FLAG_PRECIP_F64
+            if out_dtype == np.float64:
+                flags |= _FLAG_OUT_F64
         dprev = None
         if displacement_prev is not None:
             dprev = np.ascontiguousarray(displacement_prev, dtype=np.float64)
@@ -193,19 +224,31 @@ def extrapolate(
                 raise ValueError("displacement_prev must have shape (2, m, n)")
         # results on pinned blocks of the library's pool: the device-to-host copies land in the
         # arrays the caller receives (csrc/hostpath.hip)
-        out = None if precip is None else _pinned.empty((T, m, n), np.float32)
+        out = None
+        if pin is not None:
+            out = _pinned.empty((T, m, n), np.float64 if flags & _FLAG_OUT_F64 else np.float32)
         disp = _pinned.empty((2, m, n), np.float64) if return_displacement else None
+        status = ctypes.c_int(0)
         rc = lib.psh_semilag_host(
-            None if p32 is None else p32.ctypes.data, v32.ctypes.data, m, n,
+            None if pin is None else pin.ctypes.data, vin.ctypes.data, m, n,
             steps.ctypes.data, T, n_iter, int(interp_order),
             float(outval) if precip is not None else float("nan"),
             None if dprev is None else dprev.ctypes.data,
             None if disp is None else disp.ctypes.data,
-            None if out is None else out.ctypes.data,
+            None if out is None else out.ctypes.data, flags, ctypes.byref(status),
         )
+        if rc == _lib.PSH_EINPUT:  # the reference's messages, in the reference's order (:106-125)
+            st = status.value
+            if not allow_nonfinite_values and st & _ST_PRECIP_NONFINITE:
+                raise ValueError("precip contains non-finite values")
+            if not allow_nonfinite_values and st & _ST_VELOCITY_NONFINITE:
+                raise ValueError("velocity contains non-finite values")
+            if st & _ST_PRECIP_ALL_NONFINITE:
+                raise ValueError("precip contains only non-finite values")
+            raise ValueError("velocity contains only non-finite values")
         _lib.check(rc, "psh_semilag_host")
-        if out is not None and out_dtype != np.float32 and np.issubdtype(out_dtype, np.floating):
-            out = out.astype(out_dtype)
+        if out is not None and out.dtype != out_dtype and np.issubdtype(out_dtype, np.floating):
+            out = out.astype(out_dtype)  # float16 / longdouble inputs
         if precip is None:
             result = (None, disp)
         elif return_displacement:

@@ -20,6 +20,7 @@ GOLDEN_SL = [
     "sl_order0", "sl_resume", "sl_resume_K0", "sl_f64", "sl_order3", "sl_order3_nan",
     "sl_mode_nearest", "sl_mode_reflect_nan", "sl_mode_mirror", "sl_mode_wrap", "sl_mode_gridwrap",
     "sl_mode_gridconst", "sl_mode_reflect_o0", "sl_mode_gridwrap_o0",
+    "sl_velnan", "sl_velnan_K3_nanfield", "sl_velnan_K0_o0", "sl_velnan_min",
 ]
 BOUNDARY_MODES = ["constant", "nearest", "reflect", "mirror", "wrap", "grid-constant", "grid-wrap"]
 

@@ -460,17 +460,72 @@ def test_host_path_pinned_and_staged_transfers_agree(extrapolate):
         out = np.empty((T, m, n), np.float32)  # ordinary memory: staged download
         disp = np.empty((2, m, n), np.float64)
         _lib.check(lib.psh_semilag_host(pp.ctypes.data, vv.ctypes.data, m, n, steps.ctypes.data, T, 1, 1, -15.0,
-                                        None, disp.ctypes.data, out.ctypes.data), "psh_semilag_host")
+                                        None, disp.ctypes.data, out.ctypes.data, 0, None), "psh_semilag_host")
         assert np.array_equal(out, dev_out) and np.array_equal(disp, dev_disp)
     # resumed call, displacement uploaded from ordinary memory (staged upload of 17 MiB)
     more = np.empty((2, m, n), np.float32)
     d2 = np.empty((2, m, n), np.float64)
     two = np.ones(2)
     _lib.check(lib.psh_semilag_host(p.ctypes.data, v.ctypes.data, m, n, two.ctypes.data, 2, 1, 1, -15.0,
-                                    dev_disp.ctypes.data, d2.ctypes.data, more.ctypes.data), "psh_semilag_host")
+                                    dev_disp.ctypes.data, d2.ctypes.data, more.ctypes.data, 0, None), "psh_semilag_host")
     want, wd = extrapolate(p, v, 2, outval=-15.0, return_displacement=True, displacement_prev=dev_disp)
     assert np.array_equal(more, want) and np.array_equal(d2, wd)
     # the result arrays are the caller's: dropping them returns the blocks, new calls reuse them
     del got, gdisp, want, wd
     again = extrapolate(p, v, T, outval=-15.0)
     assert np.array_equal(again, dev_out)
+
+
+@pytest.mark.parametrize("name", ["sl_velnan", "sl_velnan_K3_nanfield", "sl_velnan_K0_o0", "sl_velnan_min"])
+def test_nonfinite_velocity_matches_reference_golden(extrapolate, semilag_golden, name):
+    """allow_nonfinite_values=True with NaN / +-inf in the motion field (semilagrangian.py:106-137),
+    natively: trajectories that sample a non-finite velocity are lost - the reference's
+    map_coordinates then returns cval for them at every later lead time.  Their displacement is NaN
+    here; the reference has +-inf for the few pixels whose very last sub-step met an infinite value."""
+    c = semilag_golden.case(name)
+    out, disp = extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **c["kw"])
+    assert out.shape == c["out"].shape and out.dtype == c["out"].dtype
+    assert np.array_equal(np.isfinite(disp), np.isfinite(c["disp"]))
+    ok = np.isfinite(disp)
+    assert np.max(np.abs(disp[ok] - c["disp"][ok])) < DISP_TOL
+    assert nan_mismatch(out, c["out"]) == 0
+    if c["kw"].get("interp_order", 1) == 0:
+        assert np.count_nonzero(out != c["out"]) <= 1e-4 * out.size
+    else:
+        assert rel_l2(out, c["out"]) < REL_L2_TOL
+    # and device-resident: same values
+    from pysteps_amd.device import DeviceArray
+
+    kw = dict(c["kw"])
+    dout, ddisp = extrapolate(DeviceArray.from_host(c["precip"], np.float32), DeviceArray.from_host(c["velocity"], np.float32),
+                              c["timesteps"], return_displacement=True, **kw)
+    assert np.array_equal(dout.to_host(), out, equal_nan=True)
+    assert np.array_equal(ddisp.to_host(), disp, equal_nan=True)
+
+
+def test_input_checks_run_on_the_device_with_the_reference_messages(extrapolate):
+    """semilagrangian.py:106-125: same ValueErrors, same precedence, without a host-side scan."""
+    p = np.ones((40, 50), np.float32)
+    v = np.ones((2, 40, 50), np.float32)
+    pn, vn = p.copy(), v.copy()
+    pn[3, 4] = np.nan
+    vn[1, 5, 6] = np.inf
+    with pytest.raises(ValueError, match="precip contains non-finite values"):
+        extrapolate(pn, vn, 1)
+    with pytest.raises(ValueError, match="velocity contains non-finite values"):
+        extrapolate(p, vn, 1)
+    with pytest.raises(ValueError, match="precip contains only non-finite values"):
+        extrapolate(np.full_like(p, np.nan), v, 1, allow_nonfinite_values=True)
+    with pytest.raises(ValueError, match="velocity contains only non-finite values"):
+        extrapolate(p, np.full_like(v, np.nan), 1, allow_nonfinite_values=True)
+    out = extrapolate(pn.astype(np.float64), vn.astype(np.float64), 2, allow_nonfinite_values=True)
+    assert out.dtype == np.float64 and out.shape == (2, 40, 50)  # float64 in -> float64 out, converted on the device
+    # outval="min" = np.nanmin: -inf counts as a value
+    pm = p.copy()
+    pm[0, 0] = -np.inf
+    got = extrapolate(pm, v * 3, 1, "min", allow_nonfinite_values=True)
+    assert got[0, 0, 0] == -np.inf
+    from pysteps_amd.device import DeviceArray
+
+    with pytest.raises(ValueError, match="all be NumPy arrays or all be DeviceArrays"):
+        extrapolate(DeviceArray.from_host(p), v, 1)

@@ -27,7 +27,20 @@ def semilag_cases():
     Pn[synth.border_nan_mask(m, n, 0.15)] = np.nan
     rng = np.random.default_rng(3)
     D0 = rng.normal(0, 3, (2, m, n))
+    # non-finite velocities (allow_nonfinite_values=True, reference :106-137): a NaN block, an
+    # isolated NaN, one +inf and one -inf component
+    Vn = Vs.copy()
+    Vn[:, 20:30, 40:55] = np.nan
+    Vn[0, 50, 10] = np.nan
+    Vn[1, 5, 80] = np.inf
+    Vn[0, 60, 70] = -np.inf
     return {
+        "sl_velnan": dict(precip=P, velocity=Vn, timesteps=4, kw=dict(allow_nonfinite_values=True, outval=-15.0)),
+        "sl_velnan_K3_nanfield": dict(precip=Pn, velocity=Vn, timesteps=[0.5, 1.5, 3.0],
+                                      kw=dict(allow_nonfinite_values=True, n_iter=3)),
+        "sl_velnan_K0_o0": dict(precip=P, velocity=Vn, timesteps=3,
+                                kw=dict(allow_nonfinite_values=True, n_iter=0, interp_order=0, outval=-15.0)),
+        "sl_velnan_min": dict(precip=P, velocity=Vn, timesteps=2, kw=dict(allow_nonfinite_values=True, outval="min")),
         "sl_int_T6": dict(precip=P, velocity=V, timesteps=6, kw={}),
         "sl_shear_K3": dict(precip=P, velocity=Vs, timesteps=4, kw=dict(n_iter=3)),
         "sl_K0": dict(precip=P, velocity=Vs, timesteps=3, kw=dict(n_iter=0)),
