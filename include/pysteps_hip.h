@@ -79,6 +79,10 @@ int psh_event_elapsed_ms(void *start, void *stop, float *ms); /* waits for stop 
  *   (the NumPy scans of nowcasts/extrapolation.py:76 and semilagrangian.py:171-172). Synchronous. */
 int psh_db_transform_dev(const float *in_dev, float *out_dev, size_t n, double threshold,
                          double zerovalue, int inverse);
+/* float64 <-> float32 element conversion on the device (to_f64 != 0: float32 -> float64), so that
+ * the float64 arrays pysteps works with cross the bus as they are instead of being narrowed /
+ * widened by a host pass. */
+int psh_convert_dev(const void *in_dev, void *out_dev, size_t n, int to_f64);
 int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *max_out,
                         double *nonfinite_out);
 

@@ -176,6 +176,20 @@ int field_stats_full(const float *in_dev, size_t n, FieldStats *st) {
 
 }  // namespace psh
 
+extern "C" int psh_convert_dev(const void *in_dev, void *out_dev, size_t n, int to_f64) {
+  PSH_REQUIRE_INIT();
+  if (n == 0) return PSH_OK;
+  if (!in_dev || !out_dev) return psh::fail(PSH_EINVAL, "convert: NULL pointer");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  if (to_f64)
+    PSH_HIP(psh::launch_convert_f32_f64(static_cast<const float *>(in_dev), static_cast<double *>(out_dev), n, c.stream));
+  else
+    PSH_HIP(psh::launch_convert_f64_f32(static_cast<const double *>(in_dev), static_cast<float *>(out_dev), n, c.stream));
+  return PSH_OK;
+}
+
 extern "C" int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *max_out,
                                    double *nonfinite_out) {
   PSH_REQUIRE_INIT();

@@ -44,6 +44,15 @@ class DeviceArray:
     # -- construction / transfer ---------------------------------------
     @classmethod
     def from_host(cls, array, dtype=None, sync=True):
+        src = np.asarray(array)
+        if dtype is not None and np.dtype(dtype) == np.float32 and src.dtype == np.float64 and src.size >= (1 << 16):
+            # float64 -> float32 on the device: the array crosses the bus as it is, a host-side
+            # astype of a 4096^2 plane costs more than its transfer
+            raw = cls.from_host(src, None, sync=sync)
+            out = cls(raw.shape, np.float32)
+            _lib.check(_lib.lib().psh_convert_dev(raw.ptr, out.ptr, raw.size, 0), "psh_convert_dev")
+            out._keep = raw._keep
+            return out  # `raw` goes back to the stream-ordered block cache
         arr = np.ascontiguousarray(array, dtype=dtype)
         out = cls(arr.shape, arr.dtype)
         if arr.nbytes:
@@ -55,9 +64,19 @@ class DeviceArray:
                 out._keep = arr  # the host buffer lives as long as the device array
         return out
 
-    def to_host(self, out=None):
+    def to_host(self, out=None, dtype=None):
+        """Copy to a NumPy array.  ``dtype=np.float64`` widens a float32 array on the device first
+        (the reference's operators return float64 where pysteps feeds them float64)."""
+        if dtype is not None and np.dtype(dtype) != self.dtype:
+            if self.dtype != np.float32 or np.dtype(dtype) != np.float64:
+                return self.to_host().astype(dtype)
+            wide = DeviceArray(self.shape, np.float64)
+            _lib.check(_lib.lib().psh_convert_dev(self.ptr, wide.ptr, self.size, 1), "psh_convert_dev")
+            return wide.to_host(out)
         if out is None:
-            out = np.empty(self.shape, dtype=self.dtype)
+            from . import _pinned  # noqa: PLC0415
+
+            out = _pinned.empty(self.shape, self.dtype)
         elif out.shape != self.shape or out.dtype != self.dtype or not out.flags.c_contiguous:
             raise ValueError("to_host: out must be C-contiguous with matching shape/dtype")
         if self.nbytes:

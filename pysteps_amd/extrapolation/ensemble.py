@@ -81,13 +81,14 @@ class EnsembleAdvector:
                                                            self._state.ptr), "psh_members_disp_to_state_dev")
         self._started = True
 
-    def step(self, precip_members, t_diff, t_total=None):
+    def step(self, precip_members, t_diff, t_total=None, out_dtype=None):
         """Advect all members by ``t_diff`` (lead-time increment(s) in velocity time steps, i.e.
         the ``timestep_diff`` of the reference - a sequence gives several steps in one call);
         ``t_total`` is the lead time
         handed to the perturbators (minutes, as in the reference).  ``precip_members``:
         (B,m,n) ndarray or float32 DeviceArray, or None for displacement only.
-        Returns the advected members (B,m,n) in the container type of the input."""
+        Returns the advected members (B,m,n) in the container type of the input; host results in
+        ``out_dtype`` (float32 unless given; float64 is widened on the device)."""
         on_device = isinstance(precip_members, DeviceArray)
         pm = None
         if precip_members is not None:
@@ -115,4 +116,4 @@ class EnsembleAdvector:
             return None
         if steps.size == 1:
             out = DeviceArray((self.n_members, self.m, self.n), np.float32, ptr=out.ptr, owner=out)
-        return out if on_device else out.to_host()
+        return out if on_device else out.to_host(dtype=out_dtype)

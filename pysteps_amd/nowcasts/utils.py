@@ -1,0 +1,222 @@
+"""Device-resident generic nowcast loop, mirror of ``pysteps.nowcasts.utils.nowcast_main_loop``
+(reference: pysteps/nowcasts/utils.py:265-533).
+
+The reference advects every ensemble member once per time step through ``worker1`` / ``worker2``
+(:441-462, :489-503): ``N_ens x T`` extrapolator calls, each moving 4+ full planes across PCIe when
+the extrapolator is a GPU operator, each re-materialising the perturbed motion field
+``V + generate_bps(...)`` in NumPy.  This loop keeps the same contract - signature, call order of
+``func``, sub-time-step interpolation, callbacks, return value - and, when ``extrap_method``
+resolves to the HIP extrapolator, advects ALL members with ONE launch of the member-batched
+kernel (``EnsembleAdvector``): the trajectories ``D_j`` never leave HBM and the BPS velocity
+perturbation (pysteps/noise/motion.py:146-180) is applied in-kernel from two scalars per member.
+Anything it does not recognise (another extrapolator, perturbation generators that are not the
+BPS closures of nowcasts/steps.py:931-933, exotic extrapolator options) takes the reference's own
+member-by-member route through the extrapolator callable, so results never depend on the path.
+
+``pysteps_amd.register.register(patch_main_loop=True)`` installs it in the pysteps modules that
+imported the reference loop by name (steps, sprog, anvil, linda, ...).
+"""
+
+import time
+
+import numpy as np
+
+from .. import extrapolation as _hip_extrapolation
+from ..extrapolation.ensemble import EnsembleAdvector
+from ..extrapolation.semilagrangian import extrapolate as _hip_extrapolate
+
+__all__ = ["nowcast_main_loop", "bps_perturbators"]
+
+_BPS_KEYS = ("eps_par", "eps_perp", "p_par", "p_perp", "vsf", "V_par", "V_perp")
+
+
+def _time_bins(timesteps):
+    """[(integer step t, [lead times in [t, t+1)], announce)] - the iteration plan of the
+    reference (create_timestep_range / binned_timesteps, utils.py:34-66,247-262)."""
+    if isinstance(timesteps, int):
+        return [(t, [t], t > 0) for t in range(timesteps + 1)]
+    ts = [0] + list(timesteps)
+    if sorted(ts) != ts:
+        raise ValueError("timesteps is not in ascending order")
+    if min(ts) < 0:
+        raise ValueError("negative time steps are not allowed")
+    last = int(np.ceil(ts[-1]))
+    bins = [[] for _ in range(last + 1)]
+    for v in ts:
+        # np.digitize(v, arange(last + 1), right=False) - 1
+        bins[min(int(np.floor(v)), last)].append(v)
+    return [(t, sub, bool(sub)) for t, sub in enumerate(bins)]
+
+
+def bps_perturbators(velocity_pert_gen, velocity):
+    """The scalar BPS parameters behind a list of perturbation generators, or None.
+
+    nowcasts/steps.py:931-933 wraps each perturbator dict of ``initialize_bps`` in
+    ``lambda t, vp=vp: generate_vel_noise(vp, t * timestep)``.  The dict is the lambda's default
+    argument; the time scale is recovered by calling the generator once on a 1x1 stand-in
+    perturbator, and the claim "perturbation = par(t) V/|V| + perp(t) (V/|V|)_perp of THIS motion
+    field" is verified against one full evaluation before it is trusted."""
+    out = []
+    for fn in velocity_pert_gen:
+        vp = (getattr(fn, "__defaults__", None) or (None,))[-1]
+        if not isinstance(vp, dict) or any(k not in vp for k in _BPS_KEYS):
+            return None
+        probe = dict(vp)
+        one = np.ones((2, 1, 1))
+        probe.update(V_par=one, V_perp=0 * one, eps_par=1.0, eps_perp=0.0, p_par=(1.0, 1.0, 0.0),
+                     p_perp=(0.0, 1.0, 0.0), vsf=1.0)
+        try:
+            scale = float(np.ravel(fn(1.0, vp=probe))[0])  # = 1.0 * timestep
+        except Exception:
+            return None
+        if not np.isfinite(scale) or scale <= 0:
+            return None
+        out.append(dict(eps_par=float(vp["eps_par"]), eps_perp=float(vp["eps_perp"]), p_par=tuple(vp["p_par"]),
+                        p_perp=tuple(vp["p_perp"]), vsf=float(vp["vsf"]), time_scale=scale))
+    if not out:
+        return None
+    # one full evaluation: the first generator against its closed form on this motion field
+    vel = np.asarray(velocity, dtype=np.float64)
+    norm = np.linalg.norm(vel, axis=0)
+    unit = np.where(norm > 1e-12, vel / np.where(norm > 1e-12, norm, 1.0), 0.0)
+    p, t = out[0], 1.5
+    tm = t * p["time_scale"]
+    g_par = p["p_par"][0] * pow(tm, p["p_par"][1]) + p["p_par"][2]
+    g_perp = p["p_perp"][0] * pow(tm, p["p_perp"][1]) + p["p_perp"][2]
+    closed = (g_par * p["eps_par"] * unit + g_perp * p["eps_perp"] * np.stack([-unit[1], unit[0]])) / p["vsf"]
+    try:
+        if not np.allclose(velocity_pert_gen[0](t), closed, rtol=1e-9, atol=1e-12):
+            return None
+    except Exception:
+        return None
+    return out
+
+
+def _batched_options(extrap_kwargs):
+    """Options of the extrapolator the member-batched kernel implements -> dict, else None."""
+    kw = dict(extrap_kwargs)
+    for k in ("xy_coords", "return_displacement", "displacement_prev", "allow_nonfinite_values", "verbose"):
+        kw.pop(k, None)
+    opts = dict(n_iter=int(kw.pop("n_iter", 1)), interp_order=kw.pop("interp_order", 1),
+                outval=kw.pop("outval", np.nan))
+    if kw.pop("map_coordinates_mode", "constant") != "constant" or kw.pop("vel_timestep", 1) != 1 or kw:
+        return None
+    if opts["interp_order"] not in (0, 1) or isinstance(opts["outval"], str) or opts["n_iter"] < 0:
+        return None
+    return opts
+
+
+class _MemberLoop:
+    """The reference's route: one extrapolator call per member (utils.py:441-462, 489-503)."""
+
+    def __init__(self, extrapolator, velocity, shape, extrap_kwargs, velocity_pert_gen):
+        self.extrapolator, self.velocity, self.gen = extrapolator, velocity, velocity_pert_gen
+        m, n = shape
+        xg, yg = np.meshgrid(np.arange(n), np.arange(m))
+        self.kw = dict(extrap_kwargs, xy_coords=np.stack([xg, yg]), return_displacement=True)
+        self.disp = None
+
+    def advect(self, fields, n_members, dt, t_total):
+        if self.disp is None:
+            self.disp = [None] * n_members
+        res = []
+        for j in range(n_members):
+            kw = dict(self.kw, displacement_prev=self.disp[j])
+            v = self.velocity if self.gen is None else self.velocity + self.gen[j](t_total)
+            if fields is None:
+                _, self.disp[j] = self.extrapolator(None, v, [dt], **kw)
+            else:
+                kw["allow_nonfinite_values"] = bool(np.any(~np.isfinite(fields[j])))
+                out, self.disp[j] = self.extrapolator(fields[j], v, [dt], **kw)
+                res.append(out[0])
+        return res if fields is not None else None
+
+
+class _BatchedLoop:
+    """All members in one launch, trajectories resident in HBM."""
+
+    def __init__(self, velocity, perturbators, opts):
+        self.velocity, self.perts, self.opts = velocity, perturbators, opts
+        self.adv = None
+
+    def advect(self, fields, n_members, dt, t_total):
+        if self.adv is None:
+            self.adv = EnsembleAdvector(self.velocity, n_members, self.perts, **self.opts)
+        lead = None if self.perts is None else t_total * self.perts[0]["time_scale"]  # minutes
+        if fields is None:
+            self.adv.step(None, dt, lead)
+            return None
+        got = self.adv.step(np.asarray(fields), dt, lead, out_dtype=np.asarray(fields).dtype)
+        return [got[j] for j in range(n_members)]
+
+
+def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, extrap_kwargs=None,
+                      velocity_pert_gen=None, params=None, ensemble=False, num_ensemble_members=1,
+                      callback=None, return_output=True, num_workers=1, measure_time=False):
+    """Same parameters, call order and return value as the reference (utils.py:265-345): a list /
+    array of forecast fields ``(n_timesteps, m, n)`` or ``(n_members, n_timesteps, m, n)``, with the
+    loop time when ``measure_time`` is set.  ``num_workers`` is accepted; the members are advanced
+    together on the GPU instead of by worker threads."""
+    plan = _time_bins(timesteps)
+    extrap_kwargs = {} if extrap_kwargs is None else dict(extrap_kwargs)
+    try:
+        from pysteps import extrapolation as ref_extrapolation  # noqa: PLC0415
+
+        extrapolator = ref_extrapolation.get_method(extrap_method)
+    except ImportError:
+        extrapolator = _hip_extrapolation.get_method(extrap_method)
+
+    n_members = num_ensemble_members if ensemble else 1
+    engine = None
+    if extrapolator is _hip_extrapolate:
+        opts = _batched_options(extrap_kwargs)
+        perts = None
+        if velocity_pert_gen is not None and opts is not None:
+            perts = bps_perturbators(velocity_pert_gen, velocity)
+            if perts is None:
+                opts = None
+        if opts is not None:
+            engine = _BatchedLoop(np.asarray(velocity), perts, opts)
+    if engine is None:
+        engine = _MemberLoop(extrapolator, velocity, precip.shape, extrap_kwargs, velocity_pert_gen)
+
+    prev = np.stack([precip] * n_members) if ensemble else precip[np.newaxis, :]
+    outputs = [[] for _ in range(prev.shape[0])] if return_output else None
+    t_prev = t_total = 0.0
+    started = time.time()
+    for t, subtimesteps, announce in plan:
+        if announce:
+            print(f"Computing nowcast for time step {t}... ", end="", flush=True)
+            step_started = time.time()
+        new, state = func(state, params)
+        if not ensemble:
+            new = new[np.newaxis, :]
+        for t_sub in subtimesteps:
+            if not t_sub > 0:
+                continue
+            w = t_sub - int(t_sub)  # linear interpolation between the integer-step fields (:419-427)
+            fields = (1.0 - w) * prev + w * new if w > 0.0 else prev
+            dt = t_sub - t_prev
+            t_total += dt
+            advected = engine.advect(fields, fields.shape[0], dt, t_total)
+            if return_output:
+                for j, a in enumerate(advected):
+                    outputs[j].append(a)
+            if callback is not None:
+                callback(np.stack(advected))
+            t_prev = t_sub
+        if not subtimesteps:  # no lead time in this bin: displacement only, up to the next integer step
+            dt = t + 1 - t_prev
+            t_total += dt
+            engine.advect(None, new.shape[0], dt, t_total)
+            t_prev = t + 1
+        prev = new
+        if announce:
+            print(f"{time.time() - step_started:.2f} seconds." if measure_time else "done.")
+
+    result = None
+    if return_output:
+        result = np.stack([np.stack(o) for o in outputs])
+        if not ensemble:
+            result = result[0, :]
+    return (result, time.time() - started) if measure_time else result

@@ -35,9 +35,51 @@ def register_into(motion_methods, extrapolation_methods, override=False):
     return added
 
 
-def register(override=False):
-    """Register with an importable pysteps; raises ImportError if pysteps is absent."""
+# pysteps modules that bind the generic nowcast loop by name (``from pysteps.nowcasts.utils import
+# nowcast_main_loop``): steps.py:26, sprog.py, anvil.py, linda.py
+_MAIN_LOOP_USERS = ("steps", "sprog", "anvil", "linda")
+
+
+def register(override=False, patch_main_loop=False):
+    """Register with an importable pysteps; raises ImportError if pysteps is absent.
+
+    ``patch_main_loop=True`` also installs the device-resident generic nowcast loop
+    (:func:`pysteps_amd.nowcasts.utils.nowcast_main_loop`) in the nowcast modules: with
+    ``extrap_method="semilagrangian_hip"`` all ensemble members are then advected by one kernel
+    launch per time step and their trajectories stay in HBM; any other extrapolator runs exactly as
+    before.  :func:`unpatch_main_loop` restores the reference loop."""
     import pysteps.extrapolation.interface as ext_if  # noqa: PLC0415
     import pysteps.motion.interface as mot_if  # noqa: PLC0415
 
-    return register_into(mot_if._methods, ext_if._extrapolation_methods, override=override)
+    added = register_into(mot_if._methods, ext_if._extrapolation_methods, override=override)
+    if patch_main_loop:
+        import importlib  # noqa: PLC0415
+
+        from .nowcasts.utils import nowcast_main_loop  # noqa: PLC0415
+
+        for name in _MAIN_LOOP_USERS:
+            try:
+                mod = importlib.import_module("pysteps.nowcasts." + name)
+            except Exception:
+                continue  # optional dependencies of that nowcast module are missing
+            if hasattr(mod, "nowcast_main_loop"):
+                if not hasattr(mod, "_reference_nowcast_main_loop"):
+                    mod._reference_nowcast_main_loop = mod.nowcast_main_loop
+                mod.nowcast_main_loop = nowcast_main_loop
+                added.append("main_loop:" + name)
+    return added
+
+
+def unpatch_main_loop():
+    """Undo ``register(patch_main_loop=True)``."""
+    import importlib  # noqa: PLC0415
+
+    for name in _MAIN_LOOP_USERS:
+        try:
+            mod = importlib.import_module("pysteps.nowcasts." + name)
+        except Exception:
+            continue
+        ref = getattr(mod, "_reference_nowcast_main_loop", None)
+        if ref is not None:
+            mod.nowcast_main_loop = ref
+            del mod._reference_nowcast_main_loop

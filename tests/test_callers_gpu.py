@@ -249,3 +249,41 @@ def test_ensemble_advector_against_reference_bps_and_worker(pysteps):
     gd = adv.displacement.to_host()
     for j in range(B):
         assert np.max(np.abs(gd[j] - D[j])) < 1e-4
+
+
+@pytest.mark.parametrize("timesteps,vel_pert", [(3, "bps"), ([0.5, 1.0, 2.5, 4.75], "bps"), (3, None)])
+def test_steps_with_the_resident_member_batched_loop(pysteps, timesteps, vel_pert):
+    """register(patch_main_loop=True): nowcasts.steps drives ONE member-batched launch per time step
+    (pysteps_amd.nowcasts.utils -> EnsembleAdvector), perturbators taken from the real
+    initialize_bps closures, trajectories resident in HBM - against the stock loop with the stock
+    extrapolator (nowcasts/utils.py:441-503, noise/motion.py:146-180)."""
+    from pysteps import nowcasts
+    from pysteps.nowcasts import steps as steps_mod
+    from pysteps_amd import register
+    from pysteps_amd.extrapolation import ensemble
+    from pysteps_amd.nowcasts.utils import nowcast_main_loop
+
+    frames, V = _steps_inputs(256, 256)
+    kw = _steps_kwargs()
+    kw["vel_pert_method"] = vel_pert
+    steps = nowcasts.get_method("steps")
+    want = steps(frames, V, timesteps, extrap_method="semilagrangian", **kw)
+    launches = []
+    orig_step = ensemble.EnsembleAdvector.step
+
+    def counting_step(self, *a, **k):
+        launches.append(self.n_members)
+        return orig_step(self, *a, **k)
+
+    try:
+        register.register(patch_main_loop=True)
+        assert steps_mod.nowcast_main_loop is nowcast_main_loop
+        ensemble.EnsembleAdvector.step = counting_step
+        got = steps(frames, V, timesteps, extrap_method="semilagrangian_hip", **kw)
+    finally:
+        ensemble.EnsembleAdvector.step = orig_step
+        register.unpatch_main_loop()
+    assert launches and all(b == kw["n_ens_members"] for b in launches)  # the batched route ran
+    assert got.dtype == want.dtype
+    rel = _ensemble_close(got, want)
+    assert rel < 1e-4, rel

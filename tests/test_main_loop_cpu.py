@@ -1,0 +1,98 @@
+"""pysteps_amd.nowcasts.utils.nowcast_main_loop against the reference loop (CPU).
+
+With an extrapolator it does not recognise (here: the oracle restatement registered in the real
+pysteps tables) the mirror takes the reference's own member-by-member route, so the real callers
+(nowcasts.steps, sprog) must produce BIT-IDENTICAL results whichever loop is installed - same
+``func`` call order, same sub-time-step interpolation, same perturbation generator calls, same
+callback payloads.  The member-batched GPU route of the same loop is covered by
+tests/test_callers_gpu.py.
+"""
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture()
+def patched(ref_pysteps):
+    from oracle import semilag as osl
+    from pysteps import extrapolation
+    from pysteps_amd import register
+
+    extrapolation.interface._extrapolation_methods["semilagrangian_oracle"] = osl.extrapolate
+    yield register
+    register.unpatch_main_loop()
+    extrapolation.interface._extrapolation_methods.pop("semilagrangian_oracle", None)
+
+
+@pytest.mark.parametrize("method,timesteps,kw", [
+    ("steps", 3, dict(n_ens_members=2, n_cascade_levels=4, precip_thr=-10.0, kmperpixel=1.0, timestep=5.0, seed=7)),
+    ("steps", [0.5, 1.0, 2.5, 4.75],
+     dict(n_ens_members=2, n_cascade_levels=4, precip_thr=-10.0, kmperpixel=1.0, timestep=5.0, seed=7)),
+    ("sprog", [0.25, 3.0], dict(n_cascade_levels=4, precip_thr=-10.0)),
+    ("sprog", 2, dict(n_cascade_levels=4, precip_thr=-10.0)),
+])
+def test_mirror_loop_equals_reference_loop(patched, method, timesteps, kw):
+    from pysteps import nowcasts
+    from tools import synth
+
+    frames = synth.steps_frames(96, 112, 3)
+    V = synth.true_velocity(96, 112).astype(np.float64)
+    fn = nowcasts.get_method(method)
+    seen_ref, seen_new = [], []
+    cb_ref = dict(callback=lambda a: seen_ref.append(np.array(a))) if method == "steps" else {}
+    cb_new = dict(callback=lambda a: seen_new.append(np.array(a))) if method == "steps" else {}
+    want = fn(frames, V, timesteps, extrap_method="semilagrangian_oracle", **cb_ref, **kw)
+    added = patched.register(patch_main_loop=True)
+    assert "main_loop:" + method in added
+    import importlib
+
+    mod = importlib.import_module("pysteps.nowcasts." + method)
+    from pysteps_amd.nowcasts.utils import nowcast_main_loop
+
+    assert mod.nowcast_main_loop is nowcast_main_loop
+    got = fn(frames, V, timesteps, extrap_method="semilagrangian_oracle", **cb_new, **kw)
+    assert got.shape == want.shape and got.dtype == want.dtype
+    assert np.array_equal(got, want, equal_nan=True)
+    assert len(seen_new) == len(seen_ref)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(seen_new, seen_ref))
+    patched.unpatch_main_loop()
+    assert mod.nowcast_main_loop is not nowcast_main_loop
+
+
+def test_time_bins_follow_the_reference(ref_pysteps):
+    from pysteps.nowcasts.utils import create_timestep_range
+    from pysteps_amd.nowcasts.utils import _time_bins
+
+    for ts in (4, 1, [0.5, 1.0, 2.5], [3.0], [0.2, 0.4, 5.0], [1, 2, 3], [0.9999, 7.25]):
+        bins, original, kind = create_timestep_range(ts)
+        plan = _time_bins(ts)
+        assert len(plan) == len(bins)
+        for (t, sub, announce), idx in zip(plan, bins):
+            want = [original[i] for i in idx] if kind == "list" else [idx]
+            assert sub == want
+            assert announce == (bool(want) if kind == "list" else t > 0)
+    with pytest.raises(ValueError):
+        _time_bins([2.0, 1.0])
+
+
+def test_bps_generators_are_recognised(ref_pysteps):
+    """The closures of nowcasts/steps.py:931-933 over real initialize_bps dicts."""
+    from pysteps import noise
+    from pysteps_amd.nowcasts.utils import bps_perturbators
+    from tools import synth
+
+    V = synth.true_velocity(40, 56).astype(np.float64)
+    V[:, 3, 4] = 0.0
+    init, gen = noise.get_method("bps")
+    timestep = 5.0
+    gens, vps = [], []
+    for j in range(3):
+        vp = init(V, 1.0, timestep, randstate=np.random.RandomState(j))
+        vps.append(vp)
+        gens.append(lambda t, vp=vp: gen(vp, t * timestep))
+    perts = bps_perturbators(gens, V)
+    assert perts is not None and len(perts) == 3
+    for p, vp in zip(perts, vps):
+        assert p["time_scale"] == timestep and p["eps_par"] == vp["eps_par"] and p["vsf"] == vp["vsf"]
+    assert bps_perturbators([lambda t: np.zeros_like(V)], V) is None  # not a BPS closure
+    assert bps_perturbators(gens, V * np.array([1.0, -1.0])[:, None, None]) is None  # another motion field
