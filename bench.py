@@ -8,10 +8,12 @@ already resident in HBM: motion estimate from the input frames (dense
 Lucas-Kanade) followed by the semi-Lagrangian extrapolation of the last frame
 over T lead times.  Workload at N=1: BASELINE.json configs[2] (4096x4096 fp32,
 2 input frames, 24 lead times, n_iter=1) - the configuration the metric is quoted
-on.  With N>1 ranks (one per GPU, launched by torch.distributed.run) every rank
-advects its own field ("members shard embarrassingly"): rank 0 synthesises the
-inputs, one RCCL broadcast over xGMI distributes them before the timed region,
-and there is no data-path collective afterwards (weak scaling).
+on.  With N>1 ranks (one per GPU, launched by torch.distributed.run) the workload is
+BASELINE.json configs[3]: a STEPS ensemble with 6 members per GPU (48 on 8 GPUs);
+rank 0 synthesises the inputs and estimates the motion, ONE RCCL broadcast over
+xGMI distributes [precip | u | v] before the timed region, every rank advects its
+own perturbed members and there is no data-path collective afterwards (weak
+scaling; an RCCL failure makes the run exit non-zero).
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the fields).
 """
@@ -42,6 +44,10 @@ def parse_args():
     ap.add_argument("--no-lk", action="store_true", help="time the extrapolator only (true velocity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the NumPy-in / NumPy-out leg")
+    ap.add_argument("--force-members-path", action="store_true",
+                    help="run the N > 1 code path (RCCL communicator, broadcast, member shard) at any world size")
+    ap.add_argument("--no-members-leg", action="store_true", help="skip the config-4 single-GPU reference leg")
+    ap.add_argument("--members-per-gpu", type=int, default=6, help="STEPS members per GPU (config 4: 48 on 8 GPUs)")
     ap.add_argument("--cpu-sample-steps", type=int, default=2)
     return ap.parse_args()
 
@@ -245,6 +251,53 @@ def compulsory_bytes(m, n, T, K):
     return (T + 3.0) * m * n * 4.0
 
 
+def members_workload(precip_d, vel_d, n_members, first_member, n_total, T, K):
+    """BASELINE config 4 on one rank: `n_members` of the `n_total` STEPS members (global indices
+    first_member ...), each with its own BPS-perturbed motion (perturbators recomputed from the
+    ensemble seed, pysteps/nowcasts/steps.py:885-933), advected through T single-step stateful calls
+    of the member-batched kernel - the extrapolation share of nowcasts.steps' main loop
+    (pysteps/nowcasts/utils.py:441-462).  Returns step(): one full T-step nowcast of the members."""
+    from pysteps_amd import _lib
+    from pysteps_amd.device import DeviceArray
+    from pysteps_amd.extrapolation.ensemble import EnsembleAdvector, steps_perturbators
+
+    m, n = precip_d.shape
+    timestep_min = 5.0
+    perts = steps_perturbators(n_total, 42, 1.0, timestep_min)[first_member:first_member + n_members]
+    members_d = DeviceArray((n_members, m, n), np.float32)
+    for j in range(n_members):
+        _lib.check(_lib.lib().psh_memcpy_d2d(members_d.view(j).ptr, precip_d.ptr, precip_d.nbytes), "d2d")
+    adv = EnsembleAdvector(vel_d, n_members, perts, n_iter=K, outval=-15.0)
+
+    def step():
+        adv.reset()
+        out = None
+        for t in range(T):
+            out = adv.step(members_d, 1.0, timestep_min * (t + 1))
+        return out
+
+    return step
+
+
+def time_steps(step, dist, steps, warmup, events=None):
+    from pysteps_amd.device import synchronize
+
+    for _ in range(warmup):
+        step()
+    synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if events is not None:
+            events[i][0].record()
+        step()
+        if events is not None:
+            events[i][1].record()
+    synchronize()
+    dist.barrier()
+    return dist.max(time.perf_counter() - t0)
+
+
 def main():
     args = parse_args()
     dist = Dist(args.gpus)
@@ -268,67 +321,161 @@ def main():
         except (ImportError, AttributeError):
             have_lk = False
 
-    # ---- inputs: synthesised on rank 0, broadcast, resident in HBM ------------
-    if dist.rank == 0:
-        frames_d, vel_d = make_inputs(m, n, args.frames)
-    else:
-        frames_d = DeviceArray((args.frames, m, n), np.float32)
-        vel_d = DeviceArray((2, m, n), np.float32)
-    bcast_note = None
-    if dist.world > 1:
-        from pysteps_amd import parallel
+    if dist.world > 1 or args.force_members_path:
+        return main_members(args, dist, dense_lk if have_lk else None)
 
-        t0 = time.perf_counter()
-        try:
-            comm = parallel.Communicator(dist.rank, dist.world, dist.broadcast_bytes)
-            comm.broadcast(frames_d, root=0)
-            comm.broadcast(vel_d, root=0)
-            synchronize()
-            ok = 1.0
-        except Exception as exc:  # RCCL unavailable: every rank synthesises the same seeded inputs
-            bcast_note = "RCCL broadcast failed (%s); inputs synthesised per rank" % (exc,)
-            ok = 0.0
-        if dist.max(1.0 - ok) > 0.0:  # any rank failed -> all ranks fall back consistently
-            if dist.rank != 0 or ok == 0.0:
-                frames_d, vel_d = make_inputs(m, n, args.frames)
-            bcast_note = bcast_note or "RCCL broadcast failed on another rank; inputs synthesised per rank"
-        bcast_s = time.perf_counter() - t0
-    else:
-        bcast_s = None
+    # ---- N = 1: BASELINE configs[2], inputs synthesised and resident in HBM -------------
+    frames_d, vel_d = make_inputs(m, n, args.frames)
     precip_d = frames_d.view(args.frames - 1)
 
     ev = [(Event(), Event()) for _ in range(args.steps)]
+    counter = {"i": None}
 
-    def step(i=None):
+    def step():
         v = dense_lk(frames_d) if have_lk else vel_d
+        i = counter["i"]
         if i is not None:
             ev[i][0].record()
         out = extrapolate(precip_d, v, T, outval=-15.0, n_iter=K)
         if i is not None:
             ev[i][1].record()
+            counter["i"] = i + 1
         return out
 
     for _ in range(args.warmup):
         step()
     synchronize()
     dist.barrier()
+    counter["i"] = 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for _ in range(args.steps):
+        step()
     synchronize()
     dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = dist.max(elapsed)
+    elapsed = dist.max(time.perf_counter() - t0)
+    counter["i"] = None
 
     sl_ms = sum(a.elapsed_ms(b) for a, b in ev) / args.steps
     ms_per_step = elapsed / args.steps * 1e3
-    value = dist.world * m * n * T / (ms_per_step * 1e-3) / 1e6
+    value = m * n * T / (ms_per_step * 1e-3) / 1e6
     b_alg = (16 * K + 8) if K > 0 else 16
     alg_bytes = float(b_alg) * m * n * T
     achieved = alg_bytes / (sl_ms * 1e-3) / 1e9
     workload = "%dx%d fp32, %d input frames, %s + semilag %d leadtimes n_iter=%d" % (
         m, n, args.frames, "dense LK" if have_lk else "true velocity (LK not timed)", T, K)
+    line = {
+        "metric": "Mpixels*leadsteps/s (LK+semilag) at %dx%d fp32" % (m, n),
+        "value": value,
+        "unit": "Mpx*leadsteps/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": workload,
+            "lk_in_step": have_lk,
+            "sharding": "single GPU",
+            # the two legs of the step: the extrapolation (velocity packing + kernel) by
+            # HIP events, the motion estimate as the rest of the step
+            "semilag_only_mpx_leadsteps_s": m * n * T / (sl_ms * 1e-3) / 1e6,
+            "lk_ms_per_step": (ms_per_step - sl_ms) if have_lk else None,
+        },
+        "roofline": {
+            "kernel": "semilag_fused",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "alg_bytes_per_launch": alg_bytes,
+            "kernel_ms": sl_ms,
+            "traffic": pmc_traffic("semilag_%dx%d_T%d_K%d" % (m, n, T, K)),
+        },
+    }
+    # the contract's `frac` prices ALGORITHMIC bytes; the inputs are served from L2/MALL, so the
+    # DRAM-side picture is given beside it: counter traffic over the same duration, and the time
+    # the compulsory stream alone would need at peak
+    rf = line["roofline"]
+    rf["hbm_frac"] = (rf["traffic"] / (sl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rf["traffic"] else None
+    rf["floor_ms"] = compulsory_bytes(m, n, T, K) / (HBM_PEAK_GBS * 1e9) * 1e3
+    if not args.no_host_path:
+        line["config"].update(host_path(frames_d, vel_d, T, K))
+    if not args.no_members_leg:
+        # what ONE GPU of the N > 1 runs does (config 4: members_per_gpu members, T single-step
+        # stateful calls): the single-GPU figure the multi-GPU values are to be compared with
+        mstep = members_workload(precip_d, vel_d, args.members_per_gpu, 0, args.members_per_gpu, T, K)
+        el = time_steps(mstep, dist, 3, 1)
+        line["config"]["config4_one_gpu"] = {
+            "members": args.members_per_gpu,
+            "ms_per_step": el / 3 * 1e3,
+            "value": args.members_per_gpu * m * n * T / (el / 3) / 1e6,
+            "note": "same per-GPU workload as the --gpus N > 1 runs (weak scaling reference)",
+        }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(frames_d, vel_d, K, args.cpu_sample_steps, T, have_lk)
+    print(json.dumps(line))
+    dist.close()
 
+
+def main_members(args, dist, dense_lk):
+    """N > 1 (one rank per GPU): BASELINE config 4, `members_per_gpu` STEPS members per GPU.
+
+    Rank 0 synthesises the frames, estimates the motion field and packs [precip | u | v] into one
+    buffer; ONE RCCL broadcast over xGMI (192 MiB at 4096^2) hands it to every rank before the
+    timed region; each rank then advects its own members (partition of 6N members, perturbators
+    recomputed from the ensemble seed) with no data-path collective (weak scaling).  An RCCL failure
+    is fatal: the run exits non-zero instead of reporting numbers of a run that did not communicate."""
+    from pysteps_amd import _lib, parallel
+    from pysteps_amd.device import DeviceArray, Event, synchronize
+
+    m = n = args.size
+    T, K = args.leadtimes, args.n_iter
+    pack = DeviceArray((3, m, n), np.float32)
+    if dist.rank == 0:
+        frames_d, vel_d = make_inputs(m, n, args.frames)
+        v = dense_lk(frames_d) if dense_lk is not None else vel_d
+        lib = _lib.lib()
+        _lib.check(lib.psh_memcpy_d2d(pack.view(0).ptr, frames_d.view(args.frames - 1).ptr, m * n * 4), "d2d")
+        _lib.check(lib.psh_memcpy_d2d(pack.view(1).ptr, v.ptr, 2 * m * n * 4), "d2d")
+        synchronize()
+        del frames_d, vel_d, v
+    t0 = time.perf_counter()
+    ok = 1.0
+    err = None
+    try:
+        comm = parallel.Communicator(dist.rank, dist.world, dist.broadcast_bytes)
+        comm.broadcast(pack, root=0)
+        synchronize()
+    except Exception as exc:
+        ok, err = 0.0, exc
+    if dist.max(1.0 - ok) > 0.0:
+        print("rank %d: RCCL broadcast failed on %s: %s" % (
+            dist.rank, "this rank" if ok == 0.0 else "another rank", err), file=sys.stderr)
+        dist.close()
+        sys.exit(3)
+    bcast_s = time.perf_counter() - t0
+    precip_d = pack.view(0)
+    vel_d = DeviceArray((2, m, n), np.float32, ptr=pack.view(1).ptr, owner=pack)
+
+    per = args.members_per_gpu
+    n_total = per * dist.world
+    mine = parallel.partition(n_total, dist.world, dist.rank)
+    step = members_workload(precip_d, vel_d, len(mine), mine.start, n_total, T, K)
+    ev = [(Event(), Event()) for _ in range(args.steps)]
+    elapsed = time_steps(step, dist, args.steps, args.warmup, ev)
+    kernel_ms = sum(a.elapsed_ms(b) for a, b in ev) / args.steps / T  # one batched launch
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_total * m * n * T / (ms_per_step * 1e-3) / 1e6
+    # stateful single-step call (SURVEY 8d): D read + write 16, three velocity passes 8 each
+    # (increment rebuild, midpoint, end point) for n_iter = 1, field 4, store 4 -> 48 B / px / member
+    b_alg = (24 + 16 * K + 8) if K > 0 else 32
+    alg_bytes = float(b_alg) * m * n * len(mine)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     if dist.rank == 0:
         line = {
             "metric": "Mpixels*leadsteps/s (LK+semilag) at %dx%d fp32" % (m, n),
@@ -344,39 +491,29 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": workload,
-                "lk_in_step": have_lk,
-                "sharding": "one field per rank, inputs RCCL-broadcast before the timed region"
-                if dist.world > 1 else "single GPU",
+                "workload": "%dx%d fp32, %d-member STEPS ensemble advection (BASELINE config 4), %d members per GPU, "
+                            "%d lead steps as single-step stateful calls with BPS velocity perturbations, n_iter=%d" % (
+                                m, n, n_total, per, T, K),
+                "sharding": "members partitioned over ranks, motion field from %s on rank 0, [precip|u|v] in ONE "
+                            "RCCL broadcast before the timed region, no data-path collective" % (
+                                "dense LK" if dense_lk is not None else "the synthetic truth"),
+                "rccl_ranks": dist.world,
                 "broadcast_s": bcast_s,
-                "broadcast_note": bcast_note,
-                # the two legs of the step (rank 0): the extrapolation kernel by HIP events,
-                # the motion estimate (kernels + its two host hand-overs) as the rest of the step
-                "semilag_only_mpx_leadsteps_s": m * n * T / (sl_ms * 1e-3) / 1e6,
-                "lk_ms_per_step": (ms_per_step - sl_ms) if have_lk else None,
+                "broadcast_bytes": pack.nbytes,
+                "compare_with": "config.config4_one_gpu.value of the --gpus 1 line (same per-GPU workload)",
             },
             "roofline": {
-                "kernel": "semilag_fused",
+                "kernel": "semilag_members",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "alg_bytes_per_launch": alg_bytes,
-                "kernel_ms": sl_ms,
-                "traffic": pmc_traffic("semilag_%dx%d_T%d_K%d" % (m, n, T, K)),
+                "kernel_ms": kernel_ms,
+                "traffic": None,
             },
         }
-        # the contract's `frac` prices ALGORITHMIC bytes; the inputs are served from L2/MALL, so the
-        # DRAM-side picture is given beside it: counter traffic over the same duration, and the time
-        # the compulsory stream alone would need at peak
-        rf = line["roofline"]
-        rf["hbm_frac"] = (rf["traffic"] / (sl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rf["traffic"] else None
-        rf["floor_ms"] = compulsory_bytes(m, n, T, K) / (HBM_PEAK_GBS * 1e9) * 1e3
-        if dist.world == 1 and not args.no_host_path:
-            line["config"].update(host_path(frames_d, vel_d, T, K))
-        if not args.no_cpu_baseline and dist.world == 1:
-            line["cpu_baseline"] = cpu_baseline(frames_d, vel_d, K, args.cpu_sample_steps, T, have_lk)
         print(json.dumps(line))
     dist.close()
 

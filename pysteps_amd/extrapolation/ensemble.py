@@ -14,7 +14,35 @@ import numpy as np
 from .. import _lib
 from ..device import DeviceArray
 
-__all__ = ["EnsembleAdvector", "bps_scalars"]
+__all__ = ["EnsembleAdvector", "bps_scalars", "steps_perturbators"]
+
+# defaults of pysteps/noise/motion.py:43-52 (BPS2006)
+_BPS_PAR, _BPS_PERP = (10.88, 0.23, -7.68), (5.76, 0.31, -2.72)
+
+
+def steps_perturbators(n_members, seed, kmperpixel, timestep, p_par=None, p_perp=None):
+    """The scalar part of the velocity perturbators ``nowcasts.steps`` builds for ``n_members``
+    members from ``seed`` - recomputable on every rank without communication.
+
+    Seed chain of pysteps/nowcasts/steps.py:885-898: per member ``rs = RandomState(seed)`` (precip
+    noise), ``seed = rs.randint(0, 1e9)``, ``rs = RandomState(seed)`` (motion), ``seed =
+    rs.randint(0, 1e9)``; ``initialize_bps`` (noise/motion.py:119-125) then draws ``eps_par`` and
+    ``eps_perp`` from the motion generator's Laplace distribution (scale 1/sqrt(2)) and sets
+    ``vsf = 60 / (timestep * pixelsperkm)`` with ``pixelsperkm = 1 / kmperpixel`` (steps.py:924-929).
+    Returns one dict per member for :class:`EnsembleAdvector`."""
+    out = []
+    for _ in range(int(n_members)):
+        rs = np.random.RandomState(seed)
+        seed = rs.randint(0, high=int(1e9))
+        rs = np.random.RandomState(seed)
+        seed = rs.randint(0, high=int(1e9))
+        # the randint above is drawn from the motion generator before initialize_bps uses it
+        eps_par = rs.laplace(scale=1.0 / np.sqrt(2))
+        eps_perp = rs.laplace(scale=1.0 / np.sqrt(2))
+        out.append(dict(eps_par=float(eps_par), eps_perp=float(eps_perp),
+                        p_par=tuple(p_par or _BPS_PAR), p_perp=tuple(p_perp or _BPS_PERP),
+                        vsf=60.0 / (float(timestep) * (1.0 / float(kmperpixel)))))
+    return out
 
 
 def bps_scalars(perturbators, t):
@@ -58,6 +86,10 @@ class EnsembleAdvector:
             self.vhat = DeviceArray((2, self.m, self.n), np.float32)
             _lib.check(self._lib.psh_velocity_unit_dev(self.velocity.ptr, self.m, self.n, self.vhat.ptr),
                        "psh_velocity_unit_dev")
+
+    def reset(self):
+        """Back to lead time zero (all displacements zero) without releasing the resident state."""
+        self._started = False
 
     @property
     def displacement(self):

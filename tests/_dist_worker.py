@@ -21,9 +21,16 @@ def main():
     # member sharding: 48 members, 2 ranks -> 24 each, disjoint and complete
     mine = list(parallel.partition(48, dist.world, dist.rank))
     owners = [parallel.owner_of(j, 48, dist.world) for j in mine]
+    # config 4 in bench.py: every rank recomputes the perturbators of ITS members from the seed
+    from pysteps_amd.extrapolation.ensemble import steps_perturbators
+
+    per_gpu = 6
+    n_total = per_gpu * dist.world
+    shard = parallel.partition(n_total, dist.world, dist.rank)
+    eps = [p["eps_par"] for p in steps_perturbators(n_total, 42, 1.0, 5.0)[shard.start:shard.stop]]
     with open(os.path.join(out_dir, "rank%d.json" % dist.rank), "w") as fh:
         json.dump({"rank": dist.rank, "max": slowest, "token_len": len(token), "mine": mine,
-                   "owners": owners}, fh)
+                   "owners": owners, "shard": list(shard), "eps_par": eps}, fh)
     dist.barrier()
     dist.close()
 

@@ -1,5 +1,7 @@
 """RCCL communicator on one GPU (world_size 1): dlopen, ncclCommInitRank, broadcast, all-gather."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -69,3 +71,24 @@ def test_row_band_tiling_equals_single_gpu(world):
         else:
             assert np.array_equal(np.isnan(tiled), np.isnan(full))
             assert np.nanmax(np.abs(tiled - full)) < 1e-4
+
+
+def test_bench_multi_rank_path_runs_at_world_size_one():
+    """bench.py's N > 1 leg (BASELINE config 4: RCCL communicator, ONE broadcast of [precip|u|v],
+    member shard with perturbators from the seed chain, batched single-step calls) end to end on
+    the one GPU a test box has."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    proc = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--force-members-path", "--size", "512", "--leadtimes", "4",
+         "--steps", "2", "--warmup", "1", "--members-per-gpu", "3"],
+        cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1
+    assert "config 4" in line["config"]["workload"] and line["roofline"]["kernel"] == "semilag_members"
+    assert line["value"] > 0 and line["config"]["broadcast_bytes"] == 3 * 512 * 512 * 4

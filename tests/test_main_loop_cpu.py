@@ -96,3 +96,34 @@ def test_bps_generators_are_recognised(ref_pysteps):
         assert p["time_scale"] == timestep and p["eps_par"] == vp["eps_par"] and p["vsf"] == vp["vsf"]
     assert bps_perturbators([lambda t: np.zeros_like(V)], V) is None  # not a BPS closure
     assert bps_perturbators(gens, V * np.array([1.0, -1.0])[:, None, None]) is None  # another motion field
+
+
+def test_steps_perturbators_reproduce_the_seed_chain_of_nowcasts_steps(ref_pysteps):
+    """Every rank recomputes the perturbators of its members from the ensemble seed: equal to what
+    the real nowcasts.steps hands to the main loop (captured from its velocity_pert_gen closures)."""
+    from pysteps import nowcasts
+    from pysteps.nowcasts import steps as steps_mod
+    from pysteps_amd.extrapolation.ensemble import steps_perturbators
+    from tools import synth
+
+    captured = {}
+    ref_loop = steps_mod.nowcast_main_loop
+
+    def spy(*a, **k):
+        captured["gens"] = k.get("velocity_pert_gen")
+        return ref_loop(*a, **k)
+
+    frames = synth.steps_frames(64, 64, 3)
+    V = synth.true_velocity(64, 64).astype(np.float64)
+    try:
+        steps_mod.nowcast_main_loop = spy
+        nowcasts.get_method("steps")(frames, V, 1, n_ens_members=5, n_cascade_levels=3, precip_thr=-10.0,
+                                     kmperpixel=2.0, timestep=10.0, seed=42)
+    finally:
+        steps_mod.nowcast_main_loop = ref_loop
+    want = [g.__defaults__[-1] for g in captured["gens"]]
+    got = steps_perturbators(5, 42, 2.0, 10.0)
+    assert len(got) == len(want) == 5
+    for g, w in zip(got, want):
+        assert g["eps_par"] == w["eps_par"] and g["eps_perp"] == w["eps_perp"]
+        assert g["vsf"] == w["vsf"] and tuple(g["p_par"]) == tuple(w["p_par"]) and tuple(g["p_perp"]) == tuple(w["p_perp"])

@@ -45,6 +45,13 @@ def test_two_rank_gloo_control_plane(tmp_path):
     assert [r["token_len"] for r in res] == [128, 128]    # rank-0 payload reached rank 1
     assert res[0]["mine"] == list(range(24)) and res[1]["mine"] == list(range(24, 48))
     assert res[0]["owners"] == [0] * 24 and res[1]["owners"] == [1] * 24
+    # the member shards of bench.py's N > 1 leg (6 per GPU): disjoint, complete, and the perturbators
+    # each rank derives from the ensemble seed are the slices of ONE seed chain
+    from pysteps_amd.extrapolation.ensemble import steps_perturbators
+
+    assert res[0]["shard"] == list(range(6)) and res[1]["shard"] == list(range(6, 12))
+    chain = [p["eps_par"] for p in steps_perturbators(12, 42, 1.0, 5.0)]
+    assert res[0]["eps_par"] + res[1]["eps_par"] == chain and len(set(chain)) == 12
 
 
 def test_communicator_needs_gpu():
