@@ -186,6 +186,17 @@ int psh_semilag_members_state_dev(const float *precip_dev, const float *velocity
                                   const double *pert_perp_host, int n_members, int m, int n,
                                   const double *steps_host, int T, int n_iter, int interp_order,
                                   float outval, void *state_dev, int resume, float *out_dev);
+/* The same step gathering from an interleaved plane built once per motion field by
+ * psh_members_pack_dev: (m,n,4) {u,v,V_par_x,V_par_y} when vhat is given, (m,n,2) {u,v} otherwise -
+ * one dwordx4 per tap (or per tap row) instead of one dword per plane and tap: 4 loads per sampling
+ * pass instead of 16.  Bit-identical results; velocity_dev / vhat_dev are still read on image borders. */
+int psh_members_pack_dev(const float *velocity_dev, const float *vhat_dev, int m, int n, float *packed_dev);
+int psh_semilag_members_packed_dev(const float *precip_dev, const float *velocity_dev,
+                                   const float *vhat_dev, const float *packed_dev,
+                                   const double *pert_par_host, const double *pert_perp_host,
+                                   int n_members, int m, int n, const double *steps_host, int T,
+                                   int n_iter, int interp_order, float outval, void *state_dev,
+                                   int resume, float *out_dev);
 int psh_members_state_to_disp_dev(const void *state_dev, int n_members, int m, int n, double *disp_dev);
 int psh_members_disp_to_state_dev(const double *disp_dev, int n_members, int m, int n, void *state_dev);
 

@@ -79,6 +79,8 @@ SIGNATURES = {
     "psh_outliers_local_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_void_p]),
     "psh_decluster_host": (c_int, [c_void_p, c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, POINTER(c_int)]),
     "psh_velocity_unit_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "psh_members_pack_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "psh_semilag_members_packed_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_semilag_members_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_semilag_members_state_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_members_state_to_disp_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -32,9 +32,29 @@ using namespace sl;
 
 struct Planes {
   __amdgpu_buffer_rsrc_t u, v, hu, hv, p;  // velocity, unit velocity, this member's precip
+  __amdgpu_buffer_rsrc_t packed;           // {u,v,hu,hv} float4 (PERT) or {u,v} float2 per pixel, or unused
   const float *pu, *pv, *phu, *phv, *pp;   // the same as raw pointers (border path)
   int row_bytes;
 };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 bld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(byte_off), soff, 0));
+}
+__device__ __forceinline__ f32x2 splat(float w) { return f32x2{w, w}; }
+
+// blend() of semilag_device.h on two components at once (v_pk_mul_f32 / v_pk_fma_f32), same
+// operation order per component: bit-identical to the one-plane-per-component path
+__device__ __forceinline__ f32x2 blend2(const Weights &w, f32x2 a, f32x2 b, f32x2 c, f32x2 d) {
+  f32x2 acc = a * w.w00;
+  acc = __builtin_elementwise_fma(splat(w.w01), b, acc);
+  acc = __builtin_elementwise_fma(splat(w.w10), c, acc);
+  return __builtin_elementwise_fma(splat(w.w11), d, acc);
+}
 
 __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned byte_off, int soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, static_cast<int>(byte_off), soff, 0));
@@ -52,13 +72,48 @@ __device__ __forceinline__ float tap4_clamped(const float *p, int X, int Y, cons
 }
 
 // velocity of this member at (X + fx, Y + fy), mode="nearest"; optionally the precip sample too
-template <int ORDER, bool PERT, bool WITH_P>
+template <int ORDER, bool PERT, bool WITH_P, bool PACKED>
 __device__ __forceinline__ void sample_member(const Planes &F, int X, int Y, float fx, float fy, int m,
                                               int n, float a, float b, float outval, float &su,
                                               float &sv, float &sp) {
   const Weights w = make_weights(fx, fy);
   float hu = 0.f, hv = 0.f;
-  if (wave_all_interior(X, Y, m, n)) {
+  if (PACKED && wave_all_interior(X, Y, m, n)) {
+    // A vector memory instruction costs the pipeline by its width class, not by its bytes
+    // (tools/gather_probe.py: dword ~9.5 clk, dwordx4 ~17 clk per wave): with the velocity and the
+    // unit velocity interleaved per pixel one dwordx4 delivers a whole tap - 4 loads per sampling
+    // pass instead of 16 (perturbed) / 2 instead of 8 (unperturbed, {u,v} pairs: both columns of a
+    // tap row in one load).
+    const unsigned off = static_cast<unsigned>(__mul24(Y, n) + X) << 2;
+    const int rb = F.row_bytes;
+    f32x2 uv;
+    if (PERT) {
+      const unsigned o4 = off << 2;
+      const f32x4 a0 = bld4(F.packed, o4, 0), a1 = bld4(F.packed, o4 + 16u, 0);
+      const f32x4 b0 = bld4(F.packed, o4, 4 * rb), b1 = bld4(F.packed, o4 + 16u, 4 * rb);
+      uv = blend2(w, a0.xy, a1.xy, b0.xy, b1.xy);
+      const f32x2 h = blend2(w, a0.zw, a1.zw, b0.zw, b1.zw);
+      hu = h.x;
+      hv = h.y;
+    } else {
+      const unsigned o2 = off << 1;
+      const f32x4 t = bld4(F.packed, o2, 0), bb = bld4(F.packed, o2, 2 * rb);
+      uv = blend2(w, t.xy, t.zw, bb.xy, bb.zw);
+    }
+    su = uv.x;
+    sv = uv.y;
+    if (WITH_P) {
+      if (ORDER == 1) {
+        const f32x2 pt = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(F.p, static_cast<int>(off), 0, 0));
+        const f32x2 pb = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(F.p, static_cast<int>(off), rb, 0));
+        sp = blend(w, pt.x, pt.y, pb.x, pb.y);
+      } else {
+        const int xi = X + (fx >= 0.5f ? 1 : 0), yi = Y + (fy >= 0.5f ? 1 : 0);
+        sp = bld(F.p, static_cast<unsigned>(__mul24(yi, n) + xi) << 2, 0);
+      }
+    }
+    asm volatile("" ::: "memory");
+  } else if (wave_all_interior(X, Y, m, n)) {
     const unsigned off = static_cast<unsigned>(__mul24(Y, n) + X) << 2;
     su = tap4(F.u, off, F.row_bytes, w);
     sv = tap4(F.v, off, F.row_bytes, w);
@@ -95,9 +150,10 @@ __device__ __forceinline__ void sample_member(const Planes &F, int X, int Y, flo
 // record per pixel and member: integer pixel offsets (P - x, P - y) and the two fractions as
 // float32 - half the bytes of the float64 displacement pair of the reference, read and written
 // with one dwordx4 access each, and no float64 conversions in the kernel.
-template <int ORDER, bool PERT, bool HAS_PRECIP, bool COMPACT>
+template <int ORDER, bool PERT, bool HAS_PRECIP, bool COMPACT, bool PACKED>
 __global__ __launch_bounds__(256) void semilag_members(
     const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vhat,
+    const float *__restrict__ packed,
     const float *__restrict__ pert_ab, float *__restrict__ out, void *__restrict__ state,
     const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume,
     float outval, int tiles_x, int n_tiles, int tiles_per_xcd) {
@@ -123,6 +179,8 @@ __global__ __launch_bounds__(256) void semilag_members(
   F.hu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F.phu), 0, plane_bytes, 0x00020000);
   F.hv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F.phv), 0, plane_bytes, 0x00020000);
   F.p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F.pp), 0, plane_bytes, 0x00020000);
+  F.packed = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(PACKED ? packed : vel), 0,
+                                               (PERT ? 4 : 2) * plane_bytes, 0x00020000);
   F.row_bytes = n * static_cast<int>(sizeof(float));
   const float a = PERT ? pert_ab[2 * member] : 0.f, b = PERT ? pert_ab[2 * member + 1] : 0.f;
 
@@ -142,11 +200,11 @@ __global__ __launch_bounds__(256) void semilag_members(
       split_displacement(dplane[pix], px, fx);
       split_displacement(dplane[plane + pix], py, fy);
     }
-    sample_member<ORDER, PERT, false>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+    sample_member<ORDER, PERT, false, PACKED>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
     vix = su * scale[0];
     viy = sv * scale[0];
   } else {
-    sample_member<ORDER, PERT, false>(F, px, py, 0.f, 0.f, m, n, a, b, outval, su, sv, sp);
+    sample_member<ORDER, PERT, false, PACKED>(F, px, py, 0.f, 0.f, m, n, a, b, outval, su, sv, sp);
     vix = su * first_scale;  // the very first increment is not divided by n_iter (:202)
     viy = sv * first_scale;
   }
@@ -159,20 +217,20 @@ __global__ __launch_bounds__(256) void semilag_members(
         float gx = fx, gy = fy;
         retreat(mx, gx, 0.5f * vix);
         retreat(my, gy, 0.5f * viy);
-        sample_member<ORDER, PERT, false>(F, mx, my, gx, gy, m, n, a, b, outval, su, sv, sp);
+        sample_member<ORDER, PERT, false, PACKED>(F, mx, my, gx, gy, m, n, a, b, outval, su, sv, sp);
         retreat(px, fx, su * s);
         retreat(py, fy, sv * s);
         if (HAS_PRECIP && k == n_iter - 1) {
-          sample_member<ORDER, PERT, true>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+          sample_member<ORDER, PERT, true, PACKED>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
         } else {
-          sample_member<ORDER, PERT, false>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+          sample_member<ORDER, PERT, false, PACKED>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
         }
         vix = su * s;
         viy = sv * s;
       }
     } else {
       if (t > 0 || resume) {
-        sample_member<ORDER, PERT, false>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+        sample_member<ORDER, PERT, false, PACKED>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
         vix = su * s;
         viy = sv * s;
       }
@@ -180,7 +238,7 @@ __global__ __launch_bounds__(256) void semilag_members(
       retreat(py, fy, viy);
       if (HAS_PRECIP) {
         float du, dv;
-        sample_member<ORDER, false, true>(F, px, py, fx, fy, m, n, 0.f, 0.f, outval, du, dv, sp);
+        sample_member<ORDER, false, true, false>(F, px, py, fx, fy, m, n, 0.f, 0.f, outval, du, dv, sp);
       }
     }
     if (HAS_PRECIP) {
@@ -239,8 +297,35 @@ __global__ __launch_bounds__(256) void velocity_unit(const float *__restrict__ v
   }
 }
 
+// {u,v,hu,hv} (vhat given) or {u,v} per pixel for the dwordx4 gathers of the packed kernels
+__global__ __launch_bounds__(256) void members_pack(const float *__restrict__ vel, const float *__restrict__ vhat,
+                                                    size_t plane, float *__restrict__ out) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < plane; i += stride) {
+    if (vhat) {
+      reinterpret_cast<f32x4 *>(out)[i] = f32x4{vel[i], vel[plane + i], vhat[i], vhat[plane + i]};
+    } else {
+      reinterpret_cast<f32x2 *>(out)[i] = f32x2{vel[i], vel[plane + i]};
+    }
+  }
+}
+
 }  // namespace
 }  // namespace psh
+
+extern "C" int psh_members_pack_dev(const float *velocity_dev, const float *vhat_dev, int m, int n, float *packed_dev) {
+  PSH_REQUIRE_INIT();
+  if (m <= 0 || n <= 0 || !velocity_dev || !packed_dev) return psh::fail(PSH_EINVAL, "members_pack: invalid argument");
+  if (static_cast<uint64_t>(m) * n >= (1ull << 28))
+    return psh::fail(PSH_EUNSUPPORTED, "members_pack: m*n must be < 2^28 pixels (32-bit byte offsets)");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  hipLaunchKernelGGL(psh::members_pack, dim3(4096), dim3(256), 0, c.stream, velocity_dev, vhat_dev,
+                     static_cast<size_t>(m) * n, packed_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
 
 extern "C" int psh_velocity_unit_dev(const float *velocity_dev, int m, int n, float *vhat_dev) {
   PSH_REQUIRE_INIT();
@@ -256,7 +341,7 @@ extern "C" int psh_velocity_unit_dev(const float *velocity_dev, int m, int n, fl
 }
 
 static int members_step(const float *precip_dev, const float *velocity_dev, const float *vhat_dev,
-                        const double *pert_par_host, const double *pert_perp_host, int n_members, int m,
+                        const float *packed_dev, const double *pert_par_host, const double *pert_perp_host, int n_members, int m,
                         int n, const double *steps_host, int T, int n_iter, int interp_order, float outval,
                         void *disp_dev, bool compact, int resume, float *out_dev) {
   PSH_REQUIRE_INIT();
@@ -264,6 +349,8 @@ static int members_step(const float *precip_dev, const float *velocity_dev, cons
     return psh::fail(PSH_EINVAL, "semilag_members: member count %d out of range", n_members);
   if (m <= 0 || n <= 0 || static_cast<uint64_t>(m) * n >= (1ull << 29))
     return psh::fail(PSH_EINVAL, "semilag_members: invalid shape (%d,%d)", m, n);
+  if (packed_dev && static_cast<uint64_t>(m) * n >= (1ull << 28))
+    return psh::fail(PSH_EUNSUPPORTED, "semilag_members: packed planes need m*n < 2^28 pixels");
   if (T <= 0 || T > 1024) return psh::fail(PSH_EINVAL, "semilag_members: T must be in 1..1024");
   if (n_iter < 0) return psh::fail(PSH_EINVAL, "semilag_members: n_iter must be >= 0");
   if (interp_order != 0 && interp_order != 1)
@@ -297,10 +384,18 @@ static int members_step(const float *precip_dev, const float *velocity_dev, cons
   const int tiles_per_xcd = (n_tiles + psh::kNumXcd - 1) / psh::kNumXcd;
   const dim3 grid(tiles_per_xcd * psh::kNumXcd, n_members), block(256);
   const float first_scale = static_cast<float>(steps_host[0]);
-#define PSH_MEMBERS_C(ORDER, PERT, HASP, COMPACT)                                                     \
-  hipLaunchKernelGGL((psh::semilag_members<ORDER, PERT, HASP, COMPACT>), grid, block, 0, c.stream,    \
-                     precip_dev, velocity_dev, vhat_dev, d_const + T, out_dev, disp_dev, d_const,     \
+#define PSH_MEMBERS_P(ORDER, PERT, HASP, COMPACT, PACKED)                                                  \
+  hipLaunchKernelGGL((psh::semilag_members<ORDER, PERT, HASP, COMPACT, PACKED>), grid, block, 0, c.stream, \
+                     precip_dev, velocity_dev, vhat_dev, packed_dev, d_const + T, out_dev, disp_dev, d_const,  \
                      first_scale, m, n, T, n_iter, resume, outval, tiles_x, n_tiles, tiles_per_xcd)
+#define PSH_MEMBERS_C(ORDER, PERT, HASP, COMPACT)         \
+  do {                                                    \
+    if (packed_dev) {                                     \
+      PSH_MEMBERS_P(ORDER, PERT, HASP, COMPACT, true);    \
+    } else {                                              \
+      PSH_MEMBERS_P(ORDER, PERT, HASP, COMPACT, false);   \
+    }                                                     \
+  } while (0)
 #define PSH_MEMBERS(ORDER, PERT, HASP)                  \
   do {                                                  \
     if (compact) {                                      \
@@ -316,6 +411,7 @@ static int members_step(const float *precip_dev, const float *velocity_dev, cons
   } else {
     if (pert) PSH_MEMBERS(1, true, true); else PSH_MEMBERS(1, false, true);
   }
+#undef PSH_MEMBERS_P
 #undef PSH_MEMBERS_C
 #undef PSH_MEMBERS
   const hipError_t e = hipGetLastError();
@@ -328,7 +424,7 @@ extern "C" int psh_semilag_members_dev(const float *precip_dev, const float *vel
                                        const double *pert_perp_host, int n_members, int m, int n,
                                        const double *steps_host, int T, int n_iter, int interp_order,
                                        float outval, double *disp_dev, int resume, float *out_dev) {
-  return members_step(precip_dev, velocity_dev, vhat_dev, pert_par_host, pert_perp_host, n_members, m, n,
+  return members_step(precip_dev, velocity_dev, vhat_dev, nullptr, pert_par_host, pert_perp_host, n_members, m, n,
                       steps_host, T, n_iter, interp_order, outval, disp_dev, false, resume, out_dev);
 }
 
@@ -337,7 +433,18 @@ extern "C" int psh_semilag_members_state_dev(const float *precip_dev, const floa
                                              const double *pert_perp_host, int n_members, int m, int n,
                                              const double *steps_host, int T, int n_iter, int interp_order,
                                              float outval, void *state_dev, int resume, float *out_dev) {
-  return members_step(precip_dev, velocity_dev, vhat_dev, pert_par_host, pert_perp_host, n_members, m, n,
+  return members_step(precip_dev, velocity_dev, vhat_dev, nullptr, pert_par_host, pert_perp_host, n_members, m, n,
+                      steps_host, T, n_iter, interp_order, outval, state_dev, true, resume, out_dev);
+}
+
+extern "C" int psh_semilag_members_packed_dev(const float *precip_dev, const float *velocity_dev,
+                                              const float *vhat_dev, const float *packed_dev,
+                                              const double *pert_par_host, const double *pert_perp_host,
+                                              int n_members, int m, int n, const double *steps_host, int T,
+                                              int n_iter, int interp_order, float outval, void *state_dev,
+                                              int resume, float *out_dev) {
+  if (!packed_dev) return psh::fail(PSH_EINVAL, "semilag_members_packed: NULL packed plane");
+  return members_step(precip_dev, velocity_dev, vhat_dev, packed_dev, pert_par_host, pert_perp_host, n_members, m, n,
                       steps_host, T, n_iter, interp_order, outval, state_dev, true, resume, out_dev);
 }
 

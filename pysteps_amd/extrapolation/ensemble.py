@@ -65,7 +65,8 @@ class EnsembleAdvector:
     ``p_perp``, ``vsf``); the unit fields ``V_par``/``V_perp`` are rebuilt on the device.
     """
 
-    def __init__(self, velocity, n_members, perturbators=None, n_iter=1, interp_order=1, outval=np.nan):
+    def __init__(self, velocity, n_members, perturbators=None, n_iter=1, interp_order=1, outval=np.nan,
+                 packed=True):
         self._lib = _lib.lib()
         self.velocity = velocity if isinstance(velocity, DeviceArray) else DeviceArray.from_host(velocity, np.float32)
         if self.velocity.ndim != 3 or self.velocity.shape[0] != 2 or self.velocity.dtype != np.float32:
@@ -86,6 +87,12 @@ class EnsembleAdvector:
             self.vhat = DeviceArray((2, self.m, self.n), np.float32)
             _lib.check(self._lib.psh_velocity_unit_dev(self.velocity.ptr, self.m, self.n, self.vhat.ptr),
                        "psh_velocity_unit_dev")
+        # interleaved gather plane, built once per motion field: {u,v,V_par_x,V_par_y} or {u,v}
+        self.packed = None
+        if packed and self.m * self.n < (1 << 28):
+            self.packed = DeviceArray((self.m, self.n, 4 if self.vhat is not None else 2), np.float32)
+            _lib.check(self._lib.psh_members_pack_dev(self.velocity.ptr, None if self.vhat is None else self.vhat.ptr,
+                                                      self.m, self.n, self.packed.ptr), "psh_members_pack_dev")
 
     def reset(self):
         """Back to lead time zero (all displacements zero) without releasing the resident state."""
@@ -134,14 +141,15 @@ class EnsembleAdvector:
                 raise ValueError("t_total is required with velocity perturbations")
             par, perp = bps_scalars(self.perturbators, t_total)
         out = None if pm is None else DeviceArray((self.n_members, steps.size, self.m, self.n), np.float32)
-        rc = self._lib.psh_semilag_members_state_dev(
-            None if pm is None else pm.ptr, self.velocity.ptr,
-            None if self.vhat is None else self.vhat.ptr,
-            None if par is None else par.ctypes.data, None if perp is None else perp.ctypes.data,
-            self.n_members, self.m, self.n, steps.ctypes.data, int(steps.size), self.n_iter,
-            self.interp_order, self.outval, self._state.ptr, int(self._started),
-            None if out is None else out.ptr,
-        )
+        tail = (None if par is None else par.ctypes.data, None if perp is None else perp.ctypes.data,
+                self.n_members, self.m, self.n, steps.ctypes.data, int(steps.size), self.n_iter,
+                self.interp_order, self.outval, self._state.ptr, int(self._started),
+                None if out is None else out.ptr)
+        head = (None if pm is None else pm.ptr, self.velocity.ptr, None if self.vhat is None else self.vhat.ptr)
+        if self.packed is not None:
+            rc = self._lib.psh_semilag_members_packed_dev(*head, self.packed.ptr, *tail)
+        else:
+            rc = self._lib.psh_semilag_members_state_dev(*head, *tail)
         _lib.check(rc, "psh_semilag_members_state_dev")
         self._started = True
         if out is None:

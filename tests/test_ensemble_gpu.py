@@ -125,3 +125,24 @@ def test_compact_state_float64_entry_and_restart():
     assert np.array_equal(again.step(members, 0.5), want, equal_nan=True)
     with pytest.raises(ValueError):
         again.displacement = d_host[:, :1]
+
+
+@pytest.mark.parametrize("perturb,n_iter,order", [(True, 1, 1), (False, 1, 1), (True, 3, 1), (True, 0, 0), (False, 2, 0)])
+def test_packed_gather_planes_are_bit_identical(perturb, n_iter, order):
+    """The interleaved-plane kernels (one dwordx4 per tap) against the one-plane-per-component ones."""
+    from pysteps_amd.extrapolation.ensemble import EnsembleAdvector
+    from tools import synth
+
+    B, m, n = 3, 150, 257  # odd width: border waves, unaligned rows
+    members = np.stack([synth.rain_field_db(m, n, seed=80 + j, sigma=2.0) for j in range(B)])
+    members[1, 40:50, 100:120] = np.nan
+    V = synth.true_velocity(m, n) * 1.7
+    V[:, 7, 9] = 0.0
+    perts = _perturbators(B, 11) if perturb else None
+    a = EnsembleAdvector(V, B, perts, n_iter=n_iter, interp_order=order, outval=-15.0, packed=True)
+    b = EnsembleAdvector(V, B, perts, n_iter=n_iter, interp_order=order, outval=-15.0, packed=False)
+    assert a.packed is not None and b.packed is None
+    for dt, t_total in [(1.0, 5.0), (0.5, 7.5), (2.0, 17.5)]:
+        ga, gb = a.step(members, dt, t_total), b.step(members, dt, t_total)
+        assert np.array_equal(ga, gb, equal_nan=True)
+    assert np.array_equal(a.displacement.to_host(), b.displacement.to_host())
