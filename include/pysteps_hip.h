@@ -83,6 +83,10 @@ int psh_db_transform_dev(const float *in_dev, float *out_dev, size_t n, double t
  * the float64 arrays pysteps works with cross the bus as they are instead of being narrowed /
  * widened by a host pass. */
 int psh_convert_dev(const void *in_dev, void *out_dev, size_t n, int to_f64);
+/* pysteps/utils/check_norain.py:40-50 on a resident field: number of values > threshold (NaN never
+ * counts) and np.nanmin of the field; a NaN threshold means "the minimum of the field"
+ * (precip_thr=None).  Synchronous. */
+int psh_count_above_dev(const float *in_dev, size_t n, double threshold, double *count_out, double *nanmin_out);
 int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *max_out,
                         double *nonfinite_out);
 

@@ -86,6 +86,18 @@ __global__ __launch_bounds__(256) void field_stats(const float *__restrict__ in,
   }
 }
 
+// number of elements > thr (NaN compares false, like NumPy): the rain-pixel count of
+// pysteps/utils/check_norain.py:48-49
+__global__ __launch_bounds__(256) void count_above(const float *__restrict__ in, size_t n, float thr,
+                                                   unsigned long long *__restrict__ total) {
+  unsigned cnt = 0;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) cnt += in[i] > thr ? 1u : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(total, static_cast<unsigned long long>(cnt));  // integer: order-free
+}
+
 template <typename Tin, typename Tout>
 __global__ __launch_bounds__(256) void convert_elements(const Tin *__restrict__ in, Tout *__restrict__ out, size_t n) {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
@@ -175,6 +187,38 @@ int field_stats_full(const float *in_dev, size_t n, FieldStats *st) {
 }
 
 }  // namespace psh
+
+extern "C" int psh_count_above_dev(const float *in_dev, size_t n, double threshold, double *count_out,
+                                   double *nanmin_out) {
+  PSH_REQUIRE_INIT();
+  if ((!in_dev && n) || !count_out) return psh::fail(PSH_EINVAL, "count_above: NULL pointer");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  psh::FieldStats st;
+  if (int rc = psh::field_stats_full(in_dev, n, &st)) return rc;
+  const double lowest = st.nanmin();
+  if (nanmin_out) *nanmin_out = lowest;
+  // threshold NaN = "use the minimum of the field" (precip_thr=None, check_norain.py:46-47)
+  const float thr = static_cast<float>(threshold != threshold ? lowest : threshold);
+  void *blk = nullptr;
+  if (int rc = psh_malloc(&blk, sizeof(unsigned long long))) return rc;
+  unsigned long long h = 0;
+  auto run = [&]() -> int {
+    PSH_HIP(hipMemsetAsync(blk, 0, sizeof(unsigned long long), c.stream));
+    hipLaunchKernelGGL(psh::count_above, dim3(c.cu_count * 8), dim3(256), 0, c.stream, in_dev, n, thr,
+                       static_cast<unsigned long long *>(blk));
+    PSH_HIP(hipGetLastError());
+    PSH_HIP(hipMemcpyAsync(&h, blk, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    return PSH_OK;
+  };
+  const int rc = run();
+  (void)psh_free(blk);
+  if (rc) return rc;
+  *count_out = static_cast<double>(h);
+  return PSH_OK;
+}
 
 extern "C" int psh_convert_dev(const void *in_dev, void *out_dev, size_t n, int to_f64) {
   PSH_REQUIRE_INIT();

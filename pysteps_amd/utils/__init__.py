@@ -3,3 +3,4 @@
 from .cleansing import decluster, detect_outliers, detect_outliers_device  # noqa: F401
 from .interpolate import idwinterp2d  # noqa: F401
 from .transformation import dB_transform  # noqa: F401,E402
+from .check_norain import check_norain  # noqa: F401,E402

@@ -287,3 +287,28 @@ def test_steps_with_the_resident_member_batched_loop(pysteps, timesteps, vel_per
     assert got.dtype == want.dtype
     rel = _ensemble_close(got, want)
     assert rel < 1e-4, rel
+
+
+def test_check_norain_mirror_matches_the_reference(pysteps):
+    """utils/check_norain.py:6-58 against pysteps_amd.utils.check_norain, host and device."""
+    from pysteps.utils.check_norain import check_norain as ref_check
+    from pysteps_amd.device import DeviceArray
+    from pysteps_amd.utils import check_norain
+    from tools import synth
+
+    m, n = 180, 200
+    db = synth.rain_field_db(m, n, seed=12, sigma=3.0)
+    dry = np.full((m, n), -15.0, np.float32)
+    holes = db.copy()
+    holes[:20] = np.nan
+    cases = [(db, None, 0.0), (db, -10.0, 0.0), (db, 5.0, 0.3), (db, 5.0, 0.01), (dry, None, 0.0), (dry, -15.0, 0.0),
+             (holes, None, 0.0), (holes, 0.0, 0.25)]
+    for arr, thr, frac in cases:
+        want = ref_check(arr, thr, frac, None, False)
+        assert check_norain(arr, thr, frac, None, False) == want
+        assert check_norain(DeviceArray.from_host(arr), thr, frac, None, False) == want
+    for win in ("hann", "tukey"):
+        assert check_norain(db, -10.0, 0.0, win, False) == ref_check(db, -10.0, 0.0, win, False)
+        assert check_norain(DeviceArray.from_host(db), -10.0, 0.2, win, False) == ref_check(db, -10.0, 0.2, win, False)
+    stack = np.stack([db, dry])
+    assert check_norain(stack, -10.0, 0.0, None, False) == ref_check(stack, -10.0, 0.0, None, False)
