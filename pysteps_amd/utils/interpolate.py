@@ -109,13 +109,20 @@ def idwinterp2d(xy_coord, values, xgrid, ygrid, power=0.5, k=20, dist_offset=0.5
         return np.ones((nvar,) + grid_shape) * values.ravel()[0]
 
     ax, ay = _regular_axis(xgrid, "xgrid"), _regular_axis(ygrid, "ygrid")
+    why = None
     if ax is None or ay is None or xy_coord.shape[1] != 2:
+        why = "irregular grid or coordinates that are not 2-d"
+    elif k is not None and 32 < k < nsamples:
+        why = "k=%r (the kernel keeps at most 32 neighbours unless k covers all samples)" % (k,)
+    elif not power > 0:
+        why = "power=%r (the kernel needs power > 0)" % (power,)
+    if why is not None:  # outside the kernel's limits: the reference takes the call
         ref = _reference_idw()
         if ref is None:
             raise NotImplementedError(
-                "pysteps_amd idwinterp2d needs regularly spaced xgrid/ygrid and 2-d coordinates"
+                "pysteps_amd idwinterp2d: %s is not implemented on the HIP path and pysteps is not importable" % why
             )
-        warnings.warn("pysteps_amd idwinterp2d: irregular grid -> delegating to the reference CPU path")
+        warnings.warn("pysteps_amd idwinterp2d: %s -> delegating to the reference CPU path" % why)
         return ref(xy_coord, values, xgrid, ygrid, power=power, k=k, dist_offset=dist_offset, **kwargs)
 
     lib = _lib.lib()

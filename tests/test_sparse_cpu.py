@@ -151,3 +151,35 @@ def test_decluster_native_orderings():
         wc, wv = osp.decluster(xy, uv, scale, min_samples)
         assert gc.shape == wc.shape
         assert np.array_equal(gc, wc) and np.array_equal(gv, wv)
+
+
+def test_parameters_beyond_the_kernel_limits_reach_the_reference(ref_pysteps):
+    """interp_kwargs / fd_kwargs the kernels do not implement (IDW with 32 < k < nsamples,
+    power <= 0; Shi-Tomasi block_size even or > 7; windows > 64) must behave like stock pysteps
+    when pysteps is importable - delegated with a warning, not an error from the library."""
+    import warnings
+
+    from pysteps.exceptions import MissingOptionalDependency
+    from pysteps.utils.interpolate import idwinterp2d as ref_idw
+    from pysteps_amd.motion.lucaskanade import dense_lucaskanade
+    from pysteps_amd.utils.interpolate import idwinterp2d
+
+    rng = np.random.default_rng(5)
+    xy = np.column_stack([rng.integers(0, 60, 120), rng.integers(0, 50, 120)]).astype(float)
+    uv = rng.normal(0, 1, (120, 2))
+    xg, yg = np.arange(60), np.arange(50)
+    for kw in (dict(k=50), dict(power=0.0), dict(power=-1.0, k=10)):
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            got = idwinterp2d(xy, uv, xg, yg, **kw)
+        assert any("delegating to the reference" in str(w.message) for w in caught)
+        assert np.array_equal(got, ref_idw(xy, uv, xg, yg, **kw), equal_nan=True)
+    frames = rng.random((2, 64, 64)).astype(np.float32)
+    for bad in (dict(fd_kwargs={"block_size": 4}), dict(fd_kwargs={"block_size": 9}), dict(lk_kwargs={"winsize": (80, 80)}),
+                dict(interp_kwargs={"k": 50})):
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            # the reference takes the call; here it stops at its own first line: OpenCV is not installed
+            with pytest.raises(MissingOptionalDependency):
+                dense_lucaskanade(frames, **bad)
+        assert any("delegating to the reference" in str(w.message) for w in caught)
