@@ -245,10 +245,79 @@ def pmc_traffic(workload):
         return None
 
 
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 vector peak
+LK_STREAM_KERNELS = ("lk_stats1", "lk_stats1_final", "lk_open_vec", "lk_open", "lk_open_final", "lk_to_u8",
+                     "lk_corner_response", "lk_max_final", "lk_corner_select", "lk_pyrdown", "lk_scharr")
+LK_STREAM_BYTES_PER_PX_PAIR = 42.5  # ~40-45 B / pixel / frame pair of compulsory streaming
+
+
+def roofline_lk(frames_d, m, n, pairs):
+    """Second-tier rooflines of the motion estimate, from the committed rocprofv3 kernel
+    averages of the SAME workload (profiles/kernel_stats_latest.json, written by
+    tools/collect_profiles.py): the IDW kernel against the FP32 vector peak with the brute-force
+    work model L x 8 flop per pixel, the streaming image passes against HBM with ~42.5 B per pixel
+    and frame pair.  None if the committed profile is for another size."""
+    path = os.path.join(ROOT, "profiles", "kernel_stats_latest.json")
+    try:
+        with open(path) as fh:
+            prof = json.load(fh)
+        if prof.get("workload") not in (None, "%dx%d" % (m, n)):
+            return None
+        kern = prof["kernels"]
+    except Exception:
+        return None
+    from pysteps_amd import motion
+    from pysteps_amd.utils import decluster
+
+    xy, uv = motion.get_method("LK")(frames_d.to_host(), dense=False)
+    L = len(decluster(xy, uv, 20, 1)[0]) if len(xy) else 0
+    out = {"source": prof.get("source"), "vectors_interpolated": L}
+    if "idw_fine" in kern and L:
+        ms = (kern["idw_fine"]["avg_ns"] + kern.get("idw_coarse", {}).get("avg_ns", 0.0)) / 1e6
+        flops = 8.0 * L * m * n
+        out["idw"] = {"kernel": "idw_coarse + idw_fine", "bound": "fp32 valu", "kernel_ms": ms,
+                      "model_flops": flops, "achieved": flops / (ms * 1e-3) / 1e12, "peak": FP32_VALU_PEAK_TFLOPS,
+                      "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                      "note": "work model = brute force over all L vectors; the kernel prunes to ~60 candidates per "
+                              "tile, so frac > what the VALUs really execute"}
+    ns = sum(kern[k]["ns_per_step"] for k in LK_STREAM_KERNELS if k in kern)
+    if ns:
+        nbytes = LK_STREAM_BYTES_PER_PX_PAIR * m * n * pairs
+        out["image_passes"] = {"kernels": [k for k in LK_STREAM_KERNELS if k in kern], "bound": "hbm",
+                               "ms_per_step": ns / 1e6, "alg_bytes_per_step": nbytes,
+                               "achieved": nbytes / (ns * 1e-9) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": nbytes / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS,
+                               "per_kernel_ms": {k: kern[k]["ns_per_step"] / 1e6 for k in LK_STREAM_KERNELS if k in kern}}
+    return out
+
+
 def compulsory_bytes(m, n, T, K):
     """What one launch cannot avoid moving to / from HBM: the T output planes once, the three
     input planes once."""
     return (T + 3.0) * m * n * 4.0
+
+
+class stdout_to_stderr:
+    """RCCL prints its version banner with printf on stdout (buffered by libc until exit): route the
+    file descriptor to stderr while the communicator comes up, so that stdout carries the ONE JSON
+    line and nothing else."""
+
+    def __enter__(self):
+        import ctypes
+
+        self.libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
 
 
 def members_workload(precip_d, vel_d, n_members, first_member, n_total, T, K):
@@ -403,6 +472,8 @@ def main():
     rf = line["roofline"]
     rf["hbm_frac"] = (rf["traffic"] / (sl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rf["traffic"] else None
     rf["floor_ms"] = compulsory_bytes(m, n, T, K) / (HBM_PEAK_GBS * 1e9) * 1e3
+    if have_lk:
+        line["roofline_lk"] = roofline_lk(frames_d, m, n, args.frames - 1)
     if not args.no_host_path:
         line["config"].update(host_path(frames_d, vel_d, T, K))
     if not args.no_members_leg:
@@ -448,9 +519,10 @@ def main_members(args, dist, dense_lk):
     ok = 1.0
     err = None
     try:
-        comm = parallel.Communicator(dist.rank, dist.world, dist.broadcast_bytes)
-        comm.broadcast(pack, root=0)
-        synchronize()
+        with stdout_to_stderr():
+            comm = parallel.Communicator(dist.rank, dist.world, dist.broadcast_bytes)
+            comm.broadcast(pack, root=0)
+            synchronize()
     except Exception as exc:
         ok, err = 0.0, exc
     if dist.max(1.0 - ok) > 0.0:

@@ -88,7 +88,9 @@ def test_bench_multi_rank_path_runs_at_world_size_one():
          "--steps", "2", "--warmup", "1", "--members-per-gpu", "3"],
         cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
-    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    lines = proc.stdout.strip().splitlines()
+    assert len(lines) == 1, lines  # ONE JSON line on stdout, RCCL's banner included nowhere
+    line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1
     assert "config 4" in line["config"]["workload"] and line["roofline"]["kernel"] == "semilag_members"
     assert line["value"] > 0 and line["config"]["broadcast_bytes"] == 3 * 512 * 512 * 4

@@ -13,6 +13,27 @@ for name in ("bench.json", "pytest_gpu.txt"):
 for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, "%s_rocprofv3_kernel_stats.csv" % prefix))
 
+# per-kernel averages of the traced bench run (5 timed + 2 warm-up steps) for bench.py's roofline_lk
+STEPS_TRACED = 7
+for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+    table = {}
+    for r in csv.DictReader(open(f)):
+        name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].split("::")[-1].strip()
+        if name.startswith("void "):
+            name = name[5:]
+        rec = table.setdefault(name, {"calls": 0, "total_ns": 0.0})
+        rec["calls"] += int(r["Calls"])
+        rec["total_ns"] += float(r["TotalDurationNs"])
+    for rec in table.values():
+        rec["avg_ns"] = rec["total_ns"] / max(rec["calls"], 1)
+        rec["ns_per_step"] = rec["total_ns"] / STEPS_TRACED
+    json.dump({"source": "profiles/%s/%s_rocprofv3_kernel_stats.csv" % (rnd, prefix), "steps_traced": STEPS_TRACED,
+               "workload": "4096x4096",
+               "note": "ns_per_step also spreads the input synthesis launches of semilag_fused over the steps; "
+                       "LK kernels only run inside steps", "kernels": table},
+              open(os.path.join("profiles", "kernel_stats_latest.json"), "w"), indent=1)
+
+
 def mean_counter(sub, counter, kernel):
     vals = []
     for f in glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv")):
