@@ -278,6 +278,37 @@ int psh_lk_corners_finish(float *points_host, int *count_host);
 int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m,
                         int n, int win_w, int win_h, int max_level, void **handle_out);
 int psh_lk_pyramids_free(void *handle);
+
+/* Row bands of the image passes for frames tiled over several GPUs (BASELINE config 5).  Every rank
+ * holds the whole frame and processes rows [e0, e1) - its own rows [r0, r1) plus a halo - as a
+ * sub-image; results land at their absolute rows in full-size buffers and are exact except within a
+ * few rows of band edges that are not frame borders.  Statistics and corner candidates are taken
+ * from the OWN rows only and combined across ranks by the caller:
+ *   stats   -> stats[0] min, stats[1] NaN count of the own rows             then allreduce MIN / SUM
+ *   open    -> opening of the band (needs the global stats[0..1]); stats[2] max, stats[3] / stats[4]
+ *              min / max of the feature rendering over the own rows          then allreduce MAX / MIN / MAX
+ *   to_u8   -> both uint8 renderings of the band (needs the global stats[0..4])
+ *   response-> Shi-Tomasi response of the band, stats[5] its maximum over the own rows   then allreduce MAX
+ *   select  -> candidates of the own rows as (response bits << 32 | absolute pixel address) keys, any
+ *              order (the caller gathers the keys of all ranks, sorts them descending and runs
+ *              psh_lk_greedy_host - the walking order of goodFeaturesToTrack)
+ * psh_lk_pyramids_band turns a pyramid built by psh_lk_pyramids_dev from the band sub-images (rows
+ * [band_first_row, ...) of a frame_rows-row frame; band_first_row a multiple of 2^levels) into a view of
+ * the whole-frame pyramid: points are given and tracked in whole-frame coordinates (bit-identical
+ * arithmetic), only the stored rows differ.  Tracks whose windows leave the rows that equal the
+ * whole-frame pyramid come back with status bit 1 (value 2 / 3) set and have to be redone on
+ * whole-frame data.  PSH_EUNSUPPORTED if the band is too small for the frame's number of levels. */
+int psh_lk_band_stats_dev(const float *frame_dev, int m, int n, int r0, int r1, float *stats_dev);
+int psh_lk_band_open_dev(const float *frame_dev, int m, int n, int e0, int e1, int r0, int r1, int size_opening,
+                         int buffer_mask, float *clean_dev, float *stats_dev);
+int psh_lk_band_to_u8_dev(const float *clean_dev, int m, int n, int e0, int e1, int buffer_mask, const float *stats_dev,
+                          unsigned char *track_u8_dev, unsigned char *feature_u8_dev);
+int psh_lk_band_response_dev(const unsigned char *feature_u8_dev, const float *clean_dev, int m, int n, int e0, int e1,
+                             int r0, int r1, int block_size, int buffer_mask, float *stats_dev, float *eig_dev);
+int psh_lk_band_select_dev(const float *eig_dev, const float *clean_dev, int m, int n, int e0, int e1, int r0, int r1,
+                           int buffer_mask, double quality_level, const float *stats_dev,
+                           unsigned long long *keys_dev, int cap, int *count_dev);
+int psh_lk_pyramids_band(void *handle, int frame_rows, int band_first_row, int *top_level_out);
 int psh_lk_track_pyr_dev(void *handle, const float *points_host, int npts, int max_count,
                          double epsilon, double min_eig_threshold, float *next_points_host,
                          unsigned char *status_host);
@@ -334,12 +365,19 @@ int psh_decluster_host(const double *xy, const double *values, int n, double sca
  *  psh_comm_unique_id   rank 0: 128-byte ncclUniqueId to hand to every rank (any host channel)
  *  psh_comm_init        collective: ncclCommInitRank on the GPU bound by psh_init()
  *  psh_comm_broadcast   in-place ncclBroadcast of nbytes from root, on the library stream
- *  psh_comm_allgather   ncclAllGather of nbytes_per_rank (sparse vector lists), library stream */
+ *  psh_comm_allgather   ncclAllGather of nbytes_per_rank (sparse vector lists), library stream
+ *  psh_comm_allreduce_f32  in-place ncclAllReduce of `count` floats (PSH_COMM_MIN / MAX / SUM): the global
+ *                       min / max of the uint8 rescales and the maximum corner response of the row-band
+ *                       Lucas-Kanade passes (tracking/lucaskanade.py:143-160, shitomasi.py:143-151) */
+#define PSH_COMM_SUM 0
+#define PSH_COMM_MAX 1
+#define PSH_COMM_MIN 2
 int psh_comm_unique_id_bytes(void);
 int psh_comm_unique_id(void *id_out);
 int psh_comm_init(const void *id, int nranks, int rank);
 int psh_comm_broadcast(void *buf_dev, size_t nbytes, int root);
 int psh_comm_allgather(const void *send_dev, void *recv_dev, size_t nbytes_per_rank);
+int psh_comm_allreduce_f32(float *buf_dev, size_t count, int op);
 int psh_comm_destroy(void);
 
 #ifdef __cplusplus

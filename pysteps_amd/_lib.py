@@ -76,6 +76,7 @@ SIGNATURES = {
     "psh_comm_init": (c_int, [c_void_p, c_int, c_int]),
     "psh_comm_broadcast": (c_int, [c_void_p, c_size_t, c_int]),
     "psh_comm_allgather": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "psh_comm_allreduce_f32": (c_int, [c_void_p, c_size_t, c_int]),
     "psh_comm_destroy": (c_int, []),
     "psh_outliers_local_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_void_p]),
     "psh_decluster_host": (c_int, [c_void_p, c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, POINTER(c_int)]),
@@ -90,6 +91,12 @@ SIGNATURES = {
     "psh_lk_corners_finish": (c_int, [c_void_p, POINTER(c_int)]),
     "psh_lk_pyramids_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "psh_lk_pyramids_free": (c_int, [c_void_p]),
+    "psh_lk_pyramids_band": (c_int, [c_void_p, c_int, c_int, POINTER(c_int)]),  # handle, frame_rows, band_first_row, top
+    "psh_lk_band_stats_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "psh_lk_band_open_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "psh_lk_band_to_u8_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "psh_lk_band_response_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "psh_lk_band_select_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int, c_void_p]),
     "psh_lk_track_pyr_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
     "psh_db_transform_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_double, c_double, c_int]),
     "psh_field_stats_dev": (c_int, [c_void_p, c_size_t, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),

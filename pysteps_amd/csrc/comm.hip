@@ -26,8 +26,10 @@ using CommInitRankFn = int (*)(Comm *, int, UniqueId, int);
 using CommDestroyFn = int (*)(Comm);
 using BroadcastFn = int (*)(const void *, void *, size_t, int, int, Comm, hipStream_t);
 using AllGatherFn = int (*)(const void *, void *, size_t, int, Comm, hipStream_t);
+using AllReduceFn = int (*)(const void *, void *, size_t, int, int, Comm, hipStream_t);
 using ErrStrFn = const char *(*)(int);
-constexpr int kNcclUint8 = 1;
+constexpr int kNcclUint8 = 1, kNcclFloat32 = 7;       // ncclDataType_t
+constexpr int kNcclSum = 0, kNcclMax = 2, kNcclMin = 3;  // ncclRedOp_t
 
 struct Rccl {
   void *handle = nullptr;
@@ -36,6 +38,7 @@ struct Rccl {
   CommDestroyFn comm_destroy = nullptr;
   BroadcastFn broadcast = nullptr;
   AllGatherFn all_gather = nullptr;
+  AllReduceFn all_reduce = nullptr;
   ErrStrFn err_str = nullptr;
   Comm comm = nullptr;
   int nranks = 0, rank = -1;
@@ -60,8 +63,9 @@ int load_rccl() {
   r.comm_destroy = reinterpret_cast<CommDestroyFn>(dlsym(r.handle, "ncclCommDestroy"));
   r.broadcast = reinterpret_cast<BroadcastFn>(dlsym(r.handle, "ncclBroadcast"));
   r.all_gather = reinterpret_cast<AllGatherFn>(dlsym(r.handle, "ncclAllGather"));
+  r.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(r.handle, "ncclAllReduce"));
   r.err_str = reinterpret_cast<ErrStrFn>(dlsym(r.handle, "ncclGetErrorString"));
-  if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.broadcast || !r.all_gather)
+  if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.broadcast || !r.all_gather || !r.all_reduce)
     return fail(PSH_ECOMM, "librccl.so lacks an expected symbol");
   return PSH_OK;
 }
@@ -136,6 +140,21 @@ int psh_comm_allgather(const void *send_dev, void *recv_dev, size_t nbytes_per_r
   if (nbytes_per_rank == 0) return PSH_OK;
   if (int rc = rccl().all_gather(send_dev, recv_dev, nbytes_per_rank, psh::kNcclUint8, rccl().comm, c.stream))
     return psh::rccl_fail("ncclAllGather", rc);
+  return PSH_OK;
+}
+
+int psh_comm_allreduce_f32(float *buf_dev, size_t count, int op) {
+  PSH_REQUIRE_INIT();
+  if (!rccl().comm) return fail(PSH_ECOMM, "psh_comm_allreduce: communicator not initialised");
+  if (!buf_dev && count) return fail(PSH_EINVAL, "psh_comm_allreduce: NULL buffer");
+  const int red = op == PSH_COMM_MIN ? psh::kNcclMin : op == PSH_COMM_MAX ? psh::kNcclMax : op == PSH_COMM_SUM ? psh::kNcclSum : -1;
+  if (red < 0) return fail(PSH_EINVAL, "psh_comm_allreduce: unknown reduction %d", op);
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  if (count == 0) return PSH_OK;
+  if (int rc = rccl().all_reduce(buf_dev, buf_dev, count, psh::kNcclFloat32, red, rccl().comm, c.stream))
+    return psh::rccl_fail("ncclAllReduce", rc);
   return PSH_OK;
 }
 

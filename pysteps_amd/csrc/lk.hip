@@ -40,6 +40,16 @@ enum Stat : int {
 
 constexpr int kRedBlocks = 1024;
 
+// Row band of a frame that is processed as a sub-image (multi-GPU tiling, lk_band.hip): the
+// kernels run on the rows [y_org, y_org + m) of the full frame through an offset pointer; y_org
+// restores the absolute row index where the reference's semantics depend on it (the row 0 / 1 quirk
+// of shitomasi.py:140, pixel addresses of corner candidates), [lo, hi) are the sub-image rows that
+// contribute to statistics / candidates (the rows this rank owns; the rest is halo).  The whole
+// frame is {0, 0, m}.
+struct Band {
+  int y_org, lo, hi;
+};
+
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (n == 1) return 0;
   if (i < 0) i = -i;
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(256) void lk_open(const float *__restrict__ img, in
                                                int size_opening, int buffer_mask,
                                                const float *__restrict__ stats,
                                                float *__restrict__ clean,
-                                               float *__restrict__ partial) {
+                                               float *__restrict__ partial, Band band) {
   __shared__ unsigned char fld[kOpenTY + 4][kOpenTX + 4];  // 1 = in field, 2 = outside the image
   __shared__ unsigned char ero[kOpenTY + 2][kOpenTX + 2];
   __shared__ float red[3][4];
@@ -192,9 +202,9 @@ __global__ __launch_bounds__(256) void lk_open(const float *__restrict__ img, in
       if (!opened) v = mn;
     }
     clean[static_cast<size_t>(y) * n + x] = v;
-    if (isfinite(v)) {
+    if (isfinite(v) && y >= band.lo && y < band.hi) {
       mx_all = fmaxf(mx_all, v);
-      if (y >= first_row) {
+      if (y + band.y_org >= first_row) {
         mn_feat = fminf(mn_feat, v);
         mx_feat = fmaxf(mx_feat, v);
       }
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256) void lk_open_vec(const float *__restrict__ img
                                                    int size_opening, int buffer_mask,
                                                    const float *__restrict__ stats,
                                                    float *__restrict__ clean,
-                                                   float *__restrict__ partial) {
+                                                   float *__restrict__ partial, Band band) {
   constexpr int kW4 = kOpenTX / 4 + 2;  // float4 columns of the haloed tile
   __shared__ unsigned char fld[kOpenTY + 4][kW4 * 4];  // column c <-> image x0 - 4 + c
   __shared__ unsigned char ero[kOpenTY + 2][kOpenTX + 2];
@@ -272,9 +282,9 @@ __global__ __launch_bounds__(256) void lk_open_vec(const float *__restrict__ img
                               ero[cy][cx + 1];
           if (!opened) v[j] = mn;
         }
-        if (isfinite(v[j])) {
+        if (isfinite(v[j]) && y >= band.lo && y < band.hi) {
           mx_all = fmaxf(mx_all, v[j]);
-          if (y >= first_row) {
+          if (y + band.y_org >= first_row) {
             mn_feat = fminf(mn_feat, v[j]);
             mx_feat = fmaxf(mx_feat, v[j]);
           }
@@ -331,10 +341,10 @@ __device__ __forceinline__ unsigned char quantise(float v, float lo, float hi) {
 __global__ __launch_bounds__(256) void lk_to_u8(const float *__restrict__ clean, int m, int n,
                                                 int buffer_mask, const float *__restrict__ stats,
                                                 unsigned char *__restrict__ trk,
-                                                unsigned char *__restrict__ feat) {
+                                                unsigned char *__restrict__ feat, int y_org) {
   const float fill = stats[kMinAll], hi = stats[kMaxAll];
   const float flo = stats[kMinFeat], fhi = stats[kMaxFeat];
-  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+  const int first_row = max((buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0) - y_org, 0);
   const size_t npx = static_cast<size_t>(m) * n;
   const size_t first_feature_px = static_cast<size_t>(first_row) * n;
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
@@ -391,7 +401,7 @@ template <int BS>
 __global__ __launch_bounds__(256) void lk_corner_response(
     const unsigned char *__restrict__ u8, const float *__restrict__ clean, int m, int n,
     int buffer_mask, const float *__restrict__ stats, float *__restrict__ eig,
-    float *__restrict__ partial) {
+    float *__restrict__ partial, Band band) {
   constexpr int H = kMaxBlockR + 1;  // Sobel (1) + box radius (<= 3)
   constexpr int block_size = BS;
   __shared__ float tile[kCrnTY + 2 * H][kCrnTX + 2 * H];
@@ -472,7 +482,8 @@ __global__ __launch_bounds__(256) void lk_corner_response(
         const float c = static_cast<float>(win[2]) * 0.5f;
         const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
         eig[static_cast<size_t>(y) * n + x] = e;
-        if (px_allowed(clean, m, n, x, y, buffer_mask, any_nan)) best = fmaxf(best, fmaxf(e, 0.f));
+        if (y >= band.lo && y < band.hi && px_allowed(clean, m, n, x, y, buffer_mask, any_nan))
+          best = fmaxf(best, fmaxf(e, 0.f));
       }
     }
   }
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
                                                         int n, int buffer_mask, float quality,
                                                         const float *__restrict__ stats,
                                                         CornerKey *__restrict__ out, int cap,
-                                                        int *__restrict__ count) {
+                                                        int *__restrict__ count, Band band) {
   __shared__ int wave_count[4];
   __shared__ int block_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -549,7 +560,9 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
     float v;
-    masks[r] = __ballot(corner_keep(eig, clean, m, n, x, y_first + r, buffer_mask, thr, any_nan, v));
+    const int yr = y_first + r;
+    masks[r] = __ballot(yr >= band.lo && yr < band.hi &&
+                        corner_keep(eig, clean, m, n, x, yr, buffer_mask, thr, any_nan, v));
     mine += __popcll(masks[r]);
   }
   if (lane == 0) wave_count[wave] = mine;
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
     if ((mask >> lane) & 1ull) {
       const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
       if (at < cap)
-        out[at] = make_corner_key(eig[static_cast<size_t>(y) * n + x], static_cast<unsigned>(y) * n + x);
+        out[at] = make_corner_key(eig[static_cast<size_t>(y) * n + x], static_cast<unsigned>(y + band.y_org) * n + x);
     }
     pos += __popcll(mask);
   }
@@ -640,7 +653,22 @@ struct PyrLevel {
   const unsigned char *I, *J;  // previous / next frame at this level
   const short2 *dI;            // Scharr gradients of I
   int rows, cols;
+  // rows [vlo, vhi) hold the values the pyramid of the WHOLE frame has there.  Whole frames:
+  // everything; row bands processed as sub-images (multi-GPU tiling): all but a margin at the edges
+  // that are not frame borders.  A track whose windows leave that range is marked (status bit 1)
+  // and redone on whole-frame data by the caller.
+  int vlo = -(1 << 30), vhi = 1 << 30;
+  // band pyramids store the rows [row_org, row_org + rows_stored) of the level only; `rows` stays
+  // the height of the whole level, so that positions, reflections and border tests are computed
+  // in whole-frame coordinates (float positions round by their magnitude: shifting the origin
+  // would change low-order bits of the tracks)
+  int row_org = 0, rows_stored = 1 << 30;
 };
+// offset of (whole-level) row y in the stored rows; rows outside the band are clamped (such
+// accesses are marked through vlo / vhi, they only must not leave the allocation)
+__device__ __forceinline__ size_t stored_row(const PyrLevel &L, int y) {
+  return static_cast<size_t>(min(max(y - L.row_org, 0), L.rows_stored - 1));
+}
 struct Pyramid {
   PyrLevel lv[kMaxLevels];
   int top;  // index of the coarsest level
@@ -680,7 +708,7 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
   const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
   const float2 pt = pts[p];
   float nx = 0.f, ny = 0.f;  // tracked position (with half window added back)
-  bool ok = true;
+  bool ok = true, suspect = false;
   // window samples of this thread (the same on every level and iteration): sample i = tid + 256 q
   int wxs[kPer], wys[kPer];
 #pragma unroll
@@ -704,6 +732,7 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
     px -= half_x;
     py -= half_y;
     const int ipx = static_cast<int>(floorf(px)), ipy = static_cast<int>(floorf(py));
+    if (ipy - 1 < L.vlo || ipy + win_h + 2 > L.vhi) suspect = true;
     if (ipx < -win_w || ipx >= L.cols || ipy < -win_h || ipy >= L.rows) {
       if (level == 0) ok = false;
       continue;
@@ -722,16 +751,16 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
         // image taps: reflect-101 padding; gradient taps: zero outside the image
         const int xa = reflect101(x, L.cols), xb = reflect101(x + 1, L.cols);
         const int ya = reflect101(y, L.rows), yb = reflect101(y + 1, L.rows);
-        const unsigned char *ra = L.I + static_cast<size_t>(ya) * L.cols;
-        const unsigned char *rb = L.I + static_cast<size_t>(yb) * L.cols;
+        const unsigned char *ra = L.I + stored_row(L, ya) * L.cols;
+        const unsigned char *rb = L.I + stored_row(L, yb) * L.cols;
         const int ival = descale(ra[xa] * w00 + ra[xb] * w01 + rb[xa] * w10 + rb[xb] * w11, 14 - 5);
         const bool x_in0 = x >= 0 && x < L.cols, x_in1 = x + 1 >= 0 && x + 1 < L.cols;
         const bool y_in0 = y >= 0 && y < L.rows, y_in1 = y + 1 >= 0 && y + 1 < L.rows;
         const short2 z = make_short2(0, 0);
-        const short2 g00 = (x_in0 && y_in0) ? L.dI[static_cast<size_t>(y) * L.cols + x] : z;
-        const short2 g01 = (x_in1 && y_in0) ? L.dI[static_cast<size_t>(y) * L.cols + x + 1] : z;
-        const short2 g10 = (x_in0 && y_in1) ? L.dI[static_cast<size_t>(y + 1) * L.cols + x] : z;
-        const short2 g11 = (x_in1 && y_in1) ? L.dI[static_cast<size_t>(y + 1) * L.cols + x + 1] : z;
+        const short2 g00 = (x_in0 && y_in0) ? L.dI[stored_row(L, y) * L.cols + x] : z;
+        const short2 g01 = (x_in1 && y_in0) ? L.dI[stored_row(L, y) * L.cols + x + 1] : z;
+        const short2 g10 = (x_in0 && y_in1) ? L.dI[stored_row(L, y + 1) * L.cols + x] : z;
+        const short2 g11 = (x_in1 && y_in1) ? L.dI[stored_row(L, y + 1) * L.cols + x + 1] : z;
         const int gx = descale(g00.x * w00 + g01.x * w01 + g10.x * w10 + g11.x * w11, 14);
         const int gy = descale(g00.y * w00 + g01.y * w01 + g10.y * w10 + g11.y * w11, 14);
         sI[i] = static_cast<short>(ival);
@@ -768,6 +797,7 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
     float prev_dx = 0.f, prev_dy = 0.f;
     for (int j = 0; j < max_count; ++j) {
       const int inx = static_cast<int>(floorf(qx)), iny = static_cast<int>(floorf(qy));
+      if (iny < L.vlo || iny + win_h + 1 > L.vhi) suspect = true;
       if (inx < -win_w || inx >= L.cols || iny < -win_h || iny >= L.rows) {
         if (level == 0) ok = false;
         break;
@@ -781,8 +811,8 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
         const int x = inx + wxs[q], y = iny + wys[q];
         const int xa = reflect101(x, L.cols), xb = reflect101(x + 1, L.cols);
         const int ya = reflect101(y, L.rows), yb = reflect101(y + 1, L.rows);
-        const unsigned char *ra = L.J + static_cast<size_t>(ya) * L.cols;
-        const unsigned char *rb = L.J + static_cast<size_t>(yb) * L.cols;
+        const unsigned char *ra = L.J + stored_row(L, ya) * L.cols;
+        const unsigned char *rb = L.J + stored_row(L, yb) * L.cols;
         t00[q] = ra[xa];
         t01[q] = ra[xb];
         t10[q] = rb[xa];
@@ -828,12 +858,13 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
       // the Python binding always asks for the error output: the final window must
       // start inside the (padded) image, else the feature is dropped
       const int rx = static_cast<int>(rintf(nx - half_x)), ry = static_cast<int>(rintf(ny - half_y));
+      if (ry < L.vlo || ry + win_h + 1 > L.vhi) suspect = true;
       if (rx < -win_w || rx >= L.cols || ry < -win_h || ry >= L.rows) ok = false;
     }
   }
   if (tid == 0) {
     next_pts[p] = make_float2(nx, ny);
-    status[p] = ok ? 1 : 0;
+    status[p] = (ok ? 1 : 0) | (suspect ? 2 : 0);
   }
 }
 
@@ -869,7 +900,7 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
   const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
   const float2 pt = pts[p];
   float nx = 0.f, ny = 0.f;  // tracked position (with half window added back)
-  bool ok = true;
+  bool ok = true, suspect = false;
   const int row_first = wave * ROWS;                          // window rows of this wave
   const int row_count = min(ROWS, win_h - row_first);         // may be <= 0 for the last waves
   const bool sample_lane = lane < win_w, load_lane = lane <= win_w;
@@ -888,6 +919,7 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
     px -= half_x;
     py -= half_y;
     const int ipx = static_cast<int>(floorf(px)), ipy = static_cast<int>(floorf(py));
+    if (ipy - 1 < L.vlo || ipy + win_h + 2 > L.vhi) suspect = true;
     if (ipx < -win_w || ipx >= L.cols || ipy < -win_h || ipy >= L.rows) {
       if (level == 0) ok = false;
       continue;
@@ -914,7 +946,7 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
       for (int r = 0; r < ROWS + 3; ++r) {
         ti[r] = 0;
         if (r < row_count + 3 && tpl_load)
-          ti[r] = L.I[static_cast<size_t>(reflect101(ipy + row_first - 1 + r, L.rows)) * L.cols + xa];
+          ti[r] = L.I[stored_row(L, reflect101(ipy + row_first - 1 + r, L.rows)) * L.cols + xa];
       }
       // Scharr gradients of column xd at rows ipy + row_first ... + row_count: (Ix, Iy) packed
       int tg[ROWS + 1];
@@ -981,6 +1013,7 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
     float prev_dx = 0.f, prev_dy = 0.f;
     for (int j = 0; j < max_count; ++j) {
       const int inx = static_cast<int>(floorf(qx)), iny = static_cast<int>(floorf(qy));
+      if (iny < L.vlo || iny + win_h + 1 > L.vhi) suspect = true;
       if (inx < -win_w || inx >= L.cols || iny < -win_h || iny >= L.rows) {
         if (level == 0) ok = false;
         break;
@@ -992,7 +1025,7 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
       for (int r = 0; r <= ROWS; ++r) {
         tj[r] = 0;
         if (r <= row_count && load_lane)
-          tj[r] = L.J[static_cast<size_t>(reflect101(iny + row_first + r, L.rows)) * L.cols + xa];
+          tj[r] = L.J[stored_row(L, reflect101(iny + row_first + r, L.rows)) * L.cols + xa];
       }
       int c1 = 0, c2 = 0;  // |diff * g| < 2^26, <= 16 samples per thread
 #pragma unroll
@@ -1035,12 +1068,13 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
     }
     if (level == 0 && ok) {
       const int rx = static_cast<int>(rintf(nx - half_x)), ry = static_cast<int>(rintf(ny - half_y));
+      if (ry < L.vlo || ry + win_h + 1 > L.vhi) suspect = true;
       if (rx < -win_w || rx >= L.cols || ry < -win_h || ry >= L.rows) ok = false;
     }
   }
   if (tid == 0) {
     next_pts[p] = make_float2(nx, ny);
-    status[p] = ok ? 1 : 0;
+    status[p] = (ok ? 1 : 0) | (suspect ? 2 : 0);
   }
 }
 
@@ -1140,15 +1174,154 @@ int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, i
                       reinterpret_cast<uintptr_t>(clean_dev) % 16 == 0;
   if (vec_ok) {
     hipLaunchKernelGGL(psh::lk_open_vec, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening,
-                       buffer_mask, stats_dev, clean_dev, part2);
+                       buffer_mask, stats_dev, clean_dev, part2, psh::Band{0, 0, m});
   } else {
     hipLaunchKernelGGL(psh::lk_open, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening,
-                       buffer_mask, stats_dev, clean_dev, part2);
+                       buffer_mask, stats_dev, clean_dev, part2, psh::Band{0, 0, m});
   }
   hipLaunchKernelGGL(psh::lk_open_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part2, nb_open, stats_dev);
   const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
   hipLaunchKernelGGL(psh::lk_to_u8, dim3(qgrid), dim3(256), 0, c.stream, clean_dev, m, n, buffer_mask,
-                     stats_dev, track_u8_dev, feature_u8_dev);
+                     stats_dev, track_u8_dev, feature_u8_dev, 0);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+// ---- row bands (multi-GPU tiling of the image passes, BASELINE config 5) --------------------
+// Every rank holds the whole frame (805 MB at 8192^2 is nothing next to 288 GB) and processes the
+// rows [e0, e1) = its own rows [r0, r1) plus a halo as a SUB-IMAGE through offset pointers; the
+// sub-image edges that are not frame borders produce wrong values only within a few rows (opening 2,
+// Shi-Tomasi response 4), far from the own rows.  What is global in the reference - the min / max of
+// the uint8 rescales (tracking/lucaskanade.py:143-160, shitomasi.py:143-151), the NaN count behind
+// the row 0 / 1 quirk, the maximum corner response - is reduced over the OWN rows only and then
+// combined across ranks by the caller (psh_comm_allreduce; min / max are order-free, so the result
+// is bit-identical to the single-device statistics).  Outputs land at their absolute rows in
+// full-size buffers.
+static int check_band(const char *who, int m, int n, int e0, int e1, int r0, int r1) {
+  if (m <= 0 || n <= 0 || e0 < 0 || e1 > m || e0 >= e1 || r0 < e0 || r1 > e1 || r0 > r1)
+    return fail(PSH_EINVAL, "%s: rows [%d,%d) / band [%d,%d) do not fit a %d-row frame", who, r0, r1, e0, e1, m);
+  return PSH_OK;
+}
+
+int psh_lk_band_stats_dev(const float *frame_dev, int m, int n, int r0, int r1, float *stats_dev) {
+  PSH_REQUIRE_INIT();
+  if (!frame_dev || !stats_dev) return fail(PSH_EINVAL, "lk_band_stats: NULL pointer");
+  if (int rc = check_band("lk_band_stats", m, n, r0, r1, r0, r1)) return rc;
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  void *ws = nullptr;
+  if (int rc = psh::ensure_lk_ws(sizeof(float) * 2 * psh::kRedBlocks, &ws)) return rc;
+  float *part = static_cast<float *>(ws);
+  hipLaunchKernelGGL(psh::lk_stats1, dim3(psh::kRedBlocks), dim3(256), 0, c.stream,
+                     frame_dev + static_cast<size_t>(r0) * n, static_cast<size_t>(r1 - r0) * n, part);
+  hipLaunchKernelGGL(psh::lk_stats1_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, psh::kRedBlocks, stats_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+int psh_lk_band_open_dev(const float *frame_dev, int m, int n, int e0, int e1, int r0, int r1, int size_opening,
+                         int buffer_mask, float *clean_dev, float *stats_dev) {
+  PSH_REQUIRE_INIT();
+  if (!frame_dev || !clean_dev || !stats_dev) return fail(PSH_EINVAL, "lk_band_open: NULL pointer");
+  if (int rc = check_band("lk_band_open", m, n, e0, e1, r0, r1)) return rc;
+  if (size_opening != 0 && size_opening != 3)
+    return fail(PSH_EUNSUPPORTED, "lk_prepare: size_opening %d not implemented (0 or 3)", size_opening);
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const int ms = e1 - e0;
+  const dim3 ogrid((n + psh::kOpenTX - 1) / psh::kOpenTX, (ms + psh::kOpenTY - 1) / psh::kOpenTY);
+  const int nb_open = ogrid.x * ogrid.y;
+  void *ws = nullptr;
+  if (int rc = psh::ensure_lk_ws(sizeof(float) * 3 * static_cast<size_t>(nb_open), &ws)) return rc;
+  float *part = static_cast<float *>(ws);
+  const float *img = frame_dev + static_cast<size_t>(e0) * n;
+  float *clean = clean_dev + static_cast<size_t>(e0) * n;
+  const psh::Band band{e0, r0 - e0, r1 - e0};
+  if (n % 4 == 0 && reinterpret_cast<uintptr_t>(img) % 16 == 0 && reinterpret_cast<uintptr_t>(clean) % 16 == 0) {
+    hipLaunchKernelGGL(psh::lk_open_vec, ogrid, dim3(256), 0, c.stream, img, ms, n, size_opening, buffer_mask,
+                       stats_dev, clean, part, band);
+  } else {
+    hipLaunchKernelGGL(psh::lk_open, ogrid, dim3(256), 0, c.stream, img, ms, n, size_opening, buffer_mask, stats_dev,
+                       clean, part, band);
+  }
+  hipLaunchKernelGGL(psh::lk_open_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb_open, stats_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+int psh_lk_band_to_u8_dev(const float *clean_dev, int m, int n, int e0, int e1, int buffer_mask, const float *stats_dev,
+                          unsigned char *track_u8_dev, unsigned char *feature_u8_dev) {
+  PSH_REQUIRE_INIT();
+  if (!clean_dev || !stats_dev || !track_u8_dev) return fail(PSH_EINVAL, "lk_band_to_u8: NULL pointer");
+  if (int rc = check_band("lk_band_to_u8", m, n, e0, e1, e0, e1)) return rc;
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t off = static_cast<size_t>(e0) * n, npx = static_cast<size_t>(e1 - e0) * n;
+  const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
+  hipLaunchKernelGGL(psh::lk_to_u8, dim3(qgrid), dim3(256), 0, c.stream, clean_dev + off, e1 - e0, n, buffer_mask,
+                     stats_dev, track_u8_dev + off, feature_u8_dev ? feature_u8_dev + off : nullptr, e0);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+int psh_lk_band_response_dev(const unsigned char *feature_u8_dev, const float *clean_dev, int m, int n, int e0, int e1,
+                             int r0, int r1, int block_size, int buffer_mask, float *stats_dev, float *eig_dev) {
+  PSH_REQUIRE_INIT();
+  if (!feature_u8_dev || !clean_dev || !stats_dev || !eig_dev) return fail(PSH_EINVAL, "lk_band_response: NULL pointer");
+  if (int rc = check_band("lk_band_response", m, n, e0, e1, r0, r1)) return rc;
+  if (block_size < 1 || block_size > 2 * psh::kMaxBlockR + 1 || (block_size & 1) == 0)
+    return fail(PSH_EUNSUPPORTED, "lk_corners: block_size %d not implemented (odd, <= 7)", block_size);
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const int ms = e1 - e0;
+  const dim3 rgrid((n + psh::kCrnTX - 1) / psh::kCrnTX, (ms + psh::kCrnTY - 1) / psh::kCrnTY);
+  const int nb = rgrid.x * rgrid.y;
+  void *ws = nullptr;
+  if (int rc = psh::ensure_lk_ws(sizeof(float) * static_cast<size_t>(nb), &ws)) return rc;
+  float *part = static_cast<float *>(ws);
+  const size_t off = static_cast<size_t>(e0) * n;
+  const psh::Band band{e0, r0 - e0, r1 - e0};
+#define PSH_CRN_LAUNCH(BS)                                                                                       \
+  hipLaunchKernelGGL(psh::lk_corner_response<BS>, rgrid, dim3(256), 0, c.stream, feature_u8_dev + off, clean_dev + off, \
+                     ms, n, buffer_mask, stats_dev, eig_dev + off, part, band)
+  if (block_size == 1) {
+    PSH_CRN_LAUNCH(1);
+  } else if (block_size == 3) {
+    PSH_CRN_LAUNCH(3);
+  } else if (block_size == 5) {
+    PSH_CRN_LAUNCH(5);
+  } else {
+    PSH_CRN_LAUNCH(7);
+  }
+#undef PSH_CRN_LAUNCH
+  hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb, stats_dev,
+                     static_cast<int>(psh::kEigMax));
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+int psh_lk_band_select_dev(const float *eig_dev, const float *clean_dev, int m, int n, int e0, int e1, int r0, int r1,
+                           int buffer_mask, double quality_level, const float *stats_dev,
+                           unsigned long long *keys_dev, int cap, int *count_dev) {
+  PSH_REQUIRE_INIT();
+  if (!eig_dev || !clean_dev || !stats_dev || !keys_dev || !count_dev || cap <= 0)
+    return fail(PSH_EINVAL, "lk_band_select: invalid argument");
+  if (int rc = check_band("lk_band_select", m, n, e0, e1, r0, r1)) return rc;
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const int ms = e1 - e0;
+  const size_t off = static_cast<size_t>(e0) * n;
+  PSH_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), c.stream));
+  PSH_HIP(hipMemsetAsync(keys_dev, 0, static_cast<size_t>(cap) * sizeof(psh::CornerKey), c.stream));
+  const dim3 sgrid((n + 63) / 64, (ms + psh::kSelRows - 1) / psh::kSelRows);
+  hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig_dev + off, clean_dev + off, ms, n,
+                     buffer_mask, static_cast<float>(quality_level), stats_dev, keys_dev, cap, count_dev,
+                     psh::Band{e0, r0 - e0, r1 - e0});
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }
@@ -1273,7 +1446,7 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
   psh::CornerKey *sorted = reinterpret_cast<psh::CornerKey *>(base + off_sorted);
 #define PSH_CRN_LAUNCH(BS)                                                                            \
   hipLaunchKernelGGL(psh::lk_corner_response<BS>, rgrid, dim3(256), 0, c.stream, feature_u8_dev, clean_dev, \
-                     m, n, buffer_mask, stats_dev, eig, part)
+                     m, n, buffer_mask, stats_dev, eig, part, psh::Band{0, 0, m})
   if (block_size == 1) {
     PSH_CRN_LAUNCH(1);
   } else if (block_size == 3) {
@@ -1291,7 +1464,7 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
   PSH_HIP(hipMemsetAsync(raw, 0, static_cast<size_t>(kSortSpan) * sizeof(psh::CornerKey), c.stream));
   const dim3 sgrid((n + 63) / 64, (m + psh::kSelRows - 1) / psh::kSelRows);
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n,
-                     buffer_mask, static_cast<float>(quality_level), stats_dev, raw, cap, cnt);
+                     buffer_mask, static_cast<float>(quality_level), stats_dev, raw, cap, cnt, psh::Band{0, 0, m});
   PSH_HIP(hipGetLastError());
   PSH_HIP(psh::sort_keys_desc(raw, sorted, kSortSpan, base + off_temp, &sort_temp, c.stream));
   // the count and the head of the ordered list go to pinned memory right behind the sort,
@@ -1435,7 +1608,7 @@ namespace {
 struct PyramidSet {
   psh::Pyramid pyr;
   void *block = nullptr;
-  int win_w = 0, win_h = 0;
+  int win_w = 0, win_h = 0, max_level = 0;
 };
 }  // namespace
 
@@ -1490,6 +1663,7 @@ int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *n
   ps->pyr.top = top;
   ps->win_w = win_w;
   ps->win_h = win_h;
+  ps->max_level = max_level;
   for (int l = 0; l <= top; ++l) {
     unsigned char *Il = l ? reinterpret_cast<unsigned char *>(base + off_i[l]) : const_cast<unsigned char *>(prev_u8_dev);
     unsigned char *Jl = l ? reinterpret_cast<unsigned char *>(base + off_j[l]) : const_cast<unsigned char *>(next_u8_dev);
@@ -1518,6 +1692,48 @@ int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *n
     return fail(PSH_EHIP, "lk_pyramids launch failed: %s", hipGetErrorString(e));
   }
   *handle_out = ps;
+  return PSH_OK;
+}
+
+int psh_lk_pyramids_band(void *handle, int frame_rows, int band_first_row, int *top_level_out) {
+  if (!handle) return fail(PSH_EINVAL, "lk_pyramids_band: NULL handle");
+  PyramidSet *ps = static_cast<PyramidSet *>(handle);
+  const int sub_rows = ps->pyr.lv[0].rows;
+  if (band_first_row < 0 || band_first_row + sub_rows > frame_rows)
+    return fail(PSH_EINVAL, "lk_pyramids_band: rows [%d,%d) outside the %d-row frame", band_first_row,
+                band_first_row + sub_rows, frame_rows);
+  if (band_first_row & ((1 << ps->pyr.top) - 1))
+    return fail(PSH_EINVAL, "lk_pyramids_band: the first band row must be a multiple of %d", 1 << ps->pyr.top);
+  // the whole frame must not have MORE levels than the band has (buildOpticalFlowPyramid stops when a
+  // level is not larger than the window): the caller then tracks on whole-frame data instead
+  int full_top = 0;
+  {
+    int r = frame_rows, q = ps->pyr.lv[0].cols;
+    for (int l = 1; l < psh::kMaxLevels && l <= ps->max_level; ++l) {
+      r = (r + 1) / 2;
+      q = (q + 1) / 2;
+      if (q <= ps->win_w || r <= ps->win_h) break;
+      full_top = l;
+    }
+  }
+  if (full_top != ps->pyr.top)
+    return fail(PSH_EUNSUPPORTED, "lk_pyramids_band: the band gives %d pyramid levels, the frame %d", ps->pyr.top + 1,
+                full_top + 1);
+  // opening reaches 2 rows, every pyrDown 2 rows of the level below, the gradient image 1 row: a
+  // margin of 6 rows covers every level
+  constexpr int kMargin = 6;
+  const bool top_border = band_first_row == 0, bottom_border = band_first_row + sub_rows == frame_rows;
+  int rows_full = frame_rows;
+  for (int l = 0; l <= ps->pyr.top; ++l) {
+    psh::PyrLevel &L = ps->pyr.lv[l];
+    if (l) rows_full = (rows_full + 1) / 2;
+    L.rows_stored = L.rows;
+    L.row_org = band_first_row >> l;
+    L.vlo = top_border ? -(1 << 30) : L.row_org + kMargin;
+    L.vhi = bottom_border ? (1 << 30) : L.row_org + L.rows_stored - kMargin;
+    L.rows = rows_full;
+  }
+  if (top_level_out) *top_level_out = ps->pyr.top;
   return PSH_OK;
 }
 

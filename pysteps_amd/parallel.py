@@ -74,6 +74,35 @@ class Communicator:
         _lib.check(_lib.lib().psh_comm_allgather(array.ptr, out.ptr, array.nbytes), "psh_comm_allgather")
         return out
 
+    _OPS = {"sum": 0, "max": 1, "min": 2}  # PSH_COMM_* of include/pysteps_hip.h
+
+    def allreduce(self, array, op):
+        """In-place ncclAllReduce of a float32 DeviceArray (``op``: "min", "max" or "sum")."""
+        if not isinstance(array, DeviceArray) or array.dtype != np.float32:
+            raise TypeError("allreduce expects a float32 DeviceArray")
+        _lib.check(_lib.lib().psh_comm_allreduce_f32(array.ptr, array.size, self._OPS[op]), "psh_comm_allreduce_f32")
+        return array
+
+    def allreduce_host(self, values, op):
+        """A few float32 values from the host through the device collective and back (the global
+        statistics of the row-band Lucas-Kanade passes, ``motion/banded.py``)."""
+        buf = DeviceArray.from_host(np.ascontiguousarray(values, dtype=np.float32))
+        return self.allreduce(buf, op).to_host()
+
+    def allgather_host(self, array):
+        """Gather host arrays whose leading dimension differs between ranks -> list in rank order
+        (corner candidates, tracked vectors: kilobytes).  Two device collectives: the lengths, then
+        the payloads padded to the longest."""
+        arr = np.ascontiguousarray(array)
+        lengths = self.allgather(DeviceArray.from_host(np.array([arr.shape[0]], dtype=np.int64))).to_host().ravel()
+        longest = int(lengths.max())
+        if longest == 0:
+            return [arr[:0].copy() for _ in range(self.world_size)]
+        padded = np.zeros((longest,) + arr.shape[1:], dtype=arr.dtype)
+        padded[: arr.shape[0]] = arr
+        allp = self.allgather(DeviceArray.from_host(padded)).to_host()
+        return [allp[r, : int(lengths[r])].copy() for r in range(self.world_size)]
+
     def close(self):
         _lib.check(_lib.lib().psh_comm_destroy(), "psh_comm_destroy")
 
@@ -90,6 +119,15 @@ def sharded_extrapolate(precip_members, velocity, timesteps, rank, world_size, *
     extrapolate = get_method("semilagrangian")
     mine = partition(len(precip_members), world_size, rank)
     return {j: extrapolate(precip_members[j], velocity, timesteps, **kwargs) for j in mine}
+
+
+def banded_dense_lucaskanade(frames, comm, **kwargs):
+    """Dense Lucas-Kanade of frames that every rank holds, the image passes tiled into row bands
+    over the ranks of ``comm`` (BASELINE config 5; see :mod:`pysteps_amd.motion.banded`).  Returns
+    the whole (2,m,n) field as a DeviceArray on every rank - the form ``tiled_extrapolate`` takes."""
+    from .motion import banded
+
+    return banded.run(banded.band_lucaskanade(frames, comm.rank, comm.world_size, **kwargs), comm)
 
 
 def tiled_extrapolate(precip, velocity, timesteps, rank, world_size, outval=float("nan"), n_iter=1,
