@@ -141,8 +141,11 @@ def _corner_candidates(bf, block_size, quality_level):
 class _BandPyramid:
     def __init__(self, prev, nxt, winsize, nr_levels):
         lib = _lib.lib()
+        if prev.rows != nxt.rows:  # one of the two was completed for an earlier fallback: complete the other
+            for f in (prev, nxt):
+                if f.rows[2:] != (0, f.m):
+                    f.whole_frame()
         r0, r1, e0, e1 = prev.rows
-        assert nxt.rows[2:] == (e0, e1)
         self.handle = ctypes.c_void_p()
         off = e0 * prev.n
         _lib.check(lib.psh_lk_pyramids_dev(prev.track_u8.ptr + off, nxt.track_u8.ptr + off, e1 - e0, prev.n,

@@ -281,7 +281,6 @@ def dense_lucaskanade(
         bs = fd_kwargs.get("block_size", 5)
         win = lk_kwargs.get("winsize", (50, 50))
         ik, ipow = interp_kwargs.get("k", 20), interp_kwargs.get("power", 0.5)
-        ncorn = fd_kwargs.get("max_num_features") or fd_kwargs.get("max_corners", 1000)
         if not (isinstance(bs, (int, np.integer)) and 1 <= bs <= 7 and bs % 2 == 1):
             unsupported = "block_size=%r (odd, <= 7 on the HIP path)" % (bs,)
         elif not (len(win) == 2 and 3 <= int(win[0]) <= 64 and 3 <= int(win[1]) <= 64):
@@ -290,8 +289,7 @@ def dense_lucaskanade(
             unsupported = "interp_kwargs k=%r (k <= 32 or k=None on the HIP path)" % (ik,)
         elif not ipow > 0:
             unsupported = "interp_kwargs power=%r (> 0 on the HIP path)" % (ipow,)
-        elif ncorn is not None and ncorn * max(int(input_images.shape[0]) - 1, 1) > 8192:
-            unsupported = "more than 8192 pooled vectors (max_num_features x frame pairs)"
+
     if unsupported is not None:
         ref = _reference_dense_lk()
         if ref is None or isinstance(input_images, DeviceArray):
