@@ -271,6 +271,14 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
  * ties by higher address first; accepted corners -> points_host (x, y) float32, at most max_corners. */
 int psh_lk_greedy_host(const unsigned long long *keys, int count, int m, int n, double min_distance,
                        int max_corners, float *points_host, int *count_host);
+/* The same pass on the DEVICE (csrc/lk_sparse.hip corner_order, the kernel the corner entry points
+ * and psh_dense_lk_dev run): keys in ANY order (host array), every response in
+ * (response_max * quality_level, response_max]; the head of the descending order is selected by a
+ * key histogram, ordered in LDS and walked in batches.  Same result as sorting the keys descending
+ * and calling psh_lk_greedy_host.  PSH_EUNSUPPORTED beyond 2048 corners / 65535 rows or columns. */
+int psh_lk_order_host(const unsigned long long *keys_host, int count, float response_max,
+                      double quality_level, int m, int n, double min_distance, int max_corners,
+                      float *points_host, int *count_host);
 int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
                               float *stats_dev, int m, int n, int block_size, int buffer_mask,
                               double quality_level, double min_distance, int max_corners);
@@ -314,8 +322,10 @@ int psh_lk_track_pyr_dev(void *handle, const float *points_host, int npts, int m
                          unsigned char *status_host);
 
 /* Whole dense_lucaskanade (pysteps/motion/lucaskanade.py:182-279, default detector and
- * interpolator) in one call, composed of the stage entry points above/below; keeps the
- * interpreter out of the four device->host hand-offs of the sparse stage.
+ * interpolator) in one call.  With field_dev the estimate is ONE chain of kernel launches on the
+ * library stream (corner ordering, tracking, pooling, outlier test, declustering and IDW all read
+ * their counts from device memory): the call returns without waiting for the device unless
+ * count_out is given (then it waits for the 4-byte sample count).
  *  frames (nframes,m,n) f32 device (NaN/Inf = missing).  field_dev (2,m,n) f32 or NULL; with
  *  NULL the sparse vectors after outlier removal are returned instead (dense=False):
  *  xy_host / uv_host (capacity,2) f64, *count_out rows.  Fields of psh_lk_params follow the
@@ -357,6 +367,17 @@ int psh_outliers_local_host(const double *xy, const double *values, int n, int k
  * are written. */
 int psh_decluster_host(const double *xy, const double *values, int n, double scale,
                        int min_samples, double *out_xy, double *out_values, int *out_count);
+/* What psh_dense_lk_dev does between the outlier test and the interpolation, as ONE device kernel
+ * (csrc/lk_sparse.hip vectors_finish; pysteps/motion/lucaskanade.py:254-274 +
+ * pysteps/decorators.py:199-208): drop the flagged vectors (none if count < 2), decluster with
+ * min_samples 1 when decl_scale > 1 (coordinates inside a 65535 x 65535 image), then the
+ * interpolator preamble: *out_mode 1 = constant field out_const[0..1] (no vector -> zeros, one
+ * vector, all values equal), 0 = interpolate the *out_count float32 samples out_xy / out_values
+ * (count rows each); *out_reach = farthest a sample can be from a node of the (m,n) pixel grid.
+ * HOST arrays in and out; at most 8192 vectors. */
+int psh_vectors_finish_host(const double *xy, const double *values, const unsigned char *outlier_flags,
+                            int count, double decl_scale, int m, int n, float *out_xy, float *out_values,
+                            int *out_count, int *out_mode, float *out_const, float *out_reach);
 
 /* ---- multi-GPU: RCCL over xGMI, one rank (process) per GPU ------------------ *
  * The reference has no communication layer (single process, optional dask threads:

@@ -66,6 +66,7 @@ SIGNATURES = {
     "psh_event_record": (c_int, [c_void_p]),
     "psh_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "psh_lk_greedy_host": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),
+    "psh_lk_order_host": (c_int, [c_void_p, c_int, c_float, c_double, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),
     "psh_idw_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_double, c_void_p]),
     "psh_idw_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_void_p]),
     "psh_lk_prepare_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -80,6 +81,8 @@ SIGNATURES = {
     "psh_comm_destroy": (c_int, []),
     "psh_outliers_local_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_void_p]),
     "psh_decluster_host": (c_int, [c_void_p, c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, POINTER(c_int)]),
+    "psh_vectors_finish_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_void_p, c_void_p,
+                                        POINTER(c_int), POINTER(c_int), c_void_p, c_void_p]),
     "psh_velocity_unit_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "psh_members_pack_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "psh_semilag_members_packed_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),

@@ -101,6 +101,17 @@ bool semilag_wide_eligible(const SemilagArgs &a);
 hipError_t launch_semilag_wide(const SemilagArgs &a, hipStream_t stream);
 hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream);
 
+// sample count and interpolator preamble kept in device memory (written by vectors_finish,
+// lk_sparse.hip): the IDW kernels read L / reach from here instead of their launch arguments, so
+// that the host never has to know how many vectors survived
+struct IdwDyn {
+  int L;        // samples in the list
+  int mode;     // 0: interpolate; 1: constant field (cu, cv) - no / one sample, all values equal
+  float cu, cv;
+  float reach;  // farthest a sample can be from a grid node (histogram range of the coarse pass)
+  int pad[3];
+};
+
 struct IdwArgs {
   const float *xy;  // (L,2) device: x, y of the sparse vectors
   const float *uv;  // (L,2) device: values
@@ -109,26 +120,41 @@ struct IdwArgs {
   float x0, dx, y0, dy;  // target grid: x = x0 + dx*i (i<n), y = y0 + dy*j (j<m)
   float inv_res, power, offset, dmax;
   void *scratch = nullptr;  // idw_scratch_bytes(m, n) of device memory: supertile candidate lists
+  // device-resident sample count: L is then the CAPACITY of xy / uv, k the requested neighbour
+  // count (not yet clamped to the sample count), dmax is ignored
+  const IdwDyn *dyn = nullptr;
 };
 hipError_t launch_idw(const IdwArgs &a, hipStream_t stream);
+int idw_resident(const float *xy_dev, const float *values_dev, int capacity, const IdwDyn *dyn_dev, int m, int n,
+                 int k, double power, double dist_offset, float *out_dev);
 size_t idw_scratch_bytes(int m, int n);
 void set_idw_variant(int v);
 
 hipError_t launch_outliers_pooled(const double *xy_dev, const double *uv_dev, const int *count_dev,
                                   int capacity, int k, double thr, unsigned char *flags_dev,
                                   hipStream_t stream);
-// tracker with device-side pooling of the successful vectors (lk.hip); asynchronous, the host
-// points are staged in a pinned slot that stays valid until the stream has consumed it
-int lk_track_pool(void *pyramid_handle, const float *points_host, int npts, int max_count, double epsilon,
-                  double min_eig_threshold, double *pool_xy_dev, double *pool_uv_dev, int *pool_count_dev,
-                  int pool_capacity);
+// tracker with device-side pooling of the successful vectors (lk.hip); asynchronous.  The points
+// come either from the host (staged in a pinned slot that stays valid until the stream has
+// consumed it) or from device memory together with their count (points_dev, npts_dev; npts is
+// then the capacity).
+int lk_track_pool(void *pyramid_handle, const float *points_host, const float *points_dev, const int *npts_dev,
+                  int npts, int max_count, double epsilon, double min_eig_threshold, double *pool_xy_dev,
+                  double *pool_uv_dev, int *pool_count_dev, int pool_capacity);
 
-// corner requests (lk.hip): drop everything in flight; how many may be in flight at once
-void lk_corners_drain();
-int lk_corners_in_flight_limit();
+// corner candidates of one frame -> accepted corners in goodFeaturesToTrack's order, everything
+// on the library stream and in device memory (lk.hip): points_dev holds max_corners (x, y) pairs
+int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_dev, float *stats_dev, int m, int n,
+                        int block_size, int buffer_mask, double quality_level, double min_distance, int max_corners,
+                        float *points_dev, int *npoints_dev);
 
-// rocPRIM descending radix sort of 64-bit keys (lk_sort.hip); temp == nullptr queries *temp_bytes
-hipError_t sort_keys_desc(const unsigned long long *in, unsigned long long *out, unsigned int n,
-                          void *temp, size_t *temp_bytes, hipStream_t stream);
+// ordered min-distance acceptance and the post-outlier-test stage on the device (lk_sparse.hip)
+int corner_order_max_corners();
+hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw_count_dev, int cap,
+                               const float *eig_max_dev, float quality, int n, double min_distance,
+                               int max_corners, float *points_dev, int *npoints_dev, hipStream_t stream);
+hipError_t launch_vectors_finish(const double *pool_xy_dev, const double *pool_uv_dev,
+                                 const unsigned char *flags_dev, const int *pool_count_dev, int capacity,
+                                 double decl_scale, int m, int n, float *xy_out_dev, float *uv_out_dev,
+                                 IdwDyn *dyn_dev, hipStream_t stream);
 
 }  // namespace psh

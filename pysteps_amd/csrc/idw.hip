@@ -438,11 +438,20 @@ __global__ __launch_bounds__(kThreads) void idw_coarse(const float2 *__restrict_
                                                        int n, float x0, float dx_grid, float y0,
                                                        float dy_grid, float dmax, int supers_x,
                                                        SuperHeader *__restrict__ headers,
-                                                       float4 *__restrict__ lists) {
+                                                       float4 *__restrict__ lists,
+                                                       const IdwDyn *__restrict__ dyn) {
   __shared__ int s_hist[kBins];
   __shared__ float s_radius;
   __shared__ int s_wave_count[4];
   const int sup = blockIdx.x;
+  if (dyn) {  // sample count, neighbour count and reach live in device memory (common.h IdwDyn)
+    L = dyn->L;
+    dmax = dyn->reach;
+    if (dyn->mode != 0 || k >= L) {  // constant field / every sample is a neighbour: no lists
+      if (threadIdx.x == 0) headers[sup] = SuperHeader{0, 0.f, 0.f, 0.f};
+      return;
+    }
+  }
   const int tx = (sup % supers_x) * kSuper, ty = (sup / supers_x) * kSuper;
   const int tid = threadIdx.x;
   const int wx = min(kSuper, n - tx), wy = min(kSuper, m - ty);
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(64) void idw_fine(const float2 *__restrict__ xy, co
                                                float offset, float *__restrict__ out, int supers_x,
                                                const SuperHeader *__restrict__ headers,
                                                const float4 *__restrict__ lists, int tiles_x, int n_tiles,
-                                               int tiles_per_xcd) {
+                                               int tiles_per_xcd, const IdwDyn *__restrict__ dyn) {
   __shared__ int s_hist[kFineBins];
   __shared__ float4 s_cand[kFineCap];  // [certain | undecided], each group in index order
   const int b = blockIdx.x;
@@ -542,6 +551,17 @@ __global__ __launch_bounds__(64) void idw_fine(const float2 *__restrict__ xy, co
   const int lane = threadIdx.x;
   const int ix = tx + (lane % kFine), iy = ty + (lane / kFine);
   const bool live = ix < n && iy < m;
+  if (dyn) {
+    L = dyn->L;
+    k = min(k, L);
+    if (dyn->mode != 0) {  // the interpolator's trivial cases (decorators.py:199-208): constant field
+      if (live) {
+        out[static_cast<size_t>(iy) * n + ix] = dyn->cu;
+        out[static_cast<size_t>(m) * n + static_cast<size_t>(iy) * n + ix] = dyn->cv;
+      }
+      return;
+    }
+  }
   const float px = x0 + dx_grid * static_cast<float>(ix);
   const float py = y0 + dy_grid * static_cast<float>(iy);
   const size_t plane = static_cast<size_t>(m) * n;
@@ -664,15 +684,17 @@ size_t idw_scratch_bytes(int m, int n) {
 hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
   const float2 *xy = reinterpret_cast<const float2 *>(a.xy);
   const float2 *uv = reinterpret_cast<const float2 *>(a.uv);
-  const int k_eff = a.k >= a.L ? 1 : a.k;
-  if (g_idw_variant == 0 && a.scratch != nullptr) {
+  // (with a device-resident sample count the instantiation follows the requested k: should the
+  // samples turn out to be fewer, every instantiation takes the same all-samples path)
+  const int k_eff = a.dyn ? (a.k > 32 ? 1 : a.k) : a.k >= a.L ? 1 : a.k;
+  if ((g_idw_variant == 0 || a.dyn != nullptr) && a.scratch != nullptr) {
     const int supers_x = (a.n + kSuper - 1) / kSuper, supers_y = (a.m + kSuper - 1) / kSuper;
     const int n_super = supers_x * supers_y;
     SuperHeader *headers = static_cast<SuperHeader *>(a.scratch);
     float4 *lists = reinterpret_cast<float4 *>(headers + n_super);
-    if (a.k < a.L) {
+    if (a.dyn != nullptr || a.k < a.L) {
       hipLaunchKernelGGL(idw_coarse, dim3(n_super), dim3(kThreads), 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0,
-                         a.dx, a.y0, a.dy, a.dmax, supers_x, headers, lists);
+                         a.dx, a.y0, a.dy, a.dmax, supers_x, headers, lists, a.dyn);
     } else {
       hipError_t e = hipMemsetAsync(headers, 0, n_super * sizeof(SuperHeader), stream);
       if (e != hipSuccess) return e;
@@ -684,7 +706,7 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
 #define PSH_IDW_FINE(KMAX)                                                                            \
   hipLaunchKernelGGL((idw_fine<KMAX>), grid, block, 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0, a.dx, \
                      a.y0, a.dy, a.inv_res, a.power, a.offset, a.out, supers_x, headers, lists,       \
-                     tiles_x, n_tiles, tiles_per_xcd)
+                     tiles_x, n_tiles, tiles_per_xcd, a.dyn)
     if (k_eff <= 8) {
       PSH_IDW_FINE(8);
     } else if (k_eff <= 20) {
@@ -768,6 +790,45 @@ extern "C" int psh_idw_dev(const float *xy_dev, const float *values_dev, int L, 
   if (le != hipSuccess) return psh::fail(PSH_EHIP, "idw launch failed: %s", hipGetErrorString(le));
   return PSH_OK;
 }
+
+// Interpolation onto the unit pixel grid of an (m, n) image with the sample list, its length and
+// the interpolator preamble in device memory (IdwDyn, written by vectors_finish): nothing about
+// the samples is known on the host, the call only queues kernels.  k <= 0: every sample.
+namespace psh {
+int idw_resident(const float *xy_dev, const float *values_dev, int capacity, const IdwDyn *dyn_dev, int m, int n,
+                 int k, double power, double dist_offset, float *out_dev) {
+  if (!xy_dev || !values_dev || !dyn_dev || !out_dev) return fail(PSH_EINVAL, "idw: NULL pointer");
+  if (capacity <= 0 || m <= 0 || n <= 0) return fail(PSH_EINVAL, "idw: invalid shape");
+  if (k > 32) return fail(PSH_EUNSUPPORTED, "idw: k=%d > 32 is not implemented", k);
+  if (!(power > 0.0)) return fail(PSH_EINVAL, "idw: power must be positive");
+  Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  IdwArgs a;
+  a.xy = xy_dev;
+  a.uv = values_dev;
+  a.out = out_dev;
+  a.L = capacity;
+  a.k = k <= 0 ? 0x7fffffff : k;
+  a.m = m;
+  a.n = n;
+  a.x0 = 0.f;
+  a.dx = 1.f;
+  a.y0 = 0.f;
+  a.dy = 1.f;
+  a.inv_res = 1.f;
+  a.power = static_cast<float>(power);
+  a.offset = static_cast<float>(dist_offset);
+  a.dmax = 1.f;
+  a.dyn = dyn_dev;
+  void *scratch = nullptr;
+  if (int rc = psh_malloc(&scratch, idw_scratch_bytes(m, n))) return rc;
+  a.scratch = scratch;
+  const hipError_t le = launch_idw(a, c.stream);
+  (void)psh_free(scratch);
+  if (le != hipSuccess) return fail(PSH_EHIP, "idw launch failed: %s", hipGetErrorString(le));
+  return PSH_OK;
+}
+}  // namespace psh
 
 extern "C" int psh_idw_host(const double *xy, const double *values, int L, int m, int n, double x0,
                             double dx, double y0, double dy, int k, double power,

@@ -693,8 +693,8 @@ __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1)
 // kPer: window samples per thread, >= ceil(win_w * win_h / 256) (4, 10 or 16: 32x32, 50x50, 64x64)
 template <int kPer>
 __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__restrict__ pts,
-                                                int npts, int win_w, int win_h, int max_count,
-                                                float eps2, float min_eig_thr,
+                                                int npts, const int *__restrict__ npts_dev, int win_w,
+                                                int win_h, int max_count, float eps2, float min_eig_thr,
                                                 float2 *__restrict__ next_pts,
                                                 unsigned char *__restrict__ status) {
   __shared__ short sI[kMaxWin * kMaxWin];
@@ -702,6 +702,9 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
   __shared__ short sGy[kMaxWin * kMaxWin];
   __shared__ long long red[3][4];
   const int p = blockIdx.x;
+  // the point count is either a launch argument or still in device memory (corner_order's output;
+  // the grid then covers the capacity and the surplus workgroups leave at once)
+  if (npts_dev) npts = min(npts, *npts_dev);
   if (p >= npts) return;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int area = win_w * win_h;
@@ -887,14 +890,16 @@ constexpr int kRowsMaxWin = 61;  // window columns + 3 (Scharr halo, right tap) 
 
 template <int ROWS>
 __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *__restrict__ pts, int npts,
-                                                     int win_w, int win_h, int max_count, float eps2,
-                                                     float min_eig_thr, float2 *__restrict__ next_pts,
+                                                     const int *__restrict__ npts_dev, int win_w, int win_h,
+                                                     int max_count, float eps2, float min_eig_thr,
+                                                     float2 *__restrict__ next_pts,
                                                      unsigned char *__restrict__ status) {
   __shared__ short sI[kMaxWin * kMaxWin];
   __shared__ short sGx[kMaxWin * kMaxWin];
   __shared__ short sGy[kMaxWin * kMaxWin];
   __shared__ long long red[3][4];
   const int p = blockIdx.x;
+  if (npts_dev) npts = min(npts, *npts_dev);  // count in device memory: see lk_track
   if (p >= npts) return;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const float half_x = (win_w - 1) * 0.5f, half_y = (win_h - 1) * 0.5f;
@@ -1083,12 +1088,14 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
 __global__ __launch_bounds__(256) void lk_pool_append(const float2 *__restrict__ pts,
                                                       const float2 *__restrict__ next_pts,
                                                       const unsigned char *__restrict__ status, int npts,
+                                                      const int *__restrict__ npts_dev,
                                                       double2 *__restrict__ pool_xy,
                                                       double2 *__restrict__ pool_uv,
                                                       int *__restrict__ pool_count, int capacity) {
   __shared__ int wave_total[4];
   __shared__ int running;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (npts_dev) npts = min(npts, *npts_dev);
   if (tid == 0) running = *pool_count;
   __syncthreads();
   for (int i0 = 0; i0 < npts; i0 += 256) {
@@ -1330,19 +1337,17 @@ namespace {
 // state of the corner request in flight (launch -> finish), guarded by the context mutex
 struct CornerJob {
   bool active = false;
+  bool host_ordered = false;  // max_corners beyond the device kernel's LDS list: ordered in finish()
   int m = 0, n = 0, cap = 0, max_corners = 0;
   double min_distance = 0.0;
-  psh::CornerKey *sorted_dev = nullptr;  // candidates in walking order (device)
-  psh::CornerKey *raw_dev = nullptr;     // unsorted candidates (overflow path)
+  psh::CornerKey *raw_dev = nullptr;  // candidates as the select kernel wrote them (host-ordered path)
   hipEvent_t ready = nullptr;
-  void *pinned = nullptr;  // [int count | pad | first kFirstChunk sorted keys]
-  void *ws = nullptr;      // device block of this request (response image, keys, sort scratch)
+  void *pinned = nullptr;  // [int count | pad | accepted corners (x, y) float32]
+  void *ws = nullptr;      // device block that outlives launch (host-ordered path: response image + keys)
 };
-constexpr int kSortSpan = 1 << 17;   // candidates ordered on the device (zero padded)
-constexpr int kFirstChunk = 1 << 13; // sorted keys that travel with the count (64 KiB)
 constexpr size_t kPinnedHeader = 64;
-// requests in flight, first in first out: the frame pairs of one estimate are launched back to
-// back so that the host's ordered pass over pair t overlaps the device work of pair t + 1
+// requests in flight, first in first out: the frame pairs of one estimate can be launched back to
+// back, the copies of their results are queued behind each request's own kernels
 constexpr int kMaxCornerJobs = 4;
 CornerJob g_corner_jobs[kMaxCornerJobs];
 int g_corner_head = 0, g_corner_count = 0;
@@ -1399,53 +1404,37 @@ struct GreedyGrid {
 };
 }  // namespace
 
-int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
-                              float *stats_dev, int m, int n, int block_size, int buffer_mask,
-                              double quality_level, double min_distance, int max_corners) {
-  PSH_REQUIRE_INIT();
-  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_corners: invalid shape (%d,%d)", m, n);
-  if (!feature_u8_dev || !clean_dev || !stats_dev) return fail(PSH_EINVAL, "lk_corners: NULL pointer");
-  if (block_size < 1 || block_size > 2 * psh::kMaxBlockR + 1 || (block_size & 1) == 0)
-    return fail(PSH_EUNSUPPORTED, "lk_corners: block_size %d not implemented (odd, <= 7)", block_size);
-  if (max_corners <= 0) return fail(PSH_EINVAL, "lk_corners: max_corners must be positive");
-  if (static_cast<uint64_t>(m) * static_cast<uint64_t>(n) >= (1ull << 32))
-    return fail(PSH_EUNSUPPORTED, "lk_corners: more than 2^32 pixels");
+// response image, its maximum, candidate keys (threshold + 3x3 maxima) of one frame: queued on the
+// library stream into the block `ws` (layout below); lock held by the caller
+namespace {
+struct CornerWs {
+  size_t off_part, off_cnt, off_raw, bytes;
+  int cap, nb;
+  dim3 rgrid;
+  CornerWs(int m, int n) {
+    const size_t npx = static_cast<size_t>(m) * n;
+    rgrid = dim3((n + psh::kCrnTX - 1) / psh::kCrnTX, (m + psh::kCrnTY - 1) / psh::kCrnTY);
+    nb = rgrid.x * rgrid.y;
+    // every pixel can be a candidate (plateaus of equal response pass the 3x3 test): no overflow
+    cap = static_cast<int>(std::min<size_t>(npx, 0x7fffffffu));
+    auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+    off_part = up(npx * sizeof(float));
+    off_cnt = up(off_part + static_cast<size_t>(nb) * sizeof(float));
+    off_raw = up(off_cnt + sizeof(int));
+    bytes = off_raw + static_cast<size_t>(cap) * sizeof(psh::CornerKey);
+  }
+};
+
+int corner_candidates(const CornerWs &w, void *ws, const unsigned char *feature_u8_dev, const float *clean_dev,
+                      float *stats_dev, int m, int n, int block_size, int buffer_mask, double quality_level) {
   psh::Context &c = ctx();
-  std::lock_guard<std::recursive_mutex> lock(c.mu);
-  PSH_HIP(hipSetDevice(c.device));
-  if (g_corner_count == kMaxCornerJobs)
-    return fail(PSH_EINVAL, "lk_corners: %d corner requests are already in flight", kMaxCornerJobs);
-  CornerJob &job = g_corner_jobs[(g_corner_head + g_corner_count) % kMaxCornerJobs];
-  if (!job.ready) PSH_HIP(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
-  if (!job.pinned)
-    PSH_HIP(hipHostMalloc(&job.pinned, kPinnedHeader + kFirstChunk * sizeof(psh::CornerKey), hipHostMallocDefault));
-  const size_t npx = static_cast<size_t>(m) * n;
-  const dim3 rgrid((n + psh::kCrnTX - 1) / psh::kCrnTX, (m + psh::kCrnTY - 1) / psh::kCrnTY);
-  const int nb = rgrid.x * rgrid.y;
-  const int cap = static_cast<int>(std::max<size_t>(std::min<size_t>(npx / 6 + 4096, 1u << 26), kSortSpan));
-  size_t sort_temp = 0;
-  PSH_HIP(psh::sort_keys_desc(nullptr, nullptr, kSortSpan, nullptr, &sort_temp, c.stream));
-  auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
-  const size_t off_eig = 0, off_part = up(off_eig + npx * sizeof(float));
-  const size_t off_cnt = up(off_part + static_cast<size_t>(nb) * sizeof(float));
-  const size_t off_raw = up(off_cnt + sizeof(int));
-  const size_t off_sorted = up(off_raw + static_cast<size_t>(cap) * sizeof(psh::CornerKey));
-  const size_t off_temp = up(off_sorted + static_cast<size_t>(kSortSpan) * sizeof(psh::CornerKey));
-  void *ws = nullptr;
-  if (int rc = psh_malloc(&ws, off_temp + sort_temp)) return rc;  // stream-ordered caching allocator
-  struct Guard {  // the block goes back unless the request gets registered below
-    void *p;
-    ~Guard() { if (p) (void)psh_free(p); }
-  } guard{ws};
-  job.ws = ws;
   char *base = static_cast<char *>(ws);
-  float *eig = reinterpret_cast<float *>(base + off_eig);
-  float *part = reinterpret_cast<float *>(base + off_part);
-  int *cnt = reinterpret_cast<int *>(base + off_cnt);
-  psh::CornerKey *raw = reinterpret_cast<psh::CornerKey *>(base + off_raw);
-  psh::CornerKey *sorted = reinterpret_cast<psh::CornerKey *>(base + off_sorted);
-#define PSH_CRN_LAUNCH(BS)                                                                            \
-  hipLaunchKernelGGL(psh::lk_corner_response<BS>, rgrid, dim3(256), 0, c.stream, feature_u8_dev, clean_dev, \
+  float *eig = reinterpret_cast<float *>(base);
+  float *part = reinterpret_cast<float *>(base + w.off_part);
+  int *cnt = reinterpret_cast<int *>(base + w.off_cnt);
+  psh::CornerKey *raw = reinterpret_cast<psh::CornerKey *>(base + w.off_raw);
+#define PSH_CRN_LAUNCH(BS)                                                                              \
+  hipLaunchKernelGGL(psh::lk_corner_response<BS>, w.rgrid, dim3(256), 0, c.stream, feature_u8_dev, clean_dev, \
                      m, n, buffer_mask, stats_dev, eig, part, psh::Band{0, 0, m})
   if (block_size == 1) {
     PSH_CRN_LAUNCH(1);
@@ -1457,33 +1446,124 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
     PSH_CRN_LAUNCH(7);
   }
 #undef PSH_CRN_LAUNCH
-  hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb, stats_dev,
+  hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, w.nb, stats_dev,
                      static_cast<int>(psh::kEigMax));
   PSH_HIP(hipMemsetAsync(cnt, 0, sizeof(int), c.stream));
-  // the first kSortSpan slots are zeroed: unused ones sort behind every real (positive) key
-  PSH_HIP(hipMemsetAsync(raw, 0, static_cast<size_t>(kSortSpan) * sizeof(psh::CornerKey), c.stream));
   const dim3 sgrid((n + 63) / 64, (m + psh::kSelRows - 1) / psh::kSelRows);
-  hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n,
-                     buffer_mask, static_cast<float>(quality_level), stats_dev, raw, cap, cnt, psh::Band{0, 0, m});
+  hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n, buffer_mask,
+                     static_cast<float>(quality_level), stats_dev, raw, w.cap, cnt, psh::Band{0, 0, m});
   PSH_HIP(hipGetLastError());
-  PSH_HIP(psh::sort_keys_desc(raw, sorted, kSortSpan, base + off_temp, &sort_temp, c.stream));
-  // the count and the head of the ordered list go to pinned memory right behind the sort,
-  // so that work queued afterwards (pyramids) does not delay the host's pass
+  return PSH_OK;
+}
+
+int check_corner_args(const unsigned char *feature_u8_dev, const float *clean_dev, const float *stats_dev, int m,
+                      int n, int block_size, int max_corners) {
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_corners: invalid shape (%d,%d)", m, n);
+  if (!feature_u8_dev || !clean_dev || !stats_dev) return fail(PSH_EINVAL, "lk_corners: NULL pointer");
+  if (block_size < 1 || block_size > 2 * psh::kMaxBlockR + 1 || (block_size & 1) == 0)
+    return fail(PSH_EUNSUPPORTED, "lk_corners: block_size %d not implemented (odd, <= 7)", block_size);
+  if (max_corners <= 0) return fail(PSH_EINVAL, "lk_corners: max_corners must be positive");
+  if (static_cast<uint64_t>(m) * static_cast<uint64_t>(n) >= (1ull << 31))
+    return fail(PSH_EUNSUPPORTED, "lk_corners: more than 2^31 pixels");
+  return PSH_OK;
+}
+}  // namespace
+
+extern "C++" {
+namespace psh {
+int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_dev, float *stats_dev, int m, int n,
+                        int block_size, int buffer_mask, double quality_level, double min_distance, int max_corners,
+                        float *points_dev, int *npoints_dev) {
+  if (int rc = check_corner_args(feature_u8_dev, clean_dev, stats_dev, m, n, block_size, max_corners)) return rc;
+  if (!points_dev || !npoints_dev) return fail(PSH_EINVAL, "lk_corners: NULL pointer");
+  if (max_corners > corner_order_max_corners() || m > 65535 || n > 65535)
+    return fail(PSH_EUNSUPPORTED, "lk_corners: more than %d corners or 65535 rows / columns are ordered on the host",
+                corner_order_max_corners());
+  Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const CornerWs w(m, n);
+  void *ws = nullptr;
+  if (int rc = psh_malloc(&ws, w.bytes)) return rc;  // stream-ordered caching allocator
+  int rc = corner_candidates(w, ws, feature_u8_dev, clean_dev, stats_dev, m, n, block_size, buffer_mask, quality_level);
+  if (rc == PSH_OK) {
+    char *base = static_cast<char *>(ws);
+    const hipError_t e = launch_corner_order(
+        reinterpret_cast<const CornerKey *>(base + w.off_raw), reinterpret_cast<const int *>(base + w.off_cnt), w.cap,
+        stats_dev + kEigMax, static_cast<float>(quality_level), n, min_distance, max_corners, points_dev, npoints_dev,
+        c.stream);
+    if (e != hipSuccess) rc = fail(PSH_EHIP, "corner_order launch failed: %s", hipGetErrorString(e));
+  }
+  (void)psh_free(ws);  // the kernels above are queued in front of any reuse
+  return rc;
+}
+}  // namespace psh
+}  // extern "C++"
+
+int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
+                              float *stats_dev, int m, int n, int block_size, int buffer_mask,
+                              double quality_level, double min_distance, int max_corners) {
+  PSH_REQUIRE_INIT();
+  if (int rc = check_corner_args(feature_u8_dev, clean_dev, stats_dev, m, n, block_size, max_corners)) return rc;
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  if (g_corner_count == kMaxCornerJobs)
+    return fail(PSH_EINVAL, "lk_corners: %d corner requests are already in flight", kMaxCornerJobs);
+  CornerJob &job = g_corner_jobs[(g_corner_head + g_corner_count) % kMaxCornerJobs];
+  if (!job.ready) PSH_HIP(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
+  const bool host_ordered = max_corners > psh::corner_order_max_corners() || m > 65535 || n > 65535;
+  const size_t pin_need = kPinnedHeader + (host_ordered ? 0 : static_cast<size_t>(max_corners) * sizeof(float2));
+  static size_t pin_have[kMaxCornerJobs] = {0};
+  const int slot = static_cast<int>(&job - g_corner_jobs);
+  if (pin_have[slot] < pin_need) {
+    if (job.pinned) {
+      PSH_HIP(hipStreamSynchronize(c.stream));
+      PSH_HIP(hipHostFree(job.pinned));
+      job.pinned = nullptr;
+      pin_have[slot] = 0;
+    }
+    PSH_HIP(hipHostMalloc(&job.pinned, pin_need, hipHostMallocDefault));
+    pin_have[slot] = pin_need;
+  }
   char *pin = static_cast<char *>(job.pinned);
-  PSH_HIP(hipMemcpyAsync(pin, cnt, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-  PSH_HIP(hipMemcpyAsync(pin + kPinnedHeader, sorted, kFirstChunk * sizeof(psh::CornerKey),
-                         hipMemcpyDeviceToHost, c.stream));
+  const CornerWs w(m, n);
+  void *ws = nullptr;
+  if (host_ordered) {
+    if (int rc = psh_malloc(&ws, w.bytes)) return rc;
+    if (int rc = corner_candidates(w, ws, feature_u8_dev, clean_dev, stats_dev, m, n, block_size, buffer_mask,
+                                   quality_level)) {
+      (void)psh_free(ws);
+      return rc;
+    }
+    PSH_HIP(hipMemcpyAsync(pin, static_cast<char *>(ws) + w.off_cnt, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    job.raw_dev = reinterpret_cast<psh::CornerKey *>(static_cast<char *>(ws) + w.off_raw);
+  } else {
+    // accepted corners and their count in device memory, then one copy of both behind the kernels
+    const size_t pts_bytes = static_cast<size_t>(max_corners) * sizeof(float2);
+    if (int rc = psh_malloc(&ws, kPinnedHeader + pts_bytes)) return rc;
+    char *blk = static_cast<char *>(ws);
+    const int rc = psh::lk_corners_resident(feature_u8_dev, clean_dev, stats_dev, m, n, block_size, buffer_mask,
+                                            quality_level, min_distance, max_corners,
+                                            reinterpret_cast<float *>(blk + kPinnedHeader), reinterpret_cast<int *>(blk));
+    if (rc != PSH_OK) {
+      (void)psh_free(ws);
+      return rc;
+    }
+    PSH_HIP(hipMemcpyAsync(pin, blk, kPinnedHeader + pts_bytes, hipMemcpyDeviceToHost, c.stream));
+    (void)psh_free(ws);  // stream-ordered: the copy above is queued first
+    ws = nullptr;
+  }
   PSH_HIP(hipEventRecord(job.ready, c.stream));
+  job.ws = ws;
   job.active = true;
+  job.host_ordered = host_ordered;
   ++g_corner_count;
-  guard.p = nullptr;
   job.m = m;
   job.n = n;
-  job.cap = cap;
+  job.cap = w.cap;
   job.max_corners = max_corners;
   job.min_distance = min_distance;
-  job.sorted_dev = sorted;
-  job.raw_dev = raw;
   return PSH_OK;
 }
 
@@ -1501,44 +1581,34 @@ int psh_lk_corners_finish(float *points_host, int *count_host) {
   // whatever happens below, the request's device block goes back to the allocator
   struct Release {
     void *p;
-    ~Release() { (void)psh_free(p); }
+    ~Release() {
+      if (p) (void)psh_free(p);
+    }
   } release{job.ws};
   job.ws = nullptr;
   PSH_HIP(hipEventSynchronize(job.ready));
-  const int m = job.m, n = job.n, cap = job.cap, max_corners = job.max_corners;
-  const double min_distance = job.min_distance;
   const char *pin = static_cast<const char *>(job.pinned);
   const int count = *reinterpret_cast<const int *>(pin);
-  if (count > cap)
-    return fail(PSH_EUNSUPPORTED, "lk_corners: %d corner candidates exceed the buffer of %d", count, cap);
-  // ordered candidates: the device-sorted head first; the tail (rare) is fetched on demand; more
-  // candidates than the device ordered (very rare) are ordered here
-  std::vector<psh::CornerKey> keys;
-  const psh::CornerKey *head = reinterpret_cast<const psh::CornerKey *>(pin + kPinnedHeader);
-  size_t have = std::min<size_t>(static_cast<size_t>(count), kFirstChunk);
-  const bool device_sorted = count <= kSortSpan;
-  if (!device_sorted) {
-    keys.resize(static_cast<size_t>(count));
+  if (!job.host_ordered) {  // ordered and accepted on the device (lk_sparse.hip corner_order)
+    const int accepted = std::min(std::max(count, 0), job.max_corners);
+    std::memcpy(points_host, pin + kPinnedHeader, static_cast<size_t>(accepted) * sizeof(float2));
+    *count_host = accepted;
+    return PSH_OK;
+  }
+  // more corners than the device kernel keeps: all candidates come to the host, are ordered and walked here
+  const int m = job.m, n = job.n, max_corners = job.max_corners;
+  const double min_distance = job.min_distance;
+  std::vector<psh::CornerKey> keys(static_cast<size_t>(std::min(std::max(count, 0), job.cap)));
+  if (!keys.empty()) {
     PSH_HIP(hipMemcpyAsync(keys.data(), job.raw_dev, keys.size() * sizeof(psh::CornerKey), hipMemcpyDeviceToHost,
                            c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));
     std::sort(keys.begin(), keys.end(), std::greater<psh::CornerKey>());
-    head = keys.data();
-    have = keys.size();
   }
   GreedyGrid grid(m, n, min_distance, max_corners);
   int accepted = 0;
-  for (size_t ci = 0; ci < static_cast<size_t>(count) && accepted < max_corners; ++ci) {
-    if (ci == have) {  // the head is used up: bring the rest of the device-sorted list
-      keys.resize(static_cast<size_t>(count));
-      std::memcpy(keys.data(), head, have * sizeof(psh::CornerKey));
-      PSH_HIP(hipMemcpyAsync(keys.data() + have, job.sorted_dev + have, (keys.size() - have) * sizeof(psh::CornerKey),
-                             hipMemcpyDeviceToHost, c.stream));
-      PSH_HIP(hipStreamSynchronize(c.stream));
-      head = keys.data();
-      have = keys.size();
-    }
-    const unsigned addr = static_cast<unsigned>(head[ci] & 0xffffffffull);
+  for (size_t ci = 0; ci < keys.size() && accepted < max_corners; ++ci) {
+    const unsigned addr = static_cast<unsigned>(keys[ci] & 0xffffffffull);
     const int x = static_cast<int>(addr % static_cast<unsigned>(n)), y = static_cast<int>(addr / static_cast<unsigned>(n));
     if (min_distance >= 1.0 && !grid.offer(x, y)) continue;
     points_host[2 * accepted] = static_cast<float>(x);
@@ -1747,14 +1817,14 @@ int psh_lk_pyramids_free(void *handle) {
 }
 
 // picks the instantiation with the fewest window samples per thread
-static void launch_lk_track(int npts, hipStream_t stream, const psh::Pyramid &pyr, const float2 *pts, int win_w,
-                            int win_h, int max_count, float eps2, float min_eig_thr, float2 *next_pts,
-                            unsigned char *status) {
+static void launch_lk_track(int npts, const int *npts_dev, hipStream_t stream, const psh::Pyramid &pyr,
+                            const float2 *pts, int win_w, int win_h, int max_count, float eps2, float min_eig_thr,
+                            float2 *next_pts, unsigned char *status) {
   const int per = (win_w * win_h + 255) / 256;
   if (win_w <= psh::kRowsMaxWin) {  // one lane per window column, ceil(win_h / 4) rows per wave
 #define PSH_TRACK_ROWS(R)                                                                               \
-  hipLaunchKernelGGL(psh::lk_track_rows<R>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h, \
-                     max_count, eps2, min_eig_thr, next_pts, status)
+  hipLaunchKernelGGL(psh::lk_track_rows<R>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, npts_dev, win_w, \
+                     win_h, max_count, eps2, min_eig_thr, next_pts, status)
     const int rows = (win_h + 3) / 4;
     if (rows <= 8) {
       PSH_TRACK_ROWS(8);
@@ -1767,13 +1837,13 @@ static void launch_lk_track(int npts, hipStream_t stream, const psh::Pyramid &py
     return;
   }
   if (per <= 4) {
-    hipLaunchKernelGGL(psh::lk_track<4>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h, max_count,
-                       eps2, min_eig_thr, next_pts, status);
+    hipLaunchKernelGGL(psh::lk_track<4>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, npts_dev, win_w, win_h,
+                       max_count, eps2, min_eig_thr, next_pts, status);
   } else if (per <= 10) {
-    hipLaunchKernelGGL(psh::lk_track<10>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h,
+    hipLaunchKernelGGL(psh::lk_track<10>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, npts_dev, win_w, win_h,
                        max_count, eps2, min_eig_thr, next_pts, status);
   } else {
-    hipLaunchKernelGGL(psh::lk_track<16>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, win_w, win_h,
+    hipLaunchKernelGGL(psh::lk_track<16>, dim3(npts), dim3(256), 0, stream, pyr, pts, npts, npts_dev, win_w, win_h,
                        max_count, eps2, min_eig_thr, next_pts, status);
   }
 }
@@ -1802,7 +1872,7 @@ int psh_lk_track_pyr_dev(void *handle, const float *points_host, int npts, int m
   auto run = [&]() -> int {
     PSH_HIP(hipMemcpyAsync(d_pts, points_host, static_cast<size_t>(npts) * sizeof(float2),
                            hipMemcpyHostToDevice, c.stream));
-    launch_lk_track(npts, c.stream, ps->pyr, d_pts, ps->win_w, ps->win_h, max_count, eps * eps,
+    launch_lk_track(npts, nullptr, c.stream, ps->pyr, d_pts, ps->win_w, ps->win_h, max_count, eps * eps,
                     static_cast<float>(min_eig_threshold), d_next, d_st);
     PSH_HIP(hipGetLastError());
     PSH_HIP(hipMemcpyAsync(next_points_host, d_next, static_cast<size_t>(npts) * sizeof(float2),
@@ -1833,11 +1903,13 @@ int psh_lk_track_dev(const unsigned char *prev_u8_dev, const unsigned char *next
 
 namespace psh {
 
-int lk_track_pool(void *pyramid_handle, const float *points_host, int npts, int max_count, double epsilon,
-                  double min_eig_threshold, double *pool_xy_dev, double *pool_uv_dev, int *pool_count_dev,
-                  int pool_capacity) {
-  if (!pyramid_handle || !points_host || !pool_xy_dev || !pool_uv_dev || !pool_count_dev)
+int lk_track_pool(void *pyramid_handle, const float *points_host, const float *points_dev, const int *npts_dev,
+                  int npts, int max_count, double epsilon, double min_eig_threshold, double *pool_xy_dev,
+                  double *pool_uv_dev, int *pool_count_dev, int pool_capacity) {
+  if (!pyramid_handle || !pool_xy_dev || !pool_uv_dev || !pool_count_dev)
     return fail(PSH_EINVAL, "lk_track_pool: NULL pointer");
+  if ((points_host == nullptr) == (points_dev == nullptr) || (points_dev && !npts_dev))
+    return fail(PSH_EINVAL, "lk_track_pool: points either on the host or on the device with their count");
   if (npts <= 0) return PSH_OK;
   PyramidSet *ps = static_cast<PyramidSet *>(pyramid_handle);
   max_count = std::min(std::max(max_count, 0), 100);
@@ -1851,28 +1923,30 @@ int lk_track_pool(void *pyramid_handle, const float *points_host, int npts, int 
   float2 *d_pts = reinterpret_cast<float2 *>(base);
   float2 *d_next = reinterpret_cast<float2 *>(base + pts_bytes);
   unsigned char *d_st = reinterpret_cast<unsigned char *>(base + 2 * pts_bytes);
-  // pinned staging slot per call (ring): the copy is asynchronous and the caller's buffer may
-  // be reused at once
-  static void *ring = nullptr;
-  static size_t ring_slot = 0;
-  constexpr size_t kSlots = 8, kSlotBytes = 1 << 16;
-  if (static_cast<size_t>(npts) * sizeof(float2) > kSlotBytes) {
-    (void)psh_free(blk);
-    return fail(PSH_EUNSUPPORTED, "lk_track_pool: more than %zu points", kSlotBytes / sizeof(float2));
-  }
-  if (!ring) PSH_HIP(hipHostMalloc(&ring, kSlots * kSlotBytes, hipHostMallocDefault));
-  if (ring_slot == kSlots) {
-    PSH_HIP(hipStreamSynchronize(c.stream));
-    ring_slot = 0;
-  }
-  char *slot = static_cast<char *>(ring) + (ring_slot++) * kSlotBytes;
-  std::memcpy(slot, points_host, static_cast<size_t>(npts) * sizeof(float2));
   const float eps = static_cast<float>(epsilon);
   auto run = [&]() -> int {
-    PSH_HIP(hipMemcpyAsync(d_pts, slot, static_cast<size_t>(npts) * sizeof(float2), hipMemcpyHostToDevice, c.stream));
-    launch_lk_track(npts, c.stream, ps->pyr, d_pts, ps->win_w, ps->win_h, max_count, eps * eps,
+    const float2 *pts = reinterpret_cast<const float2 *>(points_dev);
+    if (points_host) {
+      // pinned staging slot per call (ring): the copy is asynchronous and the caller's buffer may
+      // be reused at once
+      static void *ring = nullptr;
+      static size_t ring_slot = 0;
+      constexpr size_t kSlots = 8, kSlotBytes = 1 << 16;
+      if (static_cast<size_t>(npts) * sizeof(float2) > kSlotBytes)
+        return fail(PSH_EUNSUPPORTED, "lk_track_pool: more than %zu points", kSlotBytes / sizeof(float2));
+      if (!ring) PSH_HIP(hipHostMalloc(&ring, kSlots * kSlotBytes, hipHostMallocDefault));
+      if (ring_slot == kSlots) {
+        PSH_HIP(hipStreamSynchronize(c.stream));
+        ring_slot = 0;
+      }
+      char *slot = static_cast<char *>(ring) + (ring_slot++) * kSlotBytes;
+      std::memcpy(slot, points_host, static_cast<size_t>(npts) * sizeof(float2));
+      PSH_HIP(hipMemcpyAsync(d_pts, slot, static_cast<size_t>(npts) * sizeof(float2), hipMemcpyHostToDevice, c.stream));
+      pts = d_pts;
+    }
+    launch_lk_track(npts, npts_dev, c.stream, ps->pyr, pts, ps->win_w, ps->win_h, max_count, eps * eps,
                     static_cast<float>(min_eig_threshold), d_next, d_st);
-    hipLaunchKernelGGL(lk_pool_append, dim3(1), dim3(256), 0, c.stream, d_pts, d_next, d_st, npts,
+    hipLaunchKernelGGL(lk_pool_append, dim3(1), dim3(256), 0, c.stream, pts, d_next, d_st, npts, npts_dev,
                        reinterpret_cast<double2 *>(pool_xy_dev), reinterpret_cast<double2 *>(pool_uv_dev),
                        pool_count_dev, pool_capacity);
     PSH_HIP(hipGetLastError());

@@ -1,0 +1,571 @@
+// The sparse stage of dense Lucas-Kanade without a host hand-over.
+//
+// Two single-workgroup kernels that keep the ordered, data-dependent parts of
+// pysteps/motion/lucaskanade.py:207-274 on the device, so that one estimate is a chain of
+// kernel launches with no device->host copy in the middle:
+//
+//  * corner_order  - the walk of cv2.goodFeaturesToTrack over the corner candidates
+//    (pysteps/feature/shitomasi.py:152-166; OpenCV featureselect.cpp): strongest response first,
+//    ties by the higher pixel address, a candidate is accepted unless an accepted corner of a
+//    neighbouring min-distance cell lies closer than min_distance, stop at max_corners.
+//    Only the head of the ordered list is ever walked, so nothing is sorted as a whole: a
+//    1024-bin histogram over the key range picks the threshold key above which ~3 k candidates
+//    lie, those are gathered into LDS, ordered there (bitonic network) and walked in batches of
+//    64 - every wave tests the batch against its share of the accepted corners, wave 0 resolves
+//    the conflicts inside the batch in order.  If the head runs out before max_corners corners
+//    are accepted, the next chunk below the threshold is selected the same way (any number of
+//    candidates, any response distribution: an overfull bin is refined 10 key bits at a time).
+//  * vectors_finish - what follows the outlier test (lucaskanade.py:254-274): drop the flagged
+//    vectors, decluster (pysteps/utils/cleansing.py:21-121: cell = floor(xy / scale), cells in
+//    lexicographic order, component-wise medians), the trivial cases of the interpolator
+//    (pysteps/decorators.py:199-208) and the float32 sample list + sample count the IDW kernels
+//    read from device memory (IdwDyn).
+//
+// Both replace host code of earlier versions (a rocPRIM sort + host pass, psh_decluster_host);
+// results are bit-identical to those (tests/test_lk_gpu.py compares against the host entry
+// points and the oracle).
+#include "common.h"
+
+namespace psh {
+namespace {
+
+using CornerKey = unsigned long long;
+
+constexpr int kOrdThreads = 1024;
+constexpr int kOrdWaves = kOrdThreads / 64;
+constexpr int kOrdBins = 1024;
+constexpr int kChunkCap = 4096;     // candidates ordered at a time (32 KiB of keys in LDS)
+constexpr int kChunkTarget = 2560;  // a chunk holds at least this many (unless fewer are left)
+constexpr int kMaxCornersDev = 2048;  // accepted corners kept in LDS (16 KiB)
+
+// descending (DESC) or ascending bitonic sort of the first `p2` (power of two) LDS entries
+template <bool DESC>
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long *keys, int p2) {
+  for (int k = 2; k <= p2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < p2; i += blockDim.x) {
+        const int o = i ^ j;
+        if (o > i) {
+          const unsigned long long a = keys[i], b = keys[o];
+          const bool first_half = (i & k) == 0;
+          const bool swap = (first_half == DESC) ? a < b : a > b;
+          if (swap) {
+            keys[i] = b;
+            keys[o] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int next_pow2(int v) {
+  int p = 64;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// goodFeaturesToTrack: ordered min-distance acceptance
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__restrict__ raw,
+                                                            const int *__restrict__ raw_count, int cap,
+                                                            const float *__restrict__ eig_max, float quality,
+                                                            int n, int cell, double md2, int use_grid,
+                                                            int max_corners, float2 *__restrict__ points,
+                                                            int *__restrict__ npoints) {
+  __shared__ CornerKey s_keys[kChunkCap];
+  __shared__ int s_hist[kOrdBins];
+  __shared__ unsigned long long s_conf[kOrdWaves][64];
+  __shared__ unsigned long long s_rej[kOrdWaves];
+  __shared__ uint2 s_acc[kMaxCornersDev];  // accepted corners: {x | y << 16, x cell | y cell << 16}
+  __shared__ int s_fill, s_nacc, s_cut, s_cut_next;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nkeys = min(max(*raw_count, 0), cap);
+  // every candidate's response exceeds thr = max * quality (lk_corner_select), so the keys lie in
+  // [key_lo, key_hi)
+  const float top = fmaxf(*eig_max, 0.f);
+  const float thr = fmaxf(top * quality, 0.f);
+  const CornerKey key_lo = static_cast<CornerKey>(__float_as_uint(thr)) << 32;
+  CornerKey upper = (static_cast<CornerKey>(__float_as_uint(top)) + 1ull) << 32;  // exclusive
+  int nacc = 0;
+  int remaining = nkeys;  // candidates below `upper`
+  while (remaining > 0 && nacc < max_corners) {
+    // ---- threshold key T: the chunk is every candidate in [T, upper) ------------------------
+    CornerKey rlo = key_lo, rhi = upper, T = key_lo;
+    int above = 0;  // candidates in [rhi, upper): part of the chunk whatever happens below
+    for (int level = 0;; ++level) {  // (the bin width shrinks by 2^10 per level: at most 7 levels)
+      int sh = 0;
+      while (((rhi - 1ull - rlo) >> sh) >= static_cast<unsigned long long>(kOrdBins)) ++sh;
+      for (int i = tid; i < kOrdBins; i += kOrdThreads) s_hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < nkeys; i += kOrdThreads) {
+        const CornerKey k = raw[i];
+        if (k >= rlo && k < rhi) atomicAdd(&s_hist[static_cast<int>((k - rlo) >> sh)], 1);
+      }
+      __syncthreads();
+      if (wave == 0) {  // the largest bin whose suffix count (incl. `above`) no longer fits the chunk
+        constexpr int kPer = kOrdBins / 64;
+        int tot = 0;
+        for (int q = 0; q < kPer; ++q) tot += s_hist[lane * kPer + q];
+        int incl = tot;  // -> sum over lanes >= this one
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int dn = __shfl_down(incl, d);
+          if (lane + d < 64) incl += dn;
+        }
+        int run = incl - tot + above;
+        int over = -1, over_next = 0;  // bin, and the suffix count of the bins above it
+        for (int q = kPer - 1; q >= 0; --q) {
+          const int before = run;
+          run += s_hist[lane * kPer + q];
+          if (run > kChunkCap && over < 0) {
+            over = lane * kPer + q;
+            over_next = before;
+          }
+        }
+        int best = over;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d));
+        if (best < 0) {  // everything that is left fits
+          if (lane == 0) {
+            s_cut = -1;
+            s_cut_next = incl + above;  // lane 0: all bins
+          }
+        } else if (over == best) {
+          s_cut = over;
+          s_cut_next = over_next;
+        }
+      }
+      __syncthreads();
+      const int over = s_cut, fits = s_cut_next;  // `fits` candidates lie above bin `over`
+      __syncthreads();
+      if (over < 0 || level >= 8) {
+        T = rlo;
+        break;
+      }
+      if (fits >= kChunkTarget) {
+        T = rlo + (static_cast<CornerKey>(over + 1) << sh);
+        break;
+      }
+      // too few above the overfull bin: they are taken, the threshold is looked for inside the bin
+      above = fits;
+      rlo = rlo + (static_cast<CornerKey>(over) << sh);
+      const CornerKey bin_hi = rlo + (1ull << sh);
+      rhi = bin_hi < rhi ? bin_hi : rhi;
+    }
+    // ---- gather the chunk into LDS, order it --------------------------------------------------
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nkeys; i0 += kOrdThreads) {
+      const int i = i0 + tid;
+      const CornerKey k = i < nkeys ? raw[i] : 0ull;
+      const bool keep = i < nkeys && k >= T && k < upper;
+      const unsigned long long mask = __ballot(keep);
+      if (mask == 0ull) continue;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_fill, __popcll(mask));
+      base = __shfl(base, 0);
+      const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (keep && at < kChunkCap) s_keys[at] = k;
+    }
+    __syncthreads();
+    const int cnt = min(s_fill, kChunkCap);
+    if (cnt == 0) break;  // (cannot happen: the chunk holds at least the strongest candidate left)
+    const int p2 = next_pow2(cnt);
+    for (int i = cnt + tid; i < p2; i += kOrdThreads) s_keys[i] = 0ull;  // sorts behind every real key
+    __syncthreads();
+    bitonic_sort_lds<true>(s_keys, p2);
+    // ---- walk the chunk in batches of 64 ------------------------------------------------------
+    for (int b0 = 0; b0 < cnt && nacc < max_corners; b0 += 64) {
+      const int i = b0 + lane;
+      const bool valid = i < cnt;
+      const unsigned addr = valid ? static_cast<unsigned>(s_keys[i] & 0xffffffffull) : 0u;
+      const int x = static_cast<int>(addr % static_cast<unsigned>(n));
+      const int y = static_cast<int>(addr / static_cast<unsigned>(n));
+      const int cx = x / cell, cy = y / cell;
+      unsigned long long conf = 0ull;
+      bool rejected = false;
+      if (use_grid) {
+        // against this wave's share of the corners accepted so far
+        for (int j = wave; j < nacc; j += kOrdWaves) {
+          const uint2 a = s_acc[j];  // the same address in every lane: LDS broadcast
+          const int ax = static_cast<int>(a.x & 0xffffu), ay = static_cast<int>(a.x >> 16);
+          const int acx = static_cast<int>(a.y & 0xffffu), acy = static_cast<int>(a.y >> 16);
+          const double dx = static_cast<double>(x - ax), dy = static_cast<double>(y - ay);
+          // OpenCV only looks at the 3x3 cells around the candidate (cell = round(min_distance))
+          if (abs(cx - acx) <= 1 && abs(cy - acy) <= 1 && dx * dx + dy * dy < md2) rejected = true;
+        }
+        // and against the earlier candidates of the batch this wave is responsible for
+#pragma unroll
+        for (int q = 0; q < 64 / kOrdWaves; ++q) {
+          const int j = wave + q * kOrdWaves;
+          const int ox = __shfl(x, j), oy = __shfl(y, j), ocx = __shfl(cx, j), ocy = __shfl(cy, j);
+          const double dx = static_cast<double>(x - ox), dy = static_cast<double>(y - oy);
+          if (j < lane && abs(cx - ocx) <= 1 && abs(cy - ocy) <= 1 && dx * dx + dy * dy < md2) conf |= 1ull << j;
+        }
+      }
+      s_conf[wave][lane] = conf;
+      const unsigned long long rej_mask = __ballot(rejected);
+      if (lane == 0) s_rej[wave] = rej_mask;
+      __syncthreads();
+      if (wave == 0) {
+        unsigned long long rej = 0ull, cf = 0ull;
+#pragma unroll
+        for (int w = 0; w < kOrdWaves; ++w) {
+          rej |= s_rej[w];
+          cf |= s_conf[w][lane];
+        }
+        const unsigned long long alive = __ballot(valid) & ~rej;
+        const unsigned cf_lo = static_cast<unsigned>(cf), cf_hi = static_cast<unsigned>(cf >> 32);
+        unsigned long long acc = 0ull;  // accepted candidates of the batch, decided in order
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+          const unsigned long long cq =
+              (static_cast<unsigned long long>(__builtin_amdgcn_readlane(cf_hi, q)) << 32) |
+              __builtin_amdgcn_readlane(cf_lo, q);
+          if (((alive >> q) & 1ull) && (cq & acc) == 0ull) acc |= 1ull << q;
+        }
+        int room = max_corners - nacc;
+        while (__popcll(acc) > room) acc &= ~(1ull << (63 - __clzll(acc)));  // the last ones do not fit
+        if ((acc >> lane) & 1ull) {
+          const int at = nacc + __popcll(acc & ((1ull << lane) - 1ull));
+          s_acc[at] = make_uint2(static_cast<unsigned>(x) | (static_cast<unsigned>(y) << 16),
+                                 static_cast<unsigned>(cx) | (static_cast<unsigned>(cy) << 16));
+          points[at] = make_float2(static_cast<float>(x), static_cast<float>(y));
+        }
+        if (lane == 0) s_nacc = nacc + __popcll(acc);
+      }
+      __syncthreads();
+      nacc = s_nacc;
+    }
+    remaining -= cnt;
+    if (T <= key_lo) break;  // the chunk reached the bottom of the key range
+    upper = T;
+    __syncthreads();
+  }
+  if (tid == 0) *npoints = nacc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// after the outlier test: filter, decluster, interpolator preamble
+// ---------------------------------------------------------------------------------------------
+constexpr int kFinMax = 8192;  // pooled vectors (max_corners x frame pairs), as in dense_lk.hip
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmin(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d));
+  return v;
+}
+
+__global__ __launch_bounds__(kOrdThreads) void vectors_finish(const double2 *__restrict__ pool_xy,
+                                                              const double2 *__restrict__ pool_uv,
+                                                              const unsigned char *__restrict__ flags,
+                                                              const int *__restrict__ pool_count, int capacity,
+                                                              double scale, int m, int n,
+                                                              float2 *__restrict__ out_xy,
+                                                              float2 *__restrict__ out_uv,
+                                                              IdwDyn *__restrict__ dyn) {
+  __shared__ unsigned long long s_keys[kFinMax];  // (x cell << 16 | y cell) << 32 | sample index
+  __shared__ unsigned short s_seg[kFinMax];       // output slot of the cell an ordered entry belongs to
+  __shared__ int s_scan[kOrdWaves];
+  __shared__ double s_stat[6][kOrdWaves];
+  __shared__ double s_first[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pooled = min(max(*pool_count, 0), min(capacity, kFinMax));
+  const bool decl = scale > 1.0;
+  constexpr unsigned long long kDropped = ~0ull;
+  // ---- keys: dropped vectors sort behind the kept ones ----------------------------------------
+  const int p2 = next_pow2(pooled);
+  for (int i = tid; i < p2; i += kOrdThreads) {
+    unsigned long long key = kDropped;
+    if (i < pooled && !(pooled >= 2 && flags[i])) {  // fewer than two samples: nothing is an outlier
+      unsigned cellkey = 0u;
+      if (decl) {
+        const double2 p = pool_xy[i];
+        const double fx = floor(p.x / scale), fy = floor(p.y / scale);
+        const unsigned cx = static_cast<unsigned>(fmin(fmax(fx, 0.0), 65535.0));
+        const unsigned cy = static_cast<unsigned>(fmin(fmax(fy, 0.0), 65535.0));
+        cellkey = (cx << 16) | cy;
+      }
+      // without declustering every vector is its own "cell", in input order
+      key = decl ? (static_cast<unsigned long long>(cellkey) << 32) | static_cast<unsigned>(i)
+                 : static_cast<unsigned long long>(i) << 32 | static_cast<unsigned>(i);
+    }
+    s_keys[i] = key;
+  }
+  __syncthreads();
+  bitonic_sort_lds<false>(s_keys, p2);
+  // ---- cells: entry t opens a cell if its cell key differs from the entry before ---------------
+  // each thread owns p2 / 1024 consecutive entries (at least 1 when p2 < 1024: guarded)
+  const int per = max(p2 / kOrdThreads, 1);
+  const int t0 = tid * per;
+  int heads = 0, kept_here = 0;
+  for (int q = 0; q < per; ++q) {
+    const int t = t0 + q;
+    if (t >= p2) break;
+    const unsigned long long k = s_keys[t];
+    if (k == kDropped) continue;
+    ++kept_here;
+    if (t == 0 || (s_keys[t - 1] >> 32) != (k >> 32)) ++heads;
+  }
+  // exclusive scan of `heads` over the threads
+  int incl = heads;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) s_scan[wave] = incl;
+  __syncthreads();
+  int before = incl - heads, cells = 0;
+  for (int w = 0; w < kOrdWaves; ++w) {
+    if (w < wave) before += s_scan[w];
+    cells += s_scan[w];
+  }
+  {
+    int slot = before - 1;
+    for (int q = 0; q < per; ++q) {
+      const int t = t0 + q;
+      if (t >= p2) break;
+      const unsigned long long k = s_keys[t];
+      if (k == kDropped) continue;
+      if (t == 0 || (s_keys[t - 1] >> 32) != (k >> 32)) ++slot;
+      s_seg[t] = static_cast<unsigned short>(slot);
+    }
+  }
+  (void)kept_here;
+  __syncthreads();
+  // ---- medians: every entry ranks itself within its cell; the lower median's owner writes -------
+  double vmin = INFINITY, vmax = -INFINITY;
+  double xmin = 0.0, xmax = static_cast<double>(n) - 1.0, ymin = 0.0, ymax = static_cast<double>(m) - 1.0;
+  for (int t = tid; t < p2; t += kOrdThreads) {
+    const unsigned long long k = s_keys[t];
+    if (k == kDropped) continue;
+    const unsigned cellkey = static_cast<unsigned>(k >> 32);
+    int s = t, e = t + 1;
+    while (s > 0 && static_cast<unsigned>(s_keys[s - 1] >> 32) == cellkey) --s;
+    while (e < p2 && static_cast<unsigned>(s_keys[e] >> 32) == cellkey) ++e;
+    const int members = e - s;
+    const int me = static_cast<int>(k & 0xffffffffull);
+    const double2 mxy = pool_xy[me], muv = pool_uv[me];
+    const double mine[4] = {mxy.x, mxy.y, muv.x, muv.y};
+    int rank[4] = {0, 0, 0, 0};
+    double succ[4] = {INFINITY, INFINITY, INFINITY, INFINITY};  // smallest value ordered behind mine
+    for (int q = s; q < e; ++q) {
+      if (q == t) continue;
+      const int o = static_cast<int>(s_keys[q] & 0xffffffffull);
+      const double2 oxy = pool_xy[o], ouv = pool_uv[o];
+      const double other[4] = {oxy.x, oxy.y, ouv.x, ouv.y};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool below = other[c] < mine[c] || (other[c] == mine[c] && q < t);
+        rank[c] += below ? 1 : 0;
+        if (!below) succ[c] = fmin(succ[c], other[c]);
+      }
+    }
+    const int lower = (members - 1) / 2;
+    const bool even = (members & 1) == 0;
+    const int slot = s_seg[t];
+    double med[4];
+    bool have[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      have[c] = rank[c] == lower;
+      med[c] = 0.5 * (mine[c] + (even ? succ[c] : mine[c]));  // np.median: mean of the two middle values
+    }
+    if (have[0]) {
+      reinterpret_cast<float *>(out_xy)[2 * slot] = static_cast<float>(med[0]);
+      xmin = fmin(xmin, med[0]);
+      xmax = fmax(xmax, med[0]);
+    }
+    if (have[1]) {
+      reinterpret_cast<float *>(out_xy)[2 * slot + 1] = static_cast<float>(med[1]);
+      ymin = fmin(ymin, med[1]);
+      ymax = fmax(ymax, med[1]);
+    }
+    if (have[2]) {
+      reinterpret_cast<float *>(out_uv)[2 * slot] = static_cast<float>(med[2]);
+      vmin = fmin(vmin, med[2]);
+      vmax = fmax(vmax, med[2]);
+      if (slot == 0) s_first[0] = med[2];
+    }
+    if (have[3]) {
+      reinterpret_cast<float *>(out_uv)[2 * slot + 1] = static_cast<float>(med[3]);
+      vmin = fmin(vmin, med[3]);
+      vmax = fmax(vmax, med[3]);
+      if (slot == 0) s_first[1] = med[3];
+    }
+  }
+  // ---- statistics for the interpolator preamble -------------------------------------------------
+  const double part[6] = {wave_min_f64(vmin), wave_max_f64(vmax), wave_min_f64(xmin),
+                          wave_max_f64(xmax), wave_min_f64(ymin), wave_max_f64(ymax)};
+  if (lane == 0)
+    for (int c = 0; c < 6; ++c) s_stat[c][wave] = part[c];
+  __syncthreads();
+  if (tid == 0) {
+    double r[6];
+    for (int c = 0; c < 6; ++c) {
+      r[c] = s_stat[c][0];
+      for (int w = 1; w < kOrdWaves; ++w) r[c] = (c & 1) ? fmax(r[c], s_stat[c][w]) : fmin(r[c], s_stat[c][w]);
+    }
+    IdwDyn d;
+    d.L = cells;
+    d.mode = 0;
+    d.cu = 0.f;
+    d.cv = 0.f;
+    d.reach = 1.f;
+    if (cells == 0) {  // lucaskanade.py:245-249, 268-269: zero field
+      d.mode = 1;
+    } else if (cells == 1) {  // decorators.py:200-203: one sample -> constant field
+      d.mode = 1;
+      d.cu = static_cast<float>(s_first[0]);
+      d.cv = static_cast<float>(s_first[1]);
+    } else if (r[0] == r[1]) {  // decorators.py:207-208: all elements equal
+      d.mode = 1;
+      d.cu = static_cast<float>(s_first[0]);
+      d.cv = static_cast<float>(s_first[0]);
+    } else {
+      const double dx = r[3] - r[2], dy = r[5] - r[4];
+      d.reach = static_cast<float>(fma(sqrt(fma(dx, dx, dy * dy)), 1.001, 1.0));
+    }
+    *dyn = d;
+  }
+}
+
+}  // namespace
+
+int corner_order_max_corners() { return kMaxCornersDev; }
+
+hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw_count_dev, int cap,
+                               const float *eig_max_dev, float quality, int n, double min_distance,
+                               int max_corners, float *points_dev, int *npoints_dev, hipStream_t stream) {
+  const int cell = static_cast<int>(std::lrint(min_distance)) > 1 ? static_cast<int>(std::lrint(min_distance)) : 1;
+  hipLaunchKernelGGL(corner_order, dim3(1), dim3(kOrdThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
+                     quality, n, cell, min_distance * min_distance, min_distance >= 1.0 ? 1 : 0, max_corners,
+                     reinterpret_cast<float2 *>(points_dev), npoints_dev);
+  return hipGetLastError();
+}
+
+hipError_t launch_vectors_finish(const double *pool_xy_dev, const double *pool_uv_dev,
+                                 const unsigned char *flags_dev, const int *pool_count_dev, int capacity,
+                                 double decl_scale, int m, int n, float *xy_out_dev, float *uv_out_dev,
+                                 IdwDyn *dyn_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(vectors_finish, dim3(1), dim3(kOrdThreads), 0, stream,
+                     reinterpret_cast<const double2 *>(pool_xy_dev), reinterpret_cast<const double2 *>(pool_uv_dev),
+                     flags_dev, pool_count_dev, capacity, decl_scale, m, n, reinterpret_cast<float2 *>(xy_out_dev),
+                     reinterpret_cast<float2 *>(uv_out_dev), dyn_dev);
+  return hipGetLastError();
+}
+
+}  // namespace psh
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: the two kernels with host buffers (the staged Python loop, the row-band path that
+// gathers candidate keys from several ranks, and the parity tests use these)
+// ---------------------------------------------------------------------------------------------
+extern "C" int psh_lk_order_host(const unsigned long long *keys_host, int count, float response_max,
+                                 double quality_level, int m, int n, double min_distance, int max_corners,
+                                 float *points_host, int *count_host) {
+  PSH_REQUIRE_INIT();
+  if (!points_host || !count_host || (count > 0 && !keys_host)) return psh::fail(PSH_EINVAL, "lk_order: NULL pointer");
+  if (count < 0 || m <= 0 || n <= 0 || max_corners <= 0) return psh::fail(PSH_EINVAL, "lk_order: invalid argument");
+  if (max_corners > psh::kMaxCornersDev || m > 65535 || n > 65535)
+    return psh::fail(PSH_EUNSUPPORTED, "lk_order: more than %d corners or 65535 rows / columns", psh::kMaxCornersDev);
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t key_bytes = (static_cast<size_t>(count) * sizeof(unsigned long long) + 255) & ~static_cast<size_t>(255);
+  const size_t pts_bytes = static_cast<size_t>(max_corners) * 2 * sizeof(float);
+  void *blk = nullptr;
+  if (int rc = psh_malloc(&blk, key_bytes + 256 + pts_bytes)) return rc;
+  char *base = static_cast<char *>(blk);
+  unsigned long long *d_keys = reinterpret_cast<unsigned long long *>(base);
+  int *d_hdr = reinterpret_cast<int *>(base + key_bytes);  // [count | accepted | response max (float)]
+  float *d_pts = reinterpret_cast<float *>(base + key_bytes + 256);
+  int rc = PSH_OK;
+  auto run = [&]() -> int {
+    struct {
+      int count, accepted;
+      float top;
+    } hdr = {count, 0, response_max};
+    if (count > 0) PSH_HIP(hipMemcpyAsync(d_keys, keys_host, static_cast<size_t>(count) * 8, hipMemcpyHostToDevice, c.stream));
+    PSH_HIP(hipMemcpyAsync(d_hdr, &hdr, sizeof(hdr), hipMemcpyHostToDevice, c.stream));
+    PSH_HIP(hipStreamSynchronize(c.stream));  // hdr lives on this stack frame
+    PSH_HIP(psh::launch_corner_order(d_keys, d_hdr, count, reinterpret_cast<const float *>(d_hdr + 2),
+                                     static_cast<float>(quality_level), n, min_distance, max_corners, d_pts, d_hdr + 1,
+                                     c.stream));
+    int accepted = 0;
+    PSH_HIP(hipMemcpyAsync(&accepted, d_hdr + 1, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    accepted = accepted < 0 ? 0 : accepted > max_corners ? max_corners : accepted;
+    if (accepted > 0) {
+      PSH_HIP(hipMemcpyAsync(points_host, d_pts, static_cast<size_t>(accepted) * 2 * sizeof(float), hipMemcpyDeviceToHost,
+                             c.stream));
+      PSH_HIP(hipStreamSynchronize(c.stream));
+    }
+    *count_host = accepted;
+    return PSH_OK;
+  };
+  rc = run();
+  (void)psh_free(blk);
+  return rc;
+}
+
+extern "C" int psh_vectors_finish_host(const double *xy, const double *values, const unsigned char *outlier_flags,
+                                       int count, double decl_scale, int m, int n, float *out_xy, float *out_values,
+                                       int *out_count, int *out_mode, float *out_const, float *out_reach) {
+  PSH_REQUIRE_INIT();
+  if (count < 0 || m <= 0 || n <= 0) return psh::fail(PSH_EINVAL, "vectors_finish: invalid argument");
+  if (count > psh::kFinMax) return psh::fail(PSH_EUNSUPPORTED, "vectors_finish: more than %d vectors", psh::kFinMax);
+  if (!out_xy || !out_values || !out_count || !out_mode || !out_const || !out_reach ||
+      (count > 0 && (!xy || !values || !outlier_flags)))
+    return psh::fail(PSH_EINVAL, "vectors_finish: NULL pointer");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t cap = static_cast<size_t>(count > 0 ? count : 1);
+  const size_t vec = cap * 16, off_uv = vec, off_fl = 2 * vec, off_cnt = (off_fl + cap + 255) & ~static_cast<size_t>(255);
+  const size_t off_oxy = off_cnt + 256, off_ouv = off_oxy + cap * 8, off_dyn = off_ouv + cap * 8;
+  void *blk = nullptr;
+  if (int rc = psh_malloc(&blk, off_dyn + sizeof(psh::IdwDyn))) return rc;
+  char *base = static_cast<char *>(blk);
+  auto run = [&]() -> int {
+    if (count > 0) {
+      PSH_HIP(hipMemcpyAsync(base, xy, vec, hipMemcpyHostToDevice, c.stream));
+      PSH_HIP(hipMemcpyAsync(base + off_uv, values, vec, hipMemcpyHostToDevice, c.stream));
+      PSH_HIP(hipMemcpyAsync(base + off_fl, outlier_flags, cap, hipMemcpyHostToDevice, c.stream));
+    }
+    PSH_HIP(hipMemcpyAsync(base + off_cnt, &count, sizeof(int), hipMemcpyHostToDevice, c.stream));
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    PSH_HIP(psh::launch_vectors_finish(reinterpret_cast<const double *>(base), reinterpret_cast<const double *>(base + off_uv),
+                                       reinterpret_cast<const unsigned char *>(base + off_fl),
+                                       reinterpret_cast<const int *>(base + off_cnt), static_cast<int>(cap), decl_scale, m, n,
+                                       reinterpret_cast<float *>(base + off_oxy), reinterpret_cast<float *>(base + off_ouv),
+                                       reinterpret_cast<psh::IdwDyn *>(base + off_dyn), c.stream));
+    psh::IdwDyn d;
+    PSH_HIP(hipMemcpyAsync(&d, base + off_dyn, sizeof(d), hipMemcpyDeviceToHost, c.stream));
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    const int L = d.L < 0 ? 0 : d.L > count ? count : d.L;
+    if (L > 0) {
+      PSH_HIP(hipMemcpyAsync(out_xy, base + off_oxy, static_cast<size_t>(L) * 8, hipMemcpyDeviceToHost, c.stream));
+      PSH_HIP(hipMemcpyAsync(out_values, base + off_ouv, static_cast<size_t>(L) * 8, hipMemcpyDeviceToHost, c.stream));
+      PSH_HIP(hipStreamSynchronize(c.stream));
+    }
+    *out_count = L;
+    *out_mode = d.mode;
+    out_const[0] = d.cu;
+    out_const[1] = d.cv;
+    *out_reach = d.reach;
+    return PSH_OK;
+  };
+  const int rc = run();
+  (void)psh_free(blk);
+  return rc;
+}

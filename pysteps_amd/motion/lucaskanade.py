@@ -190,9 +190,10 @@ def _dense_lk_native(frames, on_device, dense, size_opening, buffer_mask, max_co
     count = ctypes.c_int(0)
     if dense:
         field = DeviceArray((2, m, n), np.float32)
-        with _corner_lock:  # the call owns the library's corner request queue while it runs
-            rc = lib.psh_dense_lk_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), field.ptr, None, None, 0,
-                                      ctypes.byref(count))
+        # resident frames in, resident field out: the call only queues kernels (no count asked for,
+        # so nothing waits for the device); host callers get the sample count with the field
+        rc = lib.psh_dense_lk_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), field.ptr, None, None, 0,
+                                  None if on_device else ctypes.byref(count))
         if rc == _lib.PSH_EUNSUPPORTED:
             return None
         _lib.check(rc, "psh_dense_lk_dev")
@@ -204,9 +205,8 @@ def _dense_lk_native(frames, on_device, dense, size_opening, buffer_mask, max_co
     capacity = int(max_corners) * max(nr_fields - 1, 1)
     xy = np.empty((capacity, 2), dtype=np.float64)
     uv = np.empty((capacity, 2), dtype=np.float64)
-    with _corner_lock:
-        rc = lib.psh_dense_lk_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), None, xy.ctypes.data,
-                                  uv.ctypes.data, capacity, ctypes.byref(count))
+    rc = lib.psh_dense_lk_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), None, xy.ctypes.data,
+                              uv.ctypes.data, capacity, ctypes.byref(count))
     if rc == _lib.PSH_EUNSUPPORTED:
         return None
     _lib.check(rc, "psh_dense_lk_dev")

@@ -1,0 +1,18 @@
+#!/bin/bash
+# One GPU-box session for the LK sparse stage: its parity tests, a bench line without the CPU legs,
+# the rocprofv3 kernel trace of the same command and the idle-gap analysis of one step.
+# Usage (from the repo root, via gpurun):  bash tools/gpu_lk_round.sh <tag>
+set -u
+TAG=${1:-lk}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_lk_sparse_gpu.py tests/test_lk_gpu.py tests/test_lk_banded_gpu.py \
+  tests/test_idw_gpu.py tests/test_callers_gpu.py -x -q 2>&1 | tail -25 | tee $OUT/pytest_lk.txt
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-members-leg"
+timeout 300 $BENCH 2>$OUT/bench.err | tee $OUT/bench_quick.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+python tools/gap_analysis.py $OUT/trace > $OUT/gaps.txt 2>&1
+tail -45 $OUT/gaps.txt
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*agent_info.csv" -delete
