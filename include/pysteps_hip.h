@@ -379,6 +379,22 @@ int psh_vectors_finish_host(const double *xy, const double *values, const unsign
                             int count, double decl_scale, int m, int n, float *out_xy, float *out_values,
                             int *out_count, int *out_mode, float *out_const, float *out_reach);
 
+/* ---- two-dimensional FFTs, float64 / complex128 (csrc/fft.hip) ----------------- *
+ * What the FFT method object of pysteps provides (pysteps/utils/fft.py:20-37: numpy.fft.rfft2,
+ * irfft2(X, s=shape), fft2, ifft2) and the STEPS member loop calls ~10 times per member and lead
+ * time (pysteps/noise/fftgenerators.py:330-400, pysteps/cascade/decomposition.py:77-262,
+ * pysteps/nowcasts/steps.py:1111,1189).  numpy's conventions: no scaling forward, 1/(m n) backward,
+ * rfft2 keeps the n/2+1 non-negative frequencies of the last axis, irfft2 ignores the imaginary
+ * parts of its zero and Nyquist bins.  Row-major device arrays; m and n powers of two in 2..8192
+ * (PSH_EUNSUPPORTED otherwise: the Python shim hands those to numpy.fft).  Asynchronous on the
+ * library stream.  Complex numbers are (re, im) float64 pairs.
+ *  psh_fft_rfft2_dev   in (m,n) f64           -> out (m,n/2+1) c128
+ *  psh_fft_irfft2_dev  in (m,n/2+1) c128      -> out (m,n) f64        (in is left untouched)
+ *  psh_fft_c2c2_dev    in (m,n) c128          -> out (m,n) c128, inverse != 0: ifft2 (in == out allowed) */
+int psh_fft_rfft2_dev(const double *in_dev, int m, int n, void *out_dev);
+int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_dev);
+int psh_fft_c2c2_dev(const void *in_dev, int m, int n, int inverse, void *out_dev);
+
 /* ---- multi-GPU: RCCL over xGMI, one rank (process) per GPU ------------------ *
  * The reference has no communication layer (single process, optional dask threads:
  * pysteps/nowcasts/utils.py:464-471); members / fields shard across GPUs with ONE

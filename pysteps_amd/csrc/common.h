@@ -149,9 +149,12 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
 
 // ordered min-distance acceptance and the post-outlier-test stage on the device (lk_sparse.hip)
 int corner_order_max_corners();
+bool corner_order_supported(int m, int n, double min_distance, int max_corners);
+size_t corner_order_ws_bytes();  // device scratch of one ordering (histogram, header, head keys)
 hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw_count_dev, int cap,
                                const float *eig_max_dev, float quality, int n, double min_distance,
-                               int max_corners, float *points_dev, int *npoints_dev, hipStream_t stream);
+                               int max_corners, void *ws_dev, float *points_dev, int *npoints_dev,
+                               hipStream_t stream);
 hipError_t launch_vectors_finish(const double *pool_xy_dev, const double *pool_uv_dev,
                                  const unsigned char *flags_dev, const int *pool_count_dev, int capacity,
                                  double decl_scale, int m, int n, float *xy_out_dev, float *uv_out_dev,

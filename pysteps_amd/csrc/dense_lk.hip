@@ -81,7 +81,7 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   const int capacity_dev = prm->max_corners * (pairs > 0 ? pairs : 1);
   if (capacity_dev > 8192)
     return psh::fail(PSH_EUNSUPPORTED, "dense_lk: more than 8192 pooled vectors (max_corners x frame pairs)");
-  if (prm->max_corners > psh::corner_order_max_corners() || m > 65535 || n > 65535)
+  if (!psh::corner_order_supported(m, n, prm->min_distance, prm->max_corners))
     return psh::fail(PSH_EUNSUPPORTED, "dense_lk: max_corners %d / image size beyond the resident corner pass",
                      prm->max_corners);
   if (field_dev && prm->idw_k > 32) return psh::fail(PSH_EUNSUPPORTED, "dense_lk: idw k=%d > 32", prm->idw_k);

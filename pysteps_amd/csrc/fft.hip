@@ -1,0 +1,336 @@
+// Two-dimensional FFTs in float64 for power-of-two grids, hand-written for gfx950.
+//
+// The FFT method object of pysteps (pysteps/utils/fft.py:20-37 get_numpy: fft2, ifft2, rfft2,
+// irfft2 of numpy.fft, all in double precision) is what the STEPS member loop spends its time in
+// once the advection is off the CPU: noise generation (pysteps/noise/fftgenerators.py:330-400),
+// cascade decomposition (pysteps/cascade/decomposition.py:77-262) and the spectral recomposition
+// run ~10 transforms of the full grid per member and lead time.  numpy's
+// transforms live in pocketfft [third party, numpy 2.2]; what has to be reproduced is the
+// mathematical transform with numpy's conventions (no scaling forward, 1/(m n) backward; rfft2
+// keeps the n/2+1 non-negative frequencies of the last axis; irfft2 ignores the imaginary parts
+// of the zero and Nyquist bins of the last axis), to round-off: parity bar rel-L2 <= 1e-12.
+//
+// Layout of a transform of an (m, n) grid, m and n powers of two:
+//  * rows: one workgroup per PAIR of real rows - row a + i * row b is one complex FFT of length
+//    n in LDS (padded against bank conflicts), the two spectra are separated on the way out
+//    (A[k] = (Z[k] + conj Z[n-k]) / 2, B[k] = (Z[k] - conj Z[n-k]) / 2i).  Complex rows: one
+//    workgroup per row.
+//  * columns: one workgroup per 2 (m <= 4096) or 1 columns of the (m, n/2+1) / (m, n) complex
+//    array, XCD-contiguous so that workgroups sharing cache lines share an L2.
+//  * the FFT itself: decimation in time, bit-reversed on the way into LDS, two radix-2 layers per
+//    pass (4 points per thread and pass: half the LDS traffic and barriers of plain radix 2),
+//    twiddles exp(-2 pi i k / N) from a table computed once per length on the host in long double.
+// FP64 vector rate on MI355X equals FP32 (78 TFLOP/s); a 4096^2 rfft2 is ~0.5 GFLOP: the transform
+// is bound by HBM / LDS traffic, not arithmetic.
+#include <cmath>
+#include <map>
+#include <vector>
+
+#include "common.h"
+
+namespace psh {
+namespace {
+
+constexpr int kFftThreads = 256;
+constexpr int kFftMaxLog = 13;  // 8192 points: 8192 * 16 B * 65/64 = 130 KiB of LDS
+
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 6); }  // 16-byte elements: spreads strided accesses
+__host__ __device__ constexpr int lds_elems(int n) { return n + (n >> 6) + 1; }
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 w) {
+  return make_double2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+
+// in-place DIT FFT of `count` independent sequences z[c * pitch + lpad(i)], i < N = 1 << logn, whose
+// elements were stored bit-reversed; INV conjugates the twiddles (unscaled inverse)
+template <bool INV>
+__device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int logn,
+                                        const double2 *__restrict__ tw) {
+  const int N = 1 << logn;
+  int s = 0;
+  if (logn & 1) {  // a single radix-2 layer first (twiddle 1), then pairs of layers
+    for (int b = threadIdx.x; b < (N >> 1) * count; b += kFftThreads) {
+      const int c = b / (N >> 1), q = b - c * (N >> 1);
+      double2 *zz = z + c * pitch;
+      const int i0 = q << 1, i1 = i0 + 1;
+      const double2 x0 = zz[lpad(i0)], x1 = zz[lpad(i1)];
+      zz[lpad(i0)] = make_double2(x0.x + x1.x, x0.y + x1.y);
+      zz[lpad(i1)] = make_double2(x0.x - x1.x, x0.y - x1.y);
+    }
+    __syncthreads();
+    s = 1;
+  }
+  for (; s < logn; s += 2) {  // (logn - s is even here)
+    const int h = 1 << s;                 // half size of the first layer
+    const int st1 = N >> (s + 1);         // W_{2h}^j = W_N^{j st1}
+    const int st2 = N >> (s + 2);         // W_{4h}^j = W_N^{j st2}
+    for (int b = threadIdx.x; b < (N >> 2) * count; b += kFftThreads) {
+      const int c = b / (N >> 2), q = b - c * (N >> 2);
+      double2 *zz = z + c * pitch;
+      const int j = q & (h - 1);
+      const int i0 = ((q >> s) << (s + 2)) + j, i1 = i0 + h, i2 = i1 + h, i3 = i2 + h;
+      double2 w1 = tw[j * st1], w2 = tw[j * st2], w3 = tw[(j + h) * st2];
+      if (INV) {
+        w1.y = -w1.y;
+        w2.y = -w2.y;
+        w3.y = -w3.y;
+      }
+      const double2 x0 = zz[lpad(i0)], x1 = zz[lpad(i1)], x2 = zz[lpad(i2)], x3 = zz[lpad(i3)];
+      const double2 t1 = cmul(x1, w1), t3 = cmul(x3, w1);
+      const double2 a0 = make_double2(x0.x + t1.x, x0.y + t1.y), a1 = make_double2(x0.x - t1.x, x0.y - t1.y);
+      const double2 a2 = make_double2(x2.x + t3.x, x2.y + t3.y), a3 = make_double2(x2.x - t3.x, x2.y - t3.y);
+      const double2 u2 = cmul(a2, w2), u3 = cmul(a3, w3);
+      zz[lpad(i0)] = make_double2(a0.x + u2.x, a0.y + u2.y);
+      zz[lpad(i2)] = make_double2(a0.x - u2.x, a0.y - u2.y);
+      zz[lpad(i1)] = make_double2(a1.x + u3.x, a1.y + u3.y);
+      zz[lpad(i3)] = make_double2(a1.x - u3.x, a1.y - u3.y);
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ int bitrev(int i, int logn) { return static_cast<int>(__brev(static_cast<unsigned>(i)) >> (32 - logn)); }
+
+// ---- real rows -> half spectra: two rows per workgroup -----------------------------------------
+__global__ __launch_bounds__(kFftThreads) void fft_rows_r2c(const double *__restrict__ x, int m, int n, int logn,
+                                                            const double2 *__restrict__ tw,
+                                                            double2 *__restrict__ out) {
+  extern __shared__ double2 z[];
+  const int ra = 2 * blockIdx.x, rb = min(ra + 1, m - 1);
+  const int nc = n / 2 + 1;
+  const double *xa = x + static_cast<size_t>(ra) * n, *xb = x + static_cast<size_t>(rb) * n;
+  for (int i = threadIdx.x; i < n; i += kFftThreads) z[lpad(bitrev(i, logn))] = make_double2(xa[i], xb[i]);
+  __syncthreads();
+  fft_lds<false>(z, 0, 1, logn, tw);
+  double2 *oa = out + static_cast<size_t>(ra) * nc, *ob = out + static_cast<size_t>(rb) * nc;
+  for (int k = threadIdx.x; k < nc; k += kFftThreads) {
+    const double2 zk = z[lpad(k)], zn = z[lpad((n - k) & (n - 1))];
+    oa[k] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
+    if (ra + 1 < m) ob[k] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));
+  }
+}
+
+// ---- half spectra -> real rows (numpy irfft: the imaginary parts of bins 0 and n/2 are ignored) --
+__global__ __launch_bounds__(kFftThreads) void fft_rows_c2r(const double2 *__restrict__ in, int m, int n, int logn,
+                                                            const double2 *__restrict__ tw, double scale,
+                                                            double *__restrict__ out) {
+  extern __shared__ double2 z[];
+  const int ra = 2 * blockIdx.x, rb = min(ra + 1, m - 1);
+  const int nc = n / 2 + 1, half = n / 2;
+  const double2 *ia = in + static_cast<size_t>(ra) * nc, *ib = in + static_cast<size_t>(rb) * nc;
+  for (int k = threadIdx.x; k < nc; k += kFftThreads) {
+    double2 a = ia[k], b = ib[k];
+    if (k == 0 || k == half) {
+      a.y = 0.0;
+      b.y = 0.0;
+    }
+    // Z[k] = A[k] + i B[k];  Z[n-k] = conj(A[k]) + i conj(B[k])
+    z[lpad(bitrev(k, logn))] = make_double2(a.x - b.y, a.y + b.x);
+    if (k != 0 && k != half) z[lpad(bitrev(n - k, logn))] = make_double2(a.x + b.y, b.x - a.y);
+  }
+  __syncthreads();
+  fft_lds<true>(z, 0, 1, logn, tw);
+  double *oa = out + static_cast<size_t>(ra) * n, *ob = out + static_cast<size_t>(rb) * n;
+  for (int i = threadIdx.x; i < n; i += kFftThreads) {
+    const double2 v = z[lpad(i)];
+    oa[i] = v.x * scale;
+    if (ra + 1 < m) ob[i] = v.y * scale;
+  }
+}
+
+// ---- complex rows: one row per workgroup ---------------------------------------------------------
+template <bool INV>
+__global__ __launch_bounds__(kFftThreads) void fft_rows_c2c(const double2 *__restrict__ in, int n, int logn,
+                                                            const double2 *__restrict__ tw,
+                                                            double2 *__restrict__ out) {
+  extern __shared__ double2 z[];
+  const double2 *src = in + static_cast<size_t>(blockIdx.x) * n;
+  for (int i = threadIdx.x; i < n; i += kFftThreads) z[lpad(bitrev(i, logn))] = src[i];
+  __syncthreads();
+  fft_lds<INV>(z, 0, 1, logn, tw);
+  double2 *dst = out + static_cast<size_t>(blockIdx.x) * n;
+  for (int i = threadIdx.x; i < n; i += kFftThreads) dst[i] = z[lpad(i)];
+}
+
+// ---- columns of an (m, nc) complex array: `cols` adjacent columns per workgroup ---------------------
+template <bool INV>
+__global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__restrict__ in, int m, int nc, int logm,
+                                                            int cols, const double2 *__restrict__ tw, double scale,
+                                                            double2 *__restrict__ out, int groups,
+                                                            int groups_per_xcd) {
+  extern __shared__ double2 z[];
+  // XCD-contiguous column groups: neighbours share 128-byte lines of every row
+  const int b = blockIdx.x;
+  const int g = (b % kNumXcd) * groups_per_xcd + b / kNumXcd;
+  if (g >= groups) return;
+  const int c0 = g * cols;
+  const int live = min(cols, nc - c0);
+  const int pitch = lds_elems(m);
+  for (int idx = threadIdx.x; idx < m * cols; idx += kFftThreads) {
+    const int r = idx / cols, c = idx - r * cols;
+    z[c * pitch + lpad(bitrev(r, logm))] = c < live ? in[static_cast<size_t>(r) * nc + c0 + c] : make_double2(0.0, 0.0);
+  }
+  __syncthreads();
+  fft_lds<INV>(z, pitch, cols, logm, tw);
+  for (int idx = threadIdx.x; idx < m * cols; idx += kFftThreads) {
+    const int r = idx / cols, c = idx - r * cols;
+    if (c < live) {
+      const double2 v = z[c * pitch + lpad(r)];
+      out[static_cast<size_t>(r) * nc + c0 + c] = make_double2(v.x * scale, v.y * scale);
+    }
+  }
+}
+
+int ilog2_exact(int v) {
+  if (v < 2 || (v & (v - 1)) != 0) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+// twiddle table of a length, device resident, computed once (lock held by the callers)
+int twiddles(int n, const double2 **tw_out) {
+  static std::map<int, double2 *> cache;
+  auto it = cache.find(n);
+  if (it != cache.end()) {
+    *tw_out = it->second;
+    return PSH_OK;
+  }
+  const int count = n / 2 > 0 ? n / 2 : 1;
+  std::vector<double2> host(static_cast<size_t>(count));
+  const long double step = -2.0L * 3.14159265358979323846264338327950288L / static_cast<long double>(n);
+  for (int k = 0; k < count; ++k) {
+    const long double a = step * static_cast<long double>(k);
+    host[k] = make_double2(static_cast<double>(cosl(a)), static_cast<double>(sinl(a)));
+  }
+  void *dev = nullptr;
+  PSH_HIP(hipMalloc(&dev, host.size() * sizeof(double2)));
+  const hipError_t e = hipMemcpy(dev, host.data(), host.size() * sizeof(double2), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(dev);
+    return fail(PSH_EHIP, "fft: twiddle upload failed: %s", hipGetErrorString(e));
+  }
+  cache[n] = static_cast<double2 *>(dev);
+  *tw_out = cache[n];
+  return PSH_OK;
+}
+
+template <class K>
+int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)
+    PSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(bytes)));
+  return PSH_OK;
+}
+
+int check_shape(const char *who, int m, int n, int *logm, int *logn) {
+  *logm = ilog2_exact(m);
+  *logn = ilog2_exact(n);
+  if (*logm < 1 || *logn < 1 || *logm > kFftMaxLog || *logn > kFftMaxLog)
+    return fail(PSH_EUNSUPPORTED, "%s: (%d,%d) - both sizes must be powers of two in 2..%d", who, m, n, 1 << kFftMaxLog);
+  return PSH_OK;
+}
+
+int launch_cols(bool inverse, const double2 *in, int m, int nc, int logm, double scale, double2 *out,
+                hipStream_t stream) {
+  const double2 *tw = nullptr;
+  if (int rc = twiddles(m, &tw)) return rc;
+  const int cols = m <= 4096 ? 2 : 1;
+  const int groups = (nc + cols - 1) / cols;
+  const int gpx = (groups + kNumXcd - 1) / kNumXcd;
+  const size_t lds = static_cast<size_t>(cols) * lds_elems(m) * sizeof(double2);
+  if (inverse) {
+    if (int rc = allow_lds(fft_cols_c2c<true>, lds)) return rc;
+    hipLaunchKernelGGL(fft_cols_c2c<true>, dim3(gpx * kNumXcd), dim3(kFftThreads), lds, stream, in, m, nc, logm, cols,
+                       tw, scale, out, groups, gpx);
+  } else {
+    if (int rc = allow_lds(fft_cols_c2c<false>, lds)) return rc;
+    hipLaunchKernelGGL(fft_cols_c2c<false>, dim3(gpx * kNumXcd), dim3(kFftThreads), lds, stream, in, m, nc, logm, cols,
+                       tw, scale, out, groups, gpx);
+  }
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+}  // namespace
+}  // namespace psh
+
+using psh::fail;
+
+// numpy.fft.rfft2 of a real (m, n) float64 array -> (m, n/2+1) complex128
+extern "C" int psh_fft_rfft2_dev(const double *in_dev, int m, int n, void *out_dev) {
+  PSH_REQUIRE_INIT();
+  if (!in_dev || !out_dev) return fail(PSH_EINVAL, "rfft2: NULL pointer");
+  int logm, logn;
+  if (int rc = psh::check_shape("rfft2", m, n, &logm, &logn)) return rc;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const double2 *tw = nullptr;
+  if (int rc = psh::twiddles(n, &tw)) return rc;
+  const size_t lds = static_cast<size_t>(psh::lds_elems(n)) * sizeof(double2);
+  if (int rc = psh::allow_lds(psh::fft_rows_r2c, lds)) return rc;
+  double2 *out = static_cast<double2 *>(out_dev);
+  hipLaunchKernelGGL(psh::fft_rows_r2c, dim3((m + 1) / 2), dim3(psh::kFftThreads), lds, c.stream, in_dev, m, n, logn, tw,
+                     out);
+  PSH_HIP(hipGetLastError());
+  return psh::launch_cols(false, out, m, n / 2 + 1, logm, 1.0, out, c.stream);
+}
+
+// numpy.fft.irfft2(X, s=(m, n)) of an (m, n/2+1) complex128 array -> real (m, n) float64; the input is
+// left untouched (the column pass writes into a scratch block)
+extern "C" int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_dev) {
+  PSH_REQUIRE_INIT();
+  if (!in_dev || !out_dev) return fail(PSH_EINVAL, "irfft2: NULL pointer");
+  int logm, logn;
+  if (int rc = psh::check_shape("irfft2", m, n, &logm, &logn)) return rc;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const int nc = n / 2 + 1;
+  void *scratch = nullptr;
+  if (int rc = psh_malloc(&scratch, static_cast<size_t>(m) * nc * sizeof(double2))) return rc;
+  auto run = [&]() -> int {
+    if (int rc = psh::launch_cols(true, static_cast<const double2 *>(in_dev), m, nc, logm, 1.0,
+                                  static_cast<double2 *>(scratch), c.stream))
+      return rc;
+    const double2 *tw = nullptr;
+    if (int rc = psh::twiddles(n, &tw)) return rc;
+    const size_t lds = static_cast<size_t>(psh::lds_elems(n)) * sizeof(double2);
+    if (int rc = psh::allow_lds(psh::fft_rows_c2r, lds)) return rc;
+    hipLaunchKernelGGL(psh::fft_rows_c2r, dim3((m + 1) / 2), dim3(psh::kFftThreads), lds, c.stream,
+                       static_cast<const double2 *>(scratch), m, n, logn, tw,
+                       1.0 / (static_cast<double>(m) * static_cast<double>(n)), out_dev);
+    PSH_HIP(hipGetLastError());
+    return PSH_OK;
+  };
+  const int rc = run();
+  (void)psh_free(scratch);  // stream-ordered
+  return rc;
+}
+
+// numpy.fft.fft2 / ifft2 of an (m, n) complex128 array (in_dev == out_dev allowed)
+extern "C" int psh_fft_c2c2_dev(const void *in_dev, int m, int n, int inverse, void *out_dev) {
+  PSH_REQUIRE_INIT();
+  if (!in_dev || !out_dev) return fail(PSH_EINVAL, "fft2: NULL pointer");
+  int logm, logn;
+  if (int rc = psh::check_shape("fft2", m, n, &logm, &logn)) return rc;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const double2 *tw = nullptr;
+  if (int rc = psh::twiddles(n, &tw)) return rc;
+  const size_t lds = static_cast<size_t>(psh::lds_elems(n)) * sizeof(double2);
+  const double2 *in = static_cast<const double2 *>(in_dev);
+  double2 *out = static_cast<double2 *>(out_dev);
+  if (inverse) {
+    if (int rc = psh::allow_lds(psh::fft_rows_c2c<true>, lds)) return rc;
+    hipLaunchKernelGGL(psh::fft_rows_c2c<true>, dim3(m), dim3(psh::kFftThreads), lds, c.stream, in, n, logn, tw, out);
+  } else {
+    if (int rc = psh::allow_lds(psh::fft_rows_c2c<false>, lds)) return rc;
+    hipLaunchKernelGGL(psh::fft_rows_c2c<false>, dim3(m), dim3(psh::kFftThreads), lds, c.stream, in, n, logn, tw, out);
+  }
+  PSH_HIP(hipGetLastError());
+  const double scale = inverse ? 1.0 / (static_cast<double>(m) * static_cast<double>(n)) : 1.0;
+  return psh::launch_cols(inverse != 0, out, m, n, logm, scale, out, c.stream);
+}

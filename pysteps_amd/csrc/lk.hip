@@ -1408,7 +1408,7 @@ struct GreedyGrid {
 // library stream into the block `ws` (layout below); lock held by the caller
 namespace {
 struct CornerWs {
-  size_t off_part, off_cnt, off_raw, bytes;
+  size_t off_part, off_cnt, off_raw, off_ord, bytes;
   int cap, nb;
   dim3 rgrid;
   CornerWs(int m, int n) {
@@ -1421,7 +1421,8 @@ struct CornerWs {
     off_part = up(npx * sizeof(float));
     off_cnt = up(off_part + static_cast<size_t>(nb) * sizeof(float));
     off_raw = up(off_cnt + sizeof(int));
-    bytes = off_raw + static_cast<size_t>(cap) * sizeof(psh::CornerKey);
+    off_ord = up(off_raw + static_cast<size_t>(cap) * sizeof(psh::CornerKey));
+    bytes = off_ord + psh::corner_order_ws_bytes();
   }
 };
 
@@ -1476,7 +1477,7 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
                         float *points_dev, int *npoints_dev) {
   if (int rc = check_corner_args(feature_u8_dev, clean_dev, stats_dev, m, n, block_size, max_corners)) return rc;
   if (!points_dev || !npoints_dev) return fail(PSH_EINVAL, "lk_corners: NULL pointer");
-  if (max_corners > corner_order_max_corners() || m > 65535 || n > 65535)
+  if (!corner_order_supported(m, n, min_distance, max_corners))
     return fail(PSH_EUNSUPPORTED, "lk_corners: more than %d corners or 65535 rows / columns are ordered on the host",
                 corner_order_max_corners());
   Context &c = ctx();
@@ -1490,8 +1491,8 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
     char *base = static_cast<char *>(ws);
     const hipError_t e = launch_corner_order(
         reinterpret_cast<const CornerKey *>(base + w.off_raw), reinterpret_cast<const int *>(base + w.off_cnt), w.cap,
-        stats_dev + kEigMax, static_cast<float>(quality_level), n, min_distance, max_corners, points_dev, npoints_dev,
-        c.stream);
+        stats_dev + kEigMax, static_cast<float>(quality_level), n, min_distance, max_corners, base + w.off_ord,
+        points_dev, npoints_dev, c.stream);
     if (e != hipSuccess) rc = fail(PSH_EHIP, "corner_order launch failed: %s", hipGetErrorString(e));
   }
   (void)psh_free(ws);  // the kernels above are queued in front of any reuse
@@ -1512,7 +1513,7 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
     return fail(PSH_EINVAL, "lk_corners: %d corner requests are already in flight", kMaxCornerJobs);
   CornerJob &job = g_corner_jobs[(g_corner_head + g_corner_count) % kMaxCornerJobs];
   if (!job.ready) PSH_HIP(hipEventCreateWithFlags(&job.ready, hipEventDisableTiming));
-  const bool host_ordered = max_corners > psh::corner_order_max_corners() || m > 65535 || n > 65535;
+  const bool host_ordered = !psh::corner_order_supported(m, n, min_distance, max_corners);
   const size_t pin_need = kPinnedHeader + (host_ordered ? 0 : static_cast<size_t>(max_corners) * sizeof(float2));
   static size_t pin_have[kMaxCornerJobs] = {0};
   const int slot = static_cast<int>(&job - g_corner_jobs);

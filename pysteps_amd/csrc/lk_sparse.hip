@@ -36,23 +36,23 @@ constexpr int kOrdWaves = kOrdThreads / 64;
 constexpr int kOrdBins = 1024;
 constexpr int kChunkCap = 4096;     // candidates ordered at a time (32 KiB of keys in LDS)
 constexpr int kChunkTarget = 2560;  // a chunk holds at least this many (unless fewer are left)
-constexpr int kMaxCornersDev = 2048;  // accepted corners kept in LDS (16 KiB)
+constexpr int kMaxCornersDev = 2048;  // accepted corners kept in LDS
+constexpr int kHashSlots = 4096;      // cell -> chain of accepted corners (open addressing, load <= 1/2)
+constexpr unsigned kNoCell = 0xffffffffu;
 
-// descending (DESC) or ascending bitonic sort of the first `p2` (power of two) LDS entries
+// descending (DESC) or ascending bitonic sort of the first `p2` (power of two, >= 2) LDS entries;
+// a thread owns whole compare-exchange pairs (p2 / 2 of them per step)
 template <bool DESC>
 __device__ __forceinline__ void bitonic_sort_lds(unsigned long long *keys, int p2) {
   for (int k = 2; k <= p2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < p2; i += blockDim.x) {
-        const int o = i ^ j;
-        if (o > i) {
-          const unsigned long long a = keys[i], b = keys[o];
-          const bool first_half = (i & k) == 0;
-          const bool swap = (first_half == DESC) ? a < b : a > b;
-          if (swap) {
-            keys[i] = b;
-            keys[o] = a;
-          }
+      for (int t = threadIdx.x; t < (p2 >> 1); t += blockDim.x) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), o = i | j;
+        const unsigned long long a = keys[i], b = keys[o];
+        const bool first_half = (i & k) == 0;
+        if ((first_half == DESC) ? a < b : a > b) {
+          keys[i] = b;
+          keys[o] = a;
         }
       }
       __syncthreads();
@@ -66,113 +66,267 @@ __device__ __forceinline__ int next_pow2(int v) {
   return p;
 }
 
+// The keys of a frame's candidates lie in [key_lo, key_hi): every response exceeds
+// thr = max * quality (lk_corner_select) and none exceeds the maximum.
+__device__ __forceinline__ void key_range(float eig_max, float quality, CornerKey &key_lo, CornerKey &key_hi) {
+  const float top = fmaxf(eig_max, 0.f);
+  const float thr = fmaxf(top * quality, 0.f);
+  key_lo = static_cast<CornerKey>(__float_as_uint(thr)) << 32;
+  key_hi = (static_cast<CornerKey>(__float_as_uint(top)) + 1ull) << 32;
+}
+__device__ __forceinline__ int bin_shift(CornerKey rlo, CornerKey rhi) {
+  int sh = 0;
+  while (((rhi - 1ull - rlo) >> sh) >= static_cast<unsigned long long>(kOrdBins)) ++sh;
+  return sh;
+}
+
+// One wave: from the histogram of [rlo, rhi) (kOrdBins bins, LDS or global) and the number of
+// candidates `above` it, the largest bin whose suffix count no longer fits a chunk.
+//  over < 0: everything left fits (`fits` of them);  otherwise `fits` candidates lie above bin `over`.
+__device__ __forceinline__ void chunk_cut(const int *hist, int above, int lane, int &over_out, int &fits_out) {
+  constexpr int kPer = kOrdBins / 64;
+  int tot = 0;
+  for (int q = 0; q < kPer; ++q) tot += hist[lane * kPer + q];
+  int incl = tot;  // -> sum over lanes >= this one
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int dn = __shfl_down(incl, d);
+    if (lane + d < 64) incl += dn;
+  }
+  int run = incl - tot + above;
+  int over = -1, over_next = 0;  // bin, and the suffix count of the bins above it
+  for (int q = kPer - 1; q >= 0; --q) {
+    const int before = run;
+    run += hist[lane * kPer + q];
+    if (run > kChunkCap && over < 0) {
+      over = lane * kPer + q;
+      over_next = before;
+    }
+  }
+  int best = over;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d));
+  const int all = __shfl(incl, 0) + above;
+  // the owner of `best` broadcasts its suffix count
+  const unsigned long long owner = __ballot(best >= 0 && over == best);
+  const int src = owner ? __ffsll(static_cast<long long>(owner)) - 1 : 0;
+  over_out = best;
+  fits_out = best < 0 ? all : __shfl(over_next, src);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the head of the walking order, selected by many workgroups (the candidate list can hold
+// millions of keys; a single workgroup streams it at the latency of one compute unit)
+// ---------------------------------------------------------------------------------------------
+struct OrderHeader {
+  CornerKey floor_key;  // head[] holds every candidate key >= floor_key
+  int count;            // their number; < 0: no head (an overfull bin has to be refined: corner_order does it)
+  int fill;             // reservation counter of corner_gather
+};
+
+constexpr int kPreThreads = 256;
+
+__global__ __launch_bounds__(kPreThreads) void corner_hist(const CornerKey *__restrict__ raw,
+                                                           const int *__restrict__ raw_count, int cap,
+                                                           const float *__restrict__ eig_max, float quality,
+                                                           int *__restrict__ hist) {
+  __shared__ int s_hist[kOrdBins];
+  for (int i = threadIdx.x; i < kOrdBins; i += kPreThreads) s_hist[i] = 0;
+  __syncthreads();
+  const int nkeys = min(max(*raw_count, 0), cap);
+  CornerKey key_lo, key_hi;
+  key_range(*eig_max, quality, key_lo, key_hi);
+  const int sh = bin_shift(key_lo, key_hi);
+  for (int i = blockIdx.x * kPreThreads + threadIdx.x; i < nkeys; i += gridDim.x * kPreThreads) {
+    const CornerKey k = raw[i];
+    if (k >= key_lo && k < key_hi) atomicAdd(&s_hist[static_cast<int>((k - key_lo) >> sh)], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kOrdBins; i += kPreThreads)
+    if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+
+__global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__restrict__ raw,
+                                                             const int *__restrict__ raw_count, int cap,
+                                                             const float *__restrict__ eig_max, float quality,
+                                                             const int *__restrict__ hist,
+                                                             CornerKey *__restrict__ head,
+                                                             OrderHeader *__restrict__ hdr) {
+  __shared__ int s_over, s_fits;
+  __shared__ int s_wave[kPreThreads / 64];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nkeys = min(max(*raw_count, 0), cap);
+  CornerKey key_lo, key_hi;
+  key_range(*eig_max, quality, key_lo, key_hi);
+  const int sh = bin_shift(key_lo, key_hi);
+  if (wave == 0) {
+    int over, fits;
+    chunk_cut(hist, 0, lane, over, fits);
+    if (lane == 0) {
+      s_over = over;
+      s_fits = fits;
+    }
+  }
+  __syncthreads();
+  const int over = s_over, fits = s_fits;
+  const bool usable = over < 0 || fits >= kChunkTarget;
+  const CornerKey T = over < 0 ? key_lo : key_lo + (static_cast<CornerKey>(over + 1) << sh);
+  if (blockIdx.x == 0 && tid == 0) {
+    hdr->floor_key = T;
+    hdr->count = usable ? fits : -1;
+  }
+  if (!usable) return;
+  // this workgroup's slice of the list: count, reserve once, write
+  const int per = (nkeys + gridDim.x - 1) / gridDim.x;
+  const int s0 = min(blockIdx.x * per, nkeys), s1 = min(s0 + per, nkeys);
+  int mine = 0;
+  for (int i = s0 + tid; i < s1; i += kPreThreads) {
+    const CornerKey k = raw[i];
+    mine += (k >= T && k < key_hi) ? 1 : 0;
+  }
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int before = incl - mine, total = 0;
+  for (int w = 0; w < kPreThreads / 64; ++w) {
+    if (w < wave) before += s_wave[w];
+    total += s_wave[w];
+  }
+  if (total == 0) return;
+  if (tid == 0) s_base = atomicAdd(&hdr->fill, total);
+  __syncthreads();
+  int at = s_base + before;
+  for (int i = s0 + tid; i < s1; i += kPreThreads) {
+    const CornerKey k = raw[i];
+    if (k >= T && k < key_hi) {
+      if (at < kChunkCap) head[at] = k;
+      ++at;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // goodFeaturesToTrack: ordered min-distance acceptance
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned cell_hash(unsigned cellkey) {
+  return ((cellkey & 0xffffu) * 0x9E3779B1u ^ (cellkey >> 16) * 0x85EBCA6Bu) >> (32 - 12);
+}
+
 __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__restrict__ raw,
                                                             const int *__restrict__ raw_count, int cap,
                                                             const float *__restrict__ eig_max, float quality,
-                                                            int n, int cell, double md2, int use_grid,
-                                                            int max_corners, float2 *__restrict__ points,
-                                                            int *__restrict__ npoints) {
+                                                            const CornerKey *__restrict__ head,
+                                                            const OrderHeader *__restrict__ hdr, int n, int cell,
+                                                            unsigned md2_ceil, int use_grid, int max_corners,
+                                                            float2 *__restrict__ points, int *__restrict__ npoints) {
   __shared__ CornerKey s_keys[kChunkCap];
   __shared__ int s_hist[kOrdBins];
   __shared__ unsigned long long s_conf[kOrdWaves][64];
   __shared__ unsigned long long s_rej[kOrdWaves];
-  __shared__ uint2 s_acc[kMaxCornersDev];  // accepted corners: {x | y << 16, x cell | y cell << 16}
-  __shared__ int s_fill, s_nacc, s_cut, s_cut_next;
+  __shared__ uint2 s_cand[64];              // the batch: {x | y << 16, x cell | y cell << 16}
+  __shared__ uint2 s_acc[kMaxCornersDev];   // accepted corners, same packing
+  __shared__ short s_next[kMaxCornersDev];  // next accepted corner of the same cell (-1: none)
+  __shared__ unsigned s_hkey[kHashSlots];   // cell key of a hash slot (kNoCell: free)
+  __shared__ int s_hhead[kHashSlots];       // first accepted corner of that cell (-1: none)
+  __shared__ int s_fill, s_nacc, s_over, s_fits;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nkeys = min(max(*raw_count, 0), cap);
-  // every candidate's response exceeds thr = max * quality (lk_corner_select), so the keys lie in
-  // [key_lo, key_hi)
-  const float top = fmaxf(*eig_max, 0.f);
-  const float thr = fmaxf(top * quality, 0.f);
-  const CornerKey key_lo = static_cast<CornerKey>(__float_as_uint(thr)) << 32;
-  CornerKey upper = (static_cast<CornerKey>(__float_as_uint(top)) + 1ull) << 32;  // exclusive
+  CornerKey key_lo, upper;  // candidates not yet walked lie in [key_lo, upper)
+  key_range(*eig_max, quality, key_lo, upper);
+  for (int i = tid; i < kHashSlots; i += kOrdThreads) {
+    s_hkey[i] = kNoCell;
+    s_hhead[i] = -1;
+  }
   int nacc = 0;
-  int remaining = nkeys;  // candidates below `upper`
+  int remaining = nkeys;
+  bool have_head = hdr != nullptr && hdr->count >= 0;
+  __syncthreads();
   while (remaining > 0 && nacc < max_corners) {
-    // ---- threshold key T: the chunk is every candidate in [T, upper) ------------------------
-    CornerKey rlo = key_lo, rhi = upper, T = key_lo;
-    int above = 0;  // candidates in [rhi, upper): part of the chunk whatever happens below
-    for (int level = 0;; ++level) {  // (the bin width shrinks by 2^10 per level: at most 7 levels)
-      int sh = 0;
-      while (((rhi - 1ull - rlo) >> sh) >= static_cast<unsigned long long>(kOrdBins)) ++sh;
-      for (int i = tid; i < kOrdBins; i += kOrdThreads) s_hist[i] = 0;
-      __syncthreads();
-      for (int i = tid; i < nkeys; i += kOrdThreads) {
-        const CornerKey k = raw[i];
-        if (k >= rlo && k < rhi) atomicAdd(&s_hist[static_cast<int>((k - rlo) >> sh)], 1);
-      }
-      __syncthreads();
-      if (wave == 0) {  // the largest bin whose suffix count (incl. `above`) no longer fits the chunk
-        constexpr int kPer = kOrdBins / 64;
-        int tot = 0;
-        for (int q = 0; q < kPer; ++q) tot += s_hist[lane * kPer + q];
-        int incl = tot;  // -> sum over lanes >= this one
+    CornerKey T = key_lo;
+    int cnt = 0;
+    if (have_head) {
+      // ---- first chunk: selected and gathered by corner_hist / corner_gather -------------------
+      T = hdr->floor_key;
+      cnt = min(hdr->count, kChunkCap);
+      for (int i = tid; i < cnt; i += kOrdThreads) s_keys[i] = head[i];
+      have_head = false;
+    } else {
+      // ---- threshold key T: the chunk is every candidate in [T, upper) ------------------------
+      CornerKey rlo = key_lo, rhi = upper;
+      int above = 0;  // candidates in [rhi, upper): part of the chunk whatever happens below
+      for (int level = 0;; ++level) {  // (the bin width shrinks by 2^10 per level: at most 7 levels)
+        const int sh = bin_shift(rlo, rhi);
+        for (int i = tid; i < kOrdBins; i += kOrdThreads) s_hist[i] = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < nkeys; i0 += 8 * kOrdThreads) {  // eight loads in flight per thread
+          CornerKey k[8];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int dn = __shfl_down(incl, d);
-          if (lane + d < 64) incl += dn;
-        }
-        int run = incl - tot + above;
-        int over = -1, over_next = 0;  // bin, and the suffix count of the bins above it
-        for (int q = kPer - 1; q >= 0; --q) {
-          const int before = run;
-          run += s_hist[lane * kPer + q];
-          if (run > kChunkCap && over < 0) {
-            over = lane * kPer + q;
-            over_next = before;
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kOrdThreads + tid;
+            k[u] = i < nkeys ? raw[i] : 0ull;
           }
-        }
-        int best = over;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) best = max(best, __shfl_xor(best, d));
-        if (best < 0) {  // everything that is left fits
+          for (int u = 0; u < 8; ++u)
+            if (k[u] >= rlo && k[u] < rhi && k[u] != 0ull) atomicAdd(&s_hist[static_cast<int>((k[u] - rlo) >> sh)], 1);
+        }
+        __syncthreads();
+        if (wave == 0) {
+          int over, fits;
+          chunk_cut(s_hist, above, lane, over, fits);
           if (lane == 0) {
-            s_cut = -1;
-            s_cut_next = incl + above;  // lane 0: all bins
+            s_over = over;
+            s_fits = fits;
           }
-        } else if (over == best) {
-          s_cut = over;
-          s_cut_next = over_next;
+        }
+        __syncthreads();
+        const int over = s_over, fits = s_fits;  // `fits` candidates lie above bin `over`
+        __syncthreads();
+        if (over < 0 || level >= 8) {
+          T = rlo;
+          break;
+        }
+        if (fits >= kChunkTarget) {
+          T = rlo + (static_cast<CornerKey>(over + 1) << sh);
+          break;
+        }
+        // too few above the overfull bin: they are taken, the threshold is looked for inside the bin
+        above = fits;
+        rlo = rlo + (static_cast<CornerKey>(over) << sh);
+        const CornerKey bin_hi = rlo + (1ull << sh);
+        rhi = bin_hi < rhi ? bin_hi : rhi;
+      }
+      // ---- gather the chunk into LDS --------------------------------------------------------------
+      if (tid == 0) s_fill = 0;
+      __syncthreads();
+      for (int i0 = 0; i0 < nkeys; i0 += 8 * kOrdThreads) {
+        CornerKey k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u * kOrdThreads + tid;
+          k[u] = i < nkeys ? raw[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool keep = k[u] >= T && k[u] < upper && k[u] != 0ull;
+          const unsigned long long mask = __ballot(keep);
+          if (mask == 0ull) continue;
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_fill, __popcll(mask));
+          base = __shfl(base, 0);
+          const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
+          if (keep && at < kChunkCap) s_keys[at] = k[u];
         }
       }
       __syncthreads();
-      const int over = s_cut, fits = s_cut_next;  // `fits` candidates lie above bin `over`
-      __syncthreads();
-      if (over < 0 || level >= 8) {
-        T = rlo;
-        break;
-      }
-      if (fits >= kChunkTarget) {
-        T = rlo + (static_cast<CornerKey>(over + 1) << sh);
-        break;
-      }
-      // too few above the overfull bin: they are taken, the threshold is looked for inside the bin
-      above = fits;
-      rlo = rlo + (static_cast<CornerKey>(over) << sh);
-      const CornerKey bin_hi = rlo + (1ull << sh);
-      rhi = bin_hi < rhi ? bin_hi : rhi;
+      cnt = min(s_fill, kChunkCap);
     }
-    // ---- gather the chunk into LDS, order it --------------------------------------------------
-    if (tid == 0) s_fill = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < nkeys; i0 += kOrdThreads) {
-      const int i = i0 + tid;
-      const CornerKey k = i < nkeys ? raw[i] : 0ull;
-      const bool keep = i < nkeys && k >= T && k < upper;
-      const unsigned long long mask = __ballot(keep);
-      if (mask == 0ull) continue;
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&s_fill, __popcll(mask));
-      base = __shfl(base, 0);
-      const int at = base + __popcll(mask & ((1ull << lane) - 1ull));
-      if (keep && at < kChunkCap) s_keys[at] = k;
-    }
-    __syncthreads();
-    const int cnt = min(s_fill, kChunkCap);
-    if (cnt == 0) break;  // (cannot happen: the chunk holds at least the strongest candidate left)
+    if (cnt == 0) break;  // (cannot happen: a chunk holds at least the strongest candidate left)
     const int p2 = next_pow2(cnt);
     for (int i = cnt + tid; i < p2; i += kOrdThreads) s_keys[i] = 0ull;  // sorts behind every real key
     __syncthreads();
@@ -185,30 +339,50 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       const int x = static_cast<int>(addr % static_cast<unsigned>(n));
       const int y = static_cast<int>(addr / static_cast<unsigned>(n));
       const int cx = x / cell, cy = y / cell;
+      if (wave == kOrdWaves - 1)
+        s_cand[lane] = make_uint2(static_cast<unsigned>(x) | (static_cast<unsigned>(y) << 16),
+                                  static_cast<unsigned>(cx) | (static_cast<unsigned>(cy) << 16));
       unsigned long long conf = 0ull;
       bool rejected = false;
-      if (use_grid) {
-        // against this wave's share of the corners accepted so far
-        for (int j = wave; j < nacc; j += kOrdWaves) {
-          const uint2 a = s_acc[j];  // the same address in every lane: LDS broadcast
-          const int ax = static_cast<int>(a.x & 0xffffu), ay = static_cast<int>(a.x >> 16);
-          const int acx = static_cast<int>(a.y & 0xffffu), acy = static_cast<int>(a.y >> 16);
-          const double dx = static_cast<double>(x - ax), dy = static_cast<double>(y - ay);
-          // OpenCV only looks at the 3x3 cells around the candidate (cell = round(min_distance))
-          if (abs(cx - acx) <= 1 && abs(cy - acy) <= 1 && dx * dx + dy * dy < md2) rejected = true;
+      if (use_grid && wave < 9 && valid) {
+        // waves 0..8 look into one of the 3x3 cells around the candidate (OpenCV looks nowhere else:
+        // cell = round(min_distance) may be smaller than min_distance)
+        const int ncx = cx + (wave % 3) - 1, ncy = cy + (wave / 3) - 1;
+        if (ncx >= 0 && ncy >= 0) {
+          const unsigned want = static_cast<unsigned>(ncx) | (static_cast<unsigned>(ncy) << 16);
+          unsigned slot = cell_hash(want);
+          for (int probe = 0; probe < kHashSlots; ++probe) {
+            const unsigned have = s_hkey[slot];
+            if (have == kNoCell) break;
+            if (have == want) {
+              for (int q = s_hhead[slot]; q >= 0; q = s_next[q]) {
+                const unsigned a = s_acc[q].x;
+                const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(a & 0xffffu)));
+                const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(a >> 16)));
+                if (dx * dx + dy * dy < md2_ceil) rejected = true;  // neighbouring cells: < 2^31
+              }
+              break;
+            }
+            slot = (slot + 1) & (kHashSlots - 1);
+          }
         }
-        // and against the earlier candidates of the batch this wave is responsible for
+      }
+      s_rej[wave] = __ballot(rejected);  // (every lane writes the same value)
+      __syncthreads();                   // s_cand is complete
+      if (use_grid) {
+        // the earlier candidates of the batch this wave is responsible for
 #pragma unroll
         for (int q = 0; q < 64 / kOrdWaves; ++q) {
           const int j = wave + q * kOrdWaves;
-          const int ox = __shfl(x, j), oy = __shfl(y, j), ocx = __shfl(cx, j), ocy = __shfl(cy, j);
-          const double dx = static_cast<double>(x - ox), dy = static_cast<double>(y - oy);
-          if (j < lane && abs(cx - ocx) <= 1 && abs(cy - ocy) <= 1 && dx * dx + dy * dy < md2) conf |= 1ull << j;
+          const uint2 o = s_cand[j];  // LDS broadcast
+          const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(o.x & 0xffffu)));
+          const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(o.x >> 16)));
+          const int ocx = static_cast<int>(o.y & 0xffffu), ocy = static_cast<int>(o.y >> 16);
+          // (the squares may wrap for far-apart candidates; those fail the cell test)
+          if (j < lane && abs(cx - ocx) <= 1 && abs(cy - ocy) <= 1 && dx * dx + dy * dy < md2_ceil) conf |= 1ull << j;
         }
       }
       s_conf[wave][lane] = conf;
-      const unsigned long long rej_mask = __ballot(rejected);
-      if (lane == 0) s_rej[wave] = rej_mask;
       __syncthreads();
       if (wave == 0) {
         unsigned long long rej = 0ull, cf = 0ull;
@@ -219,21 +393,38 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
         }
         const unsigned long long alive = __ballot(valid) & ~rej;
         const unsigned cf_lo = static_cast<unsigned>(cf), cf_hi = static_cast<unsigned>(cf >> 32);
-        unsigned long long acc = 0ull;  // accepted candidates of the batch, decided in order
-#pragma unroll
-        for (int q = 0; q < 64; ++q) {
+        // accepted candidates of the batch, decided in order: those without a conflict inside the
+        // batch at once, the others one by one
+        unsigned long long pending = __ballot(cf != 0ull) & alive;
+        unsigned long long acc = alive & ~pending;
+        while (pending != 0ull) {
+          const int q = __ffsll(static_cast<long long>(pending)) - 1;
+          pending &= pending - 1ull;
           const unsigned long long cq =
-              (static_cast<unsigned long long>(__builtin_amdgcn_readlane(cf_hi, q)) << 32) |
-              __builtin_amdgcn_readlane(cf_lo, q);
-          if (((alive >> q) & 1ull) && (cq & acc) == 0ull) acc |= 1ull << q;
+              (static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(cf_hi), q))) << 32) |
+              static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(cf_lo), q)));
+          // only accepted candidates in front of q matter; candidates behind q are not in cq
+          if ((cq & acc & ((1ull << q) - 1ull)) == 0ull) acc |= 1ull << q;
+          else acc &= ~(1ull << q);
         }
-        int room = max_corners - nacc;
-        while (__popcll(acc) > room) acc &= ~(1ull << (63 - __clzll(acc)));  // the last ones do not fit
+        // a candidate without conflicts of its own may still be in conflict with an earlier one that
+        // was only accepted in the loop above: cq holds EARLIER lanes only, so such a candidate has
+        // cf != 0 itself and went through the loop - `acc` is final here
+        const int room = max_corners - nacc;
+        while (__popcll(acc) > room) acc &= ~(1ull << (63 - __clzll(static_cast<long long>(acc))));  // the last ones do not fit
         if ((acc >> lane) & 1ull) {
           const int at = nacc + __popcll(acc & ((1ull << lane) - 1ull));
-          s_acc[at] = make_uint2(static_cast<unsigned>(x) | (static_cast<unsigned>(y) << 16),
-                                 static_cast<unsigned>(cx) | (static_cast<unsigned>(cy) << 16));
+          const unsigned cellkey = static_cast<unsigned>(cx) | (static_cast<unsigned>(cy) << 16);
+          s_acc[at] = make_uint2(static_cast<unsigned>(x) | (static_cast<unsigned>(y) << 16), cellkey);
           points[at] = make_float2(static_cast<float>(x), static_cast<float>(y));
+          // into the chain of its cell (the order inside a chain does not matter)
+          unsigned slot = cell_hash(cellkey);
+          for (;;) {
+            const unsigned prev = atomicCAS(&s_hkey[slot], kNoCell, cellkey);
+            if (prev == kNoCell || prev == cellkey) break;
+            slot = (slot + 1) & (kHashSlots - 1);
+          }
+          s_next[at] = static_cast<short>(atomicExch(&s_hhead[slot], at));
         }
         if (lane == 0) s_nacc = nacc + __popcll(acc);
       }
@@ -443,12 +634,37 @@ __global__ __launch_bounds__(kOrdThreads) void vectors_finish(const double2 *__r
 
 int corner_order_max_corners() { return kMaxCornersDev; }
 
+// workspace of one ordering: [histogram | header | head keys]
+constexpr size_t kOrdOffHdr = kOrdBins * sizeof(int);
+constexpr size_t kOrdOffHead = kOrdOffHdr + 64;
+size_t corner_order_ws_bytes() { return kOrdOffHead + kChunkCap * sizeof(CornerKey); }
+
+bool corner_order_supported(int m, int n, double min_distance, int max_corners) {
+  // LDS list of accepted corners, 16-bit coordinates, squared distances of neighbouring cells in 32 bits
+  return max_corners <= kMaxCornersDev && m <= 65535 && n <= 65535 && min_distance < 16383.0;
+}
+
 hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw_count_dev, int cap,
                                const float *eig_max_dev, float quality, int n, double min_distance,
-                               int max_corners, float *points_dev, int *npoints_dev, hipStream_t stream) {
+                               int max_corners, void *ws_dev, float *points_dev, int *npoints_dev,
+                               hipStream_t stream) {
   const int cell = static_cast<int>(std::lrint(min_distance)) > 1 ? static_cast<int>(std::lrint(min_distance)) : 1;
+  const double md2 = std::ceil(min_distance * min_distance);
+  const unsigned md2_ceil = md2 >= 2147483647.0 ? 2147483647u : static_cast<unsigned>(md2);
+  char *ws = static_cast<char *>(ws_dev);
+  int *hist = reinterpret_cast<int *>(ws);
+  OrderHeader *hdr = reinterpret_cast<OrderHeader *>(ws + kOrdOffHdr);
+  CornerKey *head = reinterpret_cast<CornerKey *>(ws + kOrdOffHead);
+  hipError_t e = hipMemsetAsync(ws, 0, kOrdOffHead, stream);
+  if (e != hipSuccess) return e;
+  // the list is streamed by up to 128 workgroups (its length is only known on the device)
+  const int groups = std::max(1, std::min(128, (cap + 4 * kPreThreads - 1) / (4 * kPreThreads)));
+  hipLaunchKernelGGL(corner_hist, dim3(groups), dim3(kPreThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
+                     quality, hist);
+  hipLaunchKernelGGL(corner_gather, dim3(groups), dim3(kPreThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
+                     quality, hist, head, hdr);
   hipLaunchKernelGGL(corner_order, dim3(1), dim3(kOrdThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
-                     quality, n, cell, min_distance * min_distance, min_distance >= 1.0 ? 1 : 0, max_corners,
+                     quality, head, hdr, n, cell, md2_ceil, min_distance >= 1.0 ? 1 : 0, max_corners,
                      reinterpret_cast<float2 *>(points_dev), npoints_dev);
   return hipGetLastError();
 }
@@ -476,19 +692,22 @@ extern "C" int psh_lk_order_host(const unsigned long long *keys_host, int count,
   PSH_REQUIRE_INIT();
   if (!points_host || !count_host || (count > 0 && !keys_host)) return psh::fail(PSH_EINVAL, "lk_order: NULL pointer");
   if (count < 0 || m <= 0 || n <= 0 || max_corners <= 0) return psh::fail(PSH_EINVAL, "lk_order: invalid argument");
-  if (max_corners > psh::kMaxCornersDev || m > 65535 || n > 65535)
-    return psh::fail(PSH_EUNSUPPORTED, "lk_order: more than %d corners or 65535 rows / columns", psh::kMaxCornersDev);
+  if (!psh::corner_order_supported(m, n, min_distance, max_corners))
+    return psh::fail(PSH_EUNSUPPORTED, "lk_order: more than %d corners, 65535 rows / columns or min_distance >= 16383",
+                     psh::kMaxCornersDev);
   psh::Context &c = psh::ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
   const size_t key_bytes = (static_cast<size_t>(count) * sizeof(unsigned long long) + 255) & ~static_cast<size_t>(255);
   const size_t pts_bytes = static_cast<size_t>(max_corners) * 2 * sizeof(float);
   void *blk = nullptr;
-  if (int rc = psh_malloc(&blk, key_bytes + 256 + pts_bytes)) return rc;
+  const size_t ws_bytes = (psh::corner_order_ws_bytes() + 255) & ~static_cast<size_t>(255);
+  if (int rc = psh_malloc(&blk, key_bytes + 256 + pts_bytes + 256 + ws_bytes)) return rc;
   char *base = static_cast<char *>(blk);
   unsigned long long *d_keys = reinterpret_cast<unsigned long long *>(base);
   int *d_hdr = reinterpret_cast<int *>(base + key_bytes);  // [count | accepted | response max (float)]
   float *d_pts = reinterpret_cast<float *>(base + key_bytes + 256);
+  void *d_ws = base + ((key_bytes + 256 + pts_bytes + 255) & ~static_cast<size_t>(255));
   int rc = PSH_OK;
   auto run = [&]() -> int {
     struct {
@@ -499,8 +718,8 @@ extern "C" int psh_lk_order_host(const unsigned long long *keys_host, int count,
     PSH_HIP(hipMemcpyAsync(d_hdr, &hdr, sizeof(hdr), hipMemcpyHostToDevice, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));  // hdr lives on this stack frame
     PSH_HIP(psh::launch_corner_order(d_keys, d_hdr, count, reinterpret_cast<const float *>(d_hdr + 2),
-                                     static_cast<float>(quality_level), n, min_distance, max_corners, d_pts, d_hdr + 1,
-                                     c.stream));
+                                     static_cast<float>(quality_level), n, min_distance, max_corners, d_ws, d_pts,
+                                     d_hdr + 1, c.stream));
     int accepted = 0;
     PSH_HIP(hipMemcpyAsync(&accepted, d_hdr + 1, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));

@@ -12,6 +12,7 @@ unchanged.  With ``override=True`` the stock names ("semilagrangian", "lk",
 pysteps/tests/test_interfaces.py:69-78,220-233 then fail by design).
 """
 
+FFT_NAME = "hip"
 EXTRAPOLATION_NAMES = ("semilagrangian_hip",)
 MOTION_NAMES = ("lk_hip", "lucaskanade_hip")
 _STOCK_EXTRAPOLATION = ("semilagrangian",)
@@ -40,7 +41,61 @@ def register_into(motion_methods, extrapolation_methods, override=False):
 _MAIN_LOOP_USERS = ("steps", "sprog", "anvil", "linda")
 
 
-def register(override=False, patch_main_loop=False):
+def _hip_aware_get_method(reference_get_method):
+    """pysteps.utils.interface.get_method hard-codes the FFT method names (interface.py:240-243: an
+    ``if name in ["numpy", "pyfftw", "scipy"]`` in front of the method dict), so a new FFT method
+    cannot be added to a table: the lookup function itself is wrapped - ``"hip"`` is answered here,
+    everything else goes to the reference function unchanged."""
+    import functools  # noqa: PLC0415
+
+    @functools.wraps(reference_get_method)
+    def get_method(name="", **kwargs):
+        if isinstance(name, str) and name.lower() == FFT_NAME:
+            if "shape" not in kwargs:
+                raise KeyError("mandatory keyword argument shape not given")  # interface.py:241-242
+            from .utils.fft import get_hip  # noqa: PLC0415
+
+            kwargs = dict(kwargs)
+            return get_hip(kwargs.pop("shape"), **kwargs)
+        return reference_get_method(name, **kwargs)
+
+    get_method._pysteps_amd_reference = reference_get_method
+    return get_method
+
+
+def register_fft():
+    """Make ``fft_method="hip"`` resolve (``pysteps.utils.get_method("hip", shape=...)``): the
+    callers that take an FFT method name - nowcasts.steps / sseps / linda, the noise generators,
+    the cascade decomposition - then run their transforms through csrc/fft.hip."""
+    import pysteps.utils as utils_pkg  # noqa: PLC0415
+    import pysteps.utils.interface as utils_if  # noqa: PLC0415
+
+    if hasattr(utils_if.get_method, "_pysteps_amd_reference"):
+        return []
+    wrapped = _hip_aware_get_method(utils_if.get_method)
+    utils_if.get_method = wrapped
+    utils_pkg.get_method = wrapped
+    try:  # the one module that binds the function by name (blending/utils.py:30)
+        import pysteps.blending.utils as blending_utils  # noqa: PLC0415
+
+        if hasattr(blending_utils, "utils_get_method"):
+            blending_utils.utils_get_method = wrapped
+    except Exception:
+        pass
+    return ["fft:" + FFT_NAME]
+
+
+def unregister_fft():
+    import pysteps.utils as utils_pkg  # noqa: PLC0415
+    import pysteps.utils.interface as utils_if  # noqa: PLC0415
+
+    ref = getattr(utils_if.get_method, "_pysteps_amd_reference", None)
+    if ref is not None:
+        utils_if.get_method = ref
+        utils_pkg.get_method = ref
+
+
+def register(override=False, patch_main_loop=False, fft=True):
     """Register with an importable pysteps; raises ImportError if pysteps is absent.
 
     ``patch_main_loop=True`` also installs the device-resident generic nowcast loop
@@ -52,6 +107,8 @@ def register(override=False, patch_main_loop=False):
     import pysteps.motion.interface as mot_if  # noqa: PLC0415
 
     added = register_into(mot_if._methods, ext_if._extrapolation_methods, override=override)
+    if fft:
+        added += register_fft()
     if patch_main_loop:
         import importlib  # noqa: PLC0415
 

@@ -52,3 +52,36 @@ def test_own_interfaces_mirror_the_reference_contract():
         extrapolation.get_method("unknown")
     with pytest.raises(ValueError):
         motion.get_method("unknown")
+
+
+def test_fft_method_name_resolves_through_the_reference_lookup(ref_pysteps):
+    """register() makes pysteps.utils.get_method("hip", shape=...) answer (the reference hard-codes
+    its FFT method names, interface.py:240-243, so the lookup function is wrapped); shapes the
+    kernels do not take are served by numpy.fft - which is all that can run without a GPU."""
+    import numpy as np
+    from pysteps import utils
+    from pysteps.utils import interface
+
+    try:
+        added = register.register()
+        assert "fft:hip" in added or hasattr(interface.get_method, "_pysteps_amd_reference")
+        assert utils.get_method is interface.get_method
+        fft = utils.get_method("hip", shape=(200, 300), n_threads=4)
+        x = np.random.default_rng(0).standard_normal((200, 300))
+        assert np.array_equal(fft.rfft2(x), np.fft.rfft2(x))
+        assert np.array_equal(fft.irfft2(np.fft.rfft2(x)), np.fft.irfft2(np.fft.rfft2(x), s=(200, 300)))
+        assert np.array_equal(fft.fft2(x), np.fft.fft2(x)) and np.array_equal(fft.ifft2(x), np.fft.ifft2(x))
+        assert np.array_equal(fft.fftshift(x), np.fft.fftshift(x))
+        with pytest.raises(KeyError):
+            utils.get_method("hip")
+        # everything else is the reference's own answer
+        ref = utils.get_method("numpy", shape=(64, 64))
+        assert ref.rfft2 is np.fft.rfft2
+        assert utils.get_method("dB") is ref_pysteps.utils.transformation.dB_transform
+        with pytest.raises(ValueError):
+            utils.get_method("no_such_method")
+    finally:
+        register.unregister_fft()
+    assert not hasattr(interface.get_method, "_pysteps_amd_reference")
+    with pytest.raises(ValueError):
+        utils.get_method("hip", shape=(64, 64))
