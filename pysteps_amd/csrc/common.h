@@ -90,10 +90,13 @@ struct SemilagArgs {
   float minval;         // interp_order 3: minimum over the finite values of precip
   int bmode = 0;        // boundary mode of the field resampling (PSH_MODE_*), interp_order 0/1
   const float *vel_packed = nullptr;  // (m,n,2) {u,v} interleaved copy of vel (launch_pack_velocity) or nullptr
+  const float *field_pairs = nullptr;  // (m,n,2) {p(y,x), p(y+1,x)} row-pair copy of precip (launch_pack_field_rows)
 };
 // true if the default kernel samples the velocity from the packed {u,v} plane for this call
 bool semilag_wants_packed(const SemilagArgs &a);
 hipError_t launch_pack_velocity(const float *vel, float *uv, size_t plane, hipStream_t stream);
+bool semilag_wants_field_pairs(const SemilagArgs &a);
+hipError_t launch_pack_field_rows(const float *precip, float *pairs, int m, int n, hipStream_t stream);
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
 void set_semilag_variant(int v);
 // three-pixels-per-lane kernel (semilag_wide.hip): interp_order 0/1, images >= 192 columns

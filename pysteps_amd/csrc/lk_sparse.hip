@@ -229,7 +229,8 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
   __shared__ int s_hist[kOrdBins];
   __shared__ unsigned long long s_conf[kOrdWaves][64];
   __shared__ unsigned long long s_rej[kOrdWaves];
-  __shared__ uint2 s_cand[64];              // the batch: {x | y << 16, x cell | y cell << 16}
+  __shared__ unsigned s_xy[kChunkCap];      // the ordered chunk: x | y << 16 ...
+  __shared__ unsigned s_cl[kChunkCap];      // ... and x cell | y cell << 16 (divisions done once per chunk)
   __shared__ uint2 s_acc[kMaxCornersDev];   // accepted corners, same packing
   __shared__ short s_next[kMaxCornersDev];  // next accepted corner of the same cell (-1: none)
   __shared__ unsigned s_hkey[kHashSlots];   // cell key of a hash slot (kNoCell: free)
@@ -331,17 +332,20 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
     for (int i = cnt + tid; i < p2; i += kOrdThreads) s_keys[i] = 0ull;  // sorts behind every real key
     __syncthreads();
     bitonic_sort_lds<true>(s_keys, p2);
+    for (int i = tid; i < cnt; i += kOrdThreads) {
+      const unsigned addr = static_cast<unsigned>(s_keys[i] & 0xffffffffull);
+      const unsigned px = addr % static_cast<unsigned>(n), py = addr / static_cast<unsigned>(n);
+      s_xy[i] = px | (py << 16);
+      s_cl[i] = (px / static_cast<unsigned>(cell)) | ((py / static_cast<unsigned>(cell)) << 16);
+    }
+    __syncthreads();
     // ---- walk the chunk in batches of 64 ------------------------------------------------------
     for (int b0 = 0; b0 < cnt && nacc < max_corners; b0 += 64) {
       const int i = b0 + lane;
       const bool valid = i < cnt;
-      const unsigned addr = valid ? static_cast<unsigned>(s_keys[i] & 0xffffffffull) : 0u;
-      const int x = static_cast<int>(addr % static_cast<unsigned>(n));
-      const int y = static_cast<int>(addr / static_cast<unsigned>(n));
-      const int cx = x / cell, cy = y / cell;
-      if (wave == kOrdWaves - 1)
-        s_cand[lane] = make_uint2(static_cast<unsigned>(x) | (static_cast<unsigned>(y) << 16),
-                                  static_cast<unsigned>(cx) | (static_cast<unsigned>(cy) << 16));
+      const unsigned xy = valid ? s_xy[i] : 0u, cl = valid ? s_cl[i] : 0u;
+      const int x = static_cast<int>(xy & 0xffffu), y = static_cast<int>(xy >> 16);
+      const int cx = static_cast<int>(cl & 0xffffu), cy = static_cast<int>(cl >> 16);
       unsigned long long conf = 0ull;
       bool rejected = false;
       if (use_grid && wave < 9 && valid) {
@@ -367,21 +371,21 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
           }
         }
       }
-      s_rej[wave] = __ballot(rejected);  // (every lane writes the same value)
-      __syncthreads();                   // s_cand is complete
       if (use_grid) {
         // the earlier candidates of the batch this wave is responsible for
 #pragma unroll
         for (int q = 0; q < 64 / kOrdWaves; ++q) {
           const int j = wave + q * kOrdWaves;
-          const uint2 o = s_cand[j];  // LDS broadcast
-          const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(o.x & 0xffffu)));
-          const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(o.x >> 16)));
-          const int ocx = static_cast<int>(o.y & 0xffffu), ocy = static_cast<int>(o.y >> 16);
+          if (b0 + j >= cnt) break;  // (uniform)
+          const unsigned oxy = s_xy[b0 + j], ocl = s_cl[b0 + j];  // LDS broadcast
+          const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(oxy & 0xffffu)));
+          const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(oxy >> 16)));
+          const int ocx = static_cast<int>(ocl & 0xffffu), ocy = static_cast<int>(ocl >> 16);
           // (the squares may wrap for far-apart candidates; those fail the cell test)
           if (j < lane && abs(cx - ocx) <= 1 && abs(cy - ocy) <= 1 && dx * dx + dy * dy < md2_ceil) conf |= 1ull << j;
         }
       }
+      s_rej[wave] = __ballot(rejected);  // (every lane writes the same value)
       s_conf[wave][lane] = conf;
       __syncthreads();
       if (wave == 0) {

@@ -457,10 +457,17 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
   void *packed_blk = nullptr;
   if (psh::semilag_wants_packed(a)) {
     // {u,v} interleaved copy of the velocity for the dwordx4 gathers (semilag.hip); cached block
+    // and, for bilinear resampling over several lead times, the row-pair copy of the field behind it
     const size_t plane = static_cast<size_t>(m) * n;
-    int rc = psh_malloc(&packed_blk, 2 * plane * sizeof(float));
+    const bool pairs = psh::semilag_wants_field_pairs(a);
+    int rc = psh_malloc(&packed_blk, (pairs ? 4 : 2) * plane * sizeof(float));
     if (rc == PSH_OK) {
-      const hipError_t pe = psh::launch_pack_velocity(velocity_dev, static_cast<float *>(packed_blk), plane, c.stream);
+      hipError_t pe = psh::launch_pack_velocity(velocity_dev, static_cast<float *>(packed_blk), plane, c.stream);
+      if (pe == hipSuccess && pairs) {
+        float *pp = static_cast<float *>(packed_blk) + 2 * plane;
+        pe = psh::launch_pack_field_rows(precip_dev, pp, m, n, c.stream);
+        a.field_pairs = pp;
+      }
       if (pe != hipSuccess) rc = fail(PSH_EHIP, "pack_velocity failed: %s", hipGetErrorString(pe));
     }
     if (rc) {

@@ -46,7 +46,8 @@ using namespace sl;
 constexpr int kTileX = 64;
 // kernel flavours: direct gathers (one pixel per lane), LDS-staged tiles, direct gathers with
 // two horizontally adjacent pixels per lane
-enum : int { kModeDirect = 0, kModeStaged = 1, kModePairX = 2, kModePacked = 3 };
+// kModePacked: {u,v} interleaved velocity plane; kModePacked2: that plus the row-pair field plane
+enum : int { kModeDirect = 0, kModeStaged = 1, kModePairX = 2, kModePacked = 3, kModePacked2 = 4 };
 constexpr int kWavesPerBlock = 4;   // LDS-staged variants: 4 waves (rows) per workgroup
 // the direct kernel runs 8 rows per workgroup: the tap row below a wave's pixels is the row the next
 // wave samples, more rows per workgroup = more of that reuse in the CU's L1 (1.55 -> 1.50 ms)
@@ -57,7 +58,8 @@ struct Fields {
   // descriptor (SGPR) + one 32-bit lane offset + immediate (+1 column) + scalar
   // offset (+1 row) - no per-load 64-bit VALU address arithmetic
   __amdgpu_buffer_rsrc_t ru, rv, rp;
-  __amdgpu_buffer_rsrc_t ruv;  // packed {u,v} float2 plane (kModePacked)
+  __amdgpu_buffer_rsrc_t ruv;  // packed {u,v} float2 plane (kModePacked, kModePacked2)
+  __amdgpu_buffer_rsrc_t rpp;  // row-pair field plane {p(y,x), p(y+1,x)} (kModePacked2)
   int row_bytes;
   const float *coef;  // cubic B-spline coefficients of the field (interp_order 3 only)
   float minval;       // minimum over its finite values (interp_order 3 only)
@@ -208,7 +210,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool WITH_P>
+// The field's four taps in ONE load (PAIRS): with the rows interleaved in pairs - plane
+// {p(y,x), p(y+1,x)} per pixel, pack_field_rows below - the 2x2 footprint of a sample is 16
+// contiguous bytes at the lane's own position, so the field costs the vector memory pipeline one
+// dwordx4 instead of two dwordx2: 5 loads per pixel and lead step instead of 6 (same values, same
+// blend order - bit-identical).
+template <bool WITH_P, bool PAIRS>
 __device__ __forceinline__ void sample_interior_packed(const Fields &F, int X, int Y, float fx, float fy,
                                                        int n, float &su, float &sv, float &sp) {
   const unsigned offp = static_cast<unsigned>(__mul24(Y, n) + X) << 2;
@@ -217,7 +224,11 @@ __device__ __forceinline__ void sample_interior_packed(const Fields &F, int X, i
   const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(F.ruv, static_cast<int>(offuv), 0, 0);
   const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(F.ruv, static_cast<int>(offuv), 2 * rb, 0);
   u32x2 pt, pb;  // {p(X), p(X+1)} of the two tap rows
-  if (WITH_P) {
+  if (WITH_P && PAIRS) {
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(F.rpp, static_cast<int>(offuv), 0, 0);
+    pt = u32x2{q.x, q.z};  // {p(Y,X), p(Y,X+1)}
+    pb = u32x2{q.y, q.w};  // {p(Y+1,X), p(Y+1,X+1)}
+  } else if (WITH_P) {
     pt = __builtin_amdgcn_raw_buffer_load_b64(F.rp, static_cast<int>(offp), 0, 0);
     pb = __builtin_amdgcn_raw_buffer_load_b64(F.rp, static_cast<int>(offp), rb, 0);
   }
@@ -249,6 +260,26 @@ __global__ __launch_bounds__(256) void pack_velocity(const float *__restrict__ v
     for (size_t k = i; k < plane; ++k) {
       uv[2 * k] = vel[k];
       uv[2 * k + 1] = vel[plane + k];
+    }
+  }
+}
+
+// row-pair copy of the field: out[(y n + x) 2 + {0,1}] = {p(y,x), p(min(y+1, m-1), x)}; 4 pixels per thread
+__global__ __launch_bounds__(256) void pack_field_rows(const float *__restrict__ p, float *__restrict__ out, int m,
+                                                       int n) {
+  const int y = blockIdx.y;
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x >= n) return;
+  const float *r0 = p + static_cast<size_t>(y) * n, *r1 = p + static_cast<size_t>(min(y + 1, m - 1)) * n;
+  float *o = out + (static_cast<size_t>(y) * n + x) * 2;
+  if (x + 3 < n && (n & 3) == 0) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(r0 + x), b = *reinterpret_cast<const f32x4 *>(r1 + x);
+    reinterpret_cast<f32x4 *>(o)[0] = f32x4{a.x, b.x, a.y, b.y};
+    reinterpret_cast<f32x4 *>(o)[1] = f32x4{a.z, b.z, a.w, b.w};
+  } else {
+    for (int k = 0; k < 4 && x + k < n; ++k) {
+      o[2 * k] = r0[x + k];
+      o[2 * k + 1] = r1[x + k];
     }
   }
 }
@@ -425,10 +456,11 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
   for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(X[j], Y[j], m, n);
   // wave-uniform branch: interior waves (almost all of them) skip every clamp
   if (inside) {
-    if (MODE == kModePacked) {
+    if (MODE == kModePacked || MODE == kModePacked2) {
 #pragma unroll
       for (int j = 0; j < NPX; ++j)
-        sample_interior_packed<kWithP && ORDER == 1>(F, X[j], Y[j], fx[j], fy[j], n, su[j], sv[j], sp[j]);
+        sample_interior_packed<kWithP && ORDER == 1, MODE == kModePacked2>(F, X[j], Y[j], fx[j], fy[j], n, su[j], sv[j],
+                                                                            sp[j]);
     } else {
       sample_interior<NPX, kWithP && ORDER == 1>(F, X, Y, fx, fy, n, su, sv, sp);
     }
@@ -463,12 +495,14 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
 // GEN: the field resampling honours F.bmode (any scipy boundary mode); otherwise the kernel only
 // contains the "constant" rule and none of the folding code
 template <int MODE>
-constexpr int waves_of() { return (MODE == kModeDirect || MODE == kModePacked) ? kDirectWaves : kWavesPerBlock; }
+constexpr int waves_of() {
+  return (MODE == kModeDirect || MODE == kModePacked || MODE == kModePacked2) ? kDirectWaves : kWavesPerBlock;
+}
 
 template <int NPX, int ORDER, bool HAS_PRECIP, int MODE, bool GEN>
 __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
     const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vel_packed,
-    float *__restrict__ out,
+    const float *__restrict__ field_pairs, float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
     int T, int n_iter, int resume, float outval, int row0, int rows, const float *__restrict__ coef,
     float minval, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd) {
@@ -493,7 +527,10 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
   F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
   F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_PRECIP ? precip : vel), 0, plane_bytes,
                                            0x00020000);
-  F.ruv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == kModePacked ? vel_packed : vel), 0,
+  constexpr bool kPackedVel = MODE == kModePacked || MODE == kModePacked2;
+  F.ruv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(kPackedVel ? vel_packed : vel), 0, 2 * plane_bytes,
+                                            0x00020000);
+  F.rpp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == kModePacked2 ? field_pairs : vel), 0,
                                             2 * plane_bytes, 0x00020000);
   F.row_bytes = n * static_cast<int>(sizeof(float));
   F.coef = coef;
@@ -678,7 +715,8 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   const dim3 grid(tiles_per_xcd * kNumXcd), block(kTileX * kWaves);
 #define PSH_SL_LAUNCH(ORDER, HASP, GEN)                                                         \
   hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, MODE, GEN>), grid, block, 0, stream,      \
-                     a.precip, a.vel, a.vel_packed, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, a.T, \
+                     a.precip, a.vel, a.vel_packed, a.field_pairs, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, \
+                     a.T,                                                                                  \
                      a.n_iter, a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, a.bmode,   \
                      tiles_x, n_tiles, tiles_per_xcd)
   if (a.precip == nullptr) {
@@ -729,6 +767,7 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
   }
   // one or two rows per thread measured equal (1.45 ms at 4096^2 x 24): the kernel is not short of
   // loads in flight
+  if (a.vel_packed != nullptr && a.field_pairs != nullptr && a.order == 1) return launch_variant<1, kModePacked2>(a, stream);
   if (a.vel_packed != nullptr) return launch_variant<1, kModePacked>(a, stream);
   return launch_variant<1, kModeDirect>(a, stream);
 }
@@ -736,7 +775,18 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
 // variant 0 (default) samples the velocity from a packed {u,v} plane when the caller provides one;
 // variant 1 = the one-plane-per-component kernel with DPP column sharing (round 1 default)
 bool semilag_wants_packed(const SemilagArgs &a) {
-  return g_semilag_variant == 0 && static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29);
+  return (g_semilag_variant == 0 || g_semilag_variant == 5) &&
+         static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29);
+}
+// variant 0 also samples the field from a row-pair plane (one dwordx4 per sample); 5 = packed
+// velocity only (two dwordx2 for the field), kept for comparison
+bool semilag_wants_field_pairs(const SemilagArgs &a) {
+  return g_semilag_variant == 0 && semilag_wants_packed(a) && a.precip != nullptr && a.order == 1 && a.T > 1;
+}
+
+hipError_t launch_pack_field_rows(const float *precip, float *pairs, int m, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_field_rows, dim3((n + 1023) / 1024, m), dim3(256), 0, stream, precip, pairs, m, n);
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_velocity(const float *vel, float *uv, size_t plane, hipStream_t stream) {

@@ -9,6 +9,8 @@ given), which the noise generators (pysteps/noise/fftgenerators.py), the cascade
 * NumPy in -> NumPy out: the array crosses the bus, is transformed on the GPU and comes back - a
   4096 x 4096 ``rfft2`` is then bound by PCIe (~5 ms) instead of pocketfft (~0.5 s).
 * :class:`~pysteps_amd.device.DeviceArray` in -> DeviceArray out: nothing leaves HBM.
+* Single-precision input gives single-precision output, as numpy >= 2.0 does (``rfft2`` of float32
+  is complex64): the transform itself always runs in float64 and the result is rounded once.
 * Shapes the kernels do not take (a side that is not a power of two in 2..8192, anything but two
   dimensions) are handed to ``numpy.fft``, the reference's default method - same results, CPU speed.
 """
@@ -36,8 +38,17 @@ def _to_device(x, dtype):
     return DeviceArray.from_host(np.ascontiguousarray(x, dtype=dtype)), False
 
 
-def _finish(out, resident):
-    return out if resident else out.to_host()
+def _finish(out, resident, single=False):
+    if resident:
+        return out
+    host = out.to_host()
+    if single:  # numpy >= 2.0 keeps single precision: float32 / complex64 in -> complex64 / float32 out
+        return host.astype(np.complex64 if host.dtype == np.complex128 else np.float32)
+    return host
+
+
+def _is_single(x):
+    return not isinstance(x, DeviceArray) and np.asarray(x).dtype in (np.float32, np.float16, np.complex64)
 
 
 def rfft2(x):
@@ -46,11 +57,12 @@ def rfft2(x):
         return np.fft.rfft2(_host(x))
     if not isinstance(x, DeviceArray) and np.iscomplexobj(x):
         x = np.real(x)  # numpy discards the imaginary part (with a ComplexWarning)
+    single = _is_single(x)
     d, resident = _to_device(x, np.float64)
     m, n = d.shape
     out = DeviceArray((m, n // 2 + 1), np.complex128)
     _lib.check(_lib.lib().psh_fft_rfft2_dev(d.ptr, m, n, out.ptr), "psh_fft_rfft2_dev")
-    return _finish(out, resident)
+    return _finish(out, resident, single)
 
 
 def irfft2(x, s):
@@ -58,20 +70,22 @@ def irfft2(x, s):
     s = tuple(int(v) for v in s)
     if not supported_shape(s) or tuple(x.shape) != (s[0], s[1] // 2 + 1):
         return np.fft.irfft2(_host(x), s=s)
+    single = _is_single(x)
     d, resident = _to_device(x, np.complex128)
     out = DeviceArray(s, np.float64)
     _lib.check(_lib.lib().psh_fft_irfft2_dev(d.ptr, s[0], s[1], out.ptr), "psh_fft_irfft2_dev")
-    return _finish(out, resident)
+    return _finish(out, resident, single)
 
 
 def _c2c(x, inverse):
     if not supported_shape(x.shape):
         return (np.fft.ifft2 if inverse else np.fft.fft2)(_host(x))
+    single = _is_single(x)
     d, resident = _to_device(x, np.complex128)
     m, n = d.shape
     out = DeviceArray((m, n), np.complex128)
     _lib.check(_lib.lib().psh_fft_c2c2_dev(d.ptr, m, n, 1 if inverse else 0, out.ptr), "psh_fft_c2c2_dev")
-    return _finish(out, resident)
+    return _finish(out, resident, single)
 
 
 def fft2(x):

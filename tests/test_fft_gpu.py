@@ -38,9 +38,15 @@ def test_transforms_match_numpy(shape):
     z = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
     assert _c(fft.fft2(z), np.fft.fft2(z)) < TOL
     assert _c(fft.ifft2(z), np.fft.ifft2(z)) < TOL
-    # real input of another dtype, like numpy
-    assert _c(fft.rfft2(x.astype(np.float32)), np.fft.rfft2(x.astype(np.float32))) < TOL
-    assert _c(fft.fft2(x), np.fft.fft2(x)) < TOL
+    assert _c(fft.fft2(x), np.fft.fft2(x)) < TOL  # real input
+    # single precision in -> single precision out, as numpy >= 2.0 (which also COMPUTES in float32:
+    # the bar here is float32 round-off)
+    x32 = x.astype(np.float32)
+    got32, want32 = fft.rfft2(x32), np.fft.rfft2(x32)
+    assert got32.dtype == want32.dtype and _c(got32, want32) < 1e-5
+    assert fft.irfft2(want32).dtype == np.fft.irfft2(want32, s=shape).dtype
+    assert fft.fft2(x32).dtype == np.fft.fft2(x32).dtype
+    assert _c(fft.rfft2(x.astype(np.int32)), np.fft.rfft2(x.astype(np.int32))) < TOL
 
 
 def test_irfft2_ignores_the_imaginary_parts_numpy_ignores():
@@ -96,7 +102,12 @@ def test_reference_noise_and_cascade_callers(ref_pysteps):
     ref = utils.get_method("numpy", shape=shape)
     pg_h = fftgenerators.initialize_param_2d_fft_filter(field, fft_method=hip)
     pg_r = fftgenerators.initialize_param_2d_fft_filter(field, fft_method=ref)
-    assert _c(pg_h["field"], pg_r["field"]) < 1e-10
+    # (the default "power-law" model FITS a parametric spectrum to the transform with scipy's
+    # curve_fit: round-off differences of the transform are amplified by the optimiser)
+    assert _c(pg_h["field"], pg_r["field"]) < 1e-6
+    np_h = fftgenerators.initialize_nonparam_2d_fft_filter(field, fft_method=hip)
+    np_r = fftgenerators.initialize_nonparam_2d_fft_filter(field, fft_method=ref)
+    assert _c(np_h["field"], np_r["field"]) < 1e-10
     n_h = fftgenerators.generate_noise_2d_fft_filter(pg_r, randstate=np.random.RandomState(3), fft_method=hip)
     n_r = fftgenerators.generate_noise_2d_fft_filter(pg_r, randstate=np.random.RandomState(3), fft_method=ref)
     assert _c(n_h, n_r) < 1e-10
