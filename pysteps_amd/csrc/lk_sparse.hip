@@ -118,10 +118,13 @@ __device__ __forceinline__ void chunk_cut(const int *hist, int above, int lane, 
 // the head of the walking order, selected by many workgroups (the candidate list can hold
 // millions of keys; a single workgroup streams it at the latency of one compute unit)
 // ---------------------------------------------------------------------------------------------
+constexpr int kHeadSegs = 4;  // consecutive chunks of the walking order prepared by the many-workgroup pass
 struct OrderHeader {
-  CornerKey floor_key;  // head[] holds every candidate key >= floor_key
-  int count;            // their number; < 0: no head (an overfull bin has to be refined: corner_order does it)
-  int fill;             // reservation counter of corner_gather
+  CornerKey floor_key[kHeadSegs];  // segment s of head[] holds every candidate key in [floor_key[s], floor_key[s-1])
+  int count[kHeadSegs];            // their numbers
+  int fill[kHeadSegs];             // reservation counters of corner_gather
+  int nseg;                        // segments that are valid; the walk selects further chunks itself
+  int pad[3];
 };
 
 constexpr int kPreThreads = 256;
@@ -152,7 +155,8 @@ __global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__
                                                              const int *__restrict__ hist,
                                                              CornerKey *__restrict__ head,
                                                              OrderHeader *__restrict__ hdr) {
-  __shared__ int s_over, s_fits;
+  __shared__ int s_suffix[kOrdBins + 1];  // candidates in bins >= c
+  __shared__ int s_cut[kHeadSegs + 1];
   __shared__ int s_wave[kPreThreads / 64];
   __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,53 +164,86 @@ __global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__
   CornerKey key_lo, key_hi;
   key_range(*eig_max, quality, key_lo, key_hi);
   const int sh = bin_shift(key_lo, key_hi);
+  // ---- suffix counts of the histogram (every workgroup repeats this small computation) ----------
   if (wave == 0) {
-    int over, fits;
-    chunk_cut(hist, 0, lane, over, fits);
+    constexpr int kPer = kOrdBins / 64;
+    int tot = 0;
+    for (int q = 0; q < kPer; ++q) tot += hist[lane * kPer + q];
+    int incl = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int dn = __shfl_down(incl, d);
+      if (lane + d < 64) incl += dn;
+    }
+    int run = incl - tot;
+    for (int q = kPer - 1; q >= 0; --q) {
+      run += hist[lane * kPer + q];
+      s_suffix[lane * kPer + q] = run;
+    }
     if (lane == 0) {
-      s_over = over;
-      s_fits = fits;
+      s_suffix[kOrdBins] = 0;
+      s_cut[0] = kOrdBins;
     }
   }
   __syncthreads();
-  const int over = s_over, fits = s_fits;
-  const bool usable = over < 0 || fits >= kChunkTarget;
-  const CornerKey T = over < 0 ? key_lo : key_lo + (static_cast<CornerKey>(over + 1) << sh);
-  if (blockIdx.x == 0 && tid == 0) {
-    hdr->floor_key = T;
-    hdr->count = usable ? fits : -1;
+  // ---- segment s = bins [cut[s+1], cut[s]): as many whole bins as fit a chunk -------------------
+  int nseg = 0;
+  for (int sgm = 0; sgm < kHeadSegs; ++sgm) {
+    const int prev = s_cut[sgm], base = s_suffix[prev];
+    if (tid == 0) s_cut[sgm + 1] = prev;
+    __syncthreads();
+    for (int c = tid; c < prev; c += kPreThreads)
+      if (s_suffix[c] - base <= kChunkCap) atomicMin(&s_cut[sgm + 1], c);
+    __syncthreads();
+    if (s_cut[sgm + 1] == prev) break;  // the next bin alone overfills a chunk: the walk refines it
+    nseg = sgm + 1;
+    if (s_cut[sgm + 1] == 0) break;  // the bottom of the key range
   }
-  if (!usable) return;
-  // this workgroup's slice of the list: count, reserve once, write
+  if (blockIdx.x == 0 && tid == 0) {
+    hdr->nseg = nseg;
+    for (int sgm = 0; sgm < nseg; ++sgm) {
+      const int c = s_cut[sgm + 1];
+      hdr->floor_key[sgm] = c == 0 ? key_lo : key_lo + (static_cast<CornerKey>(c) << sh);
+      hdr->count[sgm] = s_suffix[c] - s_suffix[s_cut[sgm]];
+    }
+  }
+  // ---- this workgroup's slice of the list, segment by segment: count, reserve once, write -------
   const int per = (nkeys + gridDim.x - 1) / gridDim.x;
   const int s0 = min(blockIdx.x * per, nkeys), s1 = min(s0 + per, nkeys);
-  int mine = 0;
-  for (int i = s0 + tid; i < s1; i += kPreThreads) {
-    const CornerKey k = raw[i];
-    mine += (k >= T && k < key_hi) ? 1 : 0;
-  }
-  int incl = mine;
+  for (int sgm = 0; sgm < nseg; ++sgm) {
+    const int c_lo = s_cut[sgm + 1], c_hi = s_cut[sgm];
+    const CornerKey lo = c_lo == 0 ? key_lo : key_lo + (static_cast<CornerKey>(c_lo) << sh);
+    const CornerKey hi = c_hi == kOrdBins ? key_hi : key_lo + (static_cast<CornerKey>(c_hi) << sh);
+    int mine = 0;
+    for (int i = s0 + tid; i < s1; i += kPreThreads) {
+      const CornerKey k = raw[i];
+      mine += (k >= lo && k < hi) ? 1 : 0;
+    }
+    int incl = mine;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(incl, d);
-    if (lane >= d) incl += up;
-  }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  int before = incl - mine, total = 0;
-  for (int w = 0; w < kPreThreads / 64; ++w) {
-    if (w < wave) before += s_wave[w];
-    total += s_wave[w];
-  }
-  if (total == 0) return;
-  if (tid == 0) s_base = atomicAdd(&hdr->fill, total);
-  __syncthreads();
-  int at = s_base + before;
-  for (int i = s0 + tid; i < s1; i += kPreThreads) {
-    const CornerKey k = raw[i];
-    if (k >= T && k < key_hi) {
-      if (at < kChunkCap) head[at] = k;
-      ++at;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if (lane >= d) incl += up;
+    }
+    __syncthreads();  // s_wave / s_base of the previous segment are no longer read
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int before = incl - mine, total = 0;
+    for (int w = 0; w < kPreThreads / 64; ++w) {
+      if (w < wave) before += s_wave[w];
+      total += s_wave[w];
+    }
+    if (total == 0) continue;  // (uniform)
+    if (tid == 0) s_base = atomicAdd(&hdr->fill[sgm], total);
+    __syncthreads();
+    int at = s_base + before;
+    CornerKey *dst = head + static_cast<size_t>(sgm) * kChunkCap;
+    for (int i = s0 + tid; i < s1; i += kPreThreads) {
+      const CornerKey k = raw[i];
+      if (k >= lo && k < hi) {
+        if (at < kChunkCap) dst[at] = k;
+        ++at;
+      }
     }
   }
 }
@@ -235,7 +272,9 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
   __shared__ short s_next[kMaxCornersDev];  // next accepted corner of the same cell (-1: none)
   __shared__ unsigned s_hkey[kHashSlots];   // cell key of a hash slot (kNoCell: free)
   __shared__ int s_hhead[kHashSlots];       // first accepted corner of that cell (-1: none)
-  __shared__ int s_fill, s_nacc, s_over, s_fits;
+  __shared__ unsigned short s_surv[kOrdThreads];  // survivors of the block test, in walking order
+  __shared__ int s_wcount[kOrdWaves];
+  __shared__ int s_fill, s_nacc, s_over, s_fits, s_nsurv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nkeys = min(max(*raw_count, 0), cap);
   CornerKey key_lo, upper;  // candidates not yet walked lie in [key_lo, upper)
@@ -246,17 +285,19 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
   }
   int nacc = 0;
   int remaining = nkeys;
-  bool have_head = hdr != nullptr && hdr->count >= 0;
+  const int head_segs = hdr != nullptr ? min(max(hdr->nseg, 0), kHeadSegs) : 0;
+  int seg = 0;
   __syncthreads();
   while (remaining > 0 && nacc < max_corners) {
     CornerKey T = key_lo;
     int cnt = 0;
-    if (have_head) {
-      // ---- first chunk: selected and gathered by corner_hist / corner_gather -------------------
-      T = hdr->floor_key;
-      cnt = min(hdr->count, kChunkCap);
-      for (int i = tid; i < cnt; i += kOrdThreads) s_keys[i] = head[i];
-      have_head = false;
+    if (seg < head_segs) {
+      // ---- the first chunks: selected and gathered by corner_hist / corner_gather ----------------
+      T = hdr->floor_key[seg];
+      cnt = min(max(hdr->count[seg], 0), kChunkCap);
+      const CornerKey *src = head + static_cast<size_t>(seg) * kChunkCap;
+      for (int i = tid; i < cnt; i += kOrdThreads) s_keys[i] = src[i];
+      ++seg;
     } else {
       // ---- threshold key T: the chunk is every candidate in [T, upper) ------------------------
       CornerKey rlo = key_lo, rhi = upper;
@@ -327,7 +368,12 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       __syncthreads();
       cnt = min(s_fill, kChunkCap);
     }
-    if (cnt == 0) break;  // (cannot happen: a chunk holds at least the strongest candidate left)
+    if (cnt == 0) {  // an empty segment (whole bins only): on to the next chunk
+      if (T <= key_lo) break;
+      upper = T;
+      __syncthreads();
+      continue;
+    }
     const int p2 = next_pow2(cnt);
     for (int i = cnt + tid; i < p2; i += kOrdThreads) s_keys[i] = 0ull;  // sorts behind every real key
     __syncthreads();
@@ -339,18 +385,65 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       s_cl[i] = (px / static_cast<unsigned>(cell)) | ((py / static_cast<unsigned>(cell)) << 16);
     }
     __syncthreads();
-    // ---- walk the chunk in batches of 64 ------------------------------------------------------
-    for (int b0 = 0; b0 < cnt && nacc < max_corners; b0 += 64) {
-      const int i = b0 + lane;
-      const bool valid = i < cnt;
+    // ---- walk the chunk: 1024 candidates at a time are first tested against the corners accepted
+    // so far by all 16 waves at once (late in the walk that removes most of them), the survivors are
+    // then decided in order in batches of 64 ----------------------------------------------------------
+    for (int sb0 = 0; sb0 < cnt && nacc < max_corners; sb0 += kOrdThreads) {
+      const int first_new = nacc;  // corners with a smaller index were seen by the test below
+      {
+        const int i = sb0 + tid;
+        const bool there = i < cnt;
+        bool gone = false;
+        if (use_grid && there && nacc > 0) {
+          const unsigned xy = s_xy[i], cl = s_cl[i];
+          const int x = static_cast<int>(xy & 0xffffu), y = static_cast<int>(xy >> 16);
+          const int cx = static_cast<int>(cl & 0xffffu), cy = static_cast<int>(cl >> 16);
+          for (int nb = 0; nb < 9 && !gone; ++nb) {
+            const int ncx = cx + (nb % 3) - 1, ncy = cy + (nb / 3) - 1;
+            if (ncx < 0 || ncy < 0) continue;
+            const unsigned want = static_cast<unsigned>(ncx) | (static_cast<unsigned>(ncy) << 16);
+            unsigned slot = cell_hash(want);
+            for (int probe = 0; probe < kHashSlots; ++probe) {
+              const unsigned have = s_hkey[slot];
+              if (have == kNoCell) break;
+              if (have == want) {
+                for (int q = s_hhead[slot]; q >= 0; q = s_next[q]) {
+                  const unsigned a = s_acc[q].x;
+                  const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(a & 0xffffu)));
+                  const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(a >> 16)));
+                  if (dx * dx + dy * dy < md2_ceil) gone = true;  // neighbouring cells: < 2^31
+                }
+                break;
+              }
+              slot = (slot + 1) & (kHashSlots - 1);
+            }
+          }
+        }
+        const unsigned long long keep = __ballot(there && !gone);
+        if (lane == 0) s_wcount[wave] = __popcll(keep);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < kOrdWaves; ++w) {
+          if (w < wave) before += s_wcount[w];
+          total += s_wcount[w];
+        }
+        if (there && !gone) s_surv[before + __popcll(keep & ((1ull << lane) - 1ull))] = static_cast<unsigned short>(i);
+        if (tid == 0) s_nsurv = total;
+        __syncthreads();
+      }
+      const int nsurv = s_nsurv;
+    for (int b0 = 0; b0 < nsurv && nacc < max_corners; b0 += 64) {
+      const bool valid = b0 + lane < nsurv;
+      const int i = valid ? s_surv[b0 + lane] : 0;
       const unsigned xy = valid ? s_xy[i] : 0u, cl = valid ? s_cl[i] : 0u;
       const int x = static_cast<int>(xy & 0xffffu), y = static_cast<int>(xy >> 16);
       const int cx = static_cast<int>(cl & 0xffffu), cy = static_cast<int>(cl >> 16);
       unsigned long long conf = 0ull;
       bool rejected = false;
-      if (use_grid && wave < 9 && valid) {
+      if (use_grid && wave < 9 && valid && nacc > first_new) {
         // waves 0..8 look into one of the 3x3 cells around the candidate (OpenCV looks nowhere else:
-        // cell = round(min_distance) may be smaller than min_distance)
+        // cell = round(min_distance) may be smaller than min_distance) - only at the corners accepted
+        // since the test above: a cell's chain runs from the newest corner to the oldest
         const int ncx = cx + (wave % 3) - 1, ncy = cy + (wave / 3) - 1;
         if (ncx >= 0 && ncy >= 0) {
           const unsigned want = static_cast<unsigned>(ncx) | (static_cast<unsigned>(ncy) << 16);
@@ -359,7 +452,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
             const unsigned have = s_hkey[slot];
             if (have == kNoCell) break;
             if (have == want) {
-              for (int q = s_hhead[slot]; q >= 0; q = s_next[q]) {
+              for (int q = s_hhead[slot]; q >= first_new; q = s_next[q]) {
                 const unsigned a = s_acc[q].x;
                 const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(a & 0xffffu)));
                 const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(a >> 16)));
@@ -376,8 +469,9 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
 #pragma unroll
         for (int q = 0; q < 64 / kOrdWaves; ++q) {
           const int j = wave + q * kOrdWaves;
-          if (b0 + j >= cnt) break;  // (uniform)
-          const unsigned oxy = s_xy[b0 + j], ocl = s_cl[b0 + j];  // LDS broadcast
+          if (b0 + j >= nsurv) break;  // (uniform)
+          const int oi = s_surv[b0 + j];
+          const unsigned oxy = s_xy[oi], ocl = s_cl[oi];  // LDS broadcast
           const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(oxy & 0xffffu)));
           const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(oxy >> 16)));
           const int ocx = static_cast<int>(ocl & 0xffffu), ocy = static_cast<int>(ocl >> 16);
@@ -434,6 +528,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       }
       __syncthreads();
       nacc = s_nacc;
+    }
     }
     remaining -= cnt;
     if (T <= key_lo) break;  // the chunk reached the bottom of the key range
@@ -640,8 +735,9 @@ int corner_order_max_corners() { return kMaxCornersDev; }
 
 // workspace of one ordering: [histogram | header | head keys]
 constexpr size_t kOrdOffHdr = kOrdBins * sizeof(int);
-constexpr size_t kOrdOffHead = kOrdOffHdr + 64;
-size_t corner_order_ws_bytes() { return kOrdOffHead + kChunkCap * sizeof(CornerKey); }
+constexpr size_t kOrdOffHead = kOrdOffHdr + 128;
+static_assert(sizeof(OrderHeader) <= 128, "header slot");
+size_t corner_order_ws_bytes() { return kOrdOffHead + static_cast<size_t>(kHeadSegs) * kChunkCap * sizeof(CornerKey); }
 
 bool corner_order_supported(int m, int n, double min_distance, int max_corners) {
   // LDS list of accepted corners, 16-bit coordinates, squared distances of neighbouring cells in 32 bits

@@ -60,27 +60,43 @@ __global__ __launch_bounds__(64) void outliers_local(const double2 *__restrict__
     keys[j] = key;
     best = key < best ? key : best;
   }
-  const int kk = min(n, k + 1);  // nearest hits incl. the vector itself
   double sa = 0.0, sb = 0.0, saa = 0.0, sab = 0.0, sbb = 0.0;
   int cnt = 0;
-  for (int t = 0; t < kk; ++t) {
-    const unsigned long long g = wave_min_u64(best);
-    const int j = static_cast<int>(g & 0xffffffffull);
-    if (t > 0) {  // the first hit is the vector itself (or a duplicate position): dropped
-      const double2 q = uv[j];
-      const double a = q.x - mine.x, b = q.y - mine.y;
-      sa += a;
-      sb += b;
-      saa += a * a;
-      sab += a * b;
-      sbb += b * b;
-      ++cnt;
+  const int kk = min(n, k + 1);  // nearest hits incl. the vector itself
+  // The neighbours are extracted first (pure LDS / cross-lane work), their vectors are then
+  // fetched by kk lanes at once - one round trip to memory instead of one per neighbour - and
+  // summed by lane 0 in extraction order (the order the sums always had: bit-identical flags).
+  __shared__ double2 s_nb[64];
+  int mine_j = -1;
+  for (int t0 = 0; t0 < kk; t0 += 64) {
+    const int tn = min(64, kk - t0);
+    for (int t = 0; t < tn; ++t) {
+      const unsigned long long g = wave_min_u64(best);
+      const int j = static_cast<int>(g & 0xffffffffull);
+      if (lane == t) mine_j = j;
+      if ((j & 63) == lane) {  // owner retires the key and rescans its entries
+        keys[j] = kGone;
+        best = kGone;
+        for (int q = lane; q < n; q += 64) best = keys[q] < best ? keys[q] : best;
+      }
     }
-    if ((j & 63) == lane) {  // owner retires the key and rescans its entries
-      keys[j] = kGone;
-      best = kGone;
-      for (int q = lane; q < n; q += 64) best = keys[q] < best ? keys[q] : best;
+    if (lane < tn) {
+      const double2 q = uv[mine_j];
+      s_nb[lane] = make_double2(q.x - mine.x, q.y - mine.y);
     }
+    __syncthreads();
+    if (lane == 0) {
+      for (int t = (t0 == 0 ? 1 : 0); t < tn; ++t) {  // the first hit is the vector itself (or a duplicate position): dropped
+        const double a = s_nb[t].x, b = s_nb[t].y;
+        sa += a;
+        sb += b;
+        saa += a * a;
+        sab += a * b;
+        sbb += b * b;
+        ++cnt;
+      }
+    }
+    __syncthreads();
   }
   if (lane != 0) return;
   bool out = false;
