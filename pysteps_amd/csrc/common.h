@@ -21,6 +21,10 @@ struct Context {
   int device = -1;
   int cu_count = 0;
   hipStream_t stream = nullptr;
+  // second stream for work that is independent of what the main stream does next (side_begin /
+  // side_end fork and join it with events; everything else is ordered on `stream`)
+  hipStream_t side = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   // small persistent device scratch (per-step scale factors etc.)
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -33,6 +37,12 @@ struct Context {
 Context &ctx();
 int fail(int code, const char *fmt, ...);
 int ensure_scratch(size_t nbytes);
+// Fork: *side will run after everything queued on the main stream so far.  Join: the main stream
+// continues after everything queued on the side stream.  Lock held by the caller.  Blocks handed
+// out by psh_malloc are ordered on the MAIN stream: a block used on the side stream has to be
+// allocated before the fork and freed after the join.
+int side_begin(hipStream_t *side);
+int side_end();
 // pinned staging slot (kConstSlotFloats floats) and its device twin for small per-call constants;
 // the caller fills *host and queues the copy to *dev on the library stream (lock held)
 constexpr size_t kConstSlotFloats = 1024;
@@ -149,6 +159,9 @@ int lk_track_pool(void *pyramid_handle, const float *points_host, const float *p
 int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_dev, float *stats_dev, int m, int n,
                         int block_size, int buffer_mask, double quality_level, double min_distance, int max_corners,
                         float *points_dev, int *npoints_dev);
+
+int lk_pyramids_beside(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m, int n, int win_w,
+                       int win_h, int max_level, void **handle_out);
 
 // ordered min-distance acceptance and the post-outlier-test stage on the device (lk_sparse.hip)
 int corner_order_max_corners();

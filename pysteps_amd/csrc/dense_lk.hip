@@ -99,14 +99,22 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   int *d_npts = corners.as<int>();
   float *d_pts = reinterpret_cast<float *>(corners.as<char>() + 256);
   for (int t = 0; t + 1 < nframes; ++t) {
-    if (int rc = psh::lk_corners_resident(feat[t].as<unsigned char>(), clean[t].as<float>(), stats[t].as<float>(), m,
-                                          n, prm->block_size, prm->buffer_mask, prm->quality_level,
-                                          prm->min_distance, prm->max_corners, d_pts, d_npts))
-      return rc;
+    // the pyramids only need the uint8 renderings: built on the side stream while the main stream
+    // selects and orders the corners (corner_order is a single workgroup - the other 255 CUs are free)
     void *pyr = nullptr;
-    if (int rc = psh_lk_pyramids_dev(trk[t].as<unsigned char>(), trk[t + 1].as<unsigned char>(), m, n, prm->win_w,
-                                     prm->win_h, prm->max_level, &pyr))
+    if (int rc = psh::lk_pyramids_beside(trk[t].as<unsigned char>(), trk[t + 1].as<unsigned char>(), m, n, prm->win_w,
+                                         prm->win_h, prm->max_level, &pyr)) {
+      (void)psh::side_end();
       return rc;
+    }
+    const int rc1 = psh::lk_corners_resident(feat[t].as<unsigned char>(), clean[t].as<float>(),
+                                             stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
+                                             prm->quality_level, prm->min_distance, prm->max_corners, d_pts, d_npts);
+    const int rcj = psh::side_end();  // the tracker needs both
+    if (rc1 || rcj) {
+      (void)psh_lk_pyramids_free(pyr);
+      return rc1 ? rc1 : rcj;
+    }
     const int rc2 = psh::lk_track_pool(pyr, nullptr, d_pts, d_npts, prm->max_corners, prm->max_count, prm->epsilon,
                                        prm->min_eig_threshold, d_pxy, d_puv, d_pcnt, capacity_dev);
     const int rc3 = psh_lk_pyramids_free(pyr);  // stream-ordered: the tracker above is queued first

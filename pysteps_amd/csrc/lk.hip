@@ -522,13 +522,11 @@ __host__ __device__ inline CornerKey make_corner_key(float val, unsigned addr) {
 
 constexpr int kSelRows = 64;  // rows per workgroup (16 per wave): one counter atomic per 64x64 pixels
 
+// v = response at (x, y), loaded by the caller (0 outside the 1-pixel frame goodFeaturesToTrack excludes)
 __device__ __forceinline__ bool corner_keep(const float *__restrict__ eig,
                                             const float *__restrict__ clean, int m, int n, int x,
                                             int y, int buffer_mask, float thr, bool any_nan,
-                                            float &v) {
-  v = 0.f;
-  if (!(x >= 1 && x < n - 1 && y >= 1 && y < m - 1)) return false;
-  v = eig[static_cast<size_t>(y) * n + x];
+                                            float v) {
   if (!(v > thr) || v == 0.f) return false;  // THRESH_TOZERO keeps values > thr
 #pragma unroll
   for (int j = -1; j <= 1; ++j)
@@ -557,12 +555,19 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
   constexpr int kRows = kSelRows / 4;
   unsigned long long masks[kRows];
   int mine = 0;
+  // the responses of the wave's 16 rows first (independent loads in flight together: the row loop
+  // below branches on every value and would otherwise wait for them one after the other)
+  float vs[kRows];
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
-    float v;
     const int yr = y_first + r;
-    masks[r] = __ballot(yr >= band.lo && yr < band.hi &&
-                        corner_keep(eig, clean, m, n, x, yr, buffer_mask, thr, any_nan, v));
+    const bool in_frame = x >= 1 && x < n - 1 && yr >= 1 && yr < m - 1 && yr >= band.lo && yr < band.hi;
+    vs[r] = in_frame ? eig[static_cast<size_t>(yr) * n + x] : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    const int yr = y_first + r;
+    masks[r] = __ballot(corner_keep(eig, clean, m, n, x, yr, buffer_mask, thr, any_nan, vs[r]));
     mine += __popcll(masks[r]);
   }
   if (lane == 0) wave_count[wave] = mine;
@@ -1683,8 +1688,32 @@ struct PyramidSet {
 };
 }  // namespace
 
+static int lk_pyramids_on(hipStream_t stream, const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev,
+                          int m, int n, int win_w, int win_h, int max_level, void **handle_out);
+
 int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m,
                         int n, int win_w, int win_h, int max_level, void **handle_out) {
+  PSH_REQUIRE_INIT();
+  return lk_pyramids_on(ctx().stream, prev_u8_dev, next_u8_dev, m, n, win_w, win_h, max_level, handle_out);
+}
+
+extern "C++" {
+namespace psh {
+// the pyramids of a frame pair on the side stream: they depend on the uint8 renderings only, so
+// they are built while the main stream orders the corner candidates (a single-workgroup kernel)
+int lk_pyramids_beside(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m, int n, int win_w,
+                       int win_h, int max_level, void **handle_out) {
+  Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  hipStream_t side = nullptr;
+  if (int rc = side_begin(&side)) return rc;
+  return lk_pyramids_on(side, prev_u8_dev, next_u8_dev, m, n, win_w, win_h, max_level, handle_out);
+}
+}  // namespace psh
+}  // extern "C++"
+
+static int lk_pyramids_on(hipStream_t stream, const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev,
+                          int m, int n, int win_w, int win_h, int max_level, void **handle_out) {
   PSH_REQUIRE_INIT();
   if (!handle_out) return fail(PSH_EINVAL, "lk_pyramids: NULL handle pointer");
   *handle_out = nullptr;
@@ -1741,14 +1770,14 @@ int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *n
     short2 *dl = need_deriv ? reinterpret_cast<short2 *>(base + off_d[l]) : nullptr;
     if (l) {
       const dim3 g((cols[l] + 31) / 32, (rows[l] + 7) / 8);
-      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, ps->pyr.lv[l - 1].I, rows[l - 1],
+      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, stream, ps->pyr.lv[l - 1].I, rows[l - 1],
                          cols[l - 1], Il, rows[l], cols[l]);
-      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, c.stream, ps->pyr.lv[l - 1].J, rows[l - 1],
+      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, stream, ps->pyr.lv[l - 1].J, rows[l - 1],
                          cols[l - 1], Jl, rows[l], cols[l]);
     }
     if (need_deriv) {
       const dim3 sg((cols[l] + 63) / 64, (rows[l] + 3) / 4);
-      hipLaunchKernelGGL(psh::lk_scharr, sg, dim3(256), 0, c.stream, Il, rows[l], cols[l], dl);
+      hipLaunchKernelGGL(psh::lk_scharr, sg, dim3(256), 0, stream, Il, rows[l], cols[l], dl);
     }
     ps->pyr.lv[l].I = Il;
     ps->pyr.lv[l].J = Jl;

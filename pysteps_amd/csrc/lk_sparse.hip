@@ -157,8 +157,6 @@ __global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__
                                                              OrderHeader *__restrict__ hdr) {
   __shared__ int s_suffix[kOrdBins + 1];  // candidates in bins >= c
   __shared__ int s_cut[kHeadSegs + 1];
-  __shared__ int s_wave[kPreThreads / 64];
-  __shared__ int s_base;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nkeys = min(max(*raw_count, 0), cap);
   CornerKey key_lo, key_hi;
@@ -207,42 +205,64 @@ __global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__
       hdr->count[sgm] = s_suffix[c] - s_suffix[s_cut[sgm]];
     }
   }
-  // ---- this workgroup's slice of the list, segment by segment: count, reserve once, write -------
+  // ---- this workgroup's slice of the list: count per segment, reserve once per segment, write -----
+  if (nseg == 0) return;
+  CornerKey floor_key[kHeadSegs];
+#pragma unroll
+  for (int sgm = 0; sgm < kHeadSegs; ++sgm) {
+    const int c = s_cut[min(sgm, nseg - 1) + 1];
+    floor_key[sgm] = sgm < nseg ? (c == 0 ? key_lo : key_lo + (static_cast<CornerKey>(c) << sh)) : ~0ull;
+  }
+  auto segment_of = [&](CornerKey k) {  // kHeadSegs: not in the head
+    if (k >= key_hi || k == 0ull) return kHeadSegs;
+#pragma unroll
+    for (int sgm = 0; sgm < kHeadSegs; ++sgm)
+      if (k >= floor_key[sgm]) return sgm;
+    return kHeadSegs;
+  };
   const int per = (nkeys + gridDim.x - 1) / gridDim.x;
   const int s0 = min(blockIdx.x * per, nkeys), s1 = min(s0 + per, nkeys);
-  for (int sgm = 0; sgm < nseg; ++sgm) {
-    const int c_lo = s_cut[sgm + 1], c_hi = s_cut[sgm];
-    const CornerKey lo = c_lo == 0 ? key_lo : key_lo + (static_cast<CornerKey>(c_lo) << sh);
-    const CornerKey hi = c_hi == kOrdBins ? key_hi : key_lo + (static_cast<CornerKey>(c_hi) << sh);
-    int mine = 0;
-    for (int i = s0 + tid; i < s1; i += kPreThreads) {
-      const CornerKey k = raw[i];
-      mine += (k >= lo && k < hi) ? 1 : 0;
-    }
-    int incl = mine;
+  int mine[kHeadSegs] = {0, 0, 0, 0};
+  for (int i = s0 + tid; i < s1; i += kPreThreads) {
+    const int sgm = segment_of(raw[i]);
+#pragma unroll
+    for (int q = 0; q < kHeadSegs; ++q) mine[q] += sgm == q ? 1 : 0;
+  }
+  __shared__ int s_wave4[kPreThreads / 64][kHeadSegs];
+  __shared__ int s_base4[kHeadSegs];
+  int before[kHeadSegs];
+#pragma unroll
+  for (int q = 0; q < kHeadSegs; ++q) {
+    int incl = mine[q];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int up = __shfl_up(incl, d);
       if (lane >= d) incl += up;
     }
-    __syncthreads();  // s_wave / s_base of the previous segment are no longer read
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    int before = incl - mine, total = 0;
-    for (int w = 0; w < kPreThreads / 64; ++w) {
-      if (w < wave) before += s_wave[w];
-      total += s_wave[w];
-    }
-    if (total == 0) continue;  // (uniform)
-    if (tid == 0) s_base = atomicAdd(&hdr->fill[sgm], total);
-    __syncthreads();
-    int at = s_base + before;
-    CornerKey *dst = head + static_cast<size_t>(sgm) * kChunkCap;
-    for (int i = s0 + tid; i < s1; i += kPreThreads) {
-      const CornerKey k = raw[i];
-      if (k >= lo && k < hi) {
-        if (at < kChunkCap) dst[at] = k;
-        ++at;
+    if (lane == 63) s_wave4[wave][q] = incl;
+    before[q] = incl - mine[q];
+  }
+  __syncthreads();
+  if (tid < kHeadSegs) {
+    int total = 0;
+    for (int w = 0; w < kPreThreads / 64; ++w) total += s_wave4[w][tid];
+    s_base4[tid] = total > 0 ? atomicAdd(&hdr->fill[tid], total) : 0;
+  }
+  __syncthreads();
+  int at[kHeadSegs];
+#pragma unroll
+  for (int q = 0; q < kHeadSegs; ++q) {
+    at[q] = s_base4[q] + before[q];
+    for (int w = 0; w < wave; ++w) at[q] += s_wave4[w][q];
+  }
+  for (int i = s0 + tid; i < s1; i += kPreThreads) {
+    const CornerKey k = raw[i];
+    const int sgm = segment_of(k);
+#pragma unroll
+    for (int q = 0; q < kHeadSegs; ++q) {
+      if (sgm == q) {
+        if (at[q] < kChunkCap) head[static_cast<size_t>(q) * kChunkCap + at[q]] = k;
+        ++at[q];
       }
     }
   }

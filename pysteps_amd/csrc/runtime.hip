@@ -157,6 +157,30 @@ int psh_init(int device_id) {
   return PSH_OK;
 }
 
+extern "C++" {
+namespace psh {
+int side_begin(hipStream_t *side) {
+  Context &c = ctx();
+  if (!c.side) {
+    PSH_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+    PSH_HIP(hipEventCreateWithFlags(&c.fork_ev, hipEventDisableTiming));
+    PSH_HIP(hipEventCreateWithFlags(&c.join_ev, hipEventDisableTiming));
+  }
+  PSH_HIP(hipEventRecord(c.fork_ev, c.stream));
+  PSH_HIP(hipStreamWaitEvent(c.side, c.fork_ev, 0));
+  *side = c.side;
+  return PSH_OK;
+}
+int side_end() {
+  Context &c = ctx();
+  if (!c.side) return PSH_OK;
+  PSH_HIP(hipEventRecord(c.join_ev, c.side));
+  PSH_HIP(hipStreamWaitEvent(c.stream, c.join_ev, 0));
+  return PSH_OK;
+}
+}  // namespace psh
+}  // extern "C++"
+
 int psh_shutdown(void) {
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
@@ -167,6 +191,14 @@ int psh_shutdown(void) {
   if (c.scratch) (void)hipFree(c.scratch);
   if (c.pinned) (void)hipHostFree(c.pinned);
   (void)hipStreamDestroy(c.stream);
+  if (c.side) {
+    (void)hipStreamSynchronize(c.side);
+    (void)hipStreamDestroy(c.side);
+    (void)hipEventDestroy(c.fork_ev);
+    (void)hipEventDestroy(c.join_ev);
+    c.side = nullptr;
+    c.fork_ev = c.join_ev = nullptr;
+  }
   c.scratch = c.pinned = nullptr;
   c.scratch_bytes = c.pinned_bytes = 0;
   c.stream = nullptr;
