@@ -395,6 +395,24 @@ int psh_fft_rfft2_dev(const double *in_dev, int m, int n, void *out_dev);
 int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_dev);
 int psh_fft_c2c2_dev(const void *in_dev, int m, int n, int inverse, void *out_dev);
 
+/* ---- spectral building blocks of the STEPS member loop (csrc/cascade.hip) -------- *
+ * float64 device arrays, sizes as for the FFTs (powers of two in 2..8192).
+ *  psh_cascade_decompose_dev  pysteps/cascade/decomposition.py:77-262 (decomposition_fft), spatial in /
+ *      spatial out, no mask: levels[k] = irfft2(rfft2(field [- mean]) * weights[k]), k < nlevels;
+ *      weights (nlevels, m, n/2+1) = bp_filter["weights_2d"]; means / stds (np.mean, np.std) of the
+ *      levels come back in HOST arrays of nlevels doubles (the call waits for them); normalize != 0:
+ *      levels[k] = (levels[k] - mean_k) / std_k; subtract_mean != 0: *field_mean_host = mean(field).
+ *  psh_cascade_recompose_dev  decomposition.py:265-305 (recompose_fft): out = sum_k levels[k] * stds[k]
+ *      + means[k] (plain sum if means_host == stds_host == NULL) + field_mean.  Asynchronous.
+ *  psh_noise_filter_dev       pysteps/noise/fftgenerators.py:420-433: out = irfft2(rfft2(white) * filter),
+ *      standardised to zero mean and unit (population) variance; filter (m, n/2+1).  Asynchronous. */
+int psh_cascade_decompose_dev(const double *field_dev, const double *weights_dev, int nlevels, int m, int n,
+                              int normalize, int subtract_mean, double *levels_dev, double *means_host,
+                              double *stds_host, double *field_mean_host);
+int psh_cascade_recompose_dev(const double *levels_dev, int nlevels, int m, int n, const double *means_host,
+                              const double *stds_host, double field_mean, double *out_dev);
+int psh_noise_filter_dev(const double *white_dev, const double *filter_dev, int m, int n, double *out_dev);
+
 /* ---- multi-GPU: RCCL over xGMI, one rank (process) per GPU ------------------ *
  * The reference has no communication layer (single process, optional dask threads:
  * pysteps/nowcasts/utils.py:464-471); members / fields shard across GPUs with ONE

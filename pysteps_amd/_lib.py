@@ -68,6 +68,11 @@ SIGNATURES = {
     "psh_fft_rfft2_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "psh_fft_irfft2_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "psh_fft_c2c2_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "psh_cascade_decompose_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                          POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "psh_cascade_recompose_dev": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_double), POINTER(c_double),
+                                          c_double, c_void_p]),
+    "psh_noise_filter_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "psh_lk_greedy_host": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),
     "psh_lk_order_host": (c_int, [c_void_p, c_int, c_float, c_double, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),
     "psh_idw_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_double, c_void_p]),

@@ -125,6 +125,11 @@ struct IdwDyn {
   int pad[3];
 };
 
+// ---- FFTs (fft.hip) -----------------------------------------------------------
+bool fft_shape_supported(int m, int n);
+int fft_irfft2_weighted(const void *spec_dev, const double *weights_dev, int m, int n, double *out_dev,
+                        void *scratch_dev);
+
 struct IdwArgs {
   const float *xy;  // (L,2) device: x, y of the sparse vectors
   const float *uv;  // (L,2) device: values
@@ -156,9 +161,13 @@ int lk_track_pool(void *pyramid_handle, const float *points_host, const float *p
 
 // corner candidates of one frame -> accepted corners in goodFeaturesToTrack's order, everything
 // on the library stream and in device memory (lk.hip): points_dev holds max_corners (x, y) pairs
+// before_walk (may be NULL) is called once everything up to the ordered walk is queued: the walk
+// is a single workgroup, so independent work forked there (side_begin) runs beside it.
+// walk_stats_host (may be NULL): waits for the stream and returns {chunks, candidates, batches} of the walk.
 int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_dev, float *stats_dev, int m, int n,
                         int block_size, int buffer_mask, double quality_level, double min_distance, int max_corners,
-                        float *points_dev, int *npoints_dev);
+                        float *points_dev, int *npoints_dev, int (*before_walk)(void *) = nullptr,
+                        void *before_walk_arg = nullptr, int *walk_stats_host = nullptr);
 
 int lk_pyramids_beside(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m, int n, int win_w,
                        int win_h, int max_level, void **handle_out);
@@ -170,7 +179,8 @@ size_t corner_order_ws_bytes();  // device scratch of one ordering (histogram, h
 hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw_count_dev, int cap,
                                const float *eig_max_dev, float quality, int n, double min_distance,
                                int max_corners, void *ws_dev, float *points_dev, int *npoints_dev,
-                               hipStream_t stream);
+                               hipStream_t stream, int (*before_walk)(void *), void *before_walk_arg);
+size_t corner_order_walk_stats_offset();  // byte offset of the int[3] walk statistics inside the workspace
 hipError_t launch_vectors_finish(const double *pool_xy_dev, const double *pool_uv_dev,
                                  const unsigned char *flags_dev, const int *pool_count_dev, int capacity,
                                  double decl_scale, int m, int n, float *xy_out_dev, float *uv_out_dev,

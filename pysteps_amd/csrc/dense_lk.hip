@@ -99,21 +99,34 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   int *d_npts = corners.as<int>();
   float *d_pts = reinterpret_cast<float *>(corners.as<char>() + 256);
   for (int t = 0; t + 1 < nframes; ++t) {
-    // the pyramids only need the uint8 renderings: built on the side stream while the main stream
-    // selects and orders the corners (corner_order is a single workgroup - the other 255 CUs are free)
-    void *pyr = nullptr;
-    if (int rc = psh::lk_pyramids_beside(trk[t].as<unsigned char>(), trk[t + 1].as<unsigned char>(), m, n, prm->win_w,
-                                         prm->win_h, prm->max_level, &pyr)) {
-      (void)psh::side_end();
-      return rc;
-    }
+    // the pyramids only need the uint8 renderings: they are forked onto the side stream right in
+    // front of the ordered corner walk (a single workgroup - the other 255 CUs are free) and joined
+    // before the tracker, which needs both
+    struct Fork {
+      const unsigned char *prev, *next;
+      int m, n, win_w, win_h, max_level;
+      void *pyr;
+      int rc;
+    } fork{trk[t].as<unsigned char>(), trk[t + 1].as<unsigned char>(), m, n, prm->win_w, prm->win_h, prm->max_level,
+           nullptr, PSH_OK};
+    auto build_pyramids = [](void *arg) -> int {
+      Fork *f = static_cast<Fork *>(arg);
+      f->rc = psh::lk_pyramids_beside(f->prev, f->next, f->m, f->n, f->win_w, f->win_h, f->max_level, &f->pyr);
+      return f->rc;
+    };
+    int walk_stats[3] = {0, 0, 0};
     const int rc1 = psh::lk_corners_resident(feat[t].as<unsigned char>(), clean[t].as<float>(),
                                              stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
-                                             prm->quality_level, prm->min_distance, prm->max_corners, d_pts, d_npts);
-    const int rcj = psh::side_end();  // the tracker needs both
-    if (rc1 || rcj) {
-      (void)psh_lk_pyramids_free(pyr);
-      return rc1 ? rc1 : rcj;
+                                             prm->quality_level, prm->min_distance, prm->max_corners, d_pts, d_npts,
+                                             build_pyramids, &fork, trace ? walk_stats : nullptr);
+    const int rcj = psh::side_end();
+    void *pyr = fork.pyr;
+    if (trace)
+      std::fprintf(stderr, "dense_lk corner walk: %d chunk(s), %d candidates, %d ordered batch(es)\n", walk_stats[0],
+                   walk_stats[1], walk_stats[2]);
+    if (rc1 || rcj || fork.rc || !pyr) {
+      if (pyr) (void)psh_lk_pyramids_free(pyr);
+      return fork.rc ? fork.rc : rc1 ? rc1 : rcj ? rcj : psh::fail(PSH_EHIP, "dense_lk: pyramids were not built");
     }
     const int rc2 = psh::lk_track_pool(pyr, nullptr, d_pts, d_npts, prm->max_corners, prm->max_count, prm->epsilon,
                                        prm->min_eig_threshold, d_pxy, d_puv, d_pcnt, capacity_dev);

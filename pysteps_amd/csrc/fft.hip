@@ -157,7 +157,7 @@ template <bool INV>
 __global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__restrict__ in, int m, int nc, int logm,
                                                             int cols, const double2 *__restrict__ tw, double scale,
                                                             double2 *__restrict__ out, int groups,
-                                                            int groups_per_xcd) {
+                                                            int groups_per_xcd, const double *__restrict__ weights) {
   extern __shared__ double2 z[];
   // XCD-contiguous column groups: neighbours share 128-byte lines of every row
   const int b = blockIdx.x;
@@ -168,7 +168,16 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__res
   const int pitch = lds_elems(m);
   for (int idx = threadIdx.x; idx < m * cols; idx += kFftThreads) {
     const int r = idx / cols, c = idx - r * cols;
-    z[c * pitch + lpad(bitrev(r, logm))] = c < live ? in[static_cast<size_t>(r) * nc + c0 + c] : make_double2(0.0, 0.0);
+    double2 v = make_double2(0.0, 0.0);
+    if (c < live) {
+      v = in[static_cast<size_t>(r) * nc + c0 + c];
+      if (weights) {  // spectrum x real filter (band-pass weights, noise filter) applied on the way in
+        const double w = weights[static_cast<size_t>(r) * nc + c0 + c];
+        v.x *= w;
+        v.y *= w;
+      }
+    }
+    z[c * pitch + lpad(bitrev(r, logm))] = v;
   }
   __syncthreads();
   fft_lds<INV>(z, pitch, cols, logm, tw);
@@ -232,7 +241,7 @@ int check_shape(const char *who, int m, int n, int *logm, int *logn) {
 }
 
 int launch_cols(bool inverse, const double2 *in, int m, int nc, int logm, double scale, double2 *out,
-                hipStream_t stream) {
+                hipStream_t stream, const double *weights = nullptr) {
   const double2 *tw = nullptr;
   if (int rc = twiddles(m, &tw)) return rc;
   const int cols = m <= 4096 ? 2 : 1;
@@ -242,11 +251,11 @@ int launch_cols(bool inverse, const double2 *in, int m, int nc, int logm, double
   if (inverse) {
     if (int rc = allow_lds(fft_cols_c2c<true>, lds)) return rc;
     hipLaunchKernelGGL(fft_cols_c2c<true>, dim3(gpx * kNumXcd), dim3(kFftThreads), lds, stream, in, m, nc, logm, cols,
-                       tw, scale, out, groups, gpx);
+                       tw, scale, out, groups, gpx, weights);
   } else {
     if (int rc = allow_lds(fft_cols_c2c<false>, lds)) return rc;
     hipLaunchKernelGGL(fft_cols_c2c<false>, dim3(gpx * kNumXcd), dim3(kFftThreads), lds, stream, in, m, nc, logm, cols,
-                       tw, scale, out, groups, gpx);
+                       tw, scale, out, groups, gpx, weights);
   }
   PSH_HIP(hipGetLastError());
   return PSH_OK;
@@ -277,6 +286,34 @@ extern "C" int psh_fft_rfft2_dev(const double *in_dev, int m, int n, void *out_d
   return psh::launch_cols(false, out, m, n / 2 + 1, logm, 1.0, out, c.stream);
 }
 
+// irfft2(spectrum * weights) -> real (m, n); weights (m, n/2+1) float64 or nullptr; the spectrum is
+// left untouched (the column pass writes into `scratch`, (m, n/2+1) complex128).  Lock held.
+namespace psh {
+int fft_irfft2_weighted(const void *spec_dev, const double *weights_dev, int m, int n, double *out_dev,
+                        void *scratch_dev) {
+  int logm, logn;
+  if (int rc = check_shape("irfft2", m, n, &logm, &logn)) return rc;
+  Context &c = ctx();
+  const int nc = n / 2 + 1;
+  if (int rc = launch_cols(true, static_cast<const double2 *>(spec_dev), m, nc, logm, 1.0,
+                           static_cast<double2 *>(scratch_dev), c.stream, weights_dev))
+    return rc;
+  const double2 *tw = nullptr;
+  if (int rc = twiddles(n, &tw)) return rc;
+  const size_t lds = static_cast<size_t>(lds_elems(n)) * sizeof(double2);
+  if (int rc = allow_lds(fft_rows_c2r, lds)) return rc;
+  hipLaunchKernelGGL(fft_rows_c2r, dim3((m + 1) / 2), dim3(kFftThreads), lds, c.stream,
+                     static_cast<const double2 *>(scratch_dev), m, n, logn, tw,
+                     1.0 / (static_cast<double>(m) * static_cast<double>(n)), out_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+bool fft_shape_supported(int m, int n) {
+  const int lm = ilog2_exact(m), ln = ilog2_exact(n);
+  return lm >= 1 && ln >= 1 && lm <= kFftMaxLog && ln <= kFftMaxLog;
+}
+}  // namespace psh
+
 // numpy.fft.irfft2(X, s=(m, n)) of an (m, n/2+1) complex128 array -> real (m, n) float64; the input is
 // left untouched (the column pass writes into a scratch block)
 extern "C" int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_dev) {
@@ -287,24 +324,9 @@ extern "C" int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_
   psh::Context &c = psh::ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  const int nc = n / 2 + 1;
   void *scratch = nullptr;
-  if (int rc = psh_malloc(&scratch, static_cast<size_t>(m) * nc * sizeof(double2))) return rc;
-  auto run = [&]() -> int {
-    if (int rc = psh::launch_cols(true, static_cast<const double2 *>(in_dev), m, nc, logm, 1.0,
-                                  static_cast<double2 *>(scratch), c.stream))
-      return rc;
-    const double2 *tw = nullptr;
-    if (int rc = psh::twiddles(n, &tw)) return rc;
-    const size_t lds = static_cast<size_t>(psh::lds_elems(n)) * sizeof(double2);
-    if (int rc = psh::allow_lds(psh::fft_rows_c2r, lds)) return rc;
-    hipLaunchKernelGGL(psh::fft_rows_c2r, dim3((m + 1) / 2), dim3(psh::kFftThreads), lds, c.stream,
-                       static_cast<const double2 *>(scratch), m, n, logn, tw,
-                       1.0 / (static_cast<double>(m) * static_cast<double>(n)), out_dev);
-    PSH_HIP(hipGetLastError());
-    return PSH_OK;
-  };
-  const int rc = run();
+  if (int rc = psh_malloc(&scratch, static_cast<size_t>(m) * (n / 2 + 1) * sizeof(double2))) return rc;
+  const int rc = psh::fft_irfft2_weighted(in_dev, nullptr, m, n, out_dev, scratch);
   (void)psh_free(scratch);  // stream-ordered
   return rc;
 }

@@ -1479,7 +1479,8 @@ extern "C++" {
 namespace psh {
 int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_dev, float *stats_dev, int m, int n,
                         int block_size, int buffer_mask, double quality_level, double min_distance, int max_corners,
-                        float *points_dev, int *npoints_dev) {
+                        float *points_dev, int *npoints_dev, int (*before_walk)(void *), void *before_walk_arg,
+                        int *walk_stats_host) {
   if (int rc = check_corner_args(feature_u8_dev, clean_dev, stats_dev, m, n, block_size, max_corners)) return rc;
   if (!points_dev || !npoints_dev) return fail(PSH_EINVAL, "lk_corners: NULL pointer");
   if (!corner_order_supported(m, n, min_distance, max_corners))
@@ -1497,8 +1498,14 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
     const hipError_t e = launch_corner_order(
         reinterpret_cast<const CornerKey *>(base + w.off_raw), reinterpret_cast<const int *>(base + w.off_cnt), w.cap,
         stats_dev + kEigMax, static_cast<float>(quality_level), n, min_distance, max_corners, base + w.off_ord,
-        points_dev, npoints_dev, c.stream);
+        points_dev, npoints_dev, c.stream, before_walk, before_walk_arg);
     if (e != hipSuccess) rc = fail(PSH_EHIP, "corner_order launch failed: %s", hipGetErrorString(e));
+    if (rc == PSH_OK && walk_stats_host) {
+      if (hipMemcpyAsync(walk_stats_host, base + w.off_ord + corner_order_walk_stats_offset(), 3 * sizeof(int),
+                         hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
+          hipStreamSynchronize(c.stream) != hipSuccess)
+        rc = fail(PSH_EHIP, "corner_order statistics copy failed");
+    }
   }
   (void)psh_free(ws);  // the kernels above are queued in front of any reuse
   return rc;

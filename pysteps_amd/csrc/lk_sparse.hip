@@ -24,6 +24,8 @@
 // Both replace host code of earlier versions (a rocPRIM sort + host pass, psh_decluster_host);
 // results are bit-identical to those (tests/test_lk_gpu.py compares against the host entry
 // points and the oracle).
+#include <cstddef>
+
 #include "common.h"
 
 namespace psh {
@@ -124,7 +126,7 @@ struct OrderHeader {
   int count[kHeadSegs];            // their numbers
   int fill[kHeadSegs];             // reservation counters of corner_gather
   int nseg;                        // segments that are valid; the walk selects further chunks itself
-  int pad[3];
+  int walk[3];                     // written by corner_order: chunks taken, candidates in them, ordered batches
 };
 
 constexpr int kPreThreads = 256;
@@ -190,8 +192,9 @@ __global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__
     const int prev = s_cut[sgm], base = s_suffix[prev];
     if (tid == 0) s_cut[sgm + 1] = prev;
     __syncthreads();
+    // bins [c, prev) fit for every c from some bin on: the thread that sees the change stores it
     for (int c = tid; c < prev; c += kPreThreads)
-      if (s_suffix[c] - base <= kChunkCap) atomicMin(&s_cut[sgm + 1], c);
+      if (s_suffix[c] - base <= kChunkCap && (c == 0 || s_suffix[c - 1] - base > kChunkCap)) s_cut[sgm + 1] = c;
     __syncthreads();
     if (s_cut[sgm + 1] == prev) break;  // the next bin alone overfills a chunk: the walk refines it
     nseg = sgm + 1;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
                                                             const int *__restrict__ raw_count, int cap,
                                                             const float *__restrict__ eig_max, float quality,
                                                             const CornerKey *__restrict__ head,
-                                                            const OrderHeader *__restrict__ hdr, int n, int cell,
+                                                            OrderHeader *__restrict__ hdr, int n, int cell,
                                                             unsigned md2_ceil, int use_grid, int max_corners,
                                                             float2 *__restrict__ points, int *__restrict__ npoints) {
   __shared__ CornerKey s_keys[kChunkCap];
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
   }
   int nacc = 0;
   int remaining = nkeys;
+  int st_chunks = 0, st_walked = 0, st_batches = 0;  // statistics of the walk (PYSTEPS_HIP_TRACE)
   const int head_segs = hdr != nullptr ? min(max(hdr->nseg, 0), kHeadSegs) : 0;
   int seg = 0;
   __syncthreads();
@@ -394,6 +398,8 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       __syncthreads();
       continue;
     }
+    ++st_chunks;
+    st_walked += cnt;
     const int p2 = next_pow2(cnt);
     for (int i = cnt + tid; i < p2; i += kOrdThreads) s_keys[i] = 0ull;  // sorts behind every real key
     __syncthreads();
@@ -453,6 +459,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       }
       const int nsurv = s_nsurv;
     for (int b0 = 0; b0 < nsurv && nacc < max_corners; b0 += 64) {
+      ++st_batches;
       const bool valid = b0 + lane < nsurv;
       const int i = valid ? s_surv[b0 + lane] : 0;
       const unsigned xy = valid ? s_xy[i] : 0u, cl = valid ? s_cl[i] : 0u;
@@ -555,7 +562,14 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
     upper = T;
     __syncthreads();
   }
-  if (tid == 0) *npoints = nacc;
+  if (tid == 0) {
+    *npoints = nacc;
+    if (hdr) {
+      hdr->walk[0] = st_chunks;
+      hdr->walk[1] = st_walked;
+      hdr->walk[2] = st_batches;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -759,6 +773,8 @@ constexpr size_t kOrdOffHead = kOrdOffHdr + 128;
 static_assert(sizeof(OrderHeader) <= 128, "header slot");
 size_t corner_order_ws_bytes() { return kOrdOffHead + static_cast<size_t>(kHeadSegs) * kChunkCap * sizeof(CornerKey); }
 
+size_t corner_order_walk_stats_offset() { return kOrdOffHdr + offsetof(OrderHeader, walk); }
+
 bool corner_order_supported(int m, int n, double min_distance, int max_corners) {
   // LDS list of accepted corners, 16-bit coordinates, squared distances of neighbouring cells in 32 bits
   return max_corners <= kMaxCornersDev && m <= 65535 && n <= 65535 && min_distance < 16383.0;
@@ -767,7 +783,7 @@ bool corner_order_supported(int m, int n, double min_distance, int max_corners) 
 hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw_count_dev, int cap,
                                const float *eig_max_dev, float quality, int n, double min_distance,
                                int max_corners, void *ws_dev, float *points_dev, int *npoints_dev,
-                               hipStream_t stream) {
+                               hipStream_t stream, int (*before_walk)(void *), void *before_walk_arg) {
   const int cell = static_cast<int>(std::lrint(min_distance)) > 1 ? static_cast<int>(std::lrint(min_distance)) : 1;
   const double md2 = std::ceil(min_distance * min_distance);
   const unsigned md2_ceil = md2 >= 2147483647.0 ? 2147483647u : static_cast<unsigned>(md2);
@@ -783,6 +799,8 @@ hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw
                      quality, hist);
   hipLaunchKernelGGL(corner_gather, dim3(groups), dim3(kPreThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
                      quality, hist, head, hdr);
+  // the walk is a single workgroup: whatever the caller can run beside it is forked off here
+  if (before_walk != nullptr && before_walk(before_walk_arg) != 0) return hipErrorUnknown;
   hipLaunchKernelGGL(corner_order, dim3(1), dim3(kOrdThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
                      quality, head, hdr, n, cell, md2_ceil, min_distance >= 1.0 ? 1 : 0, max_corners,
                      reinterpret_cast<float2 *>(points_dev), npoints_dev);
@@ -839,7 +857,7 @@ extern "C" int psh_lk_order_host(const unsigned long long *keys_host, int count,
     PSH_HIP(hipStreamSynchronize(c.stream));  // hdr lives on this stack frame
     PSH_HIP(psh::launch_corner_order(d_keys, d_hdr, count, reinterpret_cast<const float *>(d_hdr + 2),
                                      static_cast<float>(quality_level), n, min_distance, max_corners, d_ws, d_pts,
-                                     d_hdr + 1, c.stream));
+                                     d_hdr + 1, c.stream, nullptr, nullptr));
     int accepted = 0;
     PSH_HIP(hipMemcpyAsync(&accepted, d_hdr + 1, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));

