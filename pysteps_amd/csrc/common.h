@@ -163,7 +163,8 @@ int lk_track_pool(void *pyramid_handle, const float *points_host, const float *p
 // on the library stream and in device memory (lk.hip): points_dev holds max_corners (x, y) pairs
 // before_walk (may be NULL) is called once everything up to the ordered walk is queued: the walk
 // is a single workgroup, so independent work forked there (side_begin) runs beside it.
-// walk_stats_host (may be NULL): waits for the stream and returns {chunks, candidates, batches} of the walk.
+// walk_stats_host (may be NULL, else int[9]): waits for the stream and returns {chunks, candidates, batches}
+// of the walk and the microseconds it spent {loading, sorting, on coordinates, in block tests, in batches, in all}.
 int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_dev, float *stats_dev, int m, int n,
                         int block_size, int buffer_mask, double quality_level, double min_distance, int max_corners,
                         float *points_dev, int *npoints_dev, int (*before_walk)(void *) = nullptr,

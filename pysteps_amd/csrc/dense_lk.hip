@@ -114,7 +114,7 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
       f->rc = psh::lk_pyramids_beside(f->prev, f->next, f->m, f->n, f->win_w, f->win_h, f->max_level, &f->pyr);
       return f->rc;
     };
-    int walk_stats[3] = {0, 0, 0};
+    int walk_stats[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int rc1 = psh::lk_corners_resident(feat[t].as<unsigned char>(), clean[t].as<float>(),
                                              stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
                                              prm->quality_level, prm->min_distance, prm->max_corners, d_pts, d_npts,
@@ -122,8 +122,11 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
     const int rcj = psh::side_end();
     void *pyr = fork.pyr;
     if (trace)
-      std::fprintf(stderr, "dense_lk corner walk: %d chunk(s), %d candidates, %d ordered batch(es)\n", walk_stats[0],
-                   walk_stats[1], walk_stats[2]);
+      std::fprintf(stderr,
+                   "dense_lk corner walk: %d chunk(s), %d candidates, %d ordered batch(es); us: load %d sort %d "
+                   "coordinates %d block tests %d batches %d total %d\n",
+                   walk_stats[0], walk_stats[1], walk_stats[2], walk_stats[3], walk_stats[4], walk_stats[5],
+                   walk_stats[6], walk_stats[7], walk_stats[8]);
     if (rc1 || rcj || fork.rc || !pyr) {
       if (pyr) (void)psh_lk_pyramids_free(pyr);
       return fork.rc ? fork.rc : rc1 ? rc1 : rcj ? rcj : psh::fail(PSH_EHIP, "dense_lk: pyramids were not built");

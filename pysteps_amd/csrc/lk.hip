@@ -1501,7 +1501,7 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
         points_dev, npoints_dev, c.stream, before_walk, before_walk_arg);
     if (e != hipSuccess) rc = fail(PSH_EHIP, "corner_order launch failed: %s", hipGetErrorString(e));
     if (rc == PSH_OK && walk_stats_host) {
-      if (hipMemcpyAsync(walk_stats_host, base + w.off_ord + corner_order_walk_stats_offset(), 3 * sizeof(int),
+      if (hipMemcpyAsync(walk_stats_host, base + w.off_ord + corner_order_walk_stats_offset(), 9 * sizeof(int),
                          hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
           hipStreamSynchronize(c.stream) != hipSuccess)
         rc = fail(PSH_EHIP, "corner_order statistics copy failed");

@@ -42,8 +42,12 @@ constexpr int kMaxCornersDev = 2048;  // accepted corners kept in LDS
 constexpr int kHashSlots = 4096;      // cell -> chain of accepted corners (open addressing, load <= 1/2)
 constexpr unsigned kNoCell = 0xffffffffu;
 
-// descending (DESC) or ascending bitonic sort of the first `p2` (power of two, >= 2) LDS entries;
-// a thread owns whole compare-exchange pairs (p2 / 2 of them per step)
+// descending (DESC) or ascending bitonic sort of the first `p2` (power of two, >= 128) LDS entries;
+// a thread owns whole compare-exchange pairs (p2 / 2 of them per step).  Steps with a partner
+// distance j <= 64 stay inside the 128 consecutive entries a WAVE owns (threads t and t + 64 q map
+// to the same 128-entry block), so they only need the wave's own LDS ordering; a workgroup barrier
+// is needed only where the next step reads entries another wave wrote (15 of the 78 steps at 4096
+// entries - a barrier-separated phase of 16 waves costs ~0.5 us here, the rest ~0.15 us).
 template <bool DESC>
 __device__ __forceinline__ void bitonic_sort_lds(unsigned long long *keys, int p2) {
   for (int k = 2; k <= p2; k <<= 1) {
@@ -57,13 +61,21 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned long long *keys, int p
           keys[o] = a;
         }
       }
-      __syncthreads();
+      // next step: j / 2, or k (the first step of the next stage) after j == 1
+      const int next_j = j > 1 ? (j >> 1) : k;
+      if (j > 64 || next_j > 64 || (k == p2 && j == 1)) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
     }
   }
 }
 
 __device__ __forceinline__ int next_pow2(int v) {
-  int p = 64;
+  int p = 128;
   while (p < v) p <<= 1;
   return p;
 }
@@ -127,6 +139,7 @@ struct OrderHeader {
   int fill[kHeadSegs];             // reservation counters of corner_gather
   int nseg;                        // segments that are valid; the walk selects further chunks itself
   int walk[3];                     // written by corner_order: chunks taken, candidates in them, ordered batches
+  int phase_us[6];                 // ... and where its time went: load, sort, coordinates, block tests, batches, total
 };
 
 constexpr int kPreThreads = 256;
@@ -309,6 +322,14 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
   int nacc = 0;
   int remaining = nkeys;
   int st_chunks = 0, st_walked = 0, st_batches = 0;  // statistics of the walk (PYSTEPS_HIP_TRACE)
+  long long tk_load = 0, tk_sort = 0, tk_xy = 0, tk_test = 0, tk_batch = 0;  // 100 MHz ticks per phase
+  const long long tk_start = wall_clock64();
+  long long tk_mark = tk_start;
+  auto lap = [&](long long &acc) {
+    const long long now = wall_clock64();
+    acc += now - tk_mark;
+    tk_mark = now;
+  };
   const int head_segs = hdr != nullptr ? min(max(hdr->nseg, 0), kHeadSegs) : 0;
   int seg = 0;
   __syncthreads();
@@ -400,10 +421,12 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
     }
     ++st_chunks;
     st_walked += cnt;
+    lap(tk_load);
     const int p2 = next_pow2(cnt);
     for (int i = cnt + tid; i < p2; i += kOrdThreads) s_keys[i] = 0ull;  // sorts behind every real key
     __syncthreads();
     bitonic_sort_lds<true>(s_keys, p2);
+    lap(tk_sort);
     for (int i = tid; i < cnt; i += kOrdThreads) {
       const unsigned addr = static_cast<unsigned>(s_keys[i] & 0xffffffffull);
       const unsigned px = addr % static_cast<unsigned>(n), py = addr / static_cast<unsigned>(n);
@@ -411,6 +434,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       s_cl[i] = (px / static_cast<unsigned>(cell)) | ((py / static_cast<unsigned>(cell)) << 16);
     }
     __syncthreads();
+    lap(tk_xy);
     // ---- walk the chunk: 1024 candidates at a time are first tested against the corners accepted
     // so far by all 16 waves at once (late in the walk that removes most of them), the survivors are
     // then decided in order in batches of 64 ----------------------------------------------------------
@@ -458,6 +482,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
         __syncthreads();
       }
       const int nsurv = s_nsurv;
+      lap(tk_test);
     for (int b0 = 0; b0 < nsurv && nacc < max_corners; b0 += 64) {
       ++st_batches;
       const bool valid = b0 + lane < nsurv;
@@ -556,6 +581,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       __syncthreads();
       nacc = s_nacc;
     }
+      lap(tk_batch);
     }
     remaining -= cnt;
     if (T <= key_lo) break;  // the chunk reached the bottom of the key range
@@ -568,6 +594,8 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       hdr->walk[0] = st_chunks;
       hdr->walk[1] = st_walked;
       hdr->walk[2] = st_batches;
+      const long long tk[6] = {tk_load, tk_sort, tk_xy, tk_test, tk_batch, wall_clock64() - tk_start};
+      for (int q = 0; q < 6; ++q) hdr->phase_us[q] = static_cast<int>(tk[q] / 100);
     }
   }
 }
@@ -771,6 +799,7 @@ int corner_order_max_corners() { return kMaxCornersDev; }
 constexpr size_t kOrdOffHdr = kOrdBins * sizeof(int);
 constexpr size_t kOrdOffHead = kOrdOffHdr + 128;
 static_assert(sizeof(OrderHeader) <= 128, "header slot");
+static_assert(offsetof(OrderHeader, phase_us) == offsetof(OrderHeader, walk) + 3 * sizeof(int), "walk statistics are one int[9]");
 size_t corner_order_ws_bytes() { return kOrdOffHead + static_cast<size_t>(kHeadSegs) * kChunkCap * sizeof(CornerKey); }
 
 size_t corner_order_walk_stats_offset() { return kOrdOffHdr + offsetof(OrderHeader, walk); }
