@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--no-lk", action="store_true", help="time the extrapolator only (true velocity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the NumPy-in / NumPy-out leg")
+    ap.add_argument("--no-spectral", action="store_true", help="skip the FFT / cascade decomposition leg")
     ap.add_argument("--force-members-path", action="store_true",
                     help="run the N > 1 code path (RCCL communicator, broadcast, member shard) at any world size")
     ap.add_argument("--no-members-leg", action="store_true", help="skip the config-4 single-GPU reference leg")
@@ -348,6 +349,65 @@ def members_workload(precip_d, vel_d, n_members, first_member, n_total, T, K):
     return step
 
 
+def spectral_leg(m, n):
+    """SURVEY 8f rank 3 (first pieces): what the STEPS member loop calls per member and lead time -
+    the FFT method object and the cascade decomposition - resident on the device (HIP events) with
+    numpy's pocketfft timed once beside it.  Reported under config, not part of `value`."""
+    from pysteps_amd.device import DeviceArray, Event, synchronize
+    from pysteps_amd.utils.fft import get_hip, supported_shape
+
+    if not supported_shape((m, n)):
+        return {}
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((m, n))
+    fft = get_hip((m, n))
+    dx = DeviceArray.from_host(x)
+    dX = fft.rfft2(dx)
+    fft.irfft2(dX)
+    synchronize()
+    reps = 5
+    e0, e1, e2 = Event(), Event(), Event()
+    e0.record()
+    for _ in range(reps):
+        dX = fft.rfft2(dx)
+    e1.record()
+    for _ in range(reps):
+        fft.irfft2(dX)
+    e2.record()
+    synchronize()
+    fwd, inv = e0.elapsed_ms(e1) / reps, e1.elapsed_ms(e2) / reps
+    t = time.perf_counter()
+    np.fft.rfft2(x)
+    cpu = (time.perf_counter() - t) * 1e3
+    # compulsory traffic of the two-pass transform: real plane in, half spectrum out, in and out again
+    spec = m * (n // 2 + 1) * 16
+    traffic = m * n * 8 + 3 * spec
+    out = {"rfft2_ms": fwd, "irfft2_ms": inv, "rfft2_hbm_frac": traffic / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "numpy_rfft2_ms": cpu, "dtype": "f64"}
+    try:
+        from pysteps_amd.cascade import decomposition_fft
+
+        nlev = 8
+        # Gaussian-shaped band weights of the reference's form (levels, m, n/2+1); their values do not
+        # change the work
+        ky, kx = np.fft.fftfreq(m)[:, None], np.fft.rfftfreq(n)[None, :]
+        r = np.hypot(ky, kx)
+        centres = 0.5 * 2.0 ** -np.arange(nlev)[::-1]
+        w = np.stack([np.exp(-0.5 * ((np.log2(r + 1e-9) - np.log2(c)) / 0.6) ** 2) for c in centres])
+        bp = {"weights_2d": w / w.sum(axis=0, keepdims=True), "weights_1d": np.zeros((nlev, 1)), "shape": (m, n)}
+        decomposition_fft(dx, bp, normalize=True, compute_stats=True)  # uploads and caches the weights
+        synchronize()
+        e3, e4 = Event(), Event()
+        e3.record()
+        decomposition_fft(dx, bp, normalize=True, compute_stats=True)
+        e4.record()
+        synchronize()
+        out["cascade_decompose_%d_levels_ms" % nlev] = e3.elapsed_ms(e4)
+    except Exception as exc:  # the spectral leg never takes the headline down
+        out["cascade_note"] = "%s: %s" % (type(exc).__name__, exc)
+    return out
+
+
 def time_steps(step, dist, steps, warmup, events=None):
     from pysteps_amd.device import synchronize
 
@@ -476,6 +536,8 @@ def main():
         line["roofline_lk"] = roofline_lk(frames_d, m, n, args.frames - 1)
     if not args.no_host_path:
         line["config"].update(host_path(frames_d, vel_d, T, K))
+    if not args.no_spectral:
+        line["config"]["spectral"] = spectral_leg(m, n)
     if not args.no_members_leg:
         # what ONE GPU of the N > 1 runs does (config 4: members_per_gpu members, T single-step
         # stateful calls): the single-GPU figure the multi-GPU values are to be compared with

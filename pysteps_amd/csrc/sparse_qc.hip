@@ -24,13 +24,34 @@ namespace {
 
 constexpr int kQcMaxN = 8192;  // LDS keys: 8 B per vector (64 KiB)
 
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const unsigned long long o = __shfl_xor(v, d);
-    v = o < v ? o : v;
+// Wave-wide minimum of a 32-bit unsigned value in six DPP steps (pure VALU: a __shfl_xor goes
+// through the LDS crossbar and costs ~100 clk each, twelve of them per 64-bit step): xor-1 / xor-2
+// inside the quads, half-mirror and mirror inside each row of 16, row_bcast15 / row_bcast31 across
+// the rows; lane 63 then holds the minimum, which is broadcast through an SGPR.
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define PSH_MIN_STEP(CTRL, ROWMASK)                                                                       \
+  {                                                                                                        \
+    const unsigned o = static_cast<unsigned>(                                                              \
+        __builtin_amdgcn_update_dpp(static_cast<int>(v), static_cast<int>(v), CTRL, ROWMASK, 0xf, false)); \
+    v = o < v ? o : v;                                                                                     \
   }
-  return v;
+  PSH_MIN_STEP(0xB1, 0xf)   // quad_perm:[1,0,3,2]
+  PSH_MIN_STEP(0x4E, 0xf)   // quad_perm:[2,3,0,1]
+  PSH_MIN_STEP(0x141, 0xf)  // row_half_mirror
+  PSH_MIN_STEP(0x140, 0xf)  // row_mirror
+  PSH_MIN_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1 and 3
+  PSH_MIN_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2 and 3
+#undef PSH_MIN_STEP
+  return static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
+// lexicographic minimum of (distance bits << 32 | index) keys: the smallest distance first, then
+// the smallest index among the lanes that hold it
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+  const unsigned hi = static_cast<unsigned>(v >> 32), lo = static_cast<unsigned>(v);
+  const unsigned m_hi = wave_min_u32(hi);
+  const unsigned m_lo = wave_min_u32(hi == m_hi ? lo : 0xffffffffu);
+  return (static_cast<unsigned long long>(m_hi) << 32) | m_lo;
 }
 
 __global__ __launch_bounds__(64) void outliers_local(const double2 *__restrict__ xy,

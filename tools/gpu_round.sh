@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q ${2:-} 2>&1 | tail -8 | tee $OUT/pytest_gpu.txt
 timeout 600 python bench.py --steps 10 --warmup 3 2>$OUT/bench.err | tee $OUT/bench.json
-BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-members-leg"
+BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-members-leg --no-spectral"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
