@@ -180,7 +180,9 @@ size_t corner_order_ws_bytes();  // device scratch of one ordering (histogram, h
 hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw_count_dev, int cap,
                                const float *eig_max_dev, float quality, int n, double min_distance,
                                int max_corners, void *ws_dev, float *points_dev, int *npoints_dev,
-                               hipStream_t stream, int (*before_walk)(void *), void *before_walk_arg);
+                               hipStream_t stream, int (*before_walk)(void *), void *before_walk_arg,
+                               bool ws_is_cleared);
+size_t corner_order_clear_bytes();  // leading bytes of the workspace that have to be zero (histogram, header)
 size_t corner_order_walk_stats_offset();  // byte offset of the int[3] walk statistics inside the workspace
 hipError_t launch_vectors_finish(const double *pool_xy_dev, const double *pool_uv_dev,
                                  const unsigned char *flags_dev, const int *pool_count_dev, int capacity,

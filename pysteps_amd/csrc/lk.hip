@@ -495,10 +495,15 @@ __global__ __launch_bounds__(256) void lk_corner_response(
         fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// (zero_a / zero_b: counters and scratch the NEXT kernels expect cleared - done here, by a kernel
+// that is a single idle-ish block anyway, instead of one 5 us fill launch each)
 __global__ __launch_bounds__(kFinalThreads) void lk_max_final(const float *__restrict__ partial,
                                                               int nb, float *__restrict__ stats,
-                                                              int slot) {
+                                                              int slot, int *__restrict__ zero_a, int count_a,
+                                                              int *__restrict__ zero_b, int count_b) {
   __shared__ float smem[16];
+  for (int i = threadIdx.x; i < count_a; i += blockDim.x) zero_a[i] = 0;
+  for (int i = threadIdx.x; i < count_b; i += blockDim.x) zero_b[i] = 0;
   float a = -INFINITY;
   for (int i = threadIdx.x; i < nb; i += blockDim.x) a = fmaxf(a, partial[i]);
   a = block_reduce<Red::kMax>(a, smem);
@@ -1311,7 +1316,7 @@ int psh_lk_band_response_dev(const unsigned char *feature_u8_dev, const float *c
   }
 #undef PSH_CRN_LAUNCH
   hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb, stats_dev,
-                     static_cast<int>(psh::kEigMax));
+                     static_cast<int>(psh::kEigMax), static_cast<int *>(nullptr), 0, static_cast<int *>(nullptr), 0);
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }
@@ -1452,9 +1457,10 @@ int corner_candidates(const CornerWs &w, void *ws, const unsigned char *feature_
     PSH_CRN_LAUNCH(7);
   }
 #undef PSH_CRN_LAUNCH
+  // the candidate counter and the ordering scratch (histogram + header) are cleared by the same launch
   hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, w.nb, stats_dev,
-                     static_cast<int>(psh::kEigMax));
-  PSH_HIP(hipMemsetAsync(cnt, 0, sizeof(int), c.stream));
+                     static_cast<int>(psh::kEigMax), cnt, 1, reinterpret_cast<int *>(base + w.off_ord),
+                     static_cast<int>(psh::corner_order_clear_bytes() / sizeof(int)));
   const dim3 sgrid((n + 63) / 64, (m + psh::kSelRows - 1) / psh::kSelRows);
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n, buffer_mask,
                      static_cast<float>(quality_level), stats_dev, raw, w.cap, cnt, psh::Band{0, 0, m});
@@ -1498,7 +1504,7 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
     const hipError_t e = launch_corner_order(
         reinterpret_cast<const CornerKey *>(base + w.off_raw), reinterpret_cast<const int *>(base + w.off_cnt), w.cap,
         stats_dev + kEigMax, static_cast<float>(quality_level), n, min_distance, max_corners, base + w.off_ord,
-        points_dev, npoints_dev, c.stream, before_walk, before_walk_arg);
+        points_dev, npoints_dev, c.stream, before_walk, before_walk_arg, /*ws_is_cleared=*/true);
     if (e != hipSuccess) rc = fail(PSH_EHIP, "corner_order launch failed: %s", hipGetErrorString(e));
     if (rc == PSH_OK && walk_stats_host) {
       if (hipMemcpyAsync(walk_stats_host, base + w.off_ord + corner_order_walk_stats_offset(), 9 * sizeof(int),

@@ -802,6 +802,7 @@ static_assert(sizeof(OrderHeader) <= 128, "header slot");
 static_assert(offsetof(OrderHeader, phase_us) == offsetof(OrderHeader, walk) + 3 * sizeof(int), "walk statistics are one int[9]");
 size_t corner_order_ws_bytes() { return kOrdOffHead + static_cast<size_t>(kHeadSegs) * kChunkCap * sizeof(CornerKey); }
 
+size_t corner_order_clear_bytes() { return kOrdOffHead; }
 size_t corner_order_walk_stats_offset() { return kOrdOffHdr + offsetof(OrderHeader, walk); }
 
 bool corner_order_supported(int m, int n, double min_distance, int max_corners) {
@@ -812,7 +813,8 @@ bool corner_order_supported(int m, int n, double min_distance, int max_corners) 
 hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw_count_dev, int cap,
                                const float *eig_max_dev, float quality, int n, double min_distance,
                                int max_corners, void *ws_dev, float *points_dev, int *npoints_dev,
-                               hipStream_t stream, int (*before_walk)(void *), void *before_walk_arg) {
+                               hipStream_t stream, int (*before_walk)(void *), void *before_walk_arg,
+                               bool ws_is_cleared) {
   const int cell = static_cast<int>(std::lrint(min_distance)) > 1 ? static_cast<int>(std::lrint(min_distance)) : 1;
   const double md2 = std::ceil(min_distance * min_distance);
   const unsigned md2_ceil = md2 >= 2147483647.0 ? 2147483647u : static_cast<unsigned>(md2);
@@ -820,8 +822,10 @@ hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw
   int *hist = reinterpret_cast<int *>(ws);
   OrderHeader *hdr = reinterpret_cast<OrderHeader *>(ws + kOrdOffHdr);
   CornerKey *head = reinterpret_cast<CornerKey *>(ws + kOrdOffHead);
-  hipError_t e = hipMemsetAsync(ws, 0, kOrdOffHead, stream);
-  if (e != hipSuccess) return e;
+  if (!ws_is_cleared) {  // (the corner entry points clear it from lk_max_final)
+    const hipError_t e = hipMemsetAsync(ws, 0, kOrdOffHead, stream);
+    if (e != hipSuccess) return e;
+  }
   // the list is streamed by up to 128 workgroups (its length is only known on the device)
   const int groups = std::max(1, std::min(128, (cap + 4 * kPreThreads - 1) / (4 * kPreThreads)));
   hipLaunchKernelGGL(corner_hist, dim3(groups), dim3(kPreThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
@@ -886,7 +890,7 @@ extern "C" int psh_lk_order_host(const unsigned long long *keys_host, int count,
     PSH_HIP(hipStreamSynchronize(c.stream));  // hdr lives on this stack frame
     PSH_HIP(psh::launch_corner_order(d_keys, d_hdr, count, reinterpret_cast<const float *>(d_hdr + 2),
                                      static_cast<float>(quality_level), n, min_distance, max_corners, d_ws, d_pts,
-                                     d_hdr + 1, c.stream, nullptr, nullptr));
+                                     d_hdr + 1, c.stream, nullptr, nullptr, false));
     int accepted = 0;
     PSH_HIP(hipMemcpyAsync(&accepted, d_hdr + 1, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));
