@@ -13,7 +13,8 @@ float64 ndarray like the reference) or a float32
 :class:`pysteps_amd.device.DeviceArray` (result stays in HBM as float32).
 
 Only the reference's default detector/interpolator pair is implemented natively
-(``fd_method="shitomasi"``, ``interp_method="idwinterp2d"``); other choices are
+(``fd_method="shitomasi"``, ``interp_method="idwinterp2d"``; any other ``interp_method`` gets the
+HIP sparse stage followed by the reference's interpolation function); other choices are
 delegated to the reference when pysteps is importable, else NotImplementedError.
 """
 
@@ -221,6 +222,39 @@ def _reference_dense_lk():
     return None if ref is dense_lucaskanade else ref
 
 
+def _dense_with_reference_interpolator(input_images, lk_kwargs, fd_kwargs, interp_method, interp_kwargs,
+                                       nr_std_outlier, k_outlier, size_opening, decl_scale, verbose):
+    """Another interpolation method (``"rbfinterp2d"``, pysteps/utils/interpolate.py:117-170, wraps
+    scipy.interpolate.Rbf): the sparse stage - features, tracking, outlier removal - runs on the HIP
+    path, the vectors are declustered here and handed to the reference's interpolation function
+    looked up by name, exactly as pysteps/motion/lucaskanade.py:199,264-274 does."""
+    if isinstance(input_images, DeviceArray):
+        raise NotImplementedError(
+            "pysteps_amd dense_lucaskanade: interp_method=%r returns a host array; pass NumPy frames" % (interp_method,)
+        )
+    try:
+        from pysteps import utils as ref_utils  # noqa: PLC0415
+    except Exception as exc:
+        raise NotImplementedError(
+            "pysteps_amd dense_lucaskanade: interp_method=%r needs pysteps' interpolation functions" % (interp_method,)
+        ) from exc
+    interpolation_method = ref_utils.get_method(interp_method)  # ValueError for unknown names, as the reference
+    xy, uv = dense_lucaskanade(
+        input_images, lk_kwargs, "shitomasi", fd_kwargs, "idwinterp2d", None, False, nr_std_outlier, k_outlier,
+        size_opening, decl_scale, verbose,
+    )
+    domain_size = input_images.shape[1:]
+    if xy.shape[0] == 0:  # lucaskanade.py:245-249
+        return np.zeros((2, domain_size[0], domain_size[1]))
+    if decl_scale > 1:  # :264-265
+        xy, uv = decluster(xy, uv, decl_scale, 1, verbose)
+    if xy.shape[0] == 0:  # :268-269
+        return np.zeros((2, domain_size[0], domain_size[1]))
+    xgrid = np.arange(domain_size[1])
+    ygrid = np.arange(domain_size[0])
+    return interpolation_method(xy, uv, xgrid, ygrid, **interp_kwargs)  # :272-274
+
+
 def _frames_to_device(input_images):
     if isinstance(input_images, DeviceArray):
         if input_images.dtype != np.float32:
@@ -267,8 +301,6 @@ def dense_lucaskanade(
     unsupported = None
     if fd_method != "shitomasi":
         unsupported = "fd_method=%r" % (fd_method,)
-    elif interp_method != "idwinterp2d":
-        unsupported = "interp_method=%r" % (interp_method,)
     elif fd_kwargs.get("use_harris", False):
         unsupported = "use_harris=True"
     elif lk_kwargs.get("flags", 0) != 0:
@@ -299,6 +331,12 @@ def dense_lucaskanade(
         warnings.warn("pysteps_amd dense_lucaskanade: %s -> delegating to the reference CPU path" % unsupported)
         return ref(input_images, lk_kwargs, fd_method, fd_kwargs, interp_method, interp_kwargs,
                    dense, nr_std_outlier, k_outlier, size_opening, decl_scale, verbose)
+
+    if dense and interp_method != "idwinterp2d":
+        return _dense_with_reference_interpolator(
+            input_images, lk_kwargs, fd_kwargs, interp_method, interp_kwargs, nr_std_outlier, k_outlier,
+            size_opening, decl_scale, verbose,
+        )
 
     if verbose:
         print("Computing the motion field with the Lucas-Kanade method.")

@@ -470,3 +470,27 @@ def test_other_feature_detectors_are_delegated(dense_lk, fd_method):
         missing = NotImplementedError
     with pytest.raises((NotImplementedError, ImportError, ModuleNotFoundError, missing)):
         dense_lk(frames, fd_method=fd_method)
+
+
+def test_other_interpolation_method_runs_on_the_hip_sparse_stage(dense_lk, ref_pysteps):
+    """interp_method="rbfinterp2d" (SURVEY 8a row a12): features, tracking and outlier removal on the
+    HIP path, declustering + the reference's own interpolation function (scipy.interpolate.Rbf behind
+    pysteps/utils/interpolate.py:117-170) afterwards, as pysteps/motion/lucaskanade.py:264-274."""
+    from pysteps.utils.cleansing import decluster as ref_decluster
+    from pysteps.utils.interpolate import rbfinterp2d
+
+    m = n = 192
+    frames, vel = _advected_frames(m, n, 2, seed=8)
+    got = dense_lk(frames, interp_method="rbfinterp2d", interp_kwargs={"epsilon": 5.0})
+    assert got.shape == (2, m, n) and got.dtype == np.float64
+    xy, uv = dense_lk(frames, dense=False)
+    dxy, duv = ref_decluster(xy, uv, 20, 1)
+    want = rbfinterp2d(dxy, duv, np.arange(n), np.arange(m), epsilon=5.0)
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    inner = (slice(None), slice(m // 4, 3 * m // 4), slice(n // 4, 3 * n // 4))
+    assert np.sqrt(np.mean((got - vel)[inner] ** 2)) < 1.0
+    with pytest.raises(ValueError):
+        dense_lk(frames, interp_method="no_such_interpolator")
+    # nothing to interpolate -> zero field, whatever the method
+    flat = np.zeros((2, 64, 64), dtype=np.float32)
+    assert not dense_lk(flat, interp_method="rbfinterp2d").any()
