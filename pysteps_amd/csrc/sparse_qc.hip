@@ -98,7 +98,15 @@ __global__ __launch_bounds__(64) void outliers_local(const double2 *__restrict__
       if ((j & 63) == lane) {  // owner retires the key and rescans its entries
         keys[j] = kGone;
         best = kGone;
-        for (int q = lane; q < n; q += 64) best = keys[q] < best ? keys[q] : best;
+        // eight LDS reads in flight at a time: a single lane is active here, so the rescan is pure
+        // latency (one read after the other cost 16 x ~100 clk per extraction at 1000 vectors)
+        for (int q0 = lane; q0 < n; q0 += 8 * 64) {
+          unsigned long long v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = q0 + u * 64 < n ? keys[q0 + u * 64] : kGone;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) best = v[u] < best ? v[u] : best;
+        }
       }
     }
     if (lane < tn) {
