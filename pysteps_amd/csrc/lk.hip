@@ -397,6 +397,23 @@ __device__ __forceinline__ bool px_allowed(const float *__restrict__ clean, int 
 // box stage start 16-byte aligned (ds_read_b128)
 constexpr int kCrnPitch = (kCrnTX + 2 * kMaxBlockR + 3) & ~3;
 
+// Sobel derivatives (ksize 3, scale s folded in as cornerMinEigenVal does) at the centre of a 3x3
+// neighbourhood a[row][col] and their three products.  One definition for both tile paths of the
+// kernel below, so that both evaluate the same expression tree.
+__device__ __forceinline__ void sobel_products(float a00, float a01, float a02, float a10, float a12, float a20,
+                                               float a21, float a22, float s, float &xx, float &xy, float &yy) {
+  const float hx0 = a02 - a00;
+  const float hx1 = a12 - a10;
+  const float hx2 = a22 - a20;
+  const float dx = (hx0 + hx2) * s + hx1 * (2.f * s);
+  const float hy0 = (a00 + a02) * s + a01 * (2.f * s);
+  const float hy2 = (a20 + a22) * s + a21 * (2.f * s);
+  const float dy = hy2 - hy0;
+  xx = dx * dx;
+  xy = dx * dy;
+  yy = dy * dy;
+}
+
 template <int BS>
 __global__ __launch_bounds__(256) void lk_corner_response(
     const unsigned char *__restrict__ u8, const float *__restrict__ clean, int m, int n,
@@ -404,7 +421,7 @@ __global__ __launch_bounds__(256) void lk_corner_response(
     float *__restrict__ partial, Band band) {
   constexpr int H = kMaxBlockR + 1;  // Sobel (1) + box radius (<= 3)
   constexpr int block_size = BS;
-  __shared__ float tile[kCrnTY + 2 * H][kCrnTX + 2 * H];
+  __shared__ __attribute__((aligned(16))) float tile[kCrnTY + 2 * H][kCrnTX + 2 * H];
   __shared__ __attribute__((aligned(16))) float cxx[kCrnTY + 2 * kMaxBlockR][kCrnPitch];
   __shared__ __attribute__((aligned(16))) float cxy[kCrnTY + 2 * kMaxBlockR][kCrnPitch];
   __shared__ __attribute__((aligned(16))) float cyy[kCrnTY + 2 * kMaxBlockR][kCrnPitch];
@@ -413,6 +430,46 @@ __global__ __launch_bounds__(256) void lk_corner_response(
   const int x0 = blockIdx.x * kCrnTX, y0 = blockIdx.y * kCrnTY;
   const int tid = threadIdx.x;
   const float s = 1.0f / (4.0f * static_cast<float>(block_size) * 255.0f);
+  const int rw = kCrnTX + 2 * r, rh = kCrnTY + 2 * r;
+  // Tiles whose haloed footprint lies inside the image (all but the frame of tiles along the
+  // border) need no reflection and no bounds tests: the u8 rows are fetched four pixels per load
+  // and every thread turns a strip of four neighbouring positions into products (the tile taps of
+  // a strip are read once).  Same arithmetic as the general path (sobel_products).
+  const bool interior = (n & 3) == 0 && x0 >= H && y0 >= H && x0 + kCrnTX + H <= n && y0 + kCrnTY + H <= m;
+  if (interior) {
+    constexpr int kTileW = kCrnTX + 2 * H, kTileH = kCrnTY + 2 * H;
+    for (int i = tid; i < kTileH * (kTileW / 4); i += 256) {
+      const int ly = i / (kTileW / 4), c = i % (kTileW / 4);
+      const unsigned w = *reinterpret_cast<const unsigned *>(u8 + static_cast<size_t>(y0 + ly - H) * n + (x0 - H) + 4 * c);
+      *reinterpret_cast<float4 *>(&tile[ly][4 * c]) =
+          make_float4(static_cast<float>(w & 0xffu), static_cast<float>((w >> 8) & 0xffu),
+                      static_cast<float>((w >> 16) & 0xffu), static_cast<float>(w >> 24));
+    }
+    __syncthreads();
+    const int strips = (rw + 3) / 4;
+    for (int i = tid; i < rh * strips; i += 256) {
+      const int ry = i / strips, rx0 = (i % strips) * 4;
+      const int ly = ry - r + H, lxb = rx0 - r + H;  // tile coordinates of the strip's first position
+      float t0[6], t1[6], t2[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const int lx = min(lxb - 1 + c, kTileW - 1);  // (beyond the region's last column: unused)
+        t0[c] = tile[ly - 1][lx];
+        t1[c] = tile[ly][lx];
+        t2[c] = tile[ly + 1][lx];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (rx0 + j < rw) {
+          float xx, xy, yy;
+          sobel_products(t0[j], t0[j + 1], t0[j + 2], t1[j], t1[j + 2], t2[j], t2[j + 1], t2[j + 2], s, xx, xy, yy);
+          cxx[ry][rx0 + j] = xx;
+          cxy[ry][rx0 + j] = xy;
+          cyy[ry][rx0 + j] = yy;
+        }
+      }
+    }
+  } else {
   // u8 tile with reflect-101 image border; covers [x0-H, x0+TX+H)
   for (int i = tid; i < (kCrnTY + 2 * H) * (kCrnTX + 2 * H); i += 256) {
     const int ly = i / (kCrnTX + 2 * H), lx = i % (kCrnTX + 2 * H);
@@ -422,23 +479,16 @@ __global__ __launch_bounds__(256) void lk_corner_response(
   __syncthreads();
   // gradient products on [x0-r, x0+TX+r): positions outside the image take the
   // value of their reflect-101 mirror pixel (boxFilter border), not a mirrored stencil
-  const int rw = kCrnTX + 2 * r, rh = kCrnTY + 2 * r;
   for (int i = tid; i < rw * rh; i += 256) {
     const int ry = i / rw, rx = i % rw;
     // rows/columns more than r beyond the image are never summed by a live pixel
     if (y0 + ry - r > m - 1 + r || x0 + rx - r > n - 1 + r) continue;
     const int y = reflect101(y0 + ry - r, m), x = reflect101(x0 + rx - r, n);
     const int ly = y - y0 + H, lx = x - x0 + H;
-    const float hx0 = tile[ly - 1][lx + 1] - tile[ly - 1][lx - 1];
-    const float hx1 = tile[ly][lx + 1] - tile[ly][lx - 1];
-    const float hx2 = tile[ly + 1][lx + 1] - tile[ly + 1][lx - 1];
-    const float dx = (hx0 + hx2) * s + hx1 * (2.f * s);
-    const float hy0 = (tile[ly - 1][lx - 1] + tile[ly - 1][lx + 1]) * s + tile[ly - 1][lx] * (2.f * s);
-    const float hy2 = (tile[ly + 1][lx - 1] + tile[ly + 1][lx + 1]) * s + tile[ly + 1][lx] * (2.f * s);
-    const float dy = hy2 - hy0;
-    cxx[ry][rx] = dx * dx;
-    cxy[ry][rx] = dx * dy;
-    cyy[ry][rx] = dy * dy;
+    sobel_products(tile[ly - 1][lx - 1], tile[ly - 1][lx], tile[ly - 1][lx + 1], tile[ly][lx - 1], tile[ly][lx + 1],
+                   tile[ly + 1][lx - 1], tile[ly + 1][lx], tile[ly + 1][lx + 1], s, cxx[ry][rx], cxy[ry][rx],
+                   cyy[ry][rx]);
+  }
   }
   __syncthreads();
   float best = 0.f;

@@ -767,7 +767,10 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
   }
   // one or two rows per thread measured equal (1.45 ms at 4096^2 x 24): the kernel is not short of
   // loads in flight
-  if (a.vel_packed != nullptr && a.field_pairs != nullptr && a.order == 1) return launch_variant<1, kModePacked2>(a, stream);
+  if (a.vel_packed != nullptr && a.field_pairs != nullptr && a.order == 1) {
+    if (g_semilag_variant == 6) return launch_variant<2, kModePacked2>(a, stream);  // two rows per lane (experiment)
+    return launch_variant<1, kModePacked2>(a, stream);
+  }
   if (a.vel_packed != nullptr) return launch_variant<1, kModePacked>(a, stream);
   return launch_variant<1, kModeDirect>(a, stream);
 }
@@ -775,13 +778,14 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
 // variant 0 (default) samples the velocity from a packed {u,v} plane when the caller provides one;
 // variant 1 = the one-plane-per-component kernel with DPP column sharing (round 1 default)
 bool semilag_wants_packed(const SemilagArgs &a) {
-  return (g_semilag_variant == 0 || g_semilag_variant == 5) &&
+  return (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 6) &&
          static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29);
 }
 // variant 0 also samples the field from a row-pair plane (one dwordx4 per sample); 5 = packed
 // velocity only (two dwordx2 for the field), kept for comparison
 bool semilag_wants_field_pairs(const SemilagArgs &a) {
-  return g_semilag_variant == 0 && semilag_wants_packed(a) && a.precip != nullptr && a.order == 1 && a.T > 1;
+  return (g_semilag_variant == 0 || g_semilag_variant == 6) && semilag_wants_packed(a) && a.precip != nullptr &&
+         a.order == 1 && a.T > 1;
 }
 
 hipError_t launch_pack_field_rows(const float *precip, float *pairs, int m, int n, hipStream_t stream) {
