@@ -310,6 +310,87 @@ __global__ __launch_bounds__(256) void lk_open_vec(const float *__restrict__ img
   }
 }
 
+// The same pass with the morphology done on BIT MASKS (default).  The two LDS kernels above spend
+// their time in byte-sized LDS reads (11 per pixel); here a wave owns 64 image columns (the outer
+// two on each side are halo, 60 are written) and 16 output rows: it loads its 20 rows first (all
+// loads in flight together), turns every row into two 64-bit masks with one ballot each - F: field
+// pixel set, N: position outside the image (neutral for the erosion) - and the 3x3 cross becomes
+// shifts and ANDs / ORs of scalar registers:
+//    A = F | N;  E_y = F_y & (A_y << 1) & (A_y >> 1) & A_{y-1} & A_{y+1};
+//    O_y = E_y | (E_y << 1) | (E_y >> 1) | E_{y-1} | E_{y+1}
+// A lane then only keeps or replaces its own 16 values.  4 waves (64 output rows) per workgroup.
+constexpr int kOpenRowsW = 16;        // output rows per wave
+constexpr int kOpenColsW = 60;        // output columns per wave (64 lanes - 2 x 2 halo)
+constexpr int kOpenRowsWG = 4 * kOpenRowsW;
+
+__global__ __launch_bounds__(256) void lk_open_bits(const float *__restrict__ img, int m, int n,
+                                                    int size_opening, int buffer_mask,
+                                                    const float *__restrict__ stats,
+                                                    float *__restrict__ clean,
+                                                    float *__restrict__ partial, Band band) {
+  __shared__ float red[3][4];
+  const float mn = stats[kMinAll];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * kOpenColsW - 2 + lane;
+  const int yb = blockIdx.y * kOpenRowsWG + wave * kOpenRowsW;  // first output row of the wave
+  const bool col_in = x >= 0 && x < n;
+  constexpr int kLoad = kOpenRowsW + 4;
+  float v[kLoad];
+#pragma unroll
+  for (int q = 0; q < kLoad; ++q) {
+    const int y = yb - 2 + q;
+    v[q] = (col_in && y >= 0 && y < m) ? img[static_cast<size_t>(y) * n + x] : 0.f;
+  }
+  unsigned long long A[kLoad], F[kLoad];
+#pragma unroll
+  for (int q = 0; q < kLoad; ++q) {
+    const int y = yb - 2 + q;
+    const bool row_in = y >= 0 && y < m;
+    F[q] = __ballot(row_in && col_in && isfinite(v[q]) && v[q] > mn);  // masked pixels are filled with the minimum
+    A[q] = F[q] | __ballot(!(row_in && col_in));
+  }
+  unsigned long long E[kLoad];  // valid for q in [1, kLoad - 1)
+#pragma unroll
+  for (int q = 1; q < kLoad - 1; ++q) E[q] = F[q] & (A[q] << 1) & (A[q] >> 1) & A[q - 1] & A[q + 1];
+  float mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
+  // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
+  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+  const bool writer = lane >= 2 && lane < 2 + kOpenColsW && col_in;
+#pragma unroll
+  for (int q = 2; q < kLoad - 2; ++q) {
+    const int y = yb - 2 + q;
+    if (y >= m) break;  // (uniform)
+    const unsigned long long O = E[q] | (E[q] << 1) | (E[q] >> 1) | E[q - 1] | E[q + 1];
+    float val = v[q];
+    if (size_opening > 0 && ((F[q] >> lane) & 1ull) && !((O >> lane) & 1ull)) val = mn;
+    if (writer) {
+      if (isfinite(val) && y >= band.lo && y < band.hi) {
+        mx_all = fmaxf(mx_all, val);
+        if (y + band.y_org >= first_row) {
+          mn_feat = fminf(mn_feat, val);
+          mx_feat = fmaxf(mx_feat, val);
+        }
+      }
+      clean[static_cast<size_t>(y) * n + x] = val;
+    }
+  }
+  mx_all = wave_max(mx_all);
+  mn_feat = wave_min(mn_feat);
+  mx_feat = wave_max(mx_feat);
+  if (lane == 0) {
+    red[0][wave] = mx_all;
+    red[1][wave] = mn_feat;
+    red[2][wave] = mx_feat;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
+    partial[b] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    partial[nb + b] = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+    partial[2 * nb + b] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+  }
+}
+
 __global__ __launch_bounds__(kFinalThreads) void lk_open_final(const float *__restrict__ partial,
                                                                int nb, float *__restrict__ stats) {
   __shared__ float smem[16];
@@ -1185,6 +1266,29 @@ __global__ __launch_bounds__(256) void lk_pool_append(const float2 *__restrict__
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// 0 = bit-mask opening (default), 1 = the LDS kernels (lk_open_vec / lk_open)
+static int g_lk_open_variant = [] {
+  const char *e = std::getenv("PYSTEPS_HIP_LK_OPEN_VARIANT");
+  return e ? std::atoi(e) : 0;
+}();
+dim3 lk_open_grid(int m, int n) {
+  if (g_lk_open_variant == 0) return dim3((n + kOpenColsW - 1) / kOpenColsW, (m + kOpenRowsWG - 1) / kOpenRowsWG);
+  return dim3((n + kOpenTX - 1) / kOpenTX, (m + kOpenTY - 1) / kOpenTY);
+}
+void launch_lk_open(dim3 grid, hipStream_t stream, const float *img, int m, int n, int size_opening, int buffer_mask,
+                    const float *stats, float *clean, float *part, Band band) {
+  if (g_lk_open_variant == 0) {
+    hipLaunchKernelGGL(lk_open_bits, grid, dim3(256), 0, stream, img, m, n, size_opening, buffer_mask, stats, clean,
+                       part, band);
+  } else if (n % 4 == 0 && reinterpret_cast<uintptr_t>(img) % 16 == 0 && reinterpret_cast<uintptr_t>(clean) % 16 == 0) {
+    hipLaunchKernelGGL(lk_open_vec, grid, dim3(256), 0, stream, img, m, n, size_opening, buffer_mask, stats, clean, part,
+                       band);
+  } else {
+    hipLaunchKernelGGL(lk_open, grid, dim3(256), 0, stream, img, m, n, size_opening, buffer_mask, stats, clean, part,
+                       band);
+  }
+}
+
 static int ensure_lk_ws(size_t nbytes, void **ptr) {
   Context &c = ctx();
   static void *ws = nullptr;
@@ -1228,7 +1332,7 @@ int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, i
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
   const size_t npx = static_cast<size_t>(m) * n;
-  const dim3 ogrid((n + psh::kOpenTX - 1) / psh::kOpenTX, (m + psh::kOpenTY - 1) / psh::kOpenTY);
+  const dim3 ogrid = psh::lk_open_grid(m, n);
   const int nb_open = ogrid.x * ogrid.y;
   void *ws = nullptr;
   const size_t need = sizeof(float) * (2 * static_cast<size_t>(psh::kRedBlocks) + 3 * static_cast<size_t>(nb_open));
@@ -1237,15 +1341,8 @@ int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, i
   float *part2 = part1 + 2 * psh::kRedBlocks;
   hipLaunchKernelGGL(psh::lk_stats1, dim3(psh::kRedBlocks), dim3(256), 0, c.stream, frame_dev, npx, part1);
   hipLaunchKernelGGL(psh::lk_stats1_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part1, psh::kRedBlocks, stats_dev);
-  const bool vec_ok = n % 4 == 0 && reinterpret_cast<uintptr_t>(frame_dev) % 16 == 0 &&
-                      reinterpret_cast<uintptr_t>(clean_dev) % 16 == 0;
-  if (vec_ok) {
-    hipLaunchKernelGGL(psh::lk_open_vec, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening,
-                       buffer_mask, stats_dev, clean_dev, part2, psh::Band{0, 0, m});
-  } else {
-    hipLaunchKernelGGL(psh::lk_open, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening,
-                       buffer_mask, stats_dev, clean_dev, part2, psh::Band{0, 0, m});
-  }
+  psh::launch_lk_open(ogrid, c.stream, frame_dev, m, n, size_opening, buffer_mask, stats_dev, clean_dev, part2,
+                      psh::Band{0, 0, m});
   hipLaunchKernelGGL(psh::lk_open_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part2, nb_open, stats_dev);
   const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
   hipLaunchKernelGGL(psh::lk_to_u8, dim3(qgrid), dim3(256), 0, c.stream, clean_dev, m, n, buffer_mask,
@@ -1298,7 +1395,7 @@ int psh_lk_band_open_dev(const float *frame_dev, int m, int n, int e0, int e1, i
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
   const int ms = e1 - e0;
-  const dim3 ogrid((n + psh::kOpenTX - 1) / psh::kOpenTX, (ms + psh::kOpenTY - 1) / psh::kOpenTY);
+  const dim3 ogrid = psh::lk_open_grid(ms, n);
   const int nb_open = ogrid.x * ogrid.y;
   void *ws = nullptr;
   if (int rc = psh::ensure_lk_ws(sizeof(float) * 3 * static_cast<size_t>(nb_open), &ws)) return rc;
@@ -1306,13 +1403,7 @@ int psh_lk_band_open_dev(const float *frame_dev, int m, int n, int e0, int e1, i
   const float *img = frame_dev + static_cast<size_t>(e0) * n;
   float *clean = clean_dev + static_cast<size_t>(e0) * n;
   const psh::Band band{e0, r0 - e0, r1 - e0};
-  if (n % 4 == 0 && reinterpret_cast<uintptr_t>(img) % 16 == 0 && reinterpret_cast<uintptr_t>(clean) % 16 == 0) {
-    hipLaunchKernelGGL(psh::lk_open_vec, ogrid, dim3(256), 0, c.stream, img, ms, n, size_opening, buffer_mask,
-                       stats_dev, clean, part, band);
-  } else {
-    hipLaunchKernelGGL(psh::lk_open, ogrid, dim3(256), 0, c.stream, img, ms, n, size_opening, buffer_mask, stats_dev,
-                       clean, part, band);
-  }
+  psh::launch_lk_open(ogrid, c.stream, img, ms, n, size_opening, buffer_mask, stats_dev, clean, part, band);
   hipLaunchKernelGGL(psh::lk_open_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb_open, stats_dev);
   PSH_HIP(hipGetLastError());
   return PSH_OK;
