@@ -37,6 +37,9 @@ struct Context {
 Context &ctx();
 int fail(int code, const char *fmt, ...);
 int ensure_scratch(size_t nbytes);
+// Small pinned host blocks that live as long as the library (staging slots of single translation
+// units): allocated on first use, released by psh_shutdown.  *slot stays NULL on failure.
+int persistent_pinned(void **slot, size_t nbytes);
 // Fork: *side will run after everything queued on the main stream so far.  Join: the main stream
 // continues after everything queued on the side stream.  Lock held by the caller.  Blocks handed
 // out by psh_malloc are ordered on the MAIN stream: a block used on the side stream has to be

@@ -157,7 +157,7 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
     mark("dense field queued");
     if (count_out) {  // the caller asks how many vectors the field was made from: one 4-byte copy
       static void *pinned_cnt = nullptr;
-      if (!pinned_cnt) PSH_HIP(hipHostMalloc(&pinned_cnt, 64, hipHostMallocDefault));
+      if (int rc = psh::persistent_pinned(&pinned_cnt, 64)) return rc;
       PSH_HIP(hipMemcpyAsync(pinned_cnt, &d_dyn->L, sizeof(int), hipMemcpyDeviceToHost, c.stream));
       PSH_HIP(hipStreamSynchronize(c.stream));
       *count_out = *static_cast<const int *>(pinned_cnt);
@@ -169,7 +169,7 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   // (xy | uv | count | flags), same layout on both sides ------------------------------------------
   static void *pinned = nullptr;  // sized for 8192 vectors
   constexpr size_t kPinBytes = 2 * 8192 * 16 + 256 + 8192;
-  if (!pinned) PSH_HIP(hipHostMalloc(&pinned, kPinBytes, hipHostMallocDefault));
+  if (int rc = psh::persistent_pinned(&pinned, kPinBytes)) return rc;
   char *pin = static_cast<char *>(pinned);
   PSH_HIP(hipMemcpyAsync(pin, pbase, off_fl + cap, hipMemcpyDeviceToHost, c.stream));
   PSH_HIP(hipStreamSynchronize(c.stream));

@@ -2118,7 +2118,7 @@ int lk_track_pool(void *pyramid_handle, const float *points_host, const float *p
       constexpr size_t kSlots = 8, kSlotBytes = 1 << 16;
       if (static_cast<size_t>(npts) * sizeof(float2) > kSlotBytes)
         return fail(PSH_EUNSUPPORTED, "lk_track_pool: more than %zu points", kSlotBytes / sizeof(float2));
-      if (!ring) PSH_HIP(hipHostMalloc(&ring, kSlots * kSlotBytes, hipHostMallocDefault));
+      if (int rc = persistent_pinned(&ring, kSlots * kSlotBytes)) return rc;
       if (ring_slot == kSlots) {
         PSH_HIP(hipStreamSynchronize(c.stream));
         ring_slot = 0;

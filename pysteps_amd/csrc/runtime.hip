@@ -159,6 +159,31 @@ int psh_init(int device_id) {
 
 extern "C++" {
 namespace psh {
+namespace {
+struct PinnedSlot {
+  void **slot;
+};
+std::vector<PinnedSlot> &pinned_slots() {
+  static std::vector<PinnedSlot> v;
+  return v;
+}
+}  // namespace
+
+int persistent_pinned(void **slot, size_t nbytes) {
+  if (*slot) return PSH_OK;
+  PSH_HIP(hipHostMalloc(slot, nbytes, hipHostMallocDefault));
+  pinned_slots().push_back(PinnedSlot{slot});
+  return PSH_OK;
+}
+
+static void release_persistent_pinned() {
+  for (PinnedSlot &p : pinned_slots()) {
+    if (*p.slot) (void)hipHostFree(*p.slot);
+    *p.slot = nullptr;
+  }
+  pinned_slots().clear();
+}
+
 int side_begin(hipStream_t *side) {
   Context &c = ctx();
   if (!c.side) {
@@ -188,6 +213,7 @@ int psh_shutdown(void) {
   (void)hipStreamSynchronize(c.stream);
   psh::release_cache();
   psh::pinned_release_cache();
+  psh::release_persistent_pinned();
   if (c.scratch) (void)hipFree(c.scratch);
   if (c.pinned) (void)hipHostFree(c.pinned);
   (void)hipStreamDestroy(c.stream);
