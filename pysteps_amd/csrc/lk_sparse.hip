@@ -302,8 +302,13 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
   __shared__ int s_hist[kOrdBins];
   __shared__ unsigned long long s_conf[kOrdWaves][64];
   __shared__ unsigned long long s_rej[kOrdWaves];
-  __shared__ unsigned s_xy[kChunkCap];      // the ordered chunk: x | y << 16 ...
-  __shared__ unsigned s_cl[kChunkCap];      // ... and x cell | y cell << 16 (divisions done once per chunk)
+  // second key buffer of the counting sort; afterwards the same memory holds, for the ordered chunk,
+  // x | y << 16 (s_xy) and x cell | y cell << 16 (s_cl): the divisions are done once per chunk
+  __shared__ CornerKey s_tmp[kChunkCap];
+  unsigned *const s_xy = reinterpret_cast<unsigned *>(s_tmp);
+  unsigned *const s_cl = s_xy + kChunkCap;
+  __shared__ int s_off[kOrdBins];
+  __shared__ int s_maxbin;
   __shared__ uint2 s_acc[kMaxCornersDev];   // accepted corners, same packing
   __shared__ short s_next[kMaxCornersDev];  // next accepted corner of the same cell (-1: none)
   __shared__ unsigned s_hkey[kHashSlots];   // cell key of a hash slot (kNoCell: free)
@@ -422,10 +427,77 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
     ++st_chunks;
     st_walked += cnt;
     lap(tk_load);
-    const int p2 = next_pow2(cnt);
-    for (int i = cnt + tid; i < p2; i += kOrdThreads) s_keys[i] = 0ull;  // sorts behind every real key
-    __syncthreads();
-    bitonic_sort_lds<true>(s_keys, p2);
+    // ---- order the chunk: counting sort over 1024 bins of [T, upper) (descending), the few keys
+    // of a bin by one thread each; chunks with a crowded bin (many equal responses) take the
+    // bitonic network instead ----------------------------------------------------------------------
+    {
+      const int sh2 = bin_shift(T, upper);
+      for (int i = tid; i < kOrdBins; i += kOrdThreads) s_hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < cnt; i += kOrdThreads) atomicAdd(&s_hist[static_cast<int>((s_keys[i] - T) >> sh2)], 1);
+      __syncthreads();
+      if (wave == 0) {  // start of bin b in descending order = keys in the bins above it
+        constexpr int kPer = kOrdBins / 64;
+        int tot = 0, big = 0;
+        for (int q = 0; q < kPer; ++q) {
+          const int h = s_hist[lane * kPer + q];
+          tot += h;
+          big = max(big, h);
+        }
+        int incl = tot;  // -> sum over lanes >= this one
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int dn = __shfl_down(incl, d);
+          if (lane + d < 64) incl += dn;
+        }
+        int run = incl - tot;
+        for (int q = kPer - 1; q >= 0; --q) {
+          s_off[lane * kPer + q] = run;
+          run += s_hist[lane * kPer + q];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) big = max(big, __shfl_xor(big, d));
+        if (lane == 0) s_maxbin = big;
+      }
+      __syncthreads();
+      if (s_maxbin <= 64) {
+        for (int i = tid; i < kOrdBins; i += kOrdThreads) s_hist[i] = 0;  // now the fill cursors
+        __syncthreads();
+        for (int i = tid; i < cnt; i += kOrdThreads) {
+          const CornerKey k = s_keys[i];
+          const int b = static_cast<int>((k - T) >> sh2);
+          s_tmp[s_off[b] + atomicAdd(&s_hist[b], 1)] = k;
+        }
+        __syncthreads();
+        for (int b = tid; b < kOrdBins; b += kOrdThreads) {  // insertion sort, descending, of the bin's keys
+          const int lo = s_off[b], hi = lo + s_hist[b];
+          for (int i = lo + 1; i < hi; ++i) {
+            const CornerKey k = s_tmp[i];
+            int j = i - 1;
+            while (j >= lo && s_tmp[j] < k) {
+              s_tmp[j + 1] = s_tmp[j];
+              --j;
+            }
+            s_tmp[j + 1] = k;
+          }
+        }
+        __syncthreads();
+        CornerKey mine[kChunkCap / kOrdThreads];
+#pragma unroll
+        for (int q = 0; q < kChunkCap / kOrdThreads; ++q)
+          mine[q] = tid + q * kOrdThreads < cnt ? s_tmp[tid + q * kOrdThreads] : 0ull;
+        __syncthreads();  // s_tmp becomes s_xy / s_cl below
+#pragma unroll
+        for (int q = 0; q < kChunkCap / kOrdThreads; ++q)
+          if (tid + q * kOrdThreads < cnt) s_keys[tid + q * kOrdThreads] = mine[q];
+        __syncthreads();
+      } else {
+        const int p2 = next_pow2(cnt);
+        for (int i = cnt + tid; i < p2; i += kOrdThreads) s_keys[i] = 0ull;  // sorts behind every real key
+        __syncthreads();
+        bitonic_sort_lds<true>(s_keys, p2);
+      }
+    }
     lap(tk_sort);
     for (int i = tid; i < cnt; i += kOrdThreads) {
       const unsigned addr = static_cast<unsigned>(s_keys[i] & 0xffffffffull);
