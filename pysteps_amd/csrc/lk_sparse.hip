@@ -460,36 +460,34 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
         if (lane == 0) s_maxbin = big;
       }
       __syncthreads();
-      if (s_maxbin <= 64) {
+      if (s_maxbin <= 1024) {
+        // every thread keeps its (up to four) keys and their bins; the keys are scattered into their
+        // bins' ranges of s_tmp in any order, then every key counts the larger keys of its bin - its
+        // rank there - and goes to its final place in s_keys (a bin holds a handful of keys as a
+        // rule; a crowded one costs its keys' owners a longer loop, not a different algorithm)
+        constexpr int kMine = kChunkCap / kOrdThreads;
+        CornerKey mine[kMine];
+        int mine_bin[kMine];
+#pragma unroll
+        for (int q = 0; q < kMine; ++q) {
+          const int i = tid + q * kOrdThreads;
+          mine[q] = i < cnt ? s_keys[i] : 0ull;
+          mine_bin[q] = i < cnt ? static_cast<int>((mine[q] - T) >> sh2) : -1;
+        }
         for (int i = tid; i < kOrdBins; i += kOrdThreads) s_hist[i] = 0;  // now the fill cursors
         __syncthreads();
-        for (int i = tid; i < cnt; i += kOrdThreads) {
-          const CornerKey k = s_keys[i];
-          const int b = static_cast<int>((k - T) >> sh2);
-          s_tmp[s_off[b] + atomicAdd(&s_hist[b], 1)] = k;
-        }
-        __syncthreads();
-        for (int b = tid; b < kOrdBins; b += kOrdThreads) {  // insertion sort, descending, of the bin's keys
-          const int lo = s_off[b], hi = lo + s_hist[b];
-          for (int i = lo + 1; i < hi; ++i) {
-            const CornerKey k = s_tmp[i];
-            int j = i - 1;
-            while (j >= lo && s_tmp[j] < k) {
-              s_tmp[j + 1] = s_tmp[j];
-              --j;
-            }
-            s_tmp[j + 1] = k;
-          }
-        }
-        __syncthreads();
-        CornerKey mine[kChunkCap / kOrdThreads];
 #pragma unroll
-        for (int q = 0; q < kChunkCap / kOrdThreads; ++q)
-          mine[q] = tid + q * kOrdThreads < cnt ? s_tmp[tid + q * kOrdThreads] : 0ull;
-        __syncthreads();  // s_tmp becomes s_xy / s_cl below
+        for (int q = 0; q < kMine; ++q)
+          if (mine_bin[q] >= 0) s_tmp[s_off[mine_bin[q]] + atomicAdd(&s_hist[mine_bin[q]], 1)] = mine[q];
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < kChunkCap / kOrdThreads; ++q)
-          if (tid + q * kOrdThreads < cnt) s_keys[tid + q * kOrdThreads] = mine[q];
+        for (int q = 0; q < kMine; ++q) {
+          if (mine_bin[q] < 0) continue;
+          const int lo = s_off[mine_bin[q]], hi = lo + s_hist[mine_bin[q]];
+          int rank = 0;
+          for (int j = lo; j < hi; ++j) rank += s_tmp[j] > mine[q] ? 1 : 0;
+          s_keys[lo + rank] = mine[q];
+        }
         __syncthreads();
       } else {
         const int p2 = next_pow2(cnt);
