@@ -251,6 +251,11 @@ int psh_idw_host(const double *xy, const double *values, int L, int m, int n, do
 int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, int buffer_mask,
                        float *clean_dev, unsigned char *track_u8_dev,
                        unsigned char *feature_u8_dev, float *stats_dev);
+/* psh_lk_prepare_dev for a float64 frame: minimum, opening test, rescale and truncation in double, as
+ * the reference computes them for float64 input; clean_dev receives the float32 copy of the cleaned frame. */
+int psh_lk_prepare_f64_dev(const double *frame_dev, int m, int n, int size_opening, int buffer_mask,
+                           float *clean_dev, unsigned char *track_u8_dev,
+                           unsigned char *feature_u8_dev, float *stats_dev);
 int psh_lk_corners_dev(const unsigned char *feature_u8_dev, const float *clean_dev,
                        float *stats_dev, int m, int n, int block_size, int buffer_mask,
                        double quality_level, double min_distance, int max_corners,
@@ -346,6 +351,7 @@ typedef struct psh_lk_params {
   double decl_scale;
   int idw_k;                 /* <= 0: use every vector (k=None) */
   double idw_power, idw_dist_offset;
+  int frames_f64;            /* != 0: frames_dev points to float64 planes (psh_lk_prepare_f64_dev) */
 } psh_lk_params;
 int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int n, const psh_lk_params *params,
                      float *field_dev, double *xy_host, double *uv_host, int capacity,

@@ -34,6 +34,7 @@ class LkParams(ctypes.Structure):
         ("nr_std_outlier", c_double), ("k_outlier", c_int),
         ("decl_scale", c_double),
         ("idw_k", c_int), ("idw_power", c_double), ("idw_dist_offset", c_double),
+        ("frames_f64", c_int),
     ]
 
 
@@ -78,6 +79,7 @@ SIGNATURES = {
     "psh_idw_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_double, c_void_p]),
     "psh_idw_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_void_p]),
     "psh_lk_prepare_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psh_lk_prepare_f64_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "psh_lk_corners_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_void_p, POINTER(c_int)]),
     "psh_lk_track_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
     "psh_comm_unique_id_bytes": (c_int, []),

@@ -65,10 +65,15 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
     if (want_feat)
       if (int rc = feat[t].alloc(plane)) return rc;
     if (int rc = stats[t].alloc(8 * sizeof(float))) return rc;
-    if (int rc = psh_lk_prepare_dev(frames_dev + static_cast<size_t>(t) * plane, m, n, prm->size_opening,
-                                    prm->buffer_mask, clean[t].as<float>(), trk[t].as<unsigned char>(),
-                                    want_feat ? feat[t].as<unsigned char>() : nullptr, stats[t].as<float>()))
-      return rc;
+    const int rc = prm->frames_f64
+                       ? psh_lk_prepare_f64_dev(reinterpret_cast<const double *>(frames_dev) + static_cast<size_t>(t) * plane,
+                                                m, n, prm->size_opening, prm->buffer_mask, clean[t].as<float>(),
+                                                trk[t].as<unsigned char>(),
+                                                want_feat ? feat[t].as<unsigned char>() : nullptr, stats[t].as<float>())
+                       : psh_lk_prepare_dev(frames_dev + static_cast<size_t>(t) * plane, m, n, prm->size_opening,
+                                            prm->buffer_mask, clean[t].as<float>(), trk[t].as<unsigned char>(),
+                                            want_feat ? feat[t].as<unsigned char>() : nullptr, stats[t].as<float>());
+    if (rc) return rc;
   }
 
   // ---- per frame pair: features, tracking, pooling (:207-242) ---------------------------

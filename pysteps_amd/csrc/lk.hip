@@ -453,6 +453,202 @@ __global__ __launch_bounds__(256) void lk_to_u8(const float *__restrict__ clean,
   }
 }
 
+// ---- float64 frames: the three frame passes in double ---------------------------------------
+// The reference cleans and quantises a frame in the dtype it is given (pysteps arrays are float64
+// as a rule): the minimum, the `> minimum` test of the opening, the min-max rescale and its
+// truncation to uint8 all happen in double there (utils/images.py:58-86,
+// tracking/lucaskanade.py:135-160, feature/shitomasi.py:128-151).  Rounding the frame to float32
+// first moves a pixel across a grey-level boundary now and then (~2e-5 of the pixels), so float64
+// frames get double-precision twins of the three passes; everything downstream works on the uint8
+// renderings and on the float32 copy of the cleaned frame (used for its NaN pattern only).
+// dstats: [0] min over finite pixels, [1] max after opening, [2] / [3] min / max of the feature rows.
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmin(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void lk_stats1_f64(const double *__restrict__ img, size_t npx,
+                                                     double *__restrict__ partial) {
+  double mn = INFINITY, bad = 0.0;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < npx; i += stride) {
+    const double v = img[i];
+    const bool fin = isfinite(v);
+    mn = fmin(mn, fin ? v : INFINITY);
+    bad += fin ? 0.0 : 1.0;
+  }
+  __shared__ double s[2][4];
+  mn = wave_min_d(mn);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) bad += __shfl_xor(bad, d);
+  if ((threadIdx.x & 63) == 0) {
+    s[0][threadIdx.x >> 6] = mn;
+    s[1][threadIdx.x >> 6] = bad;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = fmin(fmin(s[0][0], s[0][1]), fmin(s[0][2], s[0][3]));
+    partial[gridDim.x + blockIdx.x] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+  }
+}
+
+// one block: finishes either reduction (what = 0: stats pass, 1: opening pass)
+__global__ __launch_bounds__(kFinalThreads) void lk_final_f64(const double *__restrict__ partial, int nb, int what,
+                                                             float *__restrict__ stats, double *__restrict__ dstats) {
+  __shared__ double sm[3][16];
+  double a = what == 0 ? INFINITY : -INFINITY, b = what == 0 ? 0.0 : INFINITY, c = -INFINITY;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+    if (what == 0) {
+      a = fmin(a, partial[i]);
+      b += partial[nb + i];
+    } else {
+      a = fmax(a, partial[i]);
+      b = fmin(b, partial[nb + i]);
+      c = fmax(c, partial[2 * nb + i]);
+    }
+  }
+  if (what == 0) {
+    a = wave_min_d(a);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) b += __shfl_xor(b, d);
+  } else {
+    a = wave_max_d(a);
+    b = wave_min_d(b);
+    c = wave_max_d(c);
+  }
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sm[0][wave] = a;
+    sm[1][wave] = b;
+    sm[2][wave] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < nwaves; ++w) {
+      if (what == 0) {
+        a = fmin(a, sm[0][w]);
+        b += sm[1][w];
+      } else {
+        a = fmax(a, sm[0][w]);
+        b = fmin(b, sm[1][w]);
+        c = fmax(c, sm[2][w]);
+      }
+    }
+    if (what == 0) {
+      dstats[0] = a;
+      stats[kMinAll] = static_cast<float>(a);
+      stats[kNanCount] = static_cast<float>(b);
+    } else {
+      dstats[1] = a;
+      dstats[2] = b;
+      dstats[3] = c;
+      stats[kMaxAll] = static_cast<float>(a);
+      stats[kMinFeat] = static_cast<float>(b);
+      stats[kMaxFeat] = static_cast<float>(c);
+    }
+  }
+}
+
+// lk_open_bits for a float64 frame: clean64 = the cleaned frame in double (for the rescale),
+// clean32 = its float32 copy (NaN pattern for the later passes)
+__global__ __launch_bounds__(256) void lk_open_bits_f64(const double *__restrict__ img, int m, int n,
+                                                        int size_opening, int buffer_mask,
+                                                        const float *__restrict__ stats,
+                                                        const double *__restrict__ dstats,
+                                                        float *__restrict__ clean32, double *__restrict__ clean64,
+                                                        double *__restrict__ partial) {
+  __shared__ double red[3][4];
+  const double mn = dstats[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * kOpenColsW - 2 + lane;
+  const int yb = blockIdx.y * kOpenRowsWG + wave * kOpenRowsW;
+  const bool col_in = x >= 0 && x < n;
+  constexpr int kLoad = kOpenRowsW + 4;
+  double v[kLoad];
+#pragma unroll
+  for (int q = 0; q < kLoad; ++q) {
+    const int y = yb - 2 + q;
+    v[q] = (col_in && y >= 0 && y < m) ? img[static_cast<size_t>(y) * n + x] : 0.0;
+  }
+  unsigned long long A[kLoad], F[kLoad];
+#pragma unroll
+  for (int q = 0; q < kLoad; ++q) {
+    const int y = yb - 2 + q;
+    const bool row_in = y >= 0 && y < m;
+    F[q] = __ballot(row_in && col_in && isfinite(v[q]) && v[q] > mn);
+    A[q] = F[q] | __ballot(!(row_in && col_in));
+  }
+  unsigned long long E[kLoad];
+#pragma unroll
+  for (int q = 1; q < kLoad - 1; ++q) E[q] = F[q] & (A[q] << 1) & (A[q] >> 1) & A[q - 1] & A[q + 1];
+  double mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
+  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+  const bool writer = lane >= 2 && lane < 2 + kOpenColsW && col_in;
+#pragma unroll
+  for (int q = 2; q < kLoad - 2; ++q) {
+    const int y = yb - 2 + q;
+    if (y >= m) break;  // (uniform)
+    const unsigned long long O = E[q] | (E[q] << 1) | (E[q] >> 1) | E[q - 1] | E[q + 1];
+    double val = v[q];
+    if (size_opening > 0 && ((F[q] >> lane) & 1ull) && !((O >> lane) & 1ull)) val = mn;
+    if (writer) {
+      if (isfinite(val)) {
+        mx_all = fmax(mx_all, val);
+        if (y >= first_row) {
+          mn_feat = fmin(mn_feat, val);
+          mx_feat = fmax(mx_feat, val);
+        }
+      }
+      clean64[static_cast<size_t>(y) * n + x] = val;
+      clean32[static_cast<size_t>(y) * n + x] = static_cast<float>(val);
+    }
+  }
+  mx_all = wave_max_d(mx_all);
+  mn_feat = wave_min_d(mn_feat);
+  mx_feat = wave_max_d(mx_feat);
+  if (lane == 0) {
+    red[0][wave] = mx_all;
+    red[1][wave] = mn_feat;
+    red[2][wave] = mx_feat;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
+    partial[b] = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+    partial[nb + b] = fmin(fmin(red[1][0], red[1][1]), fmin(red[1][2], red[1][3]));
+    partial[2 * nb + b] = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+  }
+}
+
+__device__ __forceinline__ unsigned char quantise_f64(double v, double lo, double hi) {
+  const double s = (hi - lo) > 1e-8 ? (v - lo) / (hi - lo) * 255.0 : v - lo;
+  return static_cast<unsigned char>(static_cast<int>(s));  // astype(uint8) truncates toward zero
+}
+
+__global__ __launch_bounds__(256) void lk_to_u8_f64(const double *__restrict__ clean, int m, int n, int buffer_mask,
+                                                    const float *__restrict__ stats,
+                                                    const double *__restrict__ dstats,
+                                                    unsigned char *__restrict__ trk, unsigned char *__restrict__ feat) {
+  const double fill = dstats[0], hi = dstats[1], flo = dstats[2], fhi = dstats[3];
+  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+  const size_t npx = static_cast<size_t>(m) * n;
+  const size_t first_feature_px = static_cast<size_t>(first_row) * n;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t p = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; p < npx; p += stride) {
+    double v = clean[p];
+    const bool ok = isfinite(v);
+    if (!ok) v = fill;
+    trk[p] = quantise_f64(v, fill, hi);
+    if (feat) feat[p] = quantise_f64((ok && p >= first_feature_px) ? v : fill, flo, fhi);
+  }
+}
+
 // ---- Shi-Tomasi response: cv::cornerMinEigenVal(8U, blockSize, ksize=3) --------
 constexpr int kCrnTX = 32, kCrnTY = 32, kMaxBlockR = 3;  // block_size <= 7; 4 px per thread
 
@@ -1348,6 +1544,44 @@ int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, i
   hipLaunchKernelGGL(psh::lk_to_u8, dim3(qgrid), dim3(256), 0, c.stream, clean_dev, m, n, buffer_mask,
                      stats_dev, track_u8_dev, feature_u8_dev, 0);
   PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+// the same for a float64 frame (the dtype pysteps arrays have as a rule): everything that decides a
+// grey level is computed in double, like the reference does for such input
+int psh_lk_prepare_f64_dev(const double *frame_dev, int m, int n, int size_opening, int buffer_mask,
+                           float *clean_dev, unsigned char *track_u8_dev,
+                           unsigned char *feature_u8_dev, float *stats_dev) {
+  PSH_REQUIRE_INIT();
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_prepare: invalid shape (%d,%d)", m, n);
+  if (!frame_dev || !clean_dev || !track_u8_dev || !stats_dev)
+    return fail(PSH_EINVAL, "lk_prepare: NULL pointer");
+  if (size_opening != 0 && size_opening != 3)
+    return fail(PSH_EUNSUPPORTED, "lk_prepare: size_opening %d not implemented (0 or 3)", size_opening);
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t npx = static_cast<size_t>(m) * n;
+  const dim3 ogrid((n + psh::kOpenColsW - 1) / psh::kOpenColsW, (m + psh::kOpenRowsWG - 1) / psh::kOpenRowsWG);
+  const int nb_open = ogrid.x * ogrid.y;
+  const size_t part_doubles = 2 * static_cast<size_t>(psh::kRedBlocks) + 3 * static_cast<size_t>(nb_open) + 8;
+  void *blk = nullptr;  // [clean64 | partials | dstats]
+  if (int rc = psh_malloc(&blk, (npx + part_doubles) * sizeof(double))) return rc;
+  double *clean64 = static_cast<double *>(blk);
+  double *part1 = clean64 + npx, *part2 = part1 + 2 * psh::kRedBlocks, *dstats = part2 + 3 * nb_open;
+  hipLaunchKernelGGL(psh::lk_stats1_f64, dim3(psh::kRedBlocks), dim3(256), 0, c.stream, frame_dev, npx, part1);
+  hipLaunchKernelGGL(psh::lk_final_f64, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part1, psh::kRedBlocks, 0,
+                     stats_dev, dstats);
+  hipLaunchKernelGGL(psh::lk_open_bits_f64, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening, buffer_mask,
+                     stats_dev, dstats, clean_dev, clean64, part2);
+  hipLaunchKernelGGL(psh::lk_final_f64, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part2, nb_open, 1, stats_dev,
+                     dstats);
+  const int qgrid = static_cast<int>(std::min<size_t>((npx + 255) / 256, 8192));
+  hipLaunchKernelGGL(psh::lk_to_u8_f64, dim3(qgrid), dim3(256), 0, c.stream, clean64, m, n, buffer_mask, stats_dev,
+                     dstats, track_u8_dev, feature_u8_dev);
+  const hipError_t e = hipGetLastError();
+  (void)psh_free(blk);  // stream-ordered
+  if (e != hipSuccess) return fail(PSH_EHIP, "lk_prepare (float64) launch failed: %s", hipGetErrorString(e));
   return PSH_OK;
 }
 

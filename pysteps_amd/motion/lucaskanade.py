@@ -54,8 +54,10 @@ class PreparedFrame:
         self.track_u8 = DeviceArray((m, n), np.uint8)
         self.feature_u8 = DeviceArray((m, n), np.uint8) if want_features else None
         self.stats = DeviceArray((_N_STATS,), np.float32)
+        # float64 frames are cleaned and quantised in double, like the reference does for them
+        prepare = lib.psh_lk_prepare_f64_dev if frame_dev.dtype == np.float64 else lib.psh_lk_prepare_dev
         _lib.check(
-            lib.psh_lk_prepare_dev(
+            prepare(
                 frame_dev.ptr, m, n, int(size_opening), self.buffer_mask, self.clean.ptr,
                 self.track_u8.ptr, None if self.feature_u8 is None else self.feature_u8.ptr,
                 self.stats.ptr,
@@ -185,7 +187,7 @@ def _dense_lk_native(frames, on_device, dense, size_opening, buffer_mask, max_co
         float(quality_level), float(min_distance), int(winsize[0]), int(winsize[1]), int(nr_levels),
         max_count, eps, float(min_eig_thr), float(nr_std_outlier), int(k_outlier), float(decl_scale),
         0 if k_idw is None else int(k_idw), float(interp_kwargs.get("power", 0.5)),
-        float(interp_kwargs.get("dist_offset", 0.5)),
+        float(interp_kwargs.get("dist_offset", 0.5)), 1 if frames.dtype == np.float64 else 0,
     )
     lib = _lib.lib()
     count = ctypes.c_int(0)
@@ -257,13 +259,16 @@ def _dense_with_reference_interpolator(input_images, lk_kwargs, fd_kwargs, inter
 
 def _frames_to_device(input_images):
     if isinstance(input_images, DeviceArray):
-        if input_images.dtype != np.float32:
-            raise ValueError("device-resident input_images must be float32")
+        if input_images.dtype not in (np.float32, np.float64):
+            raise ValueError("device-resident input_images must be float32 or float64")
         return input_images, True
     arr = input_images
+    # float64 frames (what pysteps passes as a rule) keep their precision: the reference cleans and
+    # quantises in the dtype it is given; everything else is computed as float32
+    dtype = np.float64 if np.asarray(arr).dtype == np.float64 else np.float32
     if isinstance(arr, np.ma.MaskedArray):
-        arr = np.ma.filled(arr.astype(np.float32, copy=True), np.nan)
-    return DeviceArray.from_host(np.asarray(arr), dtype=np.float32), False
+        arr = np.ma.filled(arr.astype(dtype, copy=True), np.nan)
+    return DeviceArray.from_host(np.asarray(arr), dtype=dtype), False
 
 
 def dense_lucaskanade(

@@ -494,3 +494,66 @@ def test_other_interpolation_method_runs_on_the_hip_sparse_stage(dense_lk, ref_p
     # nothing to interpolate -> zero field, whatever the method
     flat = np.zeros((2, 64, 64), dtype=np.float32)
     assert not dense_lk(flat, interp_method="rbfinterp2d").any()
+
+
+@pytest.mark.parametrize("shape,nan", [((96, 130), False), ((257, 64), True), ((300, 300), True), ((1024, 1000), False)])
+def test_prepare_float64_frames_bit_exact(lkmod, shape, nan):
+    """float64 frames (what pysteps passes as a rule) are cleaned and quantised in double, like the
+    reference does for them (utils/images.py:58-86, tracking/lucaskanade.py:135-160,
+    shitomasi.py:128-151): both uint8 renderings bit-exact against the oracle run in float64 - and
+    NOT what the float32 pipeline gives for the same frame rounded to float32 (the reason the
+    float64 path exists: a grey level flips for ~2e-5 of the pixels)."""
+    from oracle import lk_opencv as olk
+    from pysteps_amd.device import DeviceArray
+
+    m, n = shape
+    rng = np.random.default_rng(n + 5)
+    img = _rain(m, n, seed=m).astype(np.float64) + rng.uniform(-1e-7, 1e-7, (m, n))  # not float32 numbers
+    speck = rng.random((m, n)) < 0.02
+    img[speck] = rng.uniform(0, 30, speck.sum())
+    if nan:
+        img[: m // 5, : n // 3] = np.nan
+        img[m // 2, n // 2] = np.nan
+    valid = np.isfinite(img)
+    prep = lkmod.PreparedFrame(DeviceArray.from_host(img), 3, 5, True)
+    clean = olk.morph_opening(img, valid, img[valid].min())
+    assert clean.dtype == np.float64
+    got_clean = prep.clean.to_host()
+    assert got_clean.dtype == np.float32 and np.array_equal(np.isnan(got_clean), ~valid)
+    assert np.array_equal(got_clean[valid], clean[valid].astype(np.float32))
+    lo, hi = clean[valid].min(), clean[valid].max()
+    want_trk = olk.to_uint8(clean, valid, lo, hi, lo)
+    assert np.array_equal(prep.track_u8.to_host(), want_trk)
+    use = valid.copy()
+    use[0, :] = False
+    if (~valid).any():
+        use[1, :] = False
+    flo, fhi = clean[use].min(), clean[use].max()
+    assert np.array_equal(prep.feature_u8.to_host(), olk.to_uint8(clean, use, flo, fhi, lo))
+    if m * n >= 1 << 20:  # the float32 pipeline differs from this on a few pixels of a frame this size
+        prep32 = _prep(lkmod, img.astype(np.float32))
+        assert np.count_nonzero(prep32.track_u8.to_host() != want_trk) > 0
+
+
+def test_dense_lk_float64_frames_match_the_oracle(dense_lk):
+    """End to end with float64 input (the dtype of pysteps arrays): sparse vectors and dense field
+    against the restatement run on the same float64 frames."""
+    from oracle import lk_opencv as olk
+
+    m = n = 320
+    frames32, vel = _advected_frames(m, n, 2, seed=31)
+    rng = np.random.default_rng(2)
+    frames = frames32.astype(np.float64) + rng.uniform(-1e-6, 1e-6, frames32.shape)
+    wxy, wuv = olk.dense_lucaskanade(frames, dense=False)
+    gxy, guv = dense_lk(frames, dense=False)
+    assert np.array_equal(gxy, wxy) and np.abs(guv - wuv).max() < 1e-2
+    got, want = dense_lk(frames), olk.dense_lucaskanade(frames)
+    assert got.dtype == np.float64 and rel_l2(got, want) < 1e-3
+    # the staged Python loop takes the same path
+    lk = __import__("pysteps_amd.motion.lucaskanade", fromlist=["x"])
+    lk.USE_NATIVE_ORCHESTRATION = False
+    try:
+        sxy, suv = dense_lk(frames, dense=False)
+    finally:
+        lk.USE_NATIVE_ORCHESTRATION = True
+    assert np.array_equal(sxy, gxy) and np.array_equal(suv, guv)
