@@ -777,15 +777,19 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
 
 // variant 0 (default) samples the velocity from a packed {u,v} plane when the caller provides one;
 // variant 1 = the one-plane-per-component kernel with DPP column sharing (round 1 default)
+// The layout passes cost one sweep over the planes each (0.04 ms at 4096^2) and save ~4 us per
+// sampling pass of a 4096^2 step: they pay off from ~8 sampling steps on.  Shorter calls - the
+// single-step calls of a generic nowcast loop - take the planar kernel (bit-identical results).
 bool semilag_wants_packed(const SemilagArgs &a) {
   return (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 6) &&
-         static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29);
+         static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29) &&
+         static_cast<long long>(a.T) * (a.n_iter > 0 ? a.n_iter : 1) >= 8;
 }
 // variant 0 also samples the field from a row-pair plane (one dwordx4 per sample); 5 = packed
 // velocity only (two dwordx2 for the field), kept for comparison
 bool semilag_wants_field_pairs(const SemilagArgs &a) {
   return (g_semilag_variant == 0 || g_semilag_variant == 6) && semilag_wants_packed(a) && a.precip != nullptr &&
-         a.order == 1 && a.T > 1;
+         a.order == 1 && a.T >= 8;
 }
 
 hipError_t launch_pack_field_rows(const float *precip, float *pairs, int m, int n, hipStream_t stream) {
