@@ -557,3 +557,21 @@ def test_dense_lk_float64_frames_match_the_oracle(dense_lk):
     finally:
         lk.USE_NATIVE_ORCHESTRATION = True
     assert np.array_equal(sxy, gxy) and np.array_equal(suv, guv)
+
+
+@pytest.mark.parametrize("max_corners,min_distance", [(1000, 7.5), (1000, 10.4), (300, 25), (3000, 6), (2500, 0)])
+def test_corner_options_match_oracle(lkmod, max_corners, min_distance):
+    """goodFeaturesToTrack options away from the defaults: a min_distance that is not an integer
+    (OpenCV's cell size is round(min_distance), only the 3x3 cells around a candidate are searched),
+    a large one, none at all, and more corners than the device walk keeps in LDS (> 2048: the
+    candidates are ordered and walked on the host instead) - identical lists, identical order."""
+    from oracle import lk_opencv as olk
+
+    m, n = 640, 768
+    img = _rain(m, n, seed=77)
+    valid = np.isfinite(img)
+    clean = olk.morph_opening(img, valid, img[valid].min())
+    want = olk.shitomasi_detection(clean, valid, max_corners=max_corners, min_distance=min_distance)
+    got = lkmod.detect_corners(_prep(lkmod, img), max_corners=max_corners, min_distance=min_distance)
+    assert len(want) > 100
+    assert np.array_equal(got, want)
