@@ -42,48 +42,87 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 w) {
 }
 
 // in-place DIT FFT of `count` independent sequences z[c * pitch + lpad(i)], i < N = 1 << logn, whose
-// elements were stored bit-reversed; INV conjugates the twiddles (unscaled inverse)
+// elements were stored bit-reversed; INV conjugates the twiddles (unscaled inverse).
+// A thread takes four butterflies per round: their sixteen LDS reads and four twiddle loads are
+// issued before any arithmetic and their sixteen writes after it (the butterflies of a pass touch
+// disjoint elements) - written as one loop body, the compiler has to assume that a butterfly's
+// writes alias the next one's reads and serialises read -> compute -> write with the LDS / L2
+// latency exposed every time (the first version: 12 us per 4096-point transform instead of ~3).
+// Only W_4h^j is fetched per butterfly: W_2h^j is its square and W_4h^(j+h) = -i W_4h^j.
 template <bool INV>
 __device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int logn,
                                         const double2 *__restrict__ tw) {
   const int N = 1 << logn;
+  constexpr int kU = 4;  // butterflies in flight per thread
   int s = 0;
   if (logn & 1) {  // a single radix-2 layer first (twiddle 1), then pairs of layers
-    for (int b = threadIdx.x; b < (N >> 1) * count; b += kFftThreads) {
-      const int c = b / (N >> 1), q = b - c * (N >> 1);
-      double2 *zz = z + c * pitch;
-      const int i0 = q << 1, i1 = i0 + 1;
-      const double2 x0 = zz[lpad(i0)], x1 = zz[lpad(i1)];
-      zz[lpad(i0)] = make_double2(x0.x + x1.x, x0.y + x1.y);
-      zz[lpad(i1)] = make_double2(x0.x - x1.x, x0.y - x1.y);
+    const int total = (N >> 1) * count;
+    for (int b0 = threadIdx.x; b0 < total; b0 += kU * kFftThreads) {
+      int at[kU];
+      double2 x0[kU], x1[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int b = b0 + u * kFftThreads;
+        const int c = b >> (logn - 1), q = b & ((N >> 1) - 1);
+        at[u] = b < total ? c * pitch + lpad(q << 1) : -1;  // lpad(2q + 1) = lpad(2q) + 1
+        if (at[u] >= 0) {
+          x0[u] = z[at[u]];
+          x1[u] = z[at[u] + 1];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (at[u] < 0) continue;
+        z[at[u]] = make_double2(x0[u].x + x1[u].x, x0[u].y + x1[u].y);
+        z[at[u] + 1] = make_double2(x0[u].x - x1[u].x, x0[u].y - x1[u].y);
+      }
     }
     __syncthreads();
     s = 1;
   }
   for (; s < logn; s += 2) {  // (logn - s is even here)
-    const int h = 1 << s;                 // half size of the first layer
-    const int st1 = N >> (s + 1);         // W_{2h}^j = W_N^{j st1}
-    const int st2 = N >> (s + 2);         // W_{4h}^j = W_N^{j st2}
-    for (int b = threadIdx.x; b < (N >> 2) * count; b += kFftThreads) {
-      const int c = b / (N >> 2), q = b - c * (N >> 2);
-      double2 *zz = z + c * pitch;
-      const int j = q & (h - 1);
-      const int i0 = ((q >> s) << (s + 2)) + j, i1 = i0 + h, i2 = i1 + h, i3 = i2 + h;
-      double2 w1 = tw[j * st1], w2 = tw[j * st2], w3 = tw[(j + h) * st2];
-      if (INV) {
-        w1.y = -w1.y;
-        w2.y = -w2.y;
-        w3.y = -w3.y;
+    const int h = 1 << s;          // half size of the first layer
+    const int st2 = N >> (s + 2);  // W_{4h}^j = W_N^{j st2}
+    const int total = (N >> 2) * count;
+    for (int b0 = threadIdx.x; b0 < total; b0 += kU * kFftThreads) {
+      int i0[kU], i1[kU], i2[kU], i3[kU];
+      double2 x0[kU], x1[kU], x2[kU], x3[kU], w2[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int b = b0 + u * kFftThreads;
+        const bool live = b < total;
+        const int c = b >> (logn - 2), q = b & ((N >> 2) - 1);
+        const int j = q & (h - 1);
+        const int e0 = ((q >> s) << (s + 2)) + j;
+        const int base = c * pitch;
+        i0[u] = live ? base + lpad(e0) : -1;
+        i1[u] = base + lpad(e0 + h);
+        i2[u] = base + lpad(e0 + 2 * h);
+        i3[u] = base + lpad(e0 + 3 * h);
+        if (live) {
+          w2[u] = tw[j * st2];
+          x0[u] = z[i0[u]];
+          x1[u] = z[i1[u]];
+          x2[u] = z[i2[u]];
+          x3[u] = z[i3[u]];
+        }
       }
-      const double2 x0 = zz[lpad(i0)], x1 = zz[lpad(i1)], x2 = zz[lpad(i2)], x3 = zz[lpad(i3)];
-      const double2 t1 = cmul(x1, w1), t3 = cmul(x3, w1);
-      const double2 a0 = make_double2(x0.x + t1.x, x0.y + t1.y), a1 = make_double2(x0.x - t1.x, x0.y - t1.y);
-      const double2 a2 = make_double2(x2.x + t3.x, x2.y + t3.y), a3 = make_double2(x2.x - t3.x, x2.y - t3.y);
-      const double2 u2 = cmul(a2, w2), u3 = cmul(a3, w3);
-      zz[lpad(i0)] = make_double2(a0.x + u2.x, a0.y + u2.y);
-      zz[lpad(i2)] = make_double2(a0.x - u2.x, a0.y - u2.y);
-      zz[lpad(i1)] = make_double2(a1.x + u3.x, a1.y + u3.y);
-      zz[lpad(i3)] = make_double2(a1.x - u3.x, a1.y - u3.y);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (i0[u] < 0) continue;
+        double2 wb = w2[u];
+        if (INV) wb.y = -wb.y;
+        const double2 wa = cmul(wb, wb);                                                  // W_2h^j
+        const double2 wc = INV ? make_double2(-wb.y, wb.x) : make_double2(wb.y, -wb.x);  // W_4h^(j+h)
+        const double2 t1 = cmul(x1[u], wa), t3 = cmul(x3[u], wa);
+        const double2 a0 = make_double2(x0[u].x + t1.x, x0[u].y + t1.y), a1 = make_double2(x0[u].x - t1.x, x0[u].y - t1.y);
+        const double2 a2 = make_double2(x2[u].x + t3.x, x2[u].y + t3.y), a3 = make_double2(x2[u].x - t3.x, x2[u].y - t3.y);
+        const double2 u2 = cmul(a2, wb), u3 = cmul(a3, wc);
+        z[i0[u]] = make_double2(a0.x + u2.x, a0.y + u2.y);
+        z[i2[u]] = make_double2(a0.x - u2.x, a0.y - u2.y);
+        z[i1[u]] = make_double2(a1.x + u3.x, a1.y + u3.y);
+        z[i3[u]] = make_double2(a1.x - u3.x, a1.y - u3.y);
+      }
     }
     __syncthreads();
   }
