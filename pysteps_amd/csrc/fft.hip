@@ -32,10 +32,16 @@ namespace psh {
 namespace {
 
 constexpr int kFftThreads = 256;
-constexpr int kFftMaxLog = 13;  // 8192 points: 8192 * 16 B * 65/64 = 130 KiB of LDS
+constexpr int kFftMaxLog = 13;  // 8192 points: 128 KiB of LDS
 
-__device__ __forceinline__ int lpad(int i) { return i + (i >> 6); }  // 16-byte elements: spreads strided accesses
-__host__ __device__ constexpr int lds_elems(int n) { return n + (n >> 6) + 1; }
+// LDS index of element i: the low four bits (the 16-byte unit inside a 256-byte LDS row) are mixed
+// with higher index bits, so that the strided accesses of the passes (4^s apart), of the bit-reversed
+// store and of the n-k mirror spread over the banks.  Found by a search over XOR swizzles against all
+// access patterns of lengths 2^10..2^13 (tools/fft_swizzle.py): 1.33 16-byte units per bank and
+// 16-lane group on average, against 2.2 for padding i + (i >> 6); a bijection on every aligned
+// block of 2^12 elements, no padding.
+__device__ __forceinline__ int lpad(int i) { return i ^ (((i >> 4) ^ (i >> 5) ^ (i >> 9)) & 15); }
+__host__ __device__ constexpr int lds_elems(int n) { return n < 16 ? 16 : n; }
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 w) {
   return make_double2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
@@ -64,17 +70,17 @@ __device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int lo
       for (int u = 0; u < kU; ++u) {
         const int b = b0 + u * kFftThreads;
         const int c = b >> (logn - 1), q = b & ((N >> 1) - 1);
-        at[u] = b < total ? c * pitch + lpad(q << 1) : -1;  // lpad(2q + 1) = lpad(2q) + 1
+        at[u] = b < total ? c * pitch + lpad(q << 1) : -1;
         if (at[u] >= 0) {
           x0[u] = z[at[u]];
-          x1[u] = z[at[u] + 1];
+          x1[u] = z[at[u] ^ 1];  // lpad(2q + 1) = lpad(2q) ^ 1: the swizzle only reads bits >= 4
         }
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         if (at[u] < 0) continue;
         z[at[u]] = make_double2(x0[u].x + x1[u].x, x0[u].y + x1[u].y);
-        z[at[u] + 1] = make_double2(x0[u].x - x1[u].x, x0[u].y - x1[u].y);
+        z[at[u] ^ 1] = make_double2(x0[u].x - x1[u].x, x0[u].y - x1[u].y);
       }
     }
     __syncthreads();
