@@ -31,7 +31,14 @@
 namespace psh {
 namespace {
 
-constexpr int kFftThreads = 256;
+constexpr int kFftThreads = 1024;  // launch bound; the launchers pick the count by transform length:
+// one transform wants ~length / 8 threads (measured: 2048 -> 256, 4096 -> 512, 8192 -> 1024 threads;
+// fewer leave the passes latency-bound, more only add barrier cost)
+inline int fft_threads(int points) {
+  int t = points / 8;
+  t = t < 64 ? 64 : t > kFftThreads ? kFftThreads : t;
+  return (t + 63) & ~63;
+}
 constexpr int kFftMaxLog = 13;  // 8192 points: 128 KiB of LDS
 
 // LDS index of element i: the low four bits (the 16-byte unit inside a 256-byte LDS row) are mixed
@@ -63,12 +70,12 @@ __device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int lo
   int s = 0;
   if (logn & 1) {  // a single radix-2 layer first (twiddle 1), then pairs of layers
     const int total = (N >> 1) * count;
-    for (int b0 = threadIdx.x; b0 < total; b0 += kU * kFftThreads) {
+    for (int b0 = threadIdx.x; b0 < total; b0 += kU * static_cast<int>(blockDim.x)) {
       int at[kU];
       double2 x0[kU], x1[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const int b = b0 + u * kFftThreads;
+        const int b = b0 + u * static_cast<int>(blockDim.x);
         const int c = b >> (logn - 1), q = b & ((N >> 1) - 1);
         at[u] = b < total ? c * pitch + lpad(q << 1) : -1;
         if (at[u] >= 0) {
@@ -90,12 +97,12 @@ __device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int lo
     const int h = 1 << s;          // half size of the first layer
     const int st2 = N >> (s + 2);  // W_{4h}^j = W_N^{j st2}
     const int total = (N >> 2) * count;
-    for (int b0 = threadIdx.x; b0 < total; b0 += kU * kFftThreads) {
+    for (int b0 = threadIdx.x; b0 < total; b0 += kU * static_cast<int>(blockDim.x)) {
       int i0[kU], i1[kU], i2[kU], i3[kU];
       double2 x0[kU], x1[kU], x2[kU], x3[kU], w2[kU];
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
-        const int b = b0 + u * kFftThreads;
+        const int b = b0 + u * static_cast<int>(blockDim.x);
         const bool live = b < total;
         const int c = b >> (logn - 2), q = b & ((N >> 2) - 1);
         const int j = q & (h - 1);
@@ -144,11 +151,11 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_r2c(const double *__rest
   const int ra = 2 * blockIdx.x, rb = min(ra + 1, m - 1);
   const int nc = n / 2 + 1;
   const double *xa = x + static_cast<size_t>(ra) * n, *xb = x + static_cast<size_t>(rb) * n;
-  for (int i = threadIdx.x; i < n; i += kFftThreads) z[lpad(bitrev(i, logn))] = make_double2(xa[i], xb[i]);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) z[lpad(bitrev(i, logn))] = make_double2(xa[i], xb[i]);
   __syncthreads();
   fft_lds<false>(z, 0, 1, logn, tw);
   double2 *oa = out + static_cast<size_t>(ra) * nc, *ob = out + static_cast<size_t>(rb) * nc;
-  for (int k = threadIdx.x; k < nc; k += kFftThreads) {
+  for (int k = threadIdx.x; k < nc; k += blockDim.x) {
     const double2 zk = z[lpad(k)], zn = z[lpad((n - k) & (n - 1))];
     oa[k] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
     if (ra + 1 < m) ob[k] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_c2r(const double2 *__res
   const int ra = 2 * blockIdx.x, rb = min(ra + 1, m - 1);
   const int nc = n / 2 + 1, half = n / 2;
   const double2 *ia = in + static_cast<size_t>(ra) * nc, *ib = in + static_cast<size_t>(rb) * nc;
-  for (int k = threadIdx.x; k < nc; k += kFftThreads) {
+  for (int k = threadIdx.x; k < nc; k += blockDim.x) {
     double2 a = ia[k], b = ib[k];
     if (k == 0 || k == half) {
       a.y = 0.0;
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_c2r(const double2 *__res
   __syncthreads();
   fft_lds<true>(z, 0, 1, logn, tw);
   double *oa = out + static_cast<size_t>(ra) * n, *ob = out + static_cast<size_t>(rb) * n;
-  for (int i = threadIdx.x; i < n; i += kFftThreads) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const double2 v = z[lpad(i)];
     oa[i] = v.x * scale;
     if (ra + 1 < m) ob[i] = v.y * scale;
@@ -190,11 +197,11 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_c2c(const double2 *__res
                                                             double2 *__restrict__ out) {
   extern __shared__ double2 z[];
   const double2 *src = in + static_cast<size_t>(blockIdx.x) * n;
-  for (int i = threadIdx.x; i < n; i += kFftThreads) z[lpad(bitrev(i, logn))] = src[i];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) z[lpad(bitrev(i, logn))] = src[i];
   __syncthreads();
   fft_lds<INV>(z, 0, 1, logn, tw);
   double2 *dst = out + static_cast<size_t>(blockIdx.x) * n;
-  for (int i = threadIdx.x; i < n; i += kFftThreads) dst[i] = z[lpad(i)];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = z[lpad(i)];
 }
 
 // ---- columns of an (m, nc) complex array: `cols` adjacent columns per workgroup ---------------------
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__res
   const int c0 = g * cols;
   const int live = min(cols, nc - c0);
   const int pitch = lds_elems(m);
-  for (int idx = threadIdx.x; idx < m * cols; idx += kFftThreads) {
+  for (int idx = threadIdx.x; idx < m * cols; idx += blockDim.x) {
     const int r = idx / cols, c = idx - r * cols;
     double2 v = make_double2(0.0, 0.0);
     if (c < live) {
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__res
   }
   __syncthreads();
   fft_lds<INV>(z, pitch, cols, logm, tw);
-  for (int idx = threadIdx.x; idx < m * cols; idx += kFftThreads) {
+  for (int idx = threadIdx.x; idx < m * cols; idx += blockDim.x) {
     const int r = idx / cols, c = idx - r * cols;
     if (c < live) {
       const double2 v = z[c * pitch + lpad(r)];
@@ -295,11 +302,11 @@ int launch_cols(bool inverse, const double2 *in, int m, int nc, int logm, double
   const size_t lds = static_cast<size_t>(cols) * lds_elems(m) * sizeof(double2);
   if (inverse) {
     if (int rc = allow_lds(fft_cols_c2c<true>, lds)) return rc;
-    hipLaunchKernelGGL(fft_cols_c2c<true>, dim3(gpx * kNumXcd), dim3(kFftThreads), lds, stream, in, m, nc, logm, cols,
+    hipLaunchKernelGGL(fft_cols_c2c<true>, dim3(gpx * kNumXcd), dim3(fft_threads(cols * m / 2)), lds, stream, in, m, nc, logm, cols,
                        tw, scale, out, groups, gpx, weights);
   } else {
     if (int rc = allow_lds(fft_cols_c2c<false>, lds)) return rc;
-    hipLaunchKernelGGL(fft_cols_c2c<false>, dim3(gpx * kNumXcd), dim3(kFftThreads), lds, stream, in, m, nc, logm, cols,
+    hipLaunchKernelGGL(fft_cols_c2c<false>, dim3(gpx * kNumXcd), dim3(fft_threads(cols * m / 2)), lds, stream, in, m, nc, logm, cols,
                        tw, scale, out, groups, gpx, weights);
   }
   PSH_HIP(hipGetLastError());
@@ -325,7 +332,7 @@ extern "C" int psh_fft_rfft2_dev(const double *in_dev, int m, int n, void *out_d
   const size_t lds = static_cast<size_t>(psh::lds_elems(n)) * sizeof(double2);
   if (int rc = psh::allow_lds(psh::fft_rows_r2c, lds)) return rc;
   double2 *out = static_cast<double2 *>(out_dev);
-  hipLaunchKernelGGL(psh::fft_rows_r2c, dim3((m + 1) / 2), dim3(psh::kFftThreads), lds, c.stream, in_dev, m, n, logn, tw,
+  hipLaunchKernelGGL(psh::fft_rows_r2c, dim3((m + 1) / 2), dim3(psh::fft_threads(n)), lds, c.stream, in_dev, m, n, logn, tw,
                      out);
   PSH_HIP(hipGetLastError());
   return psh::launch_cols(false, out, m, n / 2 + 1, logm, 1.0, out, c.stream);
@@ -347,7 +354,7 @@ int fft_irfft2_weighted(const void *spec_dev, const double *weights_dev, int m, 
   if (int rc = twiddles(n, &tw)) return rc;
   const size_t lds = static_cast<size_t>(lds_elems(n)) * sizeof(double2);
   if (int rc = allow_lds(fft_rows_c2r, lds)) return rc;
-  hipLaunchKernelGGL(fft_rows_c2r, dim3((m + 1) / 2), dim3(kFftThreads), lds, c.stream,
+  hipLaunchKernelGGL(fft_rows_c2r, dim3((m + 1) / 2), dim3(fft_threads(n)), lds, c.stream,
                      static_cast<const double2 *>(scratch_dev), m, n, logn, tw,
                      1.0 / (static_cast<double>(m) * static_cast<double>(n)), out_dev);
   PSH_HIP(hipGetLastError());
@@ -392,10 +399,10 @@ extern "C" int psh_fft_c2c2_dev(const void *in_dev, int m, int n, int inverse, v
   double2 *out = static_cast<double2 *>(out_dev);
   if (inverse) {
     if (int rc = psh::allow_lds(psh::fft_rows_c2c<true>, lds)) return rc;
-    hipLaunchKernelGGL(psh::fft_rows_c2c<true>, dim3(m), dim3(psh::kFftThreads), lds, c.stream, in, n, logn, tw, out);
+    hipLaunchKernelGGL(psh::fft_rows_c2c<true>, dim3(m), dim3(psh::fft_threads(n)), lds, c.stream, in, n, logn, tw, out);
   } else {
     if (int rc = psh::allow_lds(psh::fft_rows_c2c<false>, lds)) return rc;
-    hipLaunchKernelGGL(psh::fft_rows_c2c<false>, dim3(m), dim3(psh::kFftThreads), lds, c.stream, in, n, logn, tw, out);
+    hipLaunchKernelGGL(psh::fft_rows_c2c<false>, dim3(m), dim3(psh::fft_threads(n)), lds, c.stream, in, n, logn, tw, out);
   }
   PSH_HIP(hipGetLastError());
   const double scale = inverse ? 1.0 / (static_cast<double>(m) * static_cast<double>(n)) : 1.0;
