@@ -15,10 +15,12 @@ import csv, glob, sys, collections
 out = sys.argv[1]
 agg = collections.OrderedDict()
 for f in sorted(glob.glob(out + "/p*/*/*counter_collection.csv")):
-    rows = [r for r in csv.DictReader(open(f)) if "semilag" in r["Kernel_Name"] or "idw" in r["Kernel_Name"] or "lk_" in r["Kernel_Name"]]
+    keep = ("semilag", "idw", "lk_", "corner_", "vectors_finish", "outliers", "pack_", "fft_", "moments", "standardise")
+    rows = [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in keep)]
     by = collections.defaultdict(list)
     for r in rows:
-        by[(r["Kernel_Name"].split("(")[0][-30:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].replace("psh::", "")
+        by[(name[:40], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k, v in by.items():
         v = v[len(v)//2:]  # steady-state launches
         agg[k] = sum(v) / len(v)
