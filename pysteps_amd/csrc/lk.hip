@@ -854,20 +854,13 @@ __host__ __device__ inline CornerKey make_corner_key(float val, unsigned addr) {
 
 constexpr int kSelRows = 64;  // rows per workgroup (16 per wave): one counter atomic per 64x64 pixels
 
-// v = response at (x, y), loaded by the caller (0 outside the 1-pixel frame goodFeaturesToTrack excludes)
-__device__ __forceinline__ bool corner_keep(const float *__restrict__ eig,
-                                            const float *__restrict__ clean, int m, int n, int x,
-                                            int y, int buffer_mask, float thr, bool any_nan,
-                                            float v) {
-  if (!(v > thr) || v == 0.f) return false;  // THRESH_TOZERO keeps values > thr
-#pragma unroll
-  for (int j = -1; j <= 1; ++j)
-#pragma unroll
-    for (int i = -1; i <= 1; ++i)
-      if (eig[static_cast<size_t>(y + j) * n + (x + i)] > v) return false;  // not the 3x3 maximum
-  return px_allowed(clean, m, n, x, y, buffer_mask, any_nan);
-}
+constexpr int kSelCols = 62;  // columns per wave: 64 lanes minus one halo column on each side
 
+// A wave owns 62 columns x 16 rows: it loads its 18 rows of the response once (all loads in flight
+// together), takes the left / right neighbours from the adjacent lanes and the rows above / below
+// from its own registers - the 3x3 maximum test never goes back to memory (the first version read
+// the eight neighbours with an early exit after each: a chain of dependent loads per row, 46 us for
+// a 64 MiB image).
 __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict__ eig,
                                                         const float *__restrict__ clean, int m,
                                                         int n, int buffer_mask, float quality,
@@ -877,29 +870,38 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
   __shared__ int wave_count[4];
   __shared__ int block_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = blockIdx.x * 64 + lane;
+  const int x = blockIdx.x * kSelCols - 1 + lane;
   const int y_first = blockIdx.y * kSelRows + wave * (kSelRows / 4);
   const float thr = stats[kEigMax] * quality;
   const bool any_nan = stats[kNanCount] > 0.f;
-  // pass 1: which pixels of the wave's 16 rows are candidates (a single global counter saturates
-  // at ~90 atomics/us, so the workgroup reserves its output range with ONE atomic); the ballots
-  // are kept, the response image is streamed once
   constexpr int kRows = kSelRows / 4;
-  unsigned long long masks[kRows];
-  int mine = 0;
-  // the responses of the wave's 16 rows first (independent loads in flight together: the row loop
-  // below branches on every value and would otherwise wait for them one after the other)
-  float vs[kRows];
+  const bool col_in = x >= 0 && x < n;
+  float v[kRows + 2], m3[kRows + 2], hmax[kRows + 2];
 #pragma unroll
-  for (int r = 0; r < kRows; ++r) {
-    const int yr = y_first + r;
-    const bool in_frame = x >= 1 && x < n - 1 && yr >= 1 && yr < m - 1 && yr >= band.lo && yr < band.hi;
-    vs[r] = in_frame ? eig[static_cast<size_t>(yr) * n + x] : 0.f;
+  for (int q = 0; q < kRows + 2; ++q) {
+    const int y = y_first - 1 + q;
+    v[q] = (col_in && y >= 0 && y < m) ? eig[static_cast<size_t>(y) * n + x] : 0.f;
   }
 #pragma unroll
+  for (int q = 0; q < kRows + 2; ++q) {
+    const float left = __shfl_up(v[q], 1), right = __shfl_down(v[q], 1);
+    hmax[q] = fmaxf(left, right);  // (lanes 0 and 63 are halo: never candidates)
+    m3[q] = fmaxf(v[q], hmax[q]);
+  }
+  // pass 1: which pixels of the wave's 16 rows are candidates (a single global counter saturates
+  // at ~90 atomics/us, so the workgroup reserves its output range with ONE atomic)
+  unsigned long long masks[kRows];
+  int mine = 0;
+  const bool col_ok = lane >= 1 && lane <= kSelCols && x >= 1 && x < n - 1;
+#pragma unroll
   for (int r = 0; r < kRows; ++r) {
     const int yr = y_first + r;
-    masks[r] = __ballot(corner_keep(eig, clean, m, n, x, yr, buffer_mask, thr, any_nan, vs[r]));
+    const float c = v[r + 1];
+    bool keep = col_ok && yr >= 1 && yr < m - 1 && yr >= band.lo && yr < band.hi;
+    keep = keep && c > thr && c != 0.f;                                         // THRESH_TOZERO keeps values > thr
+    keep = keep && !(fmaxf(hmax[r + 1], fmaxf(m3[r], m3[r + 2])) > c);          // the 3x3 maximum
+    keep = keep && px_allowed(clean, m, n, x, yr, buffer_mask, any_nan);
+    masks[r] = __ballot(keep);
     mine += __popcll(masks[r]);
   }
   if (lane == 0) wave_count[wave] = mine;
@@ -920,8 +922,7 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
     const int y = y_first + r;
     if ((mask >> lane) & 1ull) {
       const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
-      if (at < cap)
-        out[at] = make_corner_key(eig[static_cast<size_t>(y) * n + x], static_cast<unsigned>(y + band.y_org) * n + x);
+      if (at < cap) out[at] = make_corner_key(v[r + 1], static_cast<unsigned>(y + band.y_org) * n + x);
     }
     pos += __popcll(mask);
   }
@@ -1710,7 +1711,7 @@ int psh_lk_band_select_dev(const float *eig_dev, const float *clean_dev, int m, 
   const size_t off = static_cast<size_t>(e0) * n;
   PSH_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), c.stream));
   PSH_HIP(hipMemsetAsync(keys_dev, 0, static_cast<size_t>(cap) * sizeof(psh::CornerKey), c.stream));
-  const dim3 sgrid((n + 63) / 64, (ms + psh::kSelRows - 1) / psh::kSelRows);
+  const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (ms + psh::kSelRows - 1) / psh::kSelRows);
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig_dev + off, clean_dev + off, ms, n,
                      buffer_mask, static_cast<float>(quality_level), stats_dev, keys_dev, cap, count_dev,
                      psh::Band{e0, r0 - e0, r1 - e0});
@@ -1836,7 +1837,7 @@ int corner_candidates(const CornerWs &w, void *ws, const unsigned char *feature_
   hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, w.nb, stats_dev,
                      static_cast<int>(psh::kEigMax), cnt, 1, reinterpret_cast<int *>(base + w.off_ord),
                      static_cast<int>(psh::corner_order_clear_bytes() / sizeof(int)));
-  const dim3 sgrid((n + 63) / 64, (m + psh::kSelRows - 1) / psh::kSelRows);
+  const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (m + psh::kSelRows - 1) / psh::kSelRows);
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n, buffer_mask,
                      static_cast<float>(quality_level), stats_dev, raw, w.cap, cnt, psh::Band{0, 0, m});
   PSH_HIP(hipGetLastError());
