@@ -852,57 +852,66 @@ __host__ __device__ inline CornerKey make_corner_key(float val, unsigned addr) {
   return (static_cast<CornerKey>(bits) << 32) | addr;
 }
 
-constexpr int kSelRows = 64;  // rows per workgroup (16 per wave): one counter atomic per 64x64 pixels
+constexpr int kSelRows = 64;  // 4 waves x 16 rows: the row unit of lk_corner_select (x kSelGroups per workgroup)
 
-constexpr int kSelCols = 62;  // columns per wave: 64 lanes minus one halo column on each side
+constexpr int kSelCols = 62;    // columns per wave: 64 lanes minus one halo column on each side
+constexpr int kSelGroups = 4;   // 16-row groups a wave works through: a workgroup covers 62 x 256 pixels
 
-// A wave owns 62 columns x 16 rows: it loads its 18 rows of the response once (all loads in flight
-// together), takes the left / right neighbours from the adjacent lanes and the rows above / below
-// from its own registers - the 3x3 maximum test never goes back to memory (the first version read
-// the eight neighbours with an early exit after each: a chain of dependent loads per row, 46 us for
-// a 64 MiB image).
+// A wave owns 62 columns and works through four groups of 16 rows: for each it loads the 18 rows
+// of the response it needs (all loads in flight together), takes the left / right neighbours from
+// the adjacent lanes and the rows above / below from its own registers - the 3x3 maximum test never
+// goes back to memory.  The candidates' masks wait in LDS until the workgroup has reserved its
+// output range with ONE atomic: a single global counter takes ~90 atomics per microsecond, which is
+// what bounded the kernel while a workgroup covered 64 x 64 pixels (4096 atomics = 46 us at 4096^2,
+// whatever the kernel did otherwise).
 __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict__ eig,
                                                         const float *__restrict__ clean, int m,
                                                         int n, int buffer_mask, float quality,
                                                         const float *__restrict__ stats,
                                                         CornerKey *__restrict__ out, int cap,
                                                         int *__restrict__ count, Band band) {
+  constexpr int kRows = kSelRows / 4;  // rows per group
+  __shared__ unsigned long long s_mask[4][kSelGroups * kRows];
   __shared__ int wave_count[4];
   __shared__ int block_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = blockIdx.x * kSelCols - 1 + lane;
-  const int y_first = blockIdx.y * kSelRows + wave * (kSelRows / 4);
+  const int y_wave = (blockIdx.y * 4 + wave) * (kSelGroups * kRows);
   const float thr = stats[kEigMax] * quality;
   const bool any_nan = stats[kNanCount] > 0.f;
-  constexpr int kRows = kSelRows / 4;
   const bool col_in = x >= 0 && x < n;
-  float v[kRows + 2], m3[kRows + 2], hmax[kRows + 2];
-#pragma unroll
-  for (int q = 0; q < kRows + 2; ++q) {
-    const int y = y_first - 1 + q;
-    v[q] = (col_in && y >= 0 && y < m) ? eig[static_cast<size_t>(y) * n + x] : 0.f;
-  }
-#pragma unroll
-  for (int q = 0; q < kRows + 2; ++q) {
-    const float left = __shfl_up(v[q], 1), right = __shfl_down(v[q], 1);
-    hmax[q] = fmaxf(left, right);  // (lanes 0 and 63 are halo: never candidates)
-    m3[q] = fmaxf(v[q], hmax[q]);
-  }
-  // pass 1: which pixels of the wave's 16 rows are candidates (a single global counter saturates
-  // at ~90 atomics/us, so the workgroup reserves its output range with ONE atomic)
-  unsigned long long masks[kRows];
-  int mine = 0;
   const bool col_ok = lane >= 1 && lane <= kSelCols && x >= 1 && x < n - 1;
+  int mine = 0;
+  for (int g = 0; g < kSelGroups; ++g) {
+    const int y_first = y_wave + g * kRows;
+    if (y_first >= m) {  // (uniform) nothing below the image
+      if (lane < kRows) s_mask[wave][g * kRows + lane] = 0ull;
+      continue;
+    }
+    float v[kRows + 2], m3[kRows + 2], hmax[kRows + 2];
 #pragma unroll
-  for (int r = 0; r < kRows; ++r) {
-    const int yr = y_first + r;
-    const float c = v[r + 1];
-    bool keep = col_ok && yr >= 1 && yr < m - 1 && yr >= band.lo && yr < band.hi;
-    keep = keep && c > thr && c != 0.f;                                         // THRESH_TOZERO keeps values > thr
-    keep = keep && !(fmaxf(hmax[r + 1], fmaxf(m3[r], m3[r + 2])) > c);          // the 3x3 maximum
-    keep = keep && px_allowed(clean, m, n, x, yr, buffer_mask, any_nan);
-    masks[r] = __ballot(keep);
-    mine += __popcll(masks[r]);
+    for (int q = 0; q < kRows + 2; ++q) {
+      const int y = y_first - 1 + q;
+      v[q] = (col_in && y >= 0 && y < m) ? eig[static_cast<size_t>(y) * n + x] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < kRows + 2; ++q) {
+      const float left = __shfl_up(v[q], 1), right = __shfl_down(v[q], 1);
+      hmax[q] = fmaxf(left, right);  // (lanes 0 and 63 are halo: never candidates)
+      m3[q] = fmaxf(v[q], hmax[q]);
+    }
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const int yr = y_first + r;
+      const float c = v[r + 1];
+      bool keep = col_ok && yr >= 1 && yr < m - 1 && yr >= band.lo && yr < band.hi;
+      keep = keep && c > thr && c != 0.f;                                 // THRESH_TOZERO keeps values > thr
+      keep = keep && !(fmaxf(hmax[r + 1], fmaxf(m3[r], m3[r + 2])) > c);  // the 3x3 maximum
+      keep = keep && px_allowed(clean, m, n, x, yr, buffer_mask, any_nan);
+      const unsigned long long mask = __ballot(keep);
+      if (lane == 0) s_mask[wave][g * kRows + r] = mask;
+      mine += __popcll(mask);
+    }
   }
   if (lane == 0) wave_count[wave] = mine;
   __syncthreads();
@@ -914,15 +923,15 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
   int pos = block_base;
   for (int w = 0; w < wave; ++w) pos += wave_count[w];
   if (mine == 0) return;
-  // pass 2: the kept pixels get their destination
-#pragma unroll
-  for (int r = 0; r < kRows; ++r) {
-    const unsigned long long mask = masks[r];
-    if (mask == 0) continue;
-    const int y = y_first + r;
+  // pass 2: the kept pixels get their destination (their responses are read again: a few per row)
+  for (int r = 0; r < kSelGroups * kRows; ++r) {
+    const unsigned long long mask = s_mask[wave][r];
+    if (mask == 0ull) continue;
+    const int y = y_wave + r;
     if ((mask >> lane) & 1ull) {
       const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
-      if (at < cap) out[at] = make_corner_key(v[r + 1], static_cast<unsigned>(y + band.y_org) * n + x);
+      if (at < cap)
+        out[at] = make_corner_key(eig[static_cast<size_t>(y) * n + x], static_cast<unsigned>(y + band.y_org) * n + x);
     }
     pos += __popcll(mask);
   }
@@ -1711,7 +1720,7 @@ int psh_lk_band_select_dev(const float *eig_dev, const float *clean_dev, int m, 
   const size_t off = static_cast<size_t>(e0) * n;
   PSH_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), c.stream));
   PSH_HIP(hipMemsetAsync(keys_dev, 0, static_cast<size_t>(cap) * sizeof(psh::CornerKey), c.stream));
-  const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (ms + psh::kSelRows - 1) / psh::kSelRows);
+  const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (ms + psh::kSelRows * psh::kSelGroups - 1) / (psh::kSelRows * psh::kSelGroups));
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig_dev + off, clean_dev + off, ms, n,
                      buffer_mask, static_cast<float>(quality_level), stats_dev, keys_dev, cap, count_dev,
                      psh::Band{e0, r0 - e0, r1 - e0});
@@ -1837,7 +1846,7 @@ int corner_candidates(const CornerWs &w, void *ws, const unsigned char *feature_
   hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, w.nb, stats_dev,
                      static_cast<int>(psh::kEigMax), cnt, 1, reinterpret_cast<int *>(base + w.off_ord),
                      static_cast<int>(psh::corner_order_clear_bytes() / sizeof(int)));
-  const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (m + psh::kSelRows - 1) / psh::kSelRows);
+  const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (m + psh::kSelRows * psh::kSelGroups - 1) / (psh::kSelRows * psh::kSelGroups));
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n, buffer_mask,
                      static_cast<float>(quality_level), stats_dev, raw, w.cap, cnt, psh::Band{0, 0, m});
   PSH_HIP(hipGetLastError());
