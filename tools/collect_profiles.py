@@ -7,7 +7,7 @@ tag, rnd, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
 src = os.path.join("gpurun_out", tag)
 dst = os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-for name in ("bench.json", "pytest_gpu.txt", "gaps.txt", "lk_timeline.txt", "fft_quick.json"):
+for name in ("bench.json", "pytest_gpu.txt", "gaps.txt", "lk_timeline.txt", "fft_quick.json", "other_shapes.jsonl"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (prefix, name)))
 for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):

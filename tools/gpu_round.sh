@@ -19,3 +19,8 @@ timeout 300 python tools/fft_quick.py 2048 4096 2>&1 | tail -1 > $OUT/fft_quick.
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT
+# the other BASELINE shapes (one bench line each, no CPU legs): config 2, config 5 on one GPU, config 1
+Q="--steps 10 --warmup 3 --no-cpu-baseline --no-host-path --no-members-leg --no-spectral"
+{ timeout 200 python bench.py --size 2048 --frames 3 --leadtimes 12 --n-iter 3 $Q 2>/dev/null
+  timeout 300 python bench.py --size 8192 --frames 2 --leadtimes 36 $Q 2>/dev/null
+  timeout 200 python bench.py --size 512 --frames 2 --leadtimes 6 $Q 2>/dev/null; } > $OUT/other_shapes.jsonl
