@@ -130,6 +130,7 @@ struct IdwDyn {
 
 // ---- FFTs (fft.hip) -----------------------------------------------------------
 bool fft_shape_supported(int m, int n);
+void fft_release();  // frees the twiddle tables (psh_shutdown)
 int fft_irfft2_weighted(const void *spec_dev, const double *weights_dev, int m, int n, double *out_dev,
                         void *scratch_dev);
 

@@ -250,8 +250,13 @@ int ilog2_exact(int v) {
 }
 
 // twiddle table of a length, device resident, computed once (lock held by the callers)
-int twiddles(int n, const double2 **tw_out) {
+std::map<int, double2 *> &twiddle_cache() {
   static std::map<int, double2 *> cache;
+  return cache;
+}
+
+int twiddles(int n, const double2 **tw_out) {
+  std::map<int, double2 *> &cache = twiddle_cache();
   auto it = cache.find(n);
   if (it != cache.end()) {
     *tw_out = it->second;
@@ -337,6 +342,13 @@ extern "C" int psh_fft_rfft2_dev(const double *in_dev, int m, int n, void *out_d
   PSH_HIP(hipGetLastError());
   return psh::launch_cols(false, out, m, n / 2 + 1, logm, 1.0, out, c.stream);
 }
+
+namespace psh {
+void fft_release() {  // psh_shutdown: the tables belong to the device that is being released
+  for (auto &kv : twiddle_cache()) (void)hipFree(kv.second);
+  twiddle_cache().clear();
+}
+}  // namespace psh
 
 // irfft2(spectrum * weights) -> real (m, n); weights (m, n/2+1) float64 or nullptr; the spectrum is
 // left untouched (the column pass writes into `scratch`, (m, n/2+1) complex128).  Lock held.

@@ -214,6 +214,7 @@ int psh_shutdown(void) {
   psh::release_cache();
   psh::pinned_release_cache();
   psh::release_persistent_pinned();
+  psh::fft_release();
   if (c.scratch) (void)hipFree(c.scratch);
   if (c.pinned) (void)hipHostFree(c.pinned);
   (void)hipStreamDestroy(c.stream);
