@@ -419,6 +419,18 @@ int psh_cascade_recompose_dev(const double *levels_dev, int nlevels, int m, int 
                               const double *stds_host, double field_mean, double *out_dev);
 int psh_noise_filter_dev(const double *white_dev, const double *filter_dev, int m, int n, double *out_dev);
 
+/* ---- empirical-CDF probability matching of the member loops (csrc/probmatch.hip) -------- *
+ *  psh_probmatch_dev  pysteps/postprocessing/probmatching.py:55-140, nonparam_match_empirical_cdf(initial,
+ *      target) with ignore_indices=None (nowcasts/steps.py:1199, sprog.py:421, sseps.py:783,804): out[i] =
+ *      sorted(target')[rank of initial[i]], pixels at the minimum of initial -> minimum of target; target' =
+ *      target with its NaNs at the minimum and, if it has more wet pixels than initial, everything below
+ *      np.percentile(target, 100 * (1 - wet fraction of initial)) at the minimum.  count float64 values
+ *      each, out must not overlap the inputs.  Tied wet values of initial are ranked in pixel order.
+ *      The call waits for the result's status: PSH_EINVAL with the reference's messages (initial all NaN /
+ *      not finite), PSH_EUNSUPPORTED for inputs left to the reference (more than 16384 wet values tied or
+ *      in one of the 2^20 value buckets, infinities or no finite value in target). */
+int psh_probmatch_dev(const double *initial_dev, const double *target_dev, size_t count, double *out_dev);
+
 /* ---- multi-GPU: RCCL over xGMI, one rank (process) per GPU ------------------ *
  * The reference has no communication layer (single process, optional dask threads:
  * pysteps/nowcasts/utils.py:464-471); members / fields shard across GPUs with ONE

@@ -1,0 +1,523 @@
+// Empirical-CDF probability matching on the device:
+// pysteps/postprocessing/probmatching.py:55-140, nonparam_match_empirical_cdf(initial, target) with
+// ignore_indices=None, as the member loops call it (nowcasts/steps.py:1199, sprog.py:421,
+// sseps.py:783,804).
+//
+// The reference argsorts both arrays (two O(N log N) host sorts of the whole grid).  Only two things
+// are needed from them: the sorted values of the target and the rank of every pixel of the initial
+// array - and in both arrays the "zeros" (pixels at the minimum, NaNs of the target) form one block of
+// equal keys at the front whose internal order never reaches the output (:127-128).  So both arrays
+// are ranked by one bucket pass over their wet values only:
+//
+//   stats      min / max / NaN / inf counts                     -> zero value z, bucket scale
+//   hist       bucket b = floor((v - z) * 2^20 / (max - z)), monotone in v, count per bucket
+//              (one atomic per run of equal buckets inside a wave)
+//   scan       bucket starts (three small kernels), wet count, list of the buckets above 256 values
+//   scatter    values (and pixel indices) to their bucket's segment
+//   rank       position inside the segment by counting the smaller values of the same bucket
+//              (one thread per value; the listed large buckets by one workgroup each: a single-valued
+//              bucket - quantised observations - needs no counting at all)
+//
+// target: sorted wet values tw.  initial: rank r of every wet pixel, ties in pixel order (what
+// argsort(kind="stable") gives; the reference's default quicksort leaves the order of tied WET
+// values unspecified, see oracle/probmatch.py), and the output is written straight from it:
+//   R = zeros_initial + r,  out = R < zeros_target ? z_target : tw[R - zeros_target],
+// with the wet-area adjustment of :105-108 applied on the fly (out < p -> z_target; replacing the
+// values below a threshold by the minimum keeps the sorted order).  p is np.percentile's "linear"
+// method evaluated by one thread with the operation order of numpy (no contraction).
+//
+// Not handled here (PSH_EUNSUPPORTED, the Python shim hands those calls to the reference): more than
+// 16384 values in one bucket that are not all equal (pathological spread), more than 16384 tied wet
+// values in the initial array, infinities in the target.
+#include <algorithm>
+
+#include "common.h"
+
+namespace psh {
+namespace {
+
+constexpr unsigned kBins = 1u << 20;
+constexpr unsigned kScanBlock = 1024;  // buckets per workgroup of the scan kernels
+constexpr unsigned kScanBlocks = kBins / kScanBlock;
+constexpr unsigned kSmallBin = 256;    // up to here one thread ranks its value alone
+constexpr unsigned kLargeLimit = 16384;
+constexpr int kThreads = 256;
+constexpr int kGrid = 2048;
+
+enum { kStOk = 0, kStAllNan = 1, kStNonFinite = 2, kStTarget = 3, kStTies = 4 };
+
+// index 0: initial array, 1: target array
+struct PmHeader {
+  unsigned long long min_key[2], max_key[2];
+  unsigned int n_nan[2], n_inf[2];
+  unsigned int wet[2], n_large[2], max_bin[2];
+  int status, adjust;
+  double z[2], scale[2], p;
+};
+
+__device__ __forceinline__ unsigned long long key_of(double v) {
+  const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double value_of(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double(static_cast<long long>(b));
+}
+
+__device__ __forceinline__ unsigned bin_of(double v, double z, double scale) {
+#pragma clang fp contract(off)
+  const double f = (v - z) * scale;
+  return f >= static_cast<double>(kBins - 1) ? kBins - 1 : static_cast<unsigned>(f);
+}
+
+__global__ void pm_init(PmHeader *h) {
+  for (int y = 0; y < 2; ++y) {
+    h->min_key[y] = ~0ull;
+    h->max_key[y] = 0ull;
+    h->n_nan[y] = h->n_inf[y] = h->wet[y] = h->n_large[y] = h->max_bin[y] = 0u;
+    h->z[y] = h->scale[y] = 0.0;
+  }
+  h->status = kStOk;
+  h->adjust = 0;
+  h->p = 0.0;
+}
+
+__global__ __launch_bounds__(kThreads) void pm_stats(const double *__restrict__ a0, const double *__restrict__ a1,
+                                                     size_t n, PmHeader *h) {
+  const int y = blockIdx.y;
+  const double *a = y ? a1 : a0;
+  double mn = INFINITY, mx = -INFINITY;
+  unsigned nn = 0, ni = 0;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+    const double v = a[i];
+    if (v != v) {
+      ++nn;
+    } else {
+      ni += (v == INFINITY || v == -INFINITY) ? 1u : 0u;
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const double omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+    nn += __shfl_xor(nn, d);
+    ni += __shfl_xor(ni, d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (mn <= mx) {  // at least one value that is not NaN
+      atomicMin(&h->min_key[y], key_of(mn));
+      atomicMax(&h->max_key[y], key_of(mx));
+    }
+    if (nn) atomicAdd(&h->n_nan[y], nn);
+    if (ni) atomicAdd(&h->n_inf[y], ni);
+  }
+}
+
+__global__ void pm_prepare(PmHeader *h, size_t n) {
+  // :81-82 (only NaNs), :93-96 (any non-finite value left: without ignore_indices every NaN / inf)
+  if (h->n_nan[0] == n) {
+    h->status = kStAllNan;
+    return;
+  }
+  if (h->n_nan[0] + h->n_inf[0] > 0) {
+    h->status = kStNonFinite;
+    return;
+  }
+  if (h->n_nan[1] == n || h->n_inf[1] > 0) {
+    h->status = kStTarget;
+    return;
+  }
+  for (int y = 0; y < 2; ++y) {
+    const double z = value_of(h->min_key[y]), mx = value_of(h->max_key[y]);  // :91, :101 (np.nanmin)
+    h->z[y] = z;
+    const double range = mx - z;  // may overflow to inf: scale 0, everything in bucket 0
+    h->scale[y] = mx > z ? static_cast<double>(kBins) / range : 0.0;
+  }
+}
+
+// one atomic per run of equal buckets inside the wave; returns the value the atomic gave the run's
+// first lane plus the lane's offset in the run (slot for the scatter; unused by the histogram)
+__device__ __forceinline__ unsigned run_atomic_add(unsigned *table, unsigned bin, bool wet) {
+  const int lane = threadIdx.x & 63;
+  const unsigned key = wet ? bin : 0xffffffffu;
+  const unsigned prev = __shfl_up(key, 1);
+  const bool head = lane == 0 || prev != key;
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+  const int len = above ? __ffsll(static_cast<long long>(above)) : 64 - lane;  // up to the next head
+  unsigned base = 0;
+  if (head && wet) base = atomicAdd(&table[bin], static_cast<unsigned>(len));
+  const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  const int head_lane = 63 - __clzll(static_cast<long long>(below));
+  return __shfl(base, head_lane) + static_cast<unsigned>(lane - head_lane);
+}
+
+__global__ __launch_bounds__(kThreads) void pm_hist(const double *__restrict__ a0, const double *__restrict__ a1,
+                                                    size_t n, const PmHeader *__restrict__ h, unsigned *count) {
+  if (h->status != kStOk) return;
+  const int y = blockIdx.y;
+  const double *a = y ? a1 : a0;
+  const double z = h->z[y], scale = h->scale[y];
+  unsigned *table = count + static_cast<size_t>(y) * kBins;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i0 = static_cast<size_t>(blockIdx.x) * kThreads; i0 < n; i0 += stride) {
+    const size_t i = i0 + threadIdx.x;
+    const double v = i < n ? a[i] : z;
+    const bool wet = v > z;  // false for NaN
+    (void)run_atomic_add(table, wet ? bin_of(v, z, scale) : 0u, wet);
+  }
+}
+
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// inclusive scan over the workgroup (NW waves); *total = sum over the workgroup
+template <int NW>
+__device__ __forceinline__ unsigned block_incl_scan(unsigned v, unsigned *s_wave, unsigned *total) {
+  const int w = threadIdx.x >> 6;
+  unsigned incl = wave_incl_scan(v);
+  if ((threadIdx.x & 63) == 63) s_wave[w] = incl;
+  __syncthreads();
+  unsigned add = 0, all = 0;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const unsigned s = s_wave[k];
+    add += k < w ? s : 0u;
+    all += s;
+  }
+  __syncthreads();
+  *total = all;
+  return incl + add;
+}
+
+__global__ __launch_bounds__(kThreads) void pm_bin_sums(const unsigned *__restrict__ count, unsigned *sums) {
+  __shared__ unsigned s_wave[kThreads / 64];
+  const size_t base = static_cast<size_t>(blockIdx.y) * kBins + static_cast<size_t>(blockIdx.x) * kScanBlock;
+  const uint4 c = reinterpret_cast<const uint4 *>(count + base)[threadIdx.x];
+  unsigned total;
+  (void)block_incl_scan<kThreads / 64>(c.x + c.y + c.z + c.w, s_wave, &total);
+  if (threadIdx.x == 0) sums[blockIdx.y * kScanBlocks + blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanBlocks) void pm_scan_sums(const unsigned *__restrict__ sums, unsigned *offs,
+                                                            PmHeader *h) {
+  __shared__ unsigned s_wave[kScanBlocks / 64];
+  const unsigned v = sums[blockIdx.x * kScanBlocks + threadIdx.x];
+  unsigned total;
+  const unsigned incl = block_incl_scan<kScanBlocks / 64>(v, s_wave, &total);
+  offs[blockIdx.x * kScanBlocks + threadIdx.x] = incl - v;
+  if (threadIdx.x == 0) h->wet[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kThreads) void pm_bin_starts(const unsigned *__restrict__ count,
+                                                          const unsigned *__restrict__ offs, unsigned *start,
+                                                          unsigned *cursor, unsigned *large, unsigned large_cap,
+                                                          PmHeader *h) {
+  __shared__ unsigned s_wave[kThreads / 64];
+  const int y = blockIdx.y;
+  const size_t base = static_cast<size_t>(y) * kBins + static_cast<size_t>(blockIdx.x) * kScanBlock;
+  const uint4 c = reinterpret_cast<const uint4 *>(count + base)[threadIdx.x];
+  const unsigned mine = c.x + c.y + c.z + c.w;
+  unsigned total;
+  const unsigned incl = block_incl_scan<kThreads / 64>(mine, s_wave, &total);
+  uint4 s;
+  s.x = offs[y * kScanBlocks + blockIdx.x] + incl - mine;
+  s.y = s.x + c.x;
+  s.z = s.y + c.y;
+  s.w = s.z + c.z;
+  reinterpret_cast<uint4 *>(start + base)[threadIdx.x] = s;
+  reinterpret_cast<uint4 *>(cursor + base)[threadIdx.x] = s;
+  const unsigned cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (cs[k] > kSmallBin) {
+      const unsigned at = atomicAdd(&h->n_large[y], 1u);
+      if (at < large_cap)
+        large[static_cast<size_t>(y) * large_cap + at] = blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
+      atomicMax(&h->max_bin[y], cs[k]);
+    }
+  }
+}
+
+// IDX: the initial array (pixel indices travel with the values, the dry pixels get their output here)
+template <bool IDX>
+__global__ __launch_bounds__(kThreads) void pm_scatter(const double *__restrict__ a, size_t n,
+                                                       const PmHeader *__restrict__ h, unsigned *cursor,
+                                                       double *__restrict__ sval, unsigned *__restrict__ sidx,
+                                                       double *__restrict__ out) {
+  if (h->status != kStOk) return;
+  constexpr int y = IDX ? 0 : 1;
+  const double z = h->z[y], scale = h->scale[y], z_trg = h->z[1];
+  unsigned *table = cursor + static_cast<size_t>(y) * kBins;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i0 = static_cast<size_t>(blockIdx.x) * kThreads; i0 < n; i0 += stride) {
+    const size_t i = i0 + threadIdx.x;
+    const double v = i < n ? a[i] : z;
+    const bool wet = v > z;
+    const unsigned slot = run_atomic_add(table, wet ? bin_of(v, z, scale) : 0u, wet);
+    if (wet) {
+      sval[slot] = v;
+      if (IDX) sidx[slot] = static_cast<unsigned>(i);
+    } else if (IDX && i < n) {
+      out[i] = z_trg;  // :127-128
+    }
+  }
+}
+
+// output of one wet pixel of the initial array from its rank among the wet pixels
+__device__ __forceinline__ void pm_emit(const PmHeader *__restrict__ h, size_t n, const double *__restrict__ tw,
+                                        double *__restrict__ out, unsigned pixel, unsigned rank_wet) {
+  const size_t r = (n - h->wet[0]) + rank_wet, zeros_trg = n - h->wet[1];
+  double val = r < zeros_trg ? h->z[1] : tw[r - zeros_trg];
+  if (h->adjust && val < h->p) val = h->z[1];  // :108
+  out[pixel] = val;
+}
+
+template <bool IDX>
+__global__ __launch_bounds__(kThreads) void pm_rank_small(const PmHeader *__restrict__ h, size_t n,
+                                                          const unsigned *__restrict__ count,
+                                                          const unsigned *__restrict__ start,
+                                                          const double *__restrict__ sval,
+                                                          const unsigned *__restrict__ sidx, double *__restrict__ tw,
+                                                          double *__restrict__ out) {
+  if (h->status != kStOk) return;
+  constexpr int y = IDX ? 0 : 1;
+  const double z = h->z[y], scale = h->scale[y];
+  const unsigned wet = h->wet[y];
+  count += static_cast<size_t>(y) * kBins;
+  start += static_cast<size_t>(y) * kBins;
+  const unsigned stride = gridDim.x * kThreads;
+  for (unsigned s = blockIdx.x * kThreads + threadIdx.x; s < wet; s += stride) {
+    const double v = sval[s];
+    const unsigned b = bin_of(v, z, scale), c = count[b];
+    if (c > kSmallBin) continue;  // pm_rank_large
+    const unsigned st = start[b];
+    const unsigned me = IDX ? sidx[s] : s;
+    unsigned less = 0;
+    for (unsigned j = st; j < st + c; ++j) {
+      const double vj = sval[j];
+      if (vj < v) {
+        ++less;
+      } else if (vj == v) {
+        less += (IDX ? sidx[j] : j) < me ? 1u : 0u;
+      }
+    }
+    if (IDX) {
+      pm_emit(h, n, tw, out, me, st + less);
+    } else {
+      tw[st + less] = v;
+    }
+  }
+}
+
+template <bool IDX>
+__global__ __launch_bounds__(kThreads) void pm_rank_large(PmHeader *h, size_t n, const unsigned *__restrict__ count,
+                                                          const unsigned *__restrict__ start,
+                                                          const unsigned *__restrict__ large, unsigned large_cap,
+                                                          const double *__restrict__ sval,
+                                                          const unsigned *__restrict__ sidx, double *__restrict__ tw,
+                                                          double *__restrict__ out) {
+  __shared__ double s_mn[kThreads / 64], s_mx[kThreads / 64];
+  if (h->status != kStOk) return;
+  constexpr int y = IDX ? 0 : 1;
+  count += static_cast<size_t>(y) * kBins;
+  start += static_cast<size_t>(y) * kBins;
+  large += static_cast<size_t>(y) * large_cap;
+  const unsigned n_large = h->n_large[y] < large_cap ? h->n_large[y] : large_cap;
+  for (unsigned li = blockIdx.x; li < n_large; li += gridDim.x) {
+    const unsigned b = large[li], c = count[b], st = start[b];
+    double mn = INFINITY, mx = -INFINITY;
+    for (unsigned j = threadIdx.x; j < c; j += kThreads) {
+      const double v = sval[st + j];
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const double omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
+      mn = omn < mn ? omn : mn;
+      mx = omx > mx ? omx : mx;
+    }
+    __syncthreads();  // the previous bucket's readers of s_mn / s_mx are done
+    if ((threadIdx.x & 63) == 0) {
+      s_mn[threadIdx.x >> 6] = mn;
+      s_mx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    mn = s_mn[0];
+    mx = s_mx[0];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) {
+      mn = s_mn[w] < mn ? s_mn[w] : mn;
+      mx = s_mx[w] > mx ? s_mx[w] : mx;
+    }
+    const bool single = mn == mx;
+    if (!IDX && single) {  // equal values: already sorted
+      for (unsigned j = threadIdx.x; j < c; j += kThreads) tw[st + j] = mn;
+      continue;
+    }
+    if (c > kLargeLimit) {
+      if (threadIdx.x == 0) atomicExch(&h->status, kStTies);
+      continue;
+    }
+    for (unsigned e = threadIdx.x; e < c; e += kThreads) {
+      const double v = sval[st + e];
+      const unsigned me = IDX ? sidx[st + e] : st + e;
+      unsigned less = 0;
+      for (unsigned j = st; j < st + c; ++j) {
+        const double vj = sval[j];
+        if (vj < v) {
+          ++less;
+        } else if (vj == v) {
+          less += (IDX ? sidx[j] : j) < me ? 1u : 0u;
+        }
+      }
+      if (IDX) {
+        pm_emit(h, n, tw, out, me, st + less);
+      } else {
+        tw[st + less] = v;
+      }
+    }
+  }
+}
+
+// :104-108: the wet area of the target above that of the initial array -> p = np.percentile(target,
+// 100 * (1 - war)), method "linear" (numpy/lib/_function_base_impl.py: virtual index (n - 1) * q,
+// _get_indexes, _lerp), every operation in numpy's order and unfused
+__global__ void pm_threshold(PmHeader *h, size_t n, const double *__restrict__ tw) {
+#pragma clang fp contract(off)
+  if (h->status != kStOk) return;
+  const unsigned wi = h->wet[0], wt = h->wet[1];
+  if (wt <= wi) return;
+  const size_t zeros_trg = n - wt;
+  const double war = static_cast<double>(wi) / static_cast<double>(n);
+  const double one_minus = 1.0 - war;
+  const double percent = 100.0 * one_minus;
+  const double q = percent / 100.0;
+  const double last = static_cast<double>(n - 1);
+  const double virt = last * q;
+  size_t ia, ib;
+  double t;
+  if (virt >= last) {  // _get_indexes: both -1, gamma = virt - (-1)
+    ia = ib = n - 1;
+    t = virt + 1.0;
+  } else {
+    const double fl = floor(virt);
+    ia = static_cast<size_t>(fl);
+    ib = ia + 1;
+    t = virt - fl;
+  }
+  const double a = ia < zeros_trg ? h->z[1] : tw[ia - zeros_trg];
+  const double b = ib < zeros_trg ? h->z[1] : tw[ib - zeros_trg];
+  const double diff = b - a;
+  double p = a + diff * t;
+  if (t >= 0.5) p = b - diff * (1.0 - t);
+  h->p = p;
+  h->adjust = 1;
+}
+
+}  // namespace
+}  // namespace psh
+
+extern "C" int psh_probmatch_dev(const double *initial_dev, const double *target_dev, size_t count,
+                                 double *out_dev) {
+  using namespace psh;
+  PSH_REQUIRE_INIT();
+  if (!initial_dev || !target_dev || !out_dev) return fail(PSH_EINVAL, "probmatch: NULL pointer");
+  if (count == 0) return fail(PSH_EINVAL, "probmatch: empty arrays");
+  if (count > 0x7fffffffull) return fail(PSH_EUNSUPPORTED, "probmatch: more than 2^31-1 pixels");
+  Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+
+  // [header | counts 2 x B | starts 2 x B | cursors 2 x B | block sums 2 x 1024 | block offsets 2 x 1024 |
+  //  large-bucket lists 2 x cap | scattered values N | sorted wet target values N | pixel indices N]
+  const unsigned large_cap = static_cast<unsigned>(count / kSmallBin + 1);
+  auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
+  const size_t table_bytes = 2 * static_cast<size_t>(kBins) * sizeof(unsigned);
+  const size_t off_count = 256, off_start = off_count + table_bytes, off_cursor = off_start + table_bytes;
+  const size_t off_sums = off_cursor + table_bytes, off_offs = off_sums + 2 * kScanBlocks * sizeof(unsigned);
+  const size_t off_large = off_offs + 2 * kScanBlocks * sizeof(unsigned);
+  const size_t off_sval = up(off_large + 2 * static_cast<size_t>(large_cap) * sizeof(unsigned));
+  const size_t off_tw = up(off_sval + count * sizeof(double));
+  const size_t off_sidx = up(off_tw + count * sizeof(double));
+  const size_t total = off_sidx + count * sizeof(unsigned);
+  static_assert(sizeof(PmHeader) <= 256, "header block");
+  void *blk = nullptr;
+  if (int rc = psh_malloc(&blk, total)) return rc;
+  char *base = static_cast<char *>(blk);
+  PmHeader *h = reinterpret_cast<PmHeader *>(base);
+  unsigned *cnt = reinterpret_cast<unsigned *>(base + off_count);
+  unsigned *start = reinterpret_cast<unsigned *>(base + off_start);
+  unsigned *cursor = reinterpret_cast<unsigned *>(base + off_cursor);
+  unsigned *sums = reinterpret_cast<unsigned *>(base + off_sums);
+  unsigned *offs = reinterpret_cast<unsigned *>(base + off_offs);
+  unsigned *large = reinterpret_cast<unsigned *>(base + off_large);
+  double *sval = reinterpret_cast<double *>(base + off_sval);
+  double *tw = reinterpret_cast<double *>(base + off_tw);
+  unsigned *sidx = reinterpret_cast<unsigned *>(base + off_sidx);
+
+  int status = -1;
+  auto run = [&]() -> int {
+    const int grid = static_cast<int>(std::min<size_t>(kGrid, (count + kThreads - 1) / kThreads));
+    const int grid_large = 1024;
+    hipStream_t s = c.stream;
+    PSH_HIP(hipMemsetAsync(cnt, 0, table_bytes, s));
+    hipLaunchKernelGGL(pm_init, dim3(1), dim3(1), 0, s, h);
+    hipLaunchKernelGGL(pm_stats, dim3(grid, 2), dim3(kThreads), 0, s, initial_dev, target_dev, count, h);
+    hipLaunchKernelGGL(pm_prepare, dim3(1), dim3(1), 0, s, h, count);
+    hipLaunchKernelGGL(pm_hist, dim3(grid, 2), dim3(kThreads), 0, s, initial_dev, target_dev, count, h, cnt);
+    hipLaunchKernelGGL(pm_bin_sums, dim3(kScanBlocks, 2), dim3(kThreads), 0, s, cnt, sums);
+    hipLaunchKernelGGL(pm_scan_sums, dim3(2), dim3(kScanBlocks), 0, s, sums, offs, h);
+    hipLaunchKernelGGL(pm_bin_starts, dim3(kScanBlocks, 2), dim3(kThreads), 0, s, cnt, offs, start, cursor, large,
+                       large_cap, h);
+    // target: sorted wet values
+    hipLaunchKernelGGL(pm_scatter<false>, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cursor, sval, sidx,
+                       out_dev);
+    hipLaunchKernelGGL(pm_rank_small<false>, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, sval, sidx, tw,
+                       out_dev);
+    hipLaunchKernelGGL(pm_rank_large<false>, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large,
+                       large_cap, sval, sidx, tw, out_dev);
+    hipLaunchKernelGGL(pm_threshold, dim3(1), dim3(1), 0, s, h, count, tw);
+    // initial: ranks -> output
+    hipLaunchKernelGGL(pm_scatter<true>, dim3(grid), dim3(kThreads), 0, s, initial_dev, count, h, cursor, sval, sidx,
+                       out_dev);
+    hipLaunchKernelGGL(pm_rank_small<true>, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, sval, sidx, tw,
+                       out_dev);
+    hipLaunchKernelGGL(pm_rank_large<true>, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large,
+                       large_cap, sval, sidx, tw, out_dev);
+    PSH_HIP(hipGetLastError());
+    static void *pinned = nullptr;
+    if (int rc = persistent_pinned(&pinned, 64)) return rc;
+    PSH_HIP(hipMemcpyAsync(pinned, &h->status, sizeof(int), hipMemcpyDeviceToHost, s));
+    PSH_HIP(hipStreamSynchronize(s));
+    status = *static_cast<const int *>(pinned);
+    return PSH_OK;
+  };
+  const int rc = run();
+  (void)psh_free(blk);
+  if (rc) return rc;
+  switch (status) {
+    case kStOk:
+      return PSH_OK;
+    case kStAllNan:
+      return fail(PSH_EINVAL, "Initial array contains only nans.");
+    case kStNonFinite:
+      return fail(PSH_EINVAL, "Initial array contains non-finite values outside ignore_indices mask.");
+    case kStTarget:
+      return fail(PSH_EUNSUPPORTED, "probmatch: target array without finite values or with infinities");
+    default:
+      return fail(PSH_EUNSUPPORTED, "probmatch: more than %u tied or bucket-sharing wet values", kLargeLimit);
+  }
+}

@@ -118,7 +118,36 @@ def unregister_fft():
         utils_pkg.get_method = ref
 
 
-def register(override=False, patch_main_loop=False, fft=True):
+def patch_probmatching():
+    """Replace ``pysteps.postprocessing.probmatching.nonparam_match_empirical_cdf`` by the device
+    version.  The member loops reach it through the module attribute
+    (``probmatching.nonparam_match_empirical_cdf(...)``: nowcasts/steps.py:1199, sprog.py:421,
+    sseps.py:783,804, blending/steps.py:3333) and there is no method table for it, so the attribute is
+    what has to change; the reference function stays reachable (calls with ``ignore_indices`` and
+    inputs the device path declines are handed to it)."""
+    import pysteps.postprocessing.probmatching as ref_mod  # noqa: PLC0415
+
+    from .postprocessing import probmatching as hip_mod  # noqa: PLC0415
+
+    if ref_mod.nonparam_match_empirical_cdf is hip_mod.nonparam_match_empirical_cdf:
+        return []
+    ref_mod._reference_nonparam_match_empirical_cdf = ref_mod.nonparam_match_empirical_cdf
+    hip_mod._reference_fn = ref_mod.nonparam_match_empirical_cdf
+    ref_mod.nonparam_match_empirical_cdf = hip_mod.nonparam_match_empirical_cdf
+    return ["probmatching:nonparam_match_empirical_cdf"]
+
+
+def unpatch_probmatching():
+    """Undo :func:`patch_probmatching`."""
+    import pysteps.postprocessing.probmatching as ref_mod  # noqa: PLC0415
+
+    ref = getattr(ref_mod, "_reference_nonparam_match_empirical_cdf", None)
+    if ref is not None:
+        ref_mod.nonparam_match_empirical_cdf = ref
+        del ref_mod._reference_nonparam_match_empirical_cdf
+
+
+def register(override=False, patch_main_loop=False, fft=True, probmatching=False):
     """Register with an importable pysteps; raises ImportError if pysteps is absent.
 
     ``patch_main_loop=True`` also installs the device-resident generic nowcast loop
@@ -133,6 +162,8 @@ def register(override=False, patch_main_loop=False, fft=True):
     if fft:
         added += register_fft()
         added += register_spectral()
+    if probmatching:
+        added += patch_probmatching()
     if patch_main_loop:
         import importlib  # noqa: PLC0415
 

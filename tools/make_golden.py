@@ -127,12 +127,48 @@ def make_sparse():
     print("sparse: 3 cases")
 
 
+def probmatch_cases():
+    """(initial, target) pairs as the member loops produce them: a continuous forecast with its dry
+    pixels at the zero value against a quantised observation; wet values of the initial arrays are
+    tie-free (the reference's unstable argsort leaves tied wet values unspecified)."""
+    rng = np.random.default_rng(11)
+    m, n = 96, 128
+    obs = np.round(synth.rain_field_db(m, n, seed=5, sigma=3.0).astype(float), 1)
+    fct = synth.rain_field_db(m, n, seed=6, sigma=3.0).astype(float) + rng.normal(0, 1e-3, (m, n))
+    cases = {}
+    dry = fct.copy()
+    dry[dry < np.percentile(dry, 70)] = -15.0
+    wetobs = obs.copy()
+    wetobs[wetobs < np.percentile(wetobs, 40)] = -15.0
+    dryobs = obs.copy()
+    dryobs[dryobs < np.percentile(dryobs, 90)] = -15.0
+    nanobs = wetobs.copy()
+    nanobs[synth.border_nan_mask(m, n, 0.1)] = np.nan
+    cases["adjust"] = (dry, wetobs)          # more rain in the target: percentile threshold (:107-110)
+    cases["no_adjust"] = (dry, dryobs)       # less rain in the target
+    cases["nan_target"] = (dry, nanobs)      # NaNs of the target count as zeros (:103-104)
+    cases["all_wet"] = (fct, wetobs)         # no mask applied: every pixel above the single minimum
+    cases["gauss"] = (rng.normal(size=(64, 64)), rng.normal(size=(64, 64)))
+    return cases
+
+
+def make_probmatch():
+    pm = ref_loader.load("pysteps.postprocessing.probmatching")
+    blob = {}
+    for name, (initial, target) in probmatch_cases().items():
+        blob[name + "/initial"], blob[name + "/target"] = initial, target
+        blob[name + "/out"] = pm.nonparam_match_empirical_cdf(initial, target)
+    np.savez_compressed(os.path.join(OUT, "probmatch_reference.npz"), **blob)
+    print("probmatch: %d cases" % (len(blob) // 3))
+
+
 def main():
     if not ref_loader.available():
         sys.exit("reference not available")
     os.makedirs(OUT, exist_ok=True)
     make_semilag()
     make_sparse()
+    make_probmatch()
 
 
 if __name__ == "__main__":
