@@ -11,7 +11,8 @@
 //
 //   stats      min / max / NaN / inf counts                     -> zero value z, bucket scale
 //   hist       bucket b = floor((v - z) * 2^20 / (max - z)), monotone in v, count per bucket
-//              (one atomic per run of equal buckets inside a wave)
+//              (target: counted per workgroup in an LDS table first - one global atomic per workgroup
+//              and bucket; observations are quantised, thousands of pixels per distinct value)
 //   scan       bucket starts (three small kernels), wet count, list of the buckets above 256 values
 //   scatter    values (and pixel indices) to their bucket's segment
 //   rank       position inside the segment by counting the smaller values of the same bucket
@@ -43,26 +44,23 @@ constexpr unsigned kSmallBin = 256;    // up to here one thread ranks its value 
 constexpr unsigned kLargeLimit = 16384;
 constexpr int kThreads = 256;
 constexpr int kGrid = 2048;
+constexpr int kLoads = 4;  // independent loads in flight per thread of the streaming kernels
+constexpr unsigned kHashBits = 12, kHashSlots = 1u << kHashBits, kProbes = 8;  // per-workgroup bucket table (LDS)
 
 enum { kStOk = 0, kStAllNan = 1, kStNonFinite = 2, kStTarget = 3, kStTies = 4 };
 
 // index 0: initial array, 1: target array
 struct PmHeader {
-  unsigned long long min_key[2], max_key[2];
   unsigned int n_nan[2], n_inf[2];
   unsigned int wet[2], n_large[2], max_bin[2];
   int status, adjust;
   double z[2], scale[2], p;
 };
 
-__device__ __forceinline__ unsigned long long key_of(double v) {
-  const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
-  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double value_of(unsigned long long k) {
-  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-  return __longlong_as_double(static_cast<long long>(b));
-}
+struct PmPartial {  // statistics of one workgroup's share of an array
+  double mn, mx;    // over the values that are not NaN (+inf / -inf if there is none)
+  unsigned n_nan, n_inf;
+};
 
 __device__ __forceinline__ unsigned bin_of(double v, double z, double scale) {
 #pragma clang fp contract(off)
@@ -72,8 +70,6 @@ __device__ __forceinline__ unsigned bin_of(double v, double z, double scale) {
 
 __global__ void pm_init(PmHeader *h) {
   for (int y = 0; y < 2; ++y) {
-    h->min_key[y] = ~0ull;
-    h->max_key[y] = 0ull;
     h->n_nan[y] = h->n_inf[y] = h->wet[y] = h->n_large[y] = h->max_bin[y] = 0u;
     h->z[y] = h->scale[y] = 0.0;
   }
@@ -83,20 +79,24 @@ __global__ void pm_init(PmHeader *h) {
 }
 
 __global__ __launch_bounds__(kThreads) void pm_stats(const double *__restrict__ a0, const double *__restrict__ a1,
-                                                     size_t n, PmHeader *h) {
+                                                     size_t n, PmPartial *__restrict__ part) {
   const int y = blockIdx.y;
   const double *a = y ? a1 : a0;
   double mn = INFINITY, mx = -INFINITY;
   unsigned nn = 0, ni = 0;
   const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
-    const double v = a[i];
-    if (v != v) {
-      ++nn;
-    } else {
-      ni += (v == INFINITY || v == -INFINITY) ? 1u : 0u;
-      mn = v < mn ? v : mn;
-      mx = v > mx ? v : mx;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += kLoads * stride) {
+    double v[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) v[k] = i + k * stride < n ? a[i + k * stride] : a[i];  // a repeat changes nothing below
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const bool fresh = k == 0 || i + k * stride < n;
+      const bool nan = v[k] != v[k];
+      nn += (fresh && nan) ? 1u : 0u;
+      ni += (fresh && (v[k] == INFINITY || v[k] == -INFINITY)) ? 1u : 0u;
+      mn = v[k] < mn ? v[k] : mn;  // false for NaN
+      mx = v[k] > mx ? v[k] : mx;
     }
   }
 #pragma unroll
@@ -107,68 +107,159 @@ __global__ __launch_bounds__(kThreads) void pm_stats(const double *__restrict__ 
     nn += __shfl_xor(nn, d);
     ni += __shfl_xor(ni, d);
   }
-  if ((threadIdx.x & 63) == 0) {
-    if (mn <= mx) {  // at least one value that is not NaN
-      atomicMin(&h->min_key[y], key_of(mn));
-      atomicMax(&h->max_key[y], key_of(mx));
+  __shared__ PmPartial s_part[kThreads / 64];
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = PmPartial{mn, mx, nn, ni};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PmPartial r = s_part[0];
+    for (int w = 1; w < kThreads / 64; ++w) {
+      r.mn = s_part[w].mn < r.mn ? s_part[w].mn : r.mn;
+      r.mx = s_part[w].mx > r.mx ? s_part[w].mx : r.mx;
+      r.n_nan += s_part[w].n_nan;
+      r.n_inf += s_part[w].n_inf;
     }
-    if (nn) atomicAdd(&h->n_nan[y], nn);
-    if (ni) atomicAdd(&h->n_inf[y], ni);
+    part[static_cast<size_t>(y) * gridDim.x + blockIdx.x] = r;  // no atomics: thousands on four addresses were the bound
   }
 }
 
-__global__ void pm_prepare(PmHeader *h, size_t n) {
+// one workgroup: finishes the statistics and fixes the bucket mapping
+__global__ __launch_bounds__(kThreads) void pm_prepare(PmHeader *h, size_t n, const PmPartial *__restrict__ part,
+                                                       int nparts) {
+  __shared__ PmPartial s_part[kThreads / 64];
+  for (int y = 0; y < 2; ++y) {
+    double mn = INFINITY, mx = -INFINITY;
+    unsigned nn = 0, ni = 0;
+    for (int i = threadIdx.x; i < nparts; i += kThreads) {
+      const PmPartial r = part[static_cast<size_t>(y) * nparts + i];
+      mn = r.mn < mn ? r.mn : mn;
+      mx = r.mx > mx ? r.mx : mx;
+      nn += r.n_nan;
+      ni += r.n_inf;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const double omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
+      mn = omn < mn ? omn : mn;
+      mx = omx > mx ? omx : mx;
+      nn += __shfl_xor(nn, d);
+      ni += __shfl_xor(ni, d);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = PmPartial{mn, mx, nn, ni};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      PmPartial r = s_part[0];
+      for (int w = 1; w < kThreads / 64; ++w) {
+        r.mn = s_part[w].mn < r.mn ? s_part[w].mn : r.mn;
+        r.mx = s_part[w].mx > r.mx ? s_part[w].mx : r.mx;
+        r.n_nan += s_part[w].n_nan;
+        r.n_inf += s_part[w].n_inf;
+      }
+      h->n_nan[y] = r.n_nan;
+      h->n_inf[y] = r.n_inf;
+      h->z[y] = r.mn;  // :91, :101 (np.nanmin); +inf if there is nothing but NaNs
+      const double range = r.mx - r.mn;  // may overflow to inf: scale 0, everything in bucket 0
+      h->scale[y] = r.mx > r.mn ? static_cast<double>(kBins) / range : 0.0;
+    }
+  }
+  if (threadIdx.x != 0) return;
   // :81-82 (only NaNs), :93-96 (any non-finite value left: without ignore_indices every NaN / inf)
   if (h->n_nan[0] == n) {
     h->status = kStAllNan;
-    return;
-  }
-  if (h->n_nan[0] + h->n_inf[0] > 0) {
+  } else if (h->n_nan[0] + h->n_inf[0] > 0) {
     h->status = kStNonFinite;
-    return;
-  }
-  if (h->n_nan[1] == n || h->n_inf[1] > 0) {
+  } else if (h->n_nan[1] == n || h->n_inf[1] > 0) {
     h->status = kStTarget;
-    return;
-  }
-  for (int y = 0; y < 2; ++y) {
-    const double z = value_of(h->min_key[y]), mx = value_of(h->max_key[y]);  // :91, :101 (np.nanmin)
-    h->z[y] = z;
-    const double range = mx - z;  // may overflow to inf: scale 0, everything in bucket 0
-    h->scale[y] = mx > z ? static_cast<double>(kBins) / range : 0.0;
   }
 }
 
-// one atomic per run of equal buckets inside the wave; returns the value the atomic gave the run's
-// first lane plus the lane's offset in the run (slot for the scatter; unused by the histogram)
-__device__ __forceinline__ unsigned run_atomic_add(unsigned *table, unsigned bin, bool wet) {
-  const int lane = threadIdx.x & 63;
-  const unsigned key = wet ? bin : 0xffffffffu;
-  const unsigned prev = __shfl_up(key, 1);
-  const bool head = lane == 0 || prev != key;
-  const unsigned long long heads = __ballot(head);
-  const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
-  const int len = above ? __ffsll(static_cast<long long>(above)) : 64 - lane;  // up to the next head
-  unsigned base = 0;
-  if (head && wet) base = atomicAdd(&table[bin], static_cast<unsigned>(len));
-  const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-  const int head_lane = 63 - __clzll(static_cast<long long>(below));
-  return __shfl(base, head_lane) + static_cast<unsigned>(lane - head_lane);
+// Bucket counters of one workgroup in LDS: an open-addressing table bucket -> count over everything the
+// workgroup reads, flushed with ONE global atomic per occupied slot.  Observations are quantised
+// (thousands of pixels per distinct value): their per-pixel atomics on a few hundred addresses were the
+// bound.  Tags are never removed, so a bucket resolves to the same slot (or to "no room": the first
+// kProbes positions taken by other buckets) every time it is looked up; buckets without room go to
+// the global table one by one.
+struct PmHash {
+  unsigned tag[kHashSlots];  // bucket + 1, 0: free
+  unsigned cnt[kHashSlots];
+  unsigned base[kHashSlots];
+};
+
+__device__ __forceinline__ unsigned hash_home(unsigned bin) { return (bin * 2654435761u) >> (32 - kHashBits); }
+
+__device__ __forceinline__ int hash_insert(PmHash &t, unsigned bin) {
+  const unsigned home = hash_home(bin);
+#pragma unroll 1
+  for (unsigned p = 0; p < kProbes; ++p) {
+    const unsigned s = (home + p) & (kHashSlots - 1);
+    const unsigned old = atomicCAS(&t.tag[s], 0u, bin + 1u);
+    if (old == 0u || old == bin + 1u) return static_cast<int>(s);
+  }
+  return -1;
 }
 
-__global__ __launch_bounds__(kThreads) void pm_hist(const double *__restrict__ a0, const double *__restrict__ a1,
-                                                    size_t n, const PmHeader *__restrict__ h, unsigned *count) {
+__device__ __forceinline__ int hash_find(const PmHash &t, unsigned bin) {
+  const unsigned home = hash_home(bin);
+#pragma unroll 1
+  for (unsigned p = 0; p < kProbes; ++p) {
+    const unsigned s = (home + p) & (kHashSlots - 1);
+    if (t.tag[s] == bin + 1u) return static_cast<int>(s);
+  }
+  return -1;
+}
+
+__device__ __forceinline__ void hash_clear(PmHash &t) {
+  for (unsigned s = threadIdx.x; s < kHashSlots; s += kThreads) {
+    t.tag[s] = 0u;
+    t.cnt[s] = 0u;
+  }
+  __syncthreads();
+}
+
+// the initial array: a continuous forecast has a bucket per value, nothing to combine - plain atomics
+__global__ __launch_bounds__(kThreads) void pm_hist_initial(const double *__restrict__ a, size_t n,
+                                                            const PmHeader *__restrict__ h, unsigned *table) {
   if (h->status != kStOk) return;
-  const int y = blockIdx.y;
-  const double *a = y ? a1 : a0;
-  const double z = h->z[y], scale = h->scale[y];
-  unsigned *table = count + static_cast<size_t>(y) * kBins;
+  const double z = h->z[0], scale = h->scale[0];
   const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
-  for (size_t i0 = static_cast<size_t>(blockIdx.x) * kThreads; i0 < n; i0 += stride) {
-    const size_t i = i0 + threadIdx.x;
-    const double v = i < n ? a[i] : z;
-    const bool wet = v > z;  // false for NaN
-    (void)run_atomic_add(table, wet ? bin_of(v, z, scale) : 0u, wet);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += kLoads * stride) {
+    double v[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) v[k] = i + k * stride < n ? a[i + k * stride] : z;
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k)
+      if (v[k] > z) atomicAdd(&table[bin_of(v[k], z, scale)], 1u);  // false for NaN
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void pm_hist_target(const double *__restrict__ a, size_t n,
+                                                           const PmHeader *__restrict__ h, unsigned *table) {
+  __shared__ PmHash t;
+  if (h->status != kStOk) return;
+  const double z = h->z[1], scale = h->scale[1];
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  hash_clear(t);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += kLoads * stride) {
+    double v[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) v[k] = i + k * stride < n ? a[i + k * stride] : z;
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      if (v[k] > z) {  // false for NaN
+        const unsigned b = bin_of(v[k], z, scale);
+        const int s = hash_insert(t, b);
+        if (s >= 0) {
+          atomicAdd(&t.cnt[s], 1u);
+        } else {
+          atomicAdd(&table[b], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (unsigned s = threadIdx.x; s < kHashSlots; s += kThreads) {
+    const unsigned c = t.cnt[s];
+    if (c) atomicAdd(&table[t.tag[s] - 1u], c);
   }
 }
 
@@ -250,27 +341,80 @@ __global__ __launch_bounds__(kThreads) void pm_bin_starts(const unsigned *__rest
   }
 }
 
-// IDX: the initial array (pixel indices travel with the values, the dry pixels get their output here)
-template <bool IDX>
-__global__ __launch_bounds__(kThreads) void pm_scatter(const double *__restrict__ a, size_t n,
-                                                       const PmHeader *__restrict__ h, unsigned *cursor,
-                                                       double *__restrict__ sval, unsigned *__restrict__ sidx,
-                                                       double *__restrict__ out) {
+// the initial array: values and pixel indices to their bucket's segment, one atomic each (kLoads of
+// them in flight); the dry pixels get their output here (:127-128)
+__global__ __launch_bounds__(kThreads) void pm_scatter_initial(const double *__restrict__ a, size_t n,
+                                                               const PmHeader *__restrict__ h, unsigned *table,
+                                                               double *__restrict__ sval, unsigned *__restrict__ sidx,
+                                                               double *__restrict__ out) {
   if (h->status != kStOk) return;
-  constexpr int y = IDX ? 0 : 1;
-  const double z = h->z[y], scale = h->scale[y], z_trg = h->z[1];
-  unsigned *table = cursor + static_cast<size_t>(y) * kBins;
+  const double z = h->z[0], scale = h->scale[0], z_trg = h->z[1];
   const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
-  for (size_t i0 = static_cast<size_t>(blockIdx.x) * kThreads; i0 < n; i0 += stride) {
-    const size_t i = i0 + threadIdx.x;
-    const double v = i < n ? a[i] : z;
-    const bool wet = v > z;
-    const unsigned slot = run_atomic_add(table, wet ? bin_of(v, z, scale) : 0u, wet);
-    if (wet) {
-      sval[slot] = v;
-      if (IDX) sidx[slot] = static_cast<unsigned>(i);
-    } else if (IDX && i < n) {
-      out[i] = z_trg;  // :127-128
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += kLoads * stride) {
+    double v[kLoads];
+    unsigned slot[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) v[k] = i + k * stride < n ? a[i + k * stride] : z;
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) slot[k] = v[k] > z ? atomicAdd(&table[bin_of(v[k], z, scale)], 1u) : 0u;
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const size_t at = i + k * stride;
+      if (v[k] > z) {
+        sval[slot[k]] = v[k];
+        sidx[slot[k]] = static_cast<unsigned>(at);
+      } else if (at < n) {
+        out[at] = z_trg;
+      }
+    }
+  }
+}
+
+// the target: pass A counts the workgroup's values per bucket in the LDS table, the flush reserves one
+// range per occupied slot in the bucket's segment, pass B reads the values again and hands the
+// positions out
+__global__ __launch_bounds__(kThreads) void pm_scatter_target(const double *__restrict__ a, size_t n,
+                                                              const PmHeader *__restrict__ h, unsigned *table,
+                                                              double *__restrict__ sval) {
+  __shared__ PmHash t;
+  if (h->status != kStOk) return;
+  const double z = h->z[1], scale = h->scale[1];
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  const size_t first = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+  hash_clear(t);
+  for (size_t i = first; i < n; i += kLoads * stride) {
+    double v[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) v[k] = i + k * stride < n ? a[i + k * stride] : z;
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      if (v[k] > z) {
+        const int s = hash_insert(t, bin_of(v[k], z, scale));
+        if (s >= 0) atomicAdd(&t.cnt[s], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (unsigned s = threadIdx.x; s < kHashSlots; s += kThreads) {
+    const unsigned c = t.cnt[s];
+    if (c) {
+      t.base[s] = atomicAdd(&table[t.tag[s] - 1u], c);
+      t.cnt[s] = 0u;
+    }
+  }
+  __syncthreads();
+  for (size_t i = first; i < n; i += kLoads * stride) {
+    double v[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) v[k] = i + k * stride < n ? a[i + k * stride] : z;
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      if (v[k] > z) {
+        const unsigned b = bin_of(v[k], z, scale);
+        const int s = hash_find(t, b);
+        const unsigned slot = s >= 0 ? t.base[s] + atomicAdd(&t.cnt[s], 1u) : atomicAdd(&table[b], 1u);
+        sval[slot] = v[k];
+      }
     }
   }
 }
@@ -441,12 +585,13 @@ extern "C" int psh_probmatch_dev(const double *initial_dev, const double *target
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
 
-  // [header | counts 2 x B | starts 2 x B | cursors 2 x B | block sums 2 x 1024 | block offsets 2 x 1024 |
+  // [header | statistics partials 2 x 2048 | counts 2 x B | starts 2 x B | cursors 2 x B | block sums 2 x 1024 | block offsets 2 x 1024 |
   //  large-bucket lists 2 x cap | scattered values N | sorted wet target values N | pixel indices N]
   const unsigned large_cap = static_cast<unsigned>(count / kSmallBin + 1);
   auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   const size_t table_bytes = 2 * static_cast<size_t>(kBins) * sizeof(unsigned);
-  const size_t off_count = 256, off_start = off_count + table_bytes, off_cursor = off_start + table_bytes;
+  const size_t off_part = 256, part_bytes = 2 * static_cast<size_t>(kGrid) * sizeof(PmPartial);
+  const size_t off_count = off_part + part_bytes, off_start = off_count + table_bytes, off_cursor = off_start + table_bytes;
   const size_t off_sums = off_cursor + table_bytes, off_offs = off_sums + 2 * kScanBlocks * sizeof(unsigned);
   const size_t off_large = off_offs + 2 * kScanBlocks * sizeof(unsigned);
   const size_t off_sval = up(off_large + 2 * static_cast<size_t>(large_cap) * sizeof(unsigned));
@@ -458,6 +603,7 @@ extern "C" int psh_probmatch_dev(const double *initial_dev, const double *target
   if (int rc = psh_malloc(&blk, total)) return rc;
   char *base = static_cast<char *>(blk);
   PmHeader *h = reinterpret_cast<PmHeader *>(base);
+  PmPartial *part = reinterpret_cast<PmPartial *>(base + off_part);
   unsigned *cnt = reinterpret_cast<unsigned *>(base + off_count);
   unsigned *start = reinterpret_cast<unsigned *>(base + off_start);
   unsigned *cursor = reinterpret_cast<unsigned *>(base + off_cursor);
@@ -470,28 +616,30 @@ extern "C" int psh_probmatch_dev(const double *initial_dev, const double *target
 
   int status = -1;
   auto run = [&]() -> int {
-    const int grid = static_cast<int>(std::min<size_t>(kGrid, (count + kThreads - 1) / kThreads));
+    // every workgroup of the streaming kernels reads at least kLoads x kThreads values
+    const int grid = static_cast<int>(
+        std::min<size_t>(kGrid, (count + kLoads * kThreads - 1) / (static_cast<size_t>(kLoads) * kThreads)));
     const int grid_large = 1024;
     hipStream_t s = c.stream;
     PSH_HIP(hipMemsetAsync(cnt, 0, table_bytes, s));
     hipLaunchKernelGGL(pm_init, dim3(1), dim3(1), 0, s, h);
-    hipLaunchKernelGGL(pm_stats, dim3(grid, 2), dim3(kThreads), 0, s, initial_dev, target_dev, count, h);
-    hipLaunchKernelGGL(pm_prepare, dim3(1), dim3(1), 0, s, h, count);
-    hipLaunchKernelGGL(pm_hist, dim3(grid, 2), dim3(kThreads), 0, s, initial_dev, target_dev, count, h, cnt);
+    hipLaunchKernelGGL(pm_stats, dim3(grid, 2), dim3(kThreads), 0, s, initial_dev, target_dev, count, part);
+    hipLaunchKernelGGL(pm_prepare, dim3(1), dim3(kThreads), 0, s, h, count, part, grid);
+    hipLaunchKernelGGL(pm_hist_initial, dim3(grid), dim3(kThreads), 0, s, initial_dev, count, h, cnt);
+    hipLaunchKernelGGL(pm_hist_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cnt + kBins);
     hipLaunchKernelGGL(pm_bin_sums, dim3(kScanBlocks, 2), dim3(kThreads), 0, s, cnt, sums);
     hipLaunchKernelGGL(pm_scan_sums, dim3(2), dim3(kScanBlocks), 0, s, sums, offs, h);
     hipLaunchKernelGGL(pm_bin_starts, dim3(kScanBlocks, 2), dim3(kThreads), 0, s, cnt, offs, start, cursor, large,
                        large_cap, h);
     // target: sorted wet values
-    hipLaunchKernelGGL(pm_scatter<false>, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cursor, sval, sidx,
-                       out_dev);
+    hipLaunchKernelGGL(pm_scatter_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cursor + kBins, sval);
     hipLaunchKernelGGL(pm_rank_small<false>, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, sval, sidx, tw,
                        out_dev);
     hipLaunchKernelGGL(pm_rank_large<false>, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large,
                        large_cap, sval, sidx, tw, out_dev);
     hipLaunchKernelGGL(pm_threshold, dim3(1), dim3(1), 0, s, h, count, tw);
     // initial: ranks -> output
-    hipLaunchKernelGGL(pm_scatter<true>, dim3(grid), dim3(kThreads), 0, s, initial_dev, count, h, cursor, sval, sidx,
+    hipLaunchKernelGGL(pm_scatter_initial, dim3(grid), dim3(kThreads), 0, s, initial_dev, count, h, cursor, sval, sidx,
                        out_dev);
     hipLaunchKernelGGL(pm_rank_small<true>, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, sval, sidx, tw,
                        out_dev);

@@ -5,10 +5,11 @@ clock; the result is checked against the oracle.
     python tools/probmatch_quick.py [size ...]
 """
 import json
+import os
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from scipy.ndimage import gaussian_filter
 
