@@ -351,8 +351,8 @@ def members_workload(precip_d, vel_d, n_members, first_member, n_total, T, K):
 
 def spectral_leg(m, n):
     """SURVEY 8f rank 3 (first pieces): what the STEPS member loop calls per member and lead time -
-    the FFT method object and the cascade decomposition - resident on the device (HIP events) with
-    numpy's pocketfft timed once beside it.  Reported under config, not part of `value`."""
+    the FFT method object, the cascade decomposition and the CDF matching - resident on the device (HIP
+    events) with numpy's pocketfft timed once beside it.  Reported under config, not part of `value`."""
     from pysteps_amd.device import DeviceArray, Event, synchronize
     from pysteps_amd.utils.fft import get_hip, supported_shape
 
@@ -405,6 +405,25 @@ def spectral_leg(m, n):
         out["cascade_decompose_%d_levels_ms" % nlev] = e3.elapsed_ms(e4)
     except Exception as exc:  # the spectral leg never takes the headline down
         out["cascade_note"] = "%s: %s" % (type(exc).__name__, exc)
+    try:
+        from pysteps_amd.postprocessing.probmatching import nonparam_match_empirical_cdf
+
+        # a continuous forecast with 25 % of its pixels above the zero value against an observation
+        # quantised to 0.1 dB with 35 % wet pixels (the call of nowcasts/steps.py:1199)
+        y = rng.standard_normal((m, n))
+        d_fct = DeviceArray.from_host(np.where(x > 0.6745, 5.0 * x, -15.0))
+        d_obs = DeviceArray.from_host(np.round(np.where(y > 0.3853, 5.0 * y, -15.0), 1))
+        nonparam_match_empirical_cdf(d_fct, d_obs)
+        synchronize()
+        e5, e6 = Event(), Event()
+        e5.record()
+        for _ in range(reps):
+            nonparam_match_empirical_cdf(d_fct, d_obs)
+        e6.record()
+        synchronize()
+        out["probmatch_cdf_ms"] = e5.elapsed_ms(e6) / reps
+    except Exception as exc:
+        out["probmatch_note"] = "%s: %s" % (type(exc).__name__, exc)
     return out
 
 

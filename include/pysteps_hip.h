@@ -418,6 +418,12 @@ int psh_cascade_decompose_dev(const double *field_dev, const double *weights_dev
 int psh_cascade_recompose_dev(const double *levels_dev, int nlevels, int m, int n, const double *means_host,
                               const double *stds_host, double field_mean, double *out_dev);
 int psh_noise_filter_dev(const double *white_dev, const double *filter_dev, int m, int n, double *out_dev);
+/*  psh_ar_iterate_dev         pysteps/timeseries/autoregression.py:1020-1070 (iterate_ar_model): x (nt, plane),
+ *      phi (p + 1 host doubles, p in 1..8, nt >= p), eps (plane) or NULL; out (nt, plane) = [x[1], ..., x[nt-1],
+ *      phi[0] x[nt-1] + phi[1] x[nt-2] + ... + phi[p] eps], products rounded before the additions like the NumPy
+ *      expression (bit-identical).  out must not overlap x.  Asynchronous. */
+int psh_ar_iterate_dev(const double *x_dev, int nt, size_t plane, const double *phi_host, int p,
+                       const double *eps_dev, double *out_dev);
 
 /* ---- empirical-CDF probability matching of the member loops (csrc/probmatch.hip) -------- *
  *  psh_probmatch_dev  pysteps/postprocessing/probmatching.py:55-140, nonparam_match_empirical_cdf(initial,

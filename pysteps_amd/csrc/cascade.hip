@@ -11,6 +11,8 @@
 //    generate_noise_2d_fft_filter: irfft2(rfft2(white noise) x filter), standardised to zero mean /
 //    unit variance.  The white noise itself comes from the caller's numpy RandomState (the
 //    reference's random stream is part of its result).
+//  * psh_ar_iterate_dev        - pysteps/timeseries/autoregression.py:1020-1070 (iterate_ar_model): one step of
+//    the AR(p) model of a cascade level, bit-identical with the NumPy expression.
 // Everything is float64 like the reference; the reductions accumulate per block and are finished
 // by one block in a fixed order (deterministic, no atomics on values).
 #include "common.h"
@@ -109,6 +111,34 @@ __global__ __launch_bounds__(kRedThreads) void recompose(const double *__restric
       acc += musigma ? v * musigma[2 * k + 1] + musigma[2 * k] : v;
     }
     out[i] = acc + add;
+  }
+}
+
+// pysteps/timeseries/autoregression.py:1056-1070: x_new = 0.0 + phi_1 x[-1] + phi_2 x[-2] + ... (+ phi_{p+1} eps),
+// every product rounded before it is added (NumPy evaluates `x_new += phi[i] * x[-(i + 1)]` as two array
+// operations), result = the series moved up by one with x_new at its end
+constexpr int kArMaxOrder = 8;
+struct ArPhi {
+  double phi[kArMaxOrder + 1];
+  int p, has_eps;
+};
+
+__global__ __launch_bounds__(kRedThreads) void ar_iterate(const double *__restrict__ x, int nt, size_t plane, ArPhi a,
+                                                          const double *__restrict__ eps, double *__restrict__ out) {
+#pragma clang fp contract(off)
+  const size_t stride = static_cast<size_t>(gridDim.x) * kRedThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kRedThreads + threadIdx.x; i < plane; i += stride) {
+    double acc = 0.0;
+    for (int j = 0; j < a.p; ++j) {
+      const double term = a.phi[j] * x[static_cast<size_t>(nt - 1 - j) * plane + i];
+      acc = acc + term;
+    }
+    if (a.has_eps) {
+      const double term = a.phi[a.p] * eps[i];
+      acc = acc + term;
+    }
+    for (int k = 1; k < nt; ++k) out[static_cast<size_t>(k - 1) * plane + i] = x[static_cast<size_t>(k) * plane + i];
+    out[static_cast<size_t>(nt - 1) * plane + i] = acc;
   }
 }
 
@@ -243,4 +273,26 @@ extern "C" int psh_noise_filter_dev(const double *white_dev, const double *filte
   const int rc = run();
   (void)psh_free(blk);  // stream-ordered
   return rc;
+}
+
+extern "C" int psh_ar_iterate_dev(const double *x_dev, int nt, size_t plane, const double *phi_host, int p,
+                                  const double *eps_dev, double *out_dev) {
+  PSH_REQUIRE_INIT();
+  if (!x_dev || !phi_host || !out_dev) return fail(PSH_EINVAL, "ar_iterate: NULL pointer");
+  if (plane == 0 || nt < 1) return fail(PSH_EINVAL, "ar_iterate: empty series");
+  if (p < 1 || p > psh::kArMaxOrder) return fail(PSH_EUNSUPPORTED, "ar_iterate: AR order 1..%d", psh::kArMaxOrder);
+  if (nt < p)  // autoregression.py:1041-1045
+    return fail(PSH_EINVAL, "dimension mismatch between x and phi: x.shape[0]=%d, len(phi)=%d", nt, p + 1);
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  psh::ArPhi a;
+  for (int j = 0; j <= p; ++j) a.phi[j] = phi_host[j];
+  a.p = p;
+  a.has_eps = eps_dev != nullptr;
+  const size_t blocks = (plane + psh::kRedThreads - 1) / psh::kRedThreads;
+  hipLaunchKernelGGL(psh::ar_iterate, dim3(static_cast<unsigned>(blocks < 4096 ? blocks : 4096)),
+                     dim3(psh::kRedThreads), 0, c.stream, x_dev, nt, plane, a, eps_dev, out_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
 }

@@ -147,7 +147,33 @@ def unpatch_probmatching():
         del ref_mod._reference_nonparam_match_empirical_cdf
 
 
-def register(override=False, patch_main_loop=False, fft=True, probmatching=False):
+def patch_autoregression():
+    """Replace ``pysteps.timeseries.autoregression.iterate_ar_model`` (reached through the module
+    attribute: nowcasts/steps.py:1095,1137, sprog.py:398, sseps.py:678,749, anvil.py:483) by the device
+    version; series it does not take run the reference's function."""
+    import pysteps.timeseries.autoregression as ref_mod  # noqa: PLC0415
+
+    from .timeseries import autoregression as hip_mod  # noqa: PLC0415
+
+    if ref_mod.iterate_ar_model is hip_mod.iterate_ar_model:
+        return []
+    ref_mod._reference_iterate_ar_model = ref_mod.iterate_ar_model
+    hip_mod._reference_fn = ref_mod.iterate_ar_model
+    ref_mod.iterate_ar_model = hip_mod.iterate_ar_model
+    return ["autoregression:iterate_ar_model"]
+
+
+def unpatch_autoregression():
+    """Undo :func:`patch_autoregression`."""
+    import pysteps.timeseries.autoregression as ref_mod  # noqa: PLC0415
+
+    ref = getattr(ref_mod, "_reference_iterate_ar_model", None)
+    if ref is not None:
+        ref_mod.iterate_ar_model = ref
+        del ref_mod._reference_iterate_ar_model
+
+
+def register(override=False, patch_main_loop=False, fft=True, probmatching=False, autoregression=False):
     """Register with an importable pysteps; raises ImportError if pysteps is absent.
 
     ``patch_main_loop=True`` also installs the device-resident generic nowcast loop
@@ -164,6 +190,8 @@ def register(override=False, patch_main_loop=False, fft=True, probmatching=False
         added += register_spectral()
     if probmatching:
         added += patch_probmatching()
+    if autoregression:
+        added += patch_autoregression()
     if patch_main_loop:
         import importlib  # noqa: PLC0415
 
