@@ -27,11 +27,14 @@ def field(shape, seed, wet):
     return out
 
 
+only = os.environ.get("PM_CASE")  # "masked" / "all_wet": just that case (counter passes)
 sizes = [int(a) for a in sys.argv[1:]] or [1024, 4096]
 out = []
 for n in sizes:
     shape = (n, n)
     for label, wet_i, wet_t in (("masked", 0.25, 0.35), ("all_wet", 1.0, 0.35)):
+        if only and label != only:
+            continue
         initial = field(shape, 1, wet_i)
         target = np.round(field(shape, 2, wet_t), 1)
         di, dt = DeviceArray.from_host(initial), DeviceArray.from_host(target)
