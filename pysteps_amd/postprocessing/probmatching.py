@@ -9,7 +9,8 @@ with one bucket pass each and writes the matched field directly (``psh_probmatch
 What runs on the device is the call form of those loops: ``ignore_indices=None``.  Calls with
 ``ignore_indices``, and inputs the device path declines (more than 16384 wet values of the initial
 array tied or crowded into one of its 2**20 value buckets, infinities in the target), go to the
-reference's function.  Tied wet values of the initial array are ranked in pixel order (NumPy's stable
+reference's function, and so do host arrays below 4096 pixels (the localised windows of
+nowcasts/sseps.py:783: two NumPy sorts of that size take less than the launch chain).  Tied wet values of the initial array are ranked in pixel order (NumPy's stable
 sort); the reference's quicksort leaves their order unspecified, so fields with tied wet values agree
 with the reference as multisets per tie group, everything else bit for bit.
 """
@@ -18,6 +19,8 @@ import numpy as np
 
 from .. import _lib
 from ..device import DeviceArray
+
+MIN_HOST_SIZE = 4096  # host arrays below this many pixels: two NumPy sorts beat the launch chain + transfers
 
 _reference_fn = None  # set by register.patch_probmatching(): the function this module replaced
 
@@ -56,6 +59,11 @@ def nonparam_match_empirical_cdf(initial_array, target_array, ignore_indices=Non
         )
     if initial_array.size == 0:
         return _reference()(initial_array, target_array)  # numpy's own error for empty reductions
+    if not resident and initial_array.size < MIN_HOST_SIZE:
+        try:  # small windows (nowcasts/sseps.py:783): the reference is faster; without pysteps, the device
+            return _reference()(initial_array, target_array)
+        except (ImportError, NotImplementedError):
+            pass
     if resident:
         if initial_array.dtype != np.float64 or target_array.dtype != np.float64:
             raise ValueError("device-resident arrays must be float64")

@@ -44,6 +44,8 @@ def test_reference_goldens_bit_exact():
 
 @pytest.mark.parametrize("shape", [(1, 1), (1, 7), (5, 3), (64, 65), (300, 200), (1024, 1024)])
 def test_random_fields_against_the_oracle(ref_pysteps, shape):
+    from pysteps_amd.device import DeviceArray
+
     rng = np.random.default_rng(shape[0] * 31 + shape[1])
     for it in range(6):
         initial = rng.normal(size=shape) * 5
@@ -59,6 +61,9 @@ def test_random_fields_against_the_oracle(ref_pysteps, shape):
         with np.errstate(all="ignore"):  # a tiny target can be all NaN: the reference's (NaN) answer
             want = oracle.nonparam_match_empirical_cdf(initial, target)
         assert np.array_equal(_match(initial, target), want, equal_nan=True), it
+        if np.isfinite(target).any():  # resident arrays always take the kernels, whatever their size
+            got = _match(DeviceArray.from_host(initial), DeviceArray.from_host(target))
+            assert np.array_equal(got.to_host(), want), it
 
 
 def test_against_the_live_reference_and_input_dtypes(ref_pysteps):
@@ -74,6 +79,12 @@ def test_against_the_live_reference_and_input_dtypes(ref_pysteps):
     assert np.array_equal(_match(initial[::2, ::3], target[::2, ::3]), ref(initial[::2, ::3], target[::2, ::3]))
 
 
+def _resident(initial, target):
+    from pysteps_amd.device import DeviceArray
+
+    return _match(DeviceArray.from_host(initial), DeviceArray.from_host(target)).to_host()
+
+
 def test_degenerate_fields():
     flat = np.full((40, 50), 3.0)
     ramp = np.arange(2000.0).reshape(40, 50)
@@ -81,6 +92,9 @@ def test_degenerate_fields():
     assert np.array_equal(_match(ramp, flat), flat)                       # nothing wet in the target
     assert np.array_equal(_match(ramp, ramp[::-1].copy()), ramp)          # a permutation is undone
     assert np.array_equal(_match(ramp, ramp), oracle.nonparam_match_empirical_cdf(ramp, ramp))
+    assert np.array_equal(_resident(flat, ramp), np.full((40, 50), 0.0))  # the same through the kernels
+    assert np.array_equal(_resident(ramp, flat), flat)
+    assert np.array_equal(_resident(ramp, ramp[::-1].copy()), ramp)
 
 
 def test_crowded_buckets_take_the_workgroup_path():
@@ -102,9 +116,11 @@ def test_errors_and_declined_inputs(ref_pysteps):
 
     from pysteps_amd.device import DeviceArray
 
-    ok = np.arange(30.0).reshape(5, 6)
+    ok = np.arange(80.0 * 90).reshape(80, 90)
     with pytest.raises(ValueError, match="Initial array contains only nans"):
-        _match(np.full((5, 6), np.nan), ok)
+        _match(np.full((80, 90), np.nan), ok)
+    with pytest.raises(ValueError, match="Initial array contains only nans"):
+        _match(DeviceArray.from_host(np.full((5, 6), np.nan)), DeviceArray.from_host(ok[:5, :6].copy()))
     bad = ok.copy()
     bad[2, 2] = np.nan
     with pytest.raises(ValueError, match="non-finite values outside ignore_indices"):
