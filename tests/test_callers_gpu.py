@@ -289,6 +289,32 @@ def test_steps_with_the_resident_member_batched_loop(pysteps, timesteps, vel_per
     assert rel < 1e-4, rel
 
 
+def test_steps_with_every_device_piece_at_once(pysteps):
+    """nowcasts.steps with all the operators this library offers for its member loop switched on
+    together - extrapolator and resident member-batched loop, FFT method, cascade decomposition, noise
+    generator by name, AR(p) step and CDF matching through the patched module attributes - against the
+    stock run with the same seed (steps.py:637-720, 1095-1199)."""
+    from pysteps import nowcasts
+    from pysteps_amd import register
+
+    frames, V = _steps_inputs(256, 256)
+    kw = _steps_kwargs()
+    steps = nowcasts.get_method("steps")
+    want = steps(frames, V, 3, extrap_method="semilagrangian", **kw)
+    try:
+        added = register.register(patch_main_loop=True, probmatching=True, autoregression=True)
+        assert "probmatching:nonparam_match_empirical_cdf" in added and "autoregression:iterate_ar_model" in added
+        got = steps(frames, V, 3, extrap_method="semilagrangian_hip", fft_method="hip", decomp_method="fft_hip",
+                    noise_method="nonparametric_hip", **kw)
+    finally:
+        register.unpatch_main_loop()
+        register.unpatch_probmatching()
+        register.unpatch_autoregression()
+    assert got.dtype == want.dtype
+    rel = _ensemble_close(got, want)
+    assert rel < 1e-4, rel
+
+
 def test_check_norain_mirror_matches_the_reference(pysteps):
     """utils/check_norain.py:6-58 against pysteps_amd.utils.check_norain, host and device."""
     from pysteps.utils.check_norain import check_norain as ref_check
