@@ -437,6 +437,16 @@ int psh_ar_iterate_dev(const double *x_dev, int nt, size_t plane, const double *
  *      in one of the 2^20 value buckets, infinities or no finite value in target). */
 int psh_probmatch_dev(const double *initial_dev, const double *target_dev, size_t count, double *out_dev);
 
+/* ---- incremental precipitation mask of the member loops (csrc/mask.hip) -------- *
+ *  psh_dilated_mask_dev  pysteps/nowcasts/utils.py:69-101, compute_dilated_mask(input_mask, kr, r) (nowcasts/
+ *      steps.py:983,1210, sseps.py:472,821): mask (m,n) uint8 on the device, non-zero = set; kr (kh,kw) uint8
+ *      on the HOST, the structuring element of the first dilation (origin at its centre, at most 1024 set
+ *      elements); r in 0..254 rim iterations with the 4-neighbour cross; out (m,n) float64 = (mask0 + sum_k
+ *      dilate^k(mask0)) / its maximum, evaluated as max(0, r + 1 - L1 distance to mask0) / (r + 1) - bit-identical
+ *      with the reference (NaN everywhere if nothing is set, like 0 / 0 in NumPy).  Asynchronous. */
+int psh_dilated_mask_dev(const unsigned char *mask_dev, int m, int n, const unsigned char *kr_host, int kh, int kw,
+                         int r, double *out_dev);
+
 /* ---- multi-GPU: RCCL over xGMI, one rank (process) per GPU ------------------ *
  * The reference has no communication layer (single process, optional dask threads:
  * pysteps/nowcasts/utils.py:464-471); members / fields shard across GPUs with ONE

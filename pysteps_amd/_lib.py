@@ -75,6 +75,7 @@ SIGNATURES = {
                                           c_double, c_void_p]),
     "psh_noise_filter_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "psh_probmatch_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "psh_dilated_mask_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_ar_iterate_dev": (c_int, [c_void_p, c_int, c_size_t, POINTER(c_double), c_int, c_void_p, c_void_p]),
     "psh_lk_greedy_host": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),
     "psh_lk_order_host": (c_int, [c_void_p, c_int, c_float, c_double, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),

@@ -25,7 +25,61 @@ from .. import extrapolation as _hip_extrapolation
 from ..extrapolation.ensemble import EnsembleAdvector
 from ..extrapolation.semilagrangian import extrapolate as _hip_extrapolate
 
-__all__ = ["nowcast_main_loop", "bps_perturbators"]
+__all__ = ["nowcast_main_loop", "bps_perturbators", "compute_dilated_mask"]
+
+MIN_HOST_MASK = 4096  # host masks below this many pixels stay with scipy.ndimage
+_reference_dilated_mask = None  # set by register.patch_dilated_mask(): the function this module replaced
+
+
+def _reference_compute_dilated_mask():
+    if _reference_dilated_mask is not None:
+        return _reference_dilated_mask
+    from pysteps.nowcasts import utils as ref_mod  # noqa: PLC0415
+
+    fn = getattr(ref_mod, "_reference_compute_dilated_mask", ref_mod.compute_dilated_mask)
+    if fn is compute_dilated_mask:
+        raise NotImplementedError("the reference's compute_dilated_mask is not reachable")
+    return fn
+
+
+def compute_dilated_mask(input_mask, kr, r):
+    """Buffer the input rain mask using the given kernel and add a grayscale rim (reference:
+    pysteps/nowcasts/utils.py:69-101; parameters and return value as documented there).
+
+    ``psh_dilated_mask_dev`` (csrc/mask.hip): one dilation by ``kr`` and a truncated L1 distance
+    transform instead of ``1 + r`` calls of ``scipy.ndimage.binary_dilation``; bit-identical output.
+    A ``DeviceArray`` mask (uint8, non-zero = set) gives a ``DeviceArray``.  Masks that are not
+    two-dimensional, more than 254 rim iterations, structuring elements with more than 1024 set
+    elements and small host masks go to the reference's function."""
+    import ctypes  # noqa: PLC0415
+
+    from .. import _lib  # noqa: PLC0415
+    from ..device import DeviceArray  # noqa: PLC0415
+
+    resident = isinstance(input_mask, DeviceArray)
+    struct = np.ascontiguousarray(np.asarray(kr) != 0, dtype=np.uint8)
+    shape = tuple(input_mask.shape) if resident else np.shape(input_mask)
+    eligible = (
+        len(shape) == 2 and struct.ndim == 2 and struct.size > 0 and isinstance(r, (int, np.integer))
+        and 0 <= r <= 254 and int(struct.sum()) <= 1024 and shape[0] > 0 and shape[1] > 0
+    )
+    if resident:
+        if not eligible or input_mask.dtype != np.uint8:
+            raise NotImplementedError("device-resident masks: two-dimensional uint8, r <= 254, <= 1024 structure elements")
+        d_mask = input_mask
+    else:
+        if not eligible or shape[0] * shape[1] < MIN_HOST_MASK:
+            return _reference_compute_dilated_mask()(input_mask, kr, r)
+        # utils.py:87: the mask is cast to uint8 first (a value of 0.5 becomes 0, 256 wraps to 0)
+        d_mask = DeviceArray.from_host(np.ndarray.astype(np.asarray(input_mask), "uint8"), sync=False)
+    out = DeviceArray(shape, np.float64)
+    _lib.check(
+        _lib.lib().psh_dilated_mask_dev(d_mask.ptr, int(shape[0]), int(shape[1]),
+                                        struct.ctypes.data_as(ctypes.c_void_p), int(struct.shape[0]),
+                                        int(struct.shape[1]), int(r), out.ptr),
+        "psh_dilated_mask_dev",
+    )
+    return out if resident else out.to_host()
 
 _BPS_KEYS = ("eps_par", "eps_perp", "p_par", "p_perp", "vsf", "V_par", "V_perp")
 

@@ -173,7 +173,34 @@ def unpatch_autoregression():
         del ref_mod._reference_iterate_ar_model
 
 
-def register(override=False, patch_main_loop=False, fft=True, probmatching=False, autoregression=False):
+def patch_dilated_mask():
+    """Replace ``pysteps.nowcasts.utils.compute_dilated_mask`` (the incremental precipitation mask,
+    reached as ``nowcast_utils.compute_dilated_mask(...)``: nowcasts/steps.py:983,1210, sseps.py:472,821)
+    by the device version; masks it does not take run the reference's function."""
+    import pysteps.nowcasts.utils as ref_mod  # noqa: PLC0415
+
+    from .nowcasts import utils as hip_mod  # noqa: PLC0415
+
+    if ref_mod.compute_dilated_mask is hip_mod.compute_dilated_mask:
+        return []
+    ref_mod._reference_compute_dilated_mask = ref_mod.compute_dilated_mask
+    hip_mod._reference_dilated_mask = ref_mod.compute_dilated_mask
+    ref_mod.compute_dilated_mask = hip_mod.compute_dilated_mask
+    return ["nowcasts.utils:compute_dilated_mask"]
+
+
+def unpatch_dilated_mask():
+    """Undo :func:`patch_dilated_mask`."""
+    import pysteps.nowcasts.utils as ref_mod  # noqa: PLC0415
+
+    ref = getattr(ref_mod, "_reference_compute_dilated_mask", None)
+    if ref is not None:
+        ref_mod.compute_dilated_mask = ref
+        del ref_mod._reference_compute_dilated_mask
+
+
+def register(override=False, patch_main_loop=False, fft=True, probmatching=False, autoregression=False,
+             dilated_mask=False):
     """Register with an importable pysteps; raises ImportError if pysteps is absent.
 
     ``patch_main_loop=True`` also installs the device-resident generic nowcast loop
@@ -192,6 +219,8 @@ def register(override=False, patch_main_loop=False, fft=True, probmatching=False
         added += patch_probmatching()
     if autoregression:
         added += patch_autoregression()
+    if dilated_mask:
+        added += patch_dilated_mask()
     if patch_main_loop:
         import importlib  # noqa: PLC0415
 

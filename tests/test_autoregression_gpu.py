@@ -46,8 +46,8 @@ def test_errors_and_resident_limits(ref_pysteps):
 
 
 def test_nowcasts_steps_with_the_patched_member_loop_pieces(ref_pysteps):
-    """nowcasts.steps with the AR(p) step and the CDF matching replaced by the device versions
-    (steps.py:1095,1137,1199): the stock result, bit for bit."""
+    """nowcasts.steps with the AR(p) step, the CDF matching and the incremental mask replaced by the
+    device versions (steps.py:1095,1137,1199,1210): the stock result, bit for bit."""
     from pysteps import nowcasts
 
     from pysteps_amd import register
@@ -60,9 +60,10 @@ def test_nowcasts_steps_with_the_patched_member_loop_pieces(ref_pysteps):
     steps = nowcasts.get_method("steps")
     want = steps(frames, V, 3, **kw)
     try:
-        assert register.patch_autoregression() and register.patch_probmatching()
+        assert register.patch_autoregression() and register.patch_probmatching() and register.patch_dilated_mask()
         got = steps(frames, V, 3, **kw)
     finally:
         register.unpatch_autoregression()
         register.unpatch_probmatching()
+        register.unpatch_dilated_mask()
     assert np.array_equal(got, want, equal_nan=True)

@@ -292,7 +292,7 @@ def test_steps_with_the_resident_member_batched_loop(pysteps, timesteps, vel_per
 def test_steps_with_every_device_piece_at_once(pysteps):
     """nowcasts.steps with all the operators this library offers for its member loop switched on
     together - extrapolator and resident member-batched loop, FFT method, cascade decomposition, noise
-    generator by name, AR(p) step and CDF matching through the patched module attributes - against the
+    generator by name, AR(p) step, CDF matching and incremental mask through the patched module attributes - against the
     stock run with the same seed (steps.py:637-720, 1095-1199)."""
     from pysteps import nowcasts
     from pysteps_amd import register
@@ -302,14 +302,16 @@ def test_steps_with_every_device_piece_at_once(pysteps):
     steps = nowcasts.get_method("steps")
     want = steps(frames, V, 3, extrap_method="semilagrangian", **kw)
     try:
-        added = register.register(patch_main_loop=True, probmatching=True, autoregression=True)
+        added = register.register(patch_main_loop=True, probmatching=True, autoregression=True, dilated_mask=True)
         assert "probmatching:nonparam_match_empirical_cdf" in added and "autoregression:iterate_ar_model" in added
+        assert "nowcasts.utils:compute_dilated_mask" in added
         got = steps(frames, V, 3, extrap_method="semilagrangian_hip", fft_method="hip", decomp_method="fft_hip",
                     noise_method="nonparametric_hip", **kw)
     finally:
         register.unpatch_main_loop()
         register.unpatch_probmatching()
         register.unpatch_autoregression()
+        register.unpatch_dilated_mask()
     assert got.dtype == want.dtype
     rel = _ensemble_close(got, want)
     assert rel < 1e-4, rel
