@@ -22,6 +22,7 @@ from ..device import DeviceArray
 from ..utils import fft as hip_fft
 
 _weights_cache = {}
+MIN_HOST_PLANE = 1 << 16  # host cascades below this many pixels per level are summed by NumPy
 
 
 def _device_weights(weights):
@@ -130,8 +131,20 @@ def decomposition_fft(field, bp_filter, **kwargs):
 def recompose_fft(decomp, **kwargs):
     """Recompose a cascade obtained with decomposition_fft (reference:
     pysteps/cascade/decomposition.py:265-305).  Device-resident cascades (``cascade_levels`` a
-    DeviceArray) are summed on the GPU; host cascades take the reference's NumPy expression."""
+    DeviceArray) are summed on the GPU, and so are float64 host cascades of spatial decompositions
+    from 65536 pixels per level on; other host cascades take the reference's NumPy expression."""
     levels = decomp["cascade_levels"]
+    if (
+        isinstance(levels, np.ndarray) and levels.ndim == 3 and levels.dtype == np.float64
+        and levels.shape[1] * levels.shape[2] >= MIN_HOST_PLANE and 1 <= levels.shape[0] <= 64
+        and decomp["domain"] == "spatial" and not decomp.get("compact_output", False)
+    ):
+        # host cascade of a spatial decomposition: the same sum on the device, bit-identical with the
+        # NumPy expression below (csrc/cascade.hip `recompose`), one transfer of the levels instead of
+        # nlevels + 2 full-size temporaries
+        on_device = dict(decomp)
+        on_device["cascade_levels"] = DeviceArray.from_host(levels, sync=False)
+        return recompose_fft(on_device).to_host()
     if not isinstance(levels, DeviceArray):
         if decomp["normalized"]:
             mu = decomp["means"]

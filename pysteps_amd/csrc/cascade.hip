@@ -98,19 +98,26 @@ __global__ __launch_bounds__(kRedThreads) void standardise(double *__restrict__ 
     dst[i] = centre_only ? dst[i] - st.x : (dst[i] - st.x) / st.y;
 }
 
+// decomposition.py:294-301: sum_k (levels[k] * sigma[k] + mu[k]) (+ field mean), in NumPy's order and
+// rounding - the product and the sum of every level are separate array operations, np.sum over the
+// stacked levels adds them one after the other (the reduction axis is the outer one: no pairwise
+// blocks), the field mean comes last - so the result is bit-identical with the reference's
 __global__ __launch_bounds__(kRedThreads) void recompose(const double *__restrict__ levels, int nlevels,
                                                          size_t plane, const double *__restrict__ musigma,
-                                                         double add, double *__restrict__ out) {
+                                                         double add, int has_add, double *__restrict__ out) {
+#pragma clang fp contract(off)
   const size_t stride = static_cast<size_t>(gridDim.x) * kRedThreads;
   for (size_t i = static_cast<size_t>(blockIdx.x) * kRedThreads + threadIdx.x; i < plane; i += stride) {
-    // np.sum over the stacked levels adds them in order (pairwise blocks only matter beyond 8 terms
-    // per lane of its inner loop: here the reduction axis is the outer one, plain sequential adds)
     double acc = 0.0;
     for (int k = 0; k < nlevels; ++k) {
-      const double v = levels[static_cast<size_t>(k) * plane + i];
-      acc += musigma ? v * musigma[2 * k + 1] + musigma[2 * k] : v;
+      double v = levels[static_cast<size_t>(k) * plane + i];
+      if (musigma) {
+        const double scaled = v * musigma[2 * k + 1];
+        v = scaled + musigma[2 * k];
+      }
+      acc = k == 0 ? v : acc + v;
     }
-    out[i] = acc + add;
+    out[i] = has_add ? acc + add : acc;
   }
 }
 
@@ -242,7 +249,7 @@ extern "C" int psh_cascade_recompose_dev(const double *levels_dev, int nlevels, 
     musigma = reinterpret_cast<const double *>(d);
   }
   hipLaunchKernelGGL(psh::recompose, dim3(2048), dim3(psh::kRedThreads), 0, c.stream, levels_dev, nlevels,
-                     static_cast<size_t>(m) * n, musigma, field_mean, out_dev);
+                     static_cast<size_t>(m) * n, musigma, field_mean, field_mean != 0.0 ? 1 : 0, out_dev);
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }

@@ -47,6 +47,27 @@ def test_decomposition_matches_the_reference(ref_pysteps, shape, nlevels, normal
     assert _c(recompose_fft(got), field) < 1e-8  # the Gaussian band-pass weights sum to one
 
 
+@pytest.mark.parametrize("normalize,subtract_mean", [(True, False), (False, False), (True, True)])
+def test_recomposition_of_host_cascades_is_bit_identical(ref_pysteps, normalize, subtract_mean):
+    """recompose_fft on a NumPy cascade from 65536 pixels per level on runs on the device: products and
+    sums rounded one by one in NumPy's order (decomposition.py:294-304), so the field is the reference's
+    bit for bit - what lets nowcasts.steps switch it on without changing its result."""
+    from pysteps.cascade.bandpass_filters import filter_gaussian
+    from pysteps.cascade.decomposition import decomposition_fft as ref_decomp
+    from pysteps.cascade.decomposition import recompose_fft as ref_recomp
+
+    from pysteps_amd.cascade import recompose_fft
+
+    for shape, nlevels in (((256, 256), 6), ((512, 384), 8)):
+        field = _field(shape, 5)
+        cascade = ref_decomp(field, filter_gaussian(shape, nlevels), fft_method="numpy", normalize=normalize,
+                             compute_stats=True, subtract_mean=subtract_mean)
+        want = ref_recomp(cascade)
+        got = recompose_fft(cascade)
+        assert isinstance(got, np.ndarray) and got.dtype == want.dtype
+        assert np.array_equal(got, want) and np.array_equal(np.signbit(got), np.signbit(want))
+
+
 def test_resident_cascade_and_option_fallbacks(ref_pysteps):
     from pysteps.cascade.bandpass_filters import filter_gaussian
     from pysteps.cascade.decomposition import decomposition_fft as ref_decomp
