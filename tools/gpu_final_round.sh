@@ -1,6 +1,6 @@
 #!/bin/bash
 # Closing session of a round: the whole GPU suite, the bench line, the probability-matching timings with
-# their kernel trace.  Usage (via gpurun, repo root):  bash tools/gpu_final_round.sh <tag>
+# their kernel trace, the end-to-end nowcasts.steps comparison.  Usage (via gpurun, repo root):  bash tools/gpu_final_round.sh <tag>
 set -u
 TAG=${1:-final}
 OUT=gpurun_out/$TAG
@@ -14,4 +14,7 @@ ROOT=$PWD
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/pm_prof -o pm -- python $ROOT/tools/probmatch_quick.py 1024 4096 > $ROOT/$OUT/probmatch_quick.json 2> $ROOT/$OUT/pm_prof.log)
 cat $OUT/probmatch_quick.json
 python tools/probmatch_trace.py $OUT/pm_prof/pm_kernel_trace.csv 22 31 > $OUT/probmatch_calls.txt 2>&1
+# the real nowcasts.steps with the stock operators and with every device piece on (wall clock, host profile)
+STEPS_PROFILE=1 timeout 200 python tools/steps_quick.py 1024 4 3 > $OUT/steps_quick.json 2> $OUT/steps_host_profile.txt
+cat $OUT/steps_quick.json
 find $OUT -name "*agent_info.csv" -delete
