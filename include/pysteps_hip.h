@@ -447,6 +447,30 @@ int psh_probmatch_dev(const double *initial_dev, const double *target_dev, size_
 int psh_dilated_mask_dev(const unsigned char *mask_dev, int m, int n, const unsigned char *kr_host, int kh, int kw,
                          int r, double *out_dev);
 
+/* ---- numpy.random.RandomState.randn on the device (csrc/rng.hip) ------------------ *
+ * The white noise of the STEPS member loop: pysteps/noise/fftgenerators.py:400 draws
+ * `randstate.randn(m, n)` per member and time step from generators seeded by the chain of
+ * pysteps/nowcasts/steps.py:885-898.  NumPy's legacy generator (third party: MT19937 + polar method,
+ * numpy/random/src/legacy/legacy-distributions.c `legacy_gauss`) restated for n_streams independent
+ * generators; words, positions, accept / reject decisions and the final state are bit-identical with
+ * NumPy, the values wherever the C library's log() is correctly rounded (1 ulp otherwise, csrc/cr_log.h).
+ *  psh_rng_create     keys (n_streams, 624) uint32, pos / has_gauss / gauss per stream: the fields of
+ *                     RandomState.get_state() (has_gauss_host / gauss_host may be NULL); max_draw = the
+ *                     largest `count` psh_rng_randn_dev will be asked for
+ *  psh_rng_randn_dev  out (n_streams, count) float64: the next `count` values of every stream, like
+ *                     `randn(count)`.  Asynchronous; side != 0 runs the draw on the handle's own stream
+ *                     behind everything queued on the library stream so far (the noise of the next time
+ *                     step beside the member loop): psh_rng_wait() makes the library stream wait for it
+ *                     and has to be called before out_dev is read or freed
+ *  psh_rng_get_state  waits for the draws and returns the generators' states in get_state() form
+ *                     (RandomState.set_state() then continues the stream on the host) */
+int psh_rng_create(int n_streams, const uint32_t *keys_host, const int *pos_host, const int *has_gauss_host,
+                   const double *gauss_host, size_t max_draw, void **handle_out);
+int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, int side);
+int psh_rng_wait(void *handle);
+int psh_rng_get_state(void *handle, uint32_t *keys_host, int *pos_host, int *has_gauss_host, double *gauss_host);
+int psh_rng_destroy(void *handle);
+
 /* ---- multi-GPU: RCCL over xGMI, one rank (process) per GPU ------------------ *
  * The reference has no communication layer (single process, optional dask threads:
  * pysteps/nowcasts/utils.py:464-471); members / fields shard across GPUs with ONE

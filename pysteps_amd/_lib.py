@@ -77,6 +77,11 @@ SIGNATURES = {
     "psh_probmatch_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "psh_dilated_mask_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_ar_iterate_dev": (c_int, [c_void_p, c_int, c_size_t, POINTER(c_double), c_int, c_void_p, c_void_p]),
+    "psh_rng_create": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
+    "psh_rng_randn_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_int]),
+    "psh_rng_wait": (c_int, [c_void_p]),
+    "psh_rng_get_state": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psh_rng_destroy": (c_int, [c_void_p]),
     "psh_lk_greedy_host": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),
     "psh_lk_order_host": (c_int, [c_void_p, c_int, c_float, c_double, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),
     "psh_idw_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int, c_double, c_double, c_double, c_void_p]),
