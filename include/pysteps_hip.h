@@ -406,7 +406,8 @@ int psh_fft_c2c2_dev(const void *in_dev, int m, int n, int inverse, void *out_de
  *  psh_cascade_decompose_dev  pysteps/cascade/decomposition.py:77-262 (decomposition_fft), spatial in /
  *      spatial out, no mask: levels[k] = irfft2(rfft2(field [- mean]) * weights[k]), k < nlevels;
  *      weights (nlevels, m, n/2+1) = bp_filter["weights_2d"]; means / stds (np.mean, np.std) of the
- *      levels come back in HOST arrays of nlevels doubles (the call waits for them); normalize != 0:
+ *      levels come back in HOST arrays of nlevels doubles (the call waits for them; both NULL: nothing
+ *      is returned and the call is asynchronous - the resident member loop); normalize != 0:
  *      levels[k] = (levels[k] - mean_k) / std_k; subtract_mean != 0: *field_mean_host = mean(field).
  *  psh_cascade_recompose_dev  decomposition.py:265-305 (recompose_fft): out = sum_k levels[k] * stds[k]
  *      + means[k] (plain sum if means_host == stds_host == NULL) + field_mean.  Asynchronous.
@@ -446,6 +447,37 @@ int psh_probmatch_dev(const double *initial_dev, const double *target_dev, size_
  *      with the reference (NaN everywhere if nothing is set, like 0 / 0 in NumPy).  Asynchronous. */
 int psh_dilated_mask_dev(const unsigned char *mask_dev, int m, int n, const unsigned char *kr_host, int kh, int kw,
                          int r, double *out_dev);
+
+/* ---- element-wise half of one STEPS member update (csrc/steps_loop.hip) ------------ *
+ * pysteps/nowcasts/steps.py:1057-1219 `__update_state` between the spectral operators, the CDF
+ * matching and the incremental mask; float64, every product and sum rounded on its own like the
+ * NumPy expressions (bit-identical arithmetic).  All asynchronous on the library stream.
+ *  psh_steps_ar_recompose_dev  all cascade levels of ONE member: cascades (nlevels, p, plane) holds the
+ *      AR history of every level as a ring - x[-1-j] in slot (head + p - 1 - j) % p; the new value
+ *      x_new = 0.0 + sum_j phi[k][j] x[-1-j] + phi[k][p] (eps[k] * eps_scale[k])   (steps.py:1131-1140,
+ *      timeseries/autoregression.py:1056-1070) overwrites slot `head` (the caller advances head by one,
+ *      modulo p); field = sum_k (x_new[k] * sigma[k] + mu[k])   (cascade/decomposition.py:294-301).
+ *      phi_host (nlevels, p+1); eps_dev (nlevels, plane) or NULL; min_key_dev (may be NULL): np.min(field)
+ *      as an order-preserving 64-bit key in device memory, consumed by psh_steps_mask_dev.
+ *      nlevels <= 16, p <= 8 (PSH_EUNSUPPORTED beyond).
+ *  psh_steps_mask_dev  steps.py:1221-1240: grey_mask_dev (float64, mask_method="incremental"):
+ *      field = min + (field - min) * mask, then field = min wherever not field > min;
+ *      keep_mask_dev (uint8, "obs" / "sprog"): field = min where the mask is 0.  Exactly one of the two.
+ *  psh_steps_mean_shift_dev  steps.py:1203-1206 (probmatching_method="mean"): values >= threshold get
+ *      v - mean(those values) + mu_0 (the mean by a fixed tree of partial sums: ~1e-16 from np.mean)
+ *  psh_ge_mask_dev     out[i] = field[i] >= threshold (uint8; NaN -> 0)      (steps.py:1211)
+ *  psh_nan_where_dev   field[i] = NaN where mask[i] != 0                      (steps.py:1217)
+ *  psh_lerp_dev        out = (1 - w) * a + w * b                              (nowcasts/utils.py:419-427) */
+int psh_steps_ar_recompose_dev(double *cascades_dev, int nlevels, int p, size_t plane, int head,
+                               const double *phi_host, const double *eps_dev, const double *eps_scale_host,
+                               const double *mu_host, const double *sigma_host, double *field_dev,
+                               unsigned long long *min_key_dev);
+int psh_steps_mask_dev(double *field_dev, size_t n, const double *grey_mask_dev, const unsigned char *keep_mask_dev,
+                       const unsigned long long *min_key_dev);
+int psh_steps_mean_shift_dev(double *field_dev, size_t n, double threshold, double mu_0);
+int psh_ge_mask_dev(const double *field_dev, size_t n, double threshold, unsigned char *out_dev);
+int psh_nan_where_dev(double *field_dev, const unsigned char *mask_dev, size_t n);
+int psh_lerp_dev(const double *a_dev, const double *b_dev, double w, double *out_dev, size_t n);
 
 /* ---- numpy.random.RandomState.randn on the device (csrc/rng.hip) ------------------ *
  * The white noise of the STEPS member loop: pysteps/noise/fftgenerators.py:400 draws

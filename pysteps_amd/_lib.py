@@ -77,6 +77,13 @@ SIGNATURES = {
     "psh_probmatch_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "psh_dilated_mask_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_ar_iterate_dev": (c_int, [c_void_p, c_int, c_size_t, POINTER(c_double), c_int, c_void_p, c_void_p]),
+    "psh_steps_ar_recompose_dev": (c_int, [c_void_p, c_int, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]),
+    "psh_steps_mask_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "psh_steps_mean_shift_dev": (c_int, [c_void_p, c_size_t, c_double, c_double]),
+    "psh_ge_mask_dev": (c_int, [c_void_p, c_size_t, c_double, c_void_p]),
+    "psh_nan_where_dev": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "psh_lerp_dev": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_size_t]),
     "psh_rng_create": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
     "psh_rng_randn_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_int]),
     "psh_rng_wait": (c_int, [c_void_p]),

@@ -171,8 +171,11 @@ extern "C" int psh_cascade_decompose_dev(const double *field_dev, const double *
                                          int n, int normalize, int subtract_mean, double *levels_dev,
                                          double *means_host, double *stds_host, double *field_mean_host) {
   PSH_REQUIRE_INIT();
-  if (!field_dev || !weights_dev || !levels_dev || !means_host || !stds_host)
-    return fail(PSH_EINVAL, "cascade_decompose: NULL pointer");
+  if (!field_dev || !weights_dev || !levels_dev) return fail(PSH_EINVAL, "cascade_decompose: NULL pointer");
+  if ((means_host == nullptr) != (stds_host == nullptr))
+    return fail(PSH_EINVAL, "cascade_decompose: means and stds go together");
+  if (!means_host && subtract_mean && field_mean_host)
+    return fail(PSH_EINVAL, "cascade_decompose: the field mean is returned with the level statistics only");
   if (nlevels < 1 || nlevels > 64) return fail(PSH_EINVAL, "cascade_decompose: 1..64 cascade levels");
   if (!psh::fft_shape_supported(m, n))
     return fail(PSH_EUNSUPPORTED, "cascade_decompose: (%d,%d) - both sizes must be powers of two in 2..8192", m, n);
@@ -209,6 +212,7 @@ extern "C" int psh_cascade_decompose_dev(const double *field_dev, const double *
       hipLaunchKernelGGL(psh::standardise, dim3(psh::kRedBlocksF64, nlevels), dim3(psh::kRedThreads), 0, c.stream,
                          levels_dev, plane, stats, 0);
     PSH_HIP(hipGetLastError());
+    if (!means_host) return PSH_OK;  // resident member loop: nobody on the host needs the statistics, no wait
     double2 host[65];
     PSH_HIP(hipMemcpyAsync(host, stats, stats_bytes, hipMemcpyDeviceToHost, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));

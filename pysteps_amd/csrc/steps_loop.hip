@@ -1,0 +1,333 @@
+// The element-wise half of one STEPS member update on the device (the loop itself):
+// what pysteps/nowcasts/steps.py does per member and time step in `__update_state` (:1057-1219)
+// between the spectral operators (noise filter, cascade decomposition: cascade.hip), the CDF matching
+// (probmatch.hip) and the incremental mask (mask.hip).  Everything float64 like the reference, every
+// product and sum rounded on its own (NumPy evaluates each line as separate array operations), so the
+// results are bit-identical with the reference's arithmetic.
+//
+//  * psh_steps_ar_recompose_dev - :1116-1146 + :1176-1185, fused over all cascade levels of a member:
+//      eps_k *= noise_std_coeffs[k]                                           (:1131-1132)
+//      x_new,k = 0.0 + phi_k1 x_k[-1] + ... + phi_kp x_k[-p] + phi_k,p+1 eps_k   (autoregression.py:1056-1070)
+//      field = sum_k (x_new,k sigma_k + mu_k)                                 (decomposition.py:294-301)
+//    The AR history of a level is a ring of p planes: x_new overwrites the oldest one (the reference
+//    copies the series up by one, `x[1:]` + new).  Optionally the field's minimum (np.min) lands in a
+//    device word for the masking step.  Moves (p + 2) L + 1 planes once; no level ever leaves HBM.
+//  * psh_steps_mask_dev         - :1221-1240 `__apply_precipitation_mask` (incremental: grey-scale mask;
+//      obs: boolean mask): pf = min + (pf - min) mask, pixels not above the minimum set to it
+//  * psh_steps_mean_shift_dev   - :1203-1206 probmatching_method="mean"
+//  * psh_ge_mask_dev, psh_nan_where_dev, psh_lerp_dev - `precip_forecast >= precip_thr` (:1211),
+//      `precip_forecast[domain_mask] = nan` (:1217), `(1 - w) prev + w new` (nowcasts/utils.py:419-427)
+#include "common.h"
+
+namespace psh {
+namespace {
+
+constexpr int kMaxLevels = 16, kMaxOrder = 8, kThreads = 256;
+
+struct ArRecompose {
+  double phi[kMaxLevels][kMaxOrder + 1];
+  double eps_scale[kMaxLevels], mu[kMaxLevels], sigma[kMaxLevels];
+  int nlevels, p, head, has_eps;
+};
+
+// order-preserving map double -> uint64 (NaN -> 0, the smallest key: np.min propagates NaN)
+__device__ __forceinline__ unsigned long long min_key(double v) {
+  if (v != v) return 0ull;
+  const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double from_min_key(unsigned long long k) {
+  if (k == 0ull) return __longlong_as_double(0x7ff8000000000000ll);
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double(static_cast<long long>(b));
+}
+
+__device__ __forceinline__ void publish_min(unsigned long long key, unsigned long long *dst) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(key, d);
+    key = o < key ? o : key;
+  }
+  if ((threadIdx.x & 63) == 0 && key < __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(dst, key);
+}
+
+// cascades: (L, p, plane) of one member; eps: (L, plane) or nullptr; one thread = two pixels
+__global__ __launch_bounds__(kThreads) void ar_recompose(double *__restrict__ cascades, const double *__restrict__ eps,
+                                                         size_t plane, ArRecompose a, double *__restrict__ field,
+                                                         unsigned long long *__restrict__ min_out) {
+#pragma clang fp contract(off)
+  const size_t pairs = plane / 2;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  unsigned long long key = ~0ull;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < pairs; i += stride) {
+    double2 total = make_double2(0.0, 0.0);
+    for (int k = 0; k < a.nlevels; ++k) {
+      double *lvl = cascades + static_cast<size_t>(k) * a.p * plane;
+      double2 acc = make_double2(0.0, 0.0);
+      for (int j = 0; j < a.p; ++j) {  // x[-1-j] sits in slot (head + p - 1 - j) mod p
+        int slot = a.head + a.p - 1 - j;
+        if (slot >= a.p) slot -= a.p;
+        const double2 x = reinterpret_cast<const double2 *>(lvl + static_cast<size_t>(slot) * plane)[i];
+        const double tx = a.phi[k][j] * x.x, ty = a.phi[k][j] * x.y;
+        acc.x = acc.x + tx;
+        acc.y = acc.y + ty;
+      }
+      if (a.has_eps) {
+        const double2 e = reinterpret_cast<const double2 *>(eps + static_cast<size_t>(k) * plane)[i];
+        const double ex = e.x * a.eps_scale[k], ey = e.y * a.eps_scale[k];
+        const double tx = a.phi[k][a.p] * ex, ty = a.phi[k][a.p] * ey;
+        acc.x = acc.x + tx;
+        acc.y = acc.y + ty;
+      }
+      reinterpret_cast<double2 *>(lvl + static_cast<size_t>(a.head) * plane)[i] = acc;
+      const double sx = acc.x * a.sigma[k], sy = acc.y * a.sigma[k];
+      const double vx = sx + a.mu[k], vy = sy + a.mu[k];
+      total.x = k == 0 ? vx : total.x + vx;
+      total.y = k == 0 ? vy : total.y + vy;
+    }
+    reinterpret_cast<double2 *>(field)[i] = total;
+    const unsigned long long kx = min_key(total.x), ky = min_key(total.y);
+    key = kx < key ? kx : key;
+    key = ky < key ? ky : key;
+  }
+  if ((plane & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd plane: the last pixel on its own
+    const size_t i = plane - 1;
+    double total = 0.0;
+    for (int k = 0; k < a.nlevels; ++k) {
+      double *lvl = cascades + static_cast<size_t>(k) * a.p * plane;
+      double acc = 0.0;
+      for (int j = 0; j < a.p; ++j) {
+        int slot = a.head + a.p - 1 - j;
+        if (slot >= a.p) slot -= a.p;
+        const double t = a.phi[k][j] * lvl[static_cast<size_t>(slot) * plane + i];
+        acc = acc + t;
+      }
+      if (a.has_eps) {
+        const double e = eps[static_cast<size_t>(k) * plane + i] * a.eps_scale[k];
+        const double t = a.phi[k][a.p] * e;
+        acc = acc + t;
+      }
+      lvl[static_cast<size_t>(a.head) * plane + i] = acc;
+      const double s = acc * a.sigma[k];
+      const double v = s + a.mu[k];
+      total = k == 0 ? v : total + v;
+    }
+    field[i] = total;
+    const unsigned long long kk = min_key(total);
+    key = kk < key ? kk : key;
+  }
+  if (min_out) publish_min(key, min_out);
+}
+
+// steps.py:1221-1240
+__global__ __launch_bounds__(kThreads) void apply_mask(double *__restrict__ field, size_t n, const double *__restrict__ grey,
+                                                       const unsigned char *__restrict__ keep,
+                                                       const unsigned long long *__restrict__ min_key_in) {
+#pragma clang fp contract(off)
+  const double mn = from_min_key(*min_key_in);
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+    double v = field[i];
+    if (grey) {
+      const double d = v - mn;
+      const double s = d * grey[i];
+      v = mn + s;
+      if (!(v > mn)) v = mn;
+    } else if (!keep[i]) {
+      v = mn;
+    }
+    field[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void ge_mask(const double *__restrict__ field, size_t n, double thr,
+                                                    unsigned char *__restrict__ out) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) out[i] = field[i] >= thr ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kThreads) void nan_where(double *__restrict__ field, const unsigned char *__restrict__ mask, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride)
+    if (mask[i]) field[i] = __longlong_as_double(0x7ff8000000000000ll);
+}
+
+__global__ __launch_bounds__(kThreads) void lerp(const double *__restrict__ a, const double *__restrict__ b, double w,
+                                                 double *__restrict__ out, size_t n) {
+#pragma clang fp contract(off)
+  const double wa = 1.0 - w;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+    const double ta = wa * a[i], tb = w * b[i];
+    out[i] = ta + tb;
+  }
+}
+
+// probmatching_method="mean" (steps.py:1203-1206): sum and count of the values >= thr, then
+// v - mean + mu_0 on them.  The sum is a tree of partial sums, not NumPy's pairwise order: the mean
+// agrees with np.mean to ~1e-16 relative.
+__global__ __launch_bounds__(kThreads) void wet_sum(const double *__restrict__ field, size_t n, double thr,
+                                                    double2 *__restrict__ partial) {
+  __shared__ double2 s_part[kThreads / 64];
+  double s = 0.0, c = 0.0;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+    const double v = field[i];
+    if (v >= thr) {
+      s += v;
+      c += 1.0;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    s += __shfl_xor(s, d);
+    c += __shfl_xor(c, d);
+  }
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = make_double2(s, c);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double2 t = s_part[0];
+    for (int w = 1; w < kThreads / 64; ++w) {
+      t.x += s_part[w].x;
+      t.y += s_part[w].y;
+    }
+    partial[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void mean_shift(double *__restrict__ field, size_t n, double thr, double mu0,
+                                                       const double2 *__restrict__ partial, int nparts) {
+#pragma clang fp contract(off)
+  __shared__ double s_mean;
+  if (threadIdx.x == 0) {  // every block sums the partials in the same order
+    double s = 0.0, c = 0.0;
+    for (int k = 0; k < nparts; ++k) {
+      s += partial[k].x;
+      c += partial[k].y;
+    }
+    s_mean = s / c;  // no wet pixel: 0 / 0 = NaN, nothing is touched below (np.mean of an empty array)
+  }
+  __syncthreads();
+  const double mean = s_mean;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+    const double v = field[i];
+    if (v >= thr) {
+      const double d = v - mean;
+      field[i] = d + mu0;
+    }
+  }
+}
+
+unsigned grid_for(size_t n) {
+  const size_t blocks = (n + kThreads - 1) / kThreads;
+  return static_cast<unsigned>(blocks < 8192 ? (blocks ? blocks : 1) : 8192);
+}
+
+}  // namespace
+}  // namespace psh
+
+using psh::fail;
+
+extern "C" int psh_steps_ar_recompose_dev(double *cascades_dev, int nlevels, int p, size_t plane, int head,
+                                          const double *phi_host, const double *eps_dev, const double *eps_scale_host,
+                                          const double *mu_host, const double *sigma_host, double *field_dev,
+                                          unsigned long long *min_key_dev) {
+  PSH_REQUIRE_INIT();
+  if (!cascades_dev || !phi_host || !mu_host || !sigma_host || !field_dev)
+    return fail(PSH_EINVAL, "steps_ar_recompose: NULL pointer");
+  if (nlevels < 1 || nlevels > psh::kMaxLevels || p < 1 || p > psh::kMaxOrder)
+    return fail(PSH_EUNSUPPORTED, "steps_ar_recompose: 1..%d cascade levels, AR order 1..%d", psh::kMaxLevels, psh::kMaxOrder);
+  if (plane == 0 || head < 0 || head >= p) return fail(PSH_EINVAL, "steps_ar_recompose: empty plane or ring head outside 0..p-1");
+  if (eps_dev && !eps_scale_host) return fail(PSH_EINVAL, "steps_ar_recompose: eps without its scale factors");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  psh::ArRecompose a;
+  for (int k = 0; k < nlevels; ++k) {
+    for (int j = 0; j <= p; ++j) a.phi[k][j] = phi_host[static_cast<size_t>(k) * (p + 1) + j];
+    a.eps_scale[k] = eps_dev ? eps_scale_host[k] : 1.0;
+    a.mu[k] = mu_host[k];
+    a.sigma[k] = sigma_host[k];
+  }
+  a.nlevels = nlevels;
+  a.p = p;
+  a.head = head;
+  a.has_eps = eps_dev != nullptr;
+  if (min_key_dev) PSH_HIP(hipMemsetAsync(min_key_dev, 0xff, sizeof(unsigned long long), c.stream));
+  hipLaunchKernelGGL(psh::ar_recompose, dim3(psh::grid_for(plane / 2 + 1)), dim3(psh::kThreads), 0, c.stream, cascades_dev, eps_dev,
+                     plane, a, field_dev, min_key_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+extern "C" int psh_steps_mask_dev(double *field_dev, size_t n, const double *grey_mask_dev, const unsigned char *keep_mask_dev,
+                                  const unsigned long long *min_key_dev) {
+  PSH_REQUIRE_INIT();
+  if (!field_dev || !min_key_dev || (!grey_mask_dev == !keep_mask_dev))
+    return fail(PSH_EINVAL, "steps_mask: field, minimum and exactly one of the two masks are required");
+  if (n == 0) return PSH_OK;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  hipLaunchKernelGGL(psh::apply_mask, dim3(psh::grid_for(n)), dim3(psh::kThreads), 0, c.stream, field_dev, n, grey_mask_dev,
+                     keep_mask_dev, min_key_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+extern "C" int psh_steps_mean_shift_dev(double *field_dev, size_t n, double threshold, double mu_0) {
+  PSH_REQUIRE_INIT();
+  if (!field_dev) return fail(PSH_EINVAL, "steps_mean_shift: NULL pointer");
+  if (n == 0) return PSH_OK;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const int nparts = 1024;
+  void *partial = nullptr;
+  if (int rc = psh_malloc(&partial, nparts * sizeof(double2))) return rc;
+  hipLaunchKernelGGL(psh::wet_sum, dim3(nparts), dim3(psh::kThreads), 0, c.stream, field_dev, n, threshold,
+                     static_cast<double2 *>(partial));
+  hipLaunchKernelGGL(psh::mean_shift, dim3(psh::grid_for(n)), dim3(psh::kThreads), 0, c.stream, field_dev, n, threshold, mu_0,
+                     static_cast<const double2 *>(partial), nparts);
+  const hipError_t e = hipGetLastError();
+  (void)psh_free(partial);  // stream-ordered
+  PSH_HIP(e);
+  return PSH_OK;
+}
+
+extern "C" int psh_ge_mask_dev(const double *field_dev, size_t n, double threshold, unsigned char *out_dev) {
+  PSH_REQUIRE_INIT();
+  if (!field_dev || !out_dev) return fail(PSH_EINVAL, "ge_mask: NULL pointer");
+  if (n == 0) return PSH_OK;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  hipLaunchKernelGGL(psh::ge_mask, dim3(psh::grid_for(n)), dim3(psh::kThreads), 0, c.stream, field_dev, n, threshold, out_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+extern "C" int psh_nan_where_dev(double *field_dev, const unsigned char *mask_dev, size_t n) {
+  PSH_REQUIRE_INIT();
+  if (!field_dev || !mask_dev) return fail(PSH_EINVAL, "nan_where: NULL pointer");
+  if (n == 0) return PSH_OK;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  hipLaunchKernelGGL(psh::nan_where, dim3(psh::grid_for(n)), dim3(psh::kThreads), 0, c.stream, field_dev, mask_dev, n);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+extern "C" int psh_lerp_dev(const double *a_dev, const double *b_dev, double w, double *out_dev, size_t n) {
+  PSH_REQUIRE_INIT();
+  if (!a_dev || !b_dev || !out_dev) return fail(PSH_EINVAL, "lerp: NULL pointer");
+  if (n == 0) return PSH_OK;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  hipLaunchKernelGGL(psh::lerp, dim3(psh::grid_for(n)), dim3(psh::kThreads), 0, c.stream, a_dev, b_dev, w, out_dev, n);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}

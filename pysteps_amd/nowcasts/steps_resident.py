@@ -1,0 +1,240 @@
+"""The STEPS member update with every member's state resident in HBM (the loop).
+
+``pysteps.nowcasts.steps`` advances its ensemble once per time step through
+``StepsNowcaster.__update_state`` (pysteps/nowcasts/steps.py:1057-1219): per member white noise from
+the member's ``RandomState`` -> noise filter -> cascade decomposition -> AR(p) step per cascade level ->
+recomposition -> precipitation mask -> probability matching -> mask update -> domain mask.  The
+reference keeps all of that in NumPy arrays inside the ``state`` dictionary; with the device operators
+patched in one by one (round 2) every call still crossed PCIe twice.
+
+:class:`ResidentSteps` is that update as ONE chain of kernel launches on device-resident state:
+
+* the members' cascades - per member and level a ring of ``ar_order`` planes (``x_new`` overwrites the
+  oldest plane instead of ``np.concatenate``-ing the series up by one);
+* the members' random streams (:class:`pysteps_amd.noise.randstate.DeviceRandomStates`: MT19937 + polar
+  method, the very numbers ``randstate.randn`` would return), drawn one time step ahead on their own
+  stream, beside the rest of the update;
+* band-pass weights, noise filter, CDF-matching target, grey-scale masks.
+
+It is built from the ``state`` / ``params`` dictionaries the reference hands to ``nowcast_main_loop``
+(steps.py:1014-1055) - the drop-in point is the loop (``register(patch_main_loop=True)``), not a fork
+of the nowcaster - and :func:`try_create` declines (returns None, the reference's own update function
+runs) whenever an option is set that the chain does not implement: spectral domain, ``use_full_fft``
+filters, non power-of-two grids, the ``sprog`` mask, no noise.
+
+Parity: every element-wise step is the reference's arithmetic, operation by operation (csrc/steps_loop.hip);
+the transforms agree with numpy.fft to ~1e-16; the random stream is NumPy's up to the rounding of
+``log`` (csrc/cr_log.h).  tests/test_steps_resident_gpu.py runs the real ``nowcasts.steps`` both ways.
+"""
+
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from ..cascade.decomposition import _device_weights
+from ..device import DeviceArray
+from ..noise.randstate import DeviceRandomStates
+from ..utils import fft as hip_fft
+
+__all__ = ["ResidentSteps", "try_create"]
+
+_MAX_LEVELS, _MAX_ORDER = 16, 8
+
+
+def _is_fn(obj, module_suffix, name):
+    """``obj`` is the function ``name`` of a module ending in ``module_suffix`` (the reference's or ours)."""
+    return callable(obj) and getattr(obj, "__name__", "") == name and getattr(obj, "__module__", "").endswith(module_suffix)
+
+
+def _c_doubles(values):
+    arr = np.ascontiguousarray(values, dtype=np.float64)
+    return arr, arr.ctypes.data_as(ctypes.c_void_p)
+
+
+def try_create(func, state, params, shape, n_updates):
+    """A :class:`ResidentSteps` for the update function ``func`` of the reference's STEPS nowcaster, or
+    None if ``func`` is something else or uses options outside the resident chain."""
+    owner = getattr(func, "__self__", None)
+    if owner is None or type(owner).__name__ != "StepsNowcaster" or getattr(func, "__name__", "") != "__update_state":
+        return None
+    try:
+        return ResidentSteps(state, params, shape, n_updates)
+    except _Declined:
+        return None
+
+
+class _Declined(Exception):
+    pass
+
+
+class ResidentSteps:
+    def __init__(self, state, params, shape, n_updates):
+        need = ("noise_method", "domain", "generate_noise", "pert_gen", "decomp_method", "recomp_method", "filter", "phi",
+                "noise_std_coeffs", "n_cascade_levels", "n_ens_members", "mask_method", "probmatching_method", "precip",
+                "precip_thr", "domain_mask")
+        if not isinstance(params, dict) or not isinstance(state, dict) or any(k not in params for k in need):
+            raise _Declined
+        m, n = (int(s) for s in shape)
+        p = params
+        if p["noise_method"] is None or p["domain"] != "spatial" or not hip_fft.supported_shape((m, n)):
+            raise _Declined
+        if not _is_fn(p["generate_noise"], "noise.fftgenerators", "generate_noise_2d_fft_filter"):
+            raise _Declined
+        if not _is_fn(p["decomp_method"], "cascade.decomposition", "decomposition_fft"):
+            raise _Declined
+        if not _is_fn(p["recomp_method"], "cascade.decomposition", "recompose_fft"):
+            raise _Declined
+        F = p["pert_gen"]
+        if not isinstance(F, dict) or F.get("use_full_fft", True) or tuple(F.get("input_shape", ())) != (m, n):
+            raise _Declined
+        if np.shape(F["field"]) != (m, n // 2 + 1) or np.any(~np.isfinite(F["field"])):
+            raise _Declined  # the reference raises its ValueError on its own path
+        if p["mask_method"] not in (None, "incremental", "obs") or p["probmatching_method"] not in (None, "cdf", "mean"):
+            raise _Declined
+        self.B, self.L = int(p["n_ens_members"]), int(p["n_cascade_levels"])
+        phi = np.asarray(p["phi"], dtype=np.float64)
+        if phi.ndim != 2 or phi.shape[0] != self.L:
+            raise _Declined
+        self.p = phi.shape[1] - 1
+        weights = p["filter"]["weights_2d"]
+        if (self.L > _MAX_LEVELS or not 1 <= self.p <= _MAX_ORDER or np.shape(weights) != (self.L, m, n // 2 + 1)
+                or len(p["filter"]["weights_1d"]) != self.L):
+            raise _Declined
+        gens = state.get("randgen_prec")
+        cascades = state.get("precip_cascades")
+        decomp = state.get("precip_decomp")
+        if gens is None or len(gens) != self.B or cascades is None or len(cascades) != self.B or decomp is None:
+            raise _Declined
+        for j in range(self.B):
+            if len(cascades[j]) != self.L or any(np.shape(c) != (self.p, m, n) for c in cascades[j]):
+                raise _Declined
+            if not decomp[j].get("normalized", False) or decomp[j].get("domain") != "spatial":
+                raise _Declined
+
+        self._lib = _lib.lib()
+        self.m, self.n, self.plane = m, n, m * n
+        self.params, self.state = p, state
+        self.n_updates, self.done = int(n_updates), 0
+        self.phi, self._phi_p = _c_doubles(phi)
+        self.noise_std, self._noise_std_p = _c_doubles(np.asarray(p["noise_std_coeffs"], dtype=np.float64).reshape(self.L))
+        self.mu = [np.ascontiguousarray(decomp[j]["means"], dtype=np.float64) for j in range(self.B)]
+        self.sigma = [np.ascontiguousarray(decomp[j]["stds"], dtype=np.float64) for j in range(self.B)]
+        self.weights = _device_weights(weights)
+        self.noise_filter = _device_weights(F["field"])
+        # AR history: (B, L, p, m, n); slot s of the ring holds x[s] of the reference's series at start
+        self.cascades = DeviceArray((self.B, self.L, self.p, m, n), np.float64)
+        stride = self.p * self.plane * 8
+        for j in range(self.B):
+            for k in range(self.L):
+                src = np.ascontiguousarray(cascades[j][k], dtype=np.float64)
+                _lib.check(self._lib.psh_memcpy_h2d(self.cascades.ptr + (j * self.L + k) * stride, src.ctypes.data, src.nbytes), "h2d")
+        _lib.check(self._lib.psh_sync(), "sync")
+        self.head = 0  # slot of the oldest entry
+        self.thr = float(p["precip_thr"]) if p["precip_thr"] is not None else None
+        self.mask_method, self.pm_method = p["mask_method"], p["probmatching_method"]
+        self.grey = self.keep = None
+        if self.mask_method == "incremental":
+            masks = state["mask_prec"]
+            self.struct = np.ascontiguousarray(np.asarray(p["struct"]) != 0, dtype=np.uint8)
+            self.rim = int(p["mask_rim"])
+            if self.struct.ndim != 2 or not 0 <= self.rim <= 254 or int(self.struct.sum()) > 1024 or self.thr is None:
+                raise _Declined
+            self.grey = DeviceArray.from_host(np.stack([np.asarray(mk, dtype=np.float64) for mk in masks]))
+            self.wet = DeviceArray((m, n), np.uint8)
+        elif self.mask_method == "obs":
+            self.keep = DeviceArray.from_host(np.ascontiguousarray(state["mask_prec"], dtype=np.uint8))
+        self.target = None
+        if self.pm_method == "cdf":
+            self.target = DeviceArray.from_host(np.ascontiguousarray(p["precip"], dtype=np.float64))
+        elif self.pm_method == "mean":
+            self.mu_0 = float(p["mu_0"])
+        dm = p["domain_mask"]
+        self.domain_mask = None
+        if dm is not None and np.any(dm):
+            self.domain_mask = DeviceArray.from_host(np.ascontiguousarray(dm, dtype=np.uint8))
+        self.min_key = DeviceArray((8,), np.uint64)
+        self.eps = DeviceArray((self.L, m, n), np.float64)  # cascade of one member's noise field
+        self.noise = DeviceArray((m, n), np.float64)
+        self.rng = DeviceRandomStates(gens, self.plane)
+        self.white = [DeviceArray((self.B, m, n), np.float64), DeviceArray((self.B, m, n), np.float64)]
+        self._white_ready = False
+
+    # ------------------------------------------------------------------
+    def _draw(self, slot):
+        self.rng.randn(self.m, self.n, out=self.white[slot], side=True)
+
+    def update(self):
+        """One ``__update_state``: float64 DeviceArray ``(n_members, m, n)`` of the members' new fields."""
+        lib, m, n, plane = self._lib, self.m, self.n, self.plane
+        slot = self.done & 1
+        if not self._white_ready:
+            self._draw(slot)
+        self.rng.wait()
+        white = self.white[slot]
+        out = DeviceArray((self.B, m, n), np.float64)
+        lvl_stride = self.p * plane * 8
+        for j in range(self.B):
+            field = out.view(j)
+            # fftgenerators.py:400-433 (the filter part), decomposition.py:77-262 with normalize=True
+            _lib.check(lib.psh_noise_filter_dev(white.view(j).ptr, self.noise_filter.ptr, m, n, self.noise.ptr), "psh_noise_filter_dev")
+            if j == self.B - 1 and self.done + 1 < self.n_updates:
+                # the white noise of this step is consumed: the next step's draw runs beside the rest
+                self._draw(slot ^ 1)
+                self._white_ready = True
+            elif j == self.B - 1:
+                self._white_ready = False
+            _lib.check(lib.psh_cascade_decompose_dev(self.noise.ptr, self.weights.ptr, self.L, m, n, 1, 0, self.eps.ptr, None, None, None),
+                       "psh_cascade_decompose_dev")
+            # steps.py:1116-1146 + 1176-1185
+            _lib.check(
+                lib.psh_steps_ar_recompose_dev(self.cascades.ptr + j * self.L * lvl_stride, self.L, self.p, plane, self.head,
+                                               self._phi_p, self.eps.ptr, self._noise_std_p, self.mu[j].ctypes.data,
+                                               self.sigma[j].ctypes.data, field.ptr, self.min_key.ptr),
+                "psh_steps_ar_recompose_dev")
+            if self.grey is not None:  # steps.py:1221-1240
+                _lib.check(lib.psh_steps_mask_dev(field.ptr, plane, self.grey.view(j).ptr, None, self.min_key.ptr), "psh_steps_mask_dev")
+            elif self.keep is not None:
+                _lib.check(lib.psh_steps_mask_dev(field.ptr, plane, None, self.keep.ptr, self.min_key.ptr), "psh_steps_mask_dev")
+            if self.pm_method == "cdf":  # steps.py:1198-1201
+                matched = DeviceArray((m, n), np.float64)
+                rc = lib.psh_probmatch_dev(field.ptr, self.target.ptr, plane, matched.ptr)
+                if rc == _lib.PSH_EUNSUPPORTED:
+                    matched = self._probmatch_on_host(field)
+                else:
+                    _lib.check(rc, "psh_probmatch_dev")
+                _lib.check(lib.psh_memcpy_d2d(field.ptr, matched.ptr, plane * 8), "d2d")
+            elif self.pm_method == "mean":  # steps.py:1203-1206
+                _lib.check(lib.psh_steps_mean_shift_dev(field.ptr, plane, self.thr, self.mu_0), "psh_steps_mean_shift_dev")
+            if self.grey is not None:  # steps.py:1209-1214
+                _lib.check(lib.psh_ge_mask_dev(field.ptr, plane, self.thr, self.wet.ptr), "psh_ge_mask_dev")
+                _lib.check(
+                    lib.psh_dilated_mask_dev(self.wet.ptr, m, n, self.struct.ctypes.data_as(ctypes.c_void_p), int(self.struct.shape[0]),
+                                             int(self.struct.shape[1]), self.rim, self.grey.view(j).ptr),
+                    "psh_dilated_mask_dev")
+            if self.domain_mask is not None:  # steps.py:1217
+                _lib.check(lib.psh_nan_where_dev(field.ptr, self.domain_mask.ptr, plane), "psh_nan_where_dev")
+        self.head = (self.head + 1) % self.p
+        self.done += 1
+        return out
+
+    def _probmatch_on_host(self, field):
+        """The device CDF matching declined (thousands of tied wet values, infinities in the target):
+        this one call goes through the reference's function and comes back."""
+        from ..postprocessing.probmatching import _reference  # noqa: PLC0415
+
+        got = _reference()(field.to_host(), np.asarray(self.params["precip"], dtype=np.float64))
+        return DeviceArray.from_host(np.ascontiguousarray(got, dtype=np.float64))
+
+    def finish(self):
+        """Hand the generators back to the host ``RandomState`` objects (whatever the caller draws next
+        continues the same streams) and release the device state."""
+        self.rng.sync_back()
+        self.rng.close()
+        self.cascades = self.eps = self.white = self.grey = None
+
+    def cascade_levels(self, j):
+        """Member j's latest cascade level fields as the reference holds them (L, m, n) - test hook."""
+        newest = (self.head + self.p - 1) % self.p
+        got = self.cascades.to_host()
+        return got[j, :, newest]

@@ -21,13 +21,17 @@ import time
 
 import numpy as np
 
+from .. import _lib
 from .. import extrapolation as _hip_extrapolation
+from ..device import DeviceArray
 from ..extrapolation.ensemble import EnsembleAdvector
 from ..extrapolation.semilagrangian import extrapolate as _hip_extrapolate
 
 __all__ = ["nowcast_main_loop", "bps_perturbators", "compute_dilated_mask"]
 
 MIN_HOST_MASK = 4096  # host masks below this many pixels stay with scipy.ndimage
+# register(resident_update=...) / tests switch the resident STEPS member update (steps_resident.py) on and off
+resident_update_enabled = True
 _reference_dilated_mask = None  # set by register.patch_dilated_mask(): the function this module replaced
 
 
@@ -173,6 +177,8 @@ class _MemberLoop:
     def advect(self, fields, n_members, dt, t_total):
         if self.disp is None:
             self.disp = [None] * n_members
+        if isinstance(fields, DeviceArray):  # resident member update, foreign extrapolator: through the host
+            fields = fields.to_host()
         res = []
         for j in range(n_members):
             kw = dict(self.kw, displacement_prev=self.disp[j])
@@ -200,7 +206,14 @@ class _BatchedLoop:
         if fields is None:
             self.adv.step(None, dt, lead)
             return None
-        got = self.adv.step(np.asarray(fields), dt, lead, out_dtype=np.asarray(fields).dtype)
+        if isinstance(fields, DeviceArray):
+            # resident member update: float64 fields in HBM -> float32 for the kernel -> ONE transfer of
+            # the advected members per output time step, widened to the reference's float64 on the device
+            f32 = DeviceArray(fields.shape, np.float32)
+            _lib.check(_lib.lib().psh_convert_dev(fields.ptr, f32.ptr, fields.size, 0), "psh_convert_dev")
+            got = self.adv.step(f32, dt, lead).to_host(dtype=fields.dtype)
+        else:
+            got = self.adv.step(np.asarray(fields), dt, lead, out_dtype=np.asarray(fields).dtype)
         return [got[j] for j in range(n_members)]
 
 
@@ -234,6 +247,14 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
     if engine is None:
         engine = _MemberLoop(extrapolator, velocity, precip.shape, extrap_kwargs, velocity_pert_gen)
 
+    # the STEPS member update with all of its state in HBM (steps_resident.py), when `func` is the
+    # reference's StepsNowcaster.__update_state and its options are the ones the chain implements
+    resident = None
+    if ensemble and resident_update_enabled:
+        from .steps_resident import try_create  # noqa: PLC0415
+
+        resident = try_create(func, state, params, precip.shape, len(plan))
+
     prev = np.stack([precip] * n_members) if ensemble else precip[np.newaxis, :]
     outputs = [[] for _ in range(prev.shape[0])] if return_output else None
     t_prev = t_total = 0.0
@@ -242,17 +263,28 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
         if announce:
             print(f"Computing nowcast for time step {t}... ", end="", flush=True)
             step_started = time.time()
-        new, state = func(state, params)
-        if not ensemble:
-            new = new[np.newaxis, :]
+        if resident is not None:
+            new = resident.update()
+        else:
+            new, state = func(state, params)
+            if not ensemble:
+                new = new[np.newaxis, :]
         for t_sub in subtimesteps:
             if not t_sub > 0:
                 continue
             w = t_sub - int(t_sub)  # linear interpolation between the integer-step fields (:419-427)
-            fields = (1.0 - w) * prev + w * new if w > 0.0 else prev
+            if resident is not None and w > 0.0:
+                if not isinstance(prev, DeviceArray):
+                    prev = DeviceArray.from_host(np.ascontiguousarray(prev, dtype=np.float64))
+                fields = DeviceArray(new.shape, np.float64)
+                _lib.check(_lib.lib().psh_lerp_dev(prev.ptr, new.ptr, float(w), fields.ptr, new.size), "psh_lerp_dev")
+            else:
+                fields = (1.0 - w) * prev + w * new if w > 0.0 else prev
             dt = t_sub - t_prev
             t_total += dt
             advected = engine.advect(fields, fields.shape[0], dt, t_total)
+            if isinstance(advected, list) and advected and isinstance(advected[0], DeviceArray):
+                advected = [a.to_host() for a in advected]
             if return_output:
                 for j, a in enumerate(advected):
                     outputs[j].append(a)
@@ -268,6 +300,8 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
         if announce:
             print(f"{time.time() - step_started:.2f} seconds." if measure_time else "done.")
 
+    if resident is not None:
+        resident.finish()
     result = None
     if return_output:
         result = np.stack([np.stack(o) for o in outputs])

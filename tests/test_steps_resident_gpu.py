@@ -1,0 +1,262 @@
+"""The resident STEPS member update (pysteps_amd/nowcasts/steps_resident.py, csrc/steps_loop.hip,
+csrc/rng.hip) against the reference's own update function and the real ``nowcasts.steps``
+(pysteps/nowcasts/steps.py:1057-1219, from oracle/_ref).
+
+* the element-wise kernels against the NumPy expressions of the reference, bit for bit;
+* ``ResidentSteps.update()`` beside ``StepsNowcaster.__update_state`` on the same state, step by step:
+  same random numbers, transforms within 1e-16 of numpy.fft - the fields agree to ~1e-12 except for
+  the few pixels a threshold or a rank decides differently;
+* the real ``nowcasts.steps`` end to end with the resident loop against the stock run.
+"""
+
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import nan_mismatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    from pysteps_amd.device import DeviceArray
+
+    return DeviceArray.from_host(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("L,p,shape,with_eps", [(6, 2, (64, 64), True), (3, 1, (37, 53), True), (8, 3, (128, 64), True),
+                                                (2, 2, (31, 33), False), (16, 8, (16, 16), True)])
+def test_ar_recompose_bit_identical_with_numpy(ref_pysteps, L, p, shape, with_eps):
+    """AR(p) step of all levels + recomposition in one kernel == iterate_ar_model per level (with the
+    `eps *= noise_std_coeffs` of steps.py:1131-1132) + recompose_fft, bit for bit, ring rotation included."""
+    from pysteps.cascade.decomposition import recompose_fft
+    from pysteps.timeseries.autoregression import iterate_ar_model
+
+    from pysteps_amd import _lib
+    from pysteps_amd.device import DeviceArray
+
+    rng = np.random.default_rng(L * 100 + p)
+    m, n = shape
+    plane = m * n
+    x = [rng.standard_normal((p, m, n)) for _ in range(L)]
+    x[0][0, 0, 0] = -0.0
+    phi = rng.uniform(-0.9, 0.9, (L, p + 1))
+    scale = rng.uniform(0.5, 1.5, L)
+    mu, sigma = rng.standard_normal(L), rng.uniform(0.1, 2.0, L)
+    casc = _dev(np.stack(x))
+    field = DeviceArray((m, n), np.float64)
+    key = DeviceArray((8,), np.uint64)
+    head = 0
+    lib = _lib.lib()
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    for step in range(p + 2):
+        eps = rng.standard_normal((L, m, n)) if with_eps else None
+        d_eps = None if eps is None else _dev(eps)
+        _lib.check(lib.psh_steps_ar_recompose_dev(casc.ptr, L, p, plane, head, ptr(phi), None if eps is None else d_eps.ptr,
+                                                  ptr(scale), ptr(mu), ptr(sigma), field.ptr, key.ptr))
+        head = (head + 1) % p
+        for k in range(L):
+            e = None
+            if eps is not None:
+                e = eps[k].copy()
+                e *= scale[k]
+            x[k] = iterate_ar_model(x[k], phi[k], eps=e)
+        want = recompose_fft({"cascade_levels": np.stack([x[k][-1] for k in range(L)]), "domain": "spatial", "normalized": True,
+                              "means": list(mu), "stds": list(sigma), "compact_output": False})
+        got = field.to_host()
+        np.testing.assert_array_equal(got, want)
+        assert np.array_equal(np.signbit(got), np.signbit(want))
+        # the ring: slot (head + j) % p holds x[j]
+        ring = casc.to_host()
+        for k in range(L):
+            for j in range(p):
+                np.testing.assert_array_equal(ring[k, (head + j) % p], x[k][j])
+        # the minimum for the masking step
+        grey = rng.uniform(0, 1, (m, n))
+        grey[rng.uniform(size=(m, n)) < 0.3] = 0.0
+        d_grey = _dev(grey)
+        _lib.check(lib.psh_steps_mask_dev(field.ptr, plane, d_grey.ptr, None, key.ptr))
+        mn = want.min()
+        masked = mn + (want - mn) * grey
+        masked[~(masked > mn)] = mn
+        np.testing.assert_array_equal(field.to_host(), masked)
+
+
+def test_elementwise_pieces_bit_identical_with_numpy():
+    from pysteps_amd import _lib
+    from pysteps_amd.device import DeviceArray
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(3)
+    a, b = rng.standard_normal((97, 61)), rng.standard_normal((97, 61))
+    a[3, 4] = np.nan
+    n = a.size
+    out = DeviceArray(a.shape, np.float64)
+    d_a, d_b = _dev(a), _dev(b)  # named: a temporary would hand its block to the next allocation
+    _lib.check(lib.psh_lerp_dev(d_a.ptr, d_b.ptr, 0.3, out.ptr, n))
+    np.testing.assert_array_equal(out.to_host(), (1.0 - 0.3) * a + 0.3 * b)
+    wet = DeviceArray(a.shape, np.uint8)
+    _lib.check(lib.psh_ge_mask_dev(d_a.ptr, n, 0.25, wet.ptr))
+    np.testing.assert_array_equal(wet.to_host().astype(bool), a >= 0.25)
+    holes = rng.uniform(size=a.shape) < 0.2
+    d = _dev(b)
+    d_holes = _dev(holes.astype(np.uint8))
+    _lib.check(lib.psh_nan_where_dev(d.ptr, d_holes.ptr, n))
+    want = b.copy()
+    want[holes] = np.nan
+    np.testing.assert_array_equal(d.to_host(), want)
+    # obs-type mask (steps.py:1237-1240): pixels outside the boolean mask take the minimum
+    key = DeviceArray((8,), np.uint64)
+    x = rng.standard_normal((1, 1) + b.shape)
+    casc, field = _dev(x), DeviceArray(b.shape, np.float64)
+    one = np.ones(2)
+    p = lambda v: v.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _lib.check(lib.psh_steps_ar_recompose_dev(casc.ptr, 1, 1, n, 0, p(one), None, None, p(np.zeros(1)), p(np.ones(1)), field.ptr, key.ptr))
+    d_keep = _dev((~holes).astype(np.uint8))
+    _lib.check(lib.psh_steps_mask_dev(field.ptr, n, None, d_keep.ptr, key.ptr))
+    f = x[0, 0] * 1.0 + 0.0
+    want = f.copy()
+    want[holes] = f.min()
+    np.testing.assert_array_equal(field.to_host(), want)
+    # probmatching_method="mean" (steps.py:1203-1206)
+    d = _dev(b)
+    _lib.check(lib.psh_steps_mean_shift_dev(d.ptr, n, 0.1, 2.5))
+    want = b.copy()
+    mask = want >= 0.1
+    want[mask] = want[mask] - np.mean(want[mask]) + 2.5
+    np.testing.assert_allclose(d.to_host(), want, rtol=0, atol=1e-14)
+
+
+def _steps_inputs(m, n):
+    from tools import synth
+
+    return synth.steps_frames(m, n, 3), synth.true_velocity(m, n).astype(np.float64)
+
+
+CONFIGS = {
+    "incremental_cdf": dict(mask_method="incremental", probmatching_method="cdf"),
+    "obs_none": dict(mask_method="obs", probmatching_method=None),
+    "nomask_mean": dict(mask_method=None, probmatching_method="mean"),
+    "ar1_8levels": dict(mask_method="incremental", probmatching_method="cdf", ar_order=1, n_cascade_levels=8),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_update_beside_the_reference_update(ref_pysteps, name):
+    """ResidentSteps.update() and StepsNowcaster.__update_state advance the same initial state side by
+    side: the fields of every member and step agree to 1e-9 of the field's range on all but 1e-3 of
+    the pixels (the ones a threshold / a rank decided differently), NaN masks identical, and the host
+    generators end where the device generators end."""
+    from pysteps import nowcasts
+    from pysteps.nowcasts import steps as steps_mod
+
+    from pysteps_amd import register
+    from pysteps_amd.nowcasts.steps_resident import ResidentSteps
+
+    register.register()
+    cfg = dict(CONFIGS[name])
+    ar_order = cfg.pop("ar_order", 2)
+    m = n = 128
+    frames, V = _steps_inputs(m, n)
+    frames = frames[-(ar_order + 1):]
+    if name == "obs_none":
+        frames = frames.copy()
+        frames[:, :9, :] = np.nan  # a domain mask (steps.py:1217)
+    kw = dict(n_ens_members=3, n_cascade_levels=6, precip_thr=-10.0, kmperpixel=1.0, timestep=5.0, seed=24, vel_pert_method=None,
+              num_workers=1, ar_order=ar_order, extrap_method="semilagrangian_hip")
+    kw.update(cfg)
+    report = []
+
+    def side_by_side(precip, velocity, state, timesteps, extrap_method, func, params=None, num_ensemble_members=1, **_):
+        nsteps = timesteps + 1
+        res = ResidentSteps(state, params, precip.shape, nsteps)
+        for _t in range(nsteps):
+            want, state = func(state, params)
+            got = res.update().to_host()
+            assert nan_mismatch(got, want) == 0
+            scale = float(np.nanmax(want) - np.nanmin(want))
+            diff = np.abs(got - want)
+            ok = np.isfinite(diff)
+            report.append((float(np.count_nonzero(diff[ok] > 1e-9 * scale)) / max(1, np.count_nonzero(ok)),
+                           float(np.median(diff[ok]) / scale)))
+        gens = [np.random.RandomState() for _ in state["randgen_prec"]]
+        for g, st in zip(gens, res.rng.get_states()):
+            g.set_state(st)
+        for g, h in zip(gens, state["randgen_prec"]):
+            assert g.randint(0, 1 << 30) == h.randint(0, 1 << 30)
+        return np.zeros((num_ensemble_members, timesteps) + precip.shape)
+
+    orig = steps_mod.nowcast_main_loop
+    try:
+        steps_mod.nowcast_main_loop = side_by_side
+        nowcasts.get_method("steps")(frames, V, 3, **kw)
+    finally:
+        steps_mod.nowcast_main_loop = orig
+    assert len(report) == 4
+    for flipped, median in report:
+        assert flipped <= 1e-3, report
+        assert median <= 1e-12, report
+
+
+@pytest.mark.parametrize("timesteps,vel_pert", [(3, "bps"), ([0.5, 1.0, 2.5], None)])
+def test_steps_end_to_end_resident_loop_runs_and_matches(ref_pysteps, timesteps, vel_pert):
+    """the real nowcasts.steps with register(patch_main_loop=True): the resident update is what runs
+    (counted), the result matches the stock run with the stock operators"""
+    from pysteps import nowcasts
+
+    from pysteps_amd import register
+    from pysteps_amd.nowcasts import steps_resident
+    from test_callers_gpu import _ensemble_close, _steps_kwargs
+
+    frames, V = _steps_inputs(256, 256)
+    kw = _steps_kwargs()
+    kw["vel_pert_method"] = vel_pert
+    kw["probmatching_method"] = "cdf"
+    steps = nowcasts.get_method("steps")
+    want = steps(frames, V, timesteps, extrap_method="semilagrangian", **kw)
+    calls = []
+    orig = steps_resident.ResidentSteps.update
+
+    def counting(self):
+        calls.append(self.B)
+        return orig(self)
+
+    try:
+        register.register(patch_main_loop=True)
+        steps_resident.ResidentSteps.update = counting
+        got = steps(frames, V, timesteps, extrap_method="semilagrangian_hip", **kw)
+    finally:
+        steps_resident.ResidentSteps.update = orig
+        register.unpatch_main_loop()
+    assert len(calls) == (timesteps if isinstance(timesteps, int) else int(np.ceil(timesteps[-1]))) + 1
+    assert got.dtype == want.dtype
+    rel = _ensemble_close(got, want)
+    assert rel < 1e-4, rel
+
+
+def test_declined_options_take_the_reference_update(ref_pysteps):
+    """spectral domain / sprog mask: try_create returns None and the reference's own function runs"""
+    from pysteps import nowcasts
+
+    from pysteps_amd import register
+    from pysteps_amd.nowcasts import steps_resident
+
+    frames, V = _steps_inputs(128, 128)
+    made = []
+    orig = steps_resident.ResidentSteps.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(1)
+
+    try:
+        register.register(patch_main_loop=True)
+        steps_resident.ResidentSteps.__init__ = spy
+        out = nowcasts.get_method("steps")(frames, V, 2, n_ens_members=2, n_cascade_levels=6, precip_thr=-10.0, kmperpixel=1.0,
+                                           timestep=5.0, seed=1, mask_method="sprog", extrap_method="semilagrangian_hip",
+                                           num_workers=1)
+    finally:
+        steps_resident.ResidentSteps.__init__ = orig
+        register.unpatch_main_loop()
+    assert not made and out.shape == (2, 2, 128, 128)
