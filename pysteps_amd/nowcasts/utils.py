@@ -32,6 +32,28 @@ __all__ = ["nowcast_main_loop", "bps_perturbators", "compute_dilated_mask"]
 MIN_HOST_MASK = 4096  # host masks below this many pixels stay with scipy.ndimage
 # register(resident_update=...) / tests switch the resident STEPS member update (steps_resident.py) on and off
 resident_update_enabled = True
+# device time of the last resident run by phase (ms): {"upload", "update", "advect", "download"} -
+# events on the library stream, read once at the end of the loop (tools/steps_quick.py, bench.py)
+last_run_stats = {}
+
+
+class _Timeline:
+    """Events on the library stream between the phases of the loop; read once, at the end."""
+
+    def __init__(self):
+        from ..device import Event  # noqa: PLC0415
+
+        self._event = Event
+        self.marks = [("start", Event().record())]
+
+    def mark(self, phase):
+        self.marks.append((phase, self._event().record()))
+
+    def totals(self):
+        out = {}
+        for (_, e0), (name, e1) in zip(self.marks[:-1], self.marks[1:]):
+            out[name] = out.get(name, 0.0) + e0.elapsed_ms(e1)
+        return out
 _reference_dilated_mask = None  # set by register.patch_dilated_mask(): the function this module replaced
 
 
@@ -198,6 +220,7 @@ class _BatchedLoop:
     def __init__(self, velocity, perturbators, opts):
         self.velocity, self.perts, self.opts = velocity, perturbators, opts
         self.adv = None
+        self.timeline = None
 
     def advect(self, fields, n_members, dt, t_total):
         if self.adv is None:
@@ -211,7 +234,12 @@ class _BatchedLoop:
             # the advected members per output time step, widened to the reference's float64 on the device
             f32 = DeviceArray(fields.shape, np.float32)
             _lib.check(_lib.lib().psh_convert_dev(fields.ptr, f32.ptr, fields.size, 0), "psh_convert_dev")
-            got = self.adv.step(f32, dt, lead).to_host(dtype=fields.dtype)
+            moved = self.adv.step(f32, dt, lead)
+            if self.timeline is not None:
+                self.timeline.mark("advect")
+            got = moved.to_host(dtype=fields.dtype)
+            if self.timeline is not None:
+                self.timeline.mark("download")
         else:
             got = self.adv.step(np.asarray(fields), dt, lead, out_dtype=np.asarray(fields).dtype)
         return [got[j] for j in range(n_members)]
@@ -249,11 +277,18 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
 
     # the STEPS member update with all of its state in HBM (steps_resident.py), when `func` is the
     # reference's StepsNowcaster.__update_state and its options are the ones the chain implements
-    resident = None
+    resident = timeline = None
     if ensemble and resident_update_enabled:
         from .steps_resident import try_create  # noqa: PLC0415
 
+        timeline = _Timeline()
         resident = try_create(func, state, params, precip.shape, len(plan))
+        if resident is None:
+            timeline = None
+        else:
+            timeline.mark("upload")
+            if isinstance(engine, _BatchedLoop):
+                engine.timeline = timeline
 
     prev = np.stack([precip] * n_members) if ensemble else precip[np.newaxis, :]
     outputs = [[] for _ in range(prev.shape[0])] if return_output else None
@@ -265,6 +300,7 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
             step_started = time.time()
         if resident is not None:
             new = resident.update()
+            timeline.mark("update")
         else:
             new, state = func(state, params)
             if not ensemble:
@@ -302,6 +338,9 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
 
     if resident is not None:
         resident.finish()
+        last_run_stats.clear()
+        last_run_stats.update(timeline.totals())
+        last_run_stats["members"], last_run_stats["updates"] = n_members, len(plan)
     result = None
     if return_output:
         result = np.stack([np.stack(o) for o in outputs])
