@@ -60,6 +60,8 @@ int psh_malloc(void **dev_ptr, size_t nbytes);
 int psh_free(void *dev_ptr);
 int psh_memcpy_h2d(void *dst_dev, const void *src_host, size_t nbytes); /* async; pageable src is staged */
 int psh_memcpy_d2h(void *dst_host, const void *src_dev, size_t nbytes); /* synchronous */
+/* queued on the library stream; dst should come from psh_host_alloc (pinned) - psh_sync() before it is read */
+int psh_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t nbytes);
 int psh_memcpy_d2d(void *dst_dev, const void *src_dev, size_t nbytes);  /* async */
 int psh_memset(void *dst_dev, int byte_value, size_t nbytes);           /* async */
 int psh_sync(void);

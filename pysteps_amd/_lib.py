@@ -55,6 +55,7 @@ SIGNATURES = {
     "psh_free": (c_int, [c_void_p]),
     "psh_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_size_t]),
     "psh_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "psh_memcpy_d2h_async": (c_int, [c_void_p, c_void_p, c_size_t]),
     "psh_convert_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
     "psh_count_above_dev": (c_int, [c_void_p, c_size_t, c_double, POINTER(c_double), POINTER(c_double)]),
     "psh_host_alloc": (c_int, [POINTER(c_void_p), c_size_t]),

@@ -367,6 +367,17 @@ int psh_memcpy_d2h(void *dst_host, const void *src_dev, size_t nbytes) {
   return PSH_OK;
 }
 
+int psh_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t nbytes) {
+  PSH_REQUIRE_INIT();
+  if (nbytes == 0) return PSH_OK;
+  if (!dst_host || !src_dev) return fail(PSH_EINVAL, "psh_memcpy_d2h_async: NULL pointer");
+  psh::Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  PSH_HIP(hipMemcpyAsync(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost, c.stream));
+  return PSH_OK;
+}
+
 int psh_memcpy_d2d(void *dst_dev, const void *src_dev, size_t nbytes) {
   PSH_REQUIRE_INIT();
   if (nbytes == 0) return PSH_OK;

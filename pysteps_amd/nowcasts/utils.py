@@ -41,18 +41,29 @@ class _Timeline:
     """Events on the library stream between the phases of the loop; read once, at the end."""
 
     def __init__(self):
+        import os  # noqa: PLC0415
+
         from ..device import Event  # noqa: PLC0415
 
         self._event = Event
-        self.marks = [("start", Event().record())]
+        # PYSTEPS_HIP_LOOP_WALL=1: wait for the stream at every mark and use the host clock instead
+        # (serialises the loop; for cross-checking the event figures)
+        self.wall = os.environ.get("PYSTEPS_HIP_LOOP_WALL") == "1"
+        self.marks = [("start", self._now())]
+
+    def _now(self):
+        if self.wall:
+            _lib.check(_lib.lib().psh_sync(), "psh_sync")
+            return time.perf_counter()
+        return self._event().record()
 
     def mark(self, phase):
-        self.marks.append((phase, self._event().record()))
+        self.marks.append((phase, self._now()))
 
     def totals(self):
         out = {}
         for (_, e0), (name, e1) in zip(self.marks[:-1], self.marks[1:]):
-            out[name] = out.get(name, 0.0) + e0.elapsed_ms(e1)
+            out[name] = out.get(name, 0.0) + ((e1 - e0) * 1e3 if self.wall else e0.elapsed_ms(e1))
         return out
 _reference_dilated_mask = None  # set by register.patch_dilated_mask(): the function this module replaced
 
@@ -222,7 +233,7 @@ class _BatchedLoop:
         self.adv = None
         self.timeline = None
 
-    def advect(self, fields, n_members, dt, t_total):
+    def advect(self, fields, n_members, dt, t_total, sink=None):
         if self.adv is None:
             self.adv = EnsembleAdvector(self.velocity, n_members, self.perts, **self.opts)
         lead = None if self.perts is None else t_total * self.perts[0]["time_scale"]  # minutes
@@ -237,6 +248,18 @@ class _BatchedLoop:
             moved = self.adv.step(f32, dt, lead)
             if self.timeline is not None:
                 self.timeline.mark("advect")
+            if sink is not None:
+                # straight into the caller's (n_members, n_timesteps, m, n) result block: widened on the
+                # device, one queued copy per member, nobody waits here
+                wide = DeviceArray(moved.shape, np.float64)
+                lib = _lib.lib()
+                _lib.check(lib.psh_convert_dev(moved.ptr, wide.ptr, moved.size, 1), "psh_convert_dev")
+                plane_bytes = wide.nbytes // n_members
+                for j in range(n_members):
+                    _lib.check(lib.psh_memcpy_d2h_async(sink[j].ctypes.data, wide.ptr + j * plane_bytes, plane_bytes), "d2h")
+                if self.timeline is not None:
+                    self.timeline.mark("download")
+                return list(sink)
             got = moved.to_host(dtype=fields.dtype)
             if self.timeline is not None:
                 self.timeline.mark("download")
@@ -252,6 +275,7 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
     array of forecast fields ``(n_timesteps, m, n)`` or ``(n_members, n_timesteps, m, n)``, with the
     loop time when ``measure_time`` is set.  ``num_workers`` is accepted; the members are advanced
     together on the GPU instead of by worker threads."""
+    started = time.time()  # like the reference (utils.py:347): set-up of the loop is part of its time
     plan = _time_bins(timesteps)
     extrap_kwargs = {} if extrap_kwargs is None else dict(extrap_kwargs)
     try:
@@ -292,8 +316,20 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
 
     prev = np.stack([precip] * n_members) if ensemble else precip[np.newaxis, :]
     outputs = [[] for _ in range(prev.shape[0])] if return_output else None
+    # resident update + member-batched advection: the advected members of every output time step are
+    # copied straight into ONE (n_members, n_timesteps, m, n) block (pinned if the pool has room) by
+    # queued copies; the loop waits for them once at the end (and before every callback)
+    block = None
+    if resident is not None and isinstance(engine, _BatchedLoop) and return_output:
+        from .. import _pinned  # noqa: PLC0415
+
+        n_out = sum(1 for _, sub, _ in plan for ts in sub if ts > 0)
+        if n_out:
+            block = _pinned.empty((n_members, n_out) + tuple(precip.shape), np.float64)
+            if timeline is not None:
+                timeline.mark("result_block")
+    out_index = 0
     t_prev = t_total = 0.0
-    started = time.time()
     for t, subtimesteps, announce in plan:
         if announce:
             print(f"Computing nowcast for time step {t}... ", end="", flush=True)
@@ -318,12 +354,16 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
                 fields = (1.0 - w) * prev + w * new if w > 0.0 else prev
             dt = t_sub - t_prev
             t_total += dt
-            advected = engine.advect(fields, fields.shape[0], dt, t_total)
-            if isinstance(advected, list) and advected and isinstance(advected[0], DeviceArray):
-                advected = [a.to_host() for a in advected]
-            if return_output:
-                for j, a in enumerate(advected):
-                    outputs[j].append(a)
+            if block is not None:
+                advected = engine.advect(fields, fields.shape[0], dt, t_total, sink=block[:, out_index])
+                out_index += 1
+                if callback is not None:
+                    _lib.check(_lib.lib().psh_sync(), "psh_sync")
+            else:
+                advected = engine.advect(fields, fields.shape[0], dt, t_total)
+                if return_output:
+                    for j, a in enumerate(advected):
+                        outputs[j].append(a)
             if callback is not None:
                 callback(np.stack(advected))
             t_prev = t_sub
@@ -342,7 +382,10 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
         last_run_stats.update(timeline.totals())
         last_run_stats["members"], last_run_stats["updates"] = n_members, len(plan)
     result = None
-    if return_output:
+    if block is not None:
+        _lib.check(_lib.lib().psh_sync(), "psh_sync")
+        result = block
+    elif return_output:
         result = np.stack([np.stack(o) for o in outputs])
         if not ensemble:
             result = result[0, :]

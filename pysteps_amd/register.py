@@ -15,6 +15,7 @@ pysteps/tests/test_interfaces.py:69-78,220-233 then fail by design).
 FFT_NAME = "hip"
 CASCADE_NAME = "fft_hip"  # pysteps.cascade.get_method("fft_hip") -> (decomposition_fft, recompose_fft)
 NOISE_NAMES = {"parametric_hip": "parametric", "nonparametric_hip": "nonparametric"}
+BPS_NAME = "bps_hip"  # vel_pert_method: the reference's generate_bps behind an initialiser that shares the unit fields
 EXTRAPOLATION_NAMES = ("semilagrangian_hip",)
 MOTION_NAMES = ("lk_hip", "lucaskanade_hip")
 _STOCK_EXTRAPOLATION = ("semilagrangian",)
@@ -105,6 +106,10 @@ def register_spectral():
         init = noise_if._noise_methods[stock][0]
         noise_if._noise_methods[name] = (init, generate_noise_2d_fft_filter)
         added.append("noise:" + name)
+    from .noise.motion import initialize_bps  # noqa: PLC0415
+
+    noise_if._noise_methods[BPS_NAME] = (initialize_bps, noise_if._noise_methods["bps"][1])
+    added.append("noise:" + BPS_NAME)
     return added
 
 

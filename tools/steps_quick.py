@@ -38,6 +38,7 @@ ap.add_argument("--stock-steps", type=int, default=None)
 ap.add_argument("--no-stock", action="store_true")
 ap.add_argument("--levels", type=int, default=6)
 ap.add_argument("--no-resident", action="store_true", help="round-2 state: device operators, host member loop")
+ap.add_argument("--profile", action="store_true", help="cProfile of the device run (host side), top of the list to stderr")
 args = ap.parse_args()
 size, members, timesteps = args.size, args.members, args.timesteps
 frames = synth.steps_frames(size, size, 3)
@@ -50,7 +51,7 @@ steps = nowcasts.get_method("steps")
 def run(n_members, n_steps, **extra):
     t = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
-        out, init_s, loop_s = steps(frames, V, n_steps, n_ens_members=n_members, **kw, **extra)
+        out, init_s, loop_s = steps(frames, V, n_steps, n_ens_members=n_members, **dict(kw, **extra))
     return out, dict(total_s=time.perf_counter() - t, init_s=init_s, loop_s=loop_s)
 
 
@@ -66,14 +67,27 @@ if not args.no_stock:
     report["stock"] = stock
 register.register(patch_main_loop=True, probmatching=True, autoregression=True, dilated_mask=True)
 hip_loop.resident_update_enabled = not args.no_resident
-hip = dict(extrap_method="semilagrangian_hip", fft_method="hip", decomp_method="fft_hip", noise_method="nonparametric_hip")
-run(min(members, 2), 1, **hip)  # library initialisation, weight uploads, allocator warm-up
-got, dev = run(members, timesteps, **hip)
+hip = dict(extrap_method="semilagrangian_hip", fft_method="hip", decomp_method="fft_hip", noise_method="nonparametric_hip",
+           vel_pert_method="bps_hip")
+run(members, timesteps if size <= 2048 else 1, **hip)  # library initialisation, weight uploads, block pools
+if size > 2048:
+    run(members, timesteps, **hip)  # ... and the pinned result block of this very shape (a service repeats its shape)
+if args.profile:
+    import cProfile
+    import pstats
+
+    prof = cProfile.Profile()
+    prof.enable()
+    got, dev = run(members, timesteps, **hip)
+    prof.disable()
+    pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(32)
+else:
+    got, dev = run(members, timesteps, **hip)
 dev["resident"] = not args.no_resident
 if hip_loop.last_run_stats and not args.no_resident:
     ph = dict(hip_loop.last_run_stats)
     dev["device_ms_by_phase"] = {k: round(v, 3) for k, v in ph.items() if isinstance(v, float)}
-    moved = ph.get("upload", 0.0) + ph.get("download", 0.0)
+    moved = ph.get("upload", 0.0) + ph.get("download", 0.0) + ph.get("result_block", 0.0)
     busy = sum(v for v in ph.values() if isinstance(v, float))
     dev["transfer_share_of_loop_device_time"] = moved / busy if busy else None
     dev["ms_per_member_update"] = ph.get("update", 0.0) / (members * (timesteps + 1))
