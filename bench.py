@@ -50,6 +50,12 @@ def parse_args():
     ap.add_argument("--no-members-leg", action="store_true", help="skip the config-4 single-GPU reference leg")
     ap.add_argument("--members-per-gpu", type=int, default=6, help="STEPS members per GPU (config 4: 48 on 8 GPUs)")
     ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    ap.add_argument("--workload", choices=("default", "config5"), default="default",
+                    help="config5: 8192^2 x 36 lead times, row bands over the ranks (banded LK + tiled semilag, RCCL collectives)")
+    ap.add_argument("--no-steps-loop", action="store_true", help="skip the STEPS member-loop leg of the N = 1 line")
+    ap.add_argument("--no-steps-stock", action="store_true", help="skip the sampled stock nowcasts.steps run (oracle/_ref) of steps_e2e")
+    ap.add_argument("--advection-only", action="store_true",
+                    help="N > 1: time the member advection alone (the SL-only surrogate of rounds 1-2) instead of the member loop")
     return ap.parse_args()
 
 
@@ -349,6 +355,113 @@ def members_workload(precip_d, vel_d, n_members, first_member, n_total, T, K):
     return step
 
 
+def steps_loop_workload(precip_d, vel_d, n_members, first_member, n_total, T, K, levels=6, download=False):
+    """BASELINE config 4 on one rank as nowcasts.steps runs it: the member update of
+    pysteps/nowcasts/steps.py:1057-1219 (white noise from the member's MT19937 stream -> noise filter ->
+    cascade decomposition -> AR(2) step per level -> recomposition -> incremental mask -> CDF matching ->
+    mask update) followed by the member-batched advection with BPS-perturbed motion
+    (pysteps/nowcasts/utils.py:441-462), for `n_members` of `n_total` members (global indices
+    first_member ...: their slice of the ensemble's seed chain, steps.py:885-933), everything resident in
+    HBM.  The initial state is synthetic (cascade of the input field, Gaussian band-pass weights, AR(2)
+    parameters from lag correlations 0.9^(k+1)); the work per member and lead time does not depend on it.
+    Returns (step, info): step() = one nowcast of T lead times = T + 1 updates and T advections
+    (download=True: plus one device-to-host copy of the advected members per lead time)."""
+    from pysteps_amd import _lib, _pinned
+    from pysteps_amd.cascade import decomposition_fft, recompose_fft
+    from pysteps_amd.device import DeviceArray
+    from pysteps_amd.extrapolation.ensemble import EnsembleAdvector, steps_noise_generators, steps_perturbators
+    from pysteps_amd.noise.fftgenerators import generate_noise_2d_fft_filter
+    from pysteps_amd.nowcasts.steps_resident import ResidentSteps
+    from pysteps_amd.nowcasts.utils import compute_dilated_mask
+
+    lib = _lib.lib()
+    m, n = precip_d.shape
+    plane, p = m * n, 2
+    field = DeviceArray((m, n), np.float64)
+    _lib.check(lib.psh_convert_dev(precip_d.ptr, field.ptr, plane, 1), "psh_convert_dev")
+    host = field.to_host()
+    # the latest "observation": radar products carry ONE no-rain value; the advected input frame has it
+    # smeared over a few float32 neighbours of -15 by the interpolation
+    target = DeviceArray.from_host(np.where(host < -14.5, -15.0, host))
+    # band-pass weights of the reference's form (levels, m, n/2+1), Gaussian in log2 of the wavenumber
+    ky, kx = np.fft.fftfreq(m)[:, None], np.fft.rfftfreq(n)[None, :]
+    r = np.log2(np.hypot(ky, kx) + 1e-9)
+    centres = np.log2(0.5 * 2.0 ** -np.arange(levels)[::-1])
+    w = np.stack([np.exp(-0.5 * ((r - c) / 0.6) ** 2) for c in centres])
+    w[0][r <= centres[0]] = 1.0  # the largest scales (the mean included) belong to the first level,
+    w[-1][r >= centres[-1]] = 1.0  # the smallest to the last: every wavenumber has weight
+    bp = {"weights_2d": w / w.sum(axis=0, keepdims=True), "weights_1d": np.zeros((levels, 1)), "shape": (m, n)}
+    dec = decomposition_fft(field, bp, normalize=True, compute_stats=True)
+    cascades = DeviceArray((n_members, levels, p, m, n), np.float64)
+    for j in range(n_members):
+        for k in range(levels):
+            for slot in range(p):
+                dst = cascades.ptr + (((j * levels + k) * p + slot) * plane) * 8
+                _lib.check(lib.psh_memcpy_d2d(dst, dec["cascade_levels"].ptr + k * plane * 8, plane * 8), "d2d")
+    # AR(2) by Yule-Walker from lag-1 / lag-2 correlations (timeseries/autoregression.py estimate_ar_params_yw)
+    phi = np.empty((levels, 3))
+    for k in range(levels):
+        r1 = 0.9 ** (k + 1)
+        r2 = r1 ** 2 * 0.98
+        a1, a2 = r1 * (1.0 - r2) / (1.0 - r1 * r1), (r2 - r1 * r1) / (1.0 - r1 * r1)
+        phi[k] = (a1, a2, np.sqrt(max(1.0 - a1 * r1 - a2 * r2, 1e-6)))
+    spec = np.abs(np.fft.rfft2(host - host.mean()))
+    noise_filter = {"field": spec / spec.std(), "input_shape": (m, n), "use_full_fft": False}
+    thr = -10.0
+    wet = DeviceArray((m, n), np.uint8)
+    _lib.check(lib.psh_ge_mask_dev(field.ptr, plane, thr, wet.ptr), "psh_ge_mask_dev")
+    from scipy.ndimage import generate_binary_structure
+
+    struct = generate_binary_structure(2, 1)
+    grey0 = compute_dilated_mask(wet, struct, 10)
+    grey = DeviceArray((n_members, m, n), np.float64)
+    for j in range(n_members):
+        _lib.check(lib.psh_memcpy_d2d(grey.view(j).ptr, grey0.ptr, plane * 8), "d2d")
+    decomp = [{"means": dec["means"], "stds": dec["stds"], "normalized": True, "domain": "spatial"} for _ in range(n_members)]
+    gens = steps_noise_generators(n_total, 42)[first_member:first_member + n_members]
+    state = {"randgen_prec": gens, "precip_cascades": cascades, "precip_decomp": decomp, "mask_prec": grey}
+    params = {"noise_method": "nonparametric", "domain": "spatial", "generate_noise": generate_noise_2d_fft_filter,
+              "pert_gen": noise_filter, "decomp_method": decomposition_fft, "recomp_method": recompose_fft, "filter": bp,
+              "phi": phi, "noise_std_coeffs": np.ones(levels), "n_cascade_levels": levels, "n_ens_members": n_members,
+              "mask_method": "incremental", "probmatching_method": "cdf", "precip": target, "precip_thr": thr,
+              "domain_mask": None, "struct": struct, "mask_rim": 10}
+    loop = ResidentSteps(state, params, (m, n), 1 << 40)
+    timestep_min = 5.0
+    perts = steps_perturbators(n_total, 42, 1.0, timestep_min)[first_member:first_member + n_members]
+    adv = EnsembleAdvector(vel_d, n_members, perts, n_iter=K, outval=-15.0)
+    block = _pinned.empty((n_members, T, m, n), np.float64) if download else None
+    f32 = DeviceArray((n_members, m, n), np.float32)
+    copies = []  # (event before, event after) of every lead time's device-to-host copies
+
+    def step(events=None):
+        adv.reset()
+        loop.update()  # the update of t = 0 (nowcasts/utils.py:386-395: func is called before the first lead time)
+        out = None
+        for t in range(T):
+            new = loop.update()
+            _lib.check(lib.psh_convert_dev(new.ptr, f32.ptr, new.size, 0), "psh_convert_dev")
+            if events is not None:
+                events[t][0].record()
+            out = adv.step(f32, 1.0, timestep_min * (t + 1))
+            if events is not None:
+                events[t][1].record()
+            if block is not None:
+                from pysteps_amd.device import Event  # noqa: PLC0415
+
+                c0 = Event().record()
+                wide = DeviceArray(out.shape, np.float64)
+                _lib.check(lib.psh_convert_dev(out.ptr, wide.ptr, out.size, 1), "psh_convert_dev")
+                for j in range(n_members):
+                    _lib.check(lib.psh_memcpy_d2h_async(block[j, t].ctypes.data, wide.ptr + j * plane * 8, plane * 8), "d2h")
+                copies.append((c0, Event().record()))
+        return out
+
+    info = {"members": n_members, "cascade_levels": levels, "ar_order": p, "mask_method": "incremental",
+            "probmatching_method": "cdf", "updates_per_nowcast": T + 1, "advections_per_nowcast": T}
+    step.copies = copies
+    return step, info
+
+
 def spectral_leg(m, n):
     """SURVEY 8f rank 3 (first pieces): what the STEPS member loop calls per member and lead time -
     the FFT method object, the cascade decomposition and the CDF matching - resident on the device (HIP
@@ -394,6 +507,8 @@ def spectral_leg(m, n):
         r = np.hypot(ky, kx)
         centres = 0.5 * 2.0 ** -np.arange(nlev)[::-1]
         w = np.stack([np.exp(-0.5 * ((np.log2(r + 1e-9) - np.log2(c)) / 0.6) ** 2) for c in centres])
+        w[0][r <= centres[0]] = 1.0
+        w[-1][r >= centres[-1]] = 1.0
         bp = {"weights_2d": w / w.sum(axis=0, keepdims=True), "weights_1d": np.zeros((nlev, 1)), "shape": (m, n)}
         decomposition_fft(dx, bp, normalize=True, compute_stats=True)  # uploads and caches the weights
         synchronize()
@@ -425,6 +540,90 @@ def spectral_leg(m, n):
     except Exception as exc:
         out["probmatch_note"] = "%s: %s" % (type(exc).__name__, exc)
     return out
+
+
+def steps_loop_leg(precip_d, vel_d, members, T, K, dist, with_stock):
+    """config.steps_loop / config.steps_e2e of the N = 1 line: the per-GPU share of BASELINE config 4
+    (`members` STEPS members, T lead times) as one GPU runs it - resident (value-style, nothing leaves
+    HBM) and end to end with one device-to-host copy of the advected members per lead time - and, as
+    the CPU figure beside it, the reference's own nowcasts.steps (oracle/_ref) on a stated sample."""
+    from pysteps_amd.device import Event, synchronize
+
+    m, n = precip_d.shape
+    step, info = steps_loop_workload(precip_d, vel_d, members, 0, members, T, K)
+    ev = [(Event(), Event()) for _ in range(T)]
+    step()
+    synchronize()
+    t0 = time.perf_counter()
+    step(ev)
+    synchronize()
+    resident_s = time.perf_counter() - t0
+    adv_ms = sum(a.elapsed_ms(b) for a, b in ev) / T
+    out = dict(info)
+    out.update({"leadtimes": T, "seconds_per_nowcast": resident_s, "ms_per_leadtime_all_members": resident_s / T * 1e3,
+                "ms_per_member_update": (resident_s * 1e3 - adv_ms * T) / (members * (T + 1)),
+                "advection_ms_per_leadtime": adv_ms, "value": members * m * n * T / resident_s / 1e6,
+                "unit": "Mpx*leadsteps/s", "note": "state resident in HBM, results stay on the device"})
+    del step
+    e2e = None
+    try:
+        step, _ = steps_loop_workload(precip_d, vel_d, members, 0, members, T, K, download=True)
+        step()
+        synchronize()
+        e0, e1 = Event(), Event()
+        t0 = time.perf_counter()
+        e0.record()
+        step()
+        e1.record()
+        synchronize()
+        wall = time.perf_counter() - t0
+        moved = members * T * m * n * 8.0
+        copy_s = sum(a.elapsed_ms(b) for a, b in step.copies[-T:]) * 1e-3
+        e2e = {"device_seconds": wall, "bytes_to_host": moved, "transfer_seconds": copy_s,
+               "transfer_share": copy_s / wall if wall > 0 else None, "transfer_gb_per_s": moved / copy_s / 1e9 if copy_s else None,
+               "note": "same loop with one device-to-host copy of the advected members (widened to float64 on the device, "
+                       "pinned result block) per lead time; transfer_seconds by HIP events around the copies"}
+    except Exception as exc:  # this leg never takes the headline down
+        e2e = {"note": "%s: %s" % (type(exc).__name__, exc)}
+    if with_stock:
+        e2e["stock"] = steps_stock_sample(m, n)
+        if e2e.get("device_seconds") and e2e["stock"].get("loop_seconds_per_member_update"):
+            full = e2e["stock"]["loop_seconds_per_member_update"] * members * (T + 1)
+            e2e["stock"]["loop_seconds_scaled_to_this_nowcast"] = full
+            e2e["speedup_of_the_loop"] = full / e2e["device_seconds"]
+    e2e["real_caller"] = ("the REAL pysteps.nowcasts.steps driving this loop (register(patch_main_loop=True)) is timed by "
+                          "tools/steps_quick.py: profiles/r03/*_steps_quick.jsonl")
+    return out, e2e
+
+
+def steps_stock_sample(m, n):
+    """The reference's own nowcasts.steps (oracle/_ref, stock operators) on 1 member x 1 lead time of the
+    same grid: initialisation and loop seconds on this box's host (1 core: NumPy / SciPy are
+    single-threaded here).  CPU baseline only - never part of `value`."""
+    try:
+        import contextlib
+        import io
+
+        from oracle import build_ref
+
+        if not build_ref.available():
+            return {"note": "oracle/_ref not built"}
+        build_ref.activate()
+        from pysteps import nowcasts
+        from tools import synth
+
+        frames = synth.steps_frames(m, n, 3)
+        V = synth.true_velocity(m, n).astype(np.float64)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, init_s, loop_s = nowcasts.get_method("steps")(
+                frames, V, 1, n_ens_members=1, n_cascade_levels=6, precip_thr=-10.0, kmperpixel=1.0, timestep=5.0, seed=42,
+                vel_pert_method="bps", mask_method="incremental", probmatching_method="cdf", num_workers=1, measure_time=True)
+        return {"kind": "reference", "cores": 1, "sample": "pysteps.nowcasts.steps (oracle/_ref, unmodified), %dx%d, 1 member x 1 lead "
+                "time (2 member updates + 1 advection), stock operators" % (m, n), "total_seconds": time.perf_counter() - t0,
+                "init_seconds": init_s, "loop_seconds": loop_s, "loop_seconds_per_member_update": loop_s / 2.0}
+    except Exception as exc:
+        return {"note": "%s: %s" % (type(exc).__name__, exc)}
 
 
 def time_steps(step, dist, steps, warmup, events=None):
@@ -469,6 +668,8 @@ def main():
         except (ImportError, AttributeError):
             have_lk = False
 
+    if args.workload == "config5":
+        return main_config5(args, dist)
     if dist.world > 1 or args.force_members_path:
         return main_members(args, dist, dense_lk if have_lk else None)
 
@@ -568,34 +769,86 @@ def main():
             "value": args.members_per_gpu * m * n * T / (el / 3) / 1e6,
             "note": "same per-GPU workload as the --gpus N > 1 runs (weak scaling reference)",
         }
+    if not args.no_steps_loop:
+        try:
+            loop_T = min(T, 6)
+            sl, e2e = steps_loop_leg(precip_d, vel_d, args.members_per_gpu, loop_T, K, dist,
+                                     with_stock=not (args.no_cpu_baseline or args.no_steps_stock))
+            line["config"]["steps_loop"] = sl
+            line["config"]["steps_e2e"] = e2e
+        except Exception as exc:  # never takes the headline down
+            line["config"]["steps_loop"] = {"note": "%s: %s" % (type(exc).__name__, exc)}
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(frames_d, vel_d, K, args.cpu_sample_steps, T, have_lk)
     print(json.dumps(line))
     dist.close()
 
 
+def members_pmc_traffic(m, n, members):
+    """HBM bytes per launch of semilag_members from the committed counter passes (profiles/r03, taken
+    with tools/gpu_members_round.sh at 4096^2 x 6 members; FETCH_SIZE doubled per the gfx950 note)."""
+    if (m, n, members) != (4096, 4096, 6):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03", "a_members_pmc_traffic.json")) as fh:
+            t = json.load(fh)
+        return (2.0 * t["FETCH_SIZE_KB_mean_per_launch"] + t["WRITE_SIZE_KB_mean_per_launch"]) * 1024.0
+    except Exception:
+        return None
+
+
 def main_members(args, dist, dense_lk):
     """N > 1 (one rank per GPU): BASELINE config 4, `members_per_gpu` STEPS members per GPU.
 
     Rank 0 synthesises the frames, estimates the motion field and packs [precip | u | v] into one
-    buffer; ONE RCCL broadcast over xGMI (192 MiB at 4096^2) hands it to every rank before the
-    timed region; each rank then advects its own members (partition of 6N members, perturbators
-    recomputed from the ensemble seed) with no data-path collective (weak scaling).  An RCCL failure
-    is fatal: the run exits non-zero instead of reporting numbers of a run that did not communicate."""
+    buffer; it then times ITS per-GPU workload alone (the other ranks wait at a barrier): the in-run
+    single-GPU base of the weak-scaling figure.  ONE RCCL broadcast over xGMI (192 MiB at 4096^2)
+    hands the buffer to every rank before the timed region; each rank runs the member loop of
+    nowcasts.steps for its own members (partition of 6N members; random streams and perturbators
+    recomputed from the ensemble's seed chain; member update + advection per lead time, everything
+    resident) with no data-path collective (weak scaling).  --advection-only times the advection share
+    alone (the surrogate of rounds 1-2).  An RCCL failure is fatal: the run exits non-zero."""
     from pysteps_amd import _lib, parallel
     from pysteps_amd.device import DeviceArray, Event, synchronize
 
     m = n = args.size
     T, K = args.leadtimes, args.n_iter
+    per = args.members_per_gpu
+    n_total = per * dist.world
+    mine = parallel.partition(n_total, dist.world, dist.rank)
     pack = DeviceArray((3, m, n), np.float32)
+    precip_d = pack.view(0)
+    vel_d = DeviceArray((2, m, n), np.float32, ptr=pack.view(1).ptr, owner=pack)
+
+    def build():
+        if args.advection_only:
+            return members_workload(precip_d, vel_d, len(mine), mine.start, n_total, T, K), None
+        return steps_loop_workload(precip_d, vel_d, len(mine), mine.start, n_total, T, K)
+
+    step = info = None
+    base = None
     if dist.rank == 0:
-        frames_d, vel_d = make_inputs(m, n, args.frames)
-        v = dense_lk(frames_d) if dense_lk is not None else vel_d
+        frames_d, v_true = make_inputs(m, n, args.frames)
+        v = dense_lk(frames_d) if dense_lk is not None else v_true
         lib = _lib.lib()
         _lib.check(lib.psh_memcpy_d2d(pack.view(0).ptr, frames_d.view(args.frames - 1).ptr, m * n * 4), "d2d")
         _lib.check(lib.psh_memcpy_d2d(pack.view(1).ptr, v.ptr, 2 * m * n * 4), "d2d")
         synchronize()
-        del frames_d, vel_d, v
+        del frames_d, v_true, v
+        # the same per-GPU workload on this rank alone, before any collective
+        step, info = build()
+        reps = max(1, min(args.steps, 3))
+        for _ in range(max(1, min(args.warmup, 2))):
+            step()
+        synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        synchronize()
+        base_ms = (time.perf_counter() - t0) / reps * 1e3
+        base = {"ms_per_step": base_ms, "value": len(mine) * m * n * T / (base_ms * 1e-3) / 1e6, "steps": reps,
+                "note": "rank 0 alone on its %d members before the collective phase, other ranks idle at a barrier" % len(mine)}
+    dist.barrier()
     t0 = time.perf_counter()
     ok = 1.0
     err = None
@@ -612,16 +865,26 @@ def main_members(args, dist, dense_lk):
         dist.close()
         sys.exit(3)
     bcast_s = time.perf_counter() - t0
-    precip_d = pack.view(0)
-    vel_d = DeviceArray((2, m, n), np.float32, ptr=pack.view(1).ptr, owner=pack)
+    if step is None:
+        step, info = build()
 
-    per = args.members_per_gpu
-    n_total = per * dist.world
-    mine = parallel.partition(n_total, dist.world, dist.rank)
-    step = members_workload(precip_d, vel_d, len(mine), mine.start, n_total, T, K)
-    ev = [(Event(), Event()) for _ in range(args.steps)]
-    elapsed = time_steps(step, dist, args.steps, args.warmup, ev)
-    kernel_ms = sum(a.elapsed_ms(b) for a, b in ev) / args.steps / T  # one batched launch
+    ev = [[(Event(), Event()) for _ in range(T)] for _ in range(args.steps)]
+    if args.advection_only:
+        flat = [(Event(), Event()) for _ in range(args.steps)]
+        elapsed = time_steps(step, dist, args.steps, args.warmup, flat)
+        kernel_ms = sum(a.elapsed_ms(b) for a, b in flat) / args.steps / T
+    else:
+        for _ in range(args.warmup):
+            step()
+        synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(ev[i])
+        synchronize()
+        dist.barrier()
+        elapsed = dist.max(time.perf_counter() - t0)
+        kernel_ms = sum(a.elapsed_ms(b) for row in ev for a, b in row) / (args.steps * T)  # one batched launch
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * m * n * T / (ms_per_step * 1e-3) / 1e6
     # stateful single-step call: D read + write 16, three velocity passes 8 each
@@ -630,8 +893,11 @@ def main_members(args, dist, dense_lk):
     alg_bytes = float(b_alg) * m * n * len(mine)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     if dist.rank == 0:
+        what = "member advection only" if args.advection_only else "nowcasts.steps member loop: update + advection per lead time"
+        traffic = members_pmc_traffic(m, n, len(mine))
         line = {
-            "metric": "Mpixels*leadsteps/s (LK+semilag) at %dx%d fp32" % (m, n),
+            "metric": "Mpixels*leadsteps/s (STEPS ensemble, %s) at %dx%d" % (
+                "advection only" if args.advection_only else "member update + semilag advection", m, n),
             "value": value,
             "unit": "Mpx*leadsteps/s",
             "n_gpus": dist.world,
@@ -641,19 +907,22 @@ def main_members(args, dist, dense_lk):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 advection, f64 member update (the reference's dtypes)",
             "data": "synthetic",
+            "single_gpu_base": base,
+            "weak_scaling_efficiency": value / (dist.world * base["value"]),
             "config": {
-                "workload": "%dx%d fp32, %d-member STEPS ensemble advection (BASELINE config 4), %d members per GPU, "
-                            "%d lead steps as single-step stateful calls with BPS velocity perturbations, n_iter=%d" % (
-                                m, n, n_total, per, T, K),
-                "sharding": "members partitioned over ranks, motion field from %s on rank 0, [precip|u|v] in ONE "
-                            "RCCL broadcast before the timed region, no data-path collective" % (
-                                "dense LK" if dense_lk is not None else "the synthetic truth"),
+                "workload": "%dx%d, %d-member STEPS ensemble (BASELINE config 4), %d members per GPU, %d lead times, %s, "
+                            "BPS velocity perturbations, n_iter=%d" % (m, n, n_total, per, T, what, K),
+                "sharding": "members partitioned over ranks (random streams and perturbators from the ensemble's seed chain), "
+                            "motion field from %s on rank 0, [precip|u|v] in ONE RCCL broadcast before the timed region, no "
+                            "data-path collective" % ("dense LK" if dense_lk is not None else "the synthetic truth"),
                 "rccl_ranks": dist.world,
                 "broadcast_s": bcast_s,
                 "broadcast_bytes": pack.nbytes,
-                "compare_with": "config.config4_one_gpu.value of the --gpus 1 line (same per-GPU workload)",
+                "member_loop": info,
+                "compare_with": "single_gpu_base (same run, same per-GPU workload); the --gpus 1 line is BASELINE config 3 "
+                                "(LK + semilag of one field) and carries this workload as config.steps_loop / config4_one_gpu",
             },
             "roofline": {
                 "kernel": "semilag_members",
@@ -664,8 +933,110 @@ def main_members(args, dist, dense_lk):
                 "frac": achieved / HBM_PEAK_GBS,
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": kernel_ms,
-                "traffic": None,
+                "traffic": traffic,
+                "hbm_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             },
+        }
+        print(json.dumps(line))
+    dist.close()
+
+
+def main_config5(args, dist):
+    """--workload config5 (BASELINE configs[4]): 8192^2, 2 frames, 36 lead times tiled over the ranks.
+    Every rank holds the frames (ONE RCCL broadcast), the dense Lucas-Kanade image passes run on row
+    bands (global ranges by allreduce MIN / MAX / SUM, corner candidates and tracked vectors by
+    allgather: pysteps_amd/motion/banded.py) and every rank integrates the rows of its band
+    (parallel.tiled_extrapolate, no halo exchange: the scheme has no inter-pixel dependency).  Strong
+    scaling: the total work is fixed; rank 0 times the whole step alone first (single_gpu_base)."""
+    from pysteps_amd import _lib, extrapolation, motion, parallel
+    from pysteps_amd.device import DeviceArray, synchronize
+
+    m = n = args.size if args.size != 4096 else 8192
+    T = args.leadtimes if args.leadtimes != 24 else 36
+    K = args.n_iter
+    frames_d = DeviceArray((args.frames, m, n), np.float32)
+    base = None
+    if dist.rank == 0:
+        made, _ = make_inputs(m, n, args.frames)
+        _lib.check(_lib.lib().psh_memcpy_d2d(frames_d.ptr, made.ptr, made.nbytes), "d2d")
+        synchronize()
+        del made
+        dense_lk = motion.get_method("LK")
+        extrapolate = extrapolation.get_method("semilagrangian")
+
+        def whole():
+            return extrapolate(frames_d.view(args.frames - 1), dense_lk(frames_d), T, outval=-15.0, n_iter=K)
+
+        whole()
+        synchronize()
+        reps = max(1, min(args.steps, 3))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            whole()
+        synchronize()
+        base_ms = (time.perf_counter() - t0) / reps * 1e3
+        base = {"ms_per_step": base_ms, "value": m * n * T / (base_ms * 1e-3) / 1e6, "steps": reps,
+                "note": "rank 0 alone: single-device dense LK + semilag of the whole grid, before the collective phase"}
+    dist.barrier()
+    ok, err = 1.0, None
+    comm = None
+    try:
+        with stdout_to_stderr():
+            comm = parallel.Communicator(dist.rank, dist.world, dist.broadcast_bytes)
+            comm.broadcast(frames_d, root=0)
+            synchronize()
+    except Exception as exc:
+        ok, err = 0.0, exc
+    if dist.max(1.0 - ok) > 0.0:
+        print("rank %d: RCCL broadcast failed on %s: %s" % (dist.rank, "this rank" if ok == 0.0 else "another rank", err),
+              file=sys.stderr)
+        dist.close()
+        sys.exit(3)
+    precip_d = frames_d.view(args.frames - 1)
+
+    from pysteps_amd.device import Event
+
+    marks = []
+
+    def step():
+        v = parallel.banded_dense_lucaskanade(frames_d, comm)
+        e0 = Event().record()
+        out = parallel.tiled_extrapolate(precip_d, v, T, dist.rank, dist.world, outval=-15.0, n_iter=K)
+        marks.append((e0, Event().record()))
+        return out
+
+    try:
+        with stdout_to_stderr():
+            elapsed = time_steps(step, dist, args.steps, args.warmup)
+    except Exception as exc:
+        print("rank %d: config-5 step failed: %s" % (dist.rank, exc), file=sys.stderr)
+        dist.close()
+        sys.exit(3)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = m * n * T / (ms_per_step * 1e-3) / 1e6
+    if dist.rank == 0:
+        rows = parallel.partition(m, dist.world, 0)
+        sl_ms = sum(a.elapsed_ms(b) for a, b in marks[-args.steps:]) / args.steps
+        alg_bytes = float((16 * K + 8) if K > 0 else 16) * len(rows) * n * T
+        line = {
+            "metric": "Mpixels*leadsteps/s (LK+semilag) at %dx%d fp32, row bands over %d GPUs" % (m, n, dist.world),
+            "value": value, "unit": "Mpx*leadsteps/s", "n_gpus": dist.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "single_gpu_base": base, "strong_scaling_speedup": value / base["value"],
+            "strong_scaling_efficiency": value / base["value"] / dist.world,
+            "config": {
+                "workload": "%dx%d fp32, %d input frames, banded dense LK + tiled semilag %d leadtimes n_iter=%d (BASELINE "
+                            "config 5)" % (m, n, args.frames, T, K),
+                "sharding": "row bands: %d rows per rank; frames in ONE RCCL broadcast; per estimate allreduce MIN/MAX/SUM of "
+                            "<= 6 floats x 3, allgather of corner keys and of tracked vectors; no halo exchange for the "
+                            "extrapolation" % len(rows),
+                "rccl_ranks": dist.world,
+            },
+            "roofline": {"kernel": "semilag_fused (row band of rank 0)", "bound": "hbm", "achieved": alg_bytes / (sl_ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (sl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "alg_bytes_per_launch": alg_bytes, "kernel_ms": sl_ms, "traffic": None,
+                         "note": "kernel_ms brackets the band's extrapolation call (velocity / field packing passes included)"},
+            "config_lk_ms_per_step": ms_per_step - sl_ms,
         }
         print(json.dumps(line))
     dist.close()

@@ -14,7 +14,7 @@ import numpy as np
 from .. import _lib
 from ..device import DeviceArray
 
-__all__ = ["EnsembleAdvector", "bps_scalars", "steps_perturbators"]
+__all__ = ["EnsembleAdvector", "bps_scalars", "steps_perturbators", "steps_noise_generators"]
 
 # defaults of pysteps/noise/motion.py:43-52 (BPS2006)
 _BPS_PAR, _BPS_PERP = (10.88, 0.23, -7.68), (5.76, 0.31, -2.72)
@@ -42,6 +42,19 @@ def steps_perturbators(n_members, seed, kmperpixel, timestep, p_par=None, p_perp
         out.append(dict(eps_par=float(eps_par), eps_perp=float(eps_perp),
                         p_par=tuple(p_par or _BPS_PAR), p_perp=tuple(p_perp or _BPS_PERP),
                         vsf=60.0 / (float(timestep) * (1.0 / float(kmperpixel)))))
+    return out
+
+
+def steps_noise_generators(n_members, seed):
+    """The precipitation-noise generators ``nowcasts.steps`` creates for ``n_members`` members from
+    ``seed`` (the same chain, pysteps/nowcasts/steps.py:885-898: the first ``RandomState`` of every
+    member) - recomputable on every rank, so a rank that owns members ``a .. b`` takes ``[a:b]``."""
+    out = []
+    for _ in range(int(n_members)):
+        rs = np.random.RandomState(seed)
+        out.append(rs)
+        seed = rs.randint(0, high=int(1e9))
+        seed = np.random.RandomState(seed).randint(0, high=int(1e9))
     return out
 
 

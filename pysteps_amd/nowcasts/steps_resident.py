@@ -104,10 +104,15 @@ class ResidentSteps:
         gens = state.get("randgen_prec")
         cascades = state.get("precip_cascades")
         decomp = state.get("precip_decomp")
-        if gens is None or len(gens) != self.B or cascades is None or len(cascades) != self.B or decomp is None:
+        if gens is None or len(gens) != self.B or cascades is None or decomp is None or len(decomp) != self.B:
+            raise _Declined
+        if not isinstance(cascades, DeviceArray) and len(cascades) != self.B:
+            raise _Declined
+        resident_cascades = isinstance(cascades, DeviceArray)  # state that never was on the host (bench.py)
+        if resident_cascades and (cascades.shape != (self.B, self.L, self.p, m, n) or cascades.dtype != np.float64):
             raise _Declined
         for j in range(self.B):
-            if len(cascades[j]) != self.L or any(np.shape(c) != (self.p, m, n) for c in cascades[j]):
+            if not resident_cascades and (len(cascades[j]) != self.L or any(np.shape(c) != (self.p, m, n) for c in cascades[j])):
                 raise _Declined
             if not decomp[j].get("normalized", False) or decomp[j].get("domain") != "spatial":
                 raise _Declined
@@ -123,13 +128,16 @@ class ResidentSteps:
         self.weights = _device_weights(weights)
         self.noise_filter = _device_weights(F["field"])
         # AR history: (B, L, p, m, n); slot s of the ring holds x[s] of the reference's series at start
-        self.cascades = DeviceArray((self.B, self.L, self.p, m, n), np.float64)
-        stride = self.p * self.plane * 8
-        for j in range(self.B):
-            for k in range(self.L):
-                src = np.ascontiguousarray(cascades[j][k], dtype=np.float64)
-                _lib.check(self._lib.psh_memcpy_h2d(self.cascades.ptr + (j * self.L + k) * stride, src.ctypes.data, src.nbytes), "h2d")
-        _lib.check(self._lib.psh_sync(), "sync")
+        if resident_cascades:
+            self.cascades = cascades
+        else:
+            self.cascades = DeviceArray((self.B, self.L, self.p, m, n), np.float64)
+            stride = self.p * self.plane * 8
+            for j in range(self.B):
+                for k in range(self.L):
+                    src = np.ascontiguousarray(cascades[j][k], dtype=np.float64)
+                    _lib.check(self._lib.psh_memcpy_h2d(self.cascades.ptr + (j * self.L + k) * stride, src.ctypes.data, src.nbytes), "h2d")
+            _lib.check(self._lib.psh_sync(), "sync")
         self.head = 0  # slot of the oldest entry
         self.thr = float(p["precip_thr"]) if p["precip_thr"] is not None else None
         self.mask_method, self.pm_method = p["mask_method"], p["probmatching_method"]
@@ -140,13 +148,24 @@ class ResidentSteps:
             self.rim = int(p["mask_rim"])
             if self.struct.ndim != 2 or not 0 <= self.rim <= 254 or int(self.struct.sum()) > 1024 or self.thr is None:
                 raise _Declined
-            self.grey = DeviceArray.from_host(np.stack([np.asarray(mk, dtype=np.float64) for mk in masks]))
+            if isinstance(masks, DeviceArray):
+                if masks.shape != (self.B, m, n) or masks.dtype != np.float64:
+                    raise _Declined
+                self.grey = masks
+            else:
+                self.grey = DeviceArray.from_host(np.stack([np.asarray(mk, dtype=np.float64) for mk in masks]))
             self.wet = DeviceArray((m, n), np.uint8)
         elif self.mask_method == "obs":
             self.keep = DeviceArray.from_host(np.ascontiguousarray(state["mask_prec"], dtype=np.uint8))
         self.target = None
         if self.pm_method == "cdf":
-            self.target = DeviceArray.from_host(np.ascontiguousarray(p["precip"], dtype=np.float64))
+            tgt = p["precip"]
+            if isinstance(tgt, DeviceArray):
+                if tgt.shape != (m, n) or tgt.dtype != np.float64:
+                    raise _Declined
+                self.target = tgt
+            else:
+                self.target = DeviceArray.from_host(np.ascontiguousarray(tgt, dtype=np.float64))
         elif self.pm_method == "mean":
             self.mu_0 = float(p["mu_0"])
         dm = p["domain_mask"]
@@ -223,7 +242,7 @@ class ResidentSteps:
         this one call goes through the reference's function and comes back."""
         from ..postprocessing.probmatching import _reference  # noqa: PLC0415
 
-        got = _reference()(field.to_host(), np.asarray(self.params["precip"], dtype=np.float64))
+        got = _reference()(field.to_host(), np.asarray(self.target.to_host(), dtype=np.float64))
         return DeviceArray.from_host(np.ascontiguousarray(got, dtype=np.float64))
 
     def finish(self):

@@ -94,3 +94,45 @@ def test_bench_multi_rank_path_runs_at_world_size_one():
     assert line["n_gpus"] == 1 and line["config"]["rccl_ranks"] == 1
     assert "config 4" in line["config"]["workload"] and line["roofline"]["kernel"] == "semilag_members"
     assert line["value"] > 0 and line["config"]["broadcast_bytes"] == 3 * 512 * 512 * 4
+    # the member loop of nowcasts.steps is what runs (update + advection), with the in-run base beside it
+    assert "LK+semilag" not in line["metric"] and line["config"]["member_loop"]["updates_per_nowcast"] == 5
+    assert line["single_gpu_base"]["value"] > 0
+    assert 0.5 < line["weak_scaling_efficiency"] < 1.5  # world size 1: the same workload twice
+
+
+def test_bench_advection_only_surrogate_still_runs():
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    proc = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--force-members-path", "--advection-only", "--size", "512",
+         "--leadtimes", "4", "--steps", "2", "--warmup", "1", "--members-per-gpu", "3"],
+        cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert "advection only" in line["metric"] and line["config"]["member_loop"] is None and line["value"] > 0
+
+
+def test_bench_config5_path_runs_at_world_size_one():
+    """bench.py --workload config5 (row bands: banded LK through the RCCL allreduce / allgather calls,
+    tiled semilag) on the one GPU a test box has, small grid"""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    proc = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "config5", "--size", "1024", "--leadtimes", "4",
+         "--steps", "2", "--warmup", "1"],
+        cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = proc.stdout.strip().splitlines()
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["scaling"] == "strong" and line["config"]["rccl_ranks"] == 1 and "config 5" in line["config"]["workload"]
+    assert line["value"] > 0 and line["single_gpu_base"]["value"] > 0
+    assert 0.3 < line["strong_scaling_efficiency"] < 1.5
