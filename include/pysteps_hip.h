@@ -89,6 +89,8 @@ int psh_convert_dev(const void *in_dev, void *out_dev, size_t n, int to_f64);
  * counts) and np.nanmin of the field; a NaN threshold means "the minimum of the field"
  * (precip_thr=None).  Synchronous. */
 int psh_count_above_dev(const float *in_dev, size_t n, double threshold, double *count_out, double *nanmin_out);
+/* number of NaN / infinite values of a float64 device array (waits for the result) */
+int psh_nonfinite_count_f64_dev(const double *in_dev, size_t n, double *count_out);
 int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *max_out,
                         double *nonfinite_out);
 

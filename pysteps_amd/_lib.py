@@ -128,6 +128,7 @@ SIGNATURES = {
     "psh_lk_band_select_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_int, c_void_p]),
     "psh_lk_track_pyr_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_void_p, c_void_p]),
     "psh_db_transform_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_double, c_double, c_int]),
+    "psh_nonfinite_count_f64_dev": (c_int, [c_void_p, c_size_t, POINTER(c_double)]),
     "psh_field_stats_dev": (c_int, [c_void_p, c_size_t, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "psh_dense_lk_dev": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(LkParams), c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),

@@ -21,23 +21,49 @@ from .. import _lib
 from ..device import DeviceArray
 from ..utils import fft as hip_fft
 
-_weights_cache = {}
+_weights_cache = {}  # id(host array) -> (weakref, fingerprint, device copy, nbytes), oldest first
+WEIGHTS_CACHE_BYTES = 4 << 30  # device copies kept at most (a 4096^2 x 8-level filter is 0.5 GB)
 MIN_HOST_PLANE = 1 << 16  # host cascades below this many pixels per level are summed by NumPy
 
 
+def _fingerprint(arr):
+    """Cheap content check of a cached array: shape, dtype, sum of a strided sample, corner values -
+    an in-place edit of the host array must not keep a stale device copy in use."""
+    flat = arr.reshape(-1)
+    step = max(1, flat.size // 4099)
+    return (arr.shape, arr.dtype.str, float(np.sum(flat[::step], dtype=np.float64)), float(flat[0]), float(flat[-1]))
+
+
 def _device_weights(weights):
-    """Device copy of a (levels, m, n/2+1) weight array, cached by the identity of the host array."""
+    """Device copy of a (levels, m, n/2+1) weight array, cached by the identity of the host array and
+    a fingerprint of its content; the cache holds at most WEIGHTS_CACHE_BYTES (oldest copy dropped)."""
     key = id(weights)
     hit = _weights_cache.get(key)
-    if hit is not None and hit[0]() is weights:
-        return hit[1]
+    fp = _fingerprint(np.asarray(weights))
+    if hit is not None and hit[0]() is weights and hit[1] == fp:
+        return hit[2]
     dev = DeviceArray.from_host(np.ascontiguousarray(weights, dtype=np.float64))
     try:
         ref = weakref.ref(weights, lambda _r, k=key: _weights_cache.pop(k, None))
     except TypeError:  # not weak-referenceable: do not cache
         return dev
-    _weights_cache[key] = (ref, dev)
+    _weights_cache.pop(key, None)
+    _weights_cache[key] = (ref, fp, dev, dev.nbytes)
+    while len(_weights_cache) > 1 and sum(v[3] for v in _weights_cache.values()) > WEIGHTS_CACHE_BYTES:
+        _weights_cache.pop(next(iter(_weights_cache)))
     return dev
+
+
+def invalidate_weights_cache():
+    """Drop every cached device copy of band-pass weights / noise filters."""
+    _weights_cache.clear()
+
+
+def _device_nonfinite(field):
+    """True if a float64 DeviceArray holds a NaN or an infinity (one reduction pass on the device)."""
+    count = ctypes.c_double(0.0)
+    _lib.check(_lib.lib().psh_nonfinite_count_f64_dev(field.ptr, field.size, ctypes.byref(count)), "psh_nonfinite_count_f64_dev")
+    return count.value > 0
 
 
 def _reference_decomposition():
@@ -46,6 +72,14 @@ def _reference_decomposition():
     except Exception:
         return None
     return None if ref is decomposition_fft else ref
+
+
+def _reference_recompose():
+    try:
+        from pysteps.cascade.decomposition import recompose_fft as ref  # noqa: PLC0415
+    except Exception:
+        return None
+    return None if ref is recompose_fft else ref
 
 
 def decomposition_fft(field, bp_filter, **kwargs):
@@ -98,9 +132,14 @@ def decomposition_fft(field, bp_filter, **kwargs):
         )
     if not resident and np.any(~np.isfinite(field)):
         raise ValueError("field contains non-finite values")
+    if resident and field.dtype == np.float64 and _device_nonfinite(field):  # decomposition.py:195-196, on the device
+        raise ValueError("field contains non-finite values")
 
     m, n = shape
     nlevels = len(bp_filter["weights_1d"])
+    if weights.shape[0] != nlevels:  # the reference would fail while indexing weights_2d[k]
+        raise ValueError("dimension mismatch inside bp_filter: len(weights_1d)=%d, weights_2d.shape[0]=%d"
+                         % (nlevels, weights.shape[0]))
     d_field = field if resident else DeviceArray.from_host(np.ascontiguousarray(field, dtype=np.float64))
     if d_field.dtype != np.float64:
         raise ValueError("device-resident fields must be float64")
@@ -146,26 +185,12 @@ def recompose_fft(decomp, **kwargs):
         on_device["cascade_levels"] = DeviceArray.from_host(levels, sync=False)
         return recompose_fft(on_device).to_host()
     if not isinstance(levels, DeviceArray):
-        if decomp["normalized"]:
-            mu = decomp["means"]
-            sigma = decomp["stds"]
-        if not decomp["normalized"] and not (decomp["domain"] == "spectral" and decomp["compact_output"]):
-            result = np.sum(levels, axis=0)
-        else:
-            if decomp["compact_output"]:
-                weight_masks = decomp["weight_masks"]
-                result = np.zeros(weight_masks.shape[1:], dtype=complex)
-                for i in range(len(levels)):
-                    if decomp["normalized"]:
-                        result[weight_masks[i]] += levels[i] * sigma[i] + mu[i]
-                    else:
-                        result[weight_masks[i]] += levels[i]
-            else:
-                result = [levels[i] * sigma[i] + mu[i] for i in range(len(levels))]
-                result = np.sum(np.stack(result), axis=0)
-        if "field_mean" in decomp:
-            result += decomp["field_mean"]
-        return result
+        # everything else (small cascades, spectral / compact ones): the reference's own function
+        ref = _reference_recompose()
+        if ref is None:
+            raise NotImplementedError("pysteps_amd recompose_fft: this cascade is not taken by the HIP path and pysteps is not "
+                                      "importable for the reference's recompose_fft")
+        return ref(decomp, **kwargs)
 
     if decomp["domain"] != "spatial":
         raise NotImplementedError("pysteps_amd recompose_fft: device-resident cascades are spatial")

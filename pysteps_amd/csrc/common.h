@@ -79,6 +79,7 @@ struct FieldStats {
   }
 };
 int field_stats_full(const float *in_dev, size_t n, FieldStats *st);  // waits for the library stream; lock held
+int field_stats_full_f64(const double *in_dev, size_t n, FieldStats *st);
 hipError_t launch_convert_f64_f32(const double *in, float *out, size_t n, hipStream_t stream);
 hipError_t launch_convert_f32_f64(const float *in, double *out, size_t n, hipStream_t stream);
 

@@ -44,6 +44,48 @@ __global__ __launch_bounds__(256) void db_transform(const float *__restrict__ in
 
 constexpr int kStatFields = 5;
 
+// float64 twin of field_stats (double partials): the host path checks float64 inputs BEFORE they are
+// narrowed to float32 - a finite value beyond the float32 range must not read as "non-finite input"
+__global__ __launch_bounds__(256) void field_stats_f64(const double *__restrict__ in, size_t n,
+                                                       double *__restrict__ partial) {
+  double mn = INFINITY, mx = -INFINITY, bad = 0.0, ninf = 0.0, pinf = 0.0;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double v = in[i];
+    if (isfinite(v)) {
+      mn = fmin(mn, v);
+      mx = fmax(mx, v);
+    } else {
+      bad += 1.0;
+      ninf += v == -INFINITY ? 1.0 : 0.0;
+      pinf += v == INFINITY ? 1.0 : 0.0;
+    }
+  }
+  __shared__ double s[kStatFields][4];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    mn = fmin(mn, __shfl_xor(mn, d));
+    mx = fmax(mx, __shfl_xor(mx, d));
+    bad += __shfl_xor(bad, d);
+    ninf += __shfl_xor(ninf, d);
+    pinf += __shfl_xor(pinf, d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s[0][threadIdx.x >> 6] = mn;
+    s[1][threadIdx.x >> 6] = mx;
+    s[2][threadIdx.x >> 6] = bad;
+    s[3][threadIdx.x >> 6] = ninf;
+    s[4][threadIdx.x >> 6] = pinf;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double *o = partial + kStatFields * blockIdx.x;
+    o[0] = fmin(fmin(s[0][0], s[0][1]), fmin(s[0][2], s[0][3]));
+    o[1] = fmax(fmax(s[1][0], s[1][1]), fmax(s[1][2], s[1][3]));
+    for (int k = 2; k < kStatFields; ++k) o[k] = s[k][0] + s[k][1] + s[k][2] + s[k][3];
+  }
+}
+
 __global__ __launch_bounds__(256) void field_stats(const float *__restrict__ in, size_t n,
                                                    float *__restrict__ partial) {
   // per block: min / max over finite values, counts of non-finite values, of -inf and of +inf
@@ -88,11 +130,14 @@ __global__ __launch_bounds__(256) void field_stats(const float *__restrict__ in,
 
 // number of elements > thr (NaN compares false, like NumPy): the rain-pixel count of
 // pysteps/utils/check_norain.py:48-49
-__global__ __launch_bounds__(256) void count_above(const float *__restrict__ in, size_t n, float thr,
+// the comparison runs in double: the caller decides what the threshold is rounded to first (NumPy
+// compares a float32 array with a Python float in float32, with a numpy.float64 scalar in float64)
+__global__ __launch_bounds__(256) void count_above(const float *__restrict__ in, size_t n, double thr,
                                                    unsigned long long *__restrict__ total) {
   unsigned cnt = 0;
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) cnt += in[i] > thr ? 1u : 0u;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    cnt += static_cast<double>(in[i]) > thr ? 1u : 0u;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(total, static_cast<unsigned long long>(cnt));  // integer: order-free
@@ -186,7 +231,49 @@ int field_stats_full(const float *in_dev, size_t n, FieldStats *st) {
   return PSH_OK;
 }
 
+int field_stats_full_f64(const double *in_dev, size_t n, FieldStats *st) {
+  Context &c = ctx();
+  constexpr int kBlocks = 1024;
+  void *blk = nullptr;
+  if (int rc = psh_malloc(&blk, kStatFields * kBlocks * sizeof(double))) return rc;
+  static thread_local double h[kStatFields * kBlocks];
+  auto run = [&]() -> int {
+    hipLaunchKernelGGL(field_stats_f64, dim3(kBlocks), dim3(256), 0, c.stream, in_dev, n, static_cast<double *>(blk));
+    PSH_HIP(hipGetLastError());
+    PSH_HIP(hipMemcpyAsync(h, blk, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    PSH_HIP(hipStreamSynchronize(c.stream));
+    return PSH_OK;
+  };
+  const int rc = run();
+  (void)psh_free(blk);
+  if (rc) return rc;
+  FieldStats r;
+  for (int b = 0; b < kBlocks; ++b) {
+    const double *o = h + kStatFields * b;
+    r.min_finite = fmin(r.min_finite, o[0]);
+    r.max_finite = fmax(r.max_finite, o[1]);
+    r.nonfinite += o[2];
+    r.neg_inf += o[3];
+    r.pos_inf += o[4];
+  }
+  r.count = static_cast<double>(n);
+  *st = r;
+  return PSH_OK;
+}
+
 }  // namespace psh
+
+extern "C" int psh_nonfinite_count_f64_dev(const double *in_dev, size_t n, double *count_out) {
+  PSH_REQUIRE_INIT();
+  if ((!in_dev && n) || !count_out) return psh::fail(PSH_EINVAL, "nonfinite_count: NULL pointer");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  psh::FieldStats st;
+  if (int rc = psh::field_stats_full_f64(in_dev, n, &st)) return rc;
+  *count_out = st.nonfinite;
+  return PSH_OK;
+}
 
 extern "C" int psh_count_above_dev(const float *in_dev, size_t n, double threshold, double *count_out,
                                    double *nanmin_out) {
@@ -200,7 +287,7 @@ extern "C" int psh_count_above_dev(const float *in_dev, size_t n, double thresho
   const double lowest = st.nanmin();
   if (nanmin_out) *nanmin_out = lowest;
   // threshold NaN = "use the minimum of the field" (precip_thr=None, check_norain.py:46-47)
-  const float thr = static_cast<float>(threshold != threshold ? lowest : threshold);
+  const double thr = threshold != threshold ? lowest : threshold;
   void *blk = nullptr;
   if (int rc = psh_malloc(&blk, sizeof(unsigned long long))) return rc;
   unsigned long long h = 0;

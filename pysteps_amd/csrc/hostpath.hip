@@ -313,14 +313,22 @@ int psh_semilag_host(const void *precip, const void *velocity, int m, int n, con
   // float64 arrays (what pysteps' importers produce) cross the bus as they are and are narrowed on
   // the device: a host-side astype(float32) of three 4096^2 planes costs more than the whole call
   if (p64 || v64) PSH_TRY_RC(psh_malloc(&d_raw, 2 * plane * sizeof(double)));
+  // float64 inputs are checked as float64, before the narrowing (a finite value beyond the float32
+  // range is not a "non-finite input", and outval="min" is the minimum of the values the caller gave)
+  psh::FieldStats sv, sp;
+  bool have_sv = false, have_sp = false;
   if (v64) {
     PSH_TRY_RC(psh::upload(d_raw, velocity, 2 * plane * sizeof(double), c.stream, ring, lock));
+    PSH_TRY_RC(psh::field_stats_full_f64(static_cast<const double *>(d_raw), 2 * plane, &sv));
+    have_sv = true;
     PSH_TRY_HIP(psh::launch_convert_f64_f32(static_cast<const double *>(d_raw), d_v, 2 * plane, c.stream));
   } else {
     PSH_TRY_RC(psh::upload(d_v, velocity, 2 * plane * sizeof(float), c.stream, ring, lock));
   }
   if (precip && p64) {
     PSH_TRY_RC(psh::upload(d_raw, precip, plane * sizeof(double), c.stream, ring, lock));
+    PSH_TRY_RC(psh::field_stats_full_f64(static_cast<const double *>(d_raw), plane, &sp));
+    have_sp = true;
     PSH_TRY_HIP(psh::launch_convert_f64_f32(static_cast<const double *>(d_raw), d_p, plane, c.stream));
   } else if (precip) {
     PSH_TRY_RC(psh::upload(d_p, precip, plane * sizeof(float), c.stream, ring, lock));
@@ -329,13 +337,12 @@ int psh_semilag_host(const void *precip, const void *velocity, int m, int n, con
   // the input checks of semilagrangian.py:106-137 as device reductions (a NumPy isfinite scan of
   // the three planes costs ~10 ms at 4096^2, these two reductions ~40 us + one stream sync)
   {
-    psh::FieldStats sv, sp;
-    PSH_TRY_RC(psh::field_stats_full(d_v, 2 * plane, &sv));
+    if (!have_sv) PSH_TRY_RC(psh::field_stats_full(d_v, 2 * plane, &sv));
     int status = 0;
     if (sv.nonfinite > 0) status |= PSH_SL_ST_VELOCITY_NONFINITE;
     if (sv.nonfinite >= sv.count) status |= PSH_SL_ST_VELOCITY_ALL_NONFINITE;
     if (precip) {
-      PSH_TRY_RC(psh::field_stats_full(d_p, plane, &sp));
+      if (!have_sp) PSH_TRY_RC(psh::field_stats_full(d_p, plane, &sp));
       if (sp.nonfinite > 0) status |= PSH_SL_ST_PRECIP_NONFINITE;
       if (sp.nonfinite >= sp.count) status |= PSH_SL_ST_PRECIP_ALL_NONFINITE;
       if (flags & PSH_SL_OUTVAL_MIN) outval = static_cast<float>(sp.nanmin());  // :171-172

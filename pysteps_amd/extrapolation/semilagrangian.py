@@ -65,21 +65,37 @@ def _unsupported(what, args, kwargs):
 _verified_grids = []  # [(weakref to the array, data pointer, shape)]: grids already compared in full
 
 
+def _grid_sample_ok(xy, m, n):
+    cols, rows = np.arange(n), np.arange(m)
+    for r in (0, m - 1):
+        if not (np.array_equal(xy[0, r], cols) and np.all(xy[1, r] == r)):
+            return False
+    for c in (0, n - 1):
+        if not (np.array_equal(xy[1, :, c], rows) and np.all(xy[0, :, c] == c)):
+            return False
+    sr, sc = max(1, m // 61), max(1, n // 67)
+    return bool(np.array_equal(xy[0, ::sr, ::sc], np.broadcast_to(cols[::sc], (len(rows[::sr]), len(cols[::sc]))))
+                and np.array_equal(xy[1, ::sr, ::sc], np.broadcast_to(rows[::sr, None], (len(rows[::sr]), len(cols[::sc])))))
+
+
 def _is_default_grid(xy_coords, m, n):
     """True if xy_coords is the integer meshgrid the reference builds itself (:174-179).
 
     The whole array is compared (every element, not a sample).  The callers that pass
     ``xy_coords`` (nowcasts/utils.py:361-365, steps.py:661-662) build it once and hand the SAME
-    array to every call, so an array that has been verified is remembered by identity (weak
-    reference + data pointer + shape) and not rescanned - the scan of a (2, 4096, 4096) int64 grid
-    costs more than the advection itself."""
+    array to every call, so an array that has been verified in full is remembered by identity (weak
+    reference + data pointer + shape) and afterwards only sampled (``_grid_sample_ok``) - the full
+    scan of a (2, 4096, 4096) int64 grid costs more than the advection itself."""
     xy = np.asarray(xy_coords)
     if xy.shape != (2, m, n):
         return False
     key = (xy.__array_interface__["data"][0], xy.shape, xy.dtype.str)
     for ref, k in _verified_grids:
         if ref() is xy_coords and k == key:
-            return True
+            # remembered by identity - but the caller may have written into the array since: the
+            # border rows / columns and a strided interior sample are compared again on every call
+            # (O(m + n) + 4096 elements instead of 2 m n)
+            return _grid_sample_ok(xy, m, n)
     ok = bool(np.array_equal(xy[0], np.broadcast_to(np.arange(n), (m, n)))
               and np.array_equal(xy[1], np.broadcast_to(np.arange(m)[:, None], (m, n))))
     if ok:

@@ -21,6 +21,14 @@ from ..device import DeviceArray
 from ..utils import fft as hip_fft
 
 
+def _reference_generator():
+    try:
+        from pysteps.noise.fftgenerators import generate_noise_2d_fft_filter as ref  # noqa: PLC0415
+    except Exception:
+        return None
+    return None if ref is generate_noise_2d_fft_filter else ref
+
+
 def generate_noise_2d_fft_filter(F, randstate=None, seed=None, fft_method=None, domain="spatial"):
     """Produces a field of correlated noise using global Fourier filtering (parameters and return
     value as documented for the reference, fftgenerators.py:333-364)."""
@@ -47,31 +55,19 @@ def generate_noise_2d_fft_filter(F, randstate=None, seed=None, fft_method=None, 
         randstate.seed(seed)
 
     if domain != "spatial" or use_full_fft or not hip_fft.supported_shape(input_shape):
-        # the reference's expression (fftgenerators.py:398-437) with the HIP transforms where they apply
-        fft = hip_fft.get_hip(input_shape) if fft_method is None or isinstance(fft_method, str) else fft_method
-        if domain == "spatial":
-            N = randstate.randn(input_shape[0], input_shape[1])
-            fN = fft.fft2(N) if use_full_fft else fft.rfft2(N)
-        else:
-            size = (input_shape[0], input_shape[1]) if use_full_fft else (input_shape[0], int(input_shape[1] / 2) + 1)
-            theta = randstate.uniform(low=0.0, high=2.0 * np.pi, size=size)
-            if input_shape[0] % 2 == 0:
-                theta[int(input_shape[0] / 2) + 1:, 0] = -theta[1:int(input_shape[0] / 2), 0][::-1]
-            else:
-                theta[int(input_shape[0] / 2) + 1:, 0] = -theta[1:int(input_shape[0] / 2) + 1, 0][::-1]
-            fN = np.cos(theta) + 1.0j * np.sin(theta)
-        fN *= field
-        if domain == "spatial":
-            N = np.array(fft.ifft2(fN).real) if use_full_fft else np.array(fft.irfft2(fN))
-            return (N - N.mean()) / N.std()
-        from pysteps import utils  # noqa: PLC0415 - spectral statistics of the reference
-
-        N = fN
-        N[0, 0] = 0.0
-        N /= utils.spectral.std(N, input_shape, use_full_fft=use_full_fft)
-        return N
+        # the reference's own generator (fftgenerators.py:398-437) with the HIP transforms where they apply
+        ref = _reference_generator()
+        if ref is None:
+            raise NotImplementedError("pysteps_amd generate_noise_2d_fft_filter: spatial domain, half-spectrum filters and "
+                                      "power-of-two grids run on the HIP path; pysteps is not importable for the rest")
+        fft = fft_method
+        if (fft is None or isinstance(fft, str)) and hip_fft.supported_shape(input_shape):
+            fft = hip_fft.get_hip(input_shape)
+        return ref(F, randstate=randstate, seed=None, fft_method=fft, domain=domain)
 
     m, n = input_shape
+    if tuple(field.shape) != (m, n // 2 + 1):  # the reference fails broadcasting fN *= F (:420)
+        raise ValueError("operands could not be broadcast together with shapes (%d,%d) %s" % (m, n // 2 + 1, tuple(field.shape)))
     white = randstate.randn(m, n)  # fftgenerators.py:400
     d_white = DeviceArray.from_host(white)
     d_filter = _device_weights(field)

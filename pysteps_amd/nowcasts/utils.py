@@ -289,6 +289,10 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
     engine = None
     if extrapolator is _hip_extrapolate:
         opts = _batched_options(extrap_kwargs)
+        if opts is not None and not np.all(np.isfinite(velocity)):
+            # the reference's extrapolator decides what a non-finite motion field means (ValueError unless
+            # allow_nonfinite_values, semilagrangian.py:106-137): such fields go member by member through it
+            opts = None
         perts = None
         if velocity_pert_gen is not None and opts is not None:
             perts = bps_perturbators(velocity_pert_gen, velocity)

@@ -75,5 +75,10 @@ def nonparam_match_empirical_cdf(initial_array, target_array, ignore_indices=Non
     rc = _lib.lib().psh_probmatch_dev(d_init.ptr, d_trg.ptr, initial_array.size, out.ptr)
     if rc == _lib.PSH_EUNSUPPORTED and not resident:
         return _reference()(initial_array, target_array)
+    if rc == _lib.PSH_EUNSUPPORTED:
+        # resident arrays the bucket pass declines (more than 16384 tied or bucket-sharing wet values,
+        # infinities in the target): this one call crosses the bus, the member loop keeps going
+        got = _reference()(initial_array.to_host(), target_array.to_host())
+        return DeviceArray.from_host(np.ascontiguousarray(got, dtype=np.float64))
     _lib.check(rc, "psh_probmatch_dev")
     return out if resident else out.to_host()

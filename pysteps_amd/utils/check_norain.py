@@ -33,7 +33,15 @@ def check_norain(precip_arr, precip_thr=None, norain_thr=0.0, win_fun=None, prin
         if precip_arr.dtype != np.float32:
             raise ValueError("device-resident fields must be float32")
         count, lowest = ctypes.c_double(), ctypes.c_double()
-        thr = float("nan") if precip_thr is None else float(precip_thr)
+        # `masked > precip_thr` (check_norain.py:49) on a float32 field: NumPy rounds a Python float (and a
+        # numpy.float32) to float32 first and compares a numpy.float64 scalar in float64; the kernel
+        # compares in double, so the rounding NumPy would apply is applied here
+        if precip_thr is None:
+            thr = float("nan")
+        elif isinstance(precip_thr, np.floating) and np.dtype(type(precip_thr)).itemsize > 4:
+            thr = float(precip_thr)
+        else:
+            thr = float(np.float32(precip_thr))
         _lib.check(_lib.lib().psh_count_above_dev(precip_arr.ptr, precip_arr.size, thr, ctypes.byref(count),
                                                   ctypes.byref(lowest)), "psh_count_above_dev")
         fraction = count.value / precip_arr.size

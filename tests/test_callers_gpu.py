@@ -80,17 +80,28 @@ def _steps_kwargs():
                 seed=42, vel_pert_method="bps", mask_method="incremental", num_workers=1)
 
 
-def _ensemble_close(got, want, field_tol=1e-4, flip_frac=2e-3):
+FLIPS_SEEN = []  # (test, NaN-mask mismatches / pixels, pixels off by > 1 % of the range / pixels)
+
+
+def _ensemble_close(got, want, field_tol=1e-4, flip_frac=2e-5):
     """STEPS thresholds (precip mask, incremental mask) and rank-matches (CDF matching) its fields:
     a 1e-7 difference in an advected value can move a pixel across such a decision.  Compare the
-    pixels that took the same side within 1e-4 rel-L2 and bound the fraction that did not."""
+    pixels that took the same side within 1e-4 rel-L2 and bound the fraction that did not: observed
+    on MI355X: none at all (0 NaN-mask mismatches, 0 pixels off by more than 1 % of the range in every
+    caller test of this file, gpurun_out/flips_seen.json), bound 2e-5 of the pixels;
+    the observed fractions are collected in FLIPS_SEEN and printed when a bound fails."""
+    import inspect
+
     assert got.shape == want.shape
-    assert nan_mismatch(got, want) <= flip_frac * want.size
+    nan_frac = nan_mismatch(got, want) / want.size
     diff = np.abs(got - want)
     ok = np.isfinite(diff)
     scale = float(np.nanmax(want) - np.nanmin(want))
     flipped = ok & (diff > 1e-2 * scale)
-    assert np.count_nonzero(flipped) <= flip_frac * want.size, np.count_nonzero(flipped) / want.size
+    frac = np.count_nonzero(flipped) / want.size
+    FLIPS_SEEN.append((inspect.stack()[1].function, nan_frac, frac))
+    assert nan_frac <= flip_frac, FLIPS_SEEN
+    assert frac <= flip_frac, FLIPS_SEEN
     same = ok & ~flipped
     return float(np.linalg.norm((got - want)[same]) / np.linalg.norm(want[same]))
 
@@ -340,3 +351,17 @@ def test_check_norain_mirror_matches_the_reference(pysteps):
         assert check_norain(DeviceArray.from_host(db), -10.0, 0.2, win, False) == ref_check(db, -10.0, 0.2, win, False)
     stack = np.stack([db, dry])
     assert check_norain(stack, -10.0, 0.0, None, False) == ref_check(stack, -10.0, 0.0, None, False)
+
+
+def test_zz_flip_fractions_observed_in_this_file():
+    """what _ensemble_close saw over the caller tests above (kept in gpurun_out/ for DESIGN.md)"""
+    import json
+    import os
+
+    from conftest import ROOT
+
+    assert FLIPS_SEEN
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "flips_seen.json"), "w") as fh:
+        json.dump(FLIPS_SEEN, fh)
+    assert max(f[1] for f in FLIPS_SEEN) <= 2e-5 and max(f[2] for f in FLIPS_SEEN) <= 2e-5, FLIPS_SEEN

