@@ -53,6 +53,8 @@ int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hb
  * lane with dwordx4 gathers (interp_order 0/1, >= 192 columns), 2 / 4 LDS-staged tiles;
  * "idw_variant": 0 two-level pre-pass (64x64 supertile lists, one wave per 8x8 tile; default),
  * 1 one pre-pass per 16x16 tile;
+ * "members_variant": members per thread of the member-batched step on packed planes: 2 (default: the two
+ * trajectories' gathers overlap) or 1;
  * "trim_cache": release the device blocks cached by psh_free (value ignored) */
 int psh_set_option(const char *key, int value);
 

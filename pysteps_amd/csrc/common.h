@@ -113,6 +113,7 @@ bool semilag_wants_field_pairs(const SemilagArgs &a);
 hipError_t launch_pack_field_rows(const float *precip, float *pairs, int m, int n, hipStream_t stream);
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
 void set_semilag_variant(int v);
+void set_members_variant(int v);
 // three-pixels-per-lane kernel (semilag_wide.hip): interp_order 0/1, images >= 192 columns
 bool semilag_wide_eligible(const SemilagArgs &a);
 hipError_t launch_semilag_wide(const SemilagArgs &a, hipStream_t stream);

@@ -243,6 +243,12 @@ int psh_set_option(const char *key, int value) {
     psh::set_semilag_variant(value);
     return PSH_OK;
   }
+  if (std::strcmp(key, "members_variant") == 0) {
+    if (value != 1 && value != 2)
+      return fail(PSH_EINVAL, "members_variant must be 2 (two members per thread, default) or 1 (one)");
+    psh::set_members_variant(value);
+    return PSH_OK;
+  }
   if (std::strcmp(key, "idw_variant") == 0) {
     if (value != 0 && value != 1)
       return fail(PSH_EINVAL, "idw_variant must be 0 (two-level pre-pass) or 1 (pre-pass per 16x16 tile)");

@@ -26,6 +26,8 @@
 #include "semilag_device.h"
 
 namespace psh {
+int g_members_variant = 2;  // members per thread of the packed kernel: 2 (default) or 1
+void set_members_variant(int v) { g_members_variant = v; }
 namespace {
 
 using namespace sl;
@@ -146,6 +148,30 @@ __device__ __forceinline__ void sample_member(const Planes &F, int X, int Y, flo
   }
 }
 
+// the advected field alone at (X + fx, Y + fy): the sample of the LAST sub-step of a call, whose
+// velocity sample nobody would read (the next call rebuilds its increment from the stored position)
+template <int ORDER>
+__device__ __forceinline__ float sample_field_only(const Planes &F, int X, int Y, float fx, float fy, int m, int n,
+                                                   float outval) {
+  float sp;
+  if (wave_all_interior(X, Y, m, n)) {
+    const unsigned off = static_cast<unsigned>(__mul24(Y, n) + X) << 2;
+    if (ORDER == 1) {
+      const Weights w = make_weights(fx, fy);
+      const f32x2 pt = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(F.p, static_cast<int>(off), 0, 0));
+      const f32x2 pb = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(F.p, static_cast<int>(off), F.row_bytes, 0));
+      sp = blend(w, pt.x, pt.y, pb.x, pb.y);
+    } else {
+      const int xi = X + (fx >= 0.5f ? 1 : 0), yi = Y + (fy >= 0.5f ? 1 : 0);
+      sp = bld(F.p, static_cast<unsigned>(__mul24(yi, n) + xi) << 2, 0);
+    }
+    asm volatile("" ::: "memory");
+  } else {
+    sp = sample_precip_border<ORDER>(F.pp, X, Y, fx, fy, m, n, outval);
+  }
+  return sp;
+}
+
 // State of a trajectory between calls.  COMPACT = the kernel's own representation, one 16-byte
 // record per pixel and member: integer pixel offsets (P - x, P - y) and the two fractions as
 // float32 - half the bytes of the float64 displacement pair of the reference, read and written
@@ -156,11 +182,17 @@ __global__ __launch_bounds__(256) void semilag_members(
     const float *__restrict__ packed,
     const float *__restrict__ pert_ab, float *__restrict__ out, void *__restrict__ state,
     const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume,
-    float outval, int tiles_x, int n_tiles, int tiles_per_xcd) {
+    float outval, int tiles_x, int n_tiles, int tiles_per_xcd, int n_members) {
+  // XCD-contiguous bands of tiles, and within an XCD the members of a tile back to back (member is the
+  // fastest index of the XCD's block sequence): the members sample the SAME velocity planes around the
+  // same pixels at the same time, so one member's gathers leave the lines in the XCD's L2 for the others
+  // - 1.6 GB of the 5.5 GB a 6-member launch fetched from HBM were re-fetches of the packed plane
+  // (profiles/r03/a_members_pmc_traffic.json)
   const int blk = blockIdx.x;
-  const int tile = (blk % kNumXcd) * tiles_per_xcd + blk / kNumXcd;  // XCD-contiguous bands
+  const int seq = blk / kNumXcd;
+  const int tile = (blk % kNumXcd) * tiles_per_xcd + seq / n_members;
   if (tile >= n_tiles) return;
-  const int member = blockIdx.y;
+  const int member = seq % n_members;
   const int x = (tile % tiles_x) * 64 + (threadIdx.x & 63);
   const int y = (tile / tiles_x) * 4 + (threadIdx.x >> 6);
   const bool live = x < n && y < m;
@@ -220,13 +252,20 @@ __global__ __launch_bounds__(256) void semilag_members(
         sample_member<ORDER, PERT, false, PACKED>(F, mx, my, gx, gy, m, n, a, b, outval, su, sv, sp);
         retreat(px, fx, su * s);
         retreat(py, fy, sv * s);
-        if (HAS_PRECIP && k == n_iter - 1) {
-          sample_member<ORDER, PERT, true, PACKED>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+        if (t == T - 1 && k == n_iter - 1) {
+          // last sub-step of the call: the increment it would prepare is rebuilt by the next call from
+          // the stored position (resume), so only the field is sampled - 4 of the 16 gathers of a
+          // single-step call were these dead velocity taps
+          if (HAS_PRECIP) sp = sample_field_only<ORDER>(F, px, py, fx, fy, m, n, outval);
         } else {
-          sample_member<ORDER, PERT, false, PACKED>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+          if (HAS_PRECIP && k == n_iter - 1) {
+            sample_member<ORDER, PERT, true, PACKED>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+          } else {
+            sample_member<ORDER, PERT, false, PACKED>(F, px, py, fx, fy, m, n, a, b, outval, su, sv, sp);
+          }
+          vix = su * s;
+          viy = sv * s;
         }
-        vix = su * s;
-        viy = sv * s;
       }
     } else {
       if (t > 0 || resume) {
@@ -255,6 +294,249 @@ __global__ __launch_bounds__(256) void semilag_members(
       dplane[pix] = static_cast<double>(px - xc) + static_cast<double>(fx);
       dplane[plane + pix] = static_cast<double>(py - yc) + static_cast<double>(fy);
     }
+  }
+}
+
+// ---- two members per thread ----------------------------------------------------------------------
+// A single-step call is a chain of four dependent memory round trips per trajectory (record ->
+// increment rebuild -> midpoint -> field): with one trajectory per thread and 8 waves per SIMD the
+// kernel ran at the latency of that chain (1.16 ms for 6 members at 4096^2, TA 60 % busy, HBM at 3.7
+// of 8 TB/s).  Here a thread carries the same pixel of TWO members: both chains' gathers are issued
+// before either is waited for, and the two members' taps fall into the same cache lines (their
+// trajectories differ by the perturbation only).  Packed planes, compact records, n_iter >= 1.
+struct PairTaps {
+  f32x4 a0, a1, b0, b1;
+  f32x2 pt, pb;
+  float p0;
+};
+
+template <int ORDER, bool PERT, bool WITH_P>
+__device__ __forceinline__ void issue_taps(const Planes &F, __amdgpu_buffer_rsrc_t prec, int X, int Y, float fx, float fy,
+                                           int n, PairTaps &t) {
+  const unsigned off = static_cast<unsigned>(__mul24(Y, n) + X) << 2;
+  const int rb = F.row_bytes;
+  if (PERT) {
+    const unsigned o4 = off << 2;
+    t.a0 = bld4(F.packed, o4, 0);
+    t.a1 = bld4(F.packed, o4 + 16u, 0);
+    t.b0 = bld4(F.packed, o4, 4 * rb);
+    t.b1 = bld4(F.packed, o4 + 16u, 4 * rb);
+  } else {
+    const unsigned o2 = off << 1;
+    t.a0 = bld4(F.packed, o2, 0);
+    t.b0 = bld4(F.packed, o2, 2 * rb);
+  }
+  if (WITH_P) {
+    if (ORDER == 1) {
+      t.pt = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prec, static_cast<int>(off), 0, 0));
+      t.pb = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prec, static_cast<int>(off), rb, 0));
+    } else {
+      const int xi = X + (fx >= 0.5f ? 1 : 0), yi = Y + (fy >= 0.5f ? 1 : 0);
+      t.p0 = bld(prec, static_cast<unsigned>(__mul24(yi, n) + xi) << 2, 0);
+    }
+  }
+}
+
+template <int ORDER, bool PERT, bool WITH_P>
+__device__ __forceinline__ void finish_taps(const PairTaps &t, float fx, float fy, float a, float b, float &su, float &sv,
+                                            float &sp) {
+  const Weights w = make_weights(fx, fy);
+  f32x2 uv;
+  if (PERT) {
+    uv = blend2(w, t.a0.xy, t.a1.xy, t.b0.xy, t.b1.xy);
+    const f32x2 h = blend2(w, t.a0.zw, t.a1.zw, t.b0.zw, t.b1.zw);
+    su = uv.x + (a * h.x - b * h.y);
+    sv = uv.y + (a * h.y + b * h.x);
+  } else {
+    uv = blend2(w, t.a0.xy, t.a0.zw, t.b0.xy, t.b0.zw);
+    su = uv.x;
+    sv = uv.y;
+  }
+  if (WITH_P) sp = ORDER == 1 ? blend(w, t.pt.x, t.pt.y, t.pb.x, t.pb.y) : t.p0;
+}
+
+struct Traj {
+  int px, py;
+  float fx, fy, vix, viy, su, sv, sp;
+};
+
+// velocity (and optionally the field) of both members at their positions (X[i] + gx[i], Y[i] + gy[i])
+template <int ORDER, bool PERT, bool WITH_P>
+__device__ __forceinline__ void sample_two(const Planes (&F)[2], const int (&X)[2], const int (&Y)[2], const float (&gx)[2],
+                                           const float (&gy)[2], int m, int n, const float (&a)[2], const float (&b)[2],
+                                           float outval, Traj (&tr)[2]) {
+  if (wave_all_interior(X[0], Y[0], m, n) && wave_all_interior(X[1], Y[1], m, n)) {
+    PairTaps t0, t1;
+    issue_taps<ORDER, PERT, WITH_P>(F[0], F[0].p, X[0], Y[0], gx[0], gy[0], n, t0);
+    issue_taps<ORDER, PERT, WITH_P>(F[1], F[1].p, X[1], Y[1], gx[1], gy[1], n, t1);
+    finish_taps<ORDER, PERT, WITH_P>(t0, gx[0], gy[0], a[0], b[0], tr[0].su, tr[0].sv, tr[0].sp);
+    finish_taps<ORDER, PERT, WITH_P>(t1, gx[1], gy[1], a[1], b[1], tr[1].su, tr[1].sv, tr[1].sp);
+    asm volatile("" ::: "memory");
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      sample_member<ORDER, PERT, WITH_P, true>(F[i], X[i], Y[i], gx[i], gy[i], m, n, a[i], b[i], outval, tr[i].su, tr[i].sv,
+                                               tr[i].sp);
+  }
+}
+
+template <int ORDER, bool PERT, bool HAS_PRECIP>
+__global__ __launch_bounds__(256) void semilag_members_pair(
+    const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vhat,
+    const float *__restrict__ packed, const float *__restrict__ pert_ab, float *__restrict__ out, void *__restrict__ state,
+    const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume, float outval,
+    int tiles_x, int n_tiles, int tiles_per_xcd, int n_members) {
+  const int groups = (n_members + 1) >> 1;
+  const int blk = blockIdx.x;
+  const int seq = blk / kNumXcd;
+  const int tile = (blk % kNumXcd) * tiles_per_xcd + seq / groups;  // XCD-contiguous bands, member pairs back to back
+  if (tile >= n_tiles) return;
+  const int first = (seq % groups) * 2;
+  const int member[2] = {first, min(first + 1, n_members - 1)};
+  const bool second = first + 1 < n_members;  // odd member count: the last thread column carries one member twice
+  const int x = (tile % tiles_x) * 64 + (threadIdx.x & 63);
+  const int y = (tile / tiles_x) * 4 + (threadIdx.x >> 6);
+  const bool live = x < n && y < m;
+  const int xc = min(x, n - 1), yc = min(y, m - 1);
+  const size_t plane = static_cast<size_t>(m) * n;
+  const int plane_bytes = static_cast<int>(plane * sizeof(float));
+  const size_t pix = static_cast<size_t>(yc) * n + xc;
+
+  Planes F[2];
+  float a[2], b[2];
+  uint4 *record[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    F[i].pu = vel;
+    F[i].pv = vel + plane;
+    F[i].phu = PERT ? vhat : vel;
+    F[i].phv = PERT ? vhat + plane : vel;
+    F[i].pp = HAS_PRECIP ? precip + static_cast<size_t>(member[i]) * plane : vel;
+    F[i].u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F[i].pu), 0, plane_bytes, 0x00020000);
+    F[i].v = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F[i].pv), 0, plane_bytes, 0x00020000);
+    F[i].hu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F[i].phu), 0, plane_bytes, 0x00020000);
+    F[i].hv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F[i].phv), 0, plane_bytes, 0x00020000);
+    F[i].p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(F[i].pp), 0, plane_bytes, 0x00020000);
+    F[i].packed = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(packed), 0, (PERT ? 4 : 2) * plane_bytes, 0x00020000);
+    F[i].row_bytes = n * static_cast<int>(sizeof(float));
+    a[i] = PERT ? pert_ab[2 * member[i]] : 0.f;
+    b[i] = PERT ? pert_ab[2 * member[i] + 1] : 0.f;
+    record[i] = static_cast<uint4 *>(state) + static_cast<size_t>(member[i]) * plane + pix;
+  }
+
+  Traj tr[2];
+  int X[2], Y[2];
+  float gx[2], gy[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    tr[i].px = xc;
+    tr[i].py = yc;
+    tr[i].fx = tr[i].fy = 0.f;
+    tr[i].sp = 0.f;
+  }
+  if (resume) {
+    const uint4 r0 = *record[0], r1 = *record[1];
+    tr[0].px += static_cast<int>(r0.x);
+    tr[0].py += static_cast<int>(r0.y);
+    tr[0].fx = __uint_as_float(r0.z);
+    tr[0].fy = __uint_as_float(r0.w);
+    tr[1].px += static_cast<int>(r1.x);
+    tr[1].py += static_cast<int>(r1.y);
+    tr[1].fx = __uint_as_float(r1.z);
+    tr[1].fy = __uint_as_float(r1.w);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    X[i] = tr[i].px;
+    Y[i] = tr[i].py;
+    gx[i] = tr[i].fx;
+    gy[i] = tr[i].fy;
+  }
+  sample_two<ORDER, PERT, false>(F, X, Y, gx, gy, m, n, a, b, outval, tr);
+  {
+    const float s0 = resume ? scale[0] : first_scale;  // the very first increment is not divided by n_iter (:202)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      tr[i].vix = tr[i].su * s0;
+      tr[i].viy = tr[i].sv * s0;
+    }
+  }
+  float *optr[2] = {out + (static_cast<size_t>(member[0]) * T) * plane + pix, out + (static_cast<size_t>(member[1]) * T) * plane + pix};
+  for (int t = 0; t < T; ++t) {
+    const float s = scale[t];
+    for (int k = 0; k < n_iter; ++k) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        X[i] = tr[i].px;
+        Y[i] = tr[i].py;
+        gx[i] = tr[i].fx;
+        gy[i] = tr[i].fy;
+        retreat(X[i], gx[i], 0.5f * tr[i].vix);
+        retreat(Y[i], gy[i], 0.5f * tr[i].viy);
+      }
+      sample_two<ORDER, PERT, false>(F, X, Y, gx, gy, m, n, a, b, outval, tr);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        retreat(tr[i].px, tr[i].fx, tr[i].su * s);
+        retreat(tr[i].py, tr[i].fy, tr[i].sv * s);
+        X[i] = tr[i].px;
+        Y[i] = tr[i].py;
+        gx[i] = tr[i].fx;
+        gy[i] = tr[i].fy;
+      }
+      if (t == T - 1 && k == n_iter - 1) {
+        // last sub-step of the call: only the field (the next call rebuilds the increment, see above)
+        if (HAS_PRECIP) {
+          if (wave_all_interior(X[0], Y[0], m, n) && wave_all_interior(X[1], Y[1], m, n)) {
+            float v[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const unsigned off = static_cast<unsigned>(__mul24(Y[i], n) + X[i]) << 2;
+              if (ORDER == 1) {
+                const f32x2 pt = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(F[i].p, static_cast<int>(off), 0, 0));
+                const f32x2 pb = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(F[i].p, static_cast<int>(off), F[i].row_bytes, 0));
+                v[i] = blend(make_weights(gx[i], gy[i]), pt.x, pt.y, pb.x, pb.y);
+              } else {
+                const int xi = X[i] + (gx[i] >= 0.5f ? 1 : 0), yi = Y[i] + (gy[i] >= 0.5f ? 1 : 0);
+                v[i] = bld(F[i].p, static_cast<unsigned>(__mul24(yi, n) + xi) << 2, 0);
+              }
+            }
+            tr[0].sp = v[0];
+            tr[1].sp = v[1];
+            asm volatile("" ::: "memory");
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) tr[i].sp = sample_precip_border<ORDER>(F[i].pp, X[i], Y[i], gx[i], gy[i], m, n, outval);
+          }
+        }
+      } else {
+        if (HAS_PRECIP && k == n_iter - 1) {
+          sample_two<ORDER, PERT, true>(F, X, Y, gx, gy, m, n, a, b, outval, tr);
+        } else {
+          sample_two<ORDER, PERT, false>(F, X, Y, gx, gy, m, n, a, b, outval, tr);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          tr[i].vix = tr[i].su * s;
+          tr[i].viy = tr[i].sv * s;
+        }
+      }
+    }
+    if (HAS_PRECIP) {
+      if (live) {
+        *optr[0] = lost(tr[0].fx, tr[0].fy) ? outval : tr[0].sp;
+        if (second) *optr[1] = lost(tr[1].fx, tr[1].fy) ? outval : tr[1].sp;
+      }
+      optr[0] += plane;
+      optr[1] += plane;
+    }
+  }
+  if (live) {
+    *record[0] = make_uint4(static_cast<unsigned>(tr[0].px - xc), static_cast<unsigned>(tr[0].py - yc), __float_as_uint(tr[0].fx),
+                            __float_as_uint(tr[0].fy));
+    if (second)
+      *record[1] = make_uint4(static_cast<unsigned>(tr[1].px - xc), static_cast<unsigned>(tr[1].py - yc),
+                              __float_as_uint(tr[1].fx), __float_as_uint(tr[1].fy));
   }
 }
 
@@ -382,12 +664,12 @@ static int members_step(const float *precip_dev, const float *velocity_dev, cons
   const int tiles_x = (n + 63) / 64, tiles_y = (m + 3) / 4;
   const int n_tiles = tiles_x * tiles_y;
   const int tiles_per_xcd = (n_tiles + psh::kNumXcd - 1) / psh::kNumXcd;
-  const dim3 grid(tiles_per_xcd * psh::kNumXcd, n_members), block(256);
+  const dim3 grid(static_cast<unsigned>(tiles_per_xcd) * psh::kNumXcd * n_members), block(256);
   const float first_scale = static_cast<float>(steps_host[0]);
 #define PSH_MEMBERS_P(ORDER, PERT, HASP, COMPACT, PACKED)                                                  \
   hipLaunchKernelGGL((psh::semilag_members<ORDER, PERT, HASP, COMPACT, PACKED>), grid, block, 0, c.stream, \
                      precip_dev, velocity_dev, vhat_dev, packed_dev, d_const + T, out_dev, disp_dev, d_const,  \
-                     first_scale, m, n, T, n_iter, resume, outval, tiles_x, n_tiles, tiles_per_xcd)
+                     first_scale, m, n, T, n_iter, resume, outval, tiles_x, n_tiles, tiles_per_xcd, n_members)
 #define PSH_MEMBERS_C(ORDER, PERT, HASP, COMPACT)         \
   do {                                                    \
     if (packed_dev) {                                     \
@@ -404,7 +686,23 @@ static int members_step(const float *precip_dev, const float *velocity_dev, cons
       PSH_MEMBERS_C(ORDER, PERT, HASP, false);          \
     }                                                   \
   } while (0)
-  if (!precip_dev) {
+  // packed planes + compact state (what EnsembleAdvector runs), n_iter >= 1: two members per thread
+  if (packed_dev && compact && n_iter > 0 && n_members > 1 && psh::g_members_variant == 2) {
+    const int groups = (n_members + 1) / 2;
+    const dim3 grid2(static_cast<unsigned>(tiles_per_xcd) * psh::kNumXcd * groups);
+#define PSH_PAIR(ORDER, PERT, HASP)                                                                        \
+  hipLaunchKernelGGL((psh::semilag_members_pair<ORDER, PERT, HASP>), grid2, block, 0, c.stream, precip_dev, \
+                     velocity_dev, vhat_dev, packed_dev, d_const + T, out_dev, disp_dev, d_const, first_scale, \
+                     m, n, T, n_iter, resume, outval, tiles_x, n_tiles, tiles_per_xcd, n_members)
+    if (!precip_dev) {
+      if (pert) PSH_PAIR(1, true, false); else PSH_PAIR(1, false, false);
+    } else if (interp_order == 0) {
+      if (pert) PSH_PAIR(0, true, true); else PSH_PAIR(0, false, true);
+    } else {
+      if (pert) PSH_PAIR(1, true, true); else PSH_PAIR(1, false, true);
+    }
+#undef PSH_PAIR
+  } else if (!precip_dev) {
     if (pert) PSH_MEMBERS(1, true, false); else PSH_MEMBERS(1, false, false);
   } else if (interp_order == 0) {
     if (pert) PSH_MEMBERS(0, true, true); else PSH_MEMBERS(0, false, true);

@@ -146,3 +146,36 @@ def test_packed_gather_planes_are_bit_identical(perturb, n_iter, order):
         ga, gb = a.step(members, dt, t_total), b.step(members, dt, t_total)
         assert np.array_equal(ga, gb, equal_nan=True)
     assert np.array_equal(a.displacement.to_host(), b.displacement.to_host())
+
+
+@pytest.mark.parametrize("B,order,n_iter", [(3, 1, 1), (4, 1, 2), (5, 0, 1), (2, 1, 1)])
+def test_two_members_per_thread_is_bit_identical(B, order, n_iter):
+    """members_variant 2 (the default: a thread carries the same pixel of two members so that the two
+    chains of gathers overlap) against variant 1 (one member per thread): the same arithmetic per
+    trajectory - outputs and trajectory records bit for bit, odd member counts, image borders, a
+    zero-velocity pixel, displacement-only calls in between"""
+    from pysteps_amd import _lib
+    from pysteps_amd.extrapolation.ensemble import EnsembleAdvector
+    from tools import synth
+
+    m, n = 130, 200
+    members = np.stack([synth.rain_field_db(m, n, seed=40 + j, sigma=2.0) for j in range(B)])
+    members[0, 5:9, 7:30] = np.nan
+    V = synth.true_velocity(m, n)
+    V[:, 17, 23] = 0.0
+    perts = [dict(eps_par=0.8 - 0.5 * j, eps_perp=-0.4 + 0.3 * j, p_par=(10.88, 0.23, -7.68), p_perp=(5.76, 0.31, -2.72), vsf=12.0)
+             for j in range(B)]
+    got = {}
+    try:
+        for variant in (1, 2):
+            _lib.check(_lib.lib().psh_set_option(b"members_variant", variant))
+            adv = EnsembleAdvector(V, B, perts, outval=-15.0, n_iter=n_iter, interp_order=order)
+            outs = [adv.step(members, 1.0, 5.0), adv.step(members, [1.0, 0.5], 10.0)]
+            adv.step(None, 1.0, 15.0)
+            outs.append(adv.step(members, 2.0, 20.0))
+            got[variant] = (outs, adv._state.to_host())
+    finally:
+        _lib.check(_lib.lib().psh_set_option(b"members_variant", 2))
+    np.testing.assert_array_equal(got[1][1], got[2][1])
+    for a, b in zip(got[1][0], got[2][0]):
+        np.testing.assert_array_equal(a, b)

@@ -21,6 +21,9 @@ rng = np.random.default_rng(0)
 perts = [dict(eps_par=rng.laplace(scale=0.7), eps_perp=rng.laplace(scale=0.7), p_par=(10.88, 0.23, -7.68),
               p_perp=(5.76, 0.31, -2.72), vsf=12.0) for _ in range(B)] if pert else None
 packed = (sys.argv[5] != "0") if len(sys.argv) > 5 else True
+if len(sys.argv) > 6:
+    from pysteps_amd import _lib as _l
+    _l.check(_l.lib().psh_set_option(b"members_variant", int(sys.argv[6])))
 adv = EnsembleAdvector(synth.true_velocity(m, n), B, perts, outval=-15.0, packed=packed)
 cur = members
 for t in range(2):
