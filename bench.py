@@ -252,18 +252,28 @@ def pmc_traffic(workload):
         return None
 
 
-FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 vector peak
-LK_STREAM_KERNELS = ("lk_stats1", "lk_stats1_final", "lk_open_vec", "lk_open", "lk_open_final", "lk_to_u8",
-                     "lk_corner_response", "lk_max_final", "lk_corner_select", "lk_pyrdown", "lk_scharr")
-LK_STREAM_BYTES_PER_PX_PAIR = 42.5  # ~40-45 B / pixel / frame pair of compulsory streaming
+N_SIMD = 1024  # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md)
+# algorithmic bytes per pixel of the streaming image passes of the motion estimate (what each pass has
+# to read and write once): float32 frame in / cleaned frame out / uint8 renderings / float32 response
+LK_PASS_BYTES = {
+    "lk_stats1": (4.0, "frame read"),
+    "lk_open_bits": (8.0, "frame read + cleaned frame written"),
+    "lk_to_u8": (5.5, "cleaned frame read + tracking rendering written (+ feature rendering for the first frame of a pair)"),
+    "lk_corner_response": (5.0, "uint8 rendering read + float32 response written"),
+    "lk_corner_select": (4.0, "response read"),
+    "lk_pyrdown": (1.25 * 1.333, "per frame: every level read once, the next one written (geometric series)"),
+}
+LK_CALLS_PER_PAIR = {"lk_stats1": 2, "lk_open_bits": 2, "lk_to_u8": 2, "lk_corner_response": 1, "lk_corner_select": 1,
+                     "lk_pyrdown": 2}
 
 
 def roofline_lk(frames_d, m, n, pairs):
-    """Second-tier rooflines of the motion estimate, from the committed rocprofv3 kernel
-    averages of the SAME workload (profiles/kernel_stats_latest.json, written by
-    tools/collect_profiles.py): the IDW kernel against the FP32 vector peak with the brute-force
-    work model L x 8 flop per pixel, the streaming image passes against HBM with ~42.5 B per pixel
-    and frame pair.  None if the committed profile is for another size."""
+    """Second-tier rooflines of the motion estimate from the committed rocprofv3 summaries of
+    the SAME workload (profiles/kernel_stats_latest.json, written by tools/collect_profiles.py from the
+    kernel trace and the PMC passes): the streaming image passes against HBM, each with its own
+    algorithmic bytes; the VALU-bound kernels (idw_fine, lk_corner_response) by the share of the
+    chip's VALU issue slots their instructions take (SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel
+    cycles)) - a work model in flops would price what the kernel (rightly) does not execute."""
     path = os.path.join(ROOT, "profiles", "kernel_stats_latest.json")
     try:
         with open(path) as fh:
@@ -273,28 +283,36 @@ def roofline_lk(frames_d, m, n, pairs):
         kern = prof["kernels"]
     except Exception:
         return None
-    from pysteps_amd import motion
-    from pysteps_amd.utils import decluster
-
-    xy, uv = motion.get_method("LK")(frames_d.to_host(), dense=False)
-    L = len(decluster(xy, uv, 20, 1)[0]) if len(xy) else 0
-    out = {"source": prof.get("source"), "vectors_interpolated": L}
-    if "idw_fine" in kern and L:
-        ms = (kern["idw_fine"]["avg_ns"] + kern.get("idw_coarse", {}).get("avg_ns", 0.0)) / 1e6
-        flops = 8.0 * L * m * n
-        out["idw"] = {"kernel": "idw_coarse + idw_fine", "bound": "fp32 valu", "kernel_ms": ms,
-                      "model_flops": flops, "achieved": flops / (ms * 1e-3) / 1e12, "peak": FP32_VALU_PEAK_TFLOPS,
-                      "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                      "note": "work model = brute force over all L vectors; the kernel prunes to ~60 candidates per "
-                              "tile, so frac > what the VALUs really execute"}
-    ns = sum(kern[k]["ns_per_step"] for k in LK_STREAM_KERNELS if k in kern)
-    if ns:
-        nbytes = LK_STREAM_BYTES_PER_PX_PAIR * m * n * pairs
-        out["image_passes"] = {"kernels": [k for k in LK_STREAM_KERNELS if k in kern], "bound": "hbm",
-                               "ms_per_step": ns / 1e6, "alg_bytes_per_step": nbytes,
-                               "achieved": nbytes / (ns * 1e-9) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": nbytes / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS,
-                               "per_kernel_ms": {k: kern[k]["ns_per_step"] / 1e6 for k in LK_STREAM_KERNELS if k in kern}}
+    counters = prof.get("counters", {})
+    out = {"source": prof.get("source"), "counter_source": prof.get("counter_source")}
+    passes = {}
+    total_ns = total_bytes = 0.0
+    for name, (bpp, what) in LK_PASS_BYTES.items():
+        if name not in kern:
+            continue
+        calls = LK_CALLS_PER_PAIR[name] * pairs
+        ns = kern[name]["ns_per_step"]
+        nbytes = bpp * m * n * calls
+        passes[name] = {"ms_per_step": ns / 1e6, "alg_bytes_per_px": bpp, "what": what,
+                        "achieved": nbytes / (ns * 1e-9) / 1e9, "frac": nbytes / (ns * 1e-9) / 1e9 / HBM_PEAK_GBS}
+        total_ns += ns
+        total_bytes += nbytes
+    if passes:
+        out["image_passes"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "ms_per_step": total_ns / 1e6,
+                               "alg_bytes_per_step": total_bytes, "achieved": total_bytes / (total_ns * 1e-9) / 1e9,
+                               "frac": total_bytes / (total_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, "per_kernel": passes}
+    valu = {}
+    for name in ("idw_fine", "idw_coarse", "lk_corner_response", "lk_track_rows", "outliers_local"):
+        c = counters.get(name)
+        if not c or "SQ_INSTS_VALU" not in c or "GRBM_GUI_ACTIVE" not in c:
+            continue
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter adds the 8 XCDs up
+        valu[name] = {"kernel_ms": kern.get(name, {}).get("avg_ns", 0.0) / 1e6, "valu_insts_per_launch": c["SQ_INSTS_VALU"],
+                      "kernel_cycles": cycles, "valu_issue_frac": c["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cycles)}
+    if valu:
+        out["valu_bound"] = {"bound": "valu issue", "definition": "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); "
+                             "float64 and transcendental instructions take more than 2 cycles, so this is a lower bound of "
+                             "the VALU busy share", "per_kernel": valu}
     return out
 
 
@@ -496,6 +514,9 @@ def spectral_leg(m, n):
     spec = m * (n // 2 + 1) * 16
     traffic = m * n * 8 + 3 * spec
     out = {"rfft2_ms": fwd, "irfft2_ms": inv, "rfft2_hbm_frac": traffic / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "irfft2_hbm_frac": traffic / (inv * 1e-3) / 1e9 / HBM_PEAK_GBS, "fft_alg_bytes": traffic,
+           "fft_alg_bytes_note": "two-pass transform: real plane once, half spectrum three times (written by the first "
+                                 "pass, read and written by the second)",
            "numpy_rfft2_ms": cpu, "dtype": "f64"}
     try:
         from pysteps_amd.cascade import decomposition_fft
@@ -517,7 +538,13 @@ def spectral_leg(m, n):
         decomposition_fft(dx, bp, normalize=True, compute_stats=True)
         e4.record()
         synchronize()
-        out["cascade_decompose_%d_levels_ms" % nlev] = e3.elapsed_ms(e4)
+        ms = e3.elapsed_ms(e4)
+        out["cascade_decompose_%d_levels_ms" % nlev] = ms
+        # per pixel: field in 8 + half spectrum out 8; per level: spectrum read 8 + weights read 4 + level written 8,
+        # moments read 8, normalisation read + write 16
+        cas_bytes = (16.0 + nlev * 44.0) * m * n
+        out["cascade_alg_bytes"] = cas_bytes
+        out["cascade_hbm_frac"] = cas_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     except Exception as exc:  # the spectral leg never takes the headline down
         out["cascade_note"] = "%s: %s" % (type(exc).__name__, exc)
     try:
@@ -536,7 +563,14 @@ def spectral_leg(m, n):
             nonparam_match_empirical_cdf(d_fct, d_obs)
         e6.record()
         synchronize()
-        out["probmatch_cdf_ms"] = e5.elapsed_ms(e6) / reps
+        pm_ms = e5.elapsed_ms(e6) / reps
+        out["probmatch_cdf_ms"] = pm_ms
+        # bound by the rate of device-scope atomics, not by bytes: one atomic per wet pixel of the
+        # forecast in the histogram, one with a returned value in the scatter; the observation's go through LDS tables
+        wet = 0.25 * m * n
+        out["probmatch_bound"] = {"bound": "device-scope atomics", "atomics_per_call": 2.0 * wet,
+                                  "atomics_per_us": 2.0 * wet / (pm_ms * 1e3),
+                                  "min_bytes_per_call": 24.0 * m * n, "hbm_frac_of_min_bytes": 24.0 * m * n / (pm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     except Exception as exc:
         out["probmatch_note"] = "%s: %s" % (type(exc).__name__, exc)
     return out

@@ -7,7 +7,9 @@ tag, rnd, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
 src = os.path.join("gpurun_out", tag)
 dst = os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-for name in ("bench.json", "pytest_gpu.txt", "gaps.txt", "lk_timeline.txt", "fft_quick.json", "other_shapes.jsonl"):
+for name in ("bench.json", "pytest_gpu.txt", "gaps.txt", "lk_timeline.txt", "fft_quick.json", "other_shapes.jsonl",
+             "bench_members_world1.json", "bench_members_advection_world1.json", "bench_config5_world1.json",
+             "steps_quick.jsonl", "rng_quick.json", "ensemble_quick.txt", "cv2_probe.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (prefix, name)))
 for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
@@ -27,8 +29,19 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
     for rec in table.values():
         rec["avg_ns"] = rec["total_ns"] / max(rec["calls"], 1)
         rec["ns_per_step"] = rec["total_ns"] / STEPS_TRACED
+    # per-kernel counters of the PMC passes of the same command (tools/pmc_passes.sh summary), if taken
+    counters, counter_source = {}, None
+    summary = os.path.join(src, "pmc", "summary.csv")
+    if os.path.exists(summary):
+        for r in csv.DictReader(open(summary)):
+            k = r["kernel"].split("<")[0].strip()
+            if k in counters and r["counter"].replace("_sum", "") in counters[k]:
+                continue  # first instantiation listed wins (the one the bench step runs)
+            counters.setdefault(k, {})[r["counter"].replace("_sum", "")] = float(r["mean_per_launch"])
+        shutil.copy(summary, os.path.join(dst, "%s_pmc_kernels.csv" % prefix))
+        counter_source = "profiles/%s/%s_pmc_kernels.csv" % (rnd, prefix)
     json.dump({"source": "profiles/%s/%s_rocprofv3_kernel_stats.csv" % (rnd, prefix), "steps_traced": STEPS_TRACED,
-               "workload": "4096x4096",
+               "workload": "4096x4096", "counters": counters, "counter_source": counter_source,
                "note": "ns_per_step also spreads the input synthesis launches of semilag_fused over the steps; "
                        "LK kernels only run inside steps", "kernels": table},
               open(os.path.join("profiles", "kernel_stats_latest.json"), "w"), indent=1)
