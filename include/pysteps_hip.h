@@ -397,8 +397,9 @@ int psh_vectors_finish_host(const double *xy, const double *values, const unsign
  * time (pysteps/noise/fftgenerators.py:330-400, pysteps/cascade/decomposition.py:77-262,
  * pysteps/nowcasts/steps.py:1111,1189).  numpy's conventions: no scaling forward, 1/(m n) backward,
  * rfft2 keeps the n/2+1 non-negative frequencies of the last axis, irfft2 ignores the imaginary
- * parts of its zero and Nyquist bins.  Row-major device arrays; m and n powers of two in 2..8192
- * (PSH_EUNSUPPORTED otherwise: the Python shim hands those to numpy.fft).  Asynchronous on the
+ * parts of its zero and Nyquist bins.  Row-major device arrays; each side a power of two in 2..8192
+ * or any other length in 2..4096 (Bluestein's chirp-z identity inside the same kernels;
+ * PSH_EUNSUPPORTED beyond: the Python shim hands those to numpy.fft).  Asynchronous on the
  * library stream.  Complex numbers are (re, im) float64 pairs.
  *  psh_fft_rfft2_dev   in (m,n) f64           -> out (m,n/2+1) c128
  *  psh_fft_irfft2_dev  in (m,n/2+1) c128      -> out (m,n) f64        (in is left untouched)
@@ -408,7 +409,7 @@ int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_dev);
 int psh_fft_c2c2_dev(const void *in_dev, int m, int n, int inverse, void *out_dev);
 
 /* ---- spectral building blocks of the STEPS member loop (csrc/cascade.hip) -------- *
- * float64 device arrays, sizes as for the FFTs (powers of two in 2..8192).
+ * float64 device arrays, sizes as for the FFTs.
  *  psh_cascade_decompose_dev  pysteps/cascade/decomposition.py:77-262 (decomposition_fft), spatial in /
  *      spatial out, no mask: levels[k] = irfft2(rfft2(field [- mean]) * weights[k]), k < nlevels;
  *      weights (nlevels, m, n/2+1) = bp_filter["weights_2d"]; means / stds (np.mean, np.std) of the

@@ -178,7 +178,7 @@ extern "C" int psh_cascade_decompose_dev(const double *field_dev, const double *
     return fail(PSH_EINVAL, "cascade_decompose: the field mean is returned with the level statistics only");
   if (nlevels < 1 || nlevels > 64) return fail(PSH_EINVAL, "cascade_decompose: 1..64 cascade levels");
   if (!psh::fft_shape_supported(m, n))
-    return fail(PSH_EUNSUPPORTED, "cascade_decompose: (%d,%d) - both sizes must be powers of two in 2..8192", m, n);
+    return fail(PSH_EUNSUPPORTED, "cascade_decompose: (%d,%d) - sides: powers of two up to 8192 or any length up to 4096", m, n);
   psh::Context &c = psh::ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
@@ -262,7 +262,7 @@ extern "C" int psh_noise_filter_dev(const double *white_dev, const double *filte
   PSH_REQUIRE_INIT();
   if (!white_dev || !filter_dev || !out_dev) return fail(PSH_EINVAL, "noise_filter: NULL pointer");
   if (!psh::fft_shape_supported(m, n))
-    return fail(PSH_EUNSUPPORTED, "noise_filter: (%d,%d) - both sizes must be powers of two in 2..8192", m, n);
+    return fail(PSH_EUNSUPPORTED, "noise_filter: (%d,%d) - sides: powers of two up to 8192 or any length up to 4096", m, n);
   psh::Context &c = psh::ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));

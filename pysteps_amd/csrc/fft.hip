@@ -22,6 +22,14 @@
 //    twiddles exp(-2 pi i k / N) from a table computed once per length on the host in long double.
 // FP64 vector rate on MI355X equals FP32 (78 TFLOP/s); a 4096^2 rfft2 is ~0.5 GFLOP: the transform
 // is bound by HBM / LDS traffic, not arithmetic.
+//
+// Sides that are NOT powers of two (radar composites: 640 x 710, 1226 x 760 ...; the reference's FFT
+// object takes any shape, pysteps/utils/fft.py:20-37) go through Bluestein's chirp-z identity inside
+// the same kernels: with b_j = exp(i pi j^2 / N)
+//     X_k = conj(b_k) sum_j (x_j conj(b_j)) b_(k-j)
+// is a circular convolution of length M = 2^ceil(log2(2N-1)), i.e. two of the power-of-two LDS
+// transforms above with a pointwise product in between (the spectrum of the chirp is a table per
+// length, computed once on the device).  One side up to 4096 (M <= 8192 = the LDS transform limit).
 #include <cmath>
 #include <map>
 #include <vector>
@@ -143,48 +151,119 @@ __device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int lo
 
 __device__ __forceinline__ int bitrev(int i, int logn) { return static_cast<int>(__brev(static_cast<unsigned>(i)) >> (32 - logn)); }
 
+// ---- any length: Bluestein on top of fft_lds -------------------------------------------------------
+// Dft describes the 1-D transform of one axis: a plain power-of-two transform (chirp == nullptr) or a
+// chirp-z transform of length n inside LDS sequences of M = 1 << logm points.
+struct Dft {
+  int n;                  // transform length
+  int logm;               // LDS transform: log2 of n (plain) or of M (Bluestein)
+  const double2 *tw;      // twiddles of the LDS transform length
+  const double2 *chirp;   // b_j = exp(+i pi j^2 / n), j < n; nullptr: plain transform
+  const double2 *filter;  // FFT_M of the symmetric extension of b (b_j at j and M - j)
+};
+
+__device__ __forceinline__ double2 cmulc(double2 a, double2 w) {  // a * conj(w)
+  return make_double2(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+}
+
+// LDS slot of input sample i (callers store x_i there, pre-multiplied by pre_chirp; Bluestein
+// sequences must hold zeros at the slots of i = n .. M-1)
+__device__ __forceinline__ int dft_in_slot(const Dft &d, int i) { return lpad(bitrev(i, d.logm)); }
+template <bool INV>
+__device__ __forceinline__ double2 dft_pre(const Dft &d, int i, double2 v) {
+  if (!d.chirp) return v;
+  return INV ? cmul(v, d.chirp[i]) : cmulc(v, d.chirp[i]);
+}
+// output k of sequence c after dft_lds (unscaled: an inverse transform still wants 1 / n)
+template <bool INV>
+__device__ __forceinline__ double2 dft_out(const Dft &d, const double2 *z, int base, int k) {
+  const double2 v = z[base + lpad(k)];
+  if (!d.chirp) return v;
+  const double inv_m = 1.0 / static_cast<double>(1 << d.logm);
+  const double2 w = INV ? cmul(v, d.chirp[k]) : cmulc(v, d.chirp[k]);
+  return make_double2(w.x * inv_m, w.y * inv_m);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dft_lds(double2 *z, int pitch, int count, const Dft &d) {
+  if (!d.chirp) {
+    fft_lds<INV>(z, pitch, count, d.logm, d.tw);
+    return;
+  }
+  fft_lds<false>(z, pitch, count, d.logm, d.tw);
+  // spectrum x spectrum of the chirp, put back bit-reversed for the second transform: element k
+  // and element rev(k) trade places (one thread per pair)
+  const int M = 1 << d.logm;
+  for (int idx = threadIdx.x; idx < count * M; idx += blockDim.x) {
+    const int c = idx >> d.logm, k = idx & (M - 1);
+    const int r = bitrev(k, d.logm);
+    if (k > r) continue;
+    const int base = c * pitch;
+    double2 fk = d.filter[k], fr = d.filter[r];
+    if (INV) {  // the chirp of the inverse transform is the conjugate one; its extension is symmetric
+      fk.y = -fk.y;
+      fr.y = -fr.y;
+    }
+    const double2 vk = cmul(z[base + lpad(k)], fk);
+    if (k == r) {
+      z[base + lpad(k)] = vk;
+    } else {
+      const double2 vr = cmul(z[base + lpad(r)], fr);
+      z[base + lpad(k)] = vr;
+      z[base + lpad(r)] = vk;
+    }
+  }
+  __syncthreads();
+  fft_lds<true>(z, pitch, count, d.logm, d.tw);
+}
+
 // ---- real rows -> half spectra: two rows per workgroup -----------------------------------------
-__global__ __launch_bounds__(kFftThreads) void fft_rows_r2c(const double *__restrict__ x, int m, int n, int logn,
-                                                            const double2 *__restrict__ tw,
+__global__ __launch_bounds__(kFftThreads) void fft_rows_r2c(const double *__restrict__ x, int m, Dft d,
                                                             double2 *__restrict__ out) {
   extern __shared__ double2 z[];
+  const int n = d.n, len = 1 << d.logm;
   const int ra = 2 * blockIdx.x, rb = min(ra + 1, m - 1);
   const int nc = n / 2 + 1;
   const double *xa = x + static_cast<size_t>(ra) * n, *xb = x + static_cast<size_t>(rb) * n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) z[lpad(bitrev(i, logn))] = make_double2(xa[i], xb[i]);
+  for (int i = threadIdx.x; i < len; i += blockDim.x)
+    z[dft_in_slot(d, i)] = i < n ? dft_pre<false>(d, i, make_double2(xa[i], xb[i])) : make_double2(0.0, 0.0);
   __syncthreads();
-  fft_lds<false>(z, 0, 1, logn, tw);
+  dft_lds<false>(z, 0, 1, d);
   double2 *oa = out + static_cast<size_t>(ra) * nc, *ob = out + static_cast<size_t>(rb) * nc;
   for (int k = threadIdx.x; k < nc; k += blockDim.x) {
-    const double2 zk = z[lpad(k)], zn = z[lpad((n - k) & (n - 1))];
+    const double2 zk = dft_out<false>(d, z, 0, k), zn = dft_out<false>(d, z, 0, k == 0 ? 0 : n - k);
     oa[k] = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
     if (ra + 1 < m) ob[k] = make_double2(0.5 * (zk.y + zn.y), -0.5 * (zk.x - zn.x));
   }
 }
 
 // ---- half spectra -> real rows (numpy irfft: the imaginary parts of bins 0 and n/2 are ignored) --
-__global__ __launch_bounds__(kFftThreads) void fft_rows_c2r(const double2 *__restrict__ in, int m, int n, int logn,
-                                                            const double2 *__restrict__ tw, double scale,
+__global__ __launch_bounds__(kFftThreads) void fft_rows_c2r(const double2 *__restrict__ in, int m, Dft d, double scale,
                                                             double *__restrict__ out) {
   extern __shared__ double2 z[];
+  const int n = d.n, len = 1 << d.logm;
   const int ra = 2 * blockIdx.x, rb = min(ra + 1, m - 1);
-  const int nc = n / 2 + 1, half = n / 2;
+  const int nc = n / 2 + 1;
+  const int nyq = (n & 1) ? -1 : n / 2;  // odd lengths have no Nyquist bin
   const double2 *ia = in + static_cast<size_t>(ra) * nc, *ib = in + static_cast<size_t>(rb) * nc;
+  if (d.chirp) {  // the slots beyond n stay zero
+    for (int i = n + threadIdx.x; i < len; i += blockDim.x) z[dft_in_slot(d, i)] = make_double2(0.0, 0.0);
+  }
   for (int k = threadIdx.x; k < nc; k += blockDim.x) {
     double2 a = ia[k], b = ib[k];
-    if (k == 0 || k == half) {
+    if (k == 0 || k == nyq) {
       a.y = 0.0;
       b.y = 0.0;
     }
     // Z[k] = A[k] + i B[k];  Z[n-k] = conj(A[k]) + i conj(B[k])
-    z[lpad(bitrev(k, logn))] = make_double2(a.x - b.y, a.y + b.x);
-    if (k != 0 && k != half) z[lpad(bitrev(n - k, logn))] = make_double2(a.x + b.y, b.x - a.y);
+    z[dft_in_slot(d, k)] = dft_pre<true>(d, k, make_double2(a.x - b.y, a.y + b.x));
+    if (k != 0 && k != nyq) z[dft_in_slot(d, n - k)] = dft_pre<true>(d, n - k, make_double2(a.x + b.y, b.x - a.y));
   }
   __syncthreads();
-  fft_lds<true>(z, 0, 1, logn, tw);
+  dft_lds<true>(z, 0, 1, d);
   double *oa = out + static_cast<size_t>(ra) * n, *ob = out + static_cast<size_t>(rb) * n;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const double2 v = z[lpad(i)];
+    const double2 v = dft_out<true>(d, z, 0, i);
     oa[i] = v.x * scale;
     if (ra + 1 < m) ob[i] = v.y * scale;
   }
@@ -192,22 +271,23 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_c2r(const double2 *__res
 
 // ---- complex rows: one row per workgroup ---------------------------------------------------------
 template <bool INV>
-__global__ __launch_bounds__(kFftThreads) void fft_rows_c2c(const double2 *__restrict__ in, int n, int logn,
-                                                            const double2 *__restrict__ tw,
+__global__ __launch_bounds__(kFftThreads) void fft_rows_c2c(const double2 *__restrict__ in, Dft d,
                                                             double2 *__restrict__ out) {
   extern __shared__ double2 z[];
+  const int n = d.n, len = 1 << d.logm;
   const double2 *src = in + static_cast<size_t>(blockIdx.x) * n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) z[lpad(bitrev(i, logn))] = src[i];
+  for (int i = threadIdx.x; i < len; i += blockDim.x)
+    z[dft_in_slot(d, i)] = i < n ? dft_pre<INV>(d, i, src[i]) : make_double2(0.0, 0.0);
   __syncthreads();
-  fft_lds<INV>(z, 0, 1, logn, tw);
+  dft_lds<INV>(z, 0, 1, d);
   double2 *dst = out + static_cast<size_t>(blockIdx.x) * n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = z[lpad(i)];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = dft_out<INV>(d, z, 0, i);
 }
 
 // ---- columns of an (m, nc) complex array: `cols` adjacent columns per workgroup ---------------------
 template <bool INV>
-__global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__restrict__ in, int m, int nc, int logm,
-                                                            int cols, const double2 *__restrict__ tw, double scale,
+__global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__restrict__ in, Dft d, int nc,
+                                                            int cols, double scale,
                                                             double2 *__restrict__ out, int groups,
                                                             int groups_per_xcd, const double *__restrict__ weights) {
   extern __shared__ double2 z[];
@@ -215,28 +295,30 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__res
   const int b = blockIdx.x;
   const int g = (b % kNumXcd) * groups_per_xcd + b / kNumXcd;
   if (g >= groups) return;
+  const int m = d.n, len = 1 << d.logm;
   const int c0 = g * cols;
   const int live = min(cols, nc - c0);
-  const int pitch = lds_elems(m);
-  for (int idx = threadIdx.x; idx < m * cols; idx += blockDim.x) {
+  const int pitch = lds_elems(len);
+  for (int idx = threadIdx.x; idx < len * cols; idx += blockDim.x) {
     const int r = idx / cols, c = idx - r * cols;
     double2 v = make_double2(0.0, 0.0);
-    if (c < live) {
+    if (c < live && r < m) {
       v = in[static_cast<size_t>(r) * nc + c0 + c];
       if (weights) {  // spectrum x real filter (band-pass weights, noise filter) applied on the way in
         const double w = weights[static_cast<size_t>(r) * nc + c0 + c];
         v.x *= w;
         v.y *= w;
       }
+      v = dft_pre<INV>(d, r, v);
     }
-    z[c * pitch + lpad(bitrev(r, logm))] = v;
+    z[c * pitch + dft_in_slot(d, r)] = v;
   }
   __syncthreads();
-  fft_lds<INV>(z, pitch, cols, logm, tw);
+  dft_lds<INV>(z, pitch, cols, d);
   for (int idx = threadIdx.x; idx < m * cols; idx += blockDim.x) {
     const int r = idx / cols, c = idx - r * cols;
     if (c < live) {
-      const double2 v = z[c * pitch + lpad(r)];
+      const double2 v = dft_out<INV>(d, z, c * pitch, r);
       out[static_cast<size_t>(r) * nc + c0 + c] = make_double2(v.x * scale, v.y * scale);
     }
   }
@@ -289,30 +371,87 @@ int allow_lds(K kernel, size_t bytes) {
   return PSH_OK;
 }
 
-int check_shape(const char *who, int m, int n, int *logm, int *logn) {
-  *logm = ilog2_exact(m);
-  *logn = ilog2_exact(n);
-  if (*logm < 1 || *logn < 1 || *logm > kFftMaxLog || *logn > kFftMaxLog)
-    return fail(PSH_EUNSUPPORTED, "%s: (%d,%d) - both sizes must be powers of two in 2..%d", who, m, n, 1 << kFftMaxLog);
+constexpr int kBluesteinMax = 1 << (kFftMaxLog - 1);  // 2 n - 1 <= 8192
+
+// chirp b_j = exp(i pi j^2 / n) and the spectrum of its symmetric extension, per length
+struct ChirpTables {
+  double2 *chirp, *filter;
+};
+std::map<int, ChirpTables> &chirp_cache() {
+  static std::map<int, ChirpTables> cache;
+  return cache;
+}
+
+// the 1-D transform of one axis (lock held by the callers)
+int make_dft(const char *who, int n, Dft *d) {
+  d->n = n;
+  d->chirp = d->filter = nullptr;
+  const int lg = ilog2_exact(n);
+  if (lg >= 1 && lg <= kFftMaxLog) {
+    d->logm = lg;
+    return twiddles(n, &d->tw);
+  }
+  if (n < 2 || n > kBluesteinMax)
+    return fail(PSH_EUNSUPPORTED, "%s: side %d - powers of two up to %d, other lengths in 2..%d", who, n, 1 << kFftMaxLog,
+                kBluesteinMax);
+  int logm = 1;
+  while ((1 << logm) < 2 * n - 1) ++logm;
+  const int M = 1 << logm;
+  d->logm = logm;
+  if (int rc = twiddles(M, &d->tw)) return rc;
+  std::map<int, ChirpTables> &cache = chirp_cache();
+  auto it = cache.find(n);
+  if (it == cache.end()) {
+    // j^2 is reduced modulo 2 n exactly before the angle is formed: b_j has period 2 n in j^2
+    std::vector<double2> b(static_cast<size_t>(n)), ext(static_cast<size_t>(M), make_double2(0.0, 0.0));
+    const long double pi = 3.14159265358979323846264338327950288L;
+    for (int j = 0; j < n; ++j) {
+      const long long q = (static_cast<long long>(j) * j) % (2LL * n);
+      const long double a = pi * static_cast<long double>(q) / static_cast<long double>(n);
+      b[j] = make_double2(static_cast<double>(cosl(a)), static_cast<double>(sinl(a)));
+      ext[j] = b[j];
+      if (j) ext[M - j] = b[j];
+    }
+    ChirpTables t{nullptr, nullptr};
+    PSH_HIP(hipMalloc(reinterpret_cast<void **>(&t.chirp), b.size() * sizeof(double2)));
+    PSH_HIP(hipMalloc(reinterpret_cast<void **>(&t.filter), ext.size() * sizeof(double2)));
+    PSH_HIP(hipMemcpy(t.chirp, b.data(), b.size() * sizeof(double2), hipMemcpyHostToDevice));
+    PSH_HIP(hipMemcpy(t.filter, ext.data(), ext.size() * sizeof(double2), hipMemcpyHostToDevice));
+    // its spectrum: one plain row transform of length M, in place
+    Dft plain{M, logm, d->tw, nullptr, nullptr};
+    const size_t lds = static_cast<size_t>(lds_elems(M)) * sizeof(double2);
+    if (int rc = allow_lds(fft_rows_c2c<false>, lds)) return rc;
+    hipStream_t stream = ctx().stream;
+    hipLaunchKernelGGL(fft_rows_c2c<false>, dim3(1), dim3(fft_threads(M)), lds, stream, t.filter, plain, t.filter);
+    PSH_HIP(hipGetLastError());
+    PSH_HIP(hipStreamSynchronize(stream));
+    it = cache.emplace(n, t).first;
+  }
+  d->chirp = it->second.chirp;
+  d->filter = it->second.filter;
   return PSH_OK;
 }
 
-int launch_cols(bool inverse, const double2 *in, int m, int nc, int logm, double scale, double2 *out,
+int check_shape(const char *who, int m, int n, Dft *rows, Dft *cols) {
+  if (int rc = make_dft(who, n, rows)) return rc;
+  return make_dft(who, m, cols);
+}
+
+int launch_cols(bool inverse, const double2 *in, const Dft &d, int nc, double scale, double2 *out,
                 hipStream_t stream, const double *weights = nullptr) {
-  const double2 *tw = nullptr;
-  if (int rc = twiddles(m, &tw)) return rc;
-  const int cols = m <= 4096 ? 2 : 1;
+  const int len = 1 << d.logm;
+  const int cols = len <= 4096 ? 2 : 1;
   const int groups = (nc + cols - 1) / cols;
   const int gpx = (groups + kNumXcd - 1) / kNumXcd;
-  const size_t lds = static_cast<size_t>(cols) * lds_elems(m) * sizeof(double2);
+  const size_t lds = static_cast<size_t>(cols) * lds_elems(len) * sizeof(double2);
   if (inverse) {
     if (int rc = allow_lds(fft_cols_c2c<true>, lds)) return rc;
-    hipLaunchKernelGGL(fft_cols_c2c<true>, dim3(gpx * kNumXcd), dim3(fft_threads(cols * m / 2)), lds, stream, in, m, nc, logm, cols,
-                       tw, scale, out, groups, gpx, weights);
+    hipLaunchKernelGGL(fft_cols_c2c<true>, dim3(gpx * kNumXcd), dim3(fft_threads(cols * len / 2)), lds, stream, in, d, nc, cols,
+                       scale, out, groups, gpx, weights);
   } else {
     if (int rc = allow_lds(fft_cols_c2c<false>, lds)) return rc;
-    hipLaunchKernelGGL(fft_cols_c2c<false>, dim3(gpx * kNumXcd), dim3(fft_threads(cols * m / 2)), lds, stream, in, m, nc, logm, cols,
-                       tw, scale, out, groups, gpx, weights);
+    hipLaunchKernelGGL(fft_cols_c2c<false>, dim3(gpx * kNumXcd), dim3(fft_threads(cols * len / 2)), lds, stream, in, d, nc, cols,
+                       scale, out, groups, gpx, weights);
   }
   PSH_HIP(hipGetLastError());
   return PSH_OK;
@@ -327,26 +466,29 @@ using psh::fail;
 extern "C" int psh_fft_rfft2_dev(const double *in_dev, int m, int n, void *out_dev) {
   PSH_REQUIRE_INIT();
   if (!in_dev || !out_dev) return fail(PSH_EINVAL, "rfft2: NULL pointer");
-  int logm, logn;
-  if (int rc = psh::check_shape("rfft2", m, n, &logm, &logn)) return rc;
   psh::Context &c = psh::ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  const double2 *tw = nullptr;
-  if (int rc = psh::twiddles(n, &tw)) return rc;
-  const size_t lds = static_cast<size_t>(psh::lds_elems(n)) * sizeof(double2);
+  psh::Dft rows, cols;
+  if (int rc = psh::check_shape("rfft2", m, n, &rows, &cols)) return rc;
+  const int len = 1 << rows.logm;
+  const size_t lds = static_cast<size_t>(psh::lds_elems(len)) * sizeof(double2);
   if (int rc = psh::allow_lds(psh::fft_rows_r2c, lds)) return rc;
   double2 *out = static_cast<double2 *>(out_dev);
-  hipLaunchKernelGGL(psh::fft_rows_r2c, dim3((m + 1) / 2), dim3(psh::fft_threads(n)), lds, c.stream, in_dev, m, n, logn, tw,
-                     out);
+  hipLaunchKernelGGL(psh::fft_rows_r2c, dim3((m + 1) / 2), dim3(psh::fft_threads(len)), lds, c.stream, in_dev, m, rows, out);
   PSH_HIP(hipGetLastError());
-  return psh::launch_cols(false, out, m, n / 2 + 1, logm, 1.0, out, c.stream);
+  return psh::launch_cols(false, out, cols, n / 2 + 1, 1.0, out, c.stream);
 }
 
 namespace psh {
 void fft_release() {  // psh_shutdown: the tables belong to the device that is being released
   for (auto &kv : twiddle_cache()) (void)hipFree(kv.second);
   twiddle_cache().clear();
+  for (auto &kv : chirp_cache()) {
+    (void)hipFree(kv.second.chirp);
+    (void)hipFree(kv.second.filter);
+  }
+  chirp_cache().clear();
 }
 }  // namespace psh
 
@@ -355,26 +497,28 @@ void fft_release() {  // psh_shutdown: the tables belong to the device that is b
 namespace psh {
 int fft_irfft2_weighted(const void *spec_dev, const double *weights_dev, int m, int n, double *out_dev,
                         void *scratch_dev) {
-  int logm, logn;
-  if (int rc = check_shape("irfft2", m, n, &logm, &logn)) return rc;
+  Dft rows, cols;
+  if (int rc = check_shape("irfft2", m, n, &rows, &cols)) return rc;
   Context &c = ctx();
   const int nc = n / 2 + 1;
-  if (int rc = launch_cols(true, static_cast<const double2 *>(spec_dev), m, nc, logm, 1.0,
+  if (int rc = launch_cols(true, static_cast<const double2 *>(spec_dev), cols, nc, 1.0,
                            static_cast<double2 *>(scratch_dev), c.stream, weights_dev))
     return rc;
-  const double2 *tw = nullptr;
-  if (int rc = twiddles(n, &tw)) return rc;
-  const size_t lds = static_cast<size_t>(lds_elems(n)) * sizeof(double2);
+  const int len = 1 << rows.logm;
+  const size_t lds = static_cast<size_t>(lds_elems(len)) * sizeof(double2);
   if (int rc = allow_lds(fft_rows_c2r, lds)) return rc;
-  hipLaunchKernelGGL(fft_rows_c2r, dim3((m + 1) / 2), dim3(fft_threads(n)), lds, c.stream,
-                     static_cast<const double2 *>(scratch_dev), m, n, logn, tw,
+  hipLaunchKernelGGL(fft_rows_c2r, dim3((m + 1) / 2), dim3(fft_threads(len)), lds, c.stream,
+                     static_cast<const double2 *>(scratch_dev), m, rows,
                      1.0 / (static_cast<double>(m) * static_cast<double>(n)), out_dev);
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }
 bool fft_shape_supported(int m, int n) {
-  const int lm = ilog2_exact(m), ln = ilog2_exact(n);
-  return lm >= 1 && ln >= 1 && lm <= kFftMaxLog && ln <= kFftMaxLog;
+  auto side = [](int v) {
+    const int l = ilog2_exact(v);
+    return (l >= 1 && l <= kFftMaxLog) || (v >= 2 && v <= kBluesteinMax);
+  };
+  return side(m) && side(n);
 }
 }  // namespace psh
 
@@ -383,8 +527,8 @@ bool fft_shape_supported(int m, int n) {
 extern "C" int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_dev) {
   PSH_REQUIRE_INIT();
   if (!in_dev || !out_dev) return fail(PSH_EINVAL, "irfft2: NULL pointer");
-  int logm, logn;
-  if (int rc = psh::check_shape("irfft2", m, n, &logm, &logn)) return rc;
+  if (!psh::fft_shape_supported(m, n))
+    return fail(PSH_EUNSUPPORTED, "irfft2: (%d,%d) - sides: powers of two up to 8192 or any length up to 4096", m, n);
   psh::Context &c = psh::ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
@@ -399,24 +543,23 @@ extern "C" int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_
 extern "C" int psh_fft_c2c2_dev(const void *in_dev, int m, int n, int inverse, void *out_dev) {
   PSH_REQUIRE_INIT();
   if (!in_dev || !out_dev) return fail(PSH_EINVAL, "fft2: NULL pointer");
-  int logm, logn;
-  if (int rc = psh::check_shape("fft2", m, n, &logm, &logn)) return rc;
   psh::Context &c = psh::ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  const double2 *tw = nullptr;
-  if (int rc = psh::twiddles(n, &tw)) return rc;
-  const size_t lds = static_cast<size_t>(psh::lds_elems(n)) * sizeof(double2);
+  psh::Dft rows, cols;
+  if (int rc = psh::check_shape("fft2", m, n, &rows, &cols)) return rc;
+  const int len = 1 << rows.logm;
+  const size_t lds = static_cast<size_t>(psh::lds_elems(len)) * sizeof(double2);
   const double2 *in = static_cast<const double2 *>(in_dev);
   double2 *out = static_cast<double2 *>(out_dev);
   if (inverse) {
     if (int rc = psh::allow_lds(psh::fft_rows_c2c<true>, lds)) return rc;
-    hipLaunchKernelGGL(psh::fft_rows_c2c<true>, dim3(m), dim3(psh::fft_threads(n)), lds, c.stream, in, n, logn, tw, out);
+    hipLaunchKernelGGL(psh::fft_rows_c2c<true>, dim3(m), dim3(psh::fft_threads(len)), lds, c.stream, in, rows, out);
   } else {
     if (int rc = psh::allow_lds(psh::fft_rows_c2c<false>, lds)) return rc;
-    hipLaunchKernelGGL(psh::fft_rows_c2c<false>, dim3(m), dim3(psh::fft_threads(n)), lds, c.stream, in, n, logn, tw, out);
+    hipLaunchKernelGGL(psh::fft_rows_c2c<false>, dim3(m), dim3(psh::fft_threads(len)), lds, c.stream, in, rows, out);
   }
   PSH_HIP(hipGetLastError());
   const double scale = inverse ? 1.0 / (static_cast<double>(m) * static_cast<double>(n)) : 1.0;
-  return psh::launch_cols(inverse != 0, out, m, n, logm, scale, out, c.stream);
+  return psh::launch_cols(inverse != 0, out, cols, n, scale, out, c.stream);
 }

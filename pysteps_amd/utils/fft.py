@@ -11,8 +11,10 @@ given), which the noise generators (pysteps/noise/fftgenerators.py), the cascade
 * :class:`~pysteps_amd.device.DeviceArray` in -> DeviceArray out: nothing leaves HBM.
 * Single-precision input gives single-precision output, as numpy >= 2.0 does (``rfft2`` of float32
   is complex64): the transform itself always runs in float64 and the result is rounded once.
-* Shapes the kernels do not take (a side that is not a power of two in 2..8192, anything but two
-  dimensions) are handed to ``numpy.fft``, the reference's default method - same results, CPU speed.
+* Any side length is taken: powers of two up to 8192 directly, every other length up to 4096
+  through Bluestein's chirp-z identity inside the same kernels (radar composites are 640 x 710,
+  1226 x 760, ...).  What is left - longer sides, anything but two dimensions - is handed to
+  ``numpy.fft``, the reference's default method: same results, CPU speed.
 """
 
 from types import SimpleNamespace
@@ -22,12 +24,18 @@ import numpy as np
 from .. import _lib
 from ..device import DeviceArray
 
-MAX_SIDE = 8192
+MAX_SIDE = 8192  # powers of two
+MAX_ANY_SIDE = 4096  # other lengths: the chirp-z transform needs 2 n - 1 <= 8192 points of LDS
 
 
 def supported_shape(shape):
-    """True if the HIP kernels transform this 2-d shape (both sides powers of two in 2..8192)."""
-    return len(shape) == 2 and all(2 <= int(s) <= MAX_SIDE and (int(s) & (int(s) - 1)) == 0 for s in shape)
+    """True if the HIP kernels transform this 2-d shape: each side a power of two in 2..8192 or any
+    length in 2..4096."""
+    def side(s):
+        s = int(s)
+        return 2 <= s <= MAX_ANY_SIDE or (s <= MAX_SIDE and s >= 2 and (s & (s - 1)) == 0)
+
+    return len(shape) == 2 and all(side(s) for s in shape)
 
 
 def _to_device(x, dtype):

@@ -19,7 +19,7 @@ def _field(shape, seed):
     return synth.rain_field_db(*shape, seed=seed).astype(np.float64)
 
 
-@pytest.mark.parametrize("shape,nlevels", [((256, 256), 6), ((128, 512), 4), ((1024, 512), 8)])
+@pytest.mark.parametrize("shape,nlevels", [((256, 256), 6), ((128, 512), 4), ((1024, 512), 8), ((200, 260), 5), ((640, 710), 6)])
 @pytest.mark.parametrize("normalize,subtract_mean", [(True, False), (False, False), (True, True)])
 def test_decomposition_matches_the_reference(ref_pysteps, shape, nlevels, normalize, subtract_mean):
     from pysteps.cascade.bandpass_filters import filter_gaussian
@@ -105,7 +105,7 @@ def test_resident_cascade_and_option_fallbacks(ref_pysteps):
         decomposition_fft(bad, bp)
 
 
-@pytest.mark.parametrize("shape", [(256, 256), (512, 1024)])
+@pytest.mark.parametrize("shape", [(256, 256), (512, 1024), (300, 250)])
 def test_noise_generator_matches_the_reference(ref_pysteps, shape):
     from pysteps.noise import fftgenerators as ref
 

@@ -15,13 +15,27 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-12
 SHAPES = [(2, 2), (2, 8), (4, 4), (16, 2), (8, 32), (64, 64), (32, 128), (256, 512), (1024, 256), (2048, 2048)]
+# sides that are not powers of two (Bluestein inside the same kernels): odd and even lengths, primes,
+# one plain and one chirp-z axis, and the radar composites the reference's examples use
+ANY_SHAPES = [(3, 5), (7, 2), (2, 7), (6, 10), (17, 31), (100, 64), (64, 100), (127, 257), (640, 710), (1226, 760),
+              (4096, 1000), (3000, 2048), (4095, 6)]
 
 
 def _c(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-@pytest.mark.parametrize("shape", SHAPES)
+def test_irfft2_of_non_hermitian_spectra_any_length():
+    """odd lengths have no Nyquist bin: numpy drops the imaginary part of bin 0 only"""
+    from pysteps_amd.utils.fft import get_hip
+
+    rng = np.random.default_rng(9)
+    for shape in ((33, 45), (40, 54), (45, 64)):
+        X = rng.standard_normal((shape[0], shape[1] // 2 + 1)) + 1j * rng.standard_normal((shape[0], shape[1] // 2 + 1))
+        assert _c(get_hip(shape).irfft2(X), np.fft.irfft2(X, s=shape)) < TOL
+
+
+@pytest.mark.parametrize("shape", SHAPES + ANY_SHAPES)
 def test_transforms_match_numpy(shape):
     from pysteps_amd.utils.fft import get_hip
 
@@ -122,10 +136,13 @@ def test_reference_noise_and_cascade_callers(ref_pysteps):
         assert np.allclose(d_h["means"], d_r["means"], rtol=1e-10, atol=1e-12)
         assert np.allclose(d_h["stds"], d_r["stds"], rtol=1e-10)
     assert _c(recompose_fft(d_h), recompose_fft(d_r)) < 1e-10
-    # other shapes go to numpy.fft unchanged
+    # sides that are not powers of two run on the device too (chirp-z), longer ones go to numpy.fft unchanged
     odd = utils.get_method("hip", shape=(200, 200))
     y = np.random.default_rng(1).standard_normal((200, 200))
-    assert np.array_equal(odd.rfft2(y), np.fft.rfft2(y))
+    assert _c(odd.rfft2(y), np.fft.rfft2(y)) < TOL and not np.array_equal(odd.rfft2(y), np.fft.rfft2(y))
+    long_side = utils.get_method("hip", shape=(5000, 6))
+    y = np.random.default_rng(2).standard_normal((5000, 6))
+    assert np.array_equal(long_side.rfft2(y), np.fft.rfft2(y))
 
 
 def test_nowcasts_steps_with_the_hip_fft_method(ref_pysteps):

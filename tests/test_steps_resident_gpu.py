@@ -136,6 +136,7 @@ def _steps_inputs(m, n):
 
 CONFIGS = {
     "incremental_cdf": dict(mask_method="incremental", probmatching_method="cdf"),
+    "composite_shape": dict(mask_method="incremental", probmatching_method="cdf", shape=(150, 190)),  # not powers of two
     "obs_none": dict(mask_method="obs", probmatching_method=None),
     "nomask_mean": dict(mask_method=None, probmatching_method="mean"),
     "ar1_8levels": dict(mask_method="incremental", probmatching_method="cdf", ar_order=1, n_cascade_levels=8),
@@ -157,7 +158,7 @@ def test_update_beside_the_reference_update(ref_pysteps, name):
     register.register()
     cfg = dict(CONFIGS[name])
     ar_order = cfg.pop("ar_order", 2)
-    m = n = 128
+    m, n = cfg.pop("shape", (128, 128))
     frames, V = _steps_inputs(m, n)
     frames = frames[-(ar_order + 1):]
     if name == "obs_none":
