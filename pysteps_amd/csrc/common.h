@@ -176,6 +176,12 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
                         float *points_dev, int *npoints_dev, int (*before_walk)(void *) = nullptr,
                         void *before_walk_arg = nullptr, int *walk_stats_host = nullptr);
 
+// the three frame passes of dense Lucas-Kanade (lk.hip) on a stream of the caller's choice, with the
+// caller's workspace of lk_prepare_ws_bytes(m, n, f64) bytes (lock held)
+size_t lk_prepare_ws_bytes(int m, int n, bool f64);
+int lk_prepare_on(hipStream_t stream, void *ws, const void *frame_dev, bool f64, int m, int n, int size_opening,
+                  int buffer_mask, float *clean_dev, unsigned char *track_u8_dev, unsigned char *feature_u8_dev,
+                  float *stats_dev);
 int lk_pyramids_beside(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m, int n, int win_w,
                        int win_h, int max_level, void **handle_out);
 

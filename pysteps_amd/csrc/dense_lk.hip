@@ -57,7 +57,14 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   };
 
   // ---- per frame: cleaning + uint8 renderings (lucaskanade.py:213-224) -----------------
+  // Only the FIRST frame is prepared up front.  Frame t + 1 is cleaned and rendered on the side stream
+  // beside the corner chain of frame t (which needs nothing of it): its passes stream the frame
+  // through HBM while the Shi-Tomasi response is bound by the VALUs and the ordered walk is a single
+  // workgroup; the pyramids of the pair follow on the same side stream, the tracker joins both.
   std::vector<DevBlock> clean(nframes), trk(nframes), feat(nframes), stats(nframes);
+  const bool f64 = prm->frames_f64 != 0;
+  const size_t frame_bytes = plane * (f64 ? sizeof(double) : sizeof(float));
+  auto frame_ptr = [&](int t) { return reinterpret_cast<const char *>(frames_dev) + static_cast<size_t>(t) * frame_bytes; };
   for (int t = 0; t < nframes; ++t) {
     const bool want_feat = t < nframes - 1;
     if (int rc = clean[t].alloc(plane * sizeof(float))) return rc;
@@ -65,16 +72,17 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
     if (want_feat)
       if (int rc = feat[t].alloc(plane)) return rc;
     if (int rc = stats[t].alloc(8 * sizeof(float))) return rc;
-    const int rc = prm->frames_f64
-                       ? psh_lk_prepare_f64_dev(reinterpret_cast<const double *>(frames_dev) + static_cast<size_t>(t) * plane,
-                                                m, n, prm->size_opening, prm->buffer_mask, clean[t].as<float>(),
-                                                trk[t].as<unsigned char>(),
-                                                want_feat ? feat[t].as<unsigned char>() : nullptr, stats[t].as<float>())
-                       : psh_lk_prepare_dev(frames_dev + static_cast<size_t>(t) * plane, m, n, prm->size_opening,
-                                            prm->buffer_mask, clean[t].as<float>(), trk[t].as<unsigned char>(),
-                                            want_feat ? feat[t].as<unsigned char>() : nullptr, stats[t].as<float>());
-    if (rc) return rc;
   }
+  DevBlock ws_main, ws_side;  // allocated before any fork, released after the last join
+  if (int rc = ws_main.alloc(psh::lk_prepare_ws_bytes(m, n, f64))) return rc;
+  if (nframes > 1)
+    if (int rc = ws_side.alloc(psh::lk_prepare_ws_bytes(m, n, f64))) return rc;
+  auto prepare = [&](int t, hipStream_t stream, void *ws) {
+    return psh::lk_prepare_on(stream, ws, frame_ptr(t), f64, m, n, prm->size_opening, prm->buffer_mask, clean[t].as<float>(),
+                              trk[t].as<unsigned char>(), t < nframes - 1 ? feat[t].as<unsigned char>() : nullptr,
+                              stats[t].as<float>());
+  };
+  if (int rc = prepare(0, c.stream, ws_main.p)) return rc;
 
   // ---- per frame pair: features, tracking, pooling (:207-242) ---------------------------
   // Everything stays on the device: the corners are ordered and accepted by corner_order
@@ -104,9 +112,14 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   int *d_npts = corners.as<int>();
   float *d_pts = reinterpret_cast<float *>(corners.as<char>() + 256);
   for (int t = 0; t + 1 < nframes; ++t) {
-    // the pyramids only need the uint8 renderings: they are forked onto the side stream right in
-    // front of the ordered corner walk (a single workgroup - the other 255 CUs are free) and joined
-    // before the tracker, which needs both
+    // side stream: the next frame's passes, then the pyramids of the pair (they only need the uint8
+    // renderings); main stream: the corner chain of this frame; joined before the tracker
+    hipStream_t side = nullptr;
+    if (int rc = psh::side_begin(&side)) return rc;
+    if (int rc = prepare(t + 1, side, ws_side.p)) {
+      (void)psh::side_end();
+      return rc;
+    }
     struct Fork {
       const unsigned char *prev, *next;
       int m, n, win_w, win_h, max_level;
@@ -120,10 +133,11 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
       return f->rc;
     };
     int walk_stats[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)build_pyramids(&fork);  // queued behind the frame passes on the side stream
     const int rc1 = psh::lk_corners_resident(feat[t].as<unsigned char>(), clean[t].as<float>(),
                                              stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
                                              prm->quality_level, prm->min_distance, prm->max_corners, d_pts, d_npts,
-                                             build_pyramids, &fork, trace ? walk_stats : nullptr);
+                                             nullptr, nullptr, trace ? walk_stats : nullptr);
     const int rcj = psh::side_end();
     void *pyr = fork.pyr;
     if (trace)

@@ -1518,6 +1518,62 @@ static int ensure_lk_ws(size_t nbytes, void **ptr) {
   return PSH_OK;
 }
 
+// the three frame passes (cleaning, opening, uint8 renderings) of one frame on `stream` with the
+// caller's workspace: psh_lk_prepare_dev / _f64_dev on the library stream, dense_lk.hip for the NEXT
+// frame of a pair on the side stream beside the corner chain of the current one
+size_t lk_prepare_ws_bytes(int m, int n, bool f64) {
+  const size_t npx = static_cast<size_t>(m) * n;
+  if (f64) {
+    const dim3 ogrid((n + kOpenColsW - 1) / kOpenColsW, (m + kOpenRowsWG - 1) / kOpenRowsWG);
+    return (npx + 2 * static_cast<size_t>(kRedBlocks) + 3 * static_cast<size_t>(ogrid.x * ogrid.y) + 8) * sizeof(double);
+  }
+  const dim3 ogrid = lk_open_grid(m, n);
+  return sizeof(float) * (2 * static_cast<size_t>(kRedBlocks) + 3 * static_cast<size_t>(ogrid.x * ogrid.y));
+}
+
+int lk_prepare_on(hipStream_t stream, void *ws, const void *frame_dev, bool f64, int m, int n, int size_opening,
+                  int buffer_mask, float *clean_dev, unsigned char *track_u8_dev, unsigned char *feature_u8_dev,
+                  float *stats_dev) {
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_prepare: invalid shape (%d,%d)", m, n);
+  if (!frame_dev || !clean_dev || !track_u8_dev || !stats_dev || !ws) return fail(PSH_EINVAL, "lk_prepare: NULL pointer");
+  if (size_opening != 0 && size_opening != 3)
+    return fail(PSH_EUNSUPPORTED, "lk_prepare: size_opening %d not implemented (0 or 3)", size_opening);
+  const size_t npx = static_cast<size_t>(m) * n;
+  if (!f64) {
+    const float *frame = static_cast<const float *>(frame_dev);
+    const dim3 ogrid = lk_open_grid(m, n);
+    const int nb_open = ogrid.x * ogrid.y;
+    float *part1 = static_cast<float *>(ws);
+    float *part2 = part1 + 2 * kRedBlocks;
+    hipLaunchKernelGGL(lk_stats1, dim3(kRedBlocks), dim3(256), 0, stream, frame, npx, part1);
+    hipLaunchKernelGGL(lk_stats1_final, dim3(1), dim3(kFinalThreads), 0, stream, part1, kRedBlocks, stats_dev);
+    launch_lk_open(ogrid, stream, frame, m, n, size_opening, buffer_mask, stats_dev, clean_dev, part2, Band{0, 0, m});
+    hipLaunchKernelGGL(lk_open_final, dim3(1), dim3(kFinalThreads), 0, stream, part2, nb_open, stats_dev);
+    const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
+    hipLaunchKernelGGL(lk_to_u8, dim3(qgrid), dim3(256), 0, stream, clean_dev, m, n, buffer_mask, stats_dev, track_u8_dev,
+                       feature_u8_dev, 0);
+  } else {
+    // everything that decides a grey level is computed in double, like the reference does for such input
+    const double *frame = static_cast<const double *>(frame_dev);
+    const dim3 ogrid((n + kOpenColsW - 1) / kOpenColsW, (m + kOpenRowsWG - 1) / kOpenRowsWG);
+    const int nb_open = ogrid.x * ogrid.y;
+    double *clean64 = static_cast<double *>(ws);
+    double *part1 = clean64 + npx, *part2 = part1 + 2 * kRedBlocks, *dstats = part2 + 3 * nb_open;
+    hipLaunchKernelGGL(lk_stats1_f64, dim3(kRedBlocks), dim3(256), 0, stream, frame, npx, part1);
+    hipLaunchKernelGGL(lk_final_f64, dim3(1), dim3(kFinalThreads), 0, stream, part1, kRedBlocks, 0, stats_dev, dstats);
+    hipLaunchKernelGGL(lk_open_bits_f64, ogrid, dim3(256), 0, stream, frame, m, n, size_opening, buffer_mask, stats_dev,
+                       dstats, clean_dev, clean64, part2);
+    hipLaunchKernelGGL(lk_final_f64, dim3(1), dim3(kFinalThreads), 0, stream, part2, nb_open, 1, stats_dev, dstats);
+    const int qgrid = static_cast<int>(std::min<size_t>((npx + 255) / 256, 8192));
+    hipLaunchKernelGGL(lk_to_u8_f64, dim3(qgrid), dim3(256), 0, stream, clean64, m, n, buffer_mask, stats_dev, dstats,
+                       track_u8_dev, feature_u8_dev);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PSH_EHIP, "lk_prepare launch failed: %s", hipGetErrorString(e));
+  return PSH_OK;
+}
+
+
 }  // namespace psh
 
 using psh::ctx;
@@ -1529,32 +1585,14 @@ int psh_lk_prepare_dev(const float *frame_dev, int m, int n, int size_opening, i
                        float *clean_dev, unsigned char *track_u8_dev,
                        unsigned char *feature_u8_dev, float *stats_dev) {
   PSH_REQUIRE_INIT();
-  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_prepare: invalid shape (%d,%d)", m, n);
-  if (!frame_dev || !clean_dev || !track_u8_dev || !stats_dev)
-    return fail(PSH_EINVAL, "lk_prepare: NULL pointer");
-  if (size_opening != 0 && size_opening != 3)
-    return fail(PSH_EUNSUPPORTED, "lk_prepare: size_opening %d not implemented (0 or 3)", size_opening);
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  const size_t npx = static_cast<size_t>(m) * n;
-  const dim3 ogrid = psh::lk_open_grid(m, n);
-  const int nb_open = ogrid.x * ogrid.y;
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_prepare: invalid shape (%d,%d)", m, n);
   void *ws = nullptr;
-  const size_t need = sizeof(float) * (2 * static_cast<size_t>(psh::kRedBlocks) + 3 * static_cast<size_t>(nb_open));
-  if (int rc = psh::ensure_lk_ws(need, &ws)) return rc;
-  float *part1 = static_cast<float *>(ws);
-  float *part2 = part1 + 2 * psh::kRedBlocks;
-  hipLaunchKernelGGL(psh::lk_stats1, dim3(psh::kRedBlocks), dim3(256), 0, c.stream, frame_dev, npx, part1);
-  hipLaunchKernelGGL(psh::lk_stats1_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part1, psh::kRedBlocks, stats_dev);
-  psh::launch_lk_open(ogrid, c.stream, frame_dev, m, n, size_opening, buffer_mask, stats_dev, clean_dev, part2,
-                      psh::Band{0, 0, m});
-  hipLaunchKernelGGL(psh::lk_open_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part2, nb_open, stats_dev);
-  const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
-  hipLaunchKernelGGL(psh::lk_to_u8, dim3(qgrid), dim3(256), 0, c.stream, clean_dev, m, n, buffer_mask,
-                     stats_dev, track_u8_dev, feature_u8_dev, 0);
-  PSH_HIP(hipGetLastError());
-  return PSH_OK;
+  if (int rc = psh::ensure_lk_ws(psh::lk_prepare_ws_bytes(m, n, false), &ws)) return rc;
+  return psh::lk_prepare_on(c.stream, ws, frame_dev, false, m, n, size_opening, buffer_mask, clean_dev, track_u8_dev,
+                            feature_u8_dev, stats_dev);
 }
 
 // the same for a float64 frame (the dtype pysteps arrays have as a rule): everything that decides a
@@ -1563,36 +1601,16 @@ int psh_lk_prepare_f64_dev(const double *frame_dev, int m, int n, int size_openi
                            float *clean_dev, unsigned char *track_u8_dev,
                            unsigned char *feature_u8_dev, float *stats_dev) {
   PSH_REQUIRE_INIT();
-  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_prepare: invalid shape (%d,%d)", m, n);
-  if (!frame_dev || !clean_dev || !track_u8_dev || !stats_dev)
-    return fail(PSH_EINVAL, "lk_prepare: NULL pointer");
-  if (size_opening != 0 && size_opening != 3)
-    return fail(PSH_EUNSUPPORTED, "lk_prepare: size_opening %d not implemented (0 or 3)", size_opening);
   psh::Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  const size_t npx = static_cast<size_t>(m) * n;
-  const dim3 ogrid((n + psh::kOpenColsW - 1) / psh::kOpenColsW, (m + psh::kOpenRowsWG - 1) / psh::kOpenRowsWG);
-  const int nb_open = ogrid.x * ogrid.y;
-  const size_t part_doubles = 2 * static_cast<size_t>(psh::kRedBlocks) + 3 * static_cast<size_t>(nb_open) + 8;
+  if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_prepare: invalid shape (%d,%d)", m, n);
   void *blk = nullptr;  // [clean64 | partials | dstats]
-  if (int rc = psh_malloc(&blk, (npx + part_doubles) * sizeof(double))) return rc;
-  double *clean64 = static_cast<double *>(blk);
-  double *part1 = clean64 + npx, *part2 = part1 + 2 * psh::kRedBlocks, *dstats = part2 + 3 * nb_open;
-  hipLaunchKernelGGL(psh::lk_stats1_f64, dim3(psh::kRedBlocks), dim3(256), 0, c.stream, frame_dev, npx, part1);
-  hipLaunchKernelGGL(psh::lk_final_f64, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part1, psh::kRedBlocks, 0,
-                     stats_dev, dstats);
-  hipLaunchKernelGGL(psh::lk_open_bits_f64, ogrid, dim3(256), 0, c.stream, frame_dev, m, n, size_opening, buffer_mask,
-                     stats_dev, dstats, clean_dev, clean64, part2);
-  hipLaunchKernelGGL(psh::lk_final_f64, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part2, nb_open, 1, stats_dev,
-                     dstats);
-  const int qgrid = static_cast<int>(std::min<size_t>((npx + 255) / 256, 8192));
-  hipLaunchKernelGGL(psh::lk_to_u8_f64, dim3(qgrid), dim3(256), 0, c.stream, clean64, m, n, buffer_mask, stats_dev,
-                     dstats, track_u8_dev, feature_u8_dev);
-  const hipError_t e = hipGetLastError();
+  if (int rc = psh_malloc(&blk, psh::lk_prepare_ws_bytes(m, n, true))) return rc;
+  const int rc = psh::lk_prepare_on(c.stream, blk, frame_dev, true, m, n, size_opening, buffer_mask, clean_dev,
+                                    track_u8_dev, feature_u8_dev, stats_dev);
   (void)psh_free(blk);  // stream-ordered
-  if (e != hipSuccess) return fail(PSH_EHIP, "lk_prepare (float64) launch failed: %s", hipGetErrorString(e));
-  return PSH_OK;
+  return rc;
 }
 
 // ---- row bands (multi-GPU tiling of the image passes, BASELINE config 5) --------------------

@@ -136,8 +136,10 @@ def test_errors_and_declined_inputs(ref_pysteps):
     tied[0, :10] = np.arange(10) + 2.0
     target = rng.normal(size=(300, 300))
     assert np.array_equal(_match(tied, target), ref(tied, target))
-    with pytest.raises(NotImplementedError):
-        _match(DeviceArray.from_host(tied), DeviceArray.from_host(target))
+    # resident arrays: the one declined call crosses the bus, runs the reference's function and comes back
+    # (a resident member loop with a plateaued forecast keeps going)
+    resident = _match(DeviceArray.from_host(tied), DeviceArray.from_host(target))
+    assert isinstance(resident, DeviceArray) and np.array_equal(resident.to_host(), ref(tied, target))
     inf_target = target.copy()
     inf_target[4, 4] = np.inf
     initial = rng.normal(size=(300, 300))

@@ -33,11 +33,13 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
     counters, counter_source = {}, None
     summary = os.path.join(src, "pmc", "summary.csv")
     if os.path.exists(summary):
-        for r in csv.DictReader(open(summary)):
-            k = r["kernel"].split("<")[0].strip()
-            if k in counters and r["counter"].replace("_sum", "") in counters[k]:
+        for line in list(open(summary))[1:]:
+            # kernel names carry commas (template arguments): the two last fields are counter and value
+            kernel, counter, value = line.rstrip("\n").rsplit(",", 2)
+            k, counter = kernel.split("<")[0].strip(), counter.replace("_sum", "")
+            if k in counters and counter in counters[k]:
                 continue  # first instantiation listed wins (the one the bench step runs)
-            counters.setdefault(k, {})[r["counter"].replace("_sum", "")] = float(r["mean_per_launch"])
+            counters.setdefault(k, {})[counter] = float(value)
         shutil.copy(summary, os.path.join(dst, "%s_pmc_kernels.csv" % prefix))
         counter_source = "profiles/%s/%s_pmc_kernels.csv" % (rnd, prefix)
     json.dump({"source": "profiles/%s/%s_rocprofv3_kernel_stats.csv" % (rnd, prefix), "steps_traced": STEPS_TRACED,
