@@ -1,7 +1,7 @@
 """Timing of the HIP FFTs (development aid / DESIGN.md 3.6): resident transforms by HIP events,
 the NumPy-in / NumPy-out path by the wall clock, numpy.fft (pocketfft) beside them.
 
-    python tools/fft_quick.py [size ...]
+    python tools/fft_quick.py [size | rowsxcols ...]      e.g.  2048 4096 640x710 1226x760
 """
 import json
 import sys
@@ -13,10 +13,11 @@ import numpy as np
 from pysteps_amd.device import DeviceArray, Event, synchronize
 from pysteps_amd.utils.fft import get_hip
 
-sizes = [int(a) for a in sys.argv[1:]] or [2048, 4096]
+sizes = sys.argv[1:] or ["2048", "4096"]
 out = []
-for n in sizes:
-    shape = (n, n)
+for a in sizes:
+    shape = tuple(int(v) for v in a.split("x")) if "x" in a else (int(a), int(a))
+    n = shape[1]
     x = np.random.default_rng(n).standard_normal(shape)
     fft = get_hip(shape)
     dx = DeviceArray.from_host(x)
