@@ -37,7 +37,7 @@ from ..device import DeviceArray
 from ..noise.randstate import DeviceRandomStates
 from ..utils import fft as hip_fft
 
-__all__ = ["ResidentSteps", "try_create"]
+__all__ = ["ResidentSteps", "try_create", "recognises"]
 
 _MAX_LEVELS, _MAX_ORDER = 16, 8
 
@@ -52,11 +52,17 @@ def _c_doubles(values):
     return arr, arr.ctypes.data_as(ctypes.c_void_p)
 
 
+def recognises(func):
+    """True if ``func`` is the update function of the reference's STEPS nowcaster
+    (``StepsNowcaster.__update_state``, bound; pysteps/nowcasts/steps.py:439-457)."""
+    owner = getattr(func, "__self__", None)
+    return owner is not None and type(owner).__name__ == "StepsNowcaster" and getattr(func, "__name__", "") == "__update_state"
+
+
 def try_create(func, state, params, shape, n_updates):
     """A :class:`ResidentSteps` for the update function ``func`` of the reference's STEPS nowcaster, or
     None if ``func`` is something else or uses options outside the resident chain."""
-    owner = getattr(func, "__self__", None)
-    if owner is None or type(owner).__name__ != "StepsNowcaster" or getattr(func, "__name__", "") != "__update_state":
+    if not recognises(func):
         return None
     try:
         return ResidentSteps(state, params, shape, n_updates)

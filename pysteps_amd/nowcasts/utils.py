@@ -305,18 +305,20 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
 
     # the STEPS member update with all of its state in HBM (steps_resident.py), when `func` is the
     # reference's StepsNowcaster.__update_state and its options are the ones the chain implements
+    # (only together with the HIP extrapolator: a caller who chose another one keeps the reference's update)
     resident = timeline = None
-    if ensemble and resident_update_enabled:
-        from .steps_resident import try_create  # noqa: PLC0415
+    if ensemble and resident_update_enabled and extrapolator is _hip_extrapolate:
+        from .steps_resident import recognises, try_create  # noqa: PLC0415
 
-        timeline = _Timeline()
-        resident = try_create(func, state, params, precip.shape, len(plan))
-        if resident is None:
-            timeline = None
-        else:
-            timeline.mark("upload")
-            if isinstance(engine, _BatchedLoop):
-                engine.timeline = timeline
+        if recognises(func):
+            timeline = _Timeline()
+            resident = try_create(func, state, params, precip.shape, len(plan))
+            if resident is None:
+                timeline = None
+            else:
+                timeline.mark("upload")
+                if isinstance(engine, _BatchedLoop):
+                    engine.timeline = timeline
 
     prev = np.stack([precip] * n_members) if ensemble else precip[np.newaxis, :]
     outputs = [[] for _ in range(prev.shape[0])] if return_output else None

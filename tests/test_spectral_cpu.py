@@ -1,6 +1,7 @@
 """The spectral mirrors on shapes the HIP kernels do not take (no GPU needed): they have to hand
 the call to the reference's own code and return exactly its result - the drop-in contract for every
-grid that is not a power of two (pysteps' own test fields are 200 x 200 and the like)."""
+grid beyond the kernels (a side longer than 4096 that is not a power of two; since round 3 every other
+shape, pysteps' 200 x 200 test fields included, runs on the device)."""
 
 import numpy as np
 import pytest
@@ -21,7 +22,7 @@ def test_decomposition_on_other_shapes_is_the_reference(ref_pysteps):
 
     from pysteps_amd.cascade import decomposition_fft, recompose_fft
 
-    shape = (200, 300)
+    shape = (4100, 12)
     field = _field(shape, 1)
     bp = filter_gaussian(shape, 5)
     for kw in (dict(normalize=True, compute_stats=True), dict(output_domain="spectral", compute_stats=True),
@@ -43,7 +44,7 @@ def test_noise_generator_on_other_shapes_is_the_reference(ref_pysteps):
 
     from pysteps_amd.noise import generate_noise_2d_fft_filter
 
-    shape = (200, 200)
+    shape = (4100, 10)
     field = _field(shape, 2)
     pg = ref.initialize_nonparam_2d_fft_filter(field)
     for domain in ("spatial", "spectral"):
