@@ -107,6 +107,28 @@ class Communicator:
         _lib.check(_lib.lib().psh_comm_destroy(), "psh_comm_destroy")
 
 
+def steps_shard(seed, n_ens_members, world_size, rank):
+    """The share of a ``pysteps.nowcasts.steps`` ensemble that ``rank`` runs (BASELINE config 4: 48 members,
+    6 per GPU) -> ``(members, kwargs)``: the global member indices and the ``n_ens_members`` / ``seed``
+    keywords to hand to ``nowcasts.steps`` on this rank.
+
+    The nowcaster seeds its members from ONE chain (pysteps/nowcasts/steps.py:885-898): per member a
+    generator for the precipitation noise, ``seed = rs.randint(0, 1e9)``, a generator for the motion
+    perturbation, ``seed = rs.randint(0, 1e9)``.  Walking the chain to this rank's first member gives the
+    seed from which the nowcaster, run with ``n_ens_members=len(members)``, builds exactly the generators
+    of the global members ``members`` - so N ranks produce the members of the single-process ensemble,
+    every one on its rank, with no communication beyond the broadcast of the inputs.  ``seed=None``
+    (unseeded run) stays None."""
+    import numpy.random as npr  # noqa: PLC0415
+
+    members = partition(n_ens_members, world_size, rank)
+    if seed is not None:
+        for _ in range(members.start):
+            seed = npr.RandomState(seed).randint(0, high=int(1e9))
+            seed = npr.RandomState(seed).randint(0, high=int(1e9))
+    return members, {"n_ens_members": len(members), "seed": seed}
+
+
 def sharded_extrapolate(precip_members, velocity, timesteps, rank, world_size, **kwargs):
     """Advect this rank's share of an ensemble (list of (m,n) fields, same velocity).
 

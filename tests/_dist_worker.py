@@ -22,15 +22,17 @@ def main():
     mine = list(parallel.partition(48, dist.world, dist.rank))
     owners = [parallel.owner_of(j, 48, dist.world) for j in mine]
     # config 4 in bench.py: every rank recomputes the perturbators of ITS members from the seed
-    from pysteps_amd.extrapolation.ensemble import steps_perturbators
+    from pysteps_amd.extrapolation.ensemble import steps_noise_generators, steps_perturbators
 
     per_gpu = 6
     n_total = per_gpu * dist.world
     shard = parallel.partition(n_total, dist.world, dist.rank)
     eps = [p["eps_par"] for p in steps_perturbators(n_total, 42, 1.0, 5.0)[shard.start:shard.stop]]
+    # ... and the random streams of its members (the first draw of each identifies the stream)
+    first_draws = [float(rs.standard_normal()) for rs in steps_noise_generators(n_total, 42)[shard.start:shard.stop]]
     with open(os.path.join(out_dir, "rank%d.json" % dist.rank), "w") as fh:
         json.dump({"rank": dist.rank, "max": slowest, "token_len": len(token), "mine": mine,
-                   "owners": owners, "shard": list(shard), "eps_par": eps}, fh)
+                   "owners": owners, "shard": list(shard), "eps_par": eps, "first_draws": first_draws}, fh)
     dist.barrier()
     dist.close()
 

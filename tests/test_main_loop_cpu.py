@@ -111,6 +111,8 @@ def test_steps_perturbators_reproduce_the_seed_chain_of_nowcasts_steps(ref_pyste
 
     def spy(*a, **k):
         captured["gens"] = k.get("velocity_pert_gen")
+        # the precipitation-noise generators as the loop receives them (state is the third positional argument)
+        captured["noise"] = [rs.get_state() for rs in a[2]["randgen_prec"]]
         return ref_loop(*a, **k)
 
     frames = synth.steps_frames(64, 64, 3)
@@ -121,9 +123,60 @@ def test_steps_perturbators_reproduce_the_seed_chain_of_nowcasts_steps(ref_pyste
                                      kmperpixel=2.0, timestep=10.0, seed=42)
     finally:
         steps_mod.nowcast_main_loop = ref_loop
+    # the members' random streams (steps.py:885-898): same keys, positions and cached values
+    from pysteps_amd.extrapolation.ensemble import steps_noise_generators
+
+    mine = steps_noise_generators(5, 42)
+    assert len(mine) == len(captured["noise"]) == 5
+    for rs, want_state in zip(mine, captured["noise"]):
+        got_state = rs.get_state()
+        assert got_state[0] == want_state[0] and np.array_equal(got_state[1], want_state[1])
+        assert got_state[2:] == want_state[2:]
     want = [g.__defaults__[-1] for g in captured["gens"]]
     got = steps_perturbators(5, 42, 2.0, 10.0)
     assert len(got) == len(want) == 5
     for g, w in zip(got, want):
         assert g["eps_par"] == w["eps_par"] and g["eps_perp"] == w["eps_perp"]
         assert g["vsf"] == w["vsf"] and tuple(g["p_par"]) == tuple(w["p_par"]) and tuple(g["p_perp"]) == tuple(w["p_perp"])
+
+
+def test_steps_shard_reproduces_the_members_of_the_whole_ensemble(ref_pysteps):
+    """parallel.steps_shard: rank r of N runs nowcasts.steps with its own n_ens_members / seed and gets the
+    generators (noise and motion) of ITS members of the single-process ensemble - captured from the real
+    nowcaster (steps.py:885-933) for the whole ensemble and for every shard of a 3-rank split."""
+    from pysteps import nowcasts
+    from pysteps.nowcasts import steps as steps_mod
+    from pysteps_amd import parallel
+    from tools import synth
+
+    frames = synth.steps_frames(64, 64, 3)
+    V = synth.true_velocity(64, 64).astype(np.float64)
+    ref_loop = steps_mod.nowcast_main_loop
+
+    def capture(**kw):
+        got = {}
+
+        def spy(*a, **k):
+            got["noise"] = [rs.get_state() for rs in a[2]["randgen_prec"]]
+            got["motion"] = [(g.__defaults__[-1]["eps_par"], g.__defaults__[-1]["eps_perp"]) for g in k["velocity_pert_gen"]]
+            return ref_loop(*a, **k)
+
+        try:
+            steps_mod.nowcast_main_loop = spy
+            nowcasts.get_method("steps")(frames, V, 1, n_cascade_levels=3, precip_thr=-10.0, kmperpixel=2.0, timestep=10.0, **kw)
+        finally:
+            steps_mod.nowcast_main_loop = ref_loop
+        return got
+
+    whole = capture(n_ens_members=7, seed=42)
+    seen = []
+    for rank in range(3):
+        members, kw = parallel.steps_shard(42, 7, 3, rank)
+        part = capture(**kw)
+        assert len(part["noise"]) == len(members)
+        for j, st, mo in zip(members, part["noise"], part["motion"]):
+            assert np.array_equal(st[1], whole["noise"][j][1]) and st[2:] == whole["noise"][j][2:]
+            assert mo == whole["motion"][j]
+        seen += list(members)
+    assert seen == list(range(7))
+    assert parallel.steps_shard(None, 7, 3, 1)[1] == {"n_ens_members": 2, "seed": None}

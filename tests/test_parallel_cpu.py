@@ -52,6 +52,11 @@ def test_two_rank_gloo_control_plane(tmp_path):
     assert res[0]["shard"] == list(range(6)) and res[1]["shard"] == list(range(6, 12))
     chain = [p["eps_par"] for p in steps_perturbators(12, 42, 1.0, 5.0)]
     assert res[0]["eps_par"] + res[1]["eps_par"] == chain and len(set(chain)) == 12
+    # ... and so are the members' random streams (the member loop of the N > 1 bench leg draws from them)
+    from pysteps_amd.extrapolation.ensemble import steps_noise_generators
+
+    draws = [float(rs.standard_normal()) for rs in steps_noise_generators(12, 42)]
+    assert res[0]["first_draws"] + res[1]["first_draws"] == draws and len(set(draws)) == 12
 
 
 def test_communicator_needs_gpu():

@@ -261,3 +261,36 @@ def test_declined_options_take_the_reference_update(ref_pysteps):
         steps_resident.ResidentSteps.__init__ = orig
         register.unpatch_main_loop()
     assert not made and out.shape == (2, 2, 128, 128)
+
+
+def test_sharded_ensemble_equals_the_whole_ensemble():
+    """parallel.steps_shard + the real nowcasts.steps with the resident loop: three shards run one after
+    the other (what three ranks would run) give exactly the members of the six-member ensemble run at
+    once - same seeds, same streams, bit-identical fields (tools/steps_sharded.py --virtual-ranks)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "steps_sharded.py"), "256", "6", "2", "--virtual-ranks", "3"],
+                          cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["shards_equal_whole_ensemble"], line
+
+
+def test_sharded_driver_runs_through_rccl_at_world_size_one():
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "steps_sharded.py"), "256", "3", "2"],
+                          cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["ranks"] == 1 and line["members_of_rank0"] == [0, 1, 2] and line["result_of_rank0"] == [3, 2, 256, 256]
