@@ -444,6 +444,12 @@ int psh_ar_iterate_dev(const double *x_dev, int nt, size_t plane, const double *
  *      not finite), PSH_EUNSUPPORTED for inputs left to the reference (more than 16384 wet values tied or
  *      in one of the 2^20 value buckets, infinities or no finite value in target). */
 int psh_probmatch_dev(const double *initial_dev, const double *target_dev, size_t count, double *out_dev);
+/* the same without the wait: *status_dev (device int) receives the outcome, to be read by the caller later
+ * and turned into the return code / error text of psh_probmatch_dev by psh_probmatch_status() - the
+ * resident member loop queues every member's matching and waits once per time step */
+int psh_probmatch_async_dev(const double *initial_dev, const double *target_dev, size_t count, double *out_dev,
+                            int *status_dev);
+int psh_probmatch_status(int status);
 
 /* ---- incremental precipitation mask of the member loops (csrc/mask.hip) -------- *
  *  psh_dilated_mask_dev  pysteps/nowcasts/utils.py:69-101, compute_dilated_mask(input_mask, kr, r) (nowcasts/

@@ -76,6 +76,8 @@ SIGNATURES = {
                                           c_double, c_void_p]),
     "psh_noise_filter_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "psh_probmatch_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "psh_probmatch_async_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "psh_probmatch_status": (c_int, [c_int]),
     "psh_dilated_mask_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_ar_iterate_dev": (c_int, [c_void_p, c_int, c_size_t, POINTER(c_double), c_int, c_void_p, c_void_p]),
     "psh_steps_ar_recompose_dev": (c_int, [c_void_p, c_int, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

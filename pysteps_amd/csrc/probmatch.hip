@@ -574,8 +574,24 @@ __global__ void pm_threshold(PmHeader *h, size_t n, const double *__restrict__ t
 }  // namespace
 }  // namespace psh
 
-extern "C" int psh_probmatch_dev(const double *initial_dev, const double *target_dev, size_t count,
-                                 double *out_dev) {
+static int probmatch_status_to_rc(int status) {
+  using namespace psh;
+  switch (status) {
+    case kStOk:
+      return PSH_OK;
+    case kStAllNan:
+      return fail(PSH_EINVAL, "Initial array contains only nans.");
+    case kStNonFinite:
+      return fail(PSH_EINVAL, "Initial array contains non-finite values outside ignore_indices mask.");
+    case kStTarget:
+      return fail(PSH_EUNSUPPORTED, "probmatch: target array without finite values or with infinities");
+    default:
+      return fail(PSH_EUNSUPPORTED, "probmatch: more than %u tied or bucket-sharing wet values", kLargeLimit);
+  }
+}
+
+static int probmatch_run(const double *initial_dev, const double *target_dev, size_t count, double *out_dev,
+                         int *status_dev) {
   using namespace psh;
   PSH_REQUIRE_INIT();
   if (!initial_dev || !target_dev || !out_dev) return fail(PSH_EINVAL, "probmatch: NULL pointer");
@@ -646,6 +662,11 @@ extern "C" int psh_probmatch_dev(const double *initial_dev, const double *target
     hipLaunchKernelGGL(pm_rank_large<true>, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large,
                        large_cap, sval, sidx, tw, out_dev);
     PSH_HIP(hipGetLastError());
+    if (status_dev) {  // the caller reads the status later (resident member loop: one wait per time step)
+      PSH_HIP(hipMemcpyAsync(status_dev, &h->status, sizeof(int), hipMemcpyDeviceToDevice, s));
+      status = kStOk;
+      return PSH_OK;
+    }
     static void *pinned = nullptr;
     if (int rc = persistent_pinned(&pinned, 64)) return rc;
     PSH_HIP(hipMemcpyAsync(pinned, &h->status, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -656,16 +677,19 @@ extern "C" int psh_probmatch_dev(const double *initial_dev, const double *target
   const int rc = run();
   (void)psh_free(blk);
   if (rc) return rc;
-  switch (status) {
-    case kStOk:
-      return PSH_OK;
-    case kStAllNan:
-      return fail(PSH_EINVAL, "Initial array contains only nans.");
-    case kStNonFinite:
-      return fail(PSH_EINVAL, "Initial array contains non-finite values outside ignore_indices mask.");
-    case kStTarget:
-      return fail(PSH_EUNSUPPORTED, "probmatch: target array without finite values or with infinities");
-    default:
-      return fail(PSH_EUNSUPPORTED, "probmatch: more than %u tied or bucket-sharing wet values", kLargeLimit);
-  }
+  return probmatch_status_to_rc(status);
+}
+
+extern "C" int psh_probmatch_dev(const double *initial_dev, const double *target_dev, size_t count, double *out_dev) {
+  return probmatch_run(initial_dev, target_dev, count, out_dev, nullptr);
+}
+
+extern "C" int psh_probmatch_async_dev(const double *initial_dev, const double *target_dev, size_t count, double *out_dev,
+                                       int *status_dev) {
+  if (!status_dev) return psh::fail(PSH_EINVAL, "probmatch_async: NULL status pointer");
+  return probmatch_run(initial_dev, target_dev, count, out_dev, status_dev);
+}
+
+extern "C" int psh_probmatch_status(int status) {
+  return probmatch_status_to_rc(status);
 }

@@ -178,6 +178,10 @@ class ResidentSteps:
         self.domain_mask = None
         if dm is not None and np.any(dm):
             self.domain_mask = DeviceArray.from_host(np.ascontiguousarray(dm, dtype=np.uint8))
+        # CDF matching without a wait per member: the fields before the matching are kept for one time step
+        # and every member's outcome lands in a device word (checked once, at the end of the update)
+        self.pre = DeviceArray((self.B, m, n), np.float64) if self.pm_method == "cdf" else None
+        self.pm_status = DeviceArray((max(self.B, 2),), np.int32) if self.pm_method == "cdf" else None
         self.min_key = DeviceArray((8,), np.uint64)
         self.eps = DeviceArray((self.L, m, n), np.float64)  # cascade of one member's noise field
         self.noise = DeviceArray((m, n), np.float64)
@@ -197,18 +201,22 @@ class ResidentSteps:
             self._draw(slot)
         self.rng.wait()
         white = self.white[slot]
+        # the NEXT time step's draw starts now, on the generators' own stream, beside this whole update: its
+        # buffer was last read by the previous update (queued long ago); producing the words of six 4096^2
+        # fields takes 30 ms - queued behind the last member's noise filter (the first version) it ran
+        # beside a sixth of the update and the next update waited for the rest
+        if self.done + 1 < self.n_updates:
+            self._draw(slot ^ 1)
+            self._white_ready = True
+        else:
+            self._white_ready = False
         out = DeviceArray((self.B, m, n), np.float64)
         lvl_stride = self.p * plane * 8
         for j in range(self.B):
-            field = out.view(j)
+            result = out.view(j)
+            field = self.pre.view(j) if self.pre is not None else result  # what the matching reads
             # fftgenerators.py:400-433 (the filter part), decomposition.py:77-262 with normalize=True
             _lib.check(lib.psh_noise_filter_dev(white.view(j).ptr, self.noise_filter.ptr, m, n, self.noise.ptr), "psh_noise_filter_dev")
-            if j == self.B - 1 and self.done + 1 < self.n_updates:
-                # the white noise of this step is consumed: the next step's draw runs beside the rest
-                self._draw(slot ^ 1)
-                self._white_ready = True
-            elif j == self.B - 1:
-                self._white_ready = False
             _lib.check(lib.psh_cascade_decompose_dev(self.noise.ptr, self.weights.ptr, self.L, m, n, 1, 0, self.eps.ptr, None, None, None),
                        "psh_cascade_decompose_dev")
             # steps.py:1116-1146 + 1176-1185
@@ -221,27 +229,40 @@ class ResidentSteps:
                 _lib.check(lib.psh_steps_mask_dev(field.ptr, plane, self.grey.view(j).ptr, None, self.min_key.ptr), "psh_steps_mask_dev")
             elif self.keep is not None:
                 _lib.check(lib.psh_steps_mask_dev(field.ptr, plane, None, self.keep.ptr, self.min_key.ptr), "psh_steps_mask_dev")
-            if self.pm_method == "cdf":  # steps.py:1198-1201
-                matched = DeviceArray((m, n), np.float64)
-                rc = lib.psh_probmatch_dev(field.ptr, self.target.ptr, plane, matched.ptr)
-                if rc == _lib.PSH_EUNSUPPORTED:
-                    matched = self._probmatch_on_host(field)
-                else:
-                    _lib.check(rc, "psh_probmatch_dev")
-                _lib.check(lib.psh_memcpy_d2d(field.ptr, matched.ptr, plane * 8), "d2d")
+            if self.pm_method == "cdf":  # steps.py:1198-1201; the outcome is read after the last member
+                _lib.check(lib.psh_probmatch_async_dev(field.ptr, self.target.ptr, plane, result.ptr, self.pm_status.ptr + 4 * j),
+                           "psh_probmatch_async_dev")
             elif self.pm_method == "mean":  # steps.py:1203-1206
-                _lib.check(lib.psh_steps_mean_shift_dev(field.ptr, plane, self.thr, self.mu_0), "psh_steps_mean_shift_dev")
-            if self.grey is not None:  # steps.py:1209-1214
-                _lib.check(lib.psh_ge_mask_dev(field.ptr, plane, self.thr, self.wet.ptr), "psh_ge_mask_dev")
-                _lib.check(
-                    lib.psh_dilated_mask_dev(self.wet.ptr, m, n, self.struct.ctypes.data_as(ctypes.c_void_p), int(self.struct.shape[0]),
-                                             int(self.struct.shape[1]), self.rim, self.grey.view(j).ptr),
-                    "psh_dilated_mask_dev")
-            if self.domain_mask is not None:  # steps.py:1217
-                _lib.check(lib.psh_nan_where_dev(field.ptr, self.domain_mask.ptr, plane), "psh_nan_where_dev")
+                _lib.check(lib.psh_steps_mean_shift_dev(result.ptr, plane, self.thr, self.mu_0), "psh_steps_mean_shift_dev")
+            self._finish_member(j, result)
+        if self.pm_method == "cdf":
+            # ONE wait per time step: a member the bucket pass declined (thousands of tied wet values) is
+            # matched by the reference's function from its kept field, its mask update is redone
+            status = self.pm_status.to_host()
+            for j in range(self.B):
+                if status[j] == 0:
+                    continue
+                rc = lib.psh_probmatch_status(int(status[j]))
+                if rc != _lib.PSH_EUNSUPPORTED:
+                    _lib.check(rc, "psh_probmatch_dev")
+                matched = self._probmatch_on_host(self.pre.view(j))
+                _lib.check(lib.psh_memcpy_d2d(out.view(j).ptr, matched.ptr, plane * 8), "d2d")
+                self._finish_member(j, out.view(j))
         self.head = (self.head + 1) % self.p
         self.done += 1
         return out
+
+    def _finish_member(self, j, field):
+        """steps.py:1209-1217: the member's incremental mask from its new field, the domain mask."""
+        lib, m, n, plane = self._lib, self.m, self.n, self.plane
+        if self.grey is not None:
+            _lib.check(lib.psh_ge_mask_dev(field.ptr, plane, self.thr, self.wet.ptr), "psh_ge_mask_dev")
+            _lib.check(
+                lib.psh_dilated_mask_dev(self.wet.ptr, m, n, self.struct.ctypes.data_as(ctypes.c_void_p), int(self.struct.shape[0]),
+                                         int(self.struct.shape[1]), self.rim, self.grey.view(j).ptr),
+                "psh_dilated_mask_dev")
+        if self.domain_mask is not None:
+            _lib.check(lib.psh_nan_where_dev(field.ptr, self.domain_mask.ptr, plane), "psh_nan_where_dev")
 
     def _probmatch_on_host(self, field):
         """The device CDF matching declined (thousands of tied wet values, infinities in the target):

@@ -190,3 +190,28 @@ def test_nowcasts_steps_with_the_patched_matching(ref_pysteps):
     finally:
         register.unpatch_probmatching()
     assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_async_variant_reports_its_outcome_in_device_memory(ref_pysteps):
+    """psh_probmatch_async_dev (the resident member loop's form: no wait, the outcome in a device word)"""
+    from pysteps.postprocessing.probmatching import nonparam_match_empirical_cdf as ref
+
+    from pysteps_amd import _lib
+    from pysteps_amd.device import DeviceArray
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(12)
+    shape = (300, 300)
+    initial, target = _forecast_like(shape, 3, 0.3), np.round(_forecast_like(shape, 4, 0.4), 1)
+    tied = np.where(rng.random(shape) < 0.5, 1.0, -15.0) + 0.0  # 45000 tied wet values: declined
+    status = DeviceArray((4,), np.int32)
+    d_t = DeviceArray.from_host(target)
+    outs = []
+    for k, arr in enumerate((initial, tied, np.full(shape, np.nan))):
+        d_i, d_o = DeviceArray.from_host(arr), DeviceArray(shape, np.float64)
+        _lib.check(lib.psh_probmatch_async_dev(d_i.ptr, d_t.ptr, arr.size, d_o.ptr, status.ptr + 4 * k))
+        outs.append((d_i, d_o))
+    got = status.to_host()
+    assert got[0] == 0 and np.array_equal(outs[0][1].to_host(), ref(initial, target))
+    assert lib.psh_probmatch_status(int(got[1])) == _lib.PSH_EUNSUPPORTED
+    assert lib.psh_probmatch_status(int(got[2])) == _lib.PSH_EINVAL and "only nans" in _lib.last_error()
