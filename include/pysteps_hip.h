@@ -501,7 +501,11 @@ int psh_lerp_dev(const double *a_dev, const double *b_dev, double w, double *out
  * NumPy, the values wherever the C library's log() is correctly rounded (1 ulp otherwise, csrc/cr_log.h).
  *  psh_rng_create     keys (n_streams, 624) uint32, pos / has_gauss / gauss per stream: the fields of
  *                     RandomState.get_state() (has_gauss_host / gauss_host may be NULL); max_draw = the
- *                     largest `count` psh_rng_randn_dev will be asked for
+ *                     largest `count` psh_rng_randn_dev will be asked for; n_draws_hint > 0: that many draws
+ *                     are expected - the streams are cut into chunks of 512 blocks whose start states are
+ *                     computed by jump-ahead (x^J mod the generator's characteristic polynomial, tables from
+ *                     tools/gen_mt_jump.py) so that every chunk is produced by its own workgroup; 0: one
+ *                     workgroup per stream produces the words in sequence (also what happens beyond the hint)
  *  psh_rng_randn_dev  out (n_streams, count) float64: the next `count` values of every stream, like
  *                     `randn(count)`.  Asynchronous; side != 0 runs the draw on the handle's own stream
  *                     behind everything queued on the library stream so far (the noise of the next time
@@ -510,7 +514,7 @@ int psh_lerp_dev(const double *a_dev, const double *b_dev, double w, double *out
  *  psh_rng_get_state  waits for the draws and returns the generators' states in get_state() form
  *                     (RandomState.set_state() then continues the stream on the host) */
 int psh_rng_create(int n_streams, const uint32_t *keys_host, const int *pos_host, const int *has_gauss_host,
-                   const double *gauss_host, size_t max_draw, void **handle_out);
+                   const double *gauss_host, size_t max_draw, int n_draws_hint, void **handle_out);
 int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, int side);
 int psh_rng_wait(void *handle);
 int psh_rng_get_state(void *handle, uint32_t *keys_host, int *pos_host, int *has_gauss_host, double *gauss_host);

@@ -87,7 +87,7 @@ SIGNATURES = {
     "psh_ge_mask_dev": (c_int, [c_void_p, c_size_t, c_double, c_void_p]),
     "psh_nan_where_dev": (c_int, [c_void_p, c_void_p, c_size_t]),
     "psh_lerp_dev": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_size_t]),
-    "psh_rng_create": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, POINTER(c_void_p)]),
+    "psh_rng_create": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
     "psh_rng_randn_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_int]),
     "psh_rng_wait": (c_int, [c_void_p]),
     "psh_rng_get_state": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -16,9 +16,16 @@
 // An attempt always consumes four words, so attempt k of a draw sits at a fixed place of the word
 // sequence and the draw is a stream compaction: output pair p comes from the p-th accepted attempt.
 //
-//   mt_produce   one workgroup per stream extends the stream's ring of raw MT19937 words: the whole
-//                624-word twist in ONE barrier phase (every new word written as a function of the old
-//                block only: 3, 5 or 7 old words), 640 threads
+//   mt_produce   one workgroup extends a stream's ring of raw MT19937 words: the whole 624-word twist
+//                in ONE barrier phase (every new word written as a function of the old block only: 3,
+//                5 or 7 old words), 640 threads.  A stream is sequential - 0.4 us per twist, 27 ms for
+//                the words of one 4096^2 field - so it is cut into chunks of 512 blocks whose start
+//                states come from the generator's GF(2)-linear structure:
+//   mt_jump      state J words ahead = g_J(A) state, g_J = x^J mod (characteristic polynomial of the
+//                word transition A), evaluated by Horner 32 coefficients at a time (mt_jump_tables.h,
+//                tools/gen_mt_jump.py); the start states of 2^l chunks in l rounds of doubling.  Every
+//                chunk is then produced by its own workgroup (mt_produce_chunks); when the start states
+//                are used up the grid is anchored anew at the last block produced (mt_anchor)
 //   polar_count  accepted attempts per tile of 1024 attempts (a window of W attempts per draw; W holds
 //                the pairs needed with > 10 sigma to spare)
 //   polar_scan   one workgroup per stream: exclusive scan of the tile counts
@@ -33,6 +40,7 @@
 
 #include "common.h"
 #include "cr_log.h"
+#include "mt_jump_tables.h"
 
 namespace psh {
 namespace {
@@ -78,6 +86,105 @@ __global__ __launch_bounds__(kProduceThreads) void mt_produce(uint32_t *__restri
   }
   __syncthreads();
   for (int k = 0; k < nblocks; ++k) {
+    const uint32_t *o = s_blk[k & 1];
+    uint32_t *nw = s_blk[(k & 1) ^ 1];
+    if (i < kMtN) {
+      uint32_t v;
+      if (i < 227) {
+        v = o[i + 397] ^ mt_mix(o[i], o[i + 1]);
+      } else if (i < 454) {
+        v = o[i + 170] ^ mt_mix(o[i - 227], o[i - 226]) ^ mt_mix(o[i], o[i + 1]);
+      } else if (i < 623) {
+        v = o[i - 57] ^ mt_mix(o[i - 454], o[i - 453]) ^ mt_mix(o[i - 227], o[i - 226]) ^ mt_mix(o[i], o[i + 1]);
+      } else {
+        const uint32_t n0 = o[397] ^ mt_mix(o[0], o[1]);
+        const uint32_t n396 = o[566] ^ mt_mix(o[169], o[170]) ^ mt_mix(o[396], o[397]);
+        v = n396 ^ mt_mix(o[623], n0);
+      }
+      nw[i] = v;
+      __builtin_nontemporal_store(v, ring + static_cast<size_t>((first_block + k) % ring_blocks) * kMtN + i);
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kChunkBlocks = PSH_MT_CHUNK_BLOCKS;
+__device__ const uint32_t d_jump_table[PSH_MT_JUMP_LEVELS][PSH_MT_JUMP_WORDS] = {PSH_MT_JUMP_TABLE};
+
+// bases: (streams, n_chunks, 624): bases[b][j] = the stream's window at word 624 * kChunkBlocks * j (block
+// kChunkBlocks * j), exact except for the low 31 bits of its first word, which the recurrence never reads.
+// One workgroup: bases[b][first_dst + x] = g_level(A) bases[b][first_dst + x - 2^level].
+// Horner, 32 coefficients per round (chunk c of the polynomial = coefficients 32 c .. 32 c + 31):
+//   acc <- A^32 acc  ^  XOR_b chunk_b A^b s0,      (A^b s0)[t] = E[b + t], E = s0 extended by 31 words
+// acc lives in LDS as a ring with head h: advancing by 32 overwrites the 32 dropped words with the 32 new
+// ones (all functions of old words, 32 <= 227) and leaves everything else in place.
+__global__ __launch_bounds__(kProduceThreads) void mt_jump(uint32_t *__restrict__ bases, unsigned n_chunks, int level,
+                                                           unsigned first_dst, unsigned count) {
+  __shared__ uint32_t s_acc[kMtN];
+  __shared__ uint32_t s_ext[kMtN + 32];
+  if (blockIdx.x >= count) return;
+  const unsigned dst_chunk = first_dst + blockIdx.x;
+  uint32_t *stream_bases = bases + static_cast<size_t>(blockIdx.y) * n_chunks * kMtN;
+  const uint32_t *src = stream_bases + static_cast<size_t>(dst_chunk - (1u << level)) * kMtN;
+  uint32_t *dst = stream_bases + static_cast<size_t>(dst_chunk) * kMtN;
+  const int t = threadIdx.x;
+  if (t < kMtN) {
+    s_ext[t] = src[t];
+    s_acc[t] = 0u;
+  }
+  __syncthreads();
+  if (t < 31) s_ext[kMtN + t] = s_ext[t + 397] ^ mt_mix(s_ext[t], s_ext[t + 1]);
+  __syncthreads();
+  const uint32_t *g = d_jump_table[level];
+  int h = 0;
+  auto slot = [](int i) { return i >= kMtN ? i - kMtN : i; };
+  for (int c = kMtN - 1; c >= 0; --c) {
+    uint32_t chunk = g[c];  // the same word in every lane
+    uint32_t fresh = 0u, x = 0u;
+    if (t >= kMtN - 32 && t < kMtN) {  // the word that enters the window at logical position t
+      const int j = t - (kMtN - 32);
+      fresh = s_acc[slot(slot(h + j) + 397)] ^ mt_mix(s_acc[slot(h + j)], s_acc[slot(slot(h + j) + 1)]);
+    }
+    if (t < kMtN) {
+      while (chunk) {
+        const int b = __builtin_ctz(chunk);
+        x ^= s_ext[t + b];
+        chunk &= chunk - 1u;
+      }
+    }
+    __syncthreads();  // every read of the old window is done
+    h = slot(h + 32);
+    if (t < kMtN) {
+      const int p = slot(h + t);
+      s_acc[p] = (t < kMtN - 32 ? s_acc[p] : fresh) ^ x;
+    }
+    __syncthreads();
+  }
+  if (t < kMtN) dst[t] = s_acc[slot(h + t)];
+}
+
+// bases[b][0] = block `block` of every stream's ring (the state the chunk grid is anchored at)
+__global__ __launch_bounds__(kProduceThreads) void mt_anchor(const uint32_t *__restrict__ rings, unsigned ring_blocks,
+                                                             unsigned long long block, uint32_t *__restrict__ bases,
+                                                             unsigned n_chunks) {
+  const uint32_t *src = rings + (static_cast<size_t>(blockIdx.x) * ring_blocks + block % ring_blocks) * kMtN;
+  uint32_t *dst = bases + static_cast<size_t>(blockIdx.x) * n_chunks * kMtN;
+  if (threadIdx.x < kMtN) dst[threadIdx.x] = src[threadIdx.x];
+}
+
+// one workgroup per (chunk, stream): blocks anchor + chunk * C + 1 .. anchor + chunk * C + C from the chunk's start state
+__global__ __launch_bounds__(kProduceThreads) void mt_produce_chunks(uint32_t *__restrict__ rings, unsigned ring_blocks,
+                                                                     const uint32_t *__restrict__ bases, unsigned n_chunks,
+                                                                     unsigned first_chunk, unsigned long long anchor_block) {
+  __shared__ uint32_t s_blk[2][kMtN];
+  const unsigned chunk = first_chunk + blockIdx.x;
+  uint32_t *ring = rings + static_cast<size_t>(blockIdx.y) * ring_blocks * kMtN;
+  const uint32_t *base = bases + (static_cast<size_t>(blockIdx.y) * n_chunks + chunk) * kMtN;
+  const int i = threadIdx.x;
+  if (i < kMtN) s_blk[0][i] = base[i];
+  __syncthreads();
+  const unsigned long long first_block = anchor_block + static_cast<unsigned long long>(chunk) * kChunkBlocks + 1;
+  for (int k = 0; k < kChunkBlocks; ++k) {
     const uint32_t *o = s_blk[k & 1];
     uint32_t *nw = s_blk[(k & 1) ^ 1];
     if (i < kMtN) {
@@ -273,6 +380,9 @@ struct Rng {
   std::vector<int> pos0, has0;
   std::vector<double> gauss0;
   bool drawn = false;
+  uint32_t *bases = nullptr;  // (streams, n_chunks, 624) start states of the chunks, or nullptr
+  unsigned n_chunks = 0;      // chunks with a start state (0: one workgroup per stream produces in sequence)
+  unsigned long long anchor_block = 0;  // block whose state is bases[.][0]: chunk c = blocks anchor + c C + 1 ...
   hipStream_t stream = nullptr;  // own stream: draws can run beside the main stream
   hipEvent_t ready = nullptr, fence = nullptr;
   bool on_side = false;  // the last draw ran on `stream` and has not been joined yet
@@ -281,6 +391,14 @@ struct Rng {
 unsigned long long window_for(unsigned long long pairs) {
   const double mean = static_cast<double>(pairs) / kAccept;
   return static_cast<unsigned long long>(mean * (1.0 + 1.0 / 1024.0)) + 8192;
+}
+
+// start states of chunks 1 .. n_chunks-1 from chunk 0's by doubling: chunk j = chunk j - 2^l jumped by D 2^l words
+void rng_build_tree(Rng *r, hipStream_t stream) {
+  for (int level = 0; (1u << level) < r->n_chunks; ++level) {
+    const unsigned first = 1u << level, count = std::min(first, r->n_chunks - first);
+    hipLaunchKernelGGL(mt_jump, dim3(count, r->streams), dim3(kProduceThreads), 0, stream, r->bases, r->n_chunks, level, first, count);
+  }
 }
 
 // waits for the draws queued so far and reads the streams' true positions
@@ -307,6 +425,7 @@ void rng_free(Rng *r) {
   if (r->rings) (void)hipFree(r->rings);
   if (r->dyn) (void)hipFree(r->dyn);
   if (r->tiles) (void)hipFree(r->tiles);
+  if (r->bases) (void)hipFree(r->bases);
   if (r->ready) (void)hipEventDestroy(r->ready);
   if (r->fence) (void)hipEventDestroy(r->fence);
   if (r->stream) (void)hipStreamDestroy(r->stream);
@@ -319,7 +438,7 @@ void rng_free(Rng *r) {
 using psh::fail;
 
 extern "C" int psh_rng_create(int n_streams, const uint32_t *keys_host, const int *pos_host, const int *has_gauss_host,
-                              const double *gauss_host, size_t max_draw, void **handle_out) {
+                              const double *gauss_host, size_t max_draw, int n_draws_hint, void **handle_out) {
   PSH_REQUIRE_INIT();
   if (!handle_out || !keys_host || !pos_host) return fail(PSH_EINVAL, "rng_create: NULL pointer");
   if (n_streams < 1 || n_streams > 4096) return fail(PSH_EINVAL, "rng_create: 1..4096 streams");
@@ -335,7 +454,8 @@ extern "C" int psh_rng_create(int n_streams, const uint32_t *keys_host, const in
   const unsigned long long window = psh::window_for((max_draw + 1) / 2);
   // two windows + a block of slack on either side: the ring holds the unread tail of one draw and
   // the whole window of the next
-  r->ring_blocks = static_cast<unsigned>((2 * 4 * window) / psh::kMtN + 8);
+  // chunked production rounds up to whole chunks: one chunk of slack
+  r->ring_blocks = static_cast<unsigned>((2 * 4 * window) / psh::kMtN + 8 + (n_draws_hint > 0 ? psh::kChunkBlocks : 0));
   r->ring_words = static_cast<size_t>(r->ring_blocks) * psh::kMtN;
   r->max_tiles = static_cast<unsigned>((window + psh::kTileAttempts - 1) / psh::kTileAttempts);
   r->key0.assign(keys_host, keys_host + static_cast<size_t>(n_streams) * psh::kMtN);
@@ -365,6 +485,25 @@ extern "C" int psh_rng_create(int n_streams, const uint32_t *keys_host, const in
                              psh::kMtN * 4, hipMemcpyHostToDevice, c.stream));
     }
     PSH_HIP(hipMemcpyAsync(r->dyn, d.data(), d.size() * sizeof(psh::RngDyn), hipMemcpyHostToDevice, c.stream));
+    if (n_draws_hint > 0) {
+      // start states of the chunks the hinted draws will read, by doubling (mt_jump): chunk j = chunk
+      // j - 2^l jumped by D 2^l words, l = 0, 1, ...; on the handle's stream, the first draw waits for it
+      const double words = static_cast<double>(n_draws_hint) * 4.0 * static_cast<double>(window) * 1.01 + 2.0 * psh::kMtN;
+      const double chunk_words = static_cast<double>(psh::kMtN) * psh::kChunkBlocks;
+      // (at most 2^12 chunks at a time: when they are used up the grid is anchored anew at the last block
+      // produced, 3 ms of jumps on the producing stream)
+      unsigned chunks = static_cast<unsigned>(std::min(words / chunk_words + 2.0, 4096.0));
+      r->n_chunks = chunks;
+      PSH_HIP(hipMalloc(reinterpret_cast<void **>(&r->bases), static_cast<size_t>(n_streams) * chunks * psh::kMtN * 4));
+      for (int b = 0; b < n_streams; ++b)
+        PSH_HIP(hipMemcpyAsync(r->bases + static_cast<size_t>(b) * chunks * psh::kMtN, keys_host + static_cast<size_t>(b) * psh::kMtN,
+                               psh::kMtN * 4, hipMemcpyHostToDevice, c.stream));
+      PSH_HIP(hipStreamSynchronize(c.stream));
+      psh::rng_build_tree(r, r->stream);
+      PSH_HIP(hipGetLastError());
+      PSH_HIP(hipEventRecord(r->ready, r->stream));
+      r->on_side = true;  // whoever draws first (on either stream) waits for the start states
+    }
     PSH_HIP(hipStreamSynchronize(c.stream));  // the host vectors die here
     return PSH_OK;
   };
@@ -413,6 +552,27 @@ extern "C" int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, in
     if (int rc = psh::rng_resync(r)) return rc;  // the bounds have drifted apart: read the positions
     want_blocks = blocks_wanted();
     if (!fits(want_blocks)) return fail(PSH_EUNSUPPORTED, "rng_randn: word ring too small for this sequence of draws");
+  }
+  // whole chunks from their own start states, each by its own workgroup, while start states last
+  // (produced_blocks - 1 stays a multiple of the chunk length on this path)
+  while (want_blocks > r->produced_blocks && r->bases) {
+    unsigned long long rel = r->produced_blocks - 1 - r->anchor_block;
+    if (rel % psh::kChunkBlocks != 0 || rel / psh::kChunkBlocks >= r->n_chunks) {
+      // start states used up (or the sequential producer ran in between): anchor the chunk grid at the
+      // last block produced and jump again - 3 ms on the producing stream
+      r->anchor_block = r->produced_blocks - 1;
+      hipLaunchKernelGGL(psh::mt_anchor, dim3(r->streams), dim3(psh::kProduceThreads), 0, s, r->rings, r->ring_blocks,
+                         r->anchor_block, r->bases, r->n_chunks);
+      psh::rng_build_tree(r, s);
+      rel = 0;
+    }
+    const unsigned long long c0 = rel / psh::kChunkBlocks;
+    unsigned long long c1 = (want_blocks - 1 - r->anchor_block + psh::kChunkBlocks - 1) / psh::kChunkBlocks;  // exclusive
+    c1 = std::min<unsigned long long>(c1, r->n_chunks);
+    if (c1 <= c0 || !fits(r->anchor_block + c1 * psh::kChunkBlocks + 1)) break;
+    hipLaunchKernelGGL(psh::mt_produce_chunks, dim3(static_cast<unsigned>(c1 - c0), r->streams), dim3(psh::kProduceThreads), 0, s,
+                       r->rings, r->ring_blocks, r->bases, r->n_chunks, static_cast<unsigned>(c0), r->anchor_block);
+    r->produced_blocks = r->anchor_block + c1 * psh::kChunkBlocks + 1;
   }
   if (want_blocks > r->produced_blocks) {
     const unsigned long long n = want_blocks - r->produced_blocks;

@@ -23,9 +23,13 @@ __all__ = ["DeviceRandomStates"]
 class DeviceRandomStates:
     """``len(randstates)`` legacy MT19937 generators continued on the device.
 
-    ``max_draw``: the largest number of values one :meth:`randn` call will ask for per generator."""
+    ``max_draw``: the largest number of values one :meth:`randn` call will ask for per generator.
+    ``n_draws``: how many such draws are expected (0 / None: unknown).  With a hint the streams are cut
+    into chunks whose start states come from MT19937's jump-ahead polynomials, so that a draw is
+    produced by hundreds of workgroups instead of one per generator; draws beyond the hint still work
+    (one workgroup per generator)."""
 
-    def __init__(self, randstates, max_draw):
+    def __init__(self, randstates, max_draw, n_draws=None):
         self._lib = _lib.lib()
         self.randstates = list(randstates)
         if not self.randstates:
@@ -47,7 +51,7 @@ class DeviceRandomStates:
         c = np.asarray(cached, dtype=np.float64)
         handle = ctypes.c_void_p()
         _lib.check(self._lib.psh_rng_create(self.n, k.ctypes.data, p.ctypes.data, h.ctypes.data, c.ctypes.data,
-                                            self.max_draw, ctypes.byref(handle)), "psh_rng_create")
+                                            self.max_draw, int(min(n_draws or 0, 1 << 20)), ctypes.byref(handle)), "psh_rng_create")
         self._h = handle
 
     def randn(self, *shape, out=None, side=False):

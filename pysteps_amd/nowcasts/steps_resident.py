@@ -185,7 +185,7 @@ class ResidentSteps:
         self.min_key = DeviceArray((8,), np.uint64)
         self.eps = DeviceArray((self.L, m, n), np.float64)  # cascade of one member's noise field
         self.noise = DeviceArray((m, n), np.float64)
-        self.rng = DeviceRandomStates(gens, self.plane)
+        self.rng = DeviceRandomStates(gens, self.plane, n_draws=min(self.n_updates, 4096))
         self.white = [DeviceArray((self.B, m, n), np.float64), DeviceArray((self.B, m, n), np.float64)]
         self._white_ready = False
 

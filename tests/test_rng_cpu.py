@@ -109,3 +109,71 @@ def test_correct_rounding_moves_few_values_by_few_ulps():
     assert d.max() <= 4
     assert np.count_nonzero(d) < 0.005 * d.size
     assert a.get_state()[2:] == b.get_state()[2:]
+
+
+def _jump_table():
+    import re
+
+    text = open(os.path.join(ROOT, "pysteps_amd", "csrc", "mt_jump_tables.h")).read()
+    chunk_blocks = int(re.search(r"PSH_MT_CHUNK_BLOCKS (\d+)", text).group(1))
+    rows = re.findall(r"\{([^}]*)\}", text[text.index("PSH_MT_JUMP_TABLE"):])
+    table = np.array([[int(v.strip().rstrip("u"), 16) for v in row.split(",")] for row in rows], dtype=np.uint64)
+    return chunk_blocks, table
+
+
+def _mix(a, b):
+    y = (a & np.uint64(0x80000000)) | (b & np.uint64(0x7FFFFFFF))
+    return (y >> np.uint64(1)) ^ np.where(b & np.uint64(1), np.uint64(0x9908B0DF), np.uint64(0))
+
+
+def _horner32(poly_words, window):
+    """g(A) window the way csrc/rng.hip `mt_jump` evaluates it: 32 coefficients per round, the window as a
+    ring whose 32 dropped words are overwritten by the 32 new ones"""
+    n = 624
+    ext = np.concatenate([window, np.zeros(32, np.uint64)])
+    t = np.arange(31)
+    ext[n + t] = ext[t + 397] ^ _mix(ext[t], ext[t + 1])
+    acc = np.zeros(n, np.uint64)
+    idx = np.arange(n)
+    for c in range(n - 1, -1, -1):
+        chunk = int(poly_words[c])
+        j = np.arange(32)
+        fresh = acc[j + 397] ^ _mix(acc[j], acc[j + 1])  # logical indexing: acc is kept in logical order here
+        x = np.zeros(n, np.uint64)
+        while chunk:
+            b = (chunk & -chunk).bit_length() - 1
+            x ^= ext[idx + b]
+            chunk &= chunk - 1
+        acc = np.concatenate([acc[32:], fresh]) ^ x
+    return acc
+
+
+def test_jump_polynomials_move_a_numpy_generator_by_whole_chunks():
+    """mt_jump_tables.h (tools/gen_mt_jump.py): level l jumps a state 624 * 512 * 2^l words ahead - checked
+    against NumPy drawing that many words, with the 32-coefficients-per-round Horner rule of the kernel"""
+    chunk_blocks, table = _jump_table()
+    assert table.shape[1] == 624 and table.shape[0] >= 10
+    rs = np.random.RandomState(2024)
+    rs.random_sample(5)  # somewhere inside a block: the key array is what jumps, not the position
+    key = rs.get_state()[1].astype(np.uint64)
+    for level in (0, 1, 3):
+        words = 624 * chunk_blocks << level
+        twin = np.random.RandomState()
+        twin.set_state(("MT19937", key.astype(np.uint32), 624, 0, 0.0))
+        twin.randint(0, 1 << 32, size=words, dtype=np.uint32)  # exactly one word each: the key is now `words` ahead
+        want = twin.get_state()[1].astype(np.uint64)
+        got = _horner32(table[level], key)
+        np.testing.assert_array_equal(got[1:], want[1:])
+        assert (int(got[0]) ^ int(want[0])) >> 31 == 0  # the low 31 bits of the first word are never read
+
+
+def test_jump_table_is_what_the_generator_writes(tmp_path):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_mt_jump", os.path.join(ROOT, "tools", "gen_mt_jump.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(gen.OUT).read()
+    gen.OUT = str(tmp_path / "t.h")
+    gen.main()
+    assert open(gen.OUT).read() == committed

@@ -154,3 +154,27 @@ def test_full_size_field_4096():
         _check_values(got.view(j).to_host(), rs.randn(4096, 4096))
     for a, rs in zip(dev.get_states(), host):
         _same_state(a, rs.get_state())
+
+
+@pytest.mark.parametrize("shape,hint,draws", [((512, 512), 8, 4), ((512, 512), 1, 5), ((64, 64), 50, 6), ((1500, 1024), 2, 4)])
+def test_chunked_production_by_jump_ahead(shape, hint, draws):
+    """n_draws given: the streams are cut into chunks of 512 blocks whose start states come from the
+    jump-ahead polynomials (mt_jump), every chunk produced by its own workgroup - the same words, so the
+    same values and the same generator states as NumPy; when the hinted start states are used up the
+    chunk grid is anchored anew at the last block produced and the stream goes on"""
+    from pysteps_amd.noise.randstate import DeviceRandomStates
+
+    host = _steps_chain(99, 3)
+    host[2].random_sample(3)
+    twin = [np.random.RandomState() for _ in host]
+    for t, h in zip(twin, host):
+        t.set_state(h.get_state())
+    dev = DeviceRandomStates(twin, int(np.prod(shape)), n_draws=hint)
+    for draw in range(draws):
+        got = dev.randn(*shape, side=bool(draw & 1))
+        dev.wait()
+        got = got.to_host()
+        for j, rs in enumerate(host):
+            _check_values(got[j], rs.randn(*shape))
+        for a, rs in zip(dev.get_states(), host):
+            _same_state(a, rs.get_state())

@@ -14,7 +14,8 @@ m = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 host = [np.random.RandomState(100 + j) for j in range(B)]
-dev = DeviceRandomStates([np.random.RandomState(100 + j) for j in range(B)], m * m)
+hint = int(sys.argv[4]) if len(sys.argv) > 4 else T + 2
+dev = DeviceRandomStates([np.random.RandomState(100 + j) for j in range(B)], m * m, n_draws=hint)
 out = DeviceArray((B, m, m), np.float64)
 dev.randn(m, m, out=out)
 synchronize()
@@ -27,5 +28,5 @@ ms = e0.elapsed_ms(e1) / T
 t = time.perf_counter()
 host[0].randn(m, m)
 host_s = time.perf_counter() - t
-print(json.dumps({"size": m, "members": B, "device_ms_per_draw_all_members": ms, "numpy_s_per_member": host_s,
+print(json.dumps({"size": m, "members": B, "n_draws_hint": hint, "device_ms_per_draw_all_members": ms, "numpy_s_per_member": host_s,
                   "values_per_s": B * m * m / ms * 1e3}))
