@@ -47,7 +47,9 @@ constexpr int kTileX = 64;
 // kernel flavours: direct gathers (one pixel per lane), LDS-staged tiles, direct gathers with
 // two horizontally adjacent pixels per lane
 // kModePacked: {u,v} interleaved velocity plane; kModePacked2: that plus the row-pair field plane
-enum : int { kModeDirect = 0, kModeStaged = 1, kModePairX = 2, kModePacked = 3, kModePacked2 = 4 };
+// kModeWave: packed velocity plane, every WAVE stages the bounding box of its own samples in LDS
+enum : int { kModeDirect = 0, kModeStaged = 1, kModePairX = 2, kModePacked = 3, kModePacked2 = 4, kModeWave = 5 };
+constexpr bool is_wave(int mode) { return mode == kModeWave; }
 constexpr int kWavesPerBlock = 4;   // LDS-staged variants: 4 waves (rows) per workgroup
 // the direct kernel runs 8 rows per workgroup: the tap row below a wave's pixels is the row the next
 // wave samples, more rows per workgroup = more of that reuse in the CU's L1 (1.55 -> 1.50 ms)
@@ -313,7 +315,11 @@ __device__ __forceinline__ void sample_velocity_border(const Fields &F, int X, i
 // (strong deformation) fall back to the direct path, block-uniformly.
 constexpr int kStageCap = 1792;  // floats per plane (7 KiB); 3 planes -> 21 KiB per workgroup
 
+struct WaveFetch;
 struct Stage {
+  const WaveFetch *fetch;  // kModeWave: per-lane constants of the staged fetch
+  unsigned lds;            // kModeWave: LDS byte address of the wave's region (scalar)
+  unsigned lds_v, lds_p;   // ... and of its two planes, as opaque lane values (address arithmetic on VALU)
   float *buf;    // [3][kStageCap]
   int *red;      // [2][8] packed per-wave bounding boxes, double buffered
   int x0, y0;    // tile origin: positions are reduced relative to it in 16 bits
@@ -424,6 +430,149 @@ __device__ __forceinline__ bool sample_staged(const Fields &F, Stage &S, const i
   return true;
 }
 
+// ---- per-wave LDS staging over the packed planes ------------------------------------------------
+// The direct kernels ask the CU's vector memory pipeline for 16 B per lane and tap row although
+// neighbouring lanes and rows want the same bytes again: 80 B per pixel and lead step for 36 B of
+// unique data, and that pipeline (64 B/clk) is the unit the kernel saturates.
+// Here a wave owns 64 x 4 pixels (4 rows per lane).  Per sampling pass it reduces the bounding box
+// of its 256 sample positions (four interleaved v_min/v_max_i32_dpp chains, read back with
+// v_readlane) and fetches the box - the pixels plus the halo the motion's shear needs - with
+// `buffer_load_dwordx4 ... lds`: consecutive lanes carry consecutive 16-byte items, the data goes
+// from the texture path straight into the wave's own LDS region (no VGPRs, no ds_write).  The box
+// has a FIXED pitch of 72 pixels (36 velocity items / 18 field items per row) and at most 7 rows,
+// so which (row, column) a lane fetches in the k-th instruction is a per-lane constant: the
+// instruction's address is that constant + a scalar offset (the box origin), no address
+// arithmetic at all, and the tap rows sit at immediate LDS offsets.  A 72 x 6 box of {u,v} pairs
+// = 4 instructions instead of the 8 dwordx4 gathers of 4 pixels; the field (plain plane, 4
+// pixels per item) 2 instead of 4.  Nothing is shared between waves: no barrier, and the hazard
+// between a pass's LDS reads and the next pass's LDS-DMA writes is a data dependence (the next box is
+// a function of the values read).  A box that does not fit (shear of more than ~6 pixels across
+// the 64 x 4 patch, a lost trajectory parked far away) falls back to the direct gathers, wave by
+// wave and pass by pass; both paths blend the same values in the same order.
+constexpr int kBoxPitch = 72;                           // pixels per box row
+constexpr int kBoxRows = 7;
+constexpr int kWaveVelItems = 256;                      // 16-byte items: kBoxRows * 36 = 252
+constexpr int kWaveFieldItems = 128;                    // kBoxRows * 18 = 126
+constexpr int kWaveLdsFloats = (kWaveVelItems + kWaveFieldItems) * 4;  // 6 KiB per wave
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+typedef __attribute__((address_space(3))) float lds_f32;
+
+// per-lane constants of the staged fetch: byte offset (relative to the box origin) of the item
+// this lane fetches in the k-th instruction
+struct WaveFetch {
+  unsigned vel[kWaveVelItems / 64];
+  unsigned field[kWaveFieldItems / 64];
+};
+
+__device__ __forceinline__ WaveFetch make_wave_fetch(int n) {
+  WaveFetch w;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < kWaveVelItems / 64; ++k) {
+    const int item = lane + 64 * k, row = item / (kBoxPitch / 2), col = item - row * (kBoxPitch / 2);
+    w.vel[k] = static_cast<unsigned>(row * n + 2 * col) << 3;
+  }
+#pragma unroll
+  for (int k = 0; k < kWaveFieldItems / 64; ++k) {
+    const int item = lane + 64 * k, row = item / (kBoxPitch / 4), col = item - row * (kBoxPitch / 4);
+    w.field[k] = static_cast<unsigned>(row * n + 4 * col) << 2;
+  }
+  return w;
+}
+
+// The box is CHOSEN from the four corner samples of the 64 x 4 patch (eight v_readlane + scalar
+// min / max: exact when the motion is affine across the patch) and VERIFIED for every sample by the
+// two differences the LDS address needs anyway, compared against the box while the fetch is in
+// flight.  (A first version reduced the exact bounding box with four interleaved 6-step
+// v_min/v_max_i32_dpp chains per pass: 98 VALU instructions per pixel and lead step instead of 68,
+// 88 % VALU-bound - profiles/r03/i_semilag_wave_pmc.csv.)
+// 0: sampled from LDS; 1: every tap inside the image, but the box does not fit; 2: border wave
+__device__ __forceinline__ int smin(int a, int b) {
+  int r;
+  asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+  return r;
+}
+__device__ __forceinline__ int smax(int a, int b) {
+  int r;
+  asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+  return r;
+}
+
+template <int NPX, bool WITH_P>
+__device__ __forceinline__ int sample_wave_staged(const Fields &F, Stage &S, const WaveFetch &wf, const int (&X)[NPX],
+                                                   const int (&Y)[NPX], const float (&fx)[NPX],
+                                                   const float (&fy)[NPX], int m, int n, float (&su)[NPX],
+                                                   float (&sv)[NPX], float (&sp)[NPX]) {
+  const int xa = __builtin_amdgcn_readlane(X[0], 0), xb = __builtin_amdgcn_readlane(X[0], 63);
+  const int xc = __builtin_amdgcn_readlane(X[NPX - 1], 0), xd = __builtin_amdgcn_readlane(X[NPX - 1], 63);
+  const int ya = __builtin_amdgcn_readlane(Y[0], 0), yb = __builtin_amdgcn_readlane(Y[0], 63);
+  const int yc = __builtin_amdgcn_readlane(Y[NPX - 1], 0), yd = __builtin_amdgcn_readlane(Y[NPX - 1], 63);
+  const int rx = smax((smin(smin(xa, xb), smin(xc, xd)) - 1) & ~3, 0);  // one pixel of slack, 16-byte aligned
+  const int by0 = smax(smin(smin(ya, yb), smin(yc, yd)), 0);
+  const int H = smin(smax(smax(ya, yb), smax(yc, yd)) - by0 + 2, kBoxRows);  // lower tap row included
+  // what a sample's offset inside the box may be: all four taps inside the box and inside the image
+  const int dx_max = smin(kBoxPitch - 2, n - 2 - rx), dy_max = smin(H - 2, m - 2 - by0);
+  const int lane = threadIdx.x & 63;
+  const int items_v = H * (kBoxPitch / 2), items_p = H * (kBoxPitch / 4);
+  const int org = by0 * n + rx;
+  const bool fetch = dx_max >= 0 && dy_max >= 0;  // a patch outside the image fetches nothing
+  if (fetch) {
+#pragma unroll
+    for (int k = 0; k < kWaveVelItems / 64; ++k) {
+      if (k * 64 >= items_v) break;
+      if (lane + 64 * k < items_v)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(F.ruv, (lds_void *)(size_t)(S.lds + 1024u * k), 16,
+                                                 static_cast<int>(wf.vel[k]), org << 3, 0, 0);
+    }
+    if (WITH_P) {
+#pragma unroll
+      for (int k = 0; k < kWaveFieldItems / 64; ++k) {
+        if (k * 64 >= items_p) break;
+        if (lane + 64 * k < items_p)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(F.rp, (lds_void *)(size_t)(S.lds + kWaveVelItems * 16u + 1024u * k), 16,
+                                                   static_cast<int>(wf.field[k]), org << 2, 0, 0);
+      }
+    }
+  }
+  int o[NPX];
+  unsigned dx_hi = 0, dy_hi = 0;  // as unsigned numbers: a negative difference is a huge one
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    const int dx = X[j] - rx, dy = Y[j] - by0;
+    dx_hi = max(dx_hi, static_cast<unsigned>(dx));
+    dy_hi = max(dy_hi, static_cast<unsigned>(dy));
+    o[j] = __mul24(dy, kBoxPitch) + dx;
+  }
+  const bool ok = dx_hi <= static_cast<unsigned>(dx_max) && dy_hi <= static_cast<unsigned>(dy_max);
+  const bool all_ok = fetch && __builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also on the way out: the region is fetched into again
+  if (!all_ok) {
+    bool inside = true;
+#pragma unroll
+    for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(X[j], Y[j], m, n);
+    return inside ? 1 : 2;
+  }
+  // LDS byte addresses: one shift-add per plane on top of the item index; the tap rows are immediates
+  const unsigned vbase = S.lds_v, pbase = S.lds_p;
+#pragma unroll
+  for (int j = 0; j < NPX; ++j) {
+    const lds_f32x2 *lv = (const lds_f32x2 *)(size_t)(vbase + (static_cast<unsigned>(o[j]) << 3));
+    const lds_f32 *lp = (const lds_f32 *)(size_t)(pbase + (static_cast<unsigned>(o[j]) << 2));
+    const f32x2 t0 = lv[0], t1 = lv[1], b0 = lv[kBoxPitch], b1 = lv[kBoxPitch + 1];
+    const Weights w = make_weights(fx[j], fy[j]);
+    f32x2 acc = t0 * w.w00;  // the order of sample_interior_packed
+    acc = __builtin_elementwise_fma(f32x2{w.w01, w.w01}, t1, acc);
+    acc = __builtin_elementwise_fma(f32x2{w.w10, w.w10}, b0, acc);
+    acc = __builtin_elementwise_fma(f32x2{w.w11, w.w11}, b1, acc);
+    su[j] = acc.x;
+    sv[j] = acc.y;
+    if (WITH_P) sp[j] = blend(w, lp[0], lp[1], lp[kBoxPitch], lp[kBoxPitch + 1]);
+  }
+  return 0;
+}
+
 template <int ORDER, bool GEN>
 __device__ __forceinline__ float sample_precip_off_fast(const float *p, int X, int Y, float fx, float fy, int m,
                                                         int n, float outval, int bmode) {
@@ -451,12 +600,20 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
     }
     return;
   }
-  bool inside = true;
+  bool inside = true, staged = false;
+  if (is_wave(MODE)) {
+    // the bounding box of the wave's samples answers both questions
+    const int st = sample_wave_staged<NPX, kWithP && ORDER == 1>(F, S, *S.fetch, X, Y, fx, fy, m, n, su, sv, sp);
+    staged = st == 0;
+    inside = st != 2;
+  } else {
 #pragma unroll
-  for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(X[j], Y[j], m, n);
+    for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(X[j], Y[j], m, n);
+  }
   // wave-uniform branch: interior waves (almost all of them) skip every clamp
   if (inside) {
-    if (MODE == kModePacked || MODE == kModePacked2) {
+    if (staged) {
+    } else if (MODE == kModePacked || MODE == kModePacked2 || is_wave(MODE)) {
 #pragma unroll
       for (int j = 0; j < NPX; ++j)
         sample_interior_packed<kWithP && ORDER == 1, MODE == kModePacked2>(F, X[j], Y[j], fx[j], fy[j], n, su[j], sv[j],
@@ -496,11 +653,17 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
 // contains the "constant" rule and none of the folding code
 template <int MODE>
 constexpr int waves_of() {
-  return (MODE == kModeDirect || MODE == kModePacked || MODE == kModePacked2) ? kDirectWaves : kWavesPerBlock;
+  return (MODE == kModeDirect || MODE == kModePacked || MODE == kModePacked2) ? kDirectWaves : kWavesPerBlock;  // kModeWave: 4
+}
+
+// kModeWave: 128 registers at most, so that four workgroups (16 waves) share a CU
+template <int MODE>
+constexpr int min_waves_per_simd() {
+  return is_wave(MODE) ? 4 : 1;
 }
 
 template <int NPX, int ORDER, bool HAS_PRECIP, int MODE, bool GEN>
-__global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
+__global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>()) void semilag_fused(
     const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vel_packed,
     const float *__restrict__ field_pairs, float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
@@ -527,7 +690,7 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
   F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
   F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_PRECIP ? precip : vel), 0, plane_bytes,
                                            0x00020000);
-  constexpr bool kPackedVel = MODE == kModePacked || MODE == kModePacked2;
+  constexpr bool kPackedVel = MODE == kModePacked || MODE == kModePacked2 || is_wave(MODE);
   F.ruv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(kPackedVel ? vel_packed : vel), 0, 2 * plane_bytes,
                                             0x00020000);
   F.rpp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == kModePacked2 ? field_pairs : vel), 0,
@@ -537,14 +700,27 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
   F.minval = minval;
   F.bmode = bmode;
 
-  __shared__ float stage_buf[MODE == kModeStaged ? 3 * kStageCap : 1];
-  __shared__ int stage_red[16];
+  __shared__ __attribute__((aligned(16))) float
+      stage_buf[MODE == kModeStaged ? 3 * kStageCap : (is_wave(MODE) ? kWavesPerBlock * kWaveLdsFloats : 4)];
+  __shared__ __attribute__((aligned(16))) int stage_red[16];
   Stage S;
-  S.buf = stage_buf;
+  S.buf = stage_buf + (is_wave(MODE) ? (threadIdx.x >> 6) * kWaveLdsFloats : 0);
   S.red = stage_red;
   S.x0 = (tile % tiles_x) * kTileX;
   S.y0 = row0 + (tile / tiles_x) * (kWaves * NPX);
   S.parity = 0;
+  WaveFetch wave_fetch;
+  if (is_wave(MODE)) wave_fetch = make_wave_fetch(n);
+  S.fetch = &wave_fetch;
+  S.lds = S.lds_v = S.lds_p = 0;
+  if (MODE == kModeWave) {
+    S.lds = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)S.buf)));
+    S.lds_v = S.lds;
+    S.lds_p = S.lds + kWaveVelItems * 16u;
+    // kept apart from the compiler's constant folding: "base + 4096" does not fit the 8-bit offsets of
+    // ds_read2 and would be re-added per tap row
+    asm volatile("" : "+v"(S.lds_v), "+v"(S.lds_p));
+  }
 
   // trajectory state per pixel: absolute integer position + fraction, and the increment
   int y[NPX], px[NPX], py[NPX];
@@ -677,6 +853,10 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
       }
     }
     if (HAS_PRECIP) {
+      // kModeWave: the plane of this lead time as a buffer - scalar descriptor + 32-bit lane offset;
+      // four 64-bit lane addresses carried through the loop cost 8 registers this variant does not have
+      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+          out, 0, is_wave(MODE) ? rows * n * static_cast<int>(sizeof(float)) : 0, 0x00020000);
 #pragma unroll
       for (int j = 0; j < NPX; ++j) {
         // Non-finite velocities (allow_nonfinite_values, semilagrangian.py:106-137): a trajectory that
@@ -685,8 +865,12 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>()) void semilag_fused(
         // the "constant" mode (and the folding modes), with NaN where it interpolates across it.
         sp[j] = lost(fx[j], fy[j]) ? lostval : sp[j];
         // streamed once, never re-read: keep the output out of the L2 ways the input planes live in
-        if (live[j])
+        if (is_wave(MODE)) {
+          if (live[j])
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sp[j]), rout, static_cast<int>(opix[j]), 0, 2 /* nt */);
+        } else if (live[j]) {
           __builtin_nontemporal_store(sp[j], reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
+        }
       }
       out += static_cast<size_t>(rows) * n;
     }
@@ -771,6 +955,10 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
     if (g_semilag_variant == 6) return launch_variant<2, kModePacked2>(a, stream);  // two rows per lane (experiment)
     return launch_variant<1, kModePacked2>(a, stream);
   }
+  // variant 8: per-wave LDS staging of the packed velocity plane and the plain field plane
+  if (a.vel_packed != nullptr && g_semilag_variant == 8 && a.order == 1 && aligned &&
+      reinterpret_cast<uintptr_t>(a.vel_packed) % 16 == 0)
+    return launch_variant<4, kModeWave>(a, stream);
   if (a.vel_packed != nullptr) return launch_variant<1, kModePacked>(a, stream);
   return launch_variant<1, kModeDirect>(a, stream);
 }
@@ -781,12 +969,13 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
 // sampling pass of a 4096^2 step: they pay off from ~8 sampling steps on.  Shorter calls - the
 // single-step calls of a generic nowcast loop - take the planar kernel (bit-identical results).
 bool semilag_wants_packed(const SemilagArgs &a) {
-  return (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 6) &&
+  return (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 6 || g_semilag_variant == 8) &&
          static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29) &&
          static_cast<long long>(a.T) * (a.n_iter > 0 ? a.n_iter : 1) >= 8;
 }
 // variant 0 also samples the field from a row-pair plane (one dwordx4 per sample); 5 = packed
-// velocity only (two dwordx2 for the field), kept for comparison
+// velocity only (two dwordx2 for the field), kept for comparison; variant 8 stages the plain field
+// plane through LDS and needs no second copy of it
 bool semilag_wants_field_pairs(const SemilagArgs &a) {
   return (g_semilag_variant == 0 || g_semilag_variant == 6) && semilag_wants_packed(a) && a.precip != nullptr &&
          a.order == 1 && a.T >= 8;

@@ -279,11 +279,12 @@ def test_device_resident_path(extrapolate):
     assert np.array_equal(dev_disp.to_host(), host_disp)  # displacement_prev untouched
 
 
-@pytest.mark.parametrize("variant", [1, 3, 2, 4])
+@pytest.mark.parametrize("variant", [1, 3, 8, 2, 4])
 def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
-    """The one-plane-per-component kernel with DPP column sharing (variant 1, the round-1 default)
-    and the three-pixels-per-lane kernel (variant 3) are bit-identical to the default kernel (packed
-    {u,v} plane, dwordx4 gathers); the LDS-staged kernels (2, 4) agree to rounding."""
+    """The one-plane-per-component kernel with DPP column sharing (variant 1, the round-1 default),
+    the three-pixels-per-lane kernel (variant 3) and the kernel that stages every wave's bounding box
+    in LDS (variant 8) are bit-identical to the default kernel (packed {u,v} plane, dwordx4 gathers);
+    the workgroup-staged kernels (2, 4) agree to rounding."""
     from pysteps_amd import _lib
     from tools import synth
 
@@ -300,15 +301,21 @@ def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
     cases.append((p, v, 3, dict(n_iter=0)))
     cases.append((pn, v, 3, dict(allow_nonfinite_values=True)))
     cases.append((p, v, 2, dict(interp_order=0, outval=-15.0)))
+    # long calls (the packed planes): boxes that fit, boxes that do not (shear), a hole in the motion field
+    cases.append((pn, v, 12, dict(n_iter=1, allow_nonfinite_values=True)))
+    vh = (4.0 * v).astype(np.float32)
+    vh[:, 60:66, 100:111] = np.nan
+    cases.append((pn, vh, 10, dict(n_iter=2, allow_nonfinite_values=True, outval=-15.0)))
     base = [extrapolate(a, b, t, return_displacement=True, **kw) for a, b, t, kw in cases]
     _lib.check(lib.psh_set_option(b"semilag_variant", variant))
     try:
         for (a, b, t, kw), (want, wdisp) in zip(cases, base):
             got, gdisp = extrapolate(a, b, t, return_displacement=True, **kw)
             assert nan_mismatch(got, want) == 0
-            assert np.max(np.abs(gdisp - wdisp)) < 1e-5
-            if variant in (1, 3):
-                assert np.array_equal(got, want, equal_nan=True) and np.array_equal(gdisp, wdisp)
+            assert np.array_equal(np.isnan(gdisp), np.isnan(wdisp))
+            assert np.nanmax(np.abs(gdisp - wdisp)) < 1e-5
+            if variant in (1, 3, 8):
+                assert np.array_equal(got, want, equal_nan=True) and np.array_equal(gdisp, wdisp, equal_nan=True)
             elif kw.get("interp_order", 1) == 0:
                 assert np.count_nonzero(got != want) <= 1e-4 * got.size
             else:

@@ -37,6 +37,19 @@ def run(tag):
         o = adv.step(members, [1.0, 1.0])
         o = adv.step(members, [1.0])
         res["%dx%d members" % (m, n)] = [digest(o), digest(adv.displacement.to_host())]
+    # long calls (the packed-plane kernels): gentle and strong shear, a hole in the motion field
+    for (m, n) in ((1024, 1024), (300, 260), (96, 4096)):
+        p = synth.rain_field_db(m, n)
+        p[synth.border_nan_mask(m, n)] = np.nan
+        for gain in (1.0, 6.0):
+            v = synth.true_velocity(m, n) * gain
+            if gain > 1.0:
+                v[:, m // 3:m // 3 + 5, n // 2:n // 2 + 9] = np.nan
+            for k in (0, 1, 2):
+                for order in (0, 1):
+                    out, d = ex(p, v, 10, outval=-15.0, n_iter=k, interp_order=order, allow_nonfinite_values=True,
+                                return_displacement=True)
+                    res["long %dx%d g%g o%d k%d" % (m, n, gain, order, k)] = [digest(out), digest(d)]
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/bitcheck_%s.json" % tag, "w") as f:
         json.dump(res, f, indent=1)
