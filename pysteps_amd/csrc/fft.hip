@@ -31,6 +31,7 @@
 // transforms above with a pointwise product in between (the spectrum of the chirp is a table per
 // length, computed once on the device).  One side up to 4096 (M <= 8192 = the LDS transform limit).
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -299,6 +300,9 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__res
   const int c0 = g * cols;
   const int live = min(cols, nc - c0);
   const int pitch = lds_elems(len);
+  // (Starting every group's walk down its columns at its own row - against all workgroups asking for
+  // the same rows, 32 KiB + 16 B apart, at the same time - was measured 7 % SLOWER at 4096^2: groups
+  // that share 128-byte lines then no longer ask for them together, and the lines leave the L2 in between.)
   for (int idx = threadIdx.x; idx < len * cols; idx += blockDim.x) {
     const int r = idx / cols, c = idx - r * cols;
     double2 v = make_double2(0.0, 0.0);
@@ -440,17 +444,24 @@ int check_shape(const char *who, int m, int n, Dft *rows, Dft *cols) {
 int launch_cols(bool inverse, const double2 *in, const Dft &d, int nc, double scale, double2 *out,
                 hipStream_t stream, const double *weights = nullptr) {
   const int len = 1 << d.logm;
-  const int cols = len <= 4096 ? 2 : 1;
+  // development knobs (tools/fft_quick.py): columns per workgroup / threads per workgroup of this pass
+  static const int forced_cols = [] { const char *e = std::getenv("PYSTEPS_HIP_FFT_COLS"); return e ? std::atoi(e) : 0; }();
+  static const int forced_threads = [] { const char *e = std::getenv("PYSTEPS_HIP_FFT_COL_THREADS"); return e ? std::atoi(e) : 0; }();
+  // two columns per workgroup share 32-byte sectors; at 1024 and 2048 points one column per workgroup
+  // of 256 threads (more workgroups per CU) measured 16 % / 6 % faster, at 4096 the two are equal
+  const bool narrow = len == 1024 || len == 2048;
+  const int cols = forced_cols > 0 && forced_cols * len <= 8192 ? forced_cols : (len <= 4096 && !narrow ? 2 : 1);
   const int groups = (nc + cols - 1) / cols;
   const int gpx = (groups + kNumXcd - 1) / kNumXcd;
   const size_t lds = static_cast<size_t>(cols) * lds_elems(len) * sizeof(double2);
+  const int threads = forced_threads > 0 ? forced_threads : (narrow && cols == 1 ? 256 : fft_threads(cols * len / 2));
   if (inverse) {
     if (int rc = allow_lds(fft_cols_c2c<true>, lds)) return rc;
-    hipLaunchKernelGGL(fft_cols_c2c<true>, dim3(gpx * kNumXcd), dim3(fft_threads(cols * len / 2)), lds, stream, in, d, nc, cols,
+    hipLaunchKernelGGL(fft_cols_c2c<true>, dim3(gpx * kNumXcd), dim3(threads), lds, stream, in, d, nc, cols,
                        scale, out, groups, gpx, weights);
   } else {
     if (int rc = allow_lds(fft_cols_c2c<false>, lds)) return rc;
-    hipLaunchKernelGGL(fft_cols_c2c<false>, dim3(gpx * kNumXcd), dim3(fft_threads(cols * len / 2)), lds, stream, in, d, nc, cols,
+    hipLaunchKernelGGL(fft_cols_c2c<false>, dim3(gpx * kNumXcd), dim3(threads), lds, stream, in, d, nc, cols,
                        scale, out, groups, gpx, weights);
   }
   PSH_HIP(hipGetLastError());
