@@ -71,9 +71,11 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 w) {
 // writes alias the next one's reads and serialises read -> compute -> write with the LDS / L2
 // latency exposed every time (the first version: 12 us per 4096-point transform instead of ~3).
 // Only W_4h^j is fetched per butterfly: W_2h^j is its square and W_4h^(j+h) = -i W_4h^j.
+// `tw` is the table of a length N * tws (entry k * tws = exp(-2 pi i k / N)): sub-transforms of a
+// longer transform read the long table with a stride.
 template <bool INV>
 __device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int logn,
-                                        const double2 *__restrict__ tw) {
+                                        const double2 *__restrict__ tw, int tws = 1) {
   const int N = 1 << logn;
   constexpr int kU = 4;  // butterflies in flight per thread
   int s = 0;
@@ -122,7 +124,7 @@ __device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int lo
         i2[u] = base + lpad(e0 + 2 * h);
         i3[u] = base + lpad(e0 + 3 * h);
         if (live) {
-          w2[u] = tw[j * st2];
+          w2[u] = tw[j * st2 * tws];
           x0[u] = z[i0[u]];
           x1[u] = z[i1[u]];
           x2[u] = z[i2[u]];
@@ -328,6 +330,99 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__res
   }
 }
 
+// ---- long columns in two sweeps (four-step FFT) ------------------------------------------------------
+// fft_cols_c2c holds whole columns in LDS: 2 x 4096 x 16 B per workgroup means 32-byte pieces of 4096
+// different rows - one L1 miss per row and column pair, and the pass is bound by misses in flight x
+// latency (190 us for 134 MB in and out at 4096^2, whatever the occupancy:
+// profiles/r03/i_fft_column_pass_probe.txt).  With N = N1 N2, n = n1 + N1 n2, k = N2 k1 + k2
+//     X[N2 k1 + k2] = sum_n1 W_N1^(n1 k1) [ W_N^(n1 k2) sum_n2 x[n1 + N1 n2] W_N2^(n2 k2) ]
+// a column transform is N1 transforms of length N2 over rows N1 apart (sweep A, which also applies
+// the twiddles W_N^(n1 k2) and leaves Z[n1, k2] at row n1 + N1 k2) followed by N2 transforms of length
+// N1 over N1 CONSECUTIVE rows (sweep B, output row N2 k1 + k2).  A workgroup then needs only 512
+// elements of a column at a time and takes EIGHT columns instead: every row it touches is a
+// 128-byte request.  Twice the traffic of the one-sweep pass, all of it in full lines.
+constexpr int kStepCols = 8;      // columns per workgroup: 128 bytes of a row
+constexpr int kStepElems = 512;   // elements per column and workgroup (64 KiB of LDS in all)
+constexpr int kStepThreads = 512;
+
+__device__ __forceinline__ double2 root_of_unity(const double2 *__restrict__ tw, int p, int half, bool inv) {
+  double2 w = tw[p >= half ? p - half : p];  // W_N^p, p < N: W^(p + N/2) = -W^p
+  if (p >= half) w = make_double2(-w.x, -w.y);
+  if (inv) w.y = -w.y;
+  return w;
+}
+
+// SWEEP 0 (A): sequences (column c, n1), elements n2, rows n1 + N1 n2 -> Z at rows n1 + N1 k2
+// SWEEP 1 (B): sequences (column c, k2), elements n1, rows n1 + N1 k2 -> X at rows N2 k1 + k2
+template <bool INV, int SWEEP>
+__global__ __launch_bounds__(kStepThreads) void fft_cols_step(const double2 *__restrict__ in, const double2 *__restrict__ tw,
+                                                              int logn, int log1, int nc, double scale,
+                                                              double2 *__restrict__ out, int items, int items_per_xcd,
+                                                              int col_tiles, const double *__restrict__ weights) {
+  extern __shared__ double2 z[];
+  const int b = blockIdx.x;
+  const int item = (b % kNumXcd) * items_per_xcd + b / kNumXcd;  // neighbouring column tiles share an L2
+  if (item >= items) return;
+  const int tile = item % col_tiles, group = item / col_tiles;
+  const int log2_ = logn - log1;                      // N2 = 1 << log2_
+  const int N1 = 1 << log1, N2 = 1 << log2_;
+  const int logl = SWEEP == 0 ? log2_ : log1;         // length of this sweep's transforms
+  const int L = 1 << logl;
+  const int per_col = kStepElems >> logl;             // sequences per column in this workgroup
+  const int pitch = L + 2;  // sequences two 16-byte units apart in the banks (the tile is walked across sequences; even: fft_lds pairs slots by ^ 1)
+  const int first = group * per_col;                  // first n1 (A) / k2 (B) of the group
+  const int c0 = tile * kStepCols;
+  const int live = min(kStepCols, nc - c0);
+  // element e of the tile: column e % 8, then (sequence, element) so that consecutive threads read one row
+  for (int idx = threadIdx.x; idx < kStepCols * kStepElems; idx += kStepThreads) {
+    const int c = idx & (kStepCols - 1), q = idx >> 3;
+    int seq, el, row;
+    if (SWEEP == 0) {
+      seq = q & (per_col - 1);  // n1 - first: rows first .. first + per_col - 1 are consecutive
+      el = q / per_col;         // n2
+      row = first + seq + (el << log1);
+    } else {
+      el = q & (L - 1);         // n1: consecutive rows
+      seq = q >> logl;          // k2 - first
+      row = el + ((first + seq) << log1);
+    }
+    double2 v = make_double2(0.0, 0.0);
+    if (c < live) {
+      const size_t at = static_cast<size_t>(row) * nc + c0 + c;
+      v = in[at];
+      if (SWEEP == 0 && weights) {
+        const double w = weights[at];
+        v.x *= w;
+        v.y *= w;
+      }
+    }
+    z[(c * per_col + seq) * pitch + lpad(bitrev(el, logl))] = v;
+  }
+  __syncthreads();
+  fft_lds<INV>(z, pitch, kStepCols * per_col, logl, tw, SWEEP == 0 ? N1 : N2);
+  for (int idx = threadIdx.x; idx < kStepCols * kStepElems; idx += kStepThreads) {
+    const int c = idx & (kStepCols - 1), q = idx >> 3;
+    int seq, k, row;
+    if (SWEEP == 0) {
+      seq = q & (per_col - 1);
+      k = q / per_col;          // k2
+      row = first + seq + (k << log1);
+    } else {
+      seq = q & (per_col - 1);  // k2 - first: rows N2 k1 + k2 of a group are consecutive
+      k = q / per_col;          // k1
+      row = (k << log2_) + first + seq;
+    }
+    if (c >= live) continue;
+    double2 v = z[(c * per_col + seq) * pitch + lpad(k)];
+    if (SWEEP == 0) {
+      v = cmul(v, root_of_unity(tw, (first + seq) * k, 1 << (logn - 1), INV));
+    } else {
+      v = make_double2(v.x * scale, v.y * scale);
+    }
+    out[static_cast<size_t>(row) * nc + c0 + c] = v;
+  }
+}
+
 int ilog2_exact(int v) {
   if (v < 2 || (v & (v - 1)) != 0) return -1;
   int l = 0;
@@ -444,6 +539,35 @@ int check_shape(const char *who, int m, int n, Dft *rows, Dft *cols) {
 int launch_cols(bool inverse, const double2 *in, const Dft &d, int nc, double scale, double2 *out,
                 hipStream_t stream, const double *weights = nullptr) {
   const int len = 1 << d.logm;
+  static const int four_step = [] { const char *e = std::getenv("PYSTEPS_HIP_FFT_FOURSTEP"); return e ? std::atoi(e) : 1; }();
+  // measured (profiles/r03/i_fft_column_pass_probe.txt): 8 % faster than one sweep at 8192 points, equal at
+  // 4096, 15-25 % slower at 1024 / 2048 (PYSTEPS_HIP_FFT_FOURSTEP=2 takes it from 1024 points on)
+  if (four_step && !d.chirp && d.logm >= (four_step == 2 ? 10 : 13)) {
+    // two sweeps over 8-column tiles (fft_cols_step) through a block of the same size
+    void *tmp = nullptr;
+    if (int rc = psh_malloc(&tmp, static_cast<size_t>(len) * nc * sizeof(double2))) return rc;
+    const int log1 = d.logm / 2, log2_ = d.logm - log1;
+    const int col_tiles = (nc + kStepCols - 1) / kStepCols;
+    auto sweep = [&](auto kernel, int logl, int sequences, const double2 *src, double2 *dst, double sc,
+                     const double *w) -> int {
+      const int per_col = kStepElems >> logl;
+      const int items = col_tiles * (sequences / per_col);
+      const int ipx = (items + kNumXcd - 1) / kNumXcd;
+      const size_t lds = static_cast<size_t>(kStepCols) * per_col * ((1 << logl) + 2) * sizeof(double2);
+      if (int rc = allow_lds(kernel, lds)) return rc;
+      hipLaunchKernelGGL(kernel, dim3(ipx * kNumXcd), dim3(kStepThreads), lds, stream, src, d.tw, d.logm, log1, nc, sc, dst,
+                         items, ipx, col_tiles, w);
+      PSH_HIP(hipGetLastError());
+      return PSH_OK;
+    };
+    int rc = inverse ? sweep(fft_cols_step<true, 0>, log2_, 1 << log1, in, static_cast<double2 *>(tmp), 1.0, weights)
+                     : sweep(fft_cols_step<false, 0>, log2_, 1 << log1, in, static_cast<double2 *>(tmp), 1.0, weights);
+    if (rc == PSH_OK)
+      rc = inverse ? sweep(fft_cols_step<true, 1>, log1, 1 << log2_, static_cast<const double2 *>(tmp), out, scale, nullptr)
+                   : sweep(fft_cols_step<false, 1>, log1, 1 << log2_, static_cast<const double2 *>(tmp), out, scale, nullptr);
+    (void)psh_free(tmp);  // stream-ordered
+    return rc;
+  }
   // development knobs (tools/fft_quick.py): columns per workgroup / threads per workgroup of this pass
   static const int forced_cols = [] { const char *e = std::getenv("PYSTEPS_HIP_FFT_COLS"); return e ? std::atoi(e) : 0; }();
   static const int forced_threads = [] { const char *e = std::getenv("PYSTEPS_HIP_FFT_COL_THREADS"); return e ? std::atoi(e) : 0; }();
