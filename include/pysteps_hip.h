@@ -423,6 +423,11 @@ int psh_fft_c2c2_dev(const void *in_dev, int m, int n, int inverse, void *out_de
 int psh_cascade_decompose_dev(const double *field_dev, const double *weights_dev, int nlevels, int m, int n,
                               int normalize, int subtract_mean, double *levels_dev, double *means_host,
                               double *stds_host, double *field_mean_host);
+/* The same with the levels left as the transforms produce them and (mean, std) per level written to
+ * stats_dev (nlevels pairs of doubles, device): nothing waits on the host; the standardisation of
+ * decomposition.py:224-232 is applied by the consumer, psh_steps_ar_recompose_raw_dev, on the way in. */
+int psh_cascade_decompose_stats_dev(const double *field_dev, const double *weights_dev, int nlevels, int m, int n,
+                                    double *levels_dev, double *stats_dev);
 int psh_cascade_recompose_dev(const double *levels_dev, int nlevels, int m, int n, const double *means_host,
                               const double *stds_host, double field_mean, double *out_dev);
 int psh_noise_filter_dev(const double *white_dev, const double *filter_dev, int m, int n, double *out_dev);
@@ -450,6 +455,14 @@ int psh_probmatch_dev(const double *initial_dev, const double *target_dev, size_
 int psh_probmatch_async_dev(const double *initial_dev, const double *target_dev, size_t count, double *out_dev,
                             int *status_dev);
 int psh_probmatch_status(int status);
+/* A target that does not change between calls - the observation nowcasts/steps.py:1199 matches every member
+ * against at every time step; the reference argsorts it again each time (probmatching.py:120-126) - needs its
+ * half of the work once: a plan keeps the target's statistics, verdict and sorted wet values.
+ * psh_probmatch_planned_dev(plan, initial, count, out, status_dev) = psh_probmatch_async_dev against the plan's
+ * target (status_dev NULL: waits and returns the verdict like psh_probmatch_dev).  Identical outputs. */
+int psh_probmatch_plan_create(const double *target_dev, size_t count, void **plan_out);
+int psh_probmatch_plan_destroy(void *plan);
+int psh_probmatch_planned_dev(const void *plan, const double *initial_dev, size_t count, double *out_dev, int *status_dev);
 
 /* ---- incremental precipitation mask of the member loops (csrc/mask.hip) -------- *
  *  psh_dilated_mask_dev  pysteps/nowcasts/utils.py:69-101, compute_dilated_mask(input_mask, kr, r) (nowcasts/
@@ -485,6 +498,13 @@ int psh_steps_ar_recompose_dev(double *cascades_dev, int nlevels, int p, size_t 
                                const double *phi_host, const double *eps_dev, const double *eps_scale_host,
                                const double *mu_host, const double *sigma_host, double *field_dev,
                                unsigned long long *min_key_dev);
+/* eps_dev = unnormalised noise levels, eps_stats_dev = their (mean, std) pairs from
+ * psh_cascade_decompose_stats_dev: eps_k = (eps_k - mean_k) / std_k first, then as above (bit-identical
+ * with standardising in a pass of its own). */
+int psh_steps_ar_recompose_raw_dev(double *cascades_dev, int nlevels, int p, size_t plane, int head,
+                                   const double *phi_host, const double *eps_dev, const double *eps_stats_dev,
+                                   const double *eps_scale_host, const double *mu_host, const double *sigma_host,
+                                   double *field_dev, unsigned long long *min_key_dev);
 int psh_steps_mask_dev(double *field_dev, size_t n, const double *grey_mask_dev, const unsigned char *keep_mask_dev,
                        const unsigned long long *min_key_dev);
 int psh_steps_mean_shift_dev(double *field_dev, size_t n, double threshold, double mu_0);

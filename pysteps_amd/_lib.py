@@ -72,16 +72,22 @@ SIGNATURES = {
     "psh_fft_c2c2_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_cascade_decompose_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                           POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "psh_cascade_decompose_stats_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "psh_cascade_recompose_dev": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_double), POINTER(c_double),
                                           c_double, c_void_p]),
     "psh_noise_filter_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "psh_probmatch_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "psh_probmatch_async_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "psh_probmatch_status": (c_int, [c_int]),
+    "psh_probmatch_plan_create": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "psh_probmatch_plan_destroy": (c_int, [c_void_p]),
+    "psh_probmatch_planned_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "psh_dilated_mask_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_ar_iterate_dev": (c_int, [c_void_p, c_int, c_size_t, POINTER(c_double), c_int, c_void_p, c_void_p]),
     "psh_steps_ar_recompose_dev": (c_int, [c_void_p, c_int, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),
+    "psh_steps_ar_recompose_raw_dev": (c_int, [c_void_p, c_int, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "psh_steps_mask_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "psh_steps_mean_shift_dev": (c_int, [c_void_p, c_size_t, c_double, c_double]),
     "psh_ge_mask_dev": (c_int, [c_void_p, c_size_t, c_double, c_void_p]),

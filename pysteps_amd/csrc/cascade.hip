@@ -167,9 +167,10 @@ int moments(const double *x_dev, int planes, size_t plane, double2 *stats_dev, h
 
 using psh::fail;
 
-extern "C" int psh_cascade_decompose_dev(const double *field_dev, const double *weights_dev, int nlevels, int m,
-                                         int n, int normalize, int subtract_mean, double *levels_dev,
-                                         double *means_host, double *stds_host, double *field_mean_host) {
+// stats_out_dev (nullable): the level statistics (mean, std per level: nlevels double2) stay on the device
+static int cascade_decompose_run(const double *field_dev, const double *weights_dev, int nlevels, int m, int n,
+                                 int normalize, int subtract_mean, double *levels_dev, double *means_host,
+                                 double *stds_host, double *field_mean_host, double *stats_out_dev) {
   PSH_REQUIRE_INIT();
   if (!field_dev || !weights_dev || !levels_dev) return fail(PSH_EINVAL, "cascade_decompose: NULL pointer");
   if ((means_host == nullptr) != (stds_host == nullptr))
@@ -208,6 +209,8 @@ extern "C" int psh_cascade_decompose_dev(const double *field_dev, const double *
         return rc;
     }
     if (int rc = psh::moments(levels_dev, nlevels, plane, stats, c.stream)) return rc;  // :217-232
+    if (stats_out_dev)
+      PSH_HIP(hipMemcpyAsync(stats_out_dev, stats, static_cast<size_t>(nlevels) * sizeof(double2), hipMemcpyDeviceToDevice, c.stream));
     if (normalize)
       hipLaunchKernelGGL(psh::standardise, dim3(psh::kRedBlocksF64, nlevels), dim3(psh::kRedThreads), 0, c.stream,
                          levels_dev, plane, stats, 0);
@@ -226,6 +229,21 @@ extern "C" int psh_cascade_decompose_dev(const double *field_dev, const double *
   const int rc = run();
   (void)psh_free(blk);
   return rc;
+}
+
+extern "C" int psh_cascade_decompose_dev(const double *field_dev, const double *weights_dev, int nlevels, int m,
+                                         int n, int normalize, int subtract_mean, double *levels_dev,
+                                         double *means_host, double *stds_host, double *field_mean_host) {
+  return cascade_decompose_run(field_dev, weights_dev, nlevels, m, n, normalize, subtract_mean, levels_dev, means_host,
+                               stds_host, field_mean_host, nullptr);
+}
+
+// the levels as the transforms leave them + their statistics in device memory, nothing waits: the
+// consumer (psh_steps_ar_recompose_raw_dev) standardises on the way in
+extern "C" int psh_cascade_decompose_stats_dev(const double *field_dev, const double *weights_dev, int nlevels, int m,
+                                               int n, double *levels_dev, double *stats_dev) {
+  if (!stats_dev) return fail(PSH_EINVAL, "cascade_decompose_stats: NULL pointer");
+  return cascade_decompose_run(field_dev, weights_dev, nlevels, m, n, 0, 0, levels_dev, nullptr, nullptr, nullptr, stats_dev);
 }
 
 extern "C" int psh_cascade_recompose_dev(const double *levels_dev, int nlevels, int m, int n, const double *means_host,

@@ -122,11 +122,14 @@ __global__ __launch_bounds__(kThreads) void pm_stats(const double *__restrict__ 
   }
 }
 
-// one workgroup: finishes the statistics and fixes the bucket mapping
+// one workgroup: finishes the statistics and fixes the bucket mapping.  `only` < 0: both arrays;
+// 1: the target alone (a plan is being made: nothing is known about an initial array yet);
+// 0: the initial array alone, the target's side of the header comes from `plan`
 __global__ __launch_bounds__(kThreads) void pm_prepare(PmHeader *h, size_t n, const PmPartial *__restrict__ part,
-                                                       int nparts) {
+                                                       int nparts, int only, const PmHeader *__restrict__ plan) {
   __shared__ PmPartial s_part[kThreads / 64];
   for (int y = 0; y < 2; ++y) {
+    if (only >= 0 && y != only) continue;  // uniform
     double mn = INFINITY, mx = -INFINITY;
     unsigned nn = 0, ni = 0;
     for (int i = threadIdx.x; i < nparts; i += kThreads) {
@@ -163,11 +166,20 @@ __global__ __launch_bounds__(kThreads) void pm_prepare(PmHeader *h, size_t n, co
     }
   }
   if (threadIdx.x != 0) return;
+  if (only == 0) {  // the target's statistics, wet count and verdict were fixed when the plan was made
+    h->n_nan[1] = plan->n_nan[1];
+    h->n_inf[1] = plan->n_inf[1];
+    h->z[1] = plan->z[1];
+    h->scale[1] = plan->scale[1];
+    h->wet[1] = plan->wet[1];
+  }
   // :81-82 (only NaNs), :93-96 (any non-finite value left: without ignore_indices every NaN / inf)
-  if (h->n_nan[0] == n) {
+  if (only != 1 && h->n_nan[0] == n) {
     h->status = kStAllNan;
-  } else if (h->n_nan[0] + h->n_inf[0] > 0) {
+  } else if (only != 1 && h->n_nan[0] + h->n_inf[0] > 0) {
     h->status = kStNonFinite;
+  } else if (only == 0 && plan->status != kStOk) {
+    h->status = plan->status;  // kStTarget, kStTies
   } else if (h->n_nan[1] == n || h->n_inf[1] > 0) {
     h->status = kStTarget;
   }
@@ -590,11 +602,23 @@ static int probmatch_status_to_rc(int status) {
   }
 }
 
+// A target that stays the same from call to call - the observation every member of a STEPS ensemble is
+// matched against at every time step (nowcasts/steps.py:1199) - needs its half of the work once: the
+// plan keeps its statistics, its verdict and its sorted wet values (36 % of a call at 4096^2).
+struct PmPlan {
+  size_t count;
+  void *blk;  // device: [PmHeader | sorted wet values of the target, `count` doubles]
+  const psh::PmHeader *header() const { return static_cast<const psh::PmHeader *>(blk); }
+  const double *tw() const { return reinterpret_cast<const double *>(static_cast<const char *>(blk) + 256); }
+};
+
+// plan == nullptr, make == nullptr: one complete call.  make: only the target's half, kept in *make.
+// plan: only the initial array's half against the plan.
 static int probmatch_run(const double *initial_dev, const double *target_dev, size_t count, double *out_dev,
-                         int *status_dev) {
+                         int *status_dev, const PmPlan *plan = nullptr, PmPlan *make = nullptr) {
   using namespace psh;
   PSH_REQUIRE_INIT();
-  if (!initial_dev || !target_dev || !out_dev) return fail(PSH_EINVAL, "probmatch: NULL pointer");
+  if ((!make && (!initial_dev || !out_dev)) || (!plan && !target_dev)) return fail(PSH_EINVAL, "probmatch: NULL pointer");
   if (count == 0) return fail(PSH_EINVAL, "probmatch: empty arrays");
   if (count > 0x7fffffffull) return fail(PSH_EUNSUPPORTED, "probmatch: more than 2^31-1 pixels");
   Context &c = ctx();
@@ -612,8 +636,8 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
   const size_t off_large = off_offs + 2 * kScanBlocks * sizeof(unsigned);
   const size_t off_sval = up(off_large + 2 * static_cast<size_t>(large_cap) * sizeof(unsigned));
   const size_t off_tw = up(off_sval + count * sizeof(double));
-  const size_t off_sidx = up(off_tw + count * sizeof(double));
-  const size_t total = off_sidx + count * sizeof(unsigned);
+  const size_t off_sidx = up(off_tw + (plan ? 0 : count * sizeof(double)));
+  const size_t total = off_sidx + (make ? 0 : count * sizeof(unsigned));
   static_assert(sizeof(PmHeader) <= 256, "header block");
   void *blk = nullptr;
   if (int rc = psh_malloc(&blk, total)) return rc;
@@ -627,7 +651,7 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
   unsigned *offs = reinterpret_cast<unsigned *>(base + off_offs);
   unsigned *large = reinterpret_cast<unsigned *>(base + off_large);
   double *sval = reinterpret_cast<double *>(base + off_sval);
-  double *tw = reinterpret_cast<double *>(base + off_tw);
+  double *tw = plan ? const_cast<double *>(plan->tw()) : reinterpret_cast<double *>(base + off_tw);
   unsigned *sidx = reinterpret_cast<unsigned *>(base + off_sidx);
 
   int status = -1;
@@ -636,23 +660,34 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
     const int grid = static_cast<int>(
         std::min<size_t>(kGrid, (count + kLoads * kThreads - 1) / (static_cast<size_t>(kLoads) * kThreads)));
     const int grid_large = 1024;
+    const int halves = plan ? 1 : 2;  // with a plan only the initial array's (first) half of every table is used
     hipStream_t s = c.stream;
-    PSH_HIP(hipMemsetAsync(cnt, 0, table_bytes, s));
+    PSH_HIP(hipMemsetAsync(cnt, 0, table_bytes / 2 * halves, s));
     hipLaunchKernelGGL(pm_init, dim3(1), dim3(1), 0, s, h);
-    hipLaunchKernelGGL(pm_stats, dim3(grid, 2), dim3(kThreads), 0, s, initial_dev, target_dev, count, part);
-    hipLaunchKernelGGL(pm_prepare, dim3(1), dim3(kThreads), 0, s, h, count, part, grid);
-    hipLaunchKernelGGL(pm_hist_initial, dim3(grid), dim3(kThreads), 0, s, initial_dev, count, h, cnt);
-    hipLaunchKernelGGL(pm_hist_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cnt + kBins);
-    hipLaunchKernelGGL(pm_bin_sums, dim3(kScanBlocks, 2), dim3(kThreads), 0, s, cnt, sums);
-    hipLaunchKernelGGL(pm_scan_sums, dim3(2), dim3(kScanBlocks), 0, s, sums, offs, h);
-    hipLaunchKernelGGL(pm_bin_starts, dim3(kScanBlocks, 2), dim3(kThreads), 0, s, cnt, offs, start, cursor, large,
+    hipLaunchKernelGGL(pm_stats, dim3(grid, halves), dim3(kThreads), 0, s, make ? target_dev : initial_dev, target_dev, count,
+                       part);
+    hipLaunchKernelGGL(pm_prepare, dim3(1), dim3(kThreads), 0, s, h, count, part, grid, plan ? 0 : (make ? 1 : -1),
+                       plan ? plan->header() : static_cast<const PmHeader *>(nullptr));
+    if (!make) hipLaunchKernelGGL(pm_hist_initial, dim3(grid), dim3(kThreads), 0, s, initial_dev, count, h, cnt);
+    if (!plan) hipLaunchKernelGGL(pm_hist_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cnt + kBins);
+    hipLaunchKernelGGL(pm_bin_sums, dim3(kScanBlocks, halves), dim3(kThreads), 0, s, cnt, sums);
+    hipLaunchKernelGGL(pm_scan_sums, dim3(halves), dim3(kScanBlocks), 0, s, sums, offs, h);
+    hipLaunchKernelGGL(pm_bin_starts, dim3(kScanBlocks, halves), dim3(kThreads), 0, s, cnt, offs, start, cursor, large,
                        large_cap, h);
-    // target: sorted wet values
-    hipLaunchKernelGGL(pm_scatter_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cursor + kBins, sval);
-    hipLaunchKernelGGL(pm_rank_small<false>, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, sval, sidx, tw,
-                       out_dev);
-    hipLaunchKernelGGL(pm_rank_large<false>, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large,
-                       large_cap, sval, sidx, tw, out_dev);
+    if (!plan) {  // target: sorted wet values
+      hipLaunchKernelGGL(pm_scatter_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cursor + kBins, sval);
+      hipLaunchKernelGGL(pm_rank_small<false>, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, sval, sidx, tw,
+                         out_dev);
+      hipLaunchKernelGGL(pm_rank_large<false>, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large,
+                         large_cap, sval, sidx, tw, out_dev);
+    }
+    if (make) {  // keep the header and the sorted values
+      PSH_HIP(hipMemcpyAsync(make->blk, h, sizeof(PmHeader), hipMemcpyDeviceToDevice, s));
+      PSH_HIP(hipMemcpyAsync(static_cast<char *>(make->blk) + 256, tw, count * sizeof(double), hipMemcpyDeviceToDevice, s));
+      PSH_HIP(hipGetLastError());
+      status = kStOk;  // the verdict on the target travels in the plan
+      return PSH_OK;
+    }
     hipLaunchKernelGGL(pm_threshold, dim3(1), dim3(1), 0, s, h, count, tw);
     // initial: ranks -> output
     hipLaunchKernelGGL(pm_scatter_initial, dim3(grid), dim3(kThreads), 0, s, initial_dev, count, h, cursor, sval, sidx,
@@ -688,6 +723,38 @@ extern "C" int psh_probmatch_async_dev(const double *initial_dev, const double *
                                        int *status_dev) {
   if (!status_dev) return psh::fail(PSH_EINVAL, "probmatch_async: NULL status pointer");
   return probmatch_run(initial_dev, target_dev, count, out_dev, status_dev);
+}
+
+extern "C" int psh_probmatch_plan_create(const double *target_dev, size_t count, void **plan_out) {
+  if (!plan_out) return psh::fail(PSH_EINVAL, "probmatch_plan_create: NULL pointer");
+  *plan_out = nullptr;
+  if (!target_dev || count == 0 || count > 0x7fffffffull) return psh::fail(PSH_EINVAL, "probmatch_plan_create: invalid target");
+  PmPlan *plan = new PmPlan{count, nullptr};
+  int rc = psh_malloc(&plan->blk, 256 + count * sizeof(double));
+  if (rc == PSH_OK) rc = probmatch_run(nullptr, target_dev, count, nullptr, nullptr, nullptr, plan);
+  if (rc != PSH_OK) {
+    if (plan->blk) (void)psh_free(plan->blk);
+    delete plan;
+    return rc;
+  }
+  *plan_out = plan;
+  return PSH_OK;
+}
+
+extern "C" int psh_probmatch_plan_destroy(void *plan_handle) {
+  PmPlan *plan = static_cast<PmPlan *>(plan_handle);
+  if (!plan) return PSH_OK;
+  const int rc = plan->blk ? psh_free(plan->blk) : PSH_OK;  // stream-ordered: queued matchings still read it
+  delete plan;
+  return rc;
+}
+
+extern "C" int psh_probmatch_planned_dev(const void *plan_handle, const double *initial_dev, size_t count, double *out_dev,
+                                         int *status_dev) {
+  const PmPlan *plan = static_cast<const PmPlan *>(plan_handle);
+  if (!plan || !plan->blk) return psh::fail(PSH_EINVAL, "probmatch_planned: NULL plan");
+  if (count != plan->count) return psh::fail(PSH_EINVAL, "probmatch_planned: the plan was made for %zu values, not %zu", plan->count, count);
+  return probmatch_run(initial_dev, nullptr, count, out_dev, status_dev, plan, nullptr);
 }
 
 extern "C" int psh_probmatch_status(int status) {

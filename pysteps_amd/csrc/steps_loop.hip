@@ -52,9 +52,12 @@ __device__ __forceinline__ void publish_min(unsigned long long key, unsigned lon
 }
 
 // cascades: (L, p, plane) of one member; eps: (L, plane) or nullptr; one thread = two pixels
+// eps_stats (nullable): (mean, std) per level of `eps` - the decomposition left its levels as they came
+// out of the transforms and the standardisation (x - mean) / std of decomposition.py:224-232 is applied
+// here, to the value on its way in: the same two operations, one sweep over the levels less
 __global__ __launch_bounds__(kThreads) void ar_recompose(double *__restrict__ cascades, const double *__restrict__ eps,
-                                                         size_t plane, ArRecompose a, double *__restrict__ field,
-                                                         unsigned long long *__restrict__ min_out) {
+                                                         const double2 *__restrict__ eps_stats, size_t plane, ArRecompose a,
+                                                         double *__restrict__ field, unsigned long long *__restrict__ min_out) {
 #pragma clang fp contract(off)
   const size_t pairs = plane / 2;
   const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
@@ -73,7 +76,13 @@ __global__ __launch_bounds__(kThreads) void ar_recompose(double *__restrict__ ca
         acc.y = acc.y + ty;
       }
       if (a.has_eps) {
-        const double2 e = reinterpret_cast<const double2 *>(eps + static_cast<size_t>(k) * plane)[i];
+        double2 e = reinterpret_cast<const double2 *>(eps + static_cast<size_t>(k) * plane)[i];
+        if (eps_stats) {
+          const double2 st = eps_stats[k];
+          const double cx = e.x - st.x, cy = e.y - st.x;
+          e.x = cx / st.y;
+          e.y = cy / st.y;
+        }
         const double ex = e.x * a.eps_scale[k], ey = e.y * a.eps_scale[k];
         const double tx = a.phi[k][a.p] * ex, ty = a.phi[k][a.p] * ey;
         acc.x = acc.x + tx;
@@ -103,7 +112,12 @@ __global__ __launch_bounds__(kThreads) void ar_recompose(double *__restrict__ ca
         acc = acc + t;
       }
       if (a.has_eps) {
-        const double e = eps[static_cast<size_t>(k) * plane + i] * a.eps_scale[k];
+        double e0 = eps[static_cast<size_t>(k) * plane + i];
+        if (eps_stats) {
+          const double c0 = e0 - eps_stats[k].x;
+          e0 = c0 / eps_stats[k].y;
+        }
+        const double e = e0 * a.eps_scale[k];
         const double t = a.phi[k][a.p] * e;
         acc = acc + t;
       }
@@ -229,10 +243,10 @@ unsigned grid_for(size_t n) {
 
 using psh::fail;
 
-extern "C" int psh_steps_ar_recompose_dev(double *cascades_dev, int nlevels, int p, size_t plane, int head,
-                                          const double *phi_host, const double *eps_dev, const double *eps_scale_host,
-                                          const double *mu_host, const double *sigma_host, double *field_dev,
-                                          unsigned long long *min_key_dev) {
+static int ar_recompose_run(double *cascades_dev, int nlevels, int p, size_t plane, int head, const double *phi_host,
+                            const double *eps_dev, const double *eps_stats_dev, const double *eps_scale_host,
+                            const double *mu_host, const double *sigma_host, double *field_dev,
+                            unsigned long long *min_key_dev) {
   PSH_REQUIRE_INIT();
   if (!cascades_dev || !phi_host || !mu_host || !sigma_host || !field_dev)
     return fail(PSH_EINVAL, "steps_ar_recompose: NULL pointer");
@@ -256,9 +270,26 @@ extern "C" int psh_steps_ar_recompose_dev(double *cascades_dev, int nlevels, int
   a.has_eps = eps_dev != nullptr;
   if (min_key_dev) PSH_HIP(hipMemsetAsync(min_key_dev, 0xff, sizeof(unsigned long long), c.stream));
   hipLaunchKernelGGL(psh::ar_recompose, dim3(psh::grid_for(plane / 2 + 1)), dim3(psh::kThreads), 0, c.stream, cascades_dev, eps_dev,
-                     plane, a, field_dev, min_key_dev);
+                     reinterpret_cast<const double2 *>(eps_stats_dev), plane, a, field_dev, min_key_dev);
   PSH_HIP(hipGetLastError());
   return PSH_OK;
+}
+
+extern "C" int psh_steps_ar_recompose_dev(double *cascades_dev, int nlevels, int p, size_t plane, int head,
+                                          const double *phi_host, const double *eps_dev, const double *eps_scale_host,
+                                          const double *mu_host, const double *sigma_host, double *field_dev,
+                                          unsigned long long *min_key_dev) {
+  return ar_recompose_run(cascades_dev, nlevels, p, plane, head, phi_host, eps_dev, nullptr, eps_scale_host, mu_host, sigma_host,
+                          field_dev, min_key_dev);
+}
+
+extern "C" int psh_steps_ar_recompose_raw_dev(double *cascades_dev, int nlevels, int p, size_t plane, int head,
+                                              const double *phi_host, const double *eps_dev, const double *eps_stats_dev,
+                                              const double *eps_scale_host, const double *mu_host, const double *sigma_host,
+                                              double *field_dev, unsigned long long *min_key_dev) {
+  if (!eps_dev || !eps_stats_dev) return fail(PSH_EINVAL, "steps_ar_recompose_raw: the noise levels and their statistics are required");
+  return ar_recompose_run(cascades_dev, nlevels, p, plane, head, phi_host, eps_dev, eps_stats_dev, eps_scale_host, mu_host,
+                          sigma_host, field_dev, min_key_dev);
 }
 
 extern "C" int psh_steps_mask_dev(double *field_dev, size_t n, const double *grey_mask_dev, const unsigned char *keep_mask_dev,

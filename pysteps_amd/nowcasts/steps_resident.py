@@ -159,7 +159,13 @@ class ResidentSteps:
                     raise _Declined
                 self.grey = masks
             else:
-                self.grey = DeviceArray.from_host(np.stack([np.asarray(mk, dtype=np.float64) for mk in masks]))
+                if len(masks) != self.B or any(np.shape(mk) != (m, n) for mk in masks):
+                    raise _Declined
+                self.grey = DeviceArray((self.B, m, n), np.float64)
+                for j, mk in enumerate(masks):  # member by member: no stacked host copy of 8 m n B bytes
+                    src = np.ascontiguousarray(mk, dtype=np.float64)
+                    _lib.check(self._lib.psh_memcpy_h2d(self.grey.ptr + j * self.plane * 8, src.ctypes.data, src.nbytes), "h2d")
+                _lib.check(self._lib.psh_sync(), "sync")
             self.wet = DeviceArray((m, n), np.uint8)
         elif self.mask_method == "obs":
             self.keep = DeviceArray.from_host(np.ascontiguousarray(state["mask_prec"], dtype=np.uint8))
@@ -180,10 +186,20 @@ class ResidentSteps:
             self.domain_mask = DeviceArray.from_host(np.ascontiguousarray(dm, dtype=np.uint8))
         # CDF matching without a wait per member: the fields before the matching are kept for one time step
         # and every member's outcome lands in a device word (checked once, at the end of the update)
+        # ... against a plan of the target: the observation is the same for every member and time step
+        self.pm_plan = None
+        if self.pm_method == "cdf":
+            import ctypes  # noqa: PLC0415
+
+            handle = ctypes.c_void_p()
+            _lib.check(self._lib.psh_probmatch_plan_create(self.target.ptr, self.plane, ctypes.byref(handle)),
+                       "psh_probmatch_plan_create")
+            self.pm_plan = handle
         self.pre = DeviceArray((self.B, m, n), np.float64) if self.pm_method == "cdf" else None
         self.pm_status = DeviceArray((max(self.B, 2),), np.int32) if self.pm_method == "cdf" else None
         self.min_key = DeviceArray((8,), np.uint64)
         self.eps = DeviceArray((self.L, m, n), np.float64)  # cascade of one member's noise field
+        self.eps_stats = DeviceArray((self.L, 2), np.float64)  # (mean, std) of its levels
         self.noise = DeviceArray((m, n), np.float64)
         self.rng = DeviceRandomStates(gens, self.plane, n_draws=min(self.n_updates, 4096))
         self.white = [DeviceArray((self.B, m, n), np.float64), DeviceArray((self.B, m, n), np.float64)]
@@ -217,21 +233,22 @@ class ResidentSteps:
             field = self.pre.view(j) if self.pre is not None else result  # what the matching reads
             # fftgenerators.py:400-433 (the filter part), decomposition.py:77-262 with normalize=True
             _lib.check(lib.psh_noise_filter_dev(white.view(j).ptr, self.noise_filter.ptr, m, n, self.noise.ptr), "psh_noise_filter_dev")
-            _lib.check(lib.psh_cascade_decompose_dev(self.noise.ptr, self.weights.ptr, self.L, m, n, 1, 0, self.eps.ptr, None, None, None),
-                       "psh_cascade_decompose_dev")
+            # (the levels stay unnormalised: the AR kernel standardises them on the way in, one sweep less)
+            _lib.check(lib.psh_cascade_decompose_stats_dev(self.noise.ptr, self.weights.ptr, self.L, m, n, self.eps.ptr, self.eps_stats.ptr),
+                       "psh_cascade_decompose_stats_dev")
             # steps.py:1116-1146 + 1176-1185
             _lib.check(
-                lib.psh_steps_ar_recompose_dev(self.cascades.ptr + j * self.L * lvl_stride, self.L, self.p, plane, self.head,
-                                               self._phi_p, self.eps.ptr, self._noise_std_p, self.mu[j].ctypes.data,
-                                               self.sigma[j].ctypes.data, field.ptr, self.min_key.ptr),
-                "psh_steps_ar_recompose_dev")
+                lib.psh_steps_ar_recompose_raw_dev(self.cascades.ptr + j * self.L * lvl_stride, self.L, self.p, plane, self.head,
+                                                   self._phi_p, self.eps.ptr, self.eps_stats.ptr, self._noise_std_p,
+                                                   self.mu[j].ctypes.data, self.sigma[j].ctypes.data, field.ptr, self.min_key.ptr),
+                "psh_steps_ar_recompose_raw_dev")
             if self.grey is not None:  # steps.py:1221-1240
                 _lib.check(lib.psh_steps_mask_dev(field.ptr, plane, self.grey.view(j).ptr, None, self.min_key.ptr), "psh_steps_mask_dev")
             elif self.keep is not None:
                 _lib.check(lib.psh_steps_mask_dev(field.ptr, plane, None, self.keep.ptr, self.min_key.ptr), "psh_steps_mask_dev")
             if self.pm_method == "cdf":  # steps.py:1198-1201; the outcome is read after the last member
-                _lib.check(lib.psh_probmatch_async_dev(field.ptr, self.target.ptr, plane, result.ptr, self.pm_status.ptr + 4 * j),
-                           "psh_probmatch_async_dev")
+                _lib.check(lib.psh_probmatch_planned_dev(self.pm_plan, field.ptr, plane, result.ptr, self.pm_status.ptr + 4 * j),
+                           "psh_probmatch_planned_dev")
             elif self.pm_method == "mean":  # steps.py:1203-1206
                 _lib.check(lib.psh_steps_mean_shift_dev(result.ptr, plane, self.thr, self.mu_0), "psh_steps_mean_shift_dev")
             self._finish_member(j, result)
@@ -277,7 +294,19 @@ class ResidentSteps:
         continues the same streams) and release the device state."""
         self.rng.sync_back()
         self.rng.close()
+        self._release_plan()
         self.cascades = self.eps = self.white = self.grey = None
+
+    def _release_plan(self):
+        if getattr(self, "pm_plan", None):
+            self._lib.psh_probmatch_plan_destroy(self.pm_plan)
+            self.pm_plan = None
+
+    def __del__(self):
+        try:
+            self._release_plan()
+        except Exception:
+            pass
 
     def cascade_levels(self, j):
         """Member j's latest cascade level fields as the reference holds them (L, m, n) - test hook."""

@@ -215,3 +215,62 @@ def test_async_variant_reports_its_outcome_in_device_memory(ref_pysteps):
     assert got[0] == 0 and np.array_equal(outs[0][1].to_host(), ref(initial, target))
     assert lib.psh_probmatch_status(int(got[1])) == _lib.PSH_EUNSUPPORTED
     assert lib.psh_probmatch_status(int(got[2])) == _lib.PSH_EINVAL and "only nans" in _lib.last_error()
+
+
+def test_plans_for_a_fixed_target_give_the_same_outputs(ref_pysteps):
+    """psh_probmatch_plan_create / _planned_dev (the target's half of the work done once: every member of a
+    STEPS ensemble is matched against the same observation at every time step) against psh_probmatch_dev."""
+    import ctypes
+
+    from pysteps.postprocessing.probmatching import nonparam_match_empirical_cdf as ref
+
+    from pysteps_amd import _lib
+    from pysteps_amd.device import DeviceArray
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(21)
+    shape = (300, 260)
+    count = shape[0] * shape[1]
+    targets = [np.round(_forecast_like(shape, 4, 0.4), 1),       # quantised observation: crowded buckets
+               _forecast_like(shape, 5, 0.1),                     # wet area below most forecasts: no adjustment
+               np.where(rng.random(shape) < 0.02, np.nan, _forecast_like(shape, 6, 0.5))]  # NaNs count as zeros
+    for t_no, target in enumerate(targets):
+        d_t = DeviceArray.from_host(target)
+        plan = ctypes.c_void_p()
+        _lib.check(lib.psh_probmatch_plan_create(d_t.ptr, count, ctypes.byref(plan)))
+        try:
+            status = DeviceArray((4,), np.int32)
+            tied = np.where(rng.random(shape) < 0.5, 1.0, -15.0) + 0.0
+            cases = [_forecast_like(shape, 30 + t_no, 0.3), _forecast_like(shape, 40 + t_no, 0.7), tied, np.full(shape, np.nan)]
+            kept = []
+            for k, initial in enumerate(cases):
+                d_i, d_o = DeviceArray.from_host(initial), DeviceArray(shape, np.float64)
+                _lib.check(lib.psh_probmatch_planned_dev(plan, d_i.ptr, count, d_o.ptr, status.ptr + 4 * k))
+                kept.append((d_i, d_o))
+            got = status.to_host()
+            for k in (0, 1):
+                assert got[k] == 0
+                with np.errstate(all="ignore"):
+                    np.testing.assert_array_equal(kept[k][1].to_host(), ref(cases[k], target))
+                direct = DeviceArray(shape, np.float64)
+                _lib.check(lib.psh_probmatch_dev(kept[k][0].ptr, d_t.ptr, count, direct.ptr))
+                np.testing.assert_array_equal(kept[k][1].to_host(), direct.to_host())
+            assert lib.psh_probmatch_status(int(got[2])) == _lib.PSH_EUNSUPPORTED
+            assert lib.psh_probmatch_status(int(got[3])) == _lib.PSH_EINVAL and "only nans" in _lib.last_error()
+            # the waiting form returns the verdict itself
+            d_o = DeviceArray(shape, np.float64)
+            assert lib.psh_probmatch_planned_dev(plan, kept[0][0].ptr, count, d_o.ptr, None) == 0
+            np.testing.assert_array_equal(d_o.to_host(), kept[0][1].to_host())
+            assert lib.psh_probmatch_planned_dev(plan, kept[2][0].ptr, count, d_o.ptr, None) == _lib.PSH_EUNSUPPORTED
+            assert lib.psh_probmatch_planned_dev(plan, kept[0][0].ptr, count - 1, d_o.ptr, None) == _lib.PSH_EINVAL
+        finally:
+            _lib.check(lib.psh_probmatch_plan_destroy(plan))
+    # a target the kernels decline (infinity): the plan carries the verdict to every call
+    bad = _forecast_like(shape, 8, 0.3)
+    bad[3, 3] = np.inf
+    d_t = DeviceArray.from_host(bad)
+    plan = ctypes.c_void_p()
+    _lib.check(lib.psh_probmatch_plan_create(d_t.ptr, count, ctypes.byref(plan)))
+    d_i, d_o = DeviceArray.from_host(_forecast_like(shape, 9, 0.3)), DeviceArray(shape, np.float64)
+    assert lib.psh_probmatch_planned_dev(plan, d_i.ptr, count, d_o.ptr, None) == _lib.PSH_EUNSUPPORTED
+    _lib.check(lib.psh_probmatch_plan_destroy(plan))

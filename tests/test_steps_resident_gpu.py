@@ -83,6 +83,51 @@ def test_ar_recompose_bit_identical_with_numpy(ref_pysteps, L, p, shape, with_ep
         np.testing.assert_array_equal(field.to_host(), masked)
 
 
+@pytest.mark.parametrize("L,shape", [(6, (64, 64)), (3, (60, 71)), (8, (128, 64))])
+def test_raw_noise_levels_standardised_on_the_way_in(ref_pysteps, L, shape):
+    """psh_cascade_decompose_stats_dev + psh_steps_ar_recompose_raw_dev (levels unnormalised, (mean, std) in
+    device memory, standardised inside the AR kernel) == the normalising decomposition followed by
+    psh_steps_ar_recompose_dev, bit for bit - and the statistics are the ones decomposition_fft reports."""
+    from pysteps.cascade.bandpass_filters import filter_gaussian
+
+    from pysteps_amd import _lib
+    from pysteps_amd.device import DeviceArray
+
+    m, n = shape
+    plane, p = m * n, 2
+    rng = np.random.default_rng(L)
+    lib = _lib.lib()
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    weights = _dev(np.ascontiguousarray(filter_gaussian((m, n), L)["weights_2d"], dtype=np.float64))
+    noise = _dev(rng.standard_normal((m, n)))
+    x0 = rng.standard_normal((L, p, m, n))
+    phi = rng.uniform(-0.9, 0.9, (L, p + 1))
+    scale, mu, sigma = rng.uniform(0.5, 1.5, L), rng.standard_normal(L), rng.uniform(0.1, 2.0, L)
+    fields, rings = [], []
+    for raw in (False, True):
+        casc, eps = _dev(x0), DeviceArray((L, m, n), np.float64)
+        field, key = DeviceArray((m, n), np.float64), DeviceArray((8,), np.uint64)
+        if raw:
+            stats = DeviceArray((L, 2), np.float64)
+            _lib.check(lib.psh_cascade_decompose_stats_dev(noise.ptr, weights.ptr, L, m, n, eps.ptr, stats.ptr))
+            _lib.check(lib.psh_steps_ar_recompose_raw_dev(casc.ptr, L, p, plane, 1, ptr(phi), eps.ptr, stats.ptr, ptr(scale),
+                                                          ptr(mu), ptr(sigma), field.ptr, key.ptr))
+            got_stats = stats.to_host()
+        else:
+            means, stds = np.zeros(L), np.zeros(L)
+            _lib.check(lib.psh_cascade_decompose_dev(noise.ptr, weights.ptr, L, m, n, 1, 0, eps.ptr,
+                                                     means.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                     stds.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), None))
+            _lib.check(lib.psh_steps_ar_recompose_dev(casc.ptr, L, p, plane, 1, ptr(phi), eps.ptr, ptr(scale), ptr(mu),
+                                                      ptr(sigma), field.ptr, key.ptr))
+        fields.append(field.to_host())
+        rings.append(casc.to_host())
+    np.testing.assert_array_equal(fields[0], fields[1])
+    np.testing.assert_array_equal(rings[0], rings[1])
+    np.testing.assert_array_equal(got_stats[:, 0], means)
+    np.testing.assert_array_equal(got_stats[:, 1], stds)
+
+
 def test_elementwise_pieces_bit_identical_with_numpy():
     from pysteps_amd import _lib
     from pysteps_amd.device import DeviceArray
