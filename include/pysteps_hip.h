@@ -112,8 +112,9 @@ int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *
  *  interp_order 0, 1 or 3 for the precip resampling (:85-90); 3 = cubic B-spline incl. the
  *              spline prefilter and the two mask warps of :146-157,234-253 (outside -> NaN).
  *              The boundary mode of that resampling (map_coordinates_mode, :91-96,225-232) rides in
- *              the second byte: interp_order | PSH_MODE_* << 8; modes other than "constant" need
- *              interp_order 0 or 1 (outval is then the cval of "grid-constant").
+ *              the second byte: interp_order | PSH_MODE_* << 8 (outval is then the cval of
+ *              "grid-constant"); with interp_order 3 the spline filter takes the mode's boundary
+ *              condition and "nearest" / "grid-constant" are padded by 12 samples first, like SciPy.
  *  outval      value for pixels advected from outside the domain (may be NaN)
  *  disp        (2,m,n) float64 or NULL; if resume != 0 it holds displacement_prev
  *              on entry (:203-207); if non-NULL it receives the final displacement

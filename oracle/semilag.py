@@ -63,10 +63,20 @@ def _bilinear(field, row, col):
     )
 
 
-def _spline_prefilter_mirror(field):
-    """Cubic B-spline coefficients with mirror boundaries along both axes, float64
-    (scipy.ndimage.spline_filter(order=3, mode="constant"|"mirror"); ni_splines.c:
-    gain 6, pole z = sqrt(3) - 2, _init_causal_mirror / _init_anticausal_mirror)."""
+# spline_filter's boundary initialisation per map_coordinates mode (ni_splines.c `apply_filter`), pinned
+# against scipy.ndimage.spline_filter1d itself (tests/test_oracle_semilag.py): "constant", "mirror",
+# "wrap" and "grid-constant" filter with whole-sample MIRROR boundaries, "nearest" and "reflect" with
+# half-sample REFLECT boundaries, "grid-wrap" periodically
+_PREFILTER_KIND = {"constant": "mirror", "mirror": "mirror", "wrap": "mirror", "grid-constant": "mirror",
+                   "nearest": "reflect", "reflect": "reflect", "grid-wrap": "wrap"}
+# "nearest" and "grid-constant" have no exact boundary condition in the filter: map_coordinates pads the
+# array by 12 samples (edge values / cval) first and shifts the coordinates (_prepad_for_spline_filter)
+_PREFILTER_PAD = {"nearest": 12, "grid-constant": 12}
+
+
+def _spline_prefilter(field, kind="mirror"):
+    """Cubic B-spline coefficients along both axes, float64 (scipy.ndimage.spline_filter(order=3); ni_splines.c:
+    gain 6, pole z = sqrt(3) - 2, _init_causal_* / _init_anticausal_* of the boundary kind)."""
     z = np.sqrt(3.0) - 2.0
     c = np.array(field, dtype=np.float64)
     for axis in (0, 1):
@@ -74,20 +84,51 @@ def _spline_prefilter_mirror(field):
         n = c.shape[0]
         if n > 1:
             c *= 6.0
-            zn1 = z ** (n - 1)
-            acc = c[0] + zn1 * c[n - 1]
-            zi = z
-            for i in range(1, n - 1):
-                acc = acc + zi * (c[i] + zn1 * c[n - 1 - i])
-                zi *= z
-            c[0] = acc / (1.0 - zn1 * zn1)
+            if kind == "mirror":
+                zn1 = z ** (n - 1)
+                acc = c[0] + zn1 * c[n - 1]
+                zi = z
+                for i in range(1, n - 1):
+                    acc = acc + zi * (c[i] + zn1 * c[n - 1 - i])
+                    zi *= z
+                c[0] = acc / (1.0 - zn1 * zn1)
+            elif kind == "reflect":
+                zn = z**n
+                first = c[0].copy()
+                acc = c[0] + zn * c[n - 1]
+                zi = z
+                for i in range(1, n):
+                    acc = acc + zi * (c[i] + zn * c[n - 1 - i])
+                    zi *= z
+                c[0] = acc * (z / (1.0 - zn * zn)) + first
+            else:  # wrap
+                acc = c[0].copy()
+                zi = z
+                for i in range(1, n):
+                    acc = acc + zi * c[n - i]
+                    zi *= z
+                c[0] = acc / (1.0 - zi)
             for i in range(1, n):
                 c[i] += z * c[i - 1]
-            c[n - 1] = (z * c[n - 2] + c[n - 1]) * z / (z * z - 1.0)
+            if kind == "mirror":
+                c[n - 1] = (z * c[n - 2] + c[n - 1]) * z / (z * z - 1.0)
+            elif kind == "reflect":
+                c[n - 1] = c[n - 1] * (z / (z - 1.0))
+            else:
+                acc = c[n - 1].copy()
+                zi = z
+                for i in range(0, n - 1):
+                    acc = acc + zi * c[i]
+                    zi *= z
+                c[n - 1] = acc * (z / (zi - 1.0))
             for i in range(n - 2, -1, -1):
                 c[i] = z * (c[i + 1] - c[i])
         c = np.moveaxis(c, 0, axis)
     return c
+
+
+def _spline_prefilter_mirror(field):
+    return _spline_prefilter(field, "mirror")
 
 
 def _mirror_index(i, n):
@@ -191,6 +232,34 @@ def _fold_tap(i, length, mode):
     return np.where(i < 0, neg, np.where(i >= length, pos, i)), no
 
 
+def _cubic_mode(field, row, col, mode, cval):
+    """order-3 map_coordinates with a boundary mode other than "constant": the array is padded for the
+    two modes the filter has no boundary condition for, filtered with the mode's boundary kind, the
+    coordinate folded like for the lower orders (on the ORIGINAL length) and shifted by the padding, the
+    4 x 4 taps around floor(c) folded index by index on the padded length ("grid-constant": cval)."""
+    m, n = field.shape
+    npad = _PREFILTER_PAD.get(mode, 0)
+    if mode == "nearest":
+        padded = np.pad(field, npad, mode="edge")
+    elif mode == "grid-constant":
+        padded = np.pad(field, npad, mode="constant", constant_values=cval)
+    else:
+        padded = field
+    coef = _spline_prefilter(padded, _PREFILTER_KIND[mode])
+    rr = _fold_coordinate(row, m, mode) + npad
+    cc = _fold_coordinate(col, n, mode) + npad
+    big_m, big_n = padded.shape
+    iy, ix = np.floor(rr).astype(np.int64), np.floor(cc).astype(np.int64)
+    wy, wx = _bspline3_weights(rr - iy), _bspline3_weights(cc - ix)
+    acc = np.zeros(np.shape(row))
+    for a in range(4):
+        ri, rcv = _fold_tap(iy - 1 + a, big_m, mode)
+        for b in range(4):
+            ci, ccv = _fold_tap(ix - 1 + b, big_n, mode)
+            acc = acc + wy[a] * wx[b] * np.where(rcv | ccv, cval, coef[ri, ci])
+    return acc
+
+
 def _numpy_sample_mode(field, row, col, mode, cval, order):
     m, n = field.shape
     f = field.astype(np.float64, copy=False)
@@ -230,6 +299,8 @@ def _numpy_sample(field, row, col, mode, cval, order):
             raise NotImplementedError("non-finite coordinates are restated for modes constant / nearest only")
         val = _numpy_sample(field, np.where(bad, 0.0, row), np.where(bad, 0.0, col), mode, cval, order)
         return np.where(bad, lost, val)
+    if mode != "constant" and order == 3:
+        return _cubic_mode(field.astype(np.float64), row, col, mode, cval)
     if mode != "constant" and order in (0, 1) and not (mode == "nearest" and np.all(np.isfinite(field))):
         return _numpy_sample_mode(field, row, col, mode, cval, order)
     if mode == "nearest":
@@ -420,9 +491,10 @@ def extrapolate(
             )
             val = val.astype(precip.dtype, copy=True)
             if interp_order > 1:
-                warped = sampler(mask_min, yy + disp[1], xx + disp[0], "constant", 0, 1)
+                # both masks with the caller's boundary mode (reference :234-253)
+                warped = sampler(mask_min, yy + disp[1], xx + disp[0], map_coordinates_mode, 0, 1)
                 val[np.asarray(warped) < 0.5] = minval
-                warped = sampler(mask_finite, yy + disp[1], xx + disp[0], "constant", 0, 1)
+                warped = sampler(mask_finite, yy + disp[1], xx + disp[0], map_coordinates_mode, 0, 1)
                 val[np.asarray(warped) < 0.5] = np.nan
             frames.append(val)
 

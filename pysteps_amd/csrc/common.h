@@ -100,7 +100,9 @@ struct SemilagArgs {
   int m, n, T, n_iter, order, resume;
   int row0, rows;       // output row band [row0, row0+rows); out is (T,rows,n)
   float outval;
-  const float *coef;    // interp_order 3: cubic B-spline coefficients of precip (m,n)
+  const float *coef;    // interp_order 3: cubic B-spline coefficients of precip (m + 2 coef_pad, n + 2 coef_pad); nullptr
+                        // with bmode != 0: every coefficient is NaN (a non-finite cval was padded in)
+  int coef_pad = 0;     // samples the coefficient plane is padded by ("nearest", "grid-constant": 12)
   float minval;         // interp_order 3: minimum over the finite values of precip
   int bmode = 0;        // boundary mode of the field resampling (PSH_MODE_*), interp_order 0/1
   const float *vel_packed = nullptr;  // (m,n,2) {u,v} interleaved copy of vel (launch_pack_velocity) or nullptr
@@ -117,7 +119,8 @@ void set_members_variant(int v);
 // three-pixels-per-lane kernel (semilag_wide.hip): interp_order 0/1, images >= 192 columns
 bool semilag_wide_eligible(const SemilagArgs &a);
 hipError_t launch_semilag_wide(const SemilagArgs &a, hipStream_t stream);
-hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream);
+hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream, int kind = 0,
+                            int npad = 0, int pad_edge = 0, float cval = 0.f);
 
 // sample count and interpolator preamble kept in device memory (written by vectors_finish,
 // lk_sparse.hip): the IDW kernels read L / reach from here instead of their launch arguments, so

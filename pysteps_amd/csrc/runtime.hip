@@ -1,5 +1,6 @@
 // Runtime half of the C ABI (include/pysteps_hip.h): device binding, memory,
 // events, error reporting.  One process drives one GPU (one rank per device).
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -107,8 +108,6 @@ int check_semilag(int m, int n, int T, int n_iter, int order_and_mode) {
   const int order = order_and_mode & 0xff, bmode = (order_and_mode >> 8) & 0xff;
   if (order_and_mode < 0 || (order_and_mode >> 16) != 0 || bmode > PSH_MODE_GRID_WRAP)
     return fail(PSH_EINVAL, "semilag: invalid interp_order / boundary mode word 0x%x", order_and_mode);
-  if (bmode != PSH_MODE_CONSTANT && order == 3)
-    return fail(PSH_EUNSUPPORTED, "semilag: interp_order 3 is implemented for mode \"constant\" only");
   if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "semilag: invalid shape (%d,%d)", m, n);
   if (static_cast<uint64_t>(m) * static_cast<uint64_t>(n) >= (1ull << 30))
     return fail(PSH_EUNSUPPORTED, "semilag: m*n must be < 2^30 pixels (32-bit byte offsets)");
@@ -515,20 +514,30 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
   a.minval = 0.f;
   void *spline_blk = nullptr;
   if (interp_order == 3 && precip_dev) {
-    // cubic B-spline coefficients (spline.hip) + the minimum the mask logic restores (:146-147)
-    const size_t plane_bytes = static_cast<size_t>(m) * n * sizeof(float);
-    if (int rc = psh_malloc(&spline_blk, 2 * plane_bytes)) return rc;
-    float *coef = static_cast<float *>(spline_blk);
-    float *tmp = coef + static_cast<size_t>(m) * n;
-    hipError_t e = psh::spline_prefilter(precip_dev, coef, tmp, m, n, c.stream);
+    // cubic B-spline coefficients (spline.hip) + the minimum the mask logic restores (:146-147).  Per boundary
+    // mode: the filter's boundary kind, and for the two modes SciPy pads before filtering the padded plane
+    const int mode = a.bmode;
+    const int kind = (mode == PSH_MODE_NEAREST || mode == PSH_MODE_REFLECT) ? 1 : (mode == PSH_MODE_GRID_WRAP ? 2 : 0);
+    const int npad = (mode == PSH_MODE_NEAREST || mode == PSH_MODE_GRID_CONSTANT) ? 12 : 0;
+    // a non-finite cval padded around the field reaches every coefficient through the filter's recursions
+    const bool all_nan = mode == PSH_MODE_GRID_CONSTANT && !std::isfinite(outval);
+    const size_t plane_bytes = static_cast<size_t>(m + 2 * npad) * (n + 2 * npad) * sizeof(float);
+    hipError_t e = hipSuccess;
+    if (!all_nan) {
+      if (int rc = psh_malloc(&spline_blk, 2 * plane_bytes)) return rc;
+      float *coef = static_cast<float *>(spline_blk);
+      float *tmp = coef + plane_bytes / sizeof(float);
+      e = psh::spline_prefilter(precip_dev, coef, tmp, m, n, c.stream, kind, npad, mode == PSH_MODE_NEAREST, outval);
+      a.coef = coef;
+      a.coef_pad = npad;
+    }
     double mn = 0.0;
     int rc = e == hipSuccess ? psh_field_stats_dev(precip_dev, static_cast<size_t>(m) * n, &mn, nullptr, nullptr)
                              : fail(PSH_EHIP, "spline prefilter failed: %s", hipGetErrorString(e));
     if (rc) {
-      (void)psh_free(spline_blk);
+      if (spline_blk) (void)psh_free(spline_blk);
       return rc;
     }
-    a.coef = coef;
     a.minval = static_cast<float>(mn);
   }
   void *packed_blk = nullptr;

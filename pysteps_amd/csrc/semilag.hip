@@ -64,6 +64,7 @@ struct Fields {
   __amdgpu_buffer_rsrc_t rpp;  // row-pair field plane {p(y,x), p(y+1,x)} (kModePacked2)
   int row_bytes;
   const float *coef;  // cubic B-spline coefficients of the field (interp_order 3 only)
+  int cpad;           // ... padded by this many samples (boundary modes "nearest", "grid-constant")
   float minval;       // minimum over its finite values (interp_order 3 only)
   int bmode;          // boundary mode of the field resampling (semilag_device.h kMode*)
 };
@@ -580,6 +581,14 @@ __device__ __forceinline__ float sample_precip_off_fast(const float *p, int X, i
   return sample_precip_border<ORDER>(p, X, Y, fx, fy, m, n, outval);
 }
 
+// interp_order 3: the "constant" rule alone, or any boundary mode (GEN)
+template <bool GEN>
+__device__ __forceinline__ float sample_cubic(const Fields &F, int X, int Y, float fx, float fy, int m, int n,
+                                              float outval) {
+  if (GEN) return sample_precip_cubic_mode(F.coef, F.p0, X, Y, fx, fy, m, n, F.minval, outval, F.bmode, F.cpad);
+  return sample_precip_cubic(F.coef, F.p0, X, Y, fx, fy, m, n, F.minval);
+}
+
 // What to sample at the NPX positions of a thread
 enum : int { kVel = 1, kPrecip = 2 };
 
@@ -631,7 +640,7 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
     if (kWithP && ORDER == 3) {
 #pragma unroll
       for (int j = 0; j < NPX; ++j)
-        sp[j] = sample_precip_cubic(F.coef, F.p0, X[j], Y[j], fx[j], fy[j], m, n, F.minval);
+        sp[j] = sample_cubic<GEN>(F, X[j], Y[j], fx[j], fy[j], m, n, outval);
     }
     // keep the optimiser from sinking both branches into one load sequence with
     // selected 64-bit addresses (that would cost the fast path its addressing)
@@ -641,7 +650,7 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
     for (int j = 0; j < NPX; ++j) {
       if (WHAT & kVel) sample_velocity_border(F, X[j], Y[j], fx[j], fy[j], m, n, su[j], sv[j]);
       if (kWithP) {
-        sp[j] = ORDER == 3 ? sample_precip_cubic(F.coef, F.p0, X[j], Y[j], fx[j], fy[j], m, n, F.minval)
+        sp[j] = ORDER == 3 ? sample_cubic<GEN>(F, X[j], Y[j], fx[j], fy[j], m, n, outval)
                            : sample_precip_off_fast<(ORDER == 3 ? 1 : ORDER), GEN>(F.p0, X[j], Y[j], fx[j], fy[j],
                                                                           m, n, outval, F.bmode);
       }
@@ -668,7 +677,7 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
     const float *__restrict__ field_pairs, float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
     int T, int n_iter, int resume, float outval, int row0, int rows, const float *__restrict__ coef,
-    float minval, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd) {
+    float minval, int bmode, int coef_pad, int tiles_x, int n_tiles, int tiles_per_xcd) {
   // XCD-aware remap: hardware block b -> XCD b % 8; give XCD k the k-th band of tiles
   const int b = blockIdx.x;
   const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
@@ -697,6 +706,7 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
                                             2 * plane_bytes, 0x00020000);
   F.row_bytes = n * static_cast<int>(sizeof(float));
   F.coef = coef;
+  F.cpad = coef_pad;
   F.minval = minval;
   F.bmode = bmode;
 
@@ -846,7 +856,7 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
 #pragma unroll
           for (int j = 0; j < NPX; ++j)
             sp[j] = ORDER == 3
-                        ? sample_precip_cubic(F.coef, F.p0, px[j], py[j], fx[j], fy[j], m, n, F.minval)
+                        ? sample_cubic<GEN>(F, px[j], py[j], fx[j], fy[j], m, n, outval)
                         : sample_precip_off_fast<(ORDER == 3 ? 1 : ORDER), GEN>(F.p0, px[j], py[j], fx[j], fy[j], m,
                                                                        n, outval, F.bmode);
         }
@@ -901,7 +911,7 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, MODE, GEN>), grid, block, 0, stream,      \
                      a.precip, a.vel, a.vel_packed, a.field_pairs, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, \
                      a.T,                                                                                  \
-                     a.n_iter, a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, a.bmode,   \
+                     a.n_iter, a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, a.bmode, a.coef_pad,  \
                      tiles_x, n_tiles, tiles_per_xcd)
   if (a.precip == nullptr) {
     PSH_SL_LAUNCH(1, false, false);
@@ -913,7 +923,11 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
     }
   } else if (a.order == 3) {
     if constexpr (MODE != kModeStaged) {
-      PSH_SL_LAUNCH(3, true, false);
+      if (a.bmode != 0) {
+        PSH_SL_LAUNCH(3, true, true);
+      } else {
+        PSH_SL_LAUNCH(3, true, false);
+      }
     } else {
       return hipErrorInvalidValue;  // the staged variants are built for order 0/1
     }

@@ -284,5 +284,61 @@ __device__ __forceinline__ float sample_precip_cubic(const float *coef, const fl
   return acc;
 }
 
+// interp_order = 3 with a map_coordinates mode other than "constant" (oracle/semilag.py::_cubic_mode,
+// pinned against SciPy): the coordinate is folded on the field's own lengths like for the lower
+// orders; the two order-1 mask warps take the field's taps folded index by index (cval 0 for
+// "grid-constant"); the 4 x 4 spline taps are folded index by index on the PADDED coefficient plane
+// ((m + 2 npad, n + 2 npad): SciPy pads "nearest" and "grid-constant" by 12 samples before filtering
+// and shifts the coordinate), "grid-constant" taps outside it are cval.  coef == nullptr: a non-finite
+// cval was padded in and the filter's recursion carried it everywhere - every coefficient is NaN.
+__device__ __forceinline__ float sample_precip_cubic_mode(const float *coef, const float *p, int X, int Y, float fx,
+                                                          float fy, int m, int n, float minval, float cval, int mode,
+                                                          int npad) {
+  fold_coord(X, fx, n, mode);
+  fold_coord(Y, fy, m, mode);
+  {
+    bool cx0 = false, cx1 = false, cy0 = false, cy1 = false;
+    const int x0 = fold_tap(X, n, mode, &cx0), x1 = fold_tap(X + 1, n, mode, &cx1);
+    const int y0 = fold_tap(Y, m, mode, &cy0), y1 = fold_tap(Y + 1, m, mode, &cy1);
+    const unsigned r0 = static_cast<unsigned>(__mul24(y0, n)), r1 = static_cast<unsigned>(__mul24(y1, n));
+    const float v00 = ld(p, (r0 + x0) << 2), v01 = ld(p, (r0 + x1) << 2);
+    const float v10 = ld(p, (r1 + x0) << 2), v11 = ld(p, (r1 + x1) << 2);
+    const bool k00 = !(cx0 || cy0), k01 = !(cx1 || cy0), k10 = !(cx0 || cy1), k11 = !(cx1 || cy1);  // not a cval tap
+    const Weights w = make_weights(fx, fy);
+    const float finite = blend(w, (k00 && isfinite(v00)) ? 1.f : 0.f, (k01 && isfinite(v01)) ? 1.f : 0.f,
+                               (k10 && isfinite(v10)) ? 1.f : 0.f, (k11 && isfinite(v11)) ? 1.f : 0.f);
+    if (finite < 0.5f) return __builtin_nanf("");
+    const float above = blend(w, (k00 && v00 > minval) ? 1.f : 0.f, (k01 && v01 > minval) ? 1.f : 0.f,
+                              (k10 && v10 > minval) ? 1.f : 0.f, (k11 && v11 > minval) ? 1.f : 0.f);
+    if (above < 0.5f) return minval;
+  }
+  if (coef == nullptr) return __builtin_nanf("");
+  const int big_m = m + 2 * npad, big_n = n + 2 * npad;
+  float wx[4], wy[4];
+  bspline3(fx, wx);
+  bspline3(fy, wy);
+  int xi[4];
+  bool xc[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    xc[b] = false;
+    xi[b] = fold_tap(X + npad - 1 + b, big_n, mode, &xc[b]);
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    bool yc = false;
+    const unsigned row = static_cast<unsigned>(__mul24(fold_tap(Y + npad - 1 + a, big_m, mode, &yc), big_n));
+    float line = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float v = ld(coef, (row + xi[b]) << 2);
+      line = fmaf(wx[b], (yc || xc[b]) ? cval : v, line);
+    }
+    acc = fmaf(wy[a], line, acc);
+  }
+  return acc;
+}
+
 }  // namespace sl
 }  // namespace psh

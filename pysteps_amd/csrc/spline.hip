@@ -5,7 +5,12 @@
 // with spline_filter (ni_splines.c): per axis  c = 6 s,  causal  c[i] += z c[i-1],  anticausal
 // c[i] = z (c[i+1] - c[i]),  z = sqrt(3) - 2,  with MIRROR boundary initialisation for mode
 // "constant" (_init_causal_mirror / _init_anticausal_mirror).  Missing values are zeroed first
-// (semilagrangian.py:151-153).
+// (semilagrangian.py:151-153).  The other map_coordinates modes (semilagrangian.py:91-96): "mirror", "wrap"
+// and "grid-constant" filter with the same MIRROR boundaries, "nearest" and "reflect" with half-sample
+// REFLECT boundaries (_init_*_reflect), "grid-wrap" periodically (_init_*_wrap); for "nearest" and
+// "grid-constant" - no exact boundary condition in the filter - map_coordinates pads the array by 12
+// samples (edge values / cval) before filtering and shifts the coordinates (_prepad_for_spline_filter).
+// All of it pinned against SciPy through oracle/semilag.py.
 //
 // A first-order recursion is sequential along its axis, but |z| = 0.268 forgets its past in ~40
 // samples (|z|^40 = 1e-23), so every column is cut into segments that start their recursion 40
@@ -32,9 +37,34 @@ __global__ __launch_bounds__(256) void spline_zero_nonfinite(const float *__rest
   }
 }
 
+enum : int { kKindMirror = 0, kKindReflect = 1, kKindWrap = 2 };
+
+// z^k as a float (0 once it underflows: |z|^64 ~ 1e-37)
+__device__ __forceinline__ float pole_pow(int k) {
+  return powf(-kPole, static_cast<float>(k)) * ((k & 1) ? -1.f : 1.f);
+}
+
+// zero-padded / edge-padded copy with the missing values zeroed: out (m + 2 npad, n + 2 npad)
+__global__ __launch_bounds__(256) void spline_pad(const float *__restrict__ in, float *__restrict__ out, int m, int n,
+                                                  int npad, int edge, float cval) {
+  const int big_n = n + 2 * npad, big_m = m + 2 * npad;
+  const size_t total = static_cast<size_t>(big_m) * big_n;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int y = static_cast<int>(i / big_n) - npad, x = static_cast<int>(i % big_n) - npad;
+    const bool inside = y >= 0 && y < m && x >= 0 && x < n;
+    float v = cval;
+    if (inside || edge) {
+      v = in[static_cast<size_t>(min(max(y, 0), m - 1)) * n + min(max(x, 0), n - 1)];
+      v = isfinite(v) ? v : 0.f;
+    }
+    out[i] = v;
+  }
+}
+
 // causal pass along axis 0 of a (len, width) row-major array: dst[i] = 6 src[i] + z dst[i-1]
 __global__ __launch_bounds__(64) void spline_causal(const float *__restrict__ src,
-                                                    float *__restrict__ dst, int len, int width) {
+                                                    float *__restrict__ dst, int len, int width, int kind) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   if (x >= width) return;
   const int s0 = blockIdx.y * kSeg, s1 = min(len, s0 + kSeg);
@@ -47,17 +77,40 @@ __global__ __launch_bounds__(64) void spline_causal(const float *__restrict__ sr
       dst[x] = src[x];  // a single sample is its own coefficient
       return;
     }
-    const float zn1 = powf(fabsf(z), static_cast<float>(len - 1)) * (((len - 1) & 1) ? -1.f : 1.f);
-    float acc = 6.f * src[x] + zn1 * 6.f * src[static_cast<size_t>(len - 1) * width + x];
-    float zi = z;
-    const int horizon = min(len - 2, 64);  // |z|^64 ~ 1e-37
-    for (int k = 1; k <= horizon; ++k) {
-      float term = 6.f * src[static_cast<size_t>(k) * width + x];
-      if (zn1 != 0.f) term += zn1 * 6.f * src[static_cast<size_t>(len - 1 - k) * width + x];
-      acc += zi * term;
-      zi *= z;
+    if (kind == kKindMirror) {
+      const float zn1 = pole_pow(len - 1);
+      float acc = 6.f * src[x] + zn1 * 6.f * src[static_cast<size_t>(len - 1) * width + x];
+      float zi = z;
+      const int horizon = min(len - 2, 64);  // |z|^64 ~ 1e-37
+      for (int k = 1; k <= horizon; ++k) {
+        float term = 6.f * src[static_cast<size_t>(k) * width + x];
+        if (zn1 != 0.f) term += zn1 * 6.f * src[static_cast<size_t>(len - 1 - k) * width + x];
+        acc += zi * term;
+        zi *= z;
+      }
+      c = acc / (1.f - zn1 * zn1);
+    } else if (kind == kKindReflect) {  // _init_causal_reflect
+      const float zn = pole_pow(len), first = 6.f * src[x];
+      float acc = first + zn * 6.f * src[static_cast<size_t>(len - 1) * width + x];
+      float zi = z;
+      const int horizon = min(len - 1, 64);
+      for (int k = 1; k <= horizon; ++k) {
+        float term = 6.f * src[static_cast<size_t>(k) * width + x];
+        if (zn != 0.f) term += zn * 6.f * src[static_cast<size_t>(len - 1 - k) * width + x];
+        acc += zi * term;
+        zi *= z;
+      }
+      c = acc * (z / (1.f - zn * zn)) + first;
+    } else {  // _init_causal_wrap
+      float acc = 6.f * src[x];
+      float zi = z;
+      const int horizon = min(len - 1, 64);
+      for (int k = 1; k <= horizon; ++k) {
+        acc += zi * 6.f * src[static_cast<size_t>(len - k) * width + x];
+        zi *= z;
+      }
+      c = acc / (1.f - pole_pow(len));
     }
-    c = acc / (1.f - zn1 * zn1);
     if (s0 == 0) dst[x] = c;
     i = 1;
   } else {
@@ -74,7 +127,7 @@ __global__ __launch_bounds__(64) void spline_causal(const float *__restrict__ sr
 // anticausal pass: dst[i] = z (dst[i+1] - cp[i]) with cp the causal result
 __global__ __launch_bounds__(64) void spline_anticausal(const float *__restrict__ cp,
                                                         float *__restrict__ dst, int len,
-                                                        int width) {
+                                                        int width, int kind) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   if (x >= width || len == 1) {
     if (x < width && blockIdx.y == 0) dst[x] = cp[x];
@@ -87,8 +140,21 @@ __global__ __launch_bounds__(64) void spline_anticausal(const float *__restrict_
   if (s1 + kWarm >= len) {
     // exact mirror initialisation at the array end (_init_anticausal_mirror)
     const float last = cp[static_cast<size_t>(len - 1) * width + x];
-    const float prev = cp[static_cast<size_t>(len - 2) * width + x];
-    c = (z * prev + last) * z / (z * z - 1.f);
+    if (kind == kKindMirror) {
+      const float prev = cp[static_cast<size_t>(len - 2) * width + x];
+      c = (z * prev + last) * z / (z * z - 1.f);
+    } else if (kind == kKindReflect) {  // _init_anticausal_reflect
+      c = last * (z / (z - 1.f));
+    } else {  // _init_anticausal_wrap: the causal values at the START of the array
+      float acc = last;
+      float zi = z;
+      const int horizon = min(len - 1, 64);
+      for (int k = 0; k < horizon; ++k) {
+        acc += zi * cp[static_cast<size_t>(k) * width + x];
+        zi *= z;
+      }
+      c = acc * (z / (pole_pow(len) - 1.f));
+    }
     if (s1 == len) dst[static_cast<size_t>(len - 1) * width + x] = c;
     i = len - 2;
   } else {
@@ -119,20 +185,26 @@ __global__ __launch_bounds__(256) void transpose32(const float *__restrict__ in,
 
 }  // namespace
 
-// coef <- cubic B-spline coefficients of precip (NaN/Inf -> 0); tmp: second (m,n) plane.
-hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n,
-                            hipStream_t stream) {
-  const size_t npx = static_cast<size_t>(m) * n;
-  hipLaunchKernelGGL(spline_zero_nonfinite, dim3(2048), dim3(256), 0, stream, precip, coef, npx);
+// coef <- cubic B-spline coefficients of precip (NaN/Inf -> 0) padded by `npad` samples (edge values
+// or `cval`), boundary kind 0 mirror / 1 reflect / 2 wrap; coef and tmp: (m + 2 npad, n + 2 npad) planes.
+hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream, int kind,
+                            int npad, int pad_edge, float cval) {
+  if (npad > 0) {
+    hipLaunchKernelGGL(spline_pad, dim3(2048), dim3(256), 0, stream, precip, coef, m, n, npad, pad_edge, cval);
+    m += 2 * npad;
+    n += 2 * npad;
+  } else {
+    hipLaunchKernelGGL(spline_zero_nonfinite, dim3(2048), dim3(256), 0, stream, precip, coef, static_cast<size_t>(m) * n);
+  }
   // axis 0 (columns of the image)
   dim3 g0((n + 63) / 64, (m + kSeg - 1) / kSeg);
-  hipLaunchKernelGGL(spline_causal, g0, dim3(64), 0, stream, coef, tmp, m, n);
-  hipLaunchKernelGGL(spline_anticausal, g0, dim3(64), 0, stream, tmp, coef, m, n);
+  hipLaunchKernelGGL(spline_causal, g0, dim3(64), 0, stream, coef, tmp, m, n, kind);
+  hipLaunchKernelGGL(spline_anticausal, g0, dim3(64), 0, stream, tmp, coef, m, n, kind);
   // axis 1 (rows) as columns of the transpose
   hipLaunchKernelGGL(transpose32, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, stream, coef, tmp, m, n);
   dim3 g1((m + 63) / 64, (n + kSeg - 1) / kSeg);
-  hipLaunchKernelGGL(spline_causal, g1, dim3(64), 0, stream, tmp, coef, n, m);
-  hipLaunchKernelGGL(spline_anticausal, g1, dim3(64), 0, stream, coef, tmp, n, m);
+  hipLaunchKernelGGL(spline_causal, g1, dim3(64), 0, stream, tmp, coef, n, m, kind);
+  hipLaunchKernelGGL(spline_anticausal, g1, dim3(64), 0, stream, coef, tmp, n, m, kind);
   hipLaunchKernelGGL(transpose32, dim3((m + 31) / 32, (n + 31) / 32), dim3(256), 0, stream, tmp, coef, n, m);
   return hipGetLastError();
 }

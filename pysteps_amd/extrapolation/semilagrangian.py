@@ -12,9 +12,7 @@ Differences, all documented in DESIGN.md:
 * arithmetic is float32 on device (the reference computes in float64 inside
   SciPy); the advected field is within 1e-4 relative L2 of the reference (measured
   ~1e-6) and the returned displacement is float64 like the reference's;
-* options the kernel does not implement (``interp_order`` other than 0/1/3,
-  ``interp_order=3`` together with a ``map_coordinates_mode`` other than
-  ``"constant"``, custom ``xy_coords``) are delegated to the reference implementation when pysteps is
+* options the kernel does not implement (``interp_order`` other than 0/1/3, custom ``xy_coords``) are delegated to the reference implementation when pysteps is
   importable and raise ``NotImplementedError`` otherwise;
 * ``precip``/``velocity``/``displacement_prev`` may also be
   :class:`pysteps_amd.device.DeviceArray` objects; then nothing crosses PCIe and
@@ -187,9 +185,6 @@ def extrapolate(
         return _unsupported("interp_order=%r" % (interp_order,), call_args, call_kwargs)
     if map_coordinates_mode not in _BOUNDARY_MODES:
         raise RuntimeError("boundary mode not supported")  # what scipy.ndimage raises
-    if map_coordinates_mode != "constant" and interp_order == 3:
-        return _unsupported("interp_order=3 with map_coordinates_mode=%r" % (map_coordinates_mode,),
-                            call_args, call_kwargs)
     # the boundary mode rides in the second byte of the interp_order word (include/pysteps_hip.h)
     interp_order = int(interp_order) | (_BOUNDARY_MODES[map_coordinates_mode] << 8)
     if xy_coords is not None and not _is_default_grid(xy_coords, m, n):

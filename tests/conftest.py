@@ -66,6 +66,12 @@ def semilag_golden():
 
 
 @pytest.fixture(scope="session")
+def semilag_o3_golden():
+    """interp_order=3 x the six other boundary modes, from the unmodified reference (tools/make_golden.py)."""
+    return GoldenCases(os.path.join(GOLDEN, "semilag_order3_modes.npz"))
+
+
+@pytest.fixture(scope="session")
 def ref_pysteps():
     """The REAL reference package, imported from oracle/_ref (built by ``python -m oracle.build_ref``
     from /root/reference; ships to the GPU box with the snapshot).  Test infrastructure only."""

@@ -171,3 +171,54 @@ def test_oracle_boundary_modes_match_live_reference(mode):
                             allow_nonfinite_values=True)
         assert nan_mismatch(a, r) == 0
         np.testing.assert_allclose(a, r, rtol=0, atol=2e-6, equal_nan=True)
+
+
+O3_MODES = ("nearest", "reflect", "mirror", "wrap", "grid-wrap", "grid-constant")
+GOLDEN_O3 = (["sl_o3_%s%s" % (m.replace("-", ""), suffix) for m in O3_MODES for suffix in ("", "_nan")]
+             + ["sl_o3_gridconstant_nancval"])
+
+
+@pytest.mark.parametrize("mode", ("constant",) + O3_MODES)
+def test_spline_prefilter_kinds_pinned_against_scipy(mode):
+    """The boundary initialisation of SciPy's spline filter per map_coordinates mode (mirror / reflect /
+    periodic) as restated in the oracle, against scipy.ndimage.spline_filter itself."""
+    from scipy.ndimage import spline_filter
+
+    rng = np.random.default_rng(5)
+    for shape in ((16, 23), (40, 33), (9, 70)):
+        a = rng.standard_normal(shape)
+        got = osl._spline_prefilter(a, osl._PREFILTER_KIND[mode])
+        want = spline_filter(a, order=3, mode=mode, output=np.float64)
+        # (the reflect initialisation is exact from ~16 samples on: its z^n terms)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 if min(shape) < 16 else 1e-13)
+
+
+@pytest.mark.parametrize("mode", O3_MODES)
+def test_order3_boundary_modes_pinned_against_scipy(mode):
+    """order-3 map_coordinates with a boundary mode: padding for the two modes without a boundary condition in
+    the filter, coordinate folding on the original lengths, taps folded on the padded ones - against SciPy
+    on coordinates up to several array lengths outside."""
+    from scipy.ndimage import map_coordinates
+
+    rng = np.random.default_rng(11)
+    for (m, n) in ((17, 21), (40, 33)):
+        f = rng.standard_normal((m, n))
+        row = rng.uniform(-2.5 * m, 3.5 * m, 3000)
+        col = rng.uniform(-2.5 * n, 3.5 * n, 3000)
+        row[:1500] = rng.uniform(-2, m + 1, 1500)
+        col[:1500] = rng.uniform(-2, n + 1, 1500)
+        row[:50] = np.round(row[:50])  # integer coordinates, the edges among them
+        col[25:75] = np.round(col[25:75])
+        want = map_coordinates(f, [row, col], order=3, mode=mode, cval=-7.5, prefilter=True)
+        got = osl._numpy_sample(f, row, col, mode, -7.5, 3)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 if m < 20 and mode == "reflect" else 1e-12)
+
+
+@pytest.mark.parametrize("name", GOLDEN_O3)
+def test_oracle_order3_modes_match_reference_golden(semilag_o3_golden, name):
+    c = semilag_o3_golden.case(name)
+    out, disp = osl.extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, backend="numpy", **c["kw"])
+    assert out.shape == c["out"].shape and out.dtype == c["out"].dtype
+    assert nan_mismatch(out, c["out"]) == 0
+    np.testing.assert_allclose(disp, c["disp"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out, c["out"], rtol=0, atol=2e-6, equal_nan=True)

@@ -94,6 +94,45 @@ def make_semilag():
     print("semilag:", len(semilag_cases()) + 1, "cases")
 
 
+def semilag_order3_mode_cases():
+    """interp_order=3 with the six map_coordinates modes other than "constant" (reference :91-96, :146-157,
+    :225-253: prefilter with the mode's boundary kind, padded for "nearest" / "grid-constant", mask warps
+    with the same mode); long lead times leave / wrap the 72 x 96 domain."""
+    base = semilag_cases()
+    P, Vs = base["sl_order3"]["precip"], base["sl_order3"]["velocity"]
+    Pn = base["sl_order3_nan"]["precip"]
+    cases = {}
+    for mode in ("nearest", "reflect", "mirror", "wrap", "grid-wrap", "grid-constant"):
+        tag = mode.replace("-", "")
+        cases["sl_o3_" + tag] = dict(precip=P, velocity=Vs, timesteps=[2.0, 10.0, 40.0],
+                                     kw=dict(interp_order=3, map_coordinates_mode=mode, outval=-15.0))
+        cases["sl_o3_" + tag + "_nan"] = dict(precip=Pn, velocity=Vs, timesteps=[3.0, 12.0],
+                                              kw=dict(interp_order=3, map_coordinates_mode=mode, allow_nonfinite_values=True,
+                                                      n_iter=2))
+    # cval = NaN padded around the field: the filter's recursions carry it into every coefficient
+    cases["sl_o3_gridconstant_nancval"] = dict(precip=P, velocity=Vs, timesteps=[2.0, 10.0],
+                                               kw=dict(interp_order=3, map_coordinates_mode="grid-constant"))
+    return cases
+
+
+def make_semilag_order3_modes():
+    ref = ref_loader.load("pysteps.extrapolation.semilagrangian")
+    blob = {}
+    for name, c in semilag_order3_mode_cases().items():
+        kw = dict(c["kw"])
+        out, disp = ref.extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **kw)
+        blob[name + "/precip"] = c["precip"]
+        blob[name + "/velocity"] = c["velocity"]
+        blob[name + "/timesteps"] = np.asarray(c["timesteps"])
+        blob[name + "/timesteps_is_int"] = np.asarray(False)
+        for k, v in kw.items():
+            blob[name + "/kw/" + k] = np.asarray(v)
+        blob[name + "/out"] = out
+        blob[name + "/disp"] = disp
+    np.savez_compressed(os.path.join(OUT, "semilag_order3_modes.npz"), **blob)
+    print("semilag order 3 x modes:", len(semilag_order3_mode_cases()), "cases")
+
+
 def sparse_vectors(L, m, n, seed, outliers=True):
     """LK-like sparse vectors: integer feature positions, smooth motion + noise (+ planted outliers)."""
     rng = np.random.default_rng(seed)
@@ -166,9 +205,11 @@ def main():
     if not ref_loader.available():
         sys.exit("reference not available")
     os.makedirs(OUT, exist_ok=True)
-    make_semilag()
-    make_sparse()
-    make_probmatch()
+    only = sys.argv[1:]
+    for name, fn in (("semilag", make_semilag), ("semilag_order3_modes", make_semilag_order3_modes), ("sparse", make_sparse),
+                     ("probmatch", make_probmatch)):
+        if not only or name in only:
+            fn()
 
 
 if __name__ == "__main__":
