@@ -461,6 +461,9 @@ int psh_probmatch_status(int status);
  * half of the work once: a plan keeps the target's statistics, verdict and sorted wet values.
  * psh_probmatch_planned_dev(plan, initial, count, out, status_dev) = psh_probmatch_async_dev against the plan's
  * target (status_dev NULL: waits and returns the verdict like psh_probmatch_dev).  Identical outputs. */
+/* k-th smallest value (0-based) of a NaN-free field: what compute_percentile_mask (pysteps/nowcasts/utils.py:102-138)
+ * takes out of its full sort for the S-PROG precipitation mask (nowcasts/steps.py:1113-1114). Waits. */
+int psh_order_statistic_dev(const double *field_dev, size_t count, size_t index, double *value_host);
 int psh_probmatch_plan_create(const double *target_dev, size_t count, void **plan_out);
 int psh_probmatch_plan_destroy(void *plan);
 int psh_probmatch_planned_dev(const void *plan, const double *initial_dev, size_t count, double *out_dev, int *status_dev);

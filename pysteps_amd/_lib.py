@@ -79,6 +79,7 @@ SIGNATURES = {
     "psh_probmatch_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "psh_probmatch_async_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "psh_probmatch_status": (c_int, [c_int]),
+    "psh_order_statistic_dev": (c_int, [c_void_p, c_size_t, c_size_t, POINTER(c_double)]),
     "psh_probmatch_plan_create": (c_int, [c_void_p, c_size_t, c_void_p]),
     "psh_probmatch_plan_destroy": (c_int, [c_void_p]),
     "psh_probmatch_planned_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

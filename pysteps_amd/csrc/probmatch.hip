@@ -757,6 +757,46 @@ extern "C" int psh_probmatch_planned_dev(const void *plan_handle, const double *
   return probmatch_run(initial_dev, nullptr, count, out_dev, status_dev, plan, nullptr);
 }
 
+// The k-th smallest value of a field without NaNs (0-based) - what compute_percentile_mask
+// (pysteps/nowcasts/utils.py:102-138: a full sort, then ONE element of it) needs for the S-PROG mask of the
+// STEPS member loop (steps.py:1113-1114).  The plan of the field as a matching target IS its sorted form:
+// `zeros` copies of the minimum followed by the sorted larger values.
+extern "C" int psh_order_statistic_dev(const double *field_dev, size_t count, size_t index, double *value_host) {
+  using namespace psh;
+  if (!value_host) return fail(PSH_EINVAL, "order_statistic: NULL pointer");
+  if (index >= count) return fail(PSH_EINVAL, "order_statistic: index %zu outside 0..%zu", index, count - 1);
+  void *handle = nullptr;
+  if (int rc = psh_probmatch_plan_create(field_dev, count, &handle)) return rc;
+  PmPlan *plan = static_cast<PmPlan *>(handle);
+  Context &c = ctx();
+  int rc = PSH_OK;
+  {
+    std::lock_guard<std::recursive_mutex> lock(c.mu);
+    static void *pinned = nullptr;
+    auto run = [&]() -> int {
+      if (int r = persistent_pinned(&pinned, 512)) return r;
+      PmHeader *h = static_cast<PmHeader *>(pinned);
+      PSH_HIP(hipMemcpyAsync(h, plan->blk, sizeof(PmHeader), hipMemcpyDeviceToHost, c.stream));
+      PSH_HIP(hipStreamSynchronize(c.stream));
+      if (h->status != kStOk) return probmatch_status_to_rc(h->status);
+      if (h->n_nan[1] != 0) return fail(PSH_EINVAL, "order_statistic: the field contains NaNs");
+      const size_t zeros = count - h->wet[1];
+      if (index < zeros) {
+        *value_host = h->z[1];
+        return PSH_OK;
+      }
+      double *slot = reinterpret_cast<double *>(static_cast<char *>(pinned) + 256);
+      PSH_HIP(hipMemcpyAsync(slot, plan->tw() + (index - zeros), sizeof(double), hipMemcpyDeviceToHost, c.stream));
+      PSH_HIP(hipStreamSynchronize(c.stream));
+      *value_host = *slot;
+      return PSH_OK;
+    };
+    rc = run();
+  }
+  (void)psh_probmatch_plan_destroy(handle);
+  return rc;
+}
+
 extern "C" int psh_probmatch_status(int status) {
   return probmatch_status_to_rc(status);
 }

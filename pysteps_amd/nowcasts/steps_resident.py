@@ -59,6 +59,21 @@ def recognises(func):
     return owner is not None and type(owner).__name__ == "StepsNowcaster" and getattr(func, "__name__", "") == "__update_state"
 
 
+def _percentile_index(count, pct):
+    """Index into the sorted field that compute_percentile_mask (nowcasts/utils.py:129-135) thresholds at:
+    ``argmin |x - pct|`` over ``x[k] = 1.0 * (count - k) / count`` (first minimum), evaluated on a window around
+    the analytic position with NumPy's own operations; ties between equal VALUES do not change the threshold.
+    None where the reference reads one element past the end (index count - 1)."""
+    if not 0.0 <= pct <= 1.0 or count < 2:
+        return None
+    k0 = int(round(count - pct * count))
+    ks = np.arange(max(0, k0 - 4), min(count, k0 + 5))
+    x = 1.0 * (count - ks) / count
+    i = int(ks[np.argmin(np.abs(x - pct))])
+    # |x - pct| falls towards the minimum and rises after it: the window holds the global first minimum
+    return None if i >= count - 1 else i
+
+
 def try_create(func, state, params, shape, n_updates):
     """A :class:`ResidentSteps` for the update function ``func`` of the reference's STEPS nowcaster, or
     None if ``func`` is something else or uses options outside the resident chain."""
@@ -96,7 +111,7 @@ class ResidentSteps:
             raise _Declined
         if np.shape(F["field"]) != (m, n // 2 + 1) or np.any(~np.isfinite(F["field"])):
             raise _Declined  # the reference raises its ValueError on its own path
-        if p["mask_method"] not in (None, "incremental", "obs") or p["probmatching_method"] not in (None, "cdf", "mean"):
+        if p["mask_method"] not in (None, "incremental", "obs", "sprog") or p["probmatching_method"] not in (None, "cdf", "mean"):
             raise _Declined
         self.B, self.L = int(p["n_ens_members"]), int(p["n_cascade_levels"])
         phi = np.asarray(p["phi"], dtype=np.float64)
@@ -169,6 +184,24 @@ class ResidentSteps:
             self.wet = DeviceArray((m, n), np.uint8)
         elif self.mask_method == "obs":
             self.keep = DeviceArray.from_host(np.ascontiguousarray(state["mask_prec"], dtype=np.uint8))
+        elif self.mask_method == "sprog":
+            # steps.py:1089-1114: the deterministic AR(p) model of the S-PROG field runs beside the members, its
+            # recomposed field thresholded at the percentile that keeps the observed wet-area ratio is the
+            # mask of EVERY member at that time step
+            det, det_d = state.get("precip_m"), state.get("precip_m_d")
+            if (det is None or not isinstance(det_d, dict) or len(det) != self.L or any(np.shape(c) != (self.p, m, n) for c in det)
+                    or not det_d.get("normalized", False) or det_d.get("domain") != "spatial" or p.get("war") is None):
+                raise _Declined
+            self.war = float(p["war"])
+            self.det_index = _percentile_index(self.plane, self.war)
+            if self.det_index is None:
+                raise _Declined  # (the reference's own index arithmetic runs off the end there)
+            self.det = DeviceArray.from_host(np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.float64) for c in det])))
+            self.det_head = 0
+            self.det_mu = np.ascontiguousarray(det_d["means"], dtype=np.float64)
+            self.det_sigma = np.ascontiguousarray(det_d["stds"], dtype=np.float64)
+            self.det_field = DeviceArray((m, n), np.float64)
+            self.keep = DeviceArray((m, n), np.uint8)
         self.target = None
         if self.pm_method == "cdf":
             tgt = p["precip"]
@@ -228,6 +261,8 @@ class ResidentSteps:
             self._white_ready = False
         out = DeviceArray((self.B, m, n), np.float64)
         lvl_stride = self.p * plane * 8
+        if self.mask_method == "sprog":
+            self._update_sprog_mask()
         for j in range(self.B):
             result = out.view(j)
             field = self.pre.view(j) if self.pre is not None else result  # what the matching reads
@@ -280,6 +315,28 @@ class ResidentSteps:
                 "psh_dilated_mask_dev")
         if self.domain_mask is not None:
             _lib.check(lib.psh_nan_where_dev(field.ptr, self.domain_mask.ptr, plane), "psh_nan_where_dev")
+
+    def _update_sprog_mask(self):
+        """steps.py:1089-1114 `__update_deterministic_ar_model` + nowcasts/utils.py:102-138 `compute_percentile_mask`:
+        AR step of the deterministic cascade (no noise), recomposition, and the mask `field >= s[i]` with s the
+        sorted field and i the index whose exceedance fraction is closest to the wet-area ratio."""
+        import ctypes  # noqa: PLC0415
+
+        lib, plane = self._lib, self.plane
+        _lib.check(lib.psh_steps_ar_recompose_dev(self.det.ptr, self.L, self.p, plane, self.det_head, self._phi_p, None, None,
+                                                  self.det_mu.ctypes.data, self.det_sigma.ctypes.data, self.det_field.ptr, None),
+                   "psh_steps_ar_recompose_dev")
+        self.det_head = (self.det_head + 1) % self.p
+        thr = ctypes.c_double()
+        rc = lib.psh_order_statistic_dev(self.det_field.ptr, plane, self.det_index, ctypes.byref(thr))
+        if rc == _lib.PSH_EUNSUPPORTED:  # a value plateau the bucket pass declines: the reference's sort
+            from pysteps.nowcasts.utils import compute_percentile_mask  # noqa: PLC0415
+
+            mask = compute_percentile_mask(self.det_field.to_host(), self.war)
+            self.keep = DeviceArray.from_host(np.ascontiguousarray(mask, dtype=np.uint8))
+            return
+        _lib.check(rc, "psh_order_statistic_dev")
+        _lib.check(lib.psh_ge_mask_dev(self.det_field.ptr, plane, thr.value, self.keep.ptr), "psh_ge_mask_dev")
 
     def _probmatch_on_host(self, field):
         """The device CDF matching declined (thousands of tied wet values, infinities in the target):

@@ -128,6 +128,35 @@ def test_raw_noise_levels_standardised_on_the_way_in(ref_pysteps, L, shape):
     np.testing.assert_array_equal(got_stats[:, 1], stds)
 
 
+def test_order_statistic_and_percentile_mask(ref_pysteps):
+    """psh_order_statistic_dev == np.sort(field)[k]; with the index arithmetic of compute_percentile_mask
+    (nowcasts/utils.py:102-138) the device mask is the reference's."""
+    from pysteps.nowcasts.utils import compute_percentile_mask
+
+    from pysteps_amd import _lib
+    from pysteps_amd.nowcasts.steps_resident import _percentile_index
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(17)
+    for shape in ((64, 64), (150, 190), (1024, 512)):
+        field = rng.standard_normal(shape) * 7.0
+        field[rng.random(shape) < 0.2] = field.min()  # a block of pixels at the minimum
+        field[3, :40] = 1.25                           # a plateau
+        d = _dev(field)
+        srt = np.sort(field, axis=None)
+        for k in (0, 5, field.size // 5, field.size // 2, field.size - 2, field.size - 1):
+            v = ctypes.c_double()
+            _lib.check(lib.psh_order_statistic_dev(d.ptr, field.size, k, ctypes.byref(v)))
+            assert v.value == srt[k], (shape, k)
+        for war in (0.03, 0.25, 0.5, 0.8):
+            i = _percentile_index(field.size, war)
+            v = ctypes.c_double()
+            _lib.check(lib.psh_order_statistic_dev(d.ptr, field.size, i, ctypes.byref(v)))
+            np.testing.assert_array_equal(field >= v.value, compute_percentile_mask(field, war))
+    v = ctypes.c_double()
+    assert lib.psh_order_statistic_dev(d.ptr, field.size, field.size, ctypes.byref(v)) == _lib.PSH_EINVAL
+
+
 def test_elementwise_pieces_bit_identical_with_numpy():
     from pysteps_amd import _lib
     from pysteps_amd.device import DeviceArray
@@ -185,6 +214,7 @@ CONFIGS = {
     "obs_none": dict(mask_method="obs", probmatching_method=None),
     "nomask_mean": dict(mask_method=None, probmatching_method="mean"),
     "ar1_8levels": dict(mask_method="incremental", probmatching_method="cdf", ar_order=1, n_cascade_levels=8),
+    "sprog_cdf": dict(mask_method="sprog", probmatching_method="cdf"),  # deterministic AR model + percentile mask per step
 }
 
 
@@ -282,7 +312,7 @@ def test_steps_end_to_end_resident_loop_runs_and_matches(ref_pysteps, timesteps,
 
 
 def test_declined_options_take_the_reference_update(ref_pysteps):
-    """spectral domain / sprog mask: try_create returns None and the reference's own function runs"""
+    """spectral domain: try_create returns None and the reference's own function runs"""
     from pysteps import nowcasts
 
     from pysteps_amd import register
@@ -300,7 +330,7 @@ def test_declined_options_take_the_reference_update(ref_pysteps):
         register.register(patch_main_loop=True)
         steps_resident.ResidentSteps.__init__ = spy
         out = nowcasts.get_method("steps")(frames, V, 2, n_ens_members=2, n_cascade_levels=6, precip_thr=-10.0, kmperpixel=1.0,
-                                           timestep=5.0, seed=1, mask_method="sprog", extrap_method="semilagrangian_hip",
+                                           timestep=5.0, seed=1, domain="spectral", extrap_method="semilagrangian_hip",
                                            num_workers=1)
     finally:
         steps_resident.ResidentSteps.__init__ = orig
