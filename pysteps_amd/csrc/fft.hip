@@ -341,9 +341,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_cols_c2c(const double2 *__res
 // N1 over N1 CONSECUTIVE rows (sweep B, output row N2 k1 + k2).  A workgroup then needs only 512
 // elements of a column at a time and takes EIGHT columns instead: every row it touches is a
 // 128-byte request.  Twice the traffic of the one-sweep pass, all of it in full lines.
-constexpr int kStepCols = 8;      // columns per workgroup: 128 bytes of a row
-constexpr int kStepElems = 512;   // elements per column and workgroup (64 KiB of LDS in all)
-constexpr int kStepThreads = 512;
+// a workgroup holds 2^LOGT elements (16 B each): 2^LOGC columns x 2^(LOGT - LOGC) elements of each, one thread per 8 elements
 
 __device__ __forceinline__ double2 root_of_unity(const double2 *__restrict__ tw, int p, int half, bool inv) {
   double2 w = tw[p >= half ? p - half : p];  // W_N^p, p < N: W^(p + N/2) = -W^p
@@ -354,8 +352,8 @@ __device__ __forceinline__ double2 root_of_unity(const double2 *__restrict__ tw,
 
 // SWEEP 0 (A): sequences (column c, n1), elements n2, rows n1 + N1 n2 -> Z at rows n1 + N1 k2
 // SWEEP 1 (B): sequences (column c, k2), elements n1, rows n1 + N1 k2 -> X at rows N2 k1 + k2
-template <bool INV, int SWEEP>
-__global__ __launch_bounds__(kStepThreads) void fft_cols_step(const double2 *__restrict__ in, const double2 *__restrict__ tw,
+template <bool INV, int SWEEP, int LOGC, int LOGT>
+__global__ __launch_bounds__(1 << (LOGT - 3)) void fft_cols_step(const double2 *__restrict__ in, const double2 *__restrict__ tw,
                                                               int logn, int log1, int nc, double scale,
                                                               double2 *__restrict__ out, int items, int items_per_xcd,
                                                               int col_tiles, const double *__restrict__ weights) {
@@ -368,6 +366,7 @@ __global__ __launch_bounds__(kStepThreads) void fft_cols_step(const double2 *__r
   const int N1 = 1 << log1, N2 = 1 << log2_;
   const int logl = SWEEP == 0 ? log2_ : log1;         // length of this sweep's transforms
   const int L = 1 << logl;
+  constexpr int kStepCols = 1 << LOGC, kStepElems = 1 << (LOGT - LOGC), kStepThreads = 1 << (LOGT - 3);
   const int per_col = kStepElems >> logl;             // sequences per column in this workgroup
   const int pitch = L + 2;  // sequences two 16-byte units apart in the banks (the tile is walked across sequences; even: fft_lds pairs slots by ^ 1)
   const int first = group * per_col;                  // first n1 (A) / k2 (B) of the group
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(kStepThreads) void fft_cols_step(const double2 *__r
   const int live = min(kStepCols, nc - c0);
   // element e of the tile: column e % 8, then (sequence, element) so that consecutive threads read one row
   for (int idx = threadIdx.x; idx < kStepCols * kStepElems; idx += kStepThreads) {
-    const int c = idx & (kStepCols - 1), q = idx >> 3;
+    const int c = idx & (kStepCols - 1), q = idx >> LOGC;
     int seq, el, row;
     if (SWEEP == 0) {
       seq = q & (per_col - 1);  // n1 - first: rows first .. first + per_col - 1 are consecutive
@@ -401,7 +400,7 @@ __global__ __launch_bounds__(kStepThreads) void fft_cols_step(const double2 *__r
   __syncthreads();
   fft_lds<INV>(z, pitch, kStepCols * per_col, logl, tw, SWEEP == 0 ? N1 : N2);
   for (int idx = threadIdx.x; idx < kStepCols * kStepElems; idx += kStepThreads) {
-    const int c = idx & (kStepCols - 1), q = idx >> 3;
+    const int c = idx & (kStepCols - 1), q = idx >> LOGC;
     int seq, k, row;
     if (SWEEP == 0) {
       seq = q & (per_col - 1);
@@ -540,31 +539,40 @@ int launch_cols(bool inverse, const double2 *in, const Dft &d, int nc, double sc
                 hipStream_t stream, const double *weights = nullptr) {
   const int len = 1 << d.logm;
   static const int four_step = [] { const char *e = std::getenv("PYSTEPS_HIP_FFT_FOURSTEP"); return e ? std::atoi(e) : 1; }();
-  // measured (profiles/r03/i_fft_column_pass_probe.txt): 8 % faster than one sweep at 8192 points, equal at
-  // 4096, 15-25 % slower at 1024 / 2048 (PYSTEPS_HIP_FFT_FOURSTEP=2 takes it from 1024 points on)
+  // measured (profiles/r03/i_fft_column_pass_probe.txt): 11 % faster than one sweep at 8192 points, equal at
+  // 4096, 10-25 % slower at 1024 / 2048 (PYSTEPS_HIP_FFT_FOURSTEP=2 takes it from 1024 points on)
   if (four_step && !d.chirp && d.logm >= (four_step == 2 ? 10 : 13)) {
-    // two sweeps over 8-column tiles (fft_cols_step) through a block of the same size
+    // two sweeps over column tiles (fft_cols_step) through a block of the same size
     void *tmp = nullptr;
     if (int rc = psh_malloc(&tmp, static_cast<size_t>(len) * nc * sizeof(double2))) return rc;
     const int log1 = d.logm / 2, log2_ = d.logm - log1;
-    const int col_tiles = (nc + kStepCols - 1) / kStepCols;
-    auto sweep = [&](auto kernel, int logl, int sequences, const double2 *src, double2 *dst, double sc,
+    auto sweep = [&](auto kernel, int lc, int lt, int logl, int sequences, const double2 *src, double2 *dst, double sc,
                      const double *w) -> int {
-      const int per_col = kStepElems >> logl;
+      const int cols = 1 << lc, elems = 1 << (lt - lc);
+      const int col_tiles = (nc + cols - 1) / cols;
+      const int per_col = elems >> logl;
+      if (per_col < 1 || sequences % per_col != 0) return fail(PSH_EINVAL, "fft: column tile does not fit the transform");
       const int items = col_tiles * (sequences / per_col);
       const int ipx = (items + kNumXcd - 1) / kNumXcd;
-      const size_t lds = static_cast<size_t>(kStepCols) * per_col * ((1 << logl) + 2) * sizeof(double2);
+      const size_t lds = static_cast<size_t>(cols) * per_col * ((1 << logl) + 2) * sizeof(double2);
       if (int rc = allow_lds(kernel, lds)) return rc;
-      hipLaunchKernelGGL(kernel, dim3(ipx * kNumXcd), dim3(kStepThreads), lds, stream, src, d.tw, d.logm, log1, nc, sc, dst,
+      hipLaunchKernelGGL(kernel, dim3(ipx * kNumXcd), dim3(1 << (lt - 3)), lds, stream, src, d.tw, d.logm, log1, nc, sc, dst,
                          items, ipx, col_tiles, w);
       PSH_HIP(hipGetLastError());
       return PSH_OK;
     };
-    int rc = inverse ? sweep(fft_cols_step<true, 0>, log2_, 1 << log1, in, static_cast<double2 *>(tmp), 1.0, weights)
-                     : sweep(fft_cols_step<false, 0>, log2_, 1 << log1, in, static_cast<double2 *>(tmp), 1.0, weights);
-    if (rc == PSH_OK)
-      rc = inverse ? sweep(fft_cols_step<true, 1>, log1, 1 << log2_, static_cast<const double2 *>(tmp), out, scale, nullptr)
-                   : sweep(fft_cols_step<false, 1>, log1, 1 << log2_, static_cast<const double2 *>(tmp), out, scale, nullptr);
+    int rc = PSH_OK;
+    double2 *mid = static_cast<double2 *>(tmp);
+#define PSH_STEPS(LC, LT)                                                                                               \
+  rc = inverse ? sweep(fft_cols_step<true, 0, LC, LT>, LC, LT, log2_, 1 << log1, in, mid, 1.0, weights)                 \
+               : sweep(fft_cols_step<false, 0, LC, LT>, LC, LT, log2_, 1 << log1, in, mid, 1.0, weights);               \
+  if (rc == PSH_OK)                                                                                                     \
+    rc = inverse ? sweep(fft_cols_step<true, 1, LC, LT>, LC, LT, log1, 1 << log2_, mid, out, scale, nullptr)            \
+                 : sweep(fft_cols_step<false, 1, LC, LT>, LC, LT, log1, 1 << log2_, mid, out, scale, nullptr)
+    // 16 columns x 128 elements per workgroup of 256 threads: tiles of 2^10 .. 2^12 elements and 8 .. 32 columns were
+    // measured within 4 % of each other (profiles/r03/i_fft_column_pass_probe.txt), this one the fastest at 8192 points
+    PSH_STEPS(4, 11);
+#undef PSH_STEPS
     (void)psh_free(tmp);  // stream-ordered
     return rc;
   }
