@@ -63,6 +63,70 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 w) {
   return make_double2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
 }
 
+// one butterfly of a pass (two radix-2 layers): wb = W_4h^j (already conjugated for INV); the results
+// replace x0..x3 at the positions they were read from (e0, e0 + h, e0 + 2h, e0 + 3h)
+template <bool INV>
+__device__ __forceinline__ void radix4(double2 &x0, double2 &x1, double2 &x2, double2 &x3, double2 wb) {
+  const double2 wa = cmul(wb, wb);                                                  // W_2h^j
+  const double2 wc = INV ? make_double2(-wb.y, wb.x) : make_double2(wb.y, -wb.x);  // W_4h^(j+h)
+  const double2 t1 = cmul(x1, wa), t3 = cmul(x3, wa);
+  const double2 a0 = make_double2(x0.x + t1.x, x0.y + t1.y), a1 = make_double2(x0.x - t1.x, x0.y - t1.y);
+  const double2 a2 = make_double2(x2.x + t3.x, x2.y + t3.y), a3 = make_double2(x2.x - t3.x, x2.y - t3.y);
+  const double2 u2 = cmul(a2, wb), u3 = cmul(a3, wc);
+  x0 = make_double2(a0.x + u2.x, a0.y + u2.y);
+  x2 = make_double2(a0.x - u2.x, a0.y - u2.y);
+  x1 = make_double2(a1.x + u3.x, a1.y + u3.y);
+  x3 = make_double2(a1.x - u3.x, a1.y - u3.y);
+}
+
+// TWO consecutive passes (four radix-2 layers, half sizes h and 4h) on 16 elements e0 + a h + b 4h held in
+// registers in between: the first pass couples a (same twiddle W_4h^j for every b), the second couples b
+// (twiddle W_16h^(j + a h)).  The same operations on the same operands as two separate passes, with one
+// LDS round trip, one barrier and one set of index arithmetic instead of two - the passes are bound by
+// VALU issue (35 instructions per point and pass, 10 of them arithmetic: profiles/r03/n_fft_pmc.csv).
+template <bool INV>
+__device__ __forceinline__ void fft_pass16(double2 *z, int pitch, int count, int logn, int s,
+                                           const double2 *__restrict__ tw, int tws) {
+  const int N = 1 << logn, h = 1 << s;
+  const int st_a = N >> (s + 2), st_b = N >> (s + 4);  // W_4h^j = W_N^(j st_a), W_16h^j' = W_N^(j' st_b)
+  const int total = (N >> 4) * count;
+  for (int t = threadIdx.x; t < total; t += static_cast<int>(blockDim.x)) {
+    const int c = t >> (logn - 4), q = t & ((N >> 4) - 1);
+    const int j = q & (h - 1);
+    const int e0 = ((q >> s) << (s + 4)) + j;
+    const int base = c * pitch;
+    int at[4][4];
+    double2 x[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        at[a][b] = base + lpad(e0 + a * h + b * 4 * h);
+        x[a][b] = z[at[a][b]];
+      }
+    }
+    double2 wa = tw[j * st_a * tws];
+    double2 wb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wb[a] = tw[(j + a * h) * st_b * tws];
+    if (INV) {
+      wa.y = -wa.y;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wb[a].y = -wb[a].y;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) radix4<INV>(x[0][b], x[1][b], x[2][b], x[3][b], wa);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) radix4<INV>(x[a][0], x[a][1], x[a][2], x[a][3], wb[a]);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) z[at[a][b]] = x[a][b];
+    }
+  }
+  __syncthreads();
+}
+
 // in-place DIT FFT of `count` independent sequences z[c * pitch + lpad(i)], i < N = 1 << logn, whose
 // elements were stored bit-reversed; INV conjugates the twiddles (unscaled inverse).
 // A thread takes four butterflies per round: their sixteen LDS reads and four twiddle loads are
@@ -73,6 +137,8 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 w) {
 // Only W_4h^j is fetched per butterfly: W_2h^j is its square and W_4h^(j+h) = -i W_4h^j.
 // `tw` is the table of a length N * tws (entry k * tws = exp(-2 pi i k / N)): sub-transforms of a
 // longer transform read the long table with a stride.
+// (Compile-time lengths - every shift, mask and twiddle stride an immediate, the pass loop unrolled - were
+// measured 2 % faster and cost four copies of every kernel: not kept.)
 template <bool INV>
 __device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int logn,
                                         const double2 *__restrict__ tw, int tws = 1) {
@@ -104,7 +170,8 @@ __device__ __forceinline__ void fft_lds(double2 *z, int pitch, int count, int lo
     __syncthreads();
     s = 1;
   }
-  for (; s < logn; s += 2) {  // (logn - s is even here)
+  for (; s + 4 <= logn; s += 4) fft_pass16<INV>(z, pitch, count, logn, s, tw, tws);
+  for (; s < logn; s += 2) {  // (logn - s is even here): the last pair of layers where the count is not a multiple of four
     const int h = 1 << s;          // half size of the first layer
     const int st2 = N >> (s + 2);  // W_{4h}^j = W_N^{j st2}
     const int total = (N >> 2) * count;
