@@ -95,13 +95,16 @@ __device__ __forceinline__ void fft_pass16(double2 *z, int pitch, int count, int
     const int j = q & (h - 1);
     const int e0 = ((q >> s) << (s + 4)) + j;
     const int base = c * pitch;
+    // lpad is linear over GF(2) and the bits of a h + b 4h are zero in e0 (no carries): the swizzled slot of
+    // e0 + a h + b 4h is lpad(e0) ^ lpad(a h + b 4h), the second factor the same for the whole wave
+    const int slot0 = lpad(e0);
     int at[4][4];
     double2 x[4][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        at[a][b] = base + lpad(e0 + a * h + b * 4 * h);
+        at[a][b] = base + (slot0 ^ lpad(a * h + b * 4 * h));
         x[a][b] = z[at[a][b]];
       }
     }
