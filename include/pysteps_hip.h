@@ -509,6 +509,23 @@ int psh_steps_ar_recompose_raw_dev(double *cascades_dev, int nlevels, int p, siz
                                    const double *phi_host, const double *eps_dev, const double *eps_stats_dev,
                                    const double *eps_scale_host, const double *mu_host, const double *sigma_host,
                                    double *field_dev, unsigned long long *min_key_dev);
+/* The same member update with the AR history kept as SPECTRA (rfft2 of the level fields): everything between the white
+ * noise and the recomposed field is linear except two standardisations, whose second moments Parseval's identity reads
+ * off the spectrum - two transforms per member update instead of nine (what the reference's domain="spectral" option
+ * does, nowcasts/steps.py:122-126; same numbers as the spatial chain up to rounding).
+ *   psh_steps_spectral_sums_dev  noise_spec = rfft2(white) (m, n/2+1) complex128, filter (m, n/2+1), weights
+ *                                (nlevels, m, n/2+1) float64 -> sums[k] = sum' |noise filter weights_k|^2 (device)
+ *   psh_steps_spectral_ar_dev    cascades (nlevels, p, m, n/2+1) complex128 rings (slot `head` = oldest, overwritten):
+ *                                X_k <- sum_j phi_kj X_k[-1-j] + phi_kp noise_std_k m n / sqrt(sums_k) noise filter weights_k;
+ *                                field_spec = sum_k sigma_k X_k + (sum_k mu_k) m n at DC   (field = irfft2(field_spec))
+ *   psh_field_min_key_dev        np.min of a field as the order-preserving key psh_steps_mask_dev reads */
+int psh_steps_spectral_sums_dev(const void *noise_spec_dev, const double *filter_dev, const double *weights_dev, int nlevels,
+                                int m, int n, double *sums_dev);
+int psh_steps_spectral_ar_dev(void *cascades_dev, int nlevels, int p, int m, int n, int head, const double *phi_host,
+                              const void *noise_spec_dev, const double *filter_dev, const double *weights_dev,
+                              const double *sums_dev, const double *noise_std_host, const double *mu_host,
+                              const double *sigma_host, void *field_spec_dev);
+int psh_field_min_key_dev(const double *field_dev, size_t n, unsigned long long *min_key_dev);
 int psh_steps_mask_dev(double *field_dev, size_t n, const double *grey_mask_dev, const unsigned char *keep_mask_dev,
                        const unsigned long long *min_key_dev);
 int psh_steps_mean_shift_dev(double *field_dev, size_t n, double threshold, double mu_0);

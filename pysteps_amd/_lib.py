@@ -89,6 +89,10 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p]),
     "psh_steps_ar_recompose_raw_dev": (c_int, [c_void_p, c_int, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psh_steps_spectral_sums_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "psh_steps_spectral_ar_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psh_field_min_key_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
     "psh_steps_mask_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "psh_steps_mean_shift_dev": (c_int, [c_void_p, c_size_t, c_double, c_double]),
     "psh_ge_mask_dev": (c_int, [c_void_p, c_size_t, c_double, c_void_p]),

@@ -238,6 +238,136 @@ unsigned grid_for(size_t n) {
   return static_cast<unsigned>(blocks < 8192 ? (blocks ? blocks : 1) : 8192);
 }
 
+// ---- the member update in the spectral domain ---------------------------------------------------------
+// Everything between the white noise and the recomposed field is linear (noise filter, band-pass
+// decomposition, AR(p) step, recomposition) except the two standardisations - of the noise field and of
+// its cascade levels (fftgenerators.py:433-437, decomposition.py:217-232) - and those need only second
+// moments, which Parseval's identity reads off the spectrum.  So the AR history is kept as SPECTRA
+// (rfft2 of the reference's level fields) and a member update needs TWO transforms - rfft2 of the white
+// noise, irfft2 of the recomposed spectrum - instead of nine:
+//   y     = rfft2(white) F                           (the noise field's spectrum; its mean is removed = DC -> 0)
+//   B_k   = sum' |y w_k|^2                            (Hermitian-weighted over the half spectrum, DC excluded)
+//   std(noise) std(level k) = sqrt(B_k) / (m n)       (the noise field's own variance cancels)
+//   X_k  <- phi_k1 X_k[-1] + ... + phi_kp X_k[-p] + phi_k,p+1 noise_std_k (m n) / sqrt(B_k) y w_k
+//   field = irfft2( sum_k sigma_k X_k  +  (sum_k mu_k) m n at DC )
+// The same numbers as the chain of the reference's spatial operators up to rounding (every step of
+// that chain goes through transforms already); this is also what the reference's own domain="spectral"
+// option does (steps.py:122-126).  Band-pass weights and noise filter are real and symmetric (functions
+// of |k|), so every spectrum stays Hermitian.
+struct SpectralAr {
+  double phi[kMaxLevels][kMaxOrder + 1];
+  double gain[kMaxLevels];  // phi_k,p+1 noise_std_k m n        (divided by sqrt(B_k) in the kernel)
+  double sigma[kMaxLevels];
+  double dc_add;            // (sum_k mu_k) m n
+  int nlevels, p, head;
+};
+
+// hermitian weight of column c of an rfft2 half spectrum: interior columns stand for two coefficients
+__device__ __forceinline__ double herm_weight(int c, int nc, int n_even) { return (c == 0 || (n_even && c == nc - 1)) ? 1.0 : 2.0; }
+
+__global__ __launch_bounds__(kThreads) void spectral_level_sums(const double2 *__restrict__ noise, const double *__restrict__ filt,
+                                                                const double *__restrict__ weights, int nlevels, int m,
+                                                                int nc, int n_even, double *__restrict__ partial) {
+  __shared__ double s_part[kThreads / 64][kMaxLevels];
+  const size_t plane = static_cast<size_t>(m) * nc, stride = static_cast<size_t>(gridDim.x) * kThreads;
+  double acc[kMaxLevels];
+#pragma unroll
+  for (int k = 0; k < kMaxLevels; ++k) acc[k] = 0.0;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < plane; i += stride) {
+    if (i == 0) continue;  // DC: the noise field's mean, removed by its standardisation
+    const int c = static_cast<int>(i % nc);
+    const double2 y = noise[i];
+    const double f = filt[i];
+    const double e = herm_weight(c, nc, n_even) * f * f * (y.x * y.x + y.y * y.y);
+#pragma unroll
+    for (int k = 0; k < kMaxLevels; ++k) {
+      if (k < nlevels) {
+        const double w = weights[static_cast<size_t>(k) * plane + i];
+        acc[k] += e * w * w;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxLevels; ++k) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc[k] += __shfl_xor(acc[k], d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < kMaxLevels; ++k) s_part[threadIdx.x >> 6][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < kMaxLevels) {
+    double t = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) t += s_part[w][threadIdx.x];
+    partial[static_cast<size_t>(blockIdx.x) * kMaxLevels + threadIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void spectral_level_sums_final(const double *__restrict__ partial, int nparts,
+                                                                      double *__restrict__ sums) {
+  __shared__ double s_part[kThreads / 64];
+  for (int k = 0; k < kMaxLevels; ++k) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += kThreads) t += partial[static_cast<size_t>(i) * kMaxLevels + k];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double all = 0.0;
+      for (int w = 0; w < kThreads / 64; ++w) all += s_part[w];
+      sums[k] = all;
+    }
+  }
+}
+
+// cascades: (L, p, plane) complex rings of one member; writes the new spectra into slot `head` and the
+// recomposed spectrum into `out`
+__global__ __launch_bounds__(kThreads) void spectral_ar(double2 *__restrict__ cascades, const double2 *__restrict__ noise,
+                                                        const double *__restrict__ filt, const double *__restrict__ weights,
+                                                        const double *__restrict__ sums, size_t plane, SpectralAr a,
+                                                        double2 *__restrict__ out) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  __shared__ double gain[kMaxLevels];
+  if (threadIdx.x < kMaxLevels) gain[threadIdx.x] = static_cast<int>(threadIdx.x) < a.nlevels ? a.gain[threadIdx.x] / sqrt(sums[threadIdx.x]) : 0.0;
+  __syncthreads();
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < plane; i += stride) {
+    const double2 y0 = noise[i];
+    const double f = i == 0 ? 0.0 : filt[i];  // the standardised noise has no DC
+    const double2 y = make_double2(y0.x * f, y0.y * f);
+    double2 total = make_double2(i == 0 ? a.dc_add : 0.0, 0.0);
+    for (int k = 0; k < a.nlevels; ++k) {
+      double2 *lvl = cascades + static_cast<size_t>(k) * a.p * plane;
+      const double g = gain[k] * weights[static_cast<size_t>(k) * plane + i];
+      double2 acc = make_double2(g * y.x, g * y.y);
+      for (int j = 0; j < a.p; ++j) {  // x[-1-j] sits in slot (head + p - 1 - j) mod p
+        int slot = a.head + a.p - 1 - j;
+        if (slot >= a.p) slot -= a.p;
+        const double2 x = lvl[static_cast<size_t>(slot) * plane + i];
+        acc.x += a.phi[k][j] * x.x;
+        acc.y += a.phi[k][j] * x.y;
+      }
+      lvl[static_cast<size_t>(a.head) * plane + i] = acc;
+      total.x += a.sigma[k] * acc.x;
+      total.y += a.sigma[k] * acc.y;
+    }
+    out[i] = total;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void field_min_key(const double *__restrict__ field, size_t n,
+                                                          unsigned long long *__restrict__ min_out) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  unsigned long long key = ~0ull;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+    const unsigned long long k = min_key(field[i]);
+    key = k < key ? k : key;
+  }
+  publish_min(key, min_out);
+}
+
 }  // namespace
 }  // namespace psh
 
@@ -359,6 +489,77 @@ extern "C" int psh_lerp_dev(const double *a_dev, const double *b_dev, double w, 
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
   hipLaunchKernelGGL(psh::lerp, dim3(psh::grid_for(n)), dim3(psh::kThreads), 0, c.stream, a_dev, b_dev, w, out_dev, n);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+// ---- spectral member update (see the kernels above) -------------------------------------------------
+extern "C" int psh_steps_spectral_sums_dev(const void *noise_spec_dev, const double *filter_dev, const double *weights_dev,
+                                           int nlevels, int m, int n, double *sums_dev) {
+  PSH_REQUIRE_INIT();
+  if (!noise_spec_dev || !filter_dev || !weights_dev || !sums_dev) return fail(PSH_EINVAL, "steps_spectral_sums: NULL pointer");
+  if (nlevels < 1 || nlevels > psh::kMaxLevels || m <= 0 || n <= 1) return fail(PSH_EUNSUPPORTED, "steps_spectral_sums: 1..%d levels", psh::kMaxLevels);
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const int nc = n / 2 + 1;
+  const size_t plane = static_cast<size_t>(m) * nc;
+  const int grid = psh::grid_for(plane);
+  void *partial = nullptr;
+  if (int rc = psh_malloc(&partial, static_cast<size_t>(grid) * psh::kMaxLevels * sizeof(double))) return rc;
+  hipLaunchKernelGGL(psh::spectral_level_sums, dim3(grid), dim3(psh::kThreads), 0, c.stream, static_cast<const double2 *>(noise_spec_dev),
+                     filter_dev, weights_dev, nlevels, m, nc, (n & 1) == 0 ? 1 : 0, static_cast<double *>(partial));
+  hipLaunchKernelGGL(psh::spectral_level_sums_final, dim3(1), dim3(psh::kThreads), 0, c.stream, static_cast<const double *>(partial), grid,
+                     sums_dev);
+  const hipError_t e = hipGetLastError();
+  (void)psh_free(partial);  // stream-ordered
+  PSH_HIP(e);
+  return PSH_OK;
+}
+
+extern "C" int psh_steps_spectral_ar_dev(void *cascades_dev, int nlevels, int p, int m, int n, int head, const double *phi_host,
+                                         const void *noise_spec_dev, const double *filter_dev, const double *weights_dev,
+                                         const double *sums_dev, const double *noise_std_host, const double *mu_host,
+                                         const double *sigma_host, void *field_spec_dev) {
+  PSH_REQUIRE_INIT();
+  if (!cascades_dev || !phi_host || !noise_spec_dev || !filter_dev || !weights_dev || !sums_dev || !noise_std_host || !mu_host ||
+      !sigma_host || !field_spec_dev)
+    return fail(PSH_EINVAL, "steps_spectral_ar: NULL pointer");
+  if (nlevels < 1 || nlevels > psh::kMaxLevels || p < 1 || p > psh::kMaxOrder)
+    return fail(PSH_EUNSUPPORTED, "steps_spectral_ar: 1..%d cascade levels, AR order 1..%d", psh::kMaxLevels, psh::kMaxOrder);
+  if (m <= 0 || n <= 1 || head < 0 || head >= p) return fail(PSH_EINVAL, "steps_spectral_ar: invalid shape or ring head");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const size_t plane = static_cast<size_t>(m) * (n / 2 + 1);
+  const double mn = static_cast<double>(m) * static_cast<double>(n);
+  psh::SpectralAr a;
+  double mu_sum = 0.0;
+  for (int k = 0; k < nlevels; ++k) {
+    for (int j = 0; j <= p; ++j) a.phi[k][j] = phi_host[static_cast<size_t>(k) * (p + 1) + j];
+    a.gain[k] = a.phi[k][p] * noise_std_host[k] * mn;
+    a.sigma[k] = sigma_host[k];
+    mu_sum += mu_host[k];
+  }
+  a.dc_add = mu_sum * mn;
+  a.nlevels = nlevels;
+  a.p = p;
+  a.head = head;
+  hipLaunchKernelGGL(psh::spectral_ar, dim3(psh::grid_for(plane)), dim3(psh::kThreads), 0, c.stream, static_cast<double2 *>(cascades_dev),
+                     static_cast<const double2 *>(noise_spec_dev), filter_dev, weights_dev, sums_dev, plane, a,
+                     static_cast<double2 *>(field_spec_dev));
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+extern "C" int psh_field_min_key_dev(const double *field_dev, size_t n, unsigned long long *min_key_dev) {
+  PSH_REQUIRE_INIT();
+  if (!field_dev || !min_key_dev || n == 0) return fail(PSH_EINVAL, "field_min_key: NULL pointer or empty field");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  PSH_HIP(hipMemsetAsync(min_key_dev, 0xff, sizeof(unsigned long long), c.stream));
+  hipLaunchKernelGGL(psh::field_min_key, dim3(psh::grid_for(n)), dim3(psh::kThreads), 0, c.stream, field_dev, n, min_key_dev);
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }

@@ -28,6 +28,7 @@ the transforms agree with numpy.fft to ~1e-16; the random stream is NumPy's up t
 """
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -159,6 +160,21 @@ class ResidentSteps:
                     src = np.ascontiguousarray(cascades[j][k], dtype=np.float64)
                     _lib.check(self._lib.psh_memcpy_h2d(self.cascades.ptr + (j * self.L + k) * stride, src.ctypes.data, src.nbytes), "h2d")
             _lib.check(self._lib.psh_sync(), "sync")
+        # The AR history as SPECTRA (default): the update is linear between the white noise and the recomposed
+        # field apart from two standardisations that need second moments only (Parseval) - two transforms per
+        # member update instead of nine (csrc/steps_loop.hip).  PYSTEPS_HIP_RESIDENT_DOMAIN=spatial keeps the
+        # level fields and the chain of the reference's spatial operators (bit-identical element-wise part).
+        self.spectral = os.environ.get("PYSTEPS_HIP_RESIDENT_DOMAIN", "spectral") != "spatial"
+        if self.spectral:
+            nc = n // 2 + 1
+            spectra = DeviceArray((self.B, self.L, self.p, m, nc), np.complex128)
+            for q in range(self.B * self.L * self.p):
+                _lib.check(self._lib.psh_fft_rfft2_dev(self.cascades.ptr + q * self.plane * 8, m, n, spectra.ptr + q * m * nc * 16),
+                           "psh_fft_rfft2_dev")
+            self.cascades = spectra  # (the level fields are not kept)
+            self.noise_spec = DeviceArray((m, nc), np.complex128)
+            self.field_spec = DeviceArray((m, nc), np.complex128)
+            self.level_sums = DeviceArray((16,), np.float64)
         self.head = 0  # slot of the oldest entry
         self.thr = float(p["precip_thr"]) if p["precip_thr"] is not None else None
         self.mask_method, self.pm_method = p["mask_method"], p["probmatching_method"]
@@ -266,17 +282,31 @@ class ResidentSteps:
         for j in range(self.B):
             result = out.view(j)
             field = self.pre.view(j) if self.pre is not None else result  # what the matching reads
-            # fftgenerators.py:400-433 (the filter part), decomposition.py:77-262 with normalize=True
-            _lib.check(lib.psh_noise_filter_dev(white.view(j).ptr, self.noise_filter.ptr, m, n, self.noise.ptr), "psh_noise_filter_dev")
-            # (the levels stay unnormalised: the AR kernel standardises them on the way in, one sweep less)
-            _lib.check(lib.psh_cascade_decompose_stats_dev(self.noise.ptr, self.weights.ptr, self.L, m, n, self.eps.ptr, self.eps_stats.ptr),
-                       "psh_cascade_decompose_stats_dev")
-            # steps.py:1116-1146 + 1176-1185
-            _lib.check(
-                lib.psh_steps_ar_recompose_raw_dev(self.cascades.ptr + j * self.L * lvl_stride, self.L, self.p, plane, self.head,
-                                                   self._phi_p, self.eps.ptr, self.eps_stats.ptr, self._noise_std_p,
-                                                   self.mu[j].ctypes.data, self.sigma[j].ctypes.data, field.ptr, self.min_key.ptr),
-                "psh_steps_ar_recompose_raw_dev")
+            if self.spectral:
+                # rfft2(white); level variances by Parseval; AR step + recomposition on the spectra; ONE inverse transform
+                nc = n // 2 + 1
+                casc = self.cascades.ptr + j * self.L * self.p * m * nc * 16
+                _lib.check(lib.psh_fft_rfft2_dev(white.view(j).ptr, m, n, self.noise_spec.ptr), "psh_fft_rfft2_dev")
+                _lib.check(lib.psh_steps_spectral_sums_dev(self.noise_spec.ptr, self.noise_filter.ptr, self.weights.ptr, self.L, m, n,
+                                                           self.level_sums.ptr), "psh_steps_spectral_sums_dev")
+                _lib.check(lib.psh_steps_spectral_ar_dev(casc, self.L, self.p, m, n, self.head, self._phi_p, self.noise_spec.ptr,
+                                                         self.noise_filter.ptr, self.weights.ptr, self.level_sums.ptr,
+                                                         self._noise_std_p, self.mu[j].ctypes.data, self.sigma[j].ctypes.data,
+                                                         self.field_spec.ptr), "psh_steps_spectral_ar_dev")
+                _lib.check(lib.psh_fft_irfft2_dev(self.field_spec.ptr, m, n, field.ptr), "psh_fft_irfft2_dev")
+                _lib.check(lib.psh_field_min_key_dev(field.ptr, plane, self.min_key.ptr), "psh_field_min_key_dev")
+            else:
+                # fftgenerators.py:400-433 (the filter part), decomposition.py:77-262 with normalize=True
+                _lib.check(lib.psh_noise_filter_dev(white.view(j).ptr, self.noise_filter.ptr, m, n, self.noise.ptr), "psh_noise_filter_dev")
+                # (the levels stay unnormalised: the AR kernel standardises them on the way in, one sweep less)
+                _lib.check(lib.psh_cascade_decompose_stats_dev(self.noise.ptr, self.weights.ptr, self.L, m, n, self.eps.ptr, self.eps_stats.ptr),
+                           "psh_cascade_decompose_stats_dev")
+                # steps.py:1116-1146 + 1176-1185
+                _lib.check(
+                    lib.psh_steps_ar_recompose_raw_dev(self.cascades.ptr + j * self.L * lvl_stride, self.L, self.p, plane, self.head,
+                                                       self._phi_p, self.eps.ptr, self.eps_stats.ptr, self._noise_std_p,
+                                                       self.mu[j].ctypes.data, self.sigma[j].ctypes.data, field.ptr, self.min_key.ptr),
+                    "psh_steps_ar_recompose_raw_dev")
             if self.grey is not None:  # steps.py:1221-1240
                 _lib.check(lib.psh_steps_mask_dev(field.ptr, plane, self.grey.view(j).ptr, None, self.min_key.ptr), "psh_steps_mask_dev")
             elif self.keep is not None:
@@ -368,5 +398,12 @@ class ResidentSteps:
     def cascade_levels(self, j):
         """Member j's latest cascade level fields as the reference holds them (L, m, n) - test hook."""
         newest = (self.head + self.p - 1) % self.p
+        if self.spectral:
+            nc = self.n // 2 + 1
+            out = DeviceArray((self.L, self.m, self.n), np.float64)
+            for k in range(self.L):
+                at = ((j * self.L + k) * self.p + newest) * self.m * nc * 16
+                _lib.check(self._lib.psh_fft_irfft2_dev(self.cascades.ptr + at, self.m, self.n, out.view(k).ptr), "psh_fft_irfft2_dev")
+            return out.to_host()
         got = self.cascades.to_host()
         return got[j, :, newest]

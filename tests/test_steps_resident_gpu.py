@@ -218,8 +218,8 @@ CONFIGS = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_update_beside_the_reference_update(ref_pysteps, name):
+@pytest.mark.parametrize("name", sorted(CONFIGS) + ["incremental_cdf/spatial", "composite_shape/spatial"])
+def test_update_beside_the_reference_update(ref_pysteps, name, monkeypatch):
     """ResidentSteps.update() and StepsNowcaster.__update_state advance the same initial state side by
     side: the fields of every member and step agree to 1e-9 of the field's range on all but 1e-3 of
     the pixels (the ones a threshold / a rank decided differently), NaN masks identical, and the host
@@ -231,6 +231,9 @@ def test_update_beside_the_reference_update(ref_pysteps, name):
     from pysteps_amd.nowcasts.steps_resident import ResidentSteps
 
     register.register()
+    if name.endswith("/spatial"):  # the chain of the reference's spatial operators instead of the spectral AR history
+        monkeypatch.setenv("PYSTEPS_HIP_RESIDENT_DOMAIN", "spatial")
+        name = name.split("/")[0]
     cfg = dict(CONFIGS[name])
     ar_order = cfg.pop("ar_order", 2)
     m, n = cfg.pop("shape", (128, 128))
