@@ -17,6 +17,8 @@
 //  * psh_steps_mean_shift_dev   - :1203-1206 probmatching_method="mean"
 //  * psh_ge_mask_dev, psh_nan_where_dev, psh_lerp_dev - `precip_forecast >= precip_thr` (:1211),
 //      `precip_forecast[domain_mask] = nan` (:1217), `(1 - w) prev + w new` (nowcasts/utils.py:419-427)
+#include <algorithm>
+
 #include "common.h"
 
 namespace psh {
@@ -269,21 +271,23 @@ __global__ __launch_bounds__(kThreads) void spectral_level_sums(const double2 *_
                                                                 const double *__restrict__ weights, int nlevels, int m,
                                                                 int nc, int n_even, double *__restrict__ partial) {
   __shared__ double s_part[kThreads / 64][kMaxLevels];
-  const size_t plane = static_cast<size_t>(m) * nc, stride = static_cast<size_t>(gridDim.x) * kThreads;
+  const size_t plane = static_cast<size_t>(m) * nc;
   double acc[kMaxLevels];
 #pragma unroll
   for (int k = 0; k < kMaxLevels; ++k) acc[k] = 0.0;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < plane; i += stride) {
-    if (i == 0) continue;  // DC: the noise field's mean, removed by its standardisation
-    const int c = static_cast<int>(i % nc);
-    const double2 y = noise[i];
-    const double f = filt[i];
-    const double e = herm_weight(c, nc, n_even) * f * f * (y.x * y.x + y.y * y.y);
+  for (int r = blockIdx.x; r < m; r += gridDim.x) {  // whole rows per workgroup: the column (its Hermitian weight) without a division
+    for (int c = threadIdx.x; c < nc; c += kThreads) {
+      if (r == 0 && c == 0) continue;  // DC: the noise field's mean, removed by its standardisation
+      const size_t i = static_cast<size_t>(r) * nc + c;
+      const double2 y = noise[i];
+      const double f = filt[i];
+      const double e = herm_weight(c, nc, n_even) * f * f * (y.x * y.x + y.y * y.y);
 #pragma unroll
-    for (int k = 0; k < kMaxLevels; ++k) {
-      if (k < nlevels) {
-        const double w = weights[static_cast<size_t>(k) * plane + i];
-        acc[k] += e * w * w;
+      for (int k = 0; k < kMaxLevels; ++k) {
+        if (k < nlevels) {
+          const double w = weights[static_cast<size_t>(k) * plane + i];
+          acc[k] += e * w * w;
+        }
       }
     }
   }
@@ -304,22 +308,21 @@ __global__ __launch_bounds__(kThreads) void spectral_level_sums(const double2 *_
   }
 }
 
+// one workgroup per level adds the workgroups' partial sums
 __global__ __launch_bounds__(kThreads) void spectral_level_sums_final(const double *__restrict__ partial, int nparts,
                                                                       double *__restrict__ sums) {
   __shared__ double s_part[kThreads / 64];
-  for (int k = 0; k < kMaxLevels; ++k) {
-    double t = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += kThreads) t += partial[static_cast<size_t>(i) * kMaxLevels + k];
+  const int k = blockIdx.x;
+  double t = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += kThreads) t += partial[static_cast<size_t>(i) * kMaxLevels + k];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double all = 0.0;
-      for (int w = 0; w < kThreads / 64; ++w) all += s_part[w];
-      sums[k] = all;
-    }
+  for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double all = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) all += s_part[w];
+    sums[k] = all;
   }
 }
 
@@ -503,14 +506,13 @@ extern "C" int psh_steps_spectral_sums_dev(const void *noise_spec_dev, const dou
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
   const int nc = n / 2 + 1;
-  const size_t plane = static_cast<size_t>(m) * nc;
-  const int grid = psh::grid_for(plane);
+  const int grid = std::min(m, 1024);  // rows are dealt to the workgroups
   void *partial = nullptr;
   if (int rc = psh_malloc(&partial, static_cast<size_t>(grid) * psh::kMaxLevels * sizeof(double))) return rc;
   hipLaunchKernelGGL(psh::spectral_level_sums, dim3(grid), dim3(psh::kThreads), 0, c.stream, static_cast<const double2 *>(noise_spec_dev),
                      filter_dev, weights_dev, nlevels, m, nc, (n & 1) == 0 ? 1 : 0, static_cast<double *>(partial));
-  hipLaunchKernelGGL(psh::spectral_level_sums_final, dim3(1), dim3(psh::kThreads), 0, c.stream, static_cast<const double *>(partial), grid,
-                     sums_dev);
+  hipLaunchKernelGGL(psh::spectral_level_sums_final, dim3(psh::kMaxLevels), dim3(psh::kThreads), 0, c.stream,
+                     static_cast<const double *>(partial), grid, sums_dev);
   const hipError_t e = hipGetLastError();
   (void)psh_free(partial);  // stream-ordered
   PSH_HIP(e);
@@ -559,7 +561,9 @@ extern "C" int psh_field_min_key_dev(const double *field_dev, size_t n, unsigned
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
   PSH_HIP(hipMemsetAsync(min_key_dev, 0xff, sizeof(unsigned long long), c.stream));
-  hipLaunchKernelGGL(psh::field_min_key, dim3(psh::grid_for(n)), dim3(psh::kThreads), 0, c.stream, field_dev, n, min_key_dev);
+  // (few workgroups: every wave ends with an atomic on one address)
+  hipLaunchKernelGGL(psh::field_min_key, dim3(std::min<unsigned>(psh::grid_for(n), 1024u)), dim3(psh::kThreads), 0, c.stream, field_dev, n,
+                     min_key_dev);
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }
