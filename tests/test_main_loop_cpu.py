@@ -180,3 +180,18 @@ def test_steps_shard_reproduces_the_members_of_the_whole_ensemble(ref_pysteps):
         seen += list(members)
     assert seen == list(range(7))
     assert parallel.steps_shard(None, 7, 3, 1)[1] == {"n_ens_members": 2, "seed": None}
+
+
+def test_percentile_index_is_numpys_argmin():
+    """The index compute_percentile_mask (pysteps/nowcasts/utils.py:129-135) thresholds the sorted field at, evaluated on
+    a window around the analytic position (steps_resident._percentile_index), against the full argmin it restates."""
+    steps_resident = pytest.importorskip("pysteps_amd.nowcasts.steps_resident")
+    rng = np.random.default_rng(0)
+    for trial in range(2000):
+        count = int(rng.integers(2, 6000))
+        pct = float(rng.random()) if trial % 3 else float(rng.integers(0, count + 1)) / count
+        x = 1.0 * np.arange(1, count + 1)[::-1] / count
+        i = int(np.argmin(np.abs(x - pct)))
+        want = None if i >= count - 1 else i  # the reference reads precip_s[i + 1]
+        assert steps_resident._percentile_index(count, pct) == want, (count, pct)
+    assert steps_resident._percentile_index(16, 1.5) is None and steps_resident._percentile_index(1, 0.5) is None
