@@ -48,9 +48,11 @@ const char *psh_version(void);
 int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hbm_free,
                     char *name, int name_len);
 
-/* knobs; "semilag_variant": 0 one pixel per lane, velocity gathered from a packed {u,v} plane with
- * dwordx4 loads (default), 1 one plane per component with DPP column sharing, 3 three pixels per
- * lane with dwordx4 gathers (interp_order 0/1, >= 192 columns), 2 / 4 LDS-staged tiles;
+/* knobs; "semilag_variant": 0 one pixel per lane, velocity gathered from a packed {u,v} plane and the
+ * field from a row-pair plane with dwordx4 loads (default), 5 the same without the row-pair plane, 1 one
+ * plane per component with DPP column sharing, 3 three pixels per lane with dwordx4 gathers
+ * (interp_order 0/1, >= 192 columns, finite motion fields), 2 / 4 workgroup LDS-staged tiles, 8 per-wave
+ * LDS staging of the sampling boxes through LDS-DMA (bit-identical with 0), 6 two rows per lane;
  * "idw_variant": 0 two-level pre-pass (64x64 supertile lists, one wave per 8x8 tile; default),
  * 1 one pre-pass per 16x16 tile;
  * "members_variant": members per thread of the member-batched step on packed planes: 2 (default: the two
