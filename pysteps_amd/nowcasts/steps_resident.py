@@ -75,6 +75,27 @@ def _percentile_index(count, pct):
     return None if i >= count - 1 else i
 
 
+def _self_conjugate_columns_symmetric(planes, n):
+    """The spectral form of the update reads level variances off the spectrum (Parseval), which needs every product
+    ``spectrum x weights`` to stay Hermitian: a real filter has to take the same value at (ky, kx) and (-ky, kx) on the
+    two columns of an rfft2 half spectrum that are their own mirror images (kx = 0 and, for even n, the Nyquist column).
+    Filters that are functions of |k| - every band-pass filter and noise filter pysteps builds - are; anything else
+    keeps the chain of spatial operators.  ``planes``: (..., m, n // 2 + 1) NumPy array; DeviceArrays are trusted."""
+    if isinstance(planes, DeviceArray):
+        return True
+    a = np.asarray(planes)
+    if a.ndim < 2 or a.shape[-1] != n // 2 + 1 or np.iscomplexobj(a):
+        return False
+    cols = [0] + ([a.shape[-1] - 1] if n % 2 == 0 else [])
+    for c in cols:
+        col = a[..., :, c]
+        mirrored = np.concatenate([col[..., :1], col[..., :0:-1]], axis=-1)
+        scale = float(np.max(np.abs(col))) if col.size else 0.0
+        if not np.allclose(col, mirrored, rtol=1e-9, atol=1e-12 * scale):
+            return False
+    return True
+
+
 def try_create(func, state, params, shape, n_updates):
     """A :class:`ResidentSteps` for the update function ``func`` of the reference's STEPS nowcaster, or
     None if ``func`` is something else or uses options outside the resident chain."""
@@ -164,7 +185,8 @@ class ResidentSteps:
         # field apart from two standardisations that need second moments only (Parseval) - two transforms per
         # member update instead of nine (csrc/steps_loop.hip).  PYSTEPS_HIP_RESIDENT_DOMAIN=spatial keeps the
         # level fields and the chain of the reference's spatial operators (bit-identical element-wise part).
-        self.spectral = os.environ.get("PYSTEPS_HIP_RESIDENT_DOMAIN", "spectral") != "spatial"
+        self.spectral = (os.environ.get("PYSTEPS_HIP_RESIDENT_DOMAIN", "spectral") != "spatial"
+                         and _self_conjugate_columns_symmetric(weights, n) and _self_conjugate_columns_symmetric(F["field"], n))
         if self.spectral:
             nc = n // 2 + 1
             spectra = DeviceArray((self.B, self.L, self.p, m, nc), np.complex128)

@@ -46,3 +46,33 @@ def test_hermitian_weights_are_parsevals():
         spec = np.fft.rfft2(x)
         total = np.sum(oss.hermitian_weights(n)[None, :] * np.abs(spec) ** 2)
         assert abs(total - m * n * np.sum(x**2)) < 1e-9 * total
+
+
+def test_filters_that_break_the_hermitian_symmetry_are_recognised():
+    """An asymmetric value on a self-conjugate column of the half spectrum breaks the equivalence (1e-4 here); the
+    resident update recognises such filters (steps_resident._self_conjugate_columns_symmetric) and keeps the spatial chain."""
+    sr = pytest.importorskip("pysteps_amd.nowcasts.steps_resident")
+    rng = np.random.default_rng(0)
+    for (m, n) in ((32, 32), (30, 41), (33, 24)):
+        w, f = _radial_filters(m, n, 4, rng)
+        assert sr._self_conjugate_columns_symmetric(w, n) and sr._self_conjugate_columns_symmetric(f, n)
+        spec = np.abs(np.fft.rfft2(rng.standard_normal((m, n))))  # what initialize_nonparam_2d_fft_filter keeps: symmetric to rounding
+        assert sr._self_conjugate_columns_symmetric(spec, n)
+        bad = w.copy()
+        bad[1, 3, 0] *= 1.7
+        assert not sr._self_conjugate_columns_symmetric(bad, n)
+        if n % 2 == 0:
+            bad = f.copy()
+            bad[5, -1] += 0.3
+            assert not sr._self_conjugate_columns_symmetric(bad, n)
+        assert not sr._self_conjugate_columns_symmetric(w[..., :-1], n)  # not a half spectrum of this grid
+    m, n, L, p = 32, 32, 4, 2
+    w, f = _radial_filters(m, n, L, rng)
+    w[:, 3, 0] *= 1.7
+    levels = rng.standard_normal((L, p, m, n))
+    phi = rng.uniform(-0.8, 0.8, (L, p + 1))
+    ns, mu, sg = rng.uniform(0.3, 1.2, L), rng.standard_normal(L), rng.uniform(0.2, 2.0, L)
+    white = rng.standard_normal((m, n))
+    _, fa = oss.update_spatial(white, f, w, levels, phi, ns, mu, sg)
+    _, fb = oss.update_spectral(white, f, w, np.fft.rfft2(levels), phi, ns, mu, sg)
+    assert np.max(np.abs(fa - fb)) > 1e-6 * np.ptp(fa)
