@@ -156,6 +156,7 @@ int idw_resident(const float *xy_dev, const float *values_dev, int capacity, con
                  int k, double power, double dist_offset, float *out_dev);
 size_t idw_scratch_bytes(int m, int n);
 void set_idw_variant(int v);
+void set_lk_response_variant(int v);
 
 hipError_t launch_outliers_pooled(const double *xy_dev, const double *uv_dev, const int *count_dev,
                                   int capacity, int k, double thr, unsigned char *flags_dev,

@@ -667,9 +667,191 @@ __global__ __launch_bounds__(64) void idw_fine(const float2 *__restrict__ xy, co
   out[plane + static_cast<size_t>(iy) * n + ix] = ov;
 }
 
+// ---- fine pass, second form (default) -------------------------------------------------------
+// idw_fine above spends about half of its instructions before the first weight is computed: an
+// LDS histogram of up to 256 centre distances (IEEE square roots and divisions, LDS atomics), a
+// prefix scan over the bins and two ballot sweeps over four list chunks.  The supertile lists are
+// short (30-60 vectors), so here the k-th smallest centre distance of the tile is found EXACTLY
+// - and without LDS - by bisection on the bit patterns of the squared distances (a non-negative
+// float orders like its bits): 25 rounds of one compare + ballot + scalar popcount fix the value
+// up to its 6 lowest mantissa bits.  Squared distances are classified against squared radii (no
+// square root per vector), the two groups are compacted into LDS with one ballot each, and a
+// small ring (<= 8 vectors, the rule at the reference's density) is ranked pairwise in registers
+// instead of going through the replace-the-maximum set.  The per-pixel arithmetic (dist2, the
+// weight, the order of the sums: certain vectors in index order, then the chosen ring vectors in
+// index order) is that of idw_fine; a vector that sits within the safety margin of a class
+// boundary may change class between the two kernels, which only changes the order of summation
+// (last-bit differences, same neighbour sets).
+template <int KMAX>
+__global__ __launch_bounds__(64) void idw_fine2(const float2 *__restrict__ xy, const float2 *__restrict__ uv,
+                                                int L, int k, int m, int n, float x0, float dx_grid,
+                                                float y0, float dy_grid, float inv_res, float power,
+                                                float offset, float *__restrict__ out, int supers_x,
+                                                const SuperHeader *__restrict__ headers,
+                                                const float4 *__restrict__ lists, int tiles_x, int n_tiles,
+                                                int tiles_per_xcd, const IdwDyn *__restrict__ dyn) {
+  __shared__ float4 s_cand[kFineCap];  // [certain | undecided], each group in index order
+  const int b = blockIdx.x;
+  const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;  // XCD-contiguous tiles
+  if (tile >= n_tiles) return;
+  const int tx = (tile % tiles_x) * kFine, ty = (tile / tiles_x) * kFine;
+  const int lane = threadIdx.x;
+  const int ix = tx + (lane % kFine), iy = ty + (lane / kFine);
+  const bool live = ix < n && iy < m;
+  if (dyn) {
+    L = dyn->L;
+    k = min(k, L);
+    if (dyn->mode != 0) {  // the interpolator's trivial cases (decorators.py:199-208): constant field
+      if (live) {
+        out[static_cast<size_t>(iy) * n + ix] = dyn->cu;
+        out[static_cast<size_t>(m) * n + static_cast<size_t>(iy) * n + ix] = dyn->cv;
+      }
+      return;
+    }
+  }
+  const float px = x0 + dx_grid * static_cast<float>(ix);
+  const float py = y0 + dy_grid * static_cast<float>(iy);
+  const size_t plane = static_cast<size_t>(m) * n;
+  const int sup = (ty / kSuper) * supers_x + tx / kSuper;
+  const SuperHeader hdr = headers[sup];
+  const float4 *list = lists + static_cast<size_t>(sup) * kSuperCap;
+  const int n_s = __builtin_amdgcn_readfirstlane(hdr.count);
+
+  bool brute = k >= L || n_s > kSuperCap || n_s < k;
+  int n_sure = 0, n_ring = 0;
+  if (!brute) {
+    const int wx = min(kFine, n - tx), wy = min(kFine, m - ty);
+    const float cx = x0 + dx_grid * (static_cast<float>(tx) + 0.5f * static_cast<float>(wx - 1));
+    const float cy = y0 + dy_grid * (static_cast<float>(ty) + 0.5f * static_cast<float>(wy - 1));
+    const float hx = 0.5f * fabsf(dx_grid) * static_cast<float>(wx - 1);
+    const float hy = 0.5f * fabsf(dy_grid) * static_cast<float>(wy - 1);
+    const float half_diag = sqrtf(hx * hx + hy * hy);
+    constexpr int kPerLane = kSuperCap / 64;
+    const int chunks = (n_s + 63) >> 6;  // (uniform)
+    float4 c[kPerLane];
+    unsigned key[kPerLane];  // bits of the squared centre distance; missing entries: +inf
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j) {
+      key[j] = 0x7f800000u;
+      c[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < chunks) {
+        const int i = j * 64 + lane;
+        if (i < n_s) {
+          c[j] = list[i];
+          key[j] = __float_as_uint(dist2(c[j].x, c[j].y, cx, cy));
+        }
+      }
+    }
+    // k-th smallest key: the largest T with fewer than k keys below it, built from the top bit
+    unsigned T = 0u;
+#pragma unroll
+    for (int bit = 30; bit >= 6; --bit) {
+      const unsigned t = T | (1u << bit);
+      int below = 0;
+#pragma unroll
+      for (int j = 0; j < kPerLane; ++j)
+        if (j < chunks) below += __popcll(__ballot(key[j] < t));
+      if (below < k) T = t;
+    }
+    // T <= (k-th smallest squared distance) < T + 64 ulp
+    const float r_lo = fast_sqrt(__uint_as_float(T)) * (1.f - 1e-6f);
+    const float r_hi = fast_sqrt(__uint_as_float(T + 64u)) * (1.f + 1e-6f);
+    const float reach = r_hi + 2.f * half_diag + 1e-3f * (r_hi + half_diag);
+    const float sure_below = r_lo - 2.f * half_diag - 1e-3f * (r_lo + half_diag);
+    const float reach2 = reach * reach;
+    const float sure2 = sure_below > 0.f ? sure_below * sure_below : -1.f;
+    // certain vectors first, then the undecided ring, each in list (= index) order
+    unsigned long long sure_mask[kPerLane], ring_mask[kPerLane];
+    int tot_sure = 0, tot_ring = 0;
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j) {
+      sure_mask[j] = ring_mask[j] = 0ull;
+      if (j < chunks) {
+        const float d2 = __uint_as_float(key[j]);
+        const bool sure = d2 <= sure2;
+        sure_mask[j] = __ballot(sure);
+        ring_mask[j] = __ballot(!sure && d2 <= reach2);
+        tot_sure += __popcll(sure_mask[j]);
+        tot_ring += __popcll(ring_mask[j]);
+      }
+    }
+    n_sure = tot_sure;
+    n_ring = tot_ring;
+    brute = n_sure + n_ring > kFineCap;  // pathological clustering: exact brute force
+    if (!brute) {
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      int at_sure = 0, at_ring = n_sure;
+#pragma unroll
+      for (int j = 0; j < kPerLane; ++j) {
+        if (j < chunks) {
+          const bool sure = (sure_mask[j] >> lane) & 1ull, ring = (ring_mask[j] >> lane) & 1ull;
+          const int slot = sure ? at_sure + __popcll(sure_mask[j] & lt) : at_ring + __popcll(ring_mask[j] & lt);
+          if (sure || ring) s_cand[slot] = c[j];
+          at_sure += __popcll(sure_mask[j]);
+          at_ring += __popcll(ring_mask[j]);
+        }
+      }
+    }
+    __syncthreads();  // (one wave: orders the LDS writes before the broadcast reads)
+  }
+  if (!live) return;
+  float ou, ov;
+  if (brute) {
+    idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
+  } else {
+    float sw = 0.f, su = 0.f, sv = 0.f;
+    for (int i = 0; i < n_sure; ++i) {  // in every pixel's neighbourhood: no selection
+      const float4 c = s_cand[i];       // same address in every lane: LDS broadcast
+      const float w = idw_weight(fast_sqrt(dist2(c.x, c.y, px, py)) * inv_res, power, offset);
+      sw += w;
+      su += w * c.z;
+      sv += w * c.w;
+    }
+    const int need = k - n_sure;  // >= 1: fewer than k vectors lie strictly inside R_lo
+    if (n_ring <= 8) {
+      // small ring: every member ranks itself among the others (ties: lower index first, as the
+      // second sweep of add_nearest takes them), the `need` first of that order are added
+      float d2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        d2[j] = INFINITY;
+        if (j < n_ring) {
+          const float4 c = s_cand[n_sure + j];
+          d2[j] = dist2(c.x, c.y, px, py);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < n_ring) {
+          int rank = 0;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (i != j && i < n_ring) rank += (d2[i] < d2[j] || (i < j && d2[i] == d2[j])) ? 1 : 0;
+          }
+          if (rank < need) {
+            const float4 c = s_cand[n_sure + j];
+            const float w = idw_weight(fast_sqrt(d2[j]) * inv_res, power, offset);
+            sw += w;
+            su += w * c.z;
+            sv += w * c.w;
+          }
+        }
+      }
+    } else if (need <= 8) {
+      add_nearest<8>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
+    } else {
+      add_nearest<KMAX>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
+    }
+    ou = su / sw;
+    ov = sv / sw;
+  }
+  out[static_cast<size_t>(iy) * n + ix] = ou;
+  out[plane + static_cast<size_t>(iy) * n + ix] = ov;
+}
+
 }  // namespace
 
-// 0 = two-level (default), 1 = one pre-pass per 16x16 tile
+// 0 = two-level, bisection fine pass (default), 2 = two-level with the histogram fine pass, 1 = one pre-pass per 16x16 tile
 static int g_idw_variant = [] {
   const char *e = std::getenv("PYSTEPS_HIP_IDW_VARIANT");
   return e ? std::atoi(e) : 0;
@@ -687,7 +869,7 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
   // (with a device-resident sample count the instantiation follows the requested k: should the
   // samples turn out to be fewer, every instantiation takes the same all-samples path)
   const int k_eff = a.dyn ? (a.k > 32 ? 1 : a.k) : a.k >= a.L ? 1 : a.k;
-  if ((g_idw_variant == 0 || a.dyn != nullptr) && a.scratch != nullptr) {
+  if ((g_idw_variant != 1 || a.dyn != nullptr) && a.scratch != nullptr) {
     const int supers_x = (a.n + kSuper - 1) / kSuper, supers_y = (a.m + kSuper - 1) / kSuper;
     const int n_super = supers_x * supers_y;
     SuperHeader *headers = static_cast<SuperHeader *>(a.scratch);
@@ -703,10 +885,15 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
     const int n_tiles = tiles_x * tiles_y;
     const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
     const dim3 grid(tiles_per_xcd * kNumXcd), block(64);
-#define PSH_IDW_FINE(KMAX)                                                                            \
-  hipLaunchKernelGGL((idw_fine<KMAX>), grid, block, 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0, a.dx, \
-                     a.y0, a.dy, a.inv_res, a.power, a.offset, a.out, supers_x, headers, lists,       \
-                     tiles_x, n_tiles, tiles_per_xcd, a.dyn)
+#define PSH_IDW_FINE_ARGS                                                                              \
+  grid, block, 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0, a.dx, a.y0, a.dy, a.inv_res, a.power, a.offset, \
+      a.out, supers_x, headers, lists, tiles_x, n_tiles, tiles_per_xcd, a.dyn
+#define PSH_IDW_FINE(KMAX)                                          \
+  if (g_idw_variant == 2) {                                         \
+    hipLaunchKernelGGL((idw_fine<KMAX>), PSH_IDW_FINE_ARGS);        \
+  } else {                                                          \
+    hipLaunchKernelGGL((idw_fine2<KMAX>), PSH_IDW_FINE_ARGS);       \
+  }
     if (k_eff <= 8) {
       PSH_IDW_FINE(8);
     } else if (k_eff <= 20) {
@@ -715,6 +902,7 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
       PSH_IDW_FINE(32);
     }
 #undef PSH_IDW_FINE
+#undef PSH_IDW_FINE_ARGS
     return hipGetLastError();
   }
   const int tiles_x = (a.n + kTile - 1) / kTile;

@@ -822,6 +822,157 @@ __global__ __launch_bounds__(256) void lk_corner_response(
         fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// ---- the same response, column-walking form (default) ------------------------------------------
+// lk_corner_response above stages a tile and three product arrays in LDS and spends its time
+// waiting for them (bank conflicts of the double-precision strips, two barriers, 0.29 of the VALU
+// issue slots busy).  Here nothing goes through LDS: a lane owns one image COLUMN, a wave walks
+// ROWS + 2 (r + 1) rows of a 64-column strip from top to bottom and keeps everything in registers.
+//  * per loaded row (one byte per lane; the neighbours' bytes come from the next lanes by DPP, so a
+//    lane works for the column one to the right of the one it loads): the horizontal difference
+//    Hd = right - left and the smoothed value G = (left + right) s + centre 2s - exact small integers
+//    until the multiplications, so the expression tree of sobel_products() is kept to the bit;
+//  * per row: dx = (Hd[-1] + Hd[+1]) s + Hd[0] 2s, dy = G[+1] - G[-1], the three products, and the
+//    vertical box sums as SLIDING column sums in double: V += P(new) - P(row leaving the window).
+//    Every partial sum of <= 7 x 7 products is exact in double (see above), so adding and subtracting
+//    in any order gives the bits of boxFilter's accumulation; the last BS product rows wait in a
+//    register ring;
+//  * the horizontal box sum takes V from the next 2r lanes (64-bit DPP moves), then the eigenvalue.
+// Image borders: the pixel loads are reflected (reflect-101 rows and columns, as the LDS tile was
+// filled); a product OUTSIDE the image has to be the product at its mirror position (boxFilter's
+// border), and the walked stencil there is the mirror image of the true one: its dx (columns) or
+// dy (rows) comes out with the opposite sign - exactly, negation commutes with every rounding -, so
+// the sign of s is flipped per lane and the sign of dy per row where the position is mirrored.
+// 4 waves = 4 row bands per workgroup; lanes 0 .. 63 - 2 (r + 1) write.
+__device__ __forceinline__ float next_lane_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double next_lane_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// true where a stencil walked through reflected coordinates comes out mirrored (i + 1 maps to the
+// pixel BEFORE the image of i); turning points have equal neighbours on both sides: either answer
+__device__ __forceinline__ bool walk_mirrored(int i, int n) {
+  if (i >= 0 && i + 1 < n) return false;
+  return reflect101(i + 1, n) != reflect101(reflect101(i, n) + 1, n);
+}
+
+constexpr int crn_cols(int block_size) { return 64 - 2 * (block_size / 2 + 1); }  // output columns per wave
+
+template <int BS, int ROWS>
+__global__ __launch_bounds__(256) void lk_corner_response_cols(
+    const unsigned char *__restrict__ u8, const float *__restrict__ clean, int m, int n,
+    int buffer_mask, const float *__restrict__ stats, float *__restrict__ eig,
+    float *__restrict__ partial, Band band) {
+  constexpr int r = BS / 2, H = r + 1, W = crn_cols(BS);
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x0 = blockIdx.x * W;
+  const int yb = (blockIdx.y * 4 + wave) * ROWS;  // first output row of the wave
+  float best = 0.f;
+  if (yb < m) {
+    const float s = 1.0f / (4.0f * static_cast<float>(BS) * 255.0f), s2 = 2.f * s;
+    const int xl = x0 - H + lane;  // column this lane loads; its products belong to column xl + 1
+    const bool neg_x = walk_mirrored(xl + 1, n);
+    const float sx = neg_x ? -s : s, sx2 = neg_x ? -s2 : s2;
+    const unsigned char *col = u8 + reflect101(xl, n);
+    // rows are reflected at most once unless the image is only a few rows high (scalar arithmetic per
+    // row: keep the division of the general form out of the walk)
+    const bool few_rows = m < 2 * H + 2;
+    auto row_of = [&](int y) -> int {
+      if (few_rows) return reflect101(y, m);
+      y = y < 0 ? -y : y;
+      return y >= m ? 2 * m - 2 - y : y;
+    };
+    // sequence row i is image row yb - H + i
+    auto load_row = [&](int i) -> int { return col[static_cast<size_t>(row_of(yb - H + i)) * n]; };
+    auto row_terms = [&](int raw, float &hd, float &g) {
+      const float a = static_cast<float>(raw);  // left
+      const float c = next_lane_f(a);           // centre
+      const float b = next_lane_f(c);           // right
+      hd = b - a;
+      g = (a + b) * s + c * s2;
+    };
+    const bool any_nan = stats[kNanCount] > 0.f;
+    const int x = x0 + lane;  // output column of the lane
+    const bool writer = lane < W && x < n;
+    const int rows_out = min(ROWS, m - yb);
+    const int last_p = rows_out + BS - 1;  // product rows 1 .. last_p; output row o = p - BS
+    double ring[3][BS], V[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < BS; ++j) ring[0][j] = ring[1][j] = ring[2][j] = 0.0;
+    int raw[BS];
+    const int raw0 = load_row(0), raw1 = load_row(1);
+#pragma unroll
+    for (int j = 0; j < BS; ++j) raw[j] = load_row(2 + j);
+    float hd_m, hd_0, g_m, g_0;
+    row_terms(raw0, hd_m, g_m);
+    row_terms(raw1, hd_0, g_0);
+    for (int base = 1; base <= last_p; base += BS) {
+      int nxt[BS];
+#pragma unroll
+      for (int j = 0; j < BS; ++j) nxt[j] = load_row(base + BS + 1 + j);  // (reflected: always inside the image)
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int p = base + j;
+        if (p > last_p) break;  // (uniform)
+        constexpr int kRingBase = 1;
+        const int slot = (kRingBase + j) % BS;  // = p % BS, a constant after unrolling
+        float hd_p, g_p;
+        row_terms(raw[j], hd_p, g_p);  // sequence row p + 1
+        const float dx = (hd_m + hd_p) * sx + hd_0 * sx2;
+        float dy = g_p - g_m;
+        const int y_seq = yb - H + p;
+        const bool row_mirrored = few_rows ? walk_mirrored(y_seq, m) : (y_seq < 0 || y_seq >= m);
+        const unsigned row_sign = row_mirrored ? 0x80000000u : 0u;  // (scalar)
+        dy = __uint_as_float(__float_as_uint(dy) ^ row_sign);
+        const double pxx = static_cast<double>(dx * dx), pxy = static_cast<double>(dx * dy);
+        const double pyy = static_cast<double>(dy * dy);
+        V[0] += pxx - ring[0][slot];
+        V[1] += pxy - ring[1][slot];
+        V[2] += pyy - ring[2][slot];
+        ring[0][slot] = pxx;
+        ring[1][slot] = pxy;
+        ring[2][slot] = pyy;
+        hd_m = hd_0;
+        hd_0 = hd_p;
+        g_m = g_0;
+        g_0 = g_p;
+        if (p >= BS) {
+          double w0 = V[0], w1 = V[1], w2 = V[2];
+          double t0 = V[0], t1 = V[1], t2 = V[2];
+#pragma unroll
+          for (int c = 0; c < 2 * r; ++c) {
+            t0 = next_lane_d(t0);
+            t1 = next_lane_d(t1);
+            t2 = next_lane_d(t2);
+            w0 += t0;
+            w1 += t1;
+            w2 += t2;
+          }
+          const int y = yb + p - BS;
+          if (writer) {
+            const float a = static_cast<float>(w0) * 0.5f, b = static_cast<float>(w1);
+            const float c = static_cast<float>(w2) * 0.5f;
+            const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+            eig[static_cast<size_t>(y) * n + x] = e;
+            if (y >= band.lo && y < band.hi && px_allowed(clean, m, n, x, y, buffer_mask, any_nan))
+              best = fmaxf(best, fmaxf(e, 0.f));
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BS; ++j) raw[j] = nxt[j];
+    }
+  }
+  best = wave_max(best);
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partial[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 // (zero_a / zero_b: counters and scratch the NEXT kernels expect cleared - done here, by a kernel
 // that is a single idle-ish block anyway, instead of one 5 us fill launch each)
 __global__ __launch_bounds__(kFinalThreads) void lk_max_final(const float *__restrict__ partial,
@@ -1495,6 +1646,53 @@ void launch_lk_open(dim3 grid, hipStream_t stream, const float *img, int m, int 
   }
 }
 
+// Shi-Tomasi response: 0 = column-walking kernel, 32 output rows per wave (default); 2 / 3 = the same
+// with 16 / 64 rows; 1 = the LDS-tile kernel
+static int g_lk_response_variant = [] {
+  const char *e = std::getenv("PYSTEPS_HIP_LK_RESPONSE_VARIANT");
+  return e ? std::atoi(e) : 0;
+}();
+void set_lk_response_variant(int v) { g_lk_response_variant = v; }
+static int lk_response_rows() { return g_lk_response_variant == 2 ? 16 : g_lk_response_variant == 3 ? 64 : 32; }
+dim3 lk_response_grid(int m, int n, int block_size) {
+  if (g_lk_response_variant == 1) return dim3((n + kCrnTX - 1) / kCrnTX, (m + kCrnTY - 1) / kCrnTY);
+  const int w = crn_cols(block_size), rows = 4 * lk_response_rows();
+  return dim3((n + w - 1) / w, (m + rows - 1) / rows);
+}
+void launch_lk_response(dim3 grid, hipStream_t stream, int block_size, const unsigned char *u8, const float *clean, int m,
+                        int n, int buffer_mask, const float *stats, float *eig, float *part, Band band) {
+#define PSH_CRN_ARGS grid, dim3(256), 0, stream, u8, clean, m, n, buffer_mask, stats, eig, part, band
+#define PSH_CRN_ROWS(BS)                                                             \
+  if (g_lk_response_variant == 2) {                                                  \
+    hipLaunchKernelGGL((lk_corner_response_cols<BS, 16>), PSH_CRN_ARGS);             \
+  } else if (g_lk_response_variant == 3) {                                           \
+    hipLaunchKernelGGL((lk_corner_response_cols<BS, 64>), PSH_CRN_ARGS);             \
+  } else {                                                                           \
+    hipLaunchKernelGGL((lk_corner_response_cols<BS, 32>), PSH_CRN_ARGS);             \
+  }
+  if (g_lk_response_variant == 1) {
+    if (block_size == 1) {
+      hipLaunchKernelGGL(lk_corner_response<1>, PSH_CRN_ARGS);
+    } else if (block_size == 3) {
+      hipLaunchKernelGGL(lk_corner_response<3>, PSH_CRN_ARGS);
+    } else if (block_size == 5) {
+      hipLaunchKernelGGL(lk_corner_response<5>, PSH_CRN_ARGS);
+    } else {
+      hipLaunchKernelGGL(lk_corner_response<7>, PSH_CRN_ARGS);
+    }
+  } else if (block_size == 1) {
+    PSH_CRN_ROWS(1)
+  } else if (block_size == 3) {
+    PSH_CRN_ROWS(3)
+  } else if (block_size == 5) {
+    PSH_CRN_ROWS(5)
+  } else {
+    PSH_CRN_ROWS(7)
+  }
+#undef PSH_CRN_ROWS
+#undef PSH_CRN_ARGS
+}
+
 static int ensure_lk_ws(size_t nbytes, void **ptr) {
   Context &c = ctx();
   static void *ws = nullptr;
@@ -1698,26 +1896,15 @@ int psh_lk_band_response_dev(const unsigned char *feature_u8_dev, const float *c
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
   const int ms = e1 - e0;
-  const dim3 rgrid((n + psh::kCrnTX - 1) / psh::kCrnTX, (ms + psh::kCrnTY - 1) / psh::kCrnTY);
+  const dim3 rgrid = psh::lk_response_grid(ms, n, block_size);
   const int nb = rgrid.x * rgrid.y;
   void *ws = nullptr;
   if (int rc = psh::ensure_lk_ws(sizeof(float) * static_cast<size_t>(nb), &ws)) return rc;
   float *part = static_cast<float *>(ws);
   const size_t off = static_cast<size_t>(e0) * n;
   const psh::Band band{e0, r0 - e0, r1 - e0};
-#define PSH_CRN_LAUNCH(BS)                                                                                       \
-  hipLaunchKernelGGL(psh::lk_corner_response<BS>, rgrid, dim3(256), 0, c.stream, feature_u8_dev + off, clean_dev + off, \
-                     ms, n, buffer_mask, stats_dev, eig_dev + off, part, band)
-  if (block_size == 1) {
-    PSH_CRN_LAUNCH(1);
-  } else if (block_size == 3) {
-    PSH_CRN_LAUNCH(3);
-  } else if (block_size == 5) {
-    PSH_CRN_LAUNCH(5);
-  } else {
-    PSH_CRN_LAUNCH(7);
-  }
-#undef PSH_CRN_LAUNCH
+  psh::launch_lk_response(rgrid, c.stream, block_size, feature_u8_dev + off, clean_dev + off, ms, n, buffer_mask, stats_dev,
+                          eig_dev + off, part, band);
   hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, nb, stats_dev,
                      static_cast<int>(psh::kEigMax), static_cast<int *>(nullptr), 0, static_cast<int *>(nullptr), 0);
   PSH_HIP(hipGetLastError());
@@ -1824,9 +2011,9 @@ struct CornerWs {
   size_t off_part, off_cnt, off_raw, off_ord, bytes;
   int cap, nb;
   dim3 rgrid;
-  CornerWs(int m, int n) {
+  CornerWs(int m, int n, int block_size) {
     const size_t npx = static_cast<size_t>(m) * n;
-    rgrid = dim3((n + psh::kCrnTX - 1) / psh::kCrnTX, (m + psh::kCrnTY - 1) / psh::kCrnTY);
+    rgrid = psh::lk_response_grid(m, n, block_size);
     nb = rgrid.x * rgrid.y;
     // every pixel can be a candidate (plateaus of equal response pass the 3x3 test): no overflow
     cap = static_cast<int>(std::min<size_t>(npx, 0x7fffffffu));
@@ -1847,19 +2034,8 @@ int corner_candidates(const CornerWs &w, void *ws, const unsigned char *feature_
   float *part = reinterpret_cast<float *>(base + w.off_part);
   int *cnt = reinterpret_cast<int *>(base + w.off_cnt);
   psh::CornerKey *raw = reinterpret_cast<psh::CornerKey *>(base + w.off_raw);
-#define PSH_CRN_LAUNCH(BS)                                                                              \
-  hipLaunchKernelGGL(psh::lk_corner_response<BS>, w.rgrid, dim3(256), 0, c.stream, feature_u8_dev, clean_dev, \
-                     m, n, buffer_mask, stats_dev, eig, part, psh::Band{0, 0, m})
-  if (block_size == 1) {
-    PSH_CRN_LAUNCH(1);
-  } else if (block_size == 3) {
-    PSH_CRN_LAUNCH(3);
-  } else if (block_size == 5) {
-    PSH_CRN_LAUNCH(5);
-  } else {
-    PSH_CRN_LAUNCH(7);
-  }
-#undef PSH_CRN_LAUNCH
+  psh::launch_lk_response(w.rgrid, c.stream, block_size, feature_u8_dev, clean_dev, m, n, buffer_mask, stats_dev, eig, part,
+                          psh::Band{0, 0, m});
   // the candidate counter and the ordering scratch (histogram + header) are cleared by the same launch
   hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, w.nb, stats_dev,
                      static_cast<int>(psh::kEigMax), cnt, 1, reinterpret_cast<int *>(base + w.off_ord),
@@ -1898,7 +2074,7 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
   Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  const CornerWs w(m, n);
+  const CornerWs w(m, n, block_size);
   void *ws = nullptr;
   if (int rc = psh_malloc(&ws, w.bytes)) return rc;  // stream-ordered caching allocator
   int rc = corner_candidates(w, ws, feature_u8_dev, clean_dev, stats_dev, m, n, block_size, buffer_mask, quality_level);
@@ -1949,7 +2125,7 @@ int psh_lk_corners_launch_dev(const unsigned char *feature_u8_dev, const float *
     pin_have[slot] = pin_need;
   }
   char *pin = static_cast<char *>(job.pinned);
-  const CornerWs w(m, n);
+  const CornerWs w(m, n, block_size);
   void *ws = nullptr;
   if (host_ordered) {
     if (int rc = psh_malloc(&ws, w.bytes)) return rc;

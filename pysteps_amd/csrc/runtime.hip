@@ -250,9 +250,17 @@ int psh_set_option(const char *key, int value) {
     return PSH_OK;
   }
   if (std::strcmp(key, "idw_variant") == 0) {
-    if (value != 0 && value != 1)
-      return fail(PSH_EINVAL, "idw_variant must be 0 (two-level pre-pass) or 1 (pre-pass per 16x16 tile)");
+    if (value < 0 || value > 2)
+      return fail(PSH_EINVAL, "idw_variant must be 0 (two-level, bisection fine pass), 2 (two-level, histogram fine pass) "
+                              "or 1 (pre-pass per 16x16 tile)");
     psh::set_idw_variant(value);
+    return PSH_OK;
+  }
+  if (std::strcmp(key, "lk_response_variant") == 0) {
+    if (value < 0 || value > 3)
+      return fail(PSH_EINVAL, "lk_response_variant must be 0 (column-walking kernel, 32 rows per wave), 2 / 3 (16 / 64 rows) "
+                              "or 1 (LDS tiles)");
+    psh::set_lk_response_variant(value);
     return PSH_OK;
   }
   if (std::strcmp(key, "trim_cache") == 0) {  // give the cached device blocks back to the driver

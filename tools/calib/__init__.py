@@ -24,6 +24,7 @@ def lib():
         _lib.calib_dpp.argtypes = [vp]
         _lib.calib_gather.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_float)]
         _lib.calib_copy.argtypes = [vp, vp, ctypes.c_size_t, ci]
+        _lib.calib_valu.argtypes = [vp, ci, ci, ci, ctypes.POINTER(ctypes.c_float)]
     return _lib
 
 

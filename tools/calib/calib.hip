@@ -74,6 +74,55 @@ __global__ __launch_bounds__(64) void calib_dpp(int *__restrict__ out) {
   out[5 * 64 + lane] = __builtin_amdgcn_update_dpp(-1, lane, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
 
+
+// VALU issue cost of single instructions (wave64, gfx950): `waves` waves per SIMD each run `iters`
+// rounds of 8 independent instances of one instruction; the cycles of a round / 8 are reported by
+// the host wrapper as (kernel time x clock) / instructions per SIMD.
+//  0 v_fma_f32   1 v_pk_fma_f32   2 v_sqrt_f32   3 v_rsq_f32   4 v_add_f64   5 v_cvt_f64_f32
+//  6 v_fma_f64   7 v_mov_b32 dpp row_shr:1   8 v_rcp_f32   9 v_cvt_f32_f64   10 v_pk_add_f32
+//  11 v_pk_mul_f32  12 v_add_f32 dpp  13 v_mul_f64  14 v_add_u32  15 ds_bpermute (shfl)
+template <int OP>
+__global__ __launch_bounds__(256) void calib_valu(float *__restrict__ sink, int iters) {
+  float a[8];
+  double d[8];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f p[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = 1.0f + 0.001f * static_cast<float>(threadIdx.x + k);
+    d[k] = 1.0 + 0.001 * static_cast<double>(threadIdx.x + k);
+    p[k] = v2f{a[k], a[k] + 0.5f};
+  }
+  const float c = 0.999f, e = 1e-6f;
+  const double dc = 1e-9;
+  const v2f pc = {0.999f, 0.998f}, pe = {1e-6f, 2e-6f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if constexpr (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(c), "v"(e));
+      if constexpr (OP == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[k]) : "v"(pc), "v"(pe));
+      if constexpr (OP == 2) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[k]));
+      if constexpr (OP == 3) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[k]));
+      if constexpr (OP == 4) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[k]) : "v"(dc));
+      if constexpr (OP == 5) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[k]) : "v"(a[k]));
+      if constexpr (OP == 6) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[k]) : "v"(dc));
+      if constexpr (OP == 7) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[k]));
+      if constexpr (OP == 8) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[k]));
+      if constexpr (OP == 9) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[k]) : "v"(d[k]));
+      if constexpr (OP == 10) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pe));
+      if constexpr (OP == 11) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[k]) : "v"(pc));
+      if constexpr (OP == 12) asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[k]));
+      if constexpr (OP == 13) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[k]) : "v"(dc));
+      if constexpr (OP == 14) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(c));
+      if constexpr (OP == 15) a[k] = __shfl_xor(a[k], 1);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += a[k] + static_cast<float>(d[k]) + p[k].x + p[k].y;
+  if (s == 123.456f) sink[threadIdx.x] = s;
+}
+
 }  // namespace
 }  // namespace psh
 
@@ -115,6 +164,35 @@ extern "C" int calib_gather(const float *src_dev, float *sink_dev, int pitch_byt
                        n_rows - 1, row_step, first, lane_stride);
   else
     return -1;
+  CALIB_HIP(hipGetLastError());
+  CALIB_HIP(hipEventRecord(e1, nullptr));
+  CALIB_HIP(hipEventSynchronize(e1));
+  if (ms) CALIB_HIP(hipEventElapsedTime(ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return 0;
+}
+
+
+// one instruction kind, `blocks_per_cu` 256-thread workgroups per CU (= waves per SIMD), `iters` rounds of 8
+// instructions per wave; *ms = kernel time (events on the null stream)
+extern "C" int calib_valu(float *sink_dev, int op, int blocks_per_cu, int iters, float *ms) {
+  int dev = 0, cus = 0;
+  CALIB_HIP(hipGetDevice(&dev));
+  CALIB_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const dim3 grid(cus * blocks_per_cu), block(256);
+  hipEvent_t e0, e1;
+  CALIB_HIP(hipEventCreate(&e0));
+  CALIB_HIP(hipEventCreate(&e1));
+  CALIB_HIP(hipEventRecord(e0, nullptr));
+#define CALIB_V(OP) \
+  case OP: hipLaunchKernelGGL(psh::calib_valu<OP>, grid, block, 0, nullptr, sink_dev, iters); break;
+  switch (op) {
+    CALIB_V(0) CALIB_V(1) CALIB_V(2) CALIB_V(3) CALIB_V(4) CALIB_V(5) CALIB_V(6) CALIB_V(7)
+    CALIB_V(8) CALIB_V(9) CALIB_V(10) CALIB_V(11) CALIB_V(12) CALIB_V(13) CALIB_V(14) CALIB_V(15)
+    default: return -1;
+  }
+#undef CALIB_V
   CALIB_HIP(hipGetLastError());
   CALIB_HIP(hipEventRecord(e1, nullptr));
   CALIB_HIP(hipEventSynchronize(e1));
