@@ -24,6 +24,7 @@
 //  * k >= L (use everything) and candidate overflow take a brute-force path.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -849,9 +850,254 @@ __global__ __launch_bounds__(64) void idw_fine2(const float2 *__restrict__ xy, c
   out[plane + static_cast<size_t>(iy) * n + ix] = ov;
 }
 
+// ---- fine pass, third form (default): two pixels per lane --------------------------------------
+// Counters of idw_fine2 (profiles/r04): the pass is bound by instruction issue - one wave-wide
+// VALU instruction occupies a SIMD for four cycles on this chip whatever its type, the sum loop is a
+// chain of dependent operations behind an LDS read, and every wave repeats the tile prologue.  Here
+// a wave owns a 16 x 8 tile and a lane the two pixels (x, y), (x + 8, y): the per-vector arithmetic of
+// the pair runs in packed FP32 instructions (v_pk_add / v_pk_mul / v_pk_fma_f32: IEEE per
+// component, so each pixel's operations and their order are those of idw_fine), only the two
+// transcendentals stay scalar; two vectors are in flight per loop iteration (four independent chains),
+// and the prologue is paid once per 128 pixels.  The tile's half diagonal grows from 4.9 to 8.3 pixels,
+// so the undecided ring holds ~1.7 times as many vectors - small against what the packing saves.
+typedef float float2v __attribute__((ext_vector_type(2)));
+constexpr int kFineW = 16, kFineH = 8;
+
+template <bool HALF>  // HALF: power == 0.5, the reference default (one v_rsq_f32 per weight)
+__device__ __forceinline__ void idw_accumulate2(const float4 c, const float2v px, float py, float inv_res, float power,
+                                                float offset, float2v &sw, float2v &su, float2v &sv) {
+  const float2v dx = float2v{c.x, c.x} - px;
+  const float dy = c.y - py;
+  const float dy2 = dy * dy;
+  const float2v d2 = __builtin_elementwise_fma(dx, dx, float2v{dy2, dy2});  // = dist2() per component
+  const float2v d = float2v{fast_sqrt(d2.x), fast_sqrt(d2.y)} * inv_res;
+  float2v w;
+  if constexpr (HALF) {
+    const float2v t = d + offset;
+    w = float2v{__builtin_amdgcn_rsqf(t.x), __builtin_amdgcn_rsqf(t.y)};
+  } else {
+    w = float2v{idw_weight(d.x, power, offset), idw_weight(d.y, power, offset)};
+  }
+  sw += w;
+  su += w * c.z;
+  sv += w * c.w;
+}
+
+// the `need` nearest of a ring of <= 8 vectors for one pixel: every member ranks itself among the
+// others (ties: lower index first, as the second sweep of add_nearest takes them)
+__device__ __forceinline__ void idw_small_ring(const float4 *ring, int n_ring, int need, float px, float py,
+                                               float inv_res, float power, float offset, float &sw, float &su,
+                                               float &sv) {
+  float d2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    d2[j] = INFINITY;
+    if (j < n_ring) {
+      const float4 c = ring[j];
+      d2[j] = dist2(c.x, c.y, px, py);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j >= n_ring) break;  // (uniform)
+    int rank = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i != j) rank += (d2[i] < d2[j] || (i < j && d2[i] == d2[j])) ? 1 : 0;  // (missing members: +inf)
+    }
+    if (rank < need) {
+      const float4 c = ring[j];
+      const float w = idw_weight(fast_sqrt(d2[j]) * inv_res, power, offset);
+      sw += w;
+      su += w * c.z;
+      sv += w * c.w;
+    }
+  }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(64) void idw_fine3(const float2 *__restrict__ xy, const float2 *__restrict__ uv,
+                                                int L, int k, int m, int n, float x0, float dx_grid,
+                                                float y0, float dy_grid, float inv_res, float power,
+                                                float offset, float *__restrict__ out, int supers_x,
+                                                const SuperHeader *__restrict__ headers,
+                                                const float4 *__restrict__ lists, int tiles_x, int n_tiles,
+                                                int tiles_per_xcd, const IdwDyn *__restrict__ dyn) {
+  __shared__ float4 s_cand[kFineCap];  // [certain | undecided], each group in index order
+  const int b = blockIdx.x;
+  const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;  // XCD-contiguous tiles
+  if (tile >= n_tiles) return;
+  const int tx = (tile % tiles_x) * kFineW, ty = (tile / tiles_x) * kFineH;
+  const int lane = threadIdx.x;
+  const int ix_a = tx + (lane & 7), ix_b = ix_a + 8, iy = ty + (lane >> 3);
+  const bool live_a = ix_a < n && iy < m, live_b = ix_b < n && iy < m;
+  const size_t plane = static_cast<size_t>(m) * n;
+  const size_t at_a = static_cast<size_t>(iy) * n + ix_a;
+  if (dyn) {
+    L = dyn->L;
+    k = min(k, L);
+    if (dyn->mode != 0) {  // the interpolator's trivial cases (decorators.py:199-208): constant field
+      const float cu = dyn->cu, cv = dyn->cv;
+      if (live_a) {
+        out[at_a] = cu;
+        out[plane + at_a] = cv;
+      }
+      if (live_b) {
+        out[at_a + 8] = cu;
+        out[plane + at_a + 8] = cv;
+      }
+      return;
+    }
+  }
+  const float2v px = {x0 + dx_grid * static_cast<float>(ix_a), x0 + dx_grid * static_cast<float>(ix_b)};
+  const float py = y0 + dy_grid * static_cast<float>(iy);
+  const int sup = (ty / kSuper) * supers_x + tx / kSuper;
+  const SuperHeader hdr = headers[sup];
+  const float4 *list = lists + static_cast<size_t>(sup) * kSuperCap;
+  const int n_s = __builtin_amdgcn_readfirstlane(hdr.count);
+
+  bool brute = k >= L || n_s > kSuperCap || n_s < k;
+  int n_sure = 0, n_ring = 0;
+  if (!brute) {
+    const int wx = min(kFineW, n - tx), wy = min(kFineH, m - ty);
+    const float cx = x0 + dx_grid * (static_cast<float>(tx) + 0.5f * static_cast<float>(wx - 1));
+    const float cy = y0 + dy_grid * (static_cast<float>(ty) + 0.5f * static_cast<float>(wy - 1));
+    const float hx = 0.5f * fabsf(dx_grid) * static_cast<float>(wx - 1);
+    const float hy = 0.5f * fabsf(dy_grid) * static_cast<float>(wy - 1);
+    const float half_diag = sqrtf(hx * hx + hy * hy);
+    constexpr int kPerLane = kSuperCap / 64;
+    const int chunks = (n_s + 63) >> 6;  // (uniform)
+    float4 c[kPerLane];
+    unsigned key[kPerLane];  // bits of the squared centre distance; missing entries: +inf
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j) {
+      key[j] = 0x7f800000u;
+      c[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < chunks) {
+        const int i = j * 64 + lane;
+        if (i < n_s) {
+          c[j] = list[i];
+          key[j] = __float_as_uint(dist2(c[j].x, c[j].y, cx, cy));
+        }
+      }
+    }
+    // k-th smallest key: the largest T with fewer than k keys below it, built from the top bit
+    // (the 6 lowest mantissa bits stay open: T <= k-th smallest squared distance < T + 64 ulp)
+    unsigned T = 0u;
+    if (chunks == 1) {
+#pragma unroll
+      for (int bit = 30; bit >= 6; --bit) {
+        const unsigned t = T | (1u << bit);
+        if (__popcll(__ballot(key[0] < t)) < k) T = t;
+      }
+    } else {
+#pragma unroll 1
+      for (int bit = 30; bit >= 6; --bit) {
+        const unsigned t = T | (1u << bit);
+        int below = 0;
+#pragma unroll
+        for (int j = 0; j < kPerLane; ++j)
+          if (j < chunks) below += __popcll(__ballot(key[j] < t));
+        if (below < k) T = t;
+      }
+    }
+    const float r_lo = fast_sqrt(__uint_as_float(T)) * (1.f - 1e-6f);
+    const float r_hi = fast_sqrt(__uint_as_float(T + 64u)) * (1.f + 1e-6f);
+    const float reach = r_hi + 2.f * half_diag + 1e-3f * (r_hi + half_diag);
+    const float sure_below = r_lo - 2.f * half_diag - 1e-3f * (r_lo + half_diag);
+    const float reach2 = reach * reach;
+    const float sure2 = sure_below > 0.f ? sure_below * sure_below : -1.f;
+    // certain vectors first, then the undecided ring, each in list (= index) order
+    unsigned long long sure_mask[kPerLane], ring_mask[kPerLane];
+    int tot_sure = 0, tot_ring = 0;
+#pragma unroll
+    for (int j = 0; j < kPerLane; ++j) {
+      sure_mask[j] = ring_mask[j] = 0ull;
+      if (j < chunks) {
+        const float d2 = __uint_as_float(key[j]);
+        const bool sure = d2 <= sure2;
+        sure_mask[j] = __ballot(sure);
+        ring_mask[j] = __ballot(!sure && d2 <= reach2);
+        tot_sure += __popcll(sure_mask[j]);
+        tot_ring += __popcll(ring_mask[j]);
+      }
+    }
+    n_sure = tot_sure;
+    n_ring = tot_ring;
+    brute = n_sure + n_ring > kFineCap;  // pathological clustering: exact brute force
+    if (!brute) {
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      int at_sure = 0, at_ring = n_sure;
+#pragma unroll
+      for (int j = 0; j < kPerLane; ++j) {
+        if (j < chunks) {
+          const bool sure = (sure_mask[j] >> lane) & 1ull, ring = (ring_mask[j] >> lane) & 1ull;
+          const int slot = sure ? at_sure + __popcll(sure_mask[j] & lt) : at_ring + __popcll(ring_mask[j] & lt);
+          if (sure || ring) s_cand[slot] = c[j];
+          at_sure += __popcll(sure_mask[j]);
+          at_ring += __popcll(ring_mask[j]);
+        }
+      }
+    }
+    __syncthreads();  // (one wave: orders the LDS writes before the broadcast reads)
+  }
+  if (!live_a) return;  // (live_b implies live_a)
+  float2v o_u, o_v;
+  if (brute) {
+    float ua, va, ub = 0.f, vb = 0.f;
+    idw_pixel_global<KMAX>(xy, uv, L, k, px.x, py, inv_res, power, offset, ua, va);
+    if (live_b) idw_pixel_global<KMAX>(xy, uv, L, k, px.y, py, inv_res, power, offset, ub, vb);
+    o_u = float2v{ua, ub};
+    o_v = float2v{va, vb};
+  } else {
+    float2v sw = {0.f, 0.f}, su = {0.f, 0.f}, sv = {0.f, 0.f};
+    // the certain vectors - in every pixel's neighbourhood, no selection - two per iteration
+    auto sum_certain = [&](auto half) {
+      constexpr bool kHalf = decltype(half)::value;
+      int i = 0;
+      for (; i + 1 < n_sure; i += 2) {
+        const float4 c0 = s_cand[i], c1 = s_cand[i + 1];  // same address in every lane: LDS broadcast
+        idw_accumulate2<kHalf>(c0, px, py, inv_res, power, offset, sw, su, sv);
+        idw_accumulate2<kHalf>(c1, px, py, inv_res, power, offset, sw, su, sv);
+      }
+      if (i < n_sure) idw_accumulate2<kHalf>(s_cand[i], px, py, inv_res, power, offset, sw, su, sv);
+    };
+    if (power == 0.5f) {
+      sum_certain(std::true_type{});
+    } else {
+      sum_certain(std::false_type{});
+    }
+    const int need = k - n_sure;  // >= 1: fewer than k vectors lie strictly inside R_lo
+    // the ring, pixel by pixel (scalar copies of the sums: vector elements cannot be passed by reference)
+    float wa = sw.x, ua = su.x, va = sv.x, wb = sw.y, ub = su.y, vb = sv.y;
+    if (n_ring <= 8) {
+      idw_small_ring(s_cand + n_sure, n_ring, need, px.x, py, inv_res, power, offset, wa, ua, va);
+      idw_small_ring(s_cand + n_sure, n_ring, need, px.y, py, inv_res, power, offset, wb, ub, vb);
+    } else if (need <= 8) {
+      add_nearest<8>(s_cand, n_sure, n_ring, need, px.x, py, inv_res, power, offset, wa, ua, va);
+      add_nearest<8>(s_cand, n_sure, n_ring, need, px.y, py, inv_res, power, offset, wb, ub, vb);
+    } else {
+      add_nearest<KMAX>(s_cand, n_sure, n_ring, need, px.x, py, inv_res, power, offset, wa, ua, va);
+      add_nearest<KMAX>(s_cand, n_sure, n_ring, need, px.y, py, inv_res, power, offset, wb, ub, vb);
+    }
+    sw = float2v{wa, wb};
+    su = float2v{ua, ub};
+    sv = float2v{va, vb};
+    o_u = float2v{su.x / sw.x, su.y / sw.y};
+    o_v = float2v{sv.x / sw.x, sv.y / sw.y};
+  }
+  out[at_a] = o_u.x;
+  out[plane + at_a] = o_v.x;
+  if (live_b) {
+    out[at_a + 8] = o_u.y;
+    out[plane + at_a + 8] = o_v.y;
+  }
+}
+
 }  // namespace
 
-// 0 = two-level, bisection fine pass (default), 2 = two-level with the histogram fine pass, 1 = one pre-pass per 16x16 tile
+// 0 = two-level, two pixels per lane (default), 3 = two-level, bisection fine pass, 2 = two-level with the histogram
+// fine pass, 1 = one pre-pass per 16x16 tile
 static int g_idw_variant = [] {
   const char *e = std::getenv("PYSTEPS_HIP_IDW_VARIANT");
   return e ? std::atoi(e) : 0;
@@ -881,7 +1127,9 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
       hipError_t e = hipMemsetAsync(headers, 0, n_super * sizeof(SuperHeader), stream);
       if (e != hipSuccess) return e;
     }
-    const int tiles_x = (a.n + kFine - 1) / kFine, tiles_y = (a.m + kFine - 1) / kFine;
+    const bool two_px = g_idw_variant != 2 && g_idw_variant != 3;
+    const int tile_w = two_px ? kFineW : kFine, tile_h = two_px ? kFineH : kFine;
+    const int tiles_x = (a.n + tile_w - 1) / tile_w, tiles_y = (a.m + tile_h - 1) / tile_h;
     const int n_tiles = tiles_x * tiles_y;
     const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
     const dim3 grid(tiles_per_xcd * kNumXcd), block(64);
@@ -891,8 +1139,10 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
 #define PSH_IDW_FINE(KMAX)                                          \
   if (g_idw_variant == 2) {                                         \
     hipLaunchKernelGGL((idw_fine<KMAX>), PSH_IDW_FINE_ARGS);        \
-  } else {                                                          \
+  } else if (g_idw_variant == 3) {                                  \
     hipLaunchKernelGGL((idw_fine2<KMAX>), PSH_IDW_FINE_ARGS);       \
+  } else {                                                          \
+    hipLaunchKernelGGL((idw_fine3<KMAX>), PSH_IDW_FINE_ARGS);       \
   }
     if (k_eff <= 8) {
       PSH_IDW_FINE(8);
