@@ -156,7 +156,6 @@ int idw_resident(const float *xy_dev, const float *values_dev, int capacity, con
                  int k, double power, double dist_offset, float *out_dev);
 size_t idw_scratch_bytes(int m, int n);
 void set_idw_variant(int v);
-void set_lk_response_variant(int v);
 
 hipError_t launch_outliers_pooled(const double *xy_dev, const double *uv_dev, const int *count_dev,
                                   int capacity, int k, double thr, unsigned char *flags_dev,
@@ -173,19 +172,24 @@ int lk_track_pool(void *pyramid_handle, const float *points_host, const float *p
 // on the library stream and in device memory (lk.hip): points_dev holds max_corners (x, y) pairs
 // before_walk (may be NULL) is called once everything up to the ordered walk is queued: the walk
 // is a single workgroup, so independent work forked there (side_begin) runs beside it.
-// walk_stats_host (may be NULL, else int[9]): waits for the stream and returns {chunks, candidates, batches}
+// walk_stats_host (may be NULL, else int[13]): waits for the stream and returns {chunks, candidates, rounds}
 // of the walk and the microseconds it spent {loading, sorting, on coordinates, in block tests, in batches, in all}.
 int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_dev, float *stats_dev, int m, int n,
                         int block_size, int buffer_mask, double quality_level, double min_distance, int max_corners,
                         float *points_dev, int *npoints_dev, int (*before_walk)(void *) = nullptr,
-                        void *before_walk_arg = nullptr, int *walk_stats_host = nullptr);
+                        void *before_walk_arg = nullptr, int *walk_stats_host = nullptr,
+                        unsigned *slots_cleared = nullptr);
 
 // the three frame passes of dense Lucas-Kanade (lk.hip) on a stream of the caller's choice, with the
 // caller's workspace of lk_prepare_ws_bytes(m, n, f64) bytes (lock held)
 size_t lk_prepare_ws_bytes(int m, int n, bool f64);
 int lk_prepare_on(hipStream_t stream, void *ws, const void *frame_dev, bool f64, int m, int n, int size_opening,
                   int buffer_mask, float *clean_dev, unsigned char *track_u8_dev, unsigned char *feature_u8_dev,
-                  float *stats_dev);
+                  float *stats_dev, unsigned *slots_cleared = nullptr);
+// Statistic slots of one frame (lk.hip): lk_slot_bytes() of zero-filled device memory that the frame passes and
+// the corner passes of the SAME frame fold their minima / maxima into instead of going through a
+// single-workgroup finishing kernel; a caller that passes none gets them cleared by a fill launch
+size_t lk_slot_bytes();
 int lk_pyramids_beside(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m, int n, int win_w,
                        int win_h, int max_level, void **handle_out);
 

@@ -73,23 +73,6 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
       if (int rc = feat[t].alloc(plane)) return rc;
     if (int rc = stats[t].alloc(8 * sizeof(float))) return rc;
   }
-  DevBlock ws_main, ws_side;  // allocated before any fork, released after the last join
-  if (int rc = ws_main.alloc(psh::lk_prepare_ws_bytes(m, n, f64))) return rc;
-  if (nframes > 1)
-    if (int rc = ws_side.alloc(psh::lk_prepare_ws_bytes(m, n, f64))) return rc;
-  auto prepare = [&](int t, hipStream_t stream, void *ws) {
-    return psh::lk_prepare_on(stream, ws, frame_ptr(t), f64, m, n, prm->size_opening, prm->buffer_mask, clean[t].as<float>(),
-                              trk[t].as<unsigned char>(), t < nframes - 1 ? feat[t].as<unsigned char>() : nullptr,
-                              stats[t].as<float>());
-  };
-  if (int rc = prepare(0, c.stream, ws_main.p)) return rc;
-
-  // ---- per frame pair: features, tracking, pooling (:207-242) ---------------------------
-  // Everything stays on the device: the corners are ordered and accepted by corner_order
-  // (lk_sparse.hip), the tracker reads them and their count from device memory, the successful
-  // tracks of all pairs are pooled by lk_pool_append and the outlier test reads its sample count
-  // from device memory.  The dense estimate is one chain of kernel launches; only dense=False
-  // (sparse vectors for the caller) ends with a copy to the host.
   const int pairs = nframes - 1;
   const int capacity_dev = prm->max_corners * (pairs > 0 ? pairs : 1);
   if (capacity_dev > 8192)
@@ -99,14 +82,37 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
                      prm->max_corners);
   if (field_dev && prm->idw_k > 32) return psh::fail(PSH_EUNSUPPORTED, "dense_lk: idw k=%d > 32", prm->idw_k);
   const size_t cap = static_cast<size_t>(capacity_dev);
+  // pooled vectors (xy | uv | count | outlier flags: the block dense=False copies to the host as a whole),
+  // behind them the statistic slots of every frame (common.h lk_slot_bytes).  Count and slots have to
+  // start out as zero: ONE fill launch per call clears the tail of the block
   const size_t off_uv = cap * 16, off_cnt = 2 * cap * 16, off_fl = off_cnt + 256;
+  const size_t slot_bytes = (psh::lk_slot_bytes() + 255) & ~static_cast<size_t>(255);
+  const size_t off_slots = (off_fl + cap + 255) & ~static_cast<size_t>(255);
   DevBlock pool;
-  if (int rc = pool.alloc(off_fl + cap)) return rc;
+  if (int rc = pool.alloc(off_slots + slot_bytes * nframes)) return rc;
   char *pbase = pool.as<char>();
   double *d_pxy = reinterpret_cast<double *>(pbase), *d_puv = reinterpret_cast<double *>(pbase + off_uv);
   int *d_pcnt = reinterpret_cast<int *>(pbase + off_cnt);
   unsigned char *d_pfl = reinterpret_cast<unsigned char *>(pbase + off_fl);
-  PSH_HIP(hipMemsetAsync(d_pcnt, 0, sizeof(int), c.stream));
+  PSH_HIP(hipMemsetAsync(pbase + off_cnt, 0, off_slots + slot_bytes * nframes - off_cnt, c.stream));
+  auto frame_slots = [&](int t) { return reinterpret_cast<unsigned *>(pbase + off_slots + slot_bytes * t); };
+  DevBlock ws_main, ws_side;  // allocated before any fork, released after the last join
+  if (int rc = ws_main.alloc(psh::lk_prepare_ws_bytes(m, n, f64))) return rc;
+  if (nframes > 1)
+    if (int rc = ws_side.alloc(psh::lk_prepare_ws_bytes(m, n, f64))) return rc;
+  auto prepare = [&](int t, hipStream_t stream, void *ws) {
+    return psh::lk_prepare_on(stream, ws, frame_ptr(t), f64, m, n, prm->size_opening, prm->buffer_mask, clean[t].as<float>(),
+                              trk[t].as<unsigned char>(), t < nframes - 1 ? feat[t].as<unsigned char>() : nullptr,
+                              stats[t].as<float>(), f64 ? nullptr : frame_slots(t));
+  };
+  if (int rc = prepare(0, c.stream, ws_main.p)) return rc;
+
+  // ---- per frame pair: features, tracking, pooling (:207-242) ---------------------------
+  // Everything stays on the device: the corners are ordered and accepted by corner_order
+  // (lk_sparse.hip), the tracker reads them and their count from device memory, the successful
+  // tracks of all pairs are pooled by lk_pool_append and the outlier test reads its sample count
+  // from device memory.  The dense estimate is one chain of kernel launches; only dense=False
+  // (sparse vectors for the caller) ends with a copy to the host.
   DevBlock corners;  // [int count | pad to 256 | max_corners (x, y) float32], reused pair after pair
   if (int rc = corners.alloc(256 + static_cast<size_t>(prm->max_corners) * 2 * sizeof(float))) return rc;
   int *d_npts = corners.as<int>();
@@ -132,20 +138,21 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
       f->rc = psh::lk_pyramids_beside(f->prev, f->next, f->m, f->n, f->win_w, f->win_h, f->max_level, &f->pyr);
       return f->rc;
     };
-    int walk_stats[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int walk_stats[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)build_pyramids(&fork);  // queued behind the frame passes on the side stream
     const int rc1 = psh::lk_corners_resident(feat[t].as<unsigned char>(), clean[t].as<float>(),
                                              stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
                                              prm->quality_level, prm->min_distance, prm->max_corners, d_pts, d_npts,
-                                             nullptr, nullptr, trace ? walk_stats : nullptr);
+                                             nullptr, nullptr, trace ? walk_stats : nullptr, frame_slots(t));
     const int rcj = psh::side_end();
     void *pyr = fork.pyr;
     if (trace)
       std::fprintf(stderr,
-                   "dense_lk corner walk: %d chunk(s), %d candidates, %d ordered batch(es); us: load %d sort %d "
-                   "coordinates %d block tests %d batches %d total %d\n",
+                   "dense_lk corner walk: %d chunk(s), %d candidates, %d round(s); us: load %d sort %d "
+                   "coordinates %d block tests %d survivors %d (cells %d first round %d later rounds %d append %d) total %d\n",
                    walk_stats[0], walk_stats[1], walk_stats[2], walk_stats[3], walk_stats[4], walk_stats[5],
-                   walk_stats[6], walk_stats[7], walk_stats[8]);
+                   walk_stats[6], walk_stats[7], walk_stats[9], walk_stats[10], walk_stats[11], walk_stats[12],
+                   walk_stats[8]);
     if (rc1 || rcj || fork.rc || !pyr) {
       if (pyr) (void)psh_lk_pyramids_free(pyr);
       return fork.rc ? fork.rc : rc1 ? rc1 : rcj ? rcj : psh::fail(PSH_EHIP, "dense_lk: pyramids were not built");

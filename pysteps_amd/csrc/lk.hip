@@ -40,6 +40,32 @@ enum Stat : int {
 
 constexpr int kRedBlocks = 1024;
 
+// Statistics without a finishing launch.  A producing pass used to write one partial per workgroup and
+// a single-workgroup kernel folded them (5 such launches per frame pair, 6-12 us each, 255 compute
+// units idle).  Minimum and maximum do not depend on the order they are taken in, so a workgroup now
+// folds its partial into one of kSlots words with a device-scope atomic (a single word would take the
+// ~90 atomics per microsecond one address sustains; 64 words take them side by side), and every
+// wave of the CONSUMING pass reads the 64 words back and reduces them itself - the kernel boundary in
+// between orders the two.  Floats are kept as order-preserving unsigned keys; minima as the complement
+// of the key, so that every word is a maximum and zero-filled memory is the identity.
+constexpr int kSlots = 64;
+enum SlotKind : int { kSlMin = 0, kSlNan, kSlMaxAll, kSlMinFeat, kSlMaxFeat, kSlEig, kSlotKinds };
+constexpr size_t kSlotBytes = sizeof(unsigned) * kSlots * kSlotKinds;  // per frame; cleared before the first pass
+
+__device__ __forceinline__ unsigned float_key(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) {
+  return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ void slot_max(unsigned *slots, int kind, int block, float v) {
+  atomicMax(&slots[kind * kSlots + (block & (kSlots - 1))], float_key(v));
+}
+__device__ __forceinline__ void slot_min(unsigned *slots, int kind, int block, float v) {
+  atomicMax(&slots[kind * kSlots + (block & (kSlots - 1))], ~float_key(v));
+}
+
 // Row band of a frame that is processed as a sub-image (multi-GPU tiling, lk_band.hip): the
 // kernels run on the rows [y_org, y_org + m) of the full frame through an offset pointer; y_org
 // restores the absolute row index where the reference's semantics depend on it (the row 0 / 1 quirk
@@ -77,6 +103,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned o = static_cast<unsigned>(__shfl_xor(static_cast<int>(v), d));
+    v = o > v ? o : v;
+  }
+  return v;
+}
+// every lane of a wave gets the statistic folded into the 64 words of `kind` (lane = word)
+__device__ __forceinline__ float slots_max(const unsigned *slots, int kind) {
+  return key_float(wave_max_u32(slots[kind * kSlots + (threadIdx.x & 63)]));
+}
+__device__ __forceinline__ float slots_min(const unsigned *slots, int kind) {
+  return key_float(~wave_max_u32(slots[kind * kSlots + (threadIdx.x & 63)]));
+}
+__device__ __forceinline__ float slots_count(const unsigned *slots, int kind) {  // sum of the words
+  unsigned v = slots[kind * kSlots + (threadIdx.x & 63)];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += static_cast<unsigned>(__shfl_xor(static_cast<int>(v), d));
+  return static_cast<float>(v);
+}
+
 // block-wide reductions for the single-block finishing kernels (up to 16 waves)
 constexpr int kFinalThreads = 1024;
 enum class Red { kMin, kMax, kSum };
@@ -94,8 +142,9 @@ __device__ __forceinline__ float block_reduce(float v, float *smem /* [16] */) {
 }
 
 // ---- pass 1: min over finite pixels + count of non-finite ones ----------------
+// (slots != nullptr: the workgroup's results go to the statistic slots instead of partial[])
 __global__ __launch_bounds__(256) void lk_stats1(const float *__restrict__ img, size_t npx,
-                                                 float *__restrict__ partial) {
+                                                 float *__restrict__ partial, unsigned *__restrict__ slots) {
   float mn = INFINITY, bad = 0.f;
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   const size_t first = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -127,8 +176,15 @@ __global__ __launch_bounds__(256) void lk_stats1(const float *__restrict__ img, 
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    partial[blockIdx.x] = fminf(fminf(s[0][0], s[0][1]), fminf(s[0][2], s[0][3]));
-    partial[gridDim.x + blockIdx.x] = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+    const float b_min = fminf(fminf(s[0][0], s[0][1]), fminf(s[0][2], s[0][3]));
+    const float b_bad = s[1][0] + s[1][1] + s[1][2] + s[1][3];
+    if (slots) {
+      slot_min(slots, kSlMin, blockIdx.x, b_min);
+      if (b_bad > 0.f) atomicAdd(&slots[kSlNan * kSlots + (blockIdx.x & (kSlots - 1))], static_cast<unsigned>(b_bad));
+    } else {
+      partial[blockIdx.x] = b_min;
+      partial[gridDim.x + blockIdx.x] = b_bad;
+    }
   }
 }
 
@@ -323,13 +379,21 @@ constexpr int kOpenRowsW = 16;        // output rows per wave
 constexpr int kOpenColsW = 60;        // output columns per wave (64 lanes - 2 x 2 halo)
 constexpr int kOpenRowsWG = 4 * kOpenRowsW;
 
+// slots != nullptr: minimum and NaN count are read from the statistic slots (lk_stats1 wrote them), the
+// results go there too, and workgroup (0, 0) writes the two input statistics into stats[] for later readers
 __global__ __launch_bounds__(256) void lk_open_bits(const float *__restrict__ img, int m, int n,
                                                     int size_opening, int buffer_mask,
-                                                    const float *__restrict__ stats,
+                                                    float *__restrict__ stats,
                                                     float *__restrict__ clean,
-                                                    float *__restrict__ partial, Band band) {
+                                                    float *__restrict__ partial, Band band,
+                                                    unsigned *__restrict__ slots) {
   __shared__ float red[3][4];
-  const float mn = stats[kMinAll];
+  const float mn = slots ? slots_min(slots, kSlMin) : stats[kMinAll];
+  const float nan_count = slots ? slots_count(slots, kSlNan) : stats[kNanCount];
+  if (slots && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    stats[kMinAll] = mn;
+    stats[kNanCount] = nan_count;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = blockIdx.x * kOpenColsW - 2 + lane;
   const int yb = blockIdx.y * kOpenRowsWG + wave * kOpenRowsW;  // first output row of the wave
@@ -354,7 +418,7 @@ __global__ __launch_bounds__(256) void lk_open_bits(const float *__restrict__ im
   for (int q = 1; q < kLoad - 1; ++q) E[q] = F[q] & (A[q] << 1) & (A[q] >> 1) & A[q - 1] & A[q + 1];
   float mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
   // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
-  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+  const int first_row = buffer_mask > 0 ? (nan_count > 0.f ? 2 : 1) : 0;
   const bool writer = lane >= 2 && lane < 2 + kOpenColsW && col_in;
 #pragma unroll
   for (int q = 2; q < kLoad - 2; ++q) {
@@ -385,9 +449,18 @@ __global__ __launch_bounds__(256) void lk_open_bits(const float *__restrict__ im
   __syncthreads();
   if (threadIdx.x == 0) {
     const int b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
-    partial[b] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    partial[nb + b] = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
-    partial[2 * nb + b] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    const float b_max = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    const float b_fmin = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+    const float b_fmax = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    if (slots) {
+      slot_max(slots, kSlMaxAll, b, b_max);
+      slot_min(slots, kSlMinFeat, b, b_fmin);
+      slot_max(slots, kSlMaxFeat, b, b_fmax);
+    } else {
+      partial[b] = b_max;
+      partial[nb + b] = b_fmin;
+      partial[2 * nb + b] = b_fmax;
+    }
   }
 }
 
@@ -419,12 +492,21 @@ __device__ __forceinline__ unsigned char quantise(float v, float lo, float hi) {
   return static_cast<unsigned char>(static_cast<int>(s));
 }
 
+// slots != nullptr: the three statistics of the cleaned frame are read from the statistic slots
+// (lk_open_bits wrote them) and workgroup 0 writes them into stats[] for later readers
 __global__ __launch_bounds__(256) void lk_to_u8(const float *__restrict__ clean, int m, int n,
-                                                int buffer_mask, const float *__restrict__ stats,
+                                                int buffer_mask, float *__restrict__ stats,
                                                 unsigned char *__restrict__ trk,
-                                                unsigned char *__restrict__ feat, int y_org) {
-  const float fill = stats[kMinAll], hi = stats[kMaxAll];
-  const float flo = stats[kMinFeat], fhi = stats[kMaxFeat];
+                                                unsigned char *__restrict__ feat, int y_org,
+                                                const unsigned *__restrict__ slots) {
+  const float fill = stats[kMinAll], hi = slots ? slots_max(slots, kSlMaxAll) : stats[kMaxAll];
+  const float flo = slots ? slots_min(slots, kSlMinFeat) : stats[kMinFeat];
+  const float fhi = slots ? slots_max(slots, kSlMaxFeat) : stats[kMaxFeat];
+  if (slots && blockIdx.x == 0 && threadIdx.x == 0) {
+    stats[kMaxAll] = hi;
+    stats[kMinFeat] = flo;
+    stats[kMaxFeat] = fhi;
+  }
   const int first_row = max((buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0) - y_org, 0);
   const size_t npx = static_cast<size_t>(m) * n;
   const size_t first_feature_px = static_cast<size_t>(first_row) * n;
@@ -650,7 +732,7 @@ __global__ __launch_bounds__(256) void lk_to_u8_f64(const double *__restrict__ c
 }
 
 // ---- Shi-Tomasi response: cv::cornerMinEigenVal(8U, blockSize, ksize=3) --------
-constexpr int kCrnTX = 32, kCrnTY = 32, kMaxBlockR = 3;  // block_size <= 7; 4 px per thread
+constexpr int kMaxBlockR = 3;  // block_size <= 7
 
 __device__ __forceinline__ bool px_allowed(const float *__restrict__ clean, int m, int n, int x,
                                            int y, int bm, bool any_nan) {
@@ -670,178 +752,34 @@ __device__ __forceinline__ bool px_allowed(const float *__restrict__ clean, int 
   return true;
 }
 
-// row pitch of the product arrays: a multiple of 4 floats, so that the 4-column strips of the
-// box stage start 16-byte aligned (ds_read_b128)
-constexpr int kCrnPitch = (kCrnTX + 2 * kMaxBlockR + 3) & ~3;
-
-// Sobel derivatives (ksize 3, scale s folded in as cornerMinEigenVal does) at the centre of a 3x3
-// neighbourhood a[row][col] and their three products.  One definition for both tile paths of the
-// kernel below, so that both evaluate the same expression tree.
-__device__ __forceinline__ void sobel_products(float a00, float a01, float a02, float a10, float a12, float a20,
-                                               float a21, float a22, float s, float &xx, float &xy, float &yy) {
-  const float hx0 = a02 - a00;
-  const float hx1 = a12 - a10;
-  const float hx2 = a22 - a20;
-  const float dx = (hx0 + hx2) * s + hx1 * (2.f * s);
-  const float hy0 = (a00 + a02) * s + a01 * (2.f * s);
-  const float hy2 = (a20 + a22) * s + a21 * (2.f * s);
-  const float dy = hy2 - hy0;
-  xx = dx * dx;
-  xy = dx * dy;
-  yy = dy * dy;
-}
-
-template <int BS>
-__global__ __launch_bounds__(256) void lk_corner_response(
-    const unsigned char *__restrict__ u8, const float *__restrict__ clean, int m, int n,
-    int buffer_mask, const float *__restrict__ stats, float *__restrict__ eig,
-    float *__restrict__ partial, Band band) {
-  constexpr int H = kMaxBlockR + 1;  // Sobel (1) + box radius (<= 3)
-  constexpr int block_size = BS;
-  __shared__ __attribute__((aligned(16))) float tile[kCrnTY + 2 * H][kCrnTX + 2 * H];
-  __shared__ __attribute__((aligned(16))) float cxx[kCrnTY + 2 * kMaxBlockR][kCrnPitch];
-  __shared__ __attribute__((aligned(16))) float cxy[kCrnTY + 2 * kMaxBlockR][kCrnPitch];
-  __shared__ __attribute__((aligned(16))) float cyy[kCrnTY + 2 * kMaxBlockR][kCrnPitch];
-  __shared__ float red[4];
-  constexpr int r = block_size / 2;
-  const int x0 = blockIdx.x * kCrnTX, y0 = blockIdx.y * kCrnTY;
-  const int tid = threadIdx.x;
-  const float s = 1.0f / (4.0f * static_cast<float>(block_size) * 255.0f);
-  const int rw = kCrnTX + 2 * r, rh = kCrnTY + 2 * r;
-  // Tiles whose haloed footprint lies inside the image (all but the frame of tiles along the
-  // border) need no reflection and no bounds tests: the u8 rows are fetched four pixels per load
-  // and every thread turns a strip of four neighbouring positions into products (the tile taps of
-  // a strip are read once).  Same arithmetic as the general path (sobel_products).
-  const bool interior = (n & 3) == 0 && x0 >= H && y0 >= H && x0 + kCrnTX + H <= n && y0 + kCrnTY + H <= m;
-  if (interior) {
-    constexpr int kTileW = kCrnTX + 2 * H, kTileH = kCrnTY + 2 * H;
-    for (int i = tid; i < kTileH * (kTileW / 4); i += 256) {
-      const int ly = i / (kTileW / 4), c = i % (kTileW / 4);
-      const unsigned w = *reinterpret_cast<const unsigned *>(u8 + static_cast<size_t>(y0 + ly - H) * n + (x0 - H) + 4 * c);
-      *reinterpret_cast<float4 *>(&tile[ly][4 * c]) =
-          make_float4(static_cast<float>(w & 0xffu), static_cast<float>((w >> 8) & 0xffu),
-                      static_cast<float>((w >> 16) & 0xffu), static_cast<float>(w >> 24));
-    }
-    __syncthreads();
-    const int strips = (rw + 3) / 4;
-    for (int i = tid; i < rh * strips; i += 256) {
-      const int ry = i / strips, rx0 = (i % strips) * 4;
-      const int ly = ry - r + H, lxb = rx0 - r + H;  // tile coordinates of the strip's first position
-      float t0[6], t1[6], t2[6];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const int lx = min(lxb - 1 + c, kTileW - 1);  // (beyond the region's last column: unused)
-        t0[c] = tile[ly - 1][lx];
-        t1[c] = tile[ly][lx];
-        t2[c] = tile[ly + 1][lx];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (rx0 + j < rw) {
-          float xx, xy, yy;
-          sobel_products(t0[j], t0[j + 1], t0[j + 2], t1[j], t1[j + 2], t2[j], t2[j + 1], t2[j + 2], s, xx, xy, yy);
-          cxx[ry][rx0 + j] = xx;
-          cxy[ry][rx0 + j] = xy;
-          cyy[ry][rx0 + j] = yy;
-        }
-      }
-    }
-  } else {
-  // u8 tile with reflect-101 image border; covers [x0-H, x0+TX+H)
-  for (int i = tid; i < (kCrnTY + 2 * H) * (kCrnTX + 2 * H); i += 256) {
-    const int ly = i / (kCrnTX + 2 * H), lx = i % (kCrnTX + 2 * H);
-    const int y = reflect101(y0 + ly - H, m), x = reflect101(x0 + lx - H, n);
-    tile[ly][lx] = static_cast<float>(u8[static_cast<size_t>(y) * n + x]);
-  }
-  __syncthreads();
-  // gradient products on [x0-r, x0+TX+r): positions outside the image take the
-  // value of their reflect-101 mirror pixel (boxFilter border), not a mirrored stencil
-  for (int i = tid; i < rw * rh; i += 256) {
-    const int ry = i / rw, rx = i % rw;
-    // rows/columns more than r beyond the image are never summed by a live pixel
-    if (y0 + ry - r > m - 1 + r || x0 + rx - r > n - 1 + r) continue;
-    const int y = reflect101(y0 + ry - r, m), x = reflect101(x0 + rx - r, n);
-    const int ly = y - y0 + H, lx = x - x0 + H;
-    sobel_products(tile[ly - 1][lx - 1], tile[ly - 1][lx], tile[ly - 1][lx + 1], tile[ly][lx - 1], tile[ly][lx + 1],
-                   tile[ly + 1][lx - 1], tile[ly + 1][lx], tile[ly + 1][lx + 1], s, cxx[ry][rx], cxy[ry][rx],
-                   cyy[ry][rx]);
-  }
-  }
-  __syncthreads();
-  float best = 0.f;
-  const bool any_nan = stats[kNanCount] > 0.f;
-  // Box sums.  boxFilter accumulates the float products in double; the products span 20 binary
-  // orders of magnitude with 24-bit mantissas, so every partial sum of a 7x7 window is EXACT in
-  // double and the order of summation is free: each thread owns a strip of four neighbouring
-  // pixels, sums the BS rows of its 4 + 2r columns once and slides the window along the strip
-  // (12 instead of 25 additions per pixel and array, rows read as 16-byte LDS loads).
-  {
-    constexpr int kStrip = 4, kCols = kStrip + 2 * r;
-    const int ly = tid / (kCrnTX / kStrip), lx0 = (tid % (kCrnTX / kStrip)) * kStrip;
-    double cs[3][kCols];
-#pragma unroll
-    for (int c = 0; c < kCols; ++c) cs[0][c] = cs[1][c] = cs[2][c] = 0.0;
-#pragma unroll
-    for (int j = 0; j < BS; ++j) {
-#pragma unroll
-      for (int c = 0; c < kCols; ++c) {
-        cs[0][c] += cxx[ly + j][lx0 + c];
-        cs[1][c] += cxy[ly + j][lx0 + c];
-        cs[2][c] += cyy[ly + j][lx0 + c];
-      }
-    }
-    double win[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c < BS; ++c) {
-      win[0] += cs[0][c];
-      win[1] += cs[1][c];
-      win[2] += cs[2][c];
-    }
-#pragma unroll
-    for (int i = 0; i < kStrip; ++i) {
-      if (i > 0) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) win[q] = win[q] - cs[q][i - 1] + cs[q][i - 1 + BS];
-      }
-      const int x = x0 + lx0 + i, y = y0 + ly;
-      if (x < n && y < m) {
-        const float a = static_cast<float>(win[0]) * 0.5f, b = static_cast<float>(win[1]);
-        const float c = static_cast<float>(win[2]) * 0.5f;
-        const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-        eig[static_cast<size_t>(y) * n + x] = e;
-        if (y >= band.lo && y < band.hi && px_allowed(clean, m, n, x, y, buffer_mask, any_nan))
-          best = fmaxf(best, fmaxf(e, 0.f));
-      }
-    }
-  }
-  best = wave_max(best);
-  if ((tid & 63) == 0) red[tid >> 6] = best;
-  __syncthreads();
-  if (tid == 0)
-    partial[blockIdx.y * gridDim.x + blockIdx.x] =
-        fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-}
-
-// ---- the same response, column-walking form (default) ------------------------------------------
-// lk_corner_response above stages a tile and three product arrays in LDS and spends its time
-// waiting for them (bank conflicts of the double-precision strips, two barriers, 0.29 of the VALU
-// issue slots busy).  Here nothing goes through LDS: a lane owns one image COLUMN, a wave walks
+// Per pixel (OpenCV cornerMinEigenVal, restated in oracle/lk_opencv.py): Sobel derivatives of the
+// 3x3 neighbourhood a[row][col] with the scale s = 1 / (4 block_size 255) folded in,
+//     dx = ((a02 - a00) + (a22 - a20)) s + (a12 - a10) 2s
+//     dy = ((a20 + a22) s + a21 2s) - ((a00 + a02) s + a01 2s)
+// (float32, every product and sum rounded: the expression tree below keeps exactly these roundings),
+// the products dx dx, dx dy, dy dy summed over the block_size x block_size window (boxFilter: float
+// products accumulated in double, BORDER_REFLECT_101 on the product images), lambda_min of the sums.
+//
+// Column-walking form: nothing goes through LDS, a lane owns one image COLUMN, a wave walks
 // ROWS + 2 (r + 1) rows of a 64-column strip from top to bottom and keeps everything in registers.
+// (Rounds 1-3 staged a 32 x 32 tile and three product arrays in LDS and spent the pass waiting for
+// them - bank conflicts of the double-precision strips, two barriers, 0.29 of the VALU issue slots
+// busy: 106 us at 4096^2; this form 63 us alone, 77 us beside the next frame's passes.)
 //  * per loaded row (one byte per lane; the neighbours' bytes come from the next lanes by DPP, so a
 //    lane works for the column one to the right of the one it loads): the horizontal difference
 //    Hd = right - left and the smoothed value G = (left + right) s + centre 2s - exact small integers
-//    until the multiplications, so the expression tree of sobel_products() is kept to the bit;
+//    until the multiplications;
 //  * per row: dx = (Hd[-1] + Hd[+1]) s + Hd[0] 2s, dy = G[+1] - G[-1], the three products, and the
 //    vertical box sums as SLIDING column sums in double: V += P(new) - P(row leaving the window).
-//    Every partial sum of <= 7 x 7 products is exact in double (see above), so adding and subtracting
-//    in any order gives the bits of boxFilter's accumulation; the last BS product rows wait in a
-//    register ring;
+//    The products span 20 binary orders of magnitude with 24-bit mantissas, so every partial sum of a
+//    7 x 7 window is EXACT in double: adding and subtracting in any order gives the bits of
+//    boxFilter's accumulation; the last BS product rows wait in a register ring;
 //  * the horizontal box sum takes V from the next 2r lanes (64-bit DPP moves), then the eigenvalue.
-// Image borders: the pixel loads are reflected (reflect-101 rows and columns, as the LDS tile was
-// filled); a product OUTSIDE the image has to be the product at its mirror position (boxFilter's
-// border), and the walked stencil there is the mirror image of the true one: its dx (columns) or
-// dy (rows) comes out with the opposite sign - exactly, negation commutes with every rounding -, so
-// the sign of s is flipped per lane and the sign of dy per row where the position is mirrored.
+// Image borders: the pixel loads are reflected (reflect-101 rows and columns); a product OUTSIDE the
+// image has to be the product at its mirror position (boxFilter's border), and the walked stencil
+// there is the mirror image of the true one: its dx (columns) or dy (rows) comes out with the
+// opposite sign - exactly, negation commutes with every rounding -, so the sign of s is flipped per
+// lane and the sign of dy per row where the position is mirrored.
 // 4 waves = 4 row bands per workgroup; lanes 0 .. 63 - 2 (r + 1) write.
 __device__ __forceinline__ float next_lane_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
@@ -864,8 +802,15 @@ template <int BS, int ROWS>
 __global__ __launch_bounds__(256) void lk_corner_response_cols(
     const unsigned char *__restrict__ u8, const float *__restrict__ clean, int m, int n,
     int buffer_mask, const float *__restrict__ stats, float *__restrict__ eig,
-    float *__restrict__ partial, Band band) {
+    float *__restrict__ partial, Band band, unsigned *__restrict__ slots, int *__restrict__ zero_a, int count_a,
+    int *__restrict__ zero_b, int count_b) {
   constexpr int r = BS / 2, H = r + 1, W = crn_cols(BS);
+  // (zero_a / zero_b: counters and scratch the NEXT kernels expect cleared - done by the first workgroup
+  // here instead of one 5 us fill launch each)
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    for (int i = threadIdx.x; i < count_a; i += 256) zero_a[i] = 0;
+    for (int i = threadIdx.x; i < count_b; i += 256) zero_b[i] = 0;
+  }
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int x0 = blockIdx.x * W;
@@ -969,8 +914,15 @@ __global__ __launch_bounds__(256) void lk_corner_response_cols(
   best = wave_max(best);
   if (lane == 0) red[wave] = best;
   __syncthreads();
-  if (threadIdx.x == 0)
-    partial[blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (threadIdx.x == 0) {
+    const int b = blockIdx.y * gridDim.x + blockIdx.x;
+    const float b_max = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (slots) {
+      slot_max(slots, kSlEig, b, b_max);
+    } else {
+      partial[b] = b_max;
+    }
+  }
 }
 
 // (zero_a / zero_b: counters and scratch the NEXT kernels expect cleared - done here, by a kernel
@@ -1018,20 +970,28 @@ constexpr int kSelGroups = 4;   // 16-row groups a wave works through: a workgro
 __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict__ eig,
                                                         const float *__restrict__ clean, int m,
                                                         int n, int buffer_mask, float quality,
-                                                        const float *__restrict__ stats,
+                                                        float *__restrict__ stats,
                                                         CornerKey *__restrict__ out, int cap,
-                                                        int *__restrict__ count, Band band) {
+                                                        int *__restrict__ count, Band band,
+                                                        const unsigned *__restrict__ slots) {
   constexpr int kRows = kSelRows / 4;  // rows per group
   __shared__ unsigned long long s_mask[4][kSelGroups * kRows];
   __shared__ int wave_count[4];
   __shared__ int block_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = blockIdx.x * kSelCols - 1 + lane;
+  // lane l LOADS column x0 - 1 + l and JUDGES the column to its right, xc = x0 + l: its own value is the
+  // left neighbour, the centre and the right neighbour come from lanes l + 1 and l + 2 (DPP wave_shl
+  // moves, 4 cycles each; the ds_bpermute behind __shfl_up / __shfl_down costs 24)
+  const int x = blockIdx.x * kSelCols - 1 + lane, xc = x + 1;
   const int y_wave = (blockIdx.y * 4 + wave) * (kSelGroups * kRows);
-  const float thr = stats[kEigMax] * quality;
+  // slots != nullptr: the maximum response comes from the statistic slots (the response pass wrote them)
+  // and workgroup (0, 0) writes it into stats[] for the ordering kernels
+  const float eig_max = slots ? slots_max(slots, kSlEig) : stats[kEigMax];
+  if (slots && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) stats[kEigMax] = eig_max;
+  const float thr = eig_max * quality;
   const bool any_nan = stats[kNanCount] > 0.f;
   const bool col_in = x >= 0 && x < n;
-  const bool col_ok = lane >= 1 && lane <= kSelCols && x >= 1 && x < n - 1;
+  const bool col_ok = lane < kSelCols && xc >= 1 && xc < n - 1;
   int mine = 0;
   for (int g = 0; g < kSelGroups; ++g) {
     const int y_first = y_wave + g * kRows;
@@ -1047,9 +1007,10 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
     }
 #pragma unroll
     for (int q = 0; q < kRows + 2; ++q) {
-      const float left = __shfl_up(v[q], 1), right = __shfl_down(v[q], 1);
-      hmax[q] = fmaxf(left, right);  // (lanes 0 and 63 are halo: never candidates)
-      m3[q] = fmaxf(v[q], hmax[q]);
+      const float left = v[q], centre = next_lane_f(left), right = next_lane_f(centre);
+      hmax[q] = fmaxf(left, right);
+      m3[q] = fmaxf(centre, hmax[q]);
+      v[q] = centre;
     }
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
@@ -1058,7 +1019,7 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
       bool keep = col_ok && yr >= 1 && yr < m - 1 && yr >= band.lo && yr < band.hi;
       keep = keep && c > thr && c != 0.f;                                 // THRESH_TOZERO keeps values > thr
       keep = keep && !(fmaxf(hmax[r + 1], fmaxf(m3[r], m3[r + 2])) > c);  // the 3x3 maximum
-      keep = keep && px_allowed(clean, m, n, x, yr, buffer_mask, any_nan);
+      keep = keep && px_allowed(clean, m, n, xc, yr, buffer_mask, any_nan);
       const unsigned long long mask = __ballot(keep);
       if (lane == 0) s_mask[wave][g * kRows + r] = mask;
       mine += __popcll(mask);
@@ -1082,7 +1043,7 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
     if ((mask >> lane) & 1ull) {
       const int at = pos + __popcll(mask & ((1ull << lane) - 1ull));
       if (at < cap)
-        out[at] = make_corner_key(eig[static_cast<size_t>(y) * n + x], static_cast<unsigned>(y + band.y_org) * n + x);
+        out[at] = make_corner_key(eig[static_cast<size_t>(y) * n + xc], static_cast<unsigned>(y + band.y_org) * n + xc);
     }
     pos += __popcll(mask);
   }
@@ -1178,6 +1139,27 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
   return v;
 }
 
+// Sum over the wave of a value that fits 32 bits per lane (|v| < 2^31), exact in 64 bits, delivered
+// to every lane.  The 64-bit sum through __shfl_xor is 12 ds_bpermute round trips (24 cycles each,
+// profiles/r04/a_valu_probe.txt); here the value is split into its low 16 bits and the rest, each half
+// is summed in 32 bits by six DPP steps (4 cycles each: <= 64 x 2^16 cannot overflow), and the halves
+// are put together once.
+__device__ __forceinline__ int wave_sum_dpp_i32(int v) {
+#define PSH_SUM_STEP(CTRL, ROWMASK) v += __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xf, false);
+  PSH_SUM_STEP(0xB1, 0xf)   // quad_perm:[1,0,3,2]
+  PSH_SUM_STEP(0x4E, 0xf)   // quad_perm:[2,3,0,1]
+  PSH_SUM_STEP(0x141, 0xf)  // row_half_mirror
+  PSH_SUM_STEP(0x140, 0xf)  // row_mirror
+  PSH_SUM_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1 and 3
+  PSH_SUM_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2 and 3
+#undef PSH_SUM_STEP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ long long wave_sum_split_i64(int v) {
+  const int lo = wave_sum_dpp_i32(v & 0xffff), hi = wave_sum_dpp_i32(v >> 16);
+  return (static_cast<long long>(hi) << 16) + lo;
+}
+
 __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01, int &w10, int &w11) {
   const float s = 16384.f;  // 1 << W_BITS
   w00 = static_cast<int>(rintf((1.f - a) * (1.f - b) * s));  // cvRound: half to even
@@ -1187,6 +1169,11 @@ __device__ __forceinline__ void lk_weights(float a, float b, int &w00, int &w01,
 }
 
 __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+// a w00 + b w01 + c w10 + d w11 for factors of at most 24 bits (signed): same integer result as the
+// 32-bit products, on the full-rate 24-bit multiplier
+__device__ __forceinline__ int bilin24(int a, int b, int c, int d, int w00, int w01, int w10, int w11) {
+  return __mul24(a, w00) + __mul24(b, w01) + __mul24(c, w10) + __mul24(d, w11);
+}
 
 // kPer: window samples per thread, >= ceil(win_w * win_h / 256) (4, 10 or 16: 32x32, 50x50, 64x64)
 template <int kPer>
@@ -1396,6 +1383,7 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
   __shared__ short sGx[kMaxWin * kMaxWin];
   __shared__ short sGy[kMaxWin * kMaxWin];
   __shared__ long long red[3][4];
+  __shared__ long long red_b[2][2][4];  // iteration sums of the four waves, two buffers in turn
   const int p = blockIdx.x;
   if (npts_dev) npts = min(npts, *npts_dev);  // count in device memory: see lk_track
   if (p >= npts) return;
@@ -1475,10 +1463,12 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
           const int i10 = from_next_lane(ti[r + 2]), i11 = from_next_lane(i10);
           const int g00 = tg[r], g01 = from_next_lane(tg[r]), g10 = tg[r + 1], g11 = from_next_lane(tg[r + 1]);
           if (sample_lane) {
-            const int ival = descale(i00 * w00 + i01 * w01 + i10 * w10 + i11 * w11, 14 - 5);
-            const int gx = descale(static_cast<short>(g00) * w00 + static_cast<short>(g01) * w01 +
-                                       static_cast<short>(g10) * w10 + static_cast<short>(g11) * w11, 14);
-            const int gy = descale((g00 >> 16) * w00 + (g01 >> 16) * w01 + (g10 >> 16) * w10 + (g11 >> 16) * w11, 14);
+            // (every factor fits 24 bits - pixels 8, gradients 14, weights 15 -: v_mad_i32_i24 runs at
+            // full rate, the 32-bit v_mul_lo_u32 the compiler would pick at a quarter of it)
+            const int ival = descale(bilin24(i00, i01, i10, i11, w00, w01, w10, w11), 14 - 5);
+            const int gx = descale(bilin24(static_cast<short>(g00), static_cast<short>(g01), static_cast<short>(g10),
+                                           static_cast<short>(g11), w00, w01, w10, w11), 14);
+            const int gy = descale(bilin24(g00 >> 16, g01 >> 16, g10 >> 16, g11 >> 16, w00, w01, w10, w11), 14);
             const int i = (row_first + r) * win_w + lane;
             sI[i] = static_cast<short>(ival);
             sGx[i] = static_cast<short>(gx);
@@ -1490,10 +1480,7 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
         }
       }
     }
-    long long a11 = s11, a12 = s12, a22 = s22;
-    a11 = wave_sum_i64(a11);
-    a12 = wave_sum_i64(a12);
-    a22 = wave_sum_i64(a22);
+    const long long a11 = wave_sum_split_i64(s11), a12 = wave_sum_split_i64(s12), a22 = wave_sum_split_i64(s22);
     if (lane == 0) {
       red[0][wave] = a11;
       red[1][wave] = a12;
@@ -1537,23 +1524,22 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
           const int j01 = from_next_lane(tj[r]), j11 = from_next_lane(tj[r + 1]);
           if (sample_lane) {
             const int i = (row_first + r) * win_w + lane;
-            const int diff = descale(tj[r] * w00 + j01 * w01 + tj[r + 1] * w10 + j11 * w11, 14 - 5) - sI[i];
+            const int diff = descale(bilin24(tj[r], j01, tj[r + 1], j11, w00, w01, w10, w11), 14 - 5) - sI[i];
             c1 += diff * sGx[i];
             c2 += diff * sGy[i];
           }
         }
       }
-      long long b1 = c1, b2 = c2;
-      b1 = wave_sum_i64(b1);
-      b2 = wave_sum_i64(b2);
-      __syncthreads();  // everyone has consumed the previous reduction
+      const long long b1 = wave_sum_split_i64(c1), b2 = wave_sum_split_i64(c2);
+      // (the buffer written now was last read two barriers ago: one barrier per iteration is enough)
+      long long (*rb)[4] = red_b[j & 1];
       if (lane == 0) {
-        red[0][wave] = b1;
-        red[1][wave] = b2;
+        rb[0][wave] = b1;
+        rb[1][wave] = b2;
       }
       __syncthreads();
-      const float B1 = static_cast<float>(red[0][0] + red[0][1] + red[0][2] + red[0][3]) * flt_scale;
-      const float B2 = static_cast<float>(red[1][0] + red[1][1] + red[1][2] + red[1][3]) * flt_scale;
+      const float B1 = static_cast<float>(rb[0][0] + rb[0][1] + rb[0][2] + rb[0][3]) * flt_scale;
+      const float B2 = static_cast<float>(rb[1][0] + rb[1][1] + rb[1][2] + rb[1][3]) * flt_scale;
       const float dx = (A12 * B2 - A22 * B1) * D;
       const float dy = (A12 * B1 - A11 * B2) * D;
       qx += dx;
@@ -1633,10 +1619,10 @@ dim3 lk_open_grid(int m, int n) {
   return dim3((n + kOpenTX - 1) / kOpenTX, (m + kOpenTY - 1) / kOpenTY);
 }
 void launch_lk_open(dim3 grid, hipStream_t stream, const float *img, int m, int n, int size_opening, int buffer_mask,
-                    const float *stats, float *clean, float *part, Band band) {
+                    float *stats, float *clean, float *part, Band band, unsigned *slots = nullptr) {
   if (g_lk_open_variant == 0) {
     hipLaunchKernelGGL(lk_open_bits, grid, dim3(256), 0, stream, img, m, n, size_opening, buffer_mask, stats, clean,
-                       part, band);
+                       part, band, slots);
   } else if (n % 4 == 0 && reinterpret_cast<uintptr_t>(img) % 16 == 0 && reinterpret_cast<uintptr_t>(clean) % 16 == 0) {
     hipLaunchKernelGGL(lk_open_vec, grid, dim3(256), 0, stream, img, m, n, size_opening, buffer_mask, stats, clean, part,
                        band);
@@ -1646,51 +1632,30 @@ void launch_lk_open(dim3 grid, hipStream_t stream, const float *img, int m, int 
   }
 }
 
-// Shi-Tomasi response: 0 = column-walking kernel, 32 output rows per wave (default); 2 / 3 = the same
-// with 16 / 64 rows; 1 = the LDS-tile kernel
-static int g_lk_response_variant = [] {
-  const char *e = std::getenv("PYSTEPS_HIP_LK_RESPONSE_VARIANT");
-  return e ? std::atoi(e) : 0;
-}();
-void set_lk_response_variant(int v) { g_lk_response_variant = v; }
-static int lk_response_rows() { return g_lk_response_variant == 2 ? 16 : g_lk_response_variant == 3 ? 64 : 32; }
+constexpr int kCrnRows = 32;  // output rows per wave of the response pass (16 and 64 measured slower: 84 / 84 vs 77 us)
 dim3 lk_response_grid(int m, int n, int block_size) {
-  if (g_lk_response_variant == 1) return dim3((n + kCrnTX - 1) / kCrnTX, (m + kCrnTY - 1) / kCrnTY);
-  const int w = crn_cols(block_size), rows = 4 * lk_response_rows();
+  const int w = crn_cols(block_size), rows = 4 * kCrnRows;
   return dim3((n + w - 1) / w, (m + rows - 1) / rows);
 }
+// slots != nullptr: the maximum goes to the statistic slots (and zero_a / zero_b are cleared by the first
+// workgroup); otherwise one partial maximum per workgroup goes to part[]
 void launch_lk_response(dim3 grid, hipStream_t stream, int block_size, const unsigned char *u8, const float *clean, int m,
-                        int n, int buffer_mask, const float *stats, float *eig, float *part, Band band) {
-#define PSH_CRN_ARGS grid, dim3(256), 0, stream, u8, clean, m, n, buffer_mask, stats, eig, part, band
-#define PSH_CRN_ROWS(BS)                                                             \
-  if (g_lk_response_variant == 2) {                                                  \
-    hipLaunchKernelGGL((lk_corner_response_cols<BS, 16>), PSH_CRN_ARGS);             \
-  } else if (g_lk_response_variant == 3) {                                           \
-    hipLaunchKernelGGL((lk_corner_response_cols<BS, 64>), PSH_CRN_ARGS);             \
-  } else {                                                                           \
-    hipLaunchKernelGGL((lk_corner_response_cols<BS, 32>), PSH_CRN_ARGS);             \
-  }
-  if (g_lk_response_variant == 1) {
-    if (block_size == 1) {
-      hipLaunchKernelGGL(lk_corner_response<1>, PSH_CRN_ARGS);
-    } else if (block_size == 3) {
-      hipLaunchKernelGGL(lk_corner_response<3>, PSH_CRN_ARGS);
-    } else if (block_size == 5) {
-      hipLaunchKernelGGL(lk_corner_response<5>, PSH_CRN_ARGS);
-    } else {
-      hipLaunchKernelGGL(lk_corner_response<7>, PSH_CRN_ARGS);
-    }
-  } else if (block_size == 1) {
-    PSH_CRN_ROWS(1)
+                        int n, int buffer_mask, const float *stats, float *eig, float *part, Band band,
+                        unsigned *slots = nullptr, int *zero_a = nullptr, int count_a = 0, int *zero_b = nullptr,
+                        int count_b = 0) {
+#define PSH_CRN_LAUNCH(BS)                                                                                          \
+  hipLaunchKernelGGL((lk_corner_response_cols<BS, kCrnRows>), grid, dim3(256), 0, stream, u8, clean, m, n, buffer_mask, \
+                     stats, eig, part, band, slots, zero_a, count_a, zero_b, count_b)
+  if (block_size == 1) {
+    PSH_CRN_LAUNCH(1);
   } else if (block_size == 3) {
-    PSH_CRN_ROWS(3)
+    PSH_CRN_LAUNCH(3);
   } else if (block_size == 5) {
-    PSH_CRN_ROWS(5)
+    PSH_CRN_LAUNCH(5);
   } else {
-    PSH_CRN_ROWS(7)
+    PSH_CRN_LAUNCH(7);
   }
-#undef PSH_CRN_ROWS
-#undef PSH_CRN_ARGS
+#undef PSH_CRN_LAUNCH
 }
 
 static int ensure_lk_ws(size_t nbytes, void **ptr) {
@@ -1726,12 +1691,13 @@ size_t lk_prepare_ws_bytes(int m, int n, bool f64) {
     return (npx + 2 * static_cast<size_t>(kRedBlocks) + 3 * static_cast<size_t>(ogrid.x * ogrid.y) + 8) * sizeof(double);
   }
   const dim3 ogrid = lk_open_grid(m, n);
-  return sizeof(float) * (2 * static_cast<size_t>(kRedBlocks) + 3 * static_cast<size_t>(ogrid.x * ogrid.y));
+  return kSlotBytes + sizeof(float) * (2 * static_cast<size_t>(kRedBlocks) + 3 * static_cast<size_t>(ogrid.x * ogrid.y));
 }
+size_t lk_slot_bytes() { return kSlotBytes; }
 
 int lk_prepare_on(hipStream_t stream, void *ws, const void *frame_dev, bool f64, int m, int n, int size_opening,
                   int buffer_mask, float *clean_dev, unsigned char *track_u8_dev, unsigned char *feature_u8_dev,
-                  float *stats_dev) {
+                  float *stats_dev, unsigned *slots_cleared) {
   if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_prepare: invalid shape (%d,%d)", m, n);
   if (!frame_dev || !clean_dev || !track_u8_dev || !stats_dev || !ws) return fail(PSH_EINVAL, "lk_prepare: NULL pointer");
   if (size_opening != 0 && size_opening != 3)
@@ -1741,15 +1707,31 @@ int lk_prepare_on(hipStream_t stream, void *ws, const void *frame_dev, bool f64,
     const float *frame = static_cast<const float *>(frame_dev);
     const dim3 ogrid = lk_open_grid(m, n);
     const int nb_open = ogrid.x * ogrid.y;
-    float *part1 = static_cast<float *>(ws);
+    unsigned *own_slots = static_cast<unsigned *>(ws);
+    float *part1 = reinterpret_cast<float *>(static_cast<char *>(ws) + kSlotBytes);
     float *part2 = part1 + 2 * kRedBlocks;
-    hipLaunchKernelGGL(lk_stats1, dim3(kRedBlocks), dim3(256), 0, stream, frame, npx, part1);
-    hipLaunchKernelGGL(lk_stats1_final, dim3(1), dim3(kFinalThreads), 0, stream, part1, kRedBlocks, stats_dev);
-    launch_lk_open(ogrid, stream, frame, m, n, size_opening, buffer_mask, stats_dev, clean_dev, part2, Band{0, 0, m});
-    hipLaunchKernelGGL(lk_open_final, dim3(1), dim3(kFinalThreads), 0, stream, part2, nb_open, stats_dev);
     const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
-    hipLaunchKernelGGL(lk_to_u8, dim3(qgrid), dim3(256), 0, stream, clean_dev, m, n, buffer_mask, stats_dev, track_u8_dev,
-                       feature_u8_dev, 0);
+    if (g_lk_open_variant == 0) {
+      // statistics through the slots: every pass folds its results into them, the next pass reads them
+      // back - three launches, no single-workgroup kernel in between
+      unsigned *slots = slots_cleared;
+      if (!slots) {
+        slots = own_slots;
+        const hipError_t e = hipMemsetAsync(slots, 0, kSlotBytes, stream);
+        if (e != hipSuccess) return fail(PSH_EHIP, "lk_prepare: clearing the statistic slots failed: %s", hipGetErrorString(e));
+      }
+      hipLaunchKernelGGL(lk_stats1, dim3(kRedBlocks), dim3(256), 0, stream, frame, npx, part1, slots);
+      launch_lk_open(ogrid, stream, frame, m, n, size_opening, buffer_mask, stats_dev, clean_dev, part2, Band{0, 0, m}, slots);
+      hipLaunchKernelGGL(lk_to_u8, dim3(qgrid), dim3(256), 0, stream, clean_dev, m, n, buffer_mask, stats_dev, track_u8_dev,
+                         feature_u8_dev, 0, static_cast<const unsigned *>(slots));
+    } else {
+      hipLaunchKernelGGL(lk_stats1, dim3(kRedBlocks), dim3(256), 0, stream, frame, npx, part1, static_cast<unsigned *>(nullptr));
+      hipLaunchKernelGGL(lk_stats1_final, dim3(1), dim3(kFinalThreads), 0, stream, part1, kRedBlocks, stats_dev);
+      launch_lk_open(ogrid, stream, frame, m, n, size_opening, buffer_mask, stats_dev, clean_dev, part2, Band{0, 0, m});
+      hipLaunchKernelGGL(lk_open_final, dim3(1), dim3(kFinalThreads), 0, stream, part2, nb_open, stats_dev);
+      hipLaunchKernelGGL(lk_to_u8, dim3(qgrid), dim3(256), 0, stream, clean_dev, m, n, buffer_mask, stats_dev, track_u8_dev,
+                         feature_u8_dev, 0, static_cast<const unsigned *>(nullptr));
+    }
   } else {
     // everything that decides a grey level is computed in double, like the reference does for such input
     const double *frame = static_cast<const double *>(frame_dev);
@@ -1838,7 +1820,8 @@ int psh_lk_band_stats_dev(const float *frame_dev, int m, int n, int r0, int r1, 
   if (int rc = psh::ensure_lk_ws(sizeof(float) * 2 * psh::kRedBlocks, &ws)) return rc;
   float *part = static_cast<float *>(ws);
   hipLaunchKernelGGL(psh::lk_stats1, dim3(psh::kRedBlocks), dim3(256), 0, c.stream,
-                     frame_dev + static_cast<size_t>(r0) * n, static_cast<size_t>(r1 - r0) * n, part);
+                     frame_dev + static_cast<size_t>(r0) * n, static_cast<size_t>(r1 - r0) * n, part,
+                     static_cast<unsigned *>(nullptr));
   hipLaunchKernelGGL(psh::lk_stats1_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, psh::kRedBlocks, stats_dev);
   PSH_HIP(hipGetLastError());
   return PSH_OK;
@@ -1880,7 +1863,8 @@ int psh_lk_band_to_u8_dev(const float *clean_dev, int m, int n, int e0, int e1, 
   const size_t off = static_cast<size_t>(e0) * n, npx = static_cast<size_t>(e1 - e0) * n;
   const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
   hipLaunchKernelGGL(psh::lk_to_u8, dim3(qgrid), dim3(256), 0, c.stream, clean_dev + off, e1 - e0, n, buffer_mask,
-                     stats_dev, track_u8_dev + off, feature_u8_dev ? feature_u8_dev + off : nullptr, e0);
+                     const_cast<float *>(stats_dev), track_u8_dev + off, feature_u8_dev ? feature_u8_dev + off : nullptr, e0,
+                     static_cast<const unsigned *>(nullptr));
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }
@@ -1927,8 +1911,8 @@ int psh_lk_band_select_dev(const float *eig_dev, const float *clean_dev, int m, 
   PSH_HIP(hipMemsetAsync(keys_dev, 0, static_cast<size_t>(cap) * sizeof(psh::CornerKey), c.stream));
   const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (ms + psh::kSelRows * psh::kSelGroups - 1) / (psh::kSelRows * psh::kSelGroups));
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig_dev + off, clean_dev + off, ms, n,
-                     buffer_mask, static_cast<float>(quality_level), stats_dev, keys_dev, cap, count_dev,
-                     psh::Band{e0, r0 - e0, r1 - e0});
+                     buffer_mask, static_cast<float>(quality_level), const_cast<float *>(stats_dev), keys_dev, cap, count_dev,
+                     psh::Band{e0, r0 - e0, r1 - e0}, static_cast<const unsigned *>(nullptr));
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }
@@ -2026,23 +2010,34 @@ struct CornerWs {
   }
 };
 
+// eig_slots != nullptr (cleared statistic slots of the frame): the maximum response travels through
+// them - the response pass clears the candidate counter and the ordering scratch, the selection pass reads
+// the maximum back: two launches; otherwise lk_max_final sits in between
 int corner_candidates(const CornerWs &w, void *ws, const unsigned char *feature_u8_dev, const float *clean_dev,
-                      float *stats_dev, int m, int n, int block_size, int buffer_mask, double quality_level) {
+                      float *stats_dev, int m, int n, int block_size, int buffer_mask, double quality_level,
+                      unsigned *eig_slots = nullptr) {
   psh::Context &c = ctx();
   char *base = static_cast<char *>(ws);
   float *eig = reinterpret_cast<float *>(base);
   float *part = reinterpret_cast<float *>(base + w.off_part);
   int *cnt = reinterpret_cast<int *>(base + w.off_cnt);
   psh::CornerKey *raw = reinterpret_cast<psh::CornerKey *>(base + w.off_raw);
-  psh::launch_lk_response(w.rgrid, c.stream, block_size, feature_u8_dev, clean_dev, m, n, buffer_mask, stats_dev, eig, part,
-                          psh::Band{0, 0, m});
-  // the candidate counter and the ordering scratch (histogram + header) are cleared by the same launch
-  hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, w.nb, stats_dev,
-                     static_cast<int>(psh::kEigMax), cnt, 1, reinterpret_cast<int *>(base + w.off_ord),
-                     static_cast<int>(psh::corner_order_clear_bytes() / sizeof(int)));
+  int *ord = reinterpret_cast<int *>(base + w.off_ord);
+  const int ord_ints = static_cast<int>(psh::corner_order_clear_bytes() / sizeof(int));
+  if (eig_slots) {
+    psh::launch_lk_response(w.rgrid, c.stream, block_size, feature_u8_dev, clean_dev, m, n, buffer_mask, stats_dev, eig,
+                            part, psh::Band{0, 0, m}, eig_slots, cnt, 1, ord, ord_ints);
+  } else {
+    psh::launch_lk_response(w.rgrid, c.stream, block_size, feature_u8_dev, clean_dev, m, n, buffer_mask, stats_dev, eig,
+                            part, psh::Band{0, 0, m});
+    // the candidate counter and the ordering scratch (histogram + header) are cleared by the same launch
+    hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, w.nb, stats_dev,
+                       static_cast<int>(psh::kEigMax), cnt, 1, ord, ord_ints);
+  }
   const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (m + psh::kSelRows * psh::kSelGroups - 1) / (psh::kSelRows * psh::kSelGroups));
   hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n, buffer_mask,
-                     static_cast<float>(quality_level), stats_dev, raw, w.cap, cnt, psh::Band{0, 0, m});
+                     static_cast<float>(quality_level), stats_dev, raw, w.cap, cnt, psh::Band{0, 0, m},
+                     static_cast<const unsigned *>(eig_slots));
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }
@@ -2065,7 +2060,7 @@ namespace psh {
 int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_dev, float *stats_dev, int m, int n,
                         int block_size, int buffer_mask, double quality_level, double min_distance, int max_corners,
                         float *points_dev, int *npoints_dev, int (*before_walk)(void *), void *before_walk_arg,
-                        int *walk_stats_host) {
+                        int *walk_stats_host, unsigned *slots_cleared) {
   if (int rc = check_corner_args(feature_u8_dev, clean_dev, stats_dev, m, n, block_size, max_corners)) return rc;
   if (!points_dev || !npoints_dev) return fail(PSH_EINVAL, "lk_corners: NULL pointer");
   if (!corner_order_supported(m, n, min_distance, max_corners))
@@ -2077,7 +2072,8 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
   const CornerWs w(m, n, block_size);
   void *ws = nullptr;
   if (int rc = psh_malloc(&ws, w.bytes)) return rc;  // stream-ordered caching allocator
-  int rc = corner_candidates(w, ws, feature_u8_dev, clean_dev, stats_dev, m, n, block_size, buffer_mask, quality_level);
+  int rc = corner_candidates(w, ws, feature_u8_dev, clean_dev, stats_dev, m, n, block_size, buffer_mask, quality_level,
+                             slots_cleared);
   if (rc == PSH_OK) {
     char *base = static_cast<char *>(ws);
     const hipError_t e = launch_corner_order(
@@ -2086,7 +2082,7 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
         points_dev, npoints_dev, c.stream, before_walk, before_walk_arg, /*ws_is_cleared=*/true);
     if (e != hipSuccess) rc = fail(PSH_EHIP, "corner_order launch failed: %s", hipGetErrorString(e));
     if (rc == PSH_OK && walk_stats_host) {
-      if (hipMemcpyAsync(walk_stats_host, base + w.off_ord + corner_order_walk_stats_offset(), 9 * sizeof(int),
+      if (hipMemcpyAsync(walk_stats_host, base + w.off_ord + corner_order_walk_stats_offset(), 13 * sizeof(int),
                          hipMemcpyDeviceToHost, c.stream) != hipSuccess ||
           hipStreamSynchronize(c.stream) != hipSuccess)
         rc = fail(PSH_EHIP, "corner_order statistics copy failed");

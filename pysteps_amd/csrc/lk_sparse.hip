@@ -36,11 +36,9 @@ using CornerKey = unsigned long long;
 constexpr int kOrdThreads = 1024;
 constexpr int kOrdWaves = kOrdThreads / 64;
 constexpr int kOrdBins = 1024;
-constexpr int kChunkCap = 4096;     // candidates ordered at a time (32 KiB of keys in LDS)
-constexpr int kChunkTarget = 2560;  // a chunk holds at least this many (unless fewer are left)
+constexpr int kChunkCap = 4096;     // most candidates ordered at a time (32 KiB of keys in LDS); launch_corner_order picks <= this
 constexpr int kMaxCornersDev = 2048;  // accepted corners kept in LDS
-constexpr int kHashSlots = 4096;      // cell -> chain of accepted corners (open addressing, load <= 1/2)
-constexpr unsigned kNoCell = 0xffffffffu;
+constexpr int kHashSlots = 8192;      // bucket (hash of the cell key) -> chain of accepted corners; mean chain length <= 1/4
 
 // descending (DESC) or ascending bitonic sort of the first `p2` (power of two, >= 128) LDS entries;
 // a thread owns whole compare-exchange pairs (p2 / 2 of them per step).  Steps with a partner
@@ -97,7 +95,7 @@ __device__ __forceinline__ int bin_shift(CornerKey rlo, CornerKey rhi) {
 // One wave: from the histogram of [rlo, rhi) (kOrdBins bins, LDS or global) and the number of
 // candidates `above` it, the largest bin whose suffix count no longer fits a chunk.
 //  over < 0: everything left fits (`fits` of them);  otherwise `fits` candidates lie above bin `over`.
-__device__ __forceinline__ void chunk_cut(const int *hist, int above, int lane, int &over_out, int &fits_out) {
+__device__ __forceinline__ void chunk_cut(const int *hist, int above, int lane, int ccap, int &over_out, int &fits_out) {
   constexpr int kPer = kOrdBins / 64;
   int tot = 0;
   for (int q = 0; q < kPer; ++q) tot += hist[lane * kPer + q];
@@ -112,7 +110,7 @@ __device__ __forceinline__ void chunk_cut(const int *hist, int above, int lane, 
   for (int q = kPer - 1; q >= 0; --q) {
     const int before = run;
     run += hist[lane * kPer + q];
-    if (run > kChunkCap && over < 0) {
+    if (run > ccap && over < 0) {
       over = lane * kPer + q;
       over_next = before;
     }
@@ -140,6 +138,7 @@ struct OrderHeader {
   int nseg;                        // segments that are valid; the walk selects further chunks itself
   int walk[3];                     // written by corner_order: chunks taken, candidates in them, ordered batches
   int phase_us[6];                 // ... and where its time went: load, sort, coordinates, block tests, batches, total
+  int sub_us[4];                   // inside 'batches': block hash build, first round, later rounds, appending
 };
 
 constexpr int kPreThreads = 256;
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__
                                                              const float *__restrict__ eig_max, float quality,
                                                              const int *__restrict__ hist,
                                                              CornerKey *__restrict__ head,
-                                                             OrderHeader *__restrict__ hdr) {
+                                                             OrderHeader *__restrict__ hdr, int ccap) {
   __shared__ int s_suffix[kOrdBins + 1];  // candidates in bins >= c
   __shared__ int s_cut[kHeadSegs + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -207,7 +206,7 @@ __global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__
     __syncthreads();
     // bins [c, prev) fit for every c from some bin on: the thread that sees the change stores it
     for (int c = tid; c < prev; c += kPreThreads)
-      if (s_suffix[c] - base <= kChunkCap && (c == 0 || s_suffix[c - 1] - base > kChunkCap)) s_cut[sgm + 1] = c;
+      if (s_suffix[c] - base <= ccap && (c == 0 || s_suffix[c - 1] - base > ccap)) s_cut[sgm + 1] = c;
     __syncthreads();
     if (s_cut[sgm + 1] == prev) break;  // the next bin alone overfills a chunk: the walk refines it
     nseg = sgm + 1;
@@ -288,7 +287,22 @@ __global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__
 // goodFeaturesToTrack: ordered min-distance acceptance
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned cell_hash(unsigned cellkey) {
-  return ((cellkey & 0xffffu) * 0x9E3779B1u ^ (cellkey >> 16) * 0x85EBCA6Bu) >> (32 - 12);
+  return ((cellkey & 0xffffu) * 0x9E3779B1u ^ (cellkey >> 16) * 0x85EBCA6Bu) >> (32 - 13);
+}
+static_assert(kHashSlots == 1 << 13, "cell_hash delivers 13 bits");
+
+// new head of a chain whose heads are 16-bit LDS entries; returns the previous head (LDS atomics are
+// 32 bits wide: compare-and-swap on the word that holds the entry)
+__device__ __forceinline__ short push_front(short *head, int value) {
+  unsigned *word = reinterpret_cast<unsigned *>(reinterpret_cast<uintptr_t>(head) & ~static_cast<uintptr_t>(3));
+  const int shift = (reinterpret_cast<uintptr_t>(head) & 2) ? 16 : 0;
+  unsigned seen = *word;
+  for (;;) {
+    const unsigned want = (seen & ~(0xffffu << shift)) | ((static_cast<unsigned>(value) & 0xffffu) << shift);
+    const unsigned prev = atomicCAS(word, seen, want);
+    if (prev == seen) return static_cast<short>((seen >> shift) & 0xffffu);
+    seen = prev;
+  }
 }
 
 __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__restrict__ raw,
@@ -296,12 +310,17 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
                                                             const float *__restrict__ eig_max, float quality,
                                                             const CornerKey *__restrict__ head,
                                                             OrderHeader *__restrict__ hdr, int n, int cell,
-                                                            unsigned md2_ceil, int use_grid, int max_corners,
+                                                            unsigned md2_ceil, int use_grid, int max_corners, int ccap,
                                                             float2 *__restrict__ points, int *__restrict__ npoints) {
   __shared__ CornerKey s_keys[kChunkCap];
   __shared__ int s_hist[kOrdBins];
-  __shared__ unsigned long long s_conf[kOrdWaves][64];
-  __shared__ unsigned long long s_rej[kOrdWaves];
+  // the block's own candidates by cell (fixed point of the acceptance among the survivors)
+  constexpr int kBlockSlots = kHashSlots;
+  __shared__ short s_bhead[kBlockSlots];
+  __shared__ short s_bnext[kOrdThreads];
+  __shared__ uint2 s_bxy[kOrdThreads];  // x | y << 16, x cell | y cell << 16
+  __shared__ unsigned char s_state[kOrdThreads];
+  __shared__ int s_more[3];
   // second key buffer of the counting sort; afterwards the same memory holds, for the ordered chunk,
   // x | y << 16 (s_xy) and x cell | y cell << 16 (s_cl): the divisions are done once per chunk
   __shared__ CornerKey s_tmp[kChunkCap];
@@ -311,23 +330,30 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
   __shared__ int s_maxbin;
   __shared__ uint2 s_acc[kMaxCornersDev];   // accepted corners, same packing
   __shared__ short s_next[kMaxCornersDev];  // next accepted corner of the same cell (-1: none)
-  __shared__ unsigned s_hkey[kHashSlots];   // cell key of a hash slot (kNoCell: free)
-  __shared__ int s_hhead[kHashSlots];       // first accepted corner of that cell (-1: none)
+  // Accepted corners by cell: bucket = hash of the cell key, chained through s_next.  The buckets carry
+  // no key: a chain may mix cells, its members are told apart by the cell key kept with each corner.
+  // A lookup is then ONE read (the bucket's head) instead of a probe sequence whose length a wave
+  // pays as the maximum over its 64 lanes, and the nine heads of a 3x3 neighbourhood are read together.
+  __shared__ short s_hhead[kHashSlots];     // newest accepted corner of the bucket (-1: none)
   __shared__ unsigned short s_surv[kOrdThreads];  // survivors of the block test, in walking order
   __shared__ int s_wcount[kOrdWaves];
-  __shared__ int s_fill, s_nacc, s_over, s_fits, s_nsurv;
+  __shared__ int s_fill, s_over, s_fits, s_nsurv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nkeys = min(max(*raw_count, 0), cap);
   CornerKey key_lo, upper;  // candidates not yet walked lie in [key_lo, upper)
   key_range(*eig_max, quality, key_lo, upper);
-  for (int i = tid; i < kHashSlots; i += kOrdThreads) {
-    s_hkey[i] = kNoCell;
-    s_hhead[i] = -1;
-  }
+  for (int i = tid; i < kHashSlots; i += kOrdThreads) s_hhead[i] = -1;
   int nacc = 0;
   int remaining = nkeys;
   int st_chunks = 0, st_walked = 0, st_batches = 0;  // statistics of the walk (PYSTEPS_HIP_TRACE)
   long long tk_load = 0, tk_sort = 0, tk_xy = 0, tk_test = 0, tk_batch = 0;  // 100 MHz ticks per phase
+  long long tk_sub[4] = {0, 0, 0, 0};
+  long long tk_sub_mark = 0;
+  auto sub_lap = [&](int which) {
+    const long long now = wall_clock64();
+    tk_sub[which] += now - tk_sub_mark;
+    tk_sub_mark = now;
+  };
   const long long tk_start = wall_clock64();
   long long tk_mark = tk_start;
   auto lap = [&](long long &acc) {
@@ -370,7 +396,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
         __syncthreads();
         if (wave == 0) {
           int over, fits;
-          chunk_cut(s_hist, above, lane, over, fits);
+          chunk_cut(s_hist, above, lane, ccap, over, fits);
           if (lane == 0) {
             s_over = over;
             s_fits = fits;
@@ -383,7 +409,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
           T = rlo;
           break;
         }
-        if (fits >= kChunkTarget) {
+        if (fits >= ccap - (ccap >> 2) - (ccap >> 3)) {  // a chunk holds at least 5/8 of its cap (unless fewer are left)
           T = rlo + (static_cast<CornerKey>(over + 1) << sh);
           break;
         }
@@ -509,7 +535,6 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
     // so far by all 16 waves at once (late in the walk that removes most of them), the survivors are
     // then decided in order in batches of 64 ----------------------------------------------------------
     for (int sb0 = 0; sb0 < cnt && nacc < max_corners; sb0 += kOrdThreads) {
-      const int first_new = nacc;  // corners with a smaller index were seen by the test below
       {
         const int i = sb0 + tid;
         const bool there = i < cnt;
@@ -518,25 +543,30 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
           const unsigned xy = s_xy[i], cl = s_cl[i];
           const int x = static_cast<int>(xy & 0xffffu), y = static_cast<int>(xy >> 16);
           const int cx = static_cast<int>(cl & 0xffffu), cy = static_cast<int>(cl >> 16);
-          for (int nb = 0; nb < 9 && !gone; ++nb) {
+          unsigned want[9];
+          int head[9];
+#pragma unroll
+          for (int nb = 0; nb < 9; ++nb) {  // the nine bucket heads: independent reads, one wait
             const int ncx = cx + (nb % 3) - 1, ncy = cy + (nb / 3) - 1;
-            if (ncx < 0 || ncy < 0) continue;
-            const unsigned want = static_cast<unsigned>(ncx) | (static_cast<unsigned>(ncy) << 16);
-            unsigned slot = cell_hash(want);
-            for (int probe = 0; probe < kHashSlots; ++probe) {
-              const unsigned have = s_hkey[slot];
-              if (have == kNoCell) break;
-              if (have == want) {
-                for (int q = s_hhead[slot]; q >= 0; q = s_next[q]) {
-                  const unsigned a = s_acc[q].x;
-                  const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(a & 0xffffu)));
-                  const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(a >> 16)));
-                  if (dx * dx + dy * dy < md2_ceil) gone = true;  // neighbouring cells: < 2^31
-                }
-                break;
-              }
-              slot = (slot + 1) & (kHashSlots - 1);
+            want[nb] = static_cast<unsigned>(ncx) | (static_cast<unsigned>(ncy) << 16);
+            head[nb] = (ncx >= 0 && ncy >= 0) ? s_hhead[cell_hash(want[nb])] : -1;
+          }
+          // the nine chains side by side: one step of each per iteration (their reads are independent),
+          // so a wave pays the LONGEST chain of its lanes once, not once per neighbour cell
+          for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int nb = 0; nb < 9; ++nb) {
+              const int q = head[nb];
+              if (q < 0) continue;
+              any = true;
+              const uint2 a = s_acc[q];
+              head[nb] = s_next[q];
+              const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(a.x & 0xffffu)));
+              const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(a.x >> 16)));
+              if (a.y == want[nb] && dx * dx + dy * dy < md2_ceil) gone = true;  // neighbouring cells: < 2^31
             }
+            if (!any || gone) break;
           }
         }
         const unsigned long long keep = __ballot(there && !gone);
@@ -553,104 +583,108 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       }
       const int nsurv = s_nsurv;
       lap(tk_test);
-    for (int b0 = 0; b0 < nsurv && nacc < max_corners; b0 += 64) {
-      ++st_batches;
-      const bool valid = b0 + lane < nsurv;
-      const int i = valid ? s_surv[b0 + lane] : 0;
-      const unsigned xy = valid ? s_xy[i] : 0u, cl = valid ? s_cl[i] : 0u;
+      // ---- the survivors among themselves: the walk accepts a candidate unless an EARLIER accepted one
+      // is too close, i.e. the accepted set is the greedy independent set of the conflict graph in
+      // walking order.  Decided as a fixed point instead of one by one: a survivor with an accepted
+      // earlier neighbour is rejected, one whose earlier neighbours are all rejected is accepted, the
+      // others wait for the next round (states only move undecided -> decided, so reading a state
+      // another thread is just writing is harmless; the first undecided survivor is decided in every
+      // round, and at the reference's corner densities nearly all of them in the first).  Neighbours
+      // are found through a hash of the block's own cells, like the accepted corners above.
+      tk_sub_mark = wall_clock64();
+      if (use_grid) {
+        for (int q = tid; q < kBlockSlots; q += kOrdThreads) s_bhead[q] = -1;
+        __syncthreads();
+      }
+      const bool mine = tid < nsurv;
+      const int ci = mine ? s_surv[tid] : 0;
+      const unsigned xy = mine ? s_xy[ci] : 0u, cl = mine ? s_cl[ci] : 0u;
       const int x = static_cast<int>(xy & 0xffffu), y = static_cast<int>(xy >> 16);
       const int cx = static_cast<int>(cl & 0xffffu), cy = static_cast<int>(cl >> 16);
-      unsigned long long conf = 0ull;
-      bool rejected = false;
-      if (use_grid && wave < 9 && valid && nacc > first_new) {
-        // waves 0..8 look into one of the 3x3 cells around the candidate (OpenCV looks nowhere else:
-        // cell = round(min_distance) may be smaller than min_distance) - only at the corners accepted
-        // since the test above: a cell's chain runs from the newest corner to the oldest
-        const int ncx = cx + (wave % 3) - 1, ncy = cy + (wave / 3) - 1;
-        if (ncx >= 0 && ncy >= 0) {
-          const unsigned want = static_cast<unsigned>(ncx) | (static_cast<unsigned>(ncy) << 16);
-          unsigned slot = cell_hash(want);
-          for (int probe = 0; probe < kHashSlots; ++probe) {
-            const unsigned have = s_hkey[slot];
-            if (have == kNoCell) break;
-            if (have == want) {
-              for (int q = s_hhead[slot]; q >= first_new; q = s_next[q]) {
-                const unsigned a = s_acc[q].x;
-                const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(a & 0xffffu)));
-                const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(a >> 16)));
-                if (dx * dx + dy * dy < md2_ceil) rejected = true;  // neighbouring cells: < 2^31
-              }
-              break;
-            }
-            slot = (slot + 1) & (kHashSlots - 1);
-          }
-        }
+      if (use_grid && mine) {
+        s_bxy[tid] = make_uint2(xy, cl);
+        s_bnext[tid] = push_front(&s_bhead[cell_hash(cl)], tid);
       }
+      enum : unsigned char { kUndecided = 0, kAccepted = 1, kRejected = 2 };
+      s_state[tid] = mine ? (use_grid ? kUndecided : kAccepted) : kRejected;
+      if (tid < 3) s_more[tid] = 0;
+      __syncthreads();
+      sub_lap(0);
       if (use_grid) {
-        // the earlier candidates of the batch this wave is responsible for
+        bool undecided = mine;
+        int round = 0;
+        for (;;) {
+          ++st_batches;  // (rounds of the fixed point)
+          if (undecided) {
+            bool rejected = false, blocked = false;
+            unsigned want[9];
+            int head[9];
 #pragma unroll
-        for (int q = 0; q < 64 / kOrdWaves; ++q) {
-          const int j = wave + q * kOrdWaves;
-          if (b0 + j >= nsurv) break;  // (uniform)
-          const int oi = s_surv[b0 + j];
-          const unsigned oxy = s_xy[oi], ocl = s_cl[oi];  // LDS broadcast
-          const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(oxy & 0xffffu)));
-          const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(oxy >> 16)));
-          const int ocx = static_cast<int>(ocl & 0xffffu), ocy = static_cast<int>(ocl >> 16);
-          // (the squares may wrap for far-apart candidates; those fail the cell test)
-          if (j < lane && abs(cx - ocx) <= 1 && abs(cy - ocy) <= 1 && dx * dx + dy * dy < md2_ceil) conf |= 1ull << j;
-        }
-      }
-      s_rej[wave] = __ballot(rejected);  // (every lane writes the same value)
-      s_conf[wave][lane] = conf;
-      __syncthreads();
-      if (wave == 0) {
-        unsigned long long rej = 0ull, cf = 0ull;
+            for (int nb = 0; nb < 9; ++nb) {
+              const int ncx = cx + (nb % 3) - 1, ncy = cy + (nb / 3) - 1;
+              want[nb] = static_cast<unsigned>(ncx) | (static_cast<unsigned>(ncy) << 16);
+              head[nb] = (ncx >= 0 && ncy >= 0) ? s_bhead[cell_hash(want[nb])] : -1;
+            }
+            for (;;) {  // the nine chains side by side, as in the block test
+              bool any = false;
 #pragma unroll
-        for (int w = 0; w < kOrdWaves; ++w) {
-          rej |= s_rej[w];
-          cf |= s_conf[w][lane];
-        }
-        const unsigned long long alive = __ballot(valid) & ~rej;
-        const unsigned cf_lo = static_cast<unsigned>(cf), cf_hi = static_cast<unsigned>(cf >> 32);
-        // accepted candidates of the batch, decided in order: those without a conflict inside the
-        // batch at once, the others one by one
-        unsigned long long pending = __ballot(cf != 0ull) & alive;
-        unsigned long long acc = alive & ~pending;
-        while (pending != 0ull) {
-          const int q = __ffsll(static_cast<long long>(pending)) - 1;
-          pending &= pending - 1ull;
-          const unsigned long long cq =
-              (static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(cf_hi), q))) << 32) |
-              static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(cf_lo), q)));
-          // only accepted candidates in front of q matter; candidates behind q are not in cq
-          if ((cq & acc & ((1ull << q) - 1ull)) == 0ull) acc |= 1ull << q;
-          else acc &= ~(1ull << q);
-        }
-        // a candidate without conflicts of its own may still be in conflict with an earlier one that
-        // was only accepted in the loop above: cq holds EARLIER lanes only, so such a candidate has
-        // cf != 0 itself and went through the loop - `acc` is final here
-        const int room = max_corners - nacc;
-        while (__popcll(acc) > room) acc &= ~(1ull << (63 - __clzll(static_cast<long long>(acc))));  // the last ones do not fit
-        if ((acc >> lane) & 1ull) {
-          const int at = nacc + __popcll(acc & ((1ull << lane) - 1ull));
-          const unsigned cellkey = static_cast<unsigned>(cx) | (static_cast<unsigned>(cy) << 16);
-          s_acc[at] = make_uint2(static_cast<unsigned>(x) | (static_cast<unsigned>(y) << 16), cellkey);
-          points[at] = make_float2(static_cast<float>(x), static_cast<float>(y));
-          // into the chain of its cell (the order inside a chain does not matter)
-          unsigned slot = cell_hash(cellkey);
-          for (;;) {
-            const unsigned prev = atomicCAS(&s_hkey[slot], kNoCell, cellkey);
-            if (prev == kNoCell || prev == cellkey) break;
-            slot = (slot + 1) & (kHashSlots - 1);
+              for (int nb = 0; nb < 9; ++nb) {
+                const int q = head[nb];
+                if (q < 0) continue;
+                any = true;
+                const uint2 a = s_bxy[q];
+                const unsigned char st = s_state[q];
+                head[nb] = s_bnext[q];
+                const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(a.x & 0xffffu)));
+                const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(a.x >> 16)));
+                // (q >= tid: later in the walk, or the candidate itself)
+                if (q < tid && a.y == want[nb] && dx * dx + dy * dy < md2_ceil) {  // neighbouring cells: < 2^31
+                  rejected = rejected || st == kAccepted;
+                  blocked = blocked || st == kUndecided;
+                }
+              }
+              if (!any || rejected) break;
+            }
+            if (rejected) {
+              s_state[tid] = kRejected;
+              undecided = false;
+            } else if (!blocked) {
+              s_state[tid] = kAccepted;
+              undecided = false;
+            }
           }
-          s_next[at] = static_cast<short>(atomicExch(&s_hhead[slot], at));
+          // "anyone still undecided?" through three rotating LDS flags (this round's is set before the
+          // barrier and read behind it; the next round's was last read two barriers ago and is cleared now)
+          if (tid == 0) s_more[(round + 1) % 3] = 0;
+          if (__ballot(undecided) != 0ull && lane == 0) s_more[round % 3] = 1;
+          __syncthreads();
+          const int more = s_more[round % 3];
+          ++round;
+          if (!more) break;
         }
-        if (lane == 0) s_nacc = nacc + __popcll(acc);
       }
-      __syncthreads();
-      nacc = s_nacc;
-    }
+      // ---- the accepted survivors, in walking order, behind the corners so far (those beyond
+      // max_corners are dropped: acceptance only depends on earlier candidates) -------------------
+      {
+        const bool acc_me = mine && s_state[tid] == kAccepted;
+        const unsigned long long am = __ballot(acc_me);
+        if (lane == 0) s_wcount[wave] = __popcll(am);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < kOrdWaves; ++w) {
+          if (w < wave) before += s_wcount[w];
+          total += s_wcount[w];
+        }
+        const int at = nacc + before + __popcll(am & ((1ull << lane) - 1ull));
+        if (acc_me && at < max_corners) {
+          s_acc[at] = make_uint2(xy, cl);
+          points[at] = make_float2(static_cast<float>(x), static_cast<float>(y));
+          s_next[at] = push_front(&s_hhead[cell_hash(cl)], at);  // (the order inside a chain does not matter)
+        }
+        nacc = min(nacc + total, max_corners);
+        __syncthreads();
+        sub_lap(3);  // (rounds + appending; a timer per round would cost more than the round)
+      }
       lap(tk_batch);
     }
     remaining -= cnt;
@@ -666,6 +700,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       hdr->walk[2] = st_batches;
       const long long tk[6] = {tk_load, tk_sort, tk_xy, tk_test, tk_batch, wall_clock64() - tk_start};
       for (int q = 0; q < 6; ++q) hdr->phase_us[q] = static_cast<int>(tk[q] / 100);
+      for (int q = 0; q < 4; ++q) hdr->sub_us[q] = static_cast<int>(tk_sub[q] / 100);
     }
   }
 }
@@ -869,7 +904,7 @@ int corner_order_max_corners() { return kMaxCornersDev; }
 constexpr size_t kOrdOffHdr = kOrdBins * sizeof(int);
 constexpr size_t kOrdOffHead = kOrdOffHdr + 128;
 static_assert(sizeof(OrderHeader) <= 128, "header slot");
-static_assert(offsetof(OrderHeader, phase_us) == offsetof(OrderHeader, walk) + 3 * sizeof(int), "walk statistics are one int[9]");
+static_assert(offsetof(OrderHeader, phase_us) == offsetof(OrderHeader, walk) + 3 * sizeof(int), "walk statistics are one int[13]");
 size_t corner_order_ws_bytes() { return kOrdOffHead + static_cast<size_t>(kHeadSegs) * kChunkCap * sizeof(CornerKey); }
 
 size_t corner_order_clear_bytes() { return kOrdOffHead; }
@@ -900,12 +935,16 @@ hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw
   const int groups = std::max(1, std::min(128, (cap + 4 * kPreThreads - 1) / (4 * kPreThreads)));
   hipLaunchKernelGGL(corner_hist, dim3(groups), dim3(kPreThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
                      quality, hist);
+  // candidates ordered at a time: the walk rarely needs more than ~2 x max_corners of them, and a chunk
+  // that covers a narrower key range is ordered faster (finer bins of the counting sort)
+  int ccap = 1024;
+  while (ccap < 2 * max_corners && ccap < kChunkCap) ccap <<= 1;
   hipLaunchKernelGGL(corner_gather, dim3(groups), dim3(kPreThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
-                     quality, hist, head, hdr);
+                     quality, hist, head, hdr, ccap);
   // the walk is a single workgroup: whatever the caller can run beside it is forked off here
   if (before_walk != nullptr && before_walk(before_walk_arg) != 0) return hipErrorUnknown;
   hipLaunchKernelGGL(corner_order, dim3(1), dim3(kOrdThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
-                     quality, head, hdr, n, cell, md2_ceil, min_distance >= 1.0 ? 1 : 0, max_corners,
+                     quality, head, hdr, n, cell, md2_ceil, min_distance >= 1.0 ? 1 : 0, max_corners, ccap,
                      reinterpret_cast<float2 *>(points_dev), npoints_dev);
   return hipGetLastError();
 }

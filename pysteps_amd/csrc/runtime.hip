@@ -256,13 +256,6 @@ int psh_set_option(const char *key, int value) {
     psh::set_idw_variant(value);
     return PSH_OK;
   }
-  if (std::strcmp(key, "lk_response_variant") == 0) {
-    if (value < 0 || value > 3)
-      return fail(PSH_EINVAL, "lk_response_variant must be 0 (column-walking kernel, 32 rows per wave), 2 / 3 (16 / 64 rows) "
-                              "or 1 (LDS tiles)");
-    psh::set_lk_response_variant(value);
-    return PSH_OK;
-  }
   if (std::strcmp(key, "trim_cache") == 0) {  // give the cached device blocks back to the driver
     psh::Context &c = ctx();
     std::lock_guard<std::recursive_mutex> lock(c.mu);
