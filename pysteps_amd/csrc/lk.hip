@@ -125,6 +125,19 @@ __device__ __forceinline__ float slots_count(const unsigned *slots, int kind) { 
   return static_cast<float>(v);
 }
 
+// v_max_f32 / v_min_f32 as they are, for operands that are known not to be NaN (fmaxf / fminf put a
+// canonicalising instruction in front of every operand that was selected or loaded)
+__device__ __forceinline__ float max_plain(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float min_plain(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // block-wide reductions for the single-block finishing kernels (up to 16 waves)
 constexpr int kFinalThreads = 1024;
 enum class Red { kMin, kMax, kSum };
@@ -394,7 +407,8 @@ __global__ __launch_bounds__(256) void lk_open_bits(const float *__restrict__ im
     stats[kMinAll] = mn;
     stats[kNanCount] = nan_count;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (readfirstlane: the wave index is the same in every lane - row tests and masks stay scalar)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int x = blockIdx.x * kOpenColsW - 2 + lane;
   const int yb = blockIdx.y * kOpenRowsWG + wave * kOpenRowsW;  // first output row of the wave
   const bool col_in = x >= 0 && x < n;
@@ -405,38 +419,57 @@ __global__ __launch_bounds__(256) void lk_open_bits(const float *__restrict__ im
     const int y = yb - 2 + q;
     v[q] = (col_in && y >= 0 && y < m) ? img[static_cast<size_t>(y) * n + x] : 0.f;
   }
-  unsigned long long A[kLoad], F[kLoad];
-#pragma unroll
-  for (int q = 0; q < kLoad; ++q) {
-    const int y = yb - 2 + q;
-    const bool row_in = y >= 0 && y < m;
-    F[q] = __ballot(row_in && col_in && isfinite(v[q]) && v[q] > mn);  // masked pixels are filled with the minimum
-    A[q] = F[q] | __ballot(!(row_in && col_in));
-  }
-  unsigned long long E[kLoad];  // valid for q in [1, kLoad - 1)
-#pragma unroll
-  for (int q = 1; q < kLoad - 1; ++q) E[q] = F[q] & (A[q] << 1) & (A[q] >> 1) & A[q - 1] & A[q + 1];
+  // Everything that is the same for a whole row stays in scalar registers: per pixel the VALUs only
+  // see two compares (finite, above the minimum), the selects by wave mask (v_cndmask with the mask as
+  // its condition: __builtin_amdgcn_inverse_ballot_w64) and the three running statistics.  The rows are
+  // walked with rolling masks (row q enters, its erosion is known one row later, the opening of row
+  // q - 2 one row after that): a dozen 64-bit masks live at a time instead of eighty.
+  const unsigned long long colmask = __ballot(col_in);
   float mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
   // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
   const int first_row = buffer_mask > 0 ? (nan_count > 0.f ? 2 : 1) : 0;
   const bool writer = lane >= 2 && lane < 2 + kOpenColsW && col_in;
+  const unsigned long long wmask = __ballot(writer);
+  unsigned long long A1 = 0ull, A2 = 0ull;                  // A of rows q - 1, q - 2
+  unsigned long long F1 = 0ull, F2 = 0ull;                  // F of rows q - 1, q - 2
+  unsigned long long FIN1 = 0ull, FIN2 = 0ull;              // finite pixels of rows q - 1, q - 2
+  unsigned long long E1 = 0ull, E2 = 0ull;                  // erosion of rows q - 2, q - 3
 #pragma unroll
-  for (int q = 2; q < kLoad - 2; ++q) {
-    const int y = yb - 2 + q;
-    if (y >= m) break;  // (uniform)
-    const unsigned long long O = E[q] | (E[q] << 1) | (E[q] >> 1) | E[q - 1] | E[q + 1];
-    float val = v[q];
-    if (size_opening > 0 && ((F[q] >> lane) & 1ull) && !((O >> lane) & 1ull)) val = mn;
-    if (writer) {
-      if (isfinite(val) && y >= band.lo && y < band.hi) {
-        mx_all = fmaxf(mx_all, val);
-        if (y + band.y_org >= first_row) {
-          mn_feat = fminf(mn_feat, val);
-          mx_feat = fmaxf(mx_feat, val);
+  for (int q = 0; q < kLoad; ++q) {
+    const int yq = yb - 2 + q;
+    const bool row_in = yq >= 0 && yq < m;  // (uniform)
+    const unsigned long long FIN0 = row_in ? (__ballot(isfinite(v[q])) & colmask) : 0ull;
+    const unsigned long long F0 = row_in ? (__ballot(v[q] > mn) & FIN0) : 0ull;  // masked pixels are filled with the minimum
+    const unsigned long long A0 = row_in ? (F0 | ~colmask) : ~0ull;  // outside the image: neutral for the erosion
+    const unsigned long long E0 = F1 & (A1 << 1) & (A1 >> 1) & A2 & A0;  // erosion of row q - 1 (valid from q = 2 on)
+    if (q >= 4) {
+      // output row q - 2: the dilation of the erosions of rows q - 3, q - 2, q - 1
+      const int y = yq - 2;
+      if (y < m) {  // (uniform)
+        const unsigned long long O = E1 | (E1 << 1) | (E1 >> 1) | E2 | E0;
+        const unsigned long long removed = size_opening > 0 ? (F2 & ~O) : 0ull;  // field pixels the opening takes away
+        const float val = __builtin_amdgcn_inverse_ballot_w64(removed) ? mn : v[q - 2];
+        // (a removed pixel was finite and the minimum is: val is finite exactly where the input was)
+        const unsigned long long counted = wmask & FIN2;
+        if (y >= band.lo && y < band.hi) {  // (uniform)
+          const float hi = __builtin_amdgcn_inverse_ballot_w64(counted) ? val : -INFINITY;
+          mx_all = max_plain(mx_all, hi);
+          if (y + band.y_org >= first_row) {  // (uniform)
+            mn_feat = min_plain(mn_feat, __builtin_amdgcn_inverse_ballot_w64(counted) ? val : INFINITY);
+            mx_feat = max_plain(mx_feat, hi);
+          }
         }
+        if (writer) clean[static_cast<size_t>(y) * n + x] = val;
       }
-      clean[static_cast<size_t>(y) * n + x] = val;
     }
+    E2 = E1;
+    E1 = E0;
+    A2 = A1;
+    A1 = A0;
+    F2 = F1;
+    F1 = F0;
+    FIN2 = FIN1;
+    FIN1 = FIN0;
   }
   mx_all = wave_max(mx_all);
   mn_feat = wave_min(mn_feat);

@@ -10,14 +10,14 @@
 // are ranked by one bucket pass over their wet values only:
 //
 //   stats      min / max / NaN / inf counts                     -> zero value z, bucket scale
-//   hist       bucket b = floor((v - z) * 2^20 / (max - z)), monotone in v, count per bucket
-//              (target: counted per workgroup in an LDS table first - one global atomic per workgroup
-//              and bucket; observations are quantised, thousands of pixels per distinct value)
-//   scan       bucket starts (three small kernels), wet count, list of the buckets above 256 values
-//   scatter    values (and pixel indices) to their bucket's segment
-//   rank       position inside the segment by counting the smaller values of the same bucket
-//              (one thread per value; the listed large buckets by one workgroup each: a single-valued
-//              bucket - quantised observations - needs no counting at all)
+//   bucket     b = floor((v - z) * 2^20 / (max - z)), monotone in v
+//   target     (once per plan) counted per workgroup in an LDS table first - one global atomic per
+//              workgroup and bucket; observations are quantised, thousands of pixels per distinct value -,
+//              bucket starts by three small scan kernels, values scattered to their bucket's segment,
+//              position inside the segment by counting the smaller values of the same bucket
+//   initial    (every call) two partition passes over the bucket bits, 2^9 coarse x 2^11 fine, with the
+//              counting in LDS and private output ranges from a scan - no device-scope atomic per
+//              pixel (pm2_* below) -, then the same counting inside the bucket
 //
 // target: sorted wet values tw.  initial: rank r of every wet pixel, ties in pixel order (what
 // argsort(kind="stable") gives; the reference's default quicksort leaves the order of tied WET
@@ -228,22 +228,6 @@ __device__ __forceinline__ void hash_clear(PmHash &t) {
   __syncthreads();
 }
 
-// the initial array: a continuous forecast has a bucket per value, nothing to combine - plain atomics
-__global__ __launch_bounds__(kThreads) void pm_hist_initial(const double *__restrict__ a, size_t n,
-                                                            const PmHeader *__restrict__ h, unsigned *table) {
-  if (h->status != kStOk) return;
-  const double z = h->z[0], scale = h->scale[0];
-  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += kLoads * stride) {
-    double v[kLoads];
-#pragma unroll
-    for (int k = 0; k < kLoads; ++k) v[k] = i + k * stride < n ? a[i + k * stride] : z;
-#pragma unroll
-    for (int k = 0; k < kLoads; ++k)
-      if (v[k] > z) atomicAdd(&table[bin_of(v[k], z, scale)], 1u);  // false for NaN
-  }
-}
-
 __global__ __launch_bounds__(kThreads) void pm_hist_target(const double *__restrict__ a, size_t n,
                                                            const PmHeader *__restrict__ h, unsigned *table) {
   __shared__ PmHash t;
@@ -304,31 +288,34 @@ __device__ __forceinline__ unsigned block_incl_scan(unsigned v, unsigned *s_wave
   return incl + add;
 }
 
-__global__ __launch_bounds__(kThreads) void pm_bin_sums(const unsigned *__restrict__ count, unsigned *sums) {
+// (y0: first array the launch works on - 1: the target alone, whose tables are the second halves)
+__global__ __launch_bounds__(kThreads) void pm_bin_sums(const unsigned *__restrict__ count, unsigned *sums, int y0) {
   __shared__ unsigned s_wave[kThreads / 64];
-  const size_t base = static_cast<size_t>(blockIdx.y) * kBins + static_cast<size_t>(blockIdx.x) * kScanBlock;
+  const int y = blockIdx.y + y0;
+  const size_t base = static_cast<size_t>(y) * kBins + static_cast<size_t>(blockIdx.x) * kScanBlock;
   const uint4 c = reinterpret_cast<const uint4 *>(count + base)[threadIdx.x];
   unsigned total;
   (void)block_incl_scan<kThreads / 64>(c.x + c.y + c.z + c.w, s_wave, &total);
-  if (threadIdx.x == 0) sums[blockIdx.y * kScanBlocks + blockIdx.x] = total;
+  if (threadIdx.x == 0) sums[y * kScanBlocks + blockIdx.x] = total;
 }
 
 __global__ __launch_bounds__(kScanBlocks) void pm_scan_sums(const unsigned *__restrict__ sums, unsigned *offs,
-                                                            PmHeader *h) {
+                                                            PmHeader *h, int y0) {
   __shared__ unsigned s_wave[kScanBlocks / 64];
-  const unsigned v = sums[blockIdx.x * kScanBlocks + threadIdx.x];
+  const int y = blockIdx.x + y0;
+  const unsigned v = sums[y * kScanBlocks + threadIdx.x];
   unsigned total;
   const unsigned incl = block_incl_scan<kScanBlocks / 64>(v, s_wave, &total);
-  offs[blockIdx.x * kScanBlocks + threadIdx.x] = incl - v;
-  if (threadIdx.x == 0) h->wet[blockIdx.x] = total;
+  offs[y * kScanBlocks + threadIdx.x] = incl - v;
+  if (threadIdx.x == 0) h->wet[y] = total;
 }
 
 __global__ __launch_bounds__(kThreads) void pm_bin_starts(const unsigned *__restrict__ count,
                                                           const unsigned *__restrict__ offs, unsigned *start,
                                                           unsigned *cursor, unsigned *large, unsigned large_cap,
-                                                          PmHeader *h) {
+                                                          PmHeader *h, int y0) {
   __shared__ unsigned s_wave[kThreads / 64];
-  const int y = blockIdx.y;
+  const int y = blockIdx.y + y0;
   const size_t base = static_cast<size_t>(y) * kBins + static_cast<size_t>(blockIdx.x) * kScanBlock;
   const uint4 c = reinterpret_cast<const uint4 *>(count + base)[threadIdx.x];
   const unsigned mine = c.x + c.y + c.z + c.w;
@@ -349,35 +336,6 @@ __global__ __launch_bounds__(kThreads) void pm_bin_starts(const unsigned *__rest
       if (at < large_cap)
         large[static_cast<size_t>(y) * large_cap + at] = blockIdx.x * kScanBlock + threadIdx.x * 4 + k;
       atomicMax(&h->max_bin[y], cs[k]);
-    }
-  }
-}
-
-// the initial array: values and pixel indices to their bucket's segment, one atomic each (kLoads of
-// them in flight); the dry pixels get their output here (:127-128)
-__global__ __launch_bounds__(kThreads) void pm_scatter_initial(const double *__restrict__ a, size_t n,
-                                                               const PmHeader *__restrict__ h, unsigned *table,
-                                                               double *__restrict__ sval, unsigned *__restrict__ sidx,
-                                                               double *__restrict__ out) {
-  if (h->status != kStOk) return;
-  const double z = h->z[0], scale = h->scale[0], z_trg = h->z[1];
-  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += kLoads * stride) {
-    double v[kLoads];
-    unsigned slot[kLoads];
-#pragma unroll
-    for (int k = 0; k < kLoads; ++k) v[k] = i + k * stride < n ? a[i + k * stride] : z;
-#pragma unroll
-    for (int k = 0; k < kLoads; ++k) slot[k] = v[k] > z ? atomicAdd(&table[bin_of(v[k], z, scale)], 1u) : 0u;
-#pragma unroll
-    for (int k = 0; k < kLoads; ++k) {
-      const size_t at = i + k * stride;
-      if (v[k] > z) {
-        sval[slot[k]] = v[k];
-        sidx[slot[k]] = static_cast<unsigned>(at);
-      } else if (at < n) {
-        out[at] = z_trg;
-      }
     }
   }
 }
@@ -440,57 +398,42 @@ __device__ __forceinline__ void pm_emit(const PmHeader *__restrict__ h, size_t n
   out[pixel] = val;
 }
 
-template <bool IDX>
-__global__ __launch_bounds__(kThreads) void pm_rank_small(const PmHeader *__restrict__ h, size_t n,
+// the target: position inside the bucket = number of smaller values in it -> sorted wet values tw
+// (one thread per value; the buckets above kSmallBin values by one workgroup each)
+__global__ __launch_bounds__(kThreads) void pm_rank_small(const PmHeader *__restrict__ h,
                                                           const unsigned *__restrict__ count,
                                                           const unsigned *__restrict__ start,
-                                                          const double *__restrict__ sval,
-                                                          const unsigned *__restrict__ sidx, double *__restrict__ tw,
-                                                          double *__restrict__ out) {
+                                                          const double *__restrict__ sval, double *__restrict__ tw) {
   if (h->status != kStOk) return;
-  constexpr int y = IDX ? 0 : 1;
-  const double z = h->z[y], scale = h->scale[y];
-  const unsigned wet = h->wet[y];
-  count += static_cast<size_t>(y) * kBins;
-  start += static_cast<size_t>(y) * kBins;
+  const double z = h->z[1], scale = h->scale[1];
+  const unsigned wet = h->wet[1];
+  count += kBins;
+  start += kBins;
   const unsigned stride = gridDim.x * kThreads;
   for (unsigned s = blockIdx.x * kThreads + threadIdx.x; s < wet; s += stride) {
     const double v = sval[s];
     const unsigned b = bin_of(v, z, scale), c = count[b];
     if (c > kSmallBin) continue;  // pm_rank_large
     const unsigned st = start[b];
-    const unsigned me = IDX ? sidx[s] : s;
     unsigned less = 0;
     for (unsigned j = st; j < st + c; ++j) {
       const double vj = sval[j];
-      if (vj < v) {
-        ++less;
-      } else if (vj == v) {
-        less += (IDX ? sidx[j] : j) < me ? 1u : 0u;
-      }
+      less += (vj < v || (vj == v && j < s)) ? 1u : 0u;
     }
-    if (IDX) {
-      pm_emit(h, n, tw, out, me, st + less);
-    } else {
-      tw[st + less] = v;
-    }
+    tw[st + less] = v;
   }
 }
 
-template <bool IDX>
-__global__ __launch_bounds__(kThreads) void pm_rank_large(PmHeader *h, size_t n, const unsigned *__restrict__ count,
+__global__ __launch_bounds__(kThreads) void pm_rank_large(PmHeader *h, const unsigned *__restrict__ count,
                                                           const unsigned *__restrict__ start,
                                                           const unsigned *__restrict__ large, unsigned large_cap,
-                                                          const double *__restrict__ sval,
-                                                          const unsigned *__restrict__ sidx, double *__restrict__ tw,
-                                                          double *__restrict__ out) {
+                                                          const double *__restrict__ sval, double *__restrict__ tw) {
   __shared__ double s_mn[kThreads / 64], s_mx[kThreads / 64];
   if (h->status != kStOk) return;
-  constexpr int y = IDX ? 0 : 1;
-  count += static_cast<size_t>(y) * kBins;
-  start += static_cast<size_t>(y) * kBins;
-  large += static_cast<size_t>(y) * large_cap;
-  const unsigned n_large = h->n_large[y] < large_cap ? h->n_large[y] : large_cap;
+  count += kBins;
+  start += kBins;
+  large += large_cap;
+  const unsigned n_large = h->n_large[1] < large_cap ? h->n_large[1] : large_cap;
   for (unsigned li = blockIdx.x; li < n_large; li += gridDim.x) {
     const unsigned b = large[li], c = count[b], st = start[b];
     double mn = INFINITY, mx = -INFINITY;
@@ -518,8 +461,7 @@ __global__ __launch_bounds__(kThreads) void pm_rank_large(PmHeader *h, size_t n,
       mn = s_mn[w] < mn ? s_mn[w] : mn;
       mx = s_mx[w] > mx ? s_mx[w] : mx;
     }
-    const bool single = mn == mx;
-    if (!IDX && single) {  // equal values: already sorted
+    if (mn == mx) {  // equal values (quantised observations): already sorted
       for (unsigned j = threadIdx.x; j < c; j += kThreads) tw[st + j] = mn;
       continue;
     }
@@ -529,21 +471,237 @@ __global__ __launch_bounds__(kThreads) void pm_rank_large(PmHeader *h, size_t n,
     }
     for (unsigned e = threadIdx.x; e < c; e += kThreads) {
       const double v = sval[st + e];
-      const unsigned me = IDX ? sidx[st + e] : st + e;
       unsigned less = 0;
       for (unsigned j = st; j < st + c; ++j) {
         const double vj = sval[j];
-        if (vj < v) {
-          ++less;
-        } else if (vj == v) {
-          less += (IDX ? sidx[j] : j) < me ? 1u : 0u;
-        }
+        less += (vj < v || (vj == v && j < st + e)) ? 1u : 0u;
       }
-      if (IDX) {
-        pm_emit(h, n, tw, out, me, st + less);
-      } else {
-        tw[st + less] = v;
+      tw[st + less] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The initial array without device-scope atomics (round 4).
+// pm_hist_initial / pm_scatter_initial cost one global atomic per wet pixel each (8.4 M per call at
+// 4096^2: 0.43 of the 1.15 ms), because a continuous forecast has a bucket of its own for nearly every
+// value.  The 2^20 buckets are an MSD radix key: kCoarse x kFine.  Two partition passes move the
+// atomics into LDS:
+//   pm2_count    a workgroup owns kPxBlock consecutive PIXELS: LDS histogram over the coarse
+//                buckets -> H[coarse][block]
+//   pm2_sums / pm2_scan_sums / pm2_offsets   exclusive scan of H in (coarse, block) order: every
+//                block gets a private range inside every coarse segment; wet count
+//   pm2_scatter  the same pixels again: position = LDS cursor of the coarse bucket -> (value, pixel)
+//                records grouped by coarse bucket; the dry pixels get their output here (:127-128)
+//   pm2_refine   one workgroup per coarse segment, streaming it twice from memory: LDS histogram over
+//                its kFine fine buckets, scan, second copy grouped by the full bucket; writes the
+//                count / start tables of its 2^11 buckets and lists the crowded ones
+//   pm2_rank_*   position inside the bucket = number of smaller (value, pixel) pairs -> output
+// Any distribution is handled (a segment is streamed, not staged: one outlier that squeezes a third
+// of the values into one coarse bucket makes that workgroup slow, not wrong); the limits on TIED or
+// bucket-sharing values are those of pm_rank_large.
+constexpr unsigned kFineBits = 11, kFine = 1u << kFineBits, kCoarse = kBins >> kFineBits;
+constexpr unsigned kPxBlock = 8192;  // pixels per workgroup of pm2_count / pm2_scatter
+constexpr unsigned kScanChunk = 4096;  // entries of H per workgroup of the scan kernels
+constexpr int kRefineThreads = 1024;
+
+struct PmRec {
+  double v;
+  unsigned idx, pad;
+};
+
+__global__ __launch_bounds__(kThreads) void pm2_count(const double *__restrict__ a, size_t n,
+                                                      const PmHeader *__restrict__ h, unsigned *__restrict__ H,
+                                                      unsigned nblk) {
+  __shared__ unsigned s_hist[kCoarse];
+  for (unsigned c = threadIdx.x; c < kCoarse; c += kThreads) s_hist[c] = 0u;
+  __syncthreads();
+  if (h->status == kStOk) {
+    const double z = h->z[0], scale = h->scale[0];
+    const size_t first = static_cast<size_t>(blockIdx.x) * kPxBlock + threadIdx.x;
+    for (unsigned k0 = 0; k0 < kPxBlock / kThreads; k0 += kLoads) {
+      double v[kLoads];
+#pragma unroll
+      for (int k = 0; k < kLoads; ++k) {
+        const size_t i = first + static_cast<size_t>(k0 + k) * kThreads;
+        v[k] = i < n ? a[i] : z;
       }
+#pragma unroll
+      for (int k = 0; k < kLoads; ++k)
+        if (v[k] > z) atomicAdd(&s_hist[bin_of(v[k], z, scale) >> kFineBits], 1u);  // false for NaN
+    }
+  }
+  __syncthreads();
+  for (unsigned c = threadIdx.x; c < kCoarse; c += kThreads) H[static_cast<size_t>(c) * nblk + blockIdx.x] = s_hist[c];
+}
+
+// exclusive scan of H[0 .. nent) in three steps: sums of kScanChunk entries, scan of the sums (one
+// workgroup), offsets written back in place
+__global__ __launch_bounds__(kThreads) void pm2_sums(const unsigned *__restrict__ H, size_t nent, unsigned *__restrict__ sums) {
+  __shared__ unsigned s_wave[kThreads / 64];
+  const size_t base = static_cast<size_t>(blockIdx.x) * kScanChunk;
+  unsigned mine = 0;
+  for (unsigned k = 0; k < kScanChunk / kThreads; ++k) {
+    const size_t i = base + static_cast<size_t>(threadIdx.x) * (kScanChunk / kThreads) + k;
+    mine += i < nent ? H[i] : 0u;
+  }
+  unsigned total;
+  (void)block_incl_scan<kThreads / 64>(mine, s_wave, &total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void pm2_scan_sums(unsigned *__restrict__ sums, unsigned nsums, PmHeader *h) {
+  __shared__ unsigned s_wave[16];
+  unsigned carry = 0;
+  for (unsigned b0 = 0; b0 < nsums; b0 += 1024) {  // (uniform trip count)
+    const unsigned i = b0 + threadIdx.x;
+    const unsigned v = i < nsums ? sums[i] : 0u;
+    unsigned total;
+    const unsigned incl = block_incl_scan<16>(v, s_wave, &total);
+    if (i < nsums) sums[i] = carry + incl - v;
+    carry += total;
+  }
+  if (threadIdx.x == 0) h->wet[0] = carry;
+}
+
+__global__ __launch_bounds__(kThreads) void pm2_offsets(unsigned *__restrict__ H, size_t nent,
+                                                        const unsigned *__restrict__ sums) {
+  __shared__ unsigned s_wave[kThreads / 64];
+  constexpr unsigned kPer = kScanChunk / kThreads;
+  const size_t base = static_cast<size_t>(blockIdx.x) * kScanChunk + static_cast<size_t>(threadIdx.x) * kPer;
+  unsigned v[kPer], mine = 0;
+#pragma unroll
+  for (unsigned k = 0; k < kPer; ++k) {
+    v[k] = base + k < nent ? H[base + k] : 0u;
+    mine += v[k];
+  }
+  unsigned total;
+  const unsigned incl = block_incl_scan<kThreads / 64>(mine, s_wave, &total);
+  unsigned run = sums[blockIdx.x] + incl - mine;
+#pragma unroll
+  for (unsigned k = 0; k < kPer; ++k) {
+    if (base + k < nent) H[base + k] = run;
+    run += v[k];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void pm2_scatter(const double *__restrict__ a, size_t n,
+                                                        const PmHeader *__restrict__ h, const unsigned *__restrict__ H,
+                                                        unsigned nblk, PmRec *__restrict__ rec, double *__restrict__ out) {
+  __shared__ unsigned s_cur[kCoarse];
+  if (h->status != kStOk) return;
+  for (unsigned c = threadIdx.x; c < kCoarse; c += kThreads) s_cur[c] = H[static_cast<size_t>(c) * nblk + blockIdx.x];
+  __syncthreads();
+  const double z = h->z[0], scale = h->scale[0], z_trg = h->z[1];
+  const size_t first = static_cast<size_t>(blockIdx.x) * kPxBlock + threadIdx.x;
+  for (unsigned k0 = 0; k0 < kPxBlock / kThreads; k0 += kLoads) {
+    double v[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const size_t i = first + static_cast<size_t>(k0 + k) * kThreads;
+      v[k] = i < n ? a[i] : z;
+    }
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const size_t i = first + static_cast<size_t>(k0 + k) * kThreads;
+      if (v[k] > z) {
+        const unsigned pos = atomicAdd(&s_cur[bin_of(v[k], z, scale) >> kFineBits], 1u);
+        rec[pos] = PmRec{v[k], static_cast<unsigned>(i), 0u};
+      } else if (i < n) {
+        out[i] = z_trg;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kRefineThreads) void pm2_refine(PmHeader *h, const unsigned *__restrict__ H, unsigned nblk,
+                                                             const PmRec *__restrict__ rec_in, PmRec *__restrict__ rec_out,
+                                                             unsigned *__restrict__ count, unsigned *__restrict__ start,
+                                                             unsigned *large, unsigned large_cap) {
+  __shared__ unsigned s_cnt[kFine], s_pos[kFine];
+  __shared__ unsigned s_wave[kRefineThreads / 64];
+  if (h->status != kStOk) return;
+  const unsigned c = blockIdx.x;
+  const double z = h->z[0], scale = h->scale[0];
+  const unsigned seg0 = H[static_cast<size_t>(c) * nblk];
+  const unsigned seg1 = c + 1 < kCoarse ? H[static_cast<size_t>(c + 1) * nblk] : h->wet[0];
+  for (unsigned f = threadIdx.x; f < kFine; f += kRefineThreads) s_cnt[f] = 0u;
+  __syncthreads();
+  for (unsigned e = seg0 + threadIdx.x; e < seg1; e += kRefineThreads)
+    atomicAdd(&s_cnt[bin_of(rec_in[e].v, z, scale) & (kFine - 1)], 1u);
+  __syncthreads();
+  // exclusive scan of the fine counts (two per thread), tables of the segment's buckets
+  static_assert(kFine == 2 * kRefineThreads, "two fine buckets per thread");
+  const unsigned c0 = s_cnt[2 * threadIdx.x], c1 = s_cnt[2 * threadIdx.x + 1];
+  unsigned total;
+  const unsigned incl = block_incl_scan<kRefineThreads / 64>(c0 + c1, s_wave, &total);
+  const unsigned st0 = seg0 + incl - (c0 + c1), st1 = st0 + c0;
+  s_pos[2 * threadIdx.x] = st0;
+  s_pos[2 * threadIdx.x + 1] = st1;
+  const size_t b0 = static_cast<size_t>(c) * kFine + 2 * threadIdx.x;
+  *reinterpret_cast<uint2 *>(count + b0) = make_uint2(c0, c1);
+  *reinterpret_cast<uint2 *>(start + b0) = make_uint2(st0, st1);
+  const unsigned cs[2] = {c0, c1};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (cs[k] > kSmallBin) {
+      const unsigned at = atomicAdd(&h->n_large[0], 1u);
+      if (at < large_cap) large[at] = static_cast<unsigned>(b0) + k;
+      atomicMax(&h->max_bin[0], cs[k]);
+    }
+  }
+  __syncthreads();
+  for (unsigned e = seg0 + threadIdx.x; e < seg1; e += kRefineThreads) {
+    const PmRec r = rec_in[e];
+    rec_out[atomicAdd(&s_pos[bin_of(r.v, z, scale) & (kFine - 1)], 1u)] = r;
+  }
+}
+
+// pm_rank_small<true> / pm_rank_large<true> on records
+__global__ __launch_bounds__(kThreads) void pm2_rank_small(const PmHeader *__restrict__ h, size_t n,
+                                                           const unsigned *__restrict__ count,
+                                                           const unsigned *__restrict__ start,
+                                                           const PmRec *__restrict__ rec, const double *__restrict__ tw,
+                                                           double *__restrict__ out) {
+  if (h->status != kStOk) return;
+  const double z = h->z[0], scale = h->scale[0];
+  const unsigned wet = h->wet[0];
+  const unsigned stride = gridDim.x * kThreads;
+  for (unsigned s = blockIdx.x * kThreads + threadIdx.x; s < wet; s += stride) {
+    const PmRec me = rec[s];
+    const unsigned b = bin_of(me.v, z, scale), c = count[b];
+    if (c > kSmallBin) continue;  // pm2_rank_large
+    const unsigned st = start[b];
+    unsigned less = 0;
+    for (unsigned j = st; j < st + c; ++j) {
+      const PmRec o = rec[j];
+      less += (o.v < me.v || (o.v == me.v && o.idx < me.idx)) ? 1u : 0u;
+    }
+    pm_emit(h, n, tw, out, me.idx, st + less);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void pm2_rank_large(PmHeader *h, size_t n, const unsigned *__restrict__ count,
+                                                           const unsigned *__restrict__ start,
+                                                           const unsigned *__restrict__ large, unsigned large_cap,
+                                                           const PmRec *__restrict__ rec, const double *__restrict__ tw,
+                                                           double *__restrict__ out) {
+  if (h->status != kStOk) return;
+  const unsigned n_large = h->n_large[0] < large_cap ? h->n_large[0] : large_cap;
+  for (unsigned li = blockIdx.x; li < n_large; li += gridDim.x) {
+    const unsigned b = large[li], c = count[b], st = start[b];
+    if (c > kLargeLimit) {
+      if (threadIdx.x == 0) atomicExch(&h->status, kStTies);
+      continue;
+    }
+    for (unsigned e = threadIdx.x; e < c; e += kThreads) {
+      const PmRec me = rec[st + e];
+      unsigned less = 0;
+      for (unsigned j = st; j < st + c; ++j) {
+        const PmRec o = rec[j];
+        less += (o.v < me.v || (o.v == me.v && o.idx < me.idx)) ? 1u : 0u;
+      }
+      pm_emit(h, n, tw, out, me.idx, st + less);
     }
   }
 }
@@ -626,7 +784,8 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
   PSH_HIP(hipSetDevice(c.device));
 
   // [header | statistics partials 2 x 2048 | counts 2 x B | starts 2 x B | cursors 2 x B | block sums 2 x 1024 | block offsets 2 x 1024 |
-  //  large-bucket lists 2 x cap | scattered values N | sorted wet target values N | pixel indices N]
+  //  large-bucket lists 2 x cap | scattered target values N | sorted wet target values N |
+  //  H: coarse x pixel blocks | sums of H | records N (by coarse bucket) | records N (by bucket)]
   const unsigned large_cap = static_cast<unsigned>(count / kSmallBin + 1);
   auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
   const size_t table_bytes = 2 * static_cast<size_t>(kBins) * sizeof(unsigned);
@@ -635,9 +794,15 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
   const size_t off_sums = off_cursor + table_bytes, off_offs = off_sums + 2 * kScanBlocks * sizeof(unsigned);
   const size_t off_large = off_offs + 2 * kScanBlocks * sizeof(unsigned);
   const size_t off_sval = up(off_large + 2 * static_cast<size_t>(large_cap) * sizeof(unsigned));
-  const size_t off_tw = up(off_sval + count * sizeof(double));
-  const size_t off_sidx = up(off_tw + (plan ? 0 : count * sizeof(double)));
-  const size_t total = off_sidx + (make ? 0 : count * sizeof(unsigned));
+  const size_t off_tw = up(off_sval + (plan ? 0 : count * sizeof(double)));
+  const unsigned nblk = static_cast<unsigned>((count + kPxBlock - 1) / kPxBlock);
+  const size_t nent = static_cast<size_t>(kCoarse) * nblk;
+  const unsigned nsums = static_cast<unsigned>((nent + kScanChunk - 1) / kScanChunk);
+  const size_t off_h = up(off_tw + (plan ? 0 : count * sizeof(double)));
+  const size_t off_hsums = up(off_h + (make ? 0 : nent * sizeof(unsigned)));
+  const size_t off_rec_a = up(off_hsums + (make ? 0 : static_cast<size_t>(nsums) * sizeof(unsigned)));
+  const size_t off_rec_b = up(off_rec_a + (make ? 0 : count * sizeof(PmRec)));
+  const size_t total = off_rec_b + (make ? 0 : count * sizeof(PmRec));
   static_assert(sizeof(PmHeader) <= 256, "header block");
   void *blk = nullptr;
   if (int rc = psh_malloc(&blk, total)) return rc;
@@ -652,7 +817,10 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
   unsigned *large = reinterpret_cast<unsigned *>(base + off_large);
   double *sval = reinterpret_cast<double *>(base + off_sval);
   double *tw = plan ? const_cast<double *>(plan->tw()) : reinterpret_cast<double *>(base + off_tw);
-  unsigned *sidx = reinterpret_cast<unsigned *>(base + off_sidx);
+  unsigned *H = reinterpret_cast<unsigned *>(base + off_h);
+  unsigned *hsums = reinterpret_cast<unsigned *>(base + off_hsums);
+  PmRec *rec_a = reinterpret_cast<PmRec *>(base + off_rec_a);
+  PmRec *rec_b = reinterpret_cast<PmRec *>(base + off_rec_b);
 
   int status = -1;
   auto run = [&]() -> int {
@@ -660,26 +828,23 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
     const int grid = static_cast<int>(
         std::min<size_t>(kGrid, (count + kLoads * kThreads - 1) / (static_cast<size_t>(kLoads) * kThreads)));
     const int grid_large = 1024;
-    const int halves = plan ? 1 : 2;  // with a plan only the initial array's (first) half of every table is used
+    const int halves = plan ? 1 : 2;
     hipStream_t s = c.stream;
-    PSH_HIP(hipMemsetAsync(cnt, 0, table_bytes / 2 * halves, s));
+    if (!plan) PSH_HIP(hipMemsetAsync(cnt + kBins, 0, table_bytes / 2, s));  // the target's bucket counts
     hipLaunchKernelGGL(pm_init, dim3(1), dim3(1), 0, s, h);
     hipLaunchKernelGGL(pm_stats, dim3(grid, halves), dim3(kThreads), 0, s, make ? target_dev : initial_dev, target_dev, count,
                        part);
     hipLaunchKernelGGL(pm_prepare, dim3(1), dim3(kThreads), 0, s, h, count, part, grid, plan ? 0 : (make ? 1 : -1),
                        plan ? plan->header() : static_cast<const PmHeader *>(nullptr));
-    if (!make) hipLaunchKernelGGL(pm_hist_initial, dim3(grid), dim3(kThreads), 0, s, initial_dev, count, h, cnt);
-    if (!plan) hipLaunchKernelGGL(pm_hist_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cnt + kBins);
-    hipLaunchKernelGGL(pm_bin_sums, dim3(kScanBlocks, halves), dim3(kThreads), 0, s, cnt, sums);
-    hipLaunchKernelGGL(pm_scan_sums, dim3(halves), dim3(kScanBlocks), 0, s, sums, offs, h);
-    hipLaunchKernelGGL(pm_bin_starts, dim3(kScanBlocks, halves), dim3(kThreads), 0, s, cnt, offs, start, cursor, large,
-                       large_cap, h);
-    if (!plan) {  // target: sorted wet values
+    if (!plan) {  // target: bucket counts, bucket starts, sorted wet values
+      hipLaunchKernelGGL(pm_hist_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cnt + kBins);
+      hipLaunchKernelGGL(pm_bin_sums, dim3(kScanBlocks, 1), dim3(kThreads), 0, s, cnt, sums, 1);
+      hipLaunchKernelGGL(pm_scan_sums, dim3(1), dim3(kScanBlocks), 0, s, sums, offs, h, 1);
+      hipLaunchKernelGGL(pm_bin_starts, dim3(kScanBlocks, 1), dim3(kThreads), 0, s, cnt, offs, start, cursor, large,
+                         large_cap, h, 1);
       hipLaunchKernelGGL(pm_scatter_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cursor + kBins, sval);
-      hipLaunchKernelGGL(pm_rank_small<false>, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, sval, sidx, tw,
-                         out_dev);
-      hipLaunchKernelGGL(pm_rank_large<false>, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large,
-                         large_cap, sval, sidx, tw, out_dev);
+      hipLaunchKernelGGL(pm_rank_small, dim3(grid), dim3(kThreads), 0, s, h, cnt, start, sval, tw);
+      hipLaunchKernelGGL(pm_rank_large, dim3(grid_large), dim3(kThreads), 0, s, h, cnt, start, large, large_cap, sval, tw);
     }
     if (make) {  // keep the header and the sorted values
       PSH_HIP(hipMemcpyAsync(make->blk, h, sizeof(PmHeader), hipMemcpyDeviceToDevice, s));
@@ -688,14 +853,18 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
       status = kStOk;  // the verdict on the target travels in the plan
       return PSH_OK;
     }
+    // initial: two partition passes (LDS atomics only), ranks inside the buckets -> output
+    hipLaunchKernelGGL(pm2_count, dim3(nblk), dim3(kThreads), 0, s, initial_dev, count, h, H, nblk);
+    hipLaunchKernelGGL(pm2_sums, dim3(nsums), dim3(kThreads), 0, s, H, nent, hsums);
+    hipLaunchKernelGGL(pm2_scan_sums, dim3(1), dim3(1024), 0, s, hsums, nsums, h);
+    hipLaunchKernelGGL(pm2_offsets, dim3(nsums), dim3(kThreads), 0, s, H, nent, hsums);
     hipLaunchKernelGGL(pm_threshold, dim3(1), dim3(1), 0, s, h, count, tw);
-    // initial: ranks -> output
-    hipLaunchKernelGGL(pm_scatter_initial, dim3(grid), dim3(kThreads), 0, s, initial_dev, count, h, cursor, sval, sidx,
-                       out_dev);
-    hipLaunchKernelGGL(pm_rank_small<true>, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, sval, sidx, tw,
-                       out_dev);
-    hipLaunchKernelGGL(pm_rank_large<true>, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large,
-                       large_cap, sval, sidx, tw, out_dev);
+    hipLaunchKernelGGL(pm2_scatter, dim3(nblk), dim3(kThreads), 0, s, initial_dev, count, h, H, nblk, rec_a, out_dev);
+    hipLaunchKernelGGL(pm2_refine, dim3(kCoarse), dim3(kRefineThreads), 0, s, h, H, nblk, rec_a, rec_b, cnt, start, large,
+                       large_cap);
+    hipLaunchKernelGGL(pm2_rank_small, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, rec_b, tw, out_dev);
+    hipLaunchKernelGGL(pm2_rank_large, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large, large_cap,
+                       rec_b, tw, out_dev);
     PSH_HIP(hipGetLastError());
     if (status_dev) {  // the caller reads the status later (resident member loop: one wait per time step)
       PSH_HIP(hipMemcpyAsync(status_dev, &h->status, sizeof(int), hipMemcpyDeviceToDevice, s));

@@ -146,3 +146,110 @@ def test_native_greedy_pass_matches_oracle(min_distance, max_corners):
     assert np.array_equal(pts[: count.value], want)
     # argument errors do not touch the device either
     assert lib.psh_lk_greedy_host(keys.ctypes.data, -1, m, n, 10.0, 10, pts.ctypes.data, ctypes.byref(count)) != 0
+
+
+# ---------------------------------------------------------------------------------------------
+# SciPy twins: an independent second implementation of the separable pieces of the OpenCV
+# restatement (cv2 is absent everywhere, so this does not pin the oracle against OpenCV; it removes
+# "one author, one reading" from the morphology, the pyramid, the derivative stencils and the box
+# sums - scipy.ndimage's own border handling and correlation code stand in for the hand-written
+# index arithmetic of oracle/lk_opencv.py).  scipy mode "mirror" = BORDER_REFLECT_101.
+# ---------------------------------------------------------------------------------------------
+from scipy import ndimage as ndi
+
+_CROSS = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], bool)
+
+
+@pytest.mark.parametrize("shape,seed", [((37, 53), 0), ((64, 64), 1), ((5, 9), 2), ((120, 17), 3)])
+def test_morph_opening_equals_scipy_binary_opening(shape, seed):
+    """utils/images.py:58-86 through cv2.morphologyEx(OPEN, 3x3 cross): erosion with the border neutral
+    (border_value=1), dilation with the border neutral (border_value=0)."""
+    rng = np.random.default_rng(seed)
+    img = np.where(rng.random(shape) < 0.45, rng.random(shape) * 30.0, -15.0).astype(np.float32)
+    img[rng.random(shape) < 0.05] = np.nan
+    valid = np.isfinite(img)
+    fill = img[valid].min()
+    got = lk.morph_opening(img, valid, fill)
+    field = np.where(valid, img, fill) > fill
+    eroded = ndi.binary_erosion(field, structure=_CROSS, border_value=1)
+    opened = ndi.binary_dilation(eroded, structure=_CROSS, border_value=0)
+    want = img.copy()
+    want[field & ~opened] = fill
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[valid], want[valid])
+
+
+@pytest.mark.parametrize("size", [1, 2, 3, 5, 6])
+def test_dilate_mask_equals_scipy_binary_dilation(size):
+    """cv2.dilate(mask, ones((size, size))) (shitomasi.py:137), anchor at size // 2: out(y, x) is the maximum over
+    mask(y + i - size // 2, x + j - size // 2), 0 <= i, j < size - for an even size the window reaches one pixel
+    further up / left than down / right.  That is scipy's maximum_filter with its default centre, and
+    binary_dilation (which mirrors the structure) with origin -1 for even sizes."""
+    rng = np.random.default_rng(size)
+    mask = rng.random((40, 33)) < 0.03
+    got = lk.dilate_mask(mask, size)
+    want = ndi.maximum_filter(mask.astype(np.uint8), footprint=np.ones((size, size)), mode="constant") > 0
+    assert np.array_equal(got, want)
+    want2 = ndi.binary_dilation(mask, structure=np.ones((size, size), bool), origin=0 if size % 2 else -1)
+    assert np.array_equal(got, want2)
+    one = np.zeros((9, 9), bool)
+    one[4, 4] = True
+    ys, xs = np.nonzero(lk.dilate_mask(one, size))  # the pixels whose window contains (4, 4)
+    assert ys.min() == 4 - (size - 1 - size // 2) and ys.max() == 4 + size // 2 and xs.min() == ys.min()
+
+
+@pytest.mark.parametrize("shape", [(51, 64), (40, 40), (7, 9), (2, 33)])
+def test_pyr_down_equals_scipy_correlation(shape):
+    """cv::pyrDown 8U: [1 4 6 4 1] x [1 4 6 4 1], BORDER_REFLECT_101, (sum + 128) >> 8, every second pixel."""
+    rng = np.random.default_rng(shape[0])
+    u8 = rng.integers(0, 256, shape, dtype=np.uint8)
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    full = ndi.correlate1d(ndi.correlate1d(u8.astype(np.int64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+    want = ((full[::2, ::2] + 128) >> 8).astype(np.uint8)
+    assert np.array_equal(lk.pyr_down(u8), want)
+
+
+@pytest.mark.parametrize("shape", [(30, 41), (64, 64), (3, 5)])
+def test_scharr_equals_scipy_correlation(shape):
+    """calcSharrDeriv: Ix = [3 10 3]^T x [-1 0 1], Iy = [-1 0 1]^T x [3 10 3], BORDER_REFLECT_101, int16."""
+    rng = np.random.default_rng(shape[1])
+    u8 = rng.integers(0, 256, shape, dtype=np.uint8)
+    a = u8.astype(np.int64)
+    smooth, diff = np.array([3, 10, 3]), np.array([-1, 0, 1])
+    want_x = ndi.correlate1d(ndi.correlate1d(a, smooth, axis=0, mode="mirror"), diff, axis=1, mode="mirror")
+    want_y = ndi.correlate1d(ndi.correlate1d(a, diff, axis=0, mode="mirror"), smooth, axis=1, mode="mirror")
+    ix, iy = lk.scharr_deriv(u8)
+    assert np.array_equal(ix, want_x.astype(np.int16)) and np.array_equal(iy, want_y.astype(np.int16))
+
+
+@pytest.mark.parametrize("block_size", [3, 5, 7])
+def test_corner_min_eigenval_equals_scipy_sobel_and_box(block_size):
+    """cornerMinEigenVal(8U, blockSize, ksize 3): Sobel derivatives scaled by 1 / (4 blockSize 255), products
+    box-summed over blockSize x blockSize (BORDER_REFLECT_101 on the products), smaller eigenvalue.  The twin
+    works in float64 throughout (scipy.ndimage.sobel / uniform_filter): agreement to float32 rounding of the
+    response - the restatement's float32 roundings are what the device has to reproduce, the twin checks the
+    STENCILS, scales and borders."""
+    rng = np.random.default_rng(block_size)
+    g = gaussian_filter(rng.standard_normal((48, 61)), 2.0)
+    u8 = ((g - g.min()) / (g.max() - g.min()) * 255).astype(np.uint8)
+    s = 1.0 / (4.0 * block_size * 255.0)
+    a = u8.astype(np.float64)
+    dx = ndi.sobel(a, axis=1, mode="mirror") * s
+    dy = ndi.sobel(a, axis=0, mode="mirror") * s
+    area = block_size * block_size
+    box = lambda q: ndi.uniform_filter(q, size=block_size, mode="mirror") * area  # noqa: E731
+    cxx, cxy, cyy = box(dx * dx), box(dx * dy), box(dy * dy)
+    want = 0.5 * (cxx + cyy) - np.sqrt((0.5 * (cxx - cyy)) ** 2 + cxy * cxy)
+    got = lk.corner_min_eigenval(u8, block_size).astype(np.float64)
+    scale = np.abs(want).max()
+    assert scale > 0
+    assert np.abs(got - want).max() <= 2e-6 * scale
+
+
+def test_reflect101_equals_numpy_pad_reflect():
+    """_pad_reflect101 against numpy.pad(mode="reflect") (the same border rule, numpy's implementation)."""
+    rng = np.random.default_rng(4)
+    for shape, r in (((5, 7), 3), ((2, 9), 1), ((30, 30), 4)):
+        a = rng.integers(0, 255, shape)
+        if r < min(shape):
+            assert np.array_equal(lk._pad_reflect101(a, r), np.pad(a, r, mode="reflect"))
