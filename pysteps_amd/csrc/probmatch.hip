@@ -493,22 +493,35 @@ __global__ __launch_bounds__(kThreads) void pm_rank_large(PmHeader *h, const uns
 //                block gets a private range inside every coarse segment; wet count
 //   pm2_scatter  the same pixels again: position = LDS cursor of the coarse bucket -> (value, pixel)
 //                records grouped by coarse bucket; the dry pixels get their output here (:127-128)
-//   pm2_refine   one workgroup per coarse segment, streaming it twice from memory: LDS histogram over
-//                its kFine fine buckets, scan, second copy grouped by the full bucket; writes the
-//                count / start tables of its 2^11 buckets and lists the crowded ones
-//   pm2_rank_*   position inside the bucket = number of smaller (value, pixel) pairs -> output
+//   pm2_refine   one workgroup per coarse segment, streaming it from memory: LDS histogram over its kFine
+//                fine buckets, scan, second copy grouped by the full bucket, then the rank of every record
+//                = bucket start + number of smaller (value, pixel) pairs in its bucket -> output
+//   pm2_rank_large  the same for the listed buckets above kSmallBin values, one workgroup each
 // Any distribution is handled (a segment is streamed, not staged: one outlier that squeezes a third
 // of the values into one coarse bucket makes that workgroup slow, not wrong); the limits on TIED or
 // bucket-sharing values are those of pm_rank_large.
-constexpr unsigned kFineBits = 11, kFine = 1u << kFineBits, kCoarse = kBins >> kFineBits;
+constexpr unsigned kCoarseBits = 9, kCoarse = 1u << kCoarseBits;
+constexpr unsigned kFineBits = 12, kFine = 1u << kFineBits;
+constexpr unsigned kBinsI = kCoarse * kFine;  // 2^21 buckets for the initial array: half the crowding of 2^20
 constexpr unsigned kPxBlock = 8192;  // pixels per workgroup of pm2_count / pm2_scatter
 constexpr unsigned kScanChunk = 4096;  // entries of H per workgroup of the scan kernels
 constexpr int kRefineThreads = 1024;
 
+// (value, pixel) of a wet pixel; `tag` is filled in by pm2_refine: position of the record inside its
+// bucket (bits 8..) and the bucket's size - 1 (bits 0..7), or kCrowded for buckets above kSmallBin values -
+// so that the ranking pass finds the bucket's members from the record alone
 struct PmRec {
   double v;
-  unsigned idx, pad;
+  unsigned idx, tag;
 };
+constexpr unsigned kCrowded = 0xffffffffu;
+
+// bucket of the initial array: the header's scale is for kBins buckets, kBinsI is a power of two times that
+__device__ __forceinline__ unsigned bin_i(double v, double z, double scale) {
+#pragma clang fp contract(off)
+  const double f = (v - z) * (scale * static_cast<double>(kBinsI / kBins));
+  return f >= static_cast<double>(kBinsI - 1) ? kBinsI - 1 : static_cast<unsigned>(f);
+}
 
 __global__ __launch_bounds__(kThreads) void pm2_count(const double *__restrict__ a, size_t n,
                                                       const PmHeader *__restrict__ h, unsigned *__restrict__ H,
@@ -528,7 +541,7 @@ __global__ __launch_bounds__(kThreads) void pm2_count(const double *__restrict__
       }
 #pragma unroll
       for (int k = 0; k < kLoads; ++k)
-        if (v[k] > z) atomicAdd(&s_hist[bin_of(v[k], z, scale) >> kFineBits], 1u);  // false for NaN
+        if (v[k] > z) atomicAdd(&s_hist[bin_i(v[k], z, scale) >> kFineBits], 1u);  // false for NaN
     }
   }
   __syncthreads();
@@ -605,7 +618,7 @@ __global__ __launch_bounds__(kThreads) void pm2_scatter(const double *__restrict
     for (int k = 0; k < kLoads; ++k) {
       const size_t i = first + static_cast<size_t>(k0 + k) * kThreads;
       if (v[k] > z) {
-        const unsigned pos = atomicAdd(&s_cur[bin_of(v[k], z, scale) >> kFineBits], 1u);
+        const unsigned pos = atomicAdd(&s_cur[bin_i(v[k], z, scale) >> kFineBits], 1u);
         rec[pos] = PmRec{v[k], static_cast<unsigned>(i), 0u};
       } else if (i < n) {
         out[i] = z_trg;
@@ -616,80 +629,113 @@ __global__ __launch_bounds__(kThreads) void pm2_scatter(const double *__restrict
 
 __global__ __launch_bounds__(kRefineThreads) void pm2_refine(PmHeader *h, const unsigned *__restrict__ H, unsigned nblk,
                                                              const PmRec *__restrict__ rec_in, PmRec *__restrict__ rec_out,
-                                                             unsigned *__restrict__ count, unsigned *__restrict__ start,
-                                                             unsigned *large, unsigned large_cap) {
-  __shared__ unsigned s_cnt[kFine], s_pos[kFine];
+                                                             uint2 *large, unsigned large_cap) {
+  __shared__ unsigned s_cnt[kFine], s_start[kFine], s_cur[kFine];
   __shared__ unsigned s_wave[kRefineThreads / 64];
   if (h->status != kStOk) return;
   const unsigned c = blockIdx.x;
   const double z = h->z[0], scale = h->scale[0];
   const unsigned seg0 = H[static_cast<size_t>(c) * nblk];
   const unsigned seg1 = c + 1 < kCoarse ? H[static_cast<size_t>(c + 1) * nblk] : h->wet[0];
-  for (unsigned f = threadIdx.x; f < kFine; f += kRefineThreads) s_cnt[f] = 0u;
-  __syncthreads();
-  for (unsigned e = seg0 + threadIdx.x; e < seg1; e += kRefineThreads)
-    atomicAdd(&s_cnt[bin_of(rec_in[e].v, z, scale) & (kFine - 1)], 1u);
-  __syncthreads();
-  // exclusive scan of the fine counts (two per thread), tables of the segment's buckets
-  static_assert(kFine == 2 * kRefineThreads, "two fine buckets per thread");
-  const unsigned c0 = s_cnt[2 * threadIdx.x], c1 = s_cnt[2 * threadIdx.x + 1];
-  unsigned total;
-  const unsigned incl = block_incl_scan<kRefineThreads / 64>(c0 + c1, s_wave, &total);
-  const unsigned st0 = seg0 + incl - (c0 + c1), st1 = st0 + c0;
-  s_pos[2 * threadIdx.x] = st0;
-  s_pos[2 * threadIdx.x + 1] = st1;
-  const size_t b0 = static_cast<size_t>(c) * kFine + 2 * threadIdx.x;
-  *reinterpret_cast<uint2 *>(count + b0) = make_uint2(c0, c1);
-  *reinterpret_cast<uint2 *>(start + b0) = make_uint2(st0, st1);
-  const unsigned cs[2] = {c0, c1};
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    if (cs[k] > kSmallBin) {
-      const unsigned at = atomicAdd(&h->n_large[0], 1u);
-      if (at < large_cap) large[at] = static_cast<unsigned>(b0) + k;
-      atomicMax(&h->max_bin[0], cs[k]);
-    }
+  for (unsigned f = threadIdx.x; f < kFine; f += kRefineThreads) {
+    s_cnt[f] = 0u;
+    s_cur[f] = 0u;
   }
   __syncthreads();
-  for (unsigned e = seg0 + threadIdx.x; e < seg1; e += kRefineThreads) {
-    const PmRec r = rec_in[e];
-    rec_out[atomicAdd(&s_pos[bin_of(r.v, z, scale) & (kFine - 1)], 1u)] = r;
+  constexpr unsigned kFly = 4;  // records in flight per thread (a workgroup streams its segment at memory latency)
+  for (unsigned e0 = seg0 + threadIdx.x; e0 < seg1; e0 += kFly * kRefineThreads) {
+    double v[kFly];
+#pragma unroll
+    for (unsigned k = 0; k < kFly; ++k) v[k] = e0 + k * kRefineThreads < seg1 ? rec_in[e0 + k * kRefineThreads].v : 0.0;
+#pragma unroll
+    for (unsigned k = 0; k < kFly; ++k)
+      if (e0 + k * kRefineThreads < seg1) atomicAdd(&s_cnt[bin_i(v[k], z, scale) & (kFine - 1)], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the fine counts (kPer per thread); the crowded buckets are listed with their range
+  constexpr unsigned kPer = kFine / kRefineThreads;
+  unsigned cs[kPer], mine = 0;
+#pragma unroll
+  for (unsigned k = 0; k < kPer; ++k) {
+    cs[k] = s_cnt[kPer * threadIdx.x + k];
+    mine += cs[k];
+  }
+  unsigned total;
+  const unsigned incl = block_incl_scan<kRefineThreads / 64>(mine, s_wave, &total);
+  unsigned run = seg0 + incl - mine;
+#pragma unroll
+  for (unsigned k = 0; k < kPer; ++k) {
+    s_start[kPer * threadIdx.x + k] = run;
+    if (cs[k] > kSmallBin) {
+      const unsigned at = atomicAdd(&h->n_large[0], 1u);
+      if (at < large_cap) large[at] = make_uint2(run, cs[k]);
+      atomicMax(&h->max_bin[0], cs[k]);
+    }
+    run += cs[k];
+  }
+  __syncthreads();
+  for (unsigned e0 = seg0 + threadIdx.x; e0 < seg1; e0 += kFly * kRefineThreads) {
+    PmRec r[kFly];
+#pragma unroll
+    for (unsigned k = 0; k < kFly; ++k)
+      r[k] = e0 + k * kRefineThreads < seg1 ? rec_in[e0 + k * kRefineThreads] : PmRec{0.0, 0u, 0u};
+#pragma unroll
+    for (unsigned k = 0; k < kFly; ++k) {
+      if (e0 + k * kRefineThreads < seg1) {
+        const unsigned f = bin_i(r[k].v, z, scale) & (kFine - 1);
+        const unsigned at = atomicAdd(&s_cur[f], 1u), cnt = s_cnt[f];
+        r[k].tag = cnt > kSmallBin ? kCrowded : ((at << 8) | (cnt - 1u));
+        rec_out[s_start[f] + at] = r[k];
+      }
+    }
   }
 }
 
-// pm_rank_small<true> / pm_rank_large<true> on records
+// position inside the bucket = number of smaller (value, pixel) pairs; the bucket's members are found
+// from the record's tag.  Two records per thread side by side: the kernel is a chain of dependent loads
+// (record -> bucket members), a second chain fills the waiting time of the first.
 __global__ __launch_bounds__(kThreads) void pm2_rank_small(const PmHeader *__restrict__ h, size_t n,
-                                                           const unsigned *__restrict__ count,
-                                                           const unsigned *__restrict__ start,
                                                            const PmRec *__restrict__ rec, const double *__restrict__ tw,
                                                            double *__restrict__ out) {
   if (h->status != kStOk) return;
-  const double z = h->z[0], scale = h->scale[0];
   const unsigned wet = h->wet[0];
   const unsigned stride = gridDim.x * kThreads;
-  for (unsigned s = blockIdx.x * kThreads + threadIdx.x; s < wet; s += stride) {
-    const PmRec me = rec[s];
-    const unsigned b = bin_of(me.v, z, scale), c = count[b];
-    if (c > kSmallBin) continue;  // pm2_rank_large
-    const unsigned st = start[b];
-    unsigned less = 0;
-    for (unsigned j = st; j < st + c; ++j) {
-      const PmRec o = rec[j];
-      less += (o.v < me.v || (o.v == me.v && o.idx < me.idx)) ? 1u : 0u;
+  for (unsigned s0 = blockIdx.x * kThreads + threadIdx.x; s0 < wet; s0 += 2 * stride) {
+    const unsigned s1 = s0 + stride;
+    const bool two = s1 < wet;
+    const PmRec me0 = rec[s0], me1 = rec[two ? s1 : s0];
+    const unsigned n0 = me0.tag == kCrowded ? 0u : (me0.tag & 0xffu) + 1u;  // crowded buckets: pm2_rank_large
+    const unsigned n1 = (!two || me1.tag == kCrowded) ? 0u : (me1.tag & 0xffu) + 1u;
+    const unsigned st0 = s0 - (me0.tag >> 8), st1 = s1 - (me1.tag >> 8);
+    unsigned less0 = 0, less1 = 0;
+    const unsigned both = n0 < n1 ? n0 : n1;
+    unsigned j = 0;
+    for (; j < both; ++j) {
+      const PmRec o0 = rec[st0 + j], o1 = rec[st1 + j];
+      less0 += (o0.v < me0.v || (o0.v == me0.v && o0.idx < me0.idx)) ? 1u : 0u;
+      less1 += (o1.v < me1.v || (o1.v == me1.v && o1.idx < me1.idx)) ? 1u : 0u;
     }
-    pm_emit(h, n, tw, out, me.idx, st + less);
+    for (unsigned q = j; q < n0; ++q) {
+      const PmRec o = rec[st0 + q];
+      less0 += (o.v < me0.v || (o.v == me0.v && o.idx < me0.idx)) ? 1u : 0u;
+    }
+    for (unsigned q = j; q < n1; ++q) {
+      const PmRec o = rec[st1 + q];
+      less1 += (o.v < me1.v || (o.v == me1.v && o.idx < me1.idx)) ? 1u : 0u;
+    }
+    if (n0) pm_emit(h, n, tw, out, me0.idx, st0 + less0);
+    if (n1) pm_emit(h, n, tw, out, me1.idx, st1 + less1);
   }
 }
 
-__global__ __launch_bounds__(kThreads) void pm2_rank_large(PmHeader *h, size_t n, const unsigned *__restrict__ count,
-                                                           const unsigned *__restrict__ start,
-                                                           const unsigned *__restrict__ large, unsigned large_cap,
-                                                           const PmRec *__restrict__ rec, const double *__restrict__ tw,
-                                                           double *__restrict__ out) {
+// the crowded buckets (more than kSmallBin values), one workgroup each
+__global__ __launch_bounds__(kThreads) void pm2_rank_large(PmHeader *h, size_t n, const uint2 *__restrict__ large,
+                                                           unsigned large_cap, const PmRec *__restrict__ rec,
+                                                           const double *__restrict__ tw, double *__restrict__ out) {
   if (h->status != kStOk) return;
   const unsigned n_large = h->n_large[0] < large_cap ? h->n_large[0] : large_cap;
   for (unsigned li = blockIdx.x; li < n_large; li += gridDim.x) {
-    const unsigned b = large[li], c = count[b], st = start[b];
+    const unsigned st = large[li].x, c = large[li].y;
     if (c > kLargeLimit) {
       if (threadIdx.x == 0) atomicExch(&h->status, kStTies);
       continue;
@@ -793,7 +839,7 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
   const size_t off_count = off_part + part_bytes, off_start = off_count + table_bytes, off_cursor = off_start + table_bytes;
   const size_t off_sums = off_cursor + table_bytes, off_offs = off_sums + 2 * kScanBlocks * sizeof(unsigned);
   const size_t off_large = off_offs + 2 * kScanBlocks * sizeof(unsigned);
-  const size_t off_sval = up(off_large + 2 * static_cast<size_t>(large_cap) * sizeof(unsigned));
+  const size_t off_sval = up(off_large + 3 * static_cast<size_t>(large_cap) * sizeof(unsigned));
   const size_t off_tw = up(off_sval + (plan ? 0 : count * sizeof(double)));
   const unsigned nblk = static_cast<unsigned>((count + kPxBlock - 1) / kPxBlock);
   const size_t nent = static_cast<size_t>(kCoarse) * nblk;
@@ -814,7 +860,9 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
   unsigned *cursor = reinterpret_cast<unsigned *>(base + off_cursor);
   unsigned *sums = reinterpret_cast<unsigned *>(base + off_sums);
   unsigned *offs = reinterpret_cast<unsigned *>(base + off_offs);
-  unsigned *large = reinterpret_cast<unsigned *>(base + off_large);
+  // (crowded buckets - target: bucket numbers in the second half; initial: (start, count) pairs - 2 x large_cap words each)
+  unsigned *large = reinterpret_cast<unsigned *>(base + off_large) + large_cap;
+  uint2 *large2 = reinterpret_cast<uint2 *>(base + off_large);
   double *sval = reinterpret_cast<double *>(base + off_sval);
   double *tw = plan ? const_cast<double *>(plan->tw()) : reinterpret_cast<double *>(base + off_tw);
   unsigned *H = reinterpret_cast<unsigned *>(base + off_h);
@@ -860,11 +908,10 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
     hipLaunchKernelGGL(pm2_offsets, dim3(nsums), dim3(kThreads), 0, s, H, nent, hsums);
     hipLaunchKernelGGL(pm_threshold, dim3(1), dim3(1), 0, s, h, count, tw);
     hipLaunchKernelGGL(pm2_scatter, dim3(nblk), dim3(kThreads), 0, s, initial_dev, count, h, H, nblk, rec_a, out_dev);
-    hipLaunchKernelGGL(pm2_refine, dim3(kCoarse), dim3(kRefineThreads), 0, s, h, H, nblk, rec_a, rec_b, cnt, start, large,
-                       large_cap);
-    hipLaunchKernelGGL(pm2_rank_small, dim3(grid), dim3(kThreads), 0, s, h, count, cnt, start, rec_b, tw, out_dev);
-    hipLaunchKernelGGL(pm2_rank_large, dim3(grid_large), dim3(kThreads), 0, s, h, count, cnt, start, large, large_cap,
-                       rec_b, tw, out_dev);
+    hipLaunchKernelGGL(pm2_refine, dim3(kCoarse), dim3(kRefineThreads), 0, s, h, H, nblk, rec_a, rec_b, large2, large_cap);
+    hipLaunchKernelGGL(pm2_rank_small, dim3(grid), dim3(kThreads), 0, s, h, count, rec_b, tw, out_dev);
+    hipLaunchKernelGGL(pm2_rank_large, dim3(grid_large), dim3(kThreads), 0, s, h, count, large2, large_cap, rec_b, tw,
+                       out_dev);
     PSH_HIP(hipGetLastError());
     if (status_dev) {  // the caller reads the status later (resident member loop: one wait per time step)
       PSH_HIP(hipMemcpyAsync(status_dev, &h->status, sizeof(int), hipMemcpyDeviceToDevice, s));
