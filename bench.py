@@ -259,11 +259,11 @@ LK_PASS_BYTES = {
     "lk_stats1": (4.0, "frame read"),
     "lk_open_bits": (8.0, "frame read + cleaned frame written"),
     "lk_to_u8": (5.5, "cleaned frame read + tracking rendering written (+ feature rendering for the first frame of a pair)"),
-    "lk_corner_response": (5.0, "uint8 rendering read + float32 response written"),
+    "lk_corner_response_cols": (5.0, "uint8 rendering read + float32 response written"),
     "lk_corner_select": (4.0, "response read"),
     "lk_pyrdown": (1.25 * 1.333, "per frame: every level read once, the next one written (geometric series)"),
 }
-LK_CALLS_PER_PAIR = {"lk_stats1": 2, "lk_open_bits": 2, "lk_to_u8": 2, "lk_corner_response": 1, "lk_corner_select": 1,
+LK_CALLS_PER_PAIR = {"lk_stats1": 2, "lk_open_bits": 2, "lk_to_u8": 2, "lk_corner_response_cols": 1, "lk_corner_select": 1,
                      "lk_pyrdown": 2}
 
 
@@ -271,9 +271,10 @@ def roofline_lk(frames_d, m, n, pairs):
     """Second-tier rooflines of the motion estimate from the committed rocprofv3 summaries of
     the SAME workload (profiles/kernel_stats_latest.json, written by tools/collect_profiles.py from the
     kernel trace and the PMC passes): the streaming image passes against HBM, each with its own
-    algorithmic bytes; the VALU-bound kernels (idw_fine, lk_corner_response) by the share of the
-    chip's VALU issue slots their instructions take (SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel
-    cycles)) - a work model in flops would price what the kernel (rightly) does not execute."""
+    algorithmic bytes; the VALU-bound kernels (idw_fine3, lk_corner_response_cols) by the share of the
+    chip's VALU issue slots their instructions take (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel
+    cycles); 4 cycles per wave64 instruction measured, profiles/r04/a_valu_probe.txt) - a work model in
+    flops would price what the kernel (rightly) does not execute."""
     path = os.path.join(ROOT, "profiles", "kernel_stats_latest.json")
     try:
         with open(path) as fh:
@@ -302,17 +303,17 @@ def roofline_lk(frames_d, m, n, pairs):
                                "alg_bytes_per_step": total_bytes, "achieved": total_bytes / (total_ns * 1e-9) / 1e9,
                                "frac": total_bytes / (total_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, "per_kernel": passes}
     valu = {}
-    for name in ("idw_fine", "idw_coarse", "lk_corner_response", "lk_track_rows", "outliers_local"):
+    for name in ("idw_fine3", "idw_coarse", "lk_corner_response_cols", "lk_track_rows", "outliers_local"):
         c = counters.get(name)
         if not c or "SQ_INSTS_VALU" not in c or "GRBM_GUI_ACTIVE" not in c:
             continue
         cycles = c["GRBM_GUI_ACTIVE"] / 8.0  # the counter adds the 8 XCDs up
         valu[name] = {"kernel_ms": kern.get(name, {}).get("avg_ns", 0.0) / 1e6, "valu_insts_per_launch": c["SQ_INSTS_VALU"],
-                      "kernel_cycles": cycles, "valu_issue_frac": c["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cycles)}
+                      "kernel_cycles": cycles, "valu_issue_frac": c["SQ_INSTS_VALU"] * 4.0 / (N_SIMD * cycles)}
     if valu:
-        out["valu_bound"] = {"bound": "valu issue", "definition": "SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); "
-                             "float64 and transcendental instructions take more than 2 cycles, so this is a lower bound of "
-                             "the VALU busy share", "per_kernel": valu}
+        out["valu_bound"] = {"bound": "valu issue", "definition": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); "
+                             "a wave64 VALU instruction occupies its SIMD for 4 cycles whatever its type (fp32, fp64, packed, DPP), "
+                             "transcendentals for 8 (profiles/r04/a_valu_probe.txt): a lower bound of the VALU busy share", "per_kernel": valu}
     return out
 
 
@@ -565,12 +566,13 @@ def spectral_leg(m, n):
         synchronize()
         pm_ms = e5.elapsed_ms(e6) / reps
         out["probmatch_cdf_ms"] = pm_ms
-        # bound by the rate of device-scope atomics, not by bytes: one atomic per wet pixel of the
-        # forecast in the histogram, one with a returned value in the scatter; the observation's go through LDS tables
-        wet = 0.25 * m * n
-        out["probmatch_bound"] = {"bound": "device-scope atomics", "atomics_per_call": 2.0 * wet,
-                                  "atomics_per_us": 2.0 * wet / (pm_ms * 1e3),
-                                  "min_bytes_per_call": 24.0 * m * n, "hbm_frac_of_min_bytes": 24.0 * m * n / (pm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # round 4: the forecast's side runs without device-scope atomics (two partition passes with LDS histograms,
+        # DESIGN.md 3.8); what bounds it now is bytes - the wet pixels travel as 16-byte records through two
+        # scatters and the ranked values go back to their pixels as scattered 8-byte stores
+        out["probmatch_bound"] = {"bound": "hbm", "min_bytes_per_call": 24.0 * m * n,
+                                  "hbm_frac_of_min_bytes": 24.0 * m * n / (pm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "min bytes: forecast read, observation read, result written once (8 B each per pixel); "
+                                          "this call also ranks the observation - the member loop keeps that in a plan"}
     except Exception as exc:
         out["probmatch_note"] = "%s: %s" % (type(exc).__name__, exc)
     return out
@@ -598,6 +600,24 @@ def steps_loop_leg(precip_d, vel_d, members, T, K, dist, with_stock):
                 "ms_per_member_update": (resident_s * 1e3 - adv_ms * T) / (members * (T + 1)),
                 "advection_ms_per_leadtime": adv_ms, "value": members * m * n * T / resident_s / 1e6,
                 "unit": "Mpx*leadsteps/s", "note": "state resident in HBM, results stay on the device"})
+    # roofline of the member update (HBM): algorithmic bytes = every array of the update read or written once
+    # per stage that has to see it whole - L (p + 1) half spectra of the AR history, white field, noise
+    # spectrum, recomposed spectrum, field, masked field (each written + read), matched field written, mask
+    # read + written: 8 (L (p + 1) + 13) B per pixel; `traffic` is the PMC measurement
+    levels, order = int(info["cascade_levels"]), int(info["ar_order"])
+    alg = 8.0 * (levels * (order + 1) + 13) * m * n
+    upd_s = out["ms_per_member_update"] * 1e-3
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "member_update_traffic.json")) as fh:
+            rec = json.load(fh)
+        if rec.get("workload", "").startswith("%dx%d" % (m, n)):
+            traffic = rec["hbm_bytes_per_member_update"]
+    except Exception:
+        pass
+    out["roofline"] = {"kernel": "member update (all kernels of one update)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                       "alg_bytes_per_member_update": alg, "achieved": alg / upd_s / 1e9, "frac": alg / upd_s / 1e9 / HBM_PEAK_GBS,
+                       "traffic": traffic, "hbm_frac": (traffic / upd_s / 1e9 / HBM_PEAK_GBS) if traffic else None}
     del step
     e2e = None
     try:

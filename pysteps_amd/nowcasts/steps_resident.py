@@ -105,6 +105,17 @@ def try_create(func, state, params, shape, n_updates):
         return ResidentSteps(state, params, shape, n_updates)
     except _Declined:
         return None
+    except (RuntimeError, MemoryError, ValueError) as exc:
+        # the device could not take the state (out of memory, a random generator the device streams do not
+        # reproduce, a HIP error while uploading): whatever was allocated is released with the half-built
+        # object and the reference's own update runs - a nowcast never fails because the fast path declined late
+        import gc
+        import warnings
+
+        gc.collect()
+        warnings.warn("pysteps_amd: the resident STEPS update is not used (%s: %s); the reference's update runs"
+                      % (type(exc).__name__, exc), RuntimeWarning, stacklevel=2)
+        return None
 
 
 class _Declined(Exception):
@@ -160,6 +171,37 @@ class ResidentSteps:
             if not decomp[j].get("normalized", False) or decomp[j].get("domain") != "spatial":
                 raise _Declined
 
+        # ---- every option that can still decline is looked at BEFORE anything is allocated or uploaded ----
+        if p["mask_method"] == "incremental":
+            masks = state.get("mask_prec")
+            struct = np.asarray(p.get("struct")) if p.get("struct") is not None else None
+            rim = p.get("mask_rim")
+            if (masks is None or struct is None or struct.ndim != 2 or rim is None or not 0 <= int(rim) <= 254
+                    or int((struct != 0).sum()) > 1024 or p["precip_thr"] is None):
+                raise _Declined
+            if isinstance(masks, DeviceArray):
+                if masks.shape != (self.B, m, n) or masks.dtype != np.float64:
+                    raise _Declined
+            elif len(masks) != self.B or any(np.shape(mk) != (m, n) for mk in masks):
+                raise _Declined
+        elif p["mask_method"] == "obs":
+            if state.get("mask_prec") is None or np.shape(state["mask_prec"]) != (m, n):
+                raise _Declined
+        elif p["mask_method"] == "sprog":
+            det, det_d = state.get("precip_m"), state.get("precip_m_d")
+            if (det is None or not isinstance(det_d, dict) or len(det) != self.L
+                    or any(np.shape(c) != (phi.shape[1] - 1, m, n) for c in det)
+                    or not det_d.get("normalized", False) or det_d.get("domain") != "spatial" or p.get("war") is None
+                    or _percentile_index(m * n, float(p["war"])) is None):
+                raise _Declined
+        if p["probmatching_method"] == "cdf":
+            tgt = p["precip"]
+            if tgt is None or (isinstance(tgt, DeviceArray) and (tgt.shape != (m, n) or tgt.dtype != np.float64)) \
+                    or (not isinstance(tgt, DeviceArray) and np.shape(tgt) != (m, n)):
+                raise _Declined
+        elif p["probmatching_method"] == "mean" and p.get("mu_0") is None:
+            raise _Declined
+
         self._lib = _lib.lib()
         self.m, self.n, self.plane = m, n, m * n
         self.params, self.state = p, state
@@ -170,8 +212,37 @@ class ResidentSteps:
         self.sigma = [np.ascontiguousarray(decomp[j]["stds"], dtype=np.float64) for j in range(self.B)]
         self.weights = _device_weights(weights)
         self.noise_filter = _device_weights(F["field"])
-        # AR history: (B, L, p, m, n); slot s of the ring holds x[s] of the reference's series at start
-        if resident_cascades:
+        # The AR history as SPECTRA (default): the update is linear between the white noise and the recomposed
+        # field apart from two standardisations that need second moments only (Parseval) - two transforms per
+        # member update instead of nine (csrc/steps_loop.hip).  PYSTEPS_HIP_RESIDENT_DOMAIN=spatial keeps the
+        # level fields and the chain of the reference's spatial operators (bit-identical element-wise part).
+        self.spectral = (os.environ.get("PYSTEPS_HIP_RESIDENT_DOMAIN", "spectral") != "spatial"
+                         and _self_conjugate_columns_symmetric(weights, n) and _self_conjugate_columns_symmetric(F["field"], n))
+        nc = n // 2 + 1
+        # AR history: (B, L, p, m, n); slot s of the ring holds x[s] of the reference's series at start.  With the
+        # spectral form a level field only passes through ONE staging plane on its way to its spectrum: the
+        # device never holds the spatial history and its spectra together (8 B L p m n bytes less at the peak).
+        if self.spectral:
+            spectra = DeviceArray((self.B, self.L, self.p, m, nc), np.complex128)
+            stage = None if resident_cascades else DeviceArray((m, n), np.float64)
+            for j in range(self.B):
+                for k in range(self.L):
+                    for slot in range(self.p):
+                        q = (j * self.L + k) * self.p + slot
+                        if resident_cascades:
+                            src_ptr = cascades.ptr + q * self.plane * 8
+                        else:
+                            src = np.ascontiguousarray(cascades[j][k][slot], dtype=np.float64)
+                            _lib.check(self._lib.psh_memcpy_h2d(stage.ptr, src.ctypes.data, src.nbytes), "h2d")
+                            src_ptr = stage.ptr
+                        _lib.check(self._lib.psh_fft_rfft2_dev(src_ptr, m, n, spectra.ptr + q * m * nc * 16), "psh_fft_rfft2_dev")
+                        if not resident_cascades:
+                            _lib.check(self._lib.psh_sync(), "sync")  # `src` and the staging plane are reused
+            self.cascades = spectra  # (the level fields are not kept)
+            self.noise_spec = DeviceArray((m, nc), np.complex128)
+            self.field_spec = DeviceArray((m, nc), np.complex128)
+            self.level_sums = DeviceArray((16,), np.float64)
+        elif resident_cascades:
             self.cascades = cascades
         else:
             self.cascades = DeviceArray((self.B, self.L, self.p, m, n), np.float64)
@@ -181,22 +252,6 @@ class ResidentSteps:
                     src = np.ascontiguousarray(cascades[j][k], dtype=np.float64)
                     _lib.check(self._lib.psh_memcpy_h2d(self.cascades.ptr + (j * self.L + k) * stride, src.ctypes.data, src.nbytes), "h2d")
             _lib.check(self._lib.psh_sync(), "sync")
-        # The AR history as SPECTRA (default): the update is linear between the white noise and the recomposed
-        # field apart from two standardisations that need second moments only (Parseval) - two transforms per
-        # member update instead of nine (csrc/steps_loop.hip).  PYSTEPS_HIP_RESIDENT_DOMAIN=spatial keeps the
-        # level fields and the chain of the reference's spatial operators (bit-identical element-wise part).
-        self.spectral = (os.environ.get("PYSTEPS_HIP_RESIDENT_DOMAIN", "spectral") != "spatial"
-                         and _self_conjugate_columns_symmetric(weights, n) and _self_conjugate_columns_symmetric(F["field"], n))
-        if self.spectral:
-            nc = n // 2 + 1
-            spectra = DeviceArray((self.B, self.L, self.p, m, nc), np.complex128)
-            for q in range(self.B * self.L * self.p):
-                _lib.check(self._lib.psh_fft_rfft2_dev(self.cascades.ptr + q * self.plane * 8, m, n, spectra.ptr + q * m * nc * 16),
-                           "psh_fft_rfft2_dev")
-            self.cascades = spectra  # (the level fields are not kept)
-            self.noise_spec = DeviceArray((m, nc), np.complex128)
-            self.field_spec = DeviceArray((m, nc), np.complex128)
-            self.level_sums = DeviceArray((16,), np.float64)
         self.head = 0  # slot of the oldest entry
         self.thr = float(p["precip_thr"]) if p["precip_thr"] is not None else None
         self.mask_method, self.pm_method = p["mask_method"], p["probmatching_method"]

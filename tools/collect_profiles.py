@@ -18,17 +18,25 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
 # per-kernel averages of the traced bench run (5 timed + 2 warm-up steps) for bench.py's roofline_lk
 STEPS_TRACED = 7
 for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
-    table = {}
+    # keyed by the kernel's base name AND, for templates, by every instantiation (round 3 mixed the one-step
+    # input synthesis launch of semilag_fused<..., 0, ...> into the averages of the 24-lead-time kernel);
+    # the base-name entry of a template is its instantiation with the largest total time
+    table, inst = {}, {}
     for r in csv.DictReader(open(f)):
-        name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].split("::")[-1].strip()
-        if name.startswith("void "):
-            name = name[5:]
-        rec = table.setdefault(name, {"calls": 0, "total_ns": 0.0})
-        rec["calls"] += int(r["Calls"])
-        rec["total_ns"] += float(r["TotalDurationNs"])
-    for rec in table.values():
+        full = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("psh::", "").strip()
+        if full.startswith("void "):
+            full = full[5:]
+        rec = {"calls": int(r["Calls"]), "total_ns": float(r["TotalDurationNs"])}
         rec["avg_ns"] = rec["total_ns"] / max(rec["calls"], 1)
         rec["ns_per_step"] = rec["total_ns"] / STEPS_TRACED
+        inst[full] = rec
+    for full, rec in inst.items():
+        base = full.split("<")[0]
+        if base not in table or rec["total_ns"] > table[base]["total_ns"]:
+            table[base] = dict(rec, instantiation=full)
+    for full, rec in inst.items():
+        if "<" in full:
+            table[full] = rec
     # per-kernel counters of the PMC passes of the same command (tools/pmc_passes.sh summary), if taken
     counters, counter_source = {}, None
     summary = os.path.join(src, "pmc", "summary.csv")
@@ -36,10 +44,13 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
         for line in list(open(summary))[1:]:
             # kernel names carry commas (template arguments): the two last fields are counter and value
             kernel, counter, value = line.rstrip("\n").rsplit(",", 2)
-            k, counter = kernel.split("<")[0].strip(), counter.replace("_sum", "")
-            if k in counters and counter in counters[k]:
-                continue  # first instantiation listed wins (the one the bench step runs)
-            counters.setdefault(k, {})[counter] = float(value)
+            kernel, counter = kernel.strip(), counter.replace("_sum", "")
+            counters.setdefault(kernel, {})[counter] = float(value)  # per instantiation (names cut at 40 characters)
+        for k in list(counters):
+            base = k.split("<")[0]
+            chosen = table.get(base, {}).get("instantiation", base)[:40]
+            if "<" in k and k == chosen:
+                counters[base] = dict(counters[k])  # the base name carries its dominant instantiation's counters
         shutil.copy(summary, os.path.join(dst, "%s_pmc_kernels.csv" % prefix))
         counter_source = "profiles/%s/%s_pmc_kernels.csv" % (rnd, prefix)
     json.dump({"source": "profiles/%s/%s_rocprofv3_kernel_stats.csv" % (rnd, prefix), "steps_traced": STEPS_TRACED,
