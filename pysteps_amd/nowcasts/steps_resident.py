@@ -461,6 +461,28 @@ class ResidentSteps:
         self._release_plan()
         self.cascades = self.eps = self.white = self.grey = None
 
+    def abort(self):
+        """The loop ended by an exception: join the generators' own stream BEFORE the noise buffers go back to
+        the block cache (a queued draw may still be writing them: a later allocation of that size would receive
+        a buffer that is being filled), hand the host generators their streams back if the device still
+        answers, release the device state.  Never raises."""
+        try:
+            if getattr(self, "rng", None) is not None:
+                try:
+                    self.rng.wait()
+                    _lib.check(self._lib.psh_sync(), "psh_sync")
+                    self.rng.sync_back()
+                except Exception:
+                    pass
+                self.rng.close()  # (waits for the generators' stream)
+        except Exception:
+            pass
+        try:
+            self._release_plan()
+        except Exception:
+            pass
+        self.cascades = self.eps = self.white = self.grey = None
+
     def _release_plan(self):
         if getattr(self, "pm_plan", None):
             self._lib.psh_probmatch_plan_destroy(self.pm_plan)

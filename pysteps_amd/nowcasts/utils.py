@@ -349,51 +349,59 @@ def nowcast_main_loop(precip, velocity, state, timesteps, extrap_method, func, e
                 timeline.mark("result_block")
     out_index = 0
     t_prev = t_total = 0.0
-    for t, subtimesteps, announce in plan:
-        if announce:
-            print(f"Computing nowcast for time step {t}... ", end="", flush=True)
-            step_started = time.time()
-        if resident is not None:
-            new = resident.update()
-            timeline.mark("update")
-        else:
-            new, state = func(state, params)
-            if not ensemble:
-                new = new[np.newaxis, :]
-        for t_sub in subtimesteps:
-            if not t_sub > 0:
-                continue
-            w = t_sub - int(t_sub)  # linear interpolation between the integer-step fields (:419-427)
-            if resident is not None and w > 0.0:
-                if not isinstance(prev, DeviceArray):
-                    prev = DeviceArray.from_host(np.ascontiguousarray(prev, dtype=np.float64))
-                fields = DeviceArray(new.shape, np.float64)
-                _lib.check(_lib.lib().psh_lerp_dev(prev.ptr, new.ptr, float(w), fields.ptr, new.size), "psh_lerp_dev")
+    try:
+        for t, subtimesteps, announce in plan:
+            if announce:
+                print(f"Computing nowcast for time step {t}... ", end="", flush=True)
+                step_started = time.time()
+            if resident is not None:
+                new = resident.update()
+                timeline.mark("update")
             else:
-                fields = (1.0 - w) * prev + w * new if w > 0.0 else prev
-            dt = t_sub - t_prev
-            t_total += dt
-            if block is not None:
-                advected = engine.advect(fields, fields.shape[0], dt, t_total, sink=block[:, out_index])
-                out_index += 1
+                new, state = func(state, params)
+                if not ensemble:
+                    new = new[np.newaxis, :]
+            for t_sub in subtimesteps:
+                if not t_sub > 0:
+                    continue
+                w = t_sub - int(t_sub)  # linear interpolation between the integer-step fields (:419-427)
+                if resident is not None and w > 0.0:
+                    if not isinstance(prev, DeviceArray):
+                        prev = DeviceArray.from_host(np.ascontiguousarray(prev, dtype=np.float64))
+                    fields = DeviceArray(new.shape, np.float64)
+                    _lib.check(_lib.lib().psh_lerp_dev(prev.ptr, new.ptr, float(w), fields.ptr, new.size), "psh_lerp_dev")
+                else:
+                    fields = (1.0 - w) * prev + w * new if w > 0.0 else prev
+                dt = t_sub - t_prev
+                t_total += dt
+                if block is not None:
+                    advected = engine.advect(fields, fields.shape[0], dt, t_total, sink=block[:, out_index])
+                    out_index += 1
+                    if callback is not None:
+                        _lib.check(_lib.lib().psh_sync(), "psh_sync")
+                else:
+                    advected = engine.advect(fields, fields.shape[0], dt, t_total)
+                    if return_output:
+                        for j, a in enumerate(advected):
+                            outputs[j].append(a)
                 if callback is not None:
-                    _lib.check(_lib.lib().psh_sync(), "psh_sync")
-            else:
-                advected = engine.advect(fields, fields.shape[0], dt, t_total)
-                if return_output:
-                    for j, a in enumerate(advected):
-                        outputs[j].append(a)
-            if callback is not None:
-                callback(np.stack(advected))
-            t_prev = t_sub
-        if not subtimesteps:  # no lead time in this bin: displacement only, up to the next integer step
-            dt = t + 1 - t_prev
-            t_total += dt
-            engine.advect(None, new.shape[0], dt, t_total)
-            t_prev = t + 1
-        prev = new
-        if announce:
-            print(f"{time.time() - step_started:.2f} seconds." if measure_time else "done.")
+                    callback(np.stack(advected))
+                t_prev = t_sub
+            if not subtimesteps:  # no lead time in this bin: displacement only, up to the next integer step
+                dt = t + 1 - t_prev
+                t_total += dt
+                engine.advect(None, new.shape[0], dt, t_total)
+                t_prev = t + 1
+            prev = new
+            if announce:
+                print(f"{time.time() - step_started:.2f} seconds." if measure_time else "done.")
+    except BaseException:
+        # a callback, a HIP error or a failed matching ended the loop: the generators' side stream is joined and
+        # the host RandomStates get their streams back before the device buffers are released
+        if resident is not None:
+            resident.abort()
+            resident = None
+        raise
 
     if resident is not None:
         resident.finish()

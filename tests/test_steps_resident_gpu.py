@@ -372,3 +372,51 @@ def test_sharded_driver_runs_through_rccl_at_world_size_one():
     assert proc.returncode == 0, proc.stderr[-2000:]
     line = json.loads(proc.stdout.strip().splitlines()[-1])
     assert line["ranks"] == 1 and line["members_of_rank0"] == [0, 1, 2] and line["result_of_rank0"] == [3, 2, 256, 256]
+
+
+def test_a_failing_callback_leaves_the_library_usable_and_a_late_failure_falls_back(ref_pysteps):
+    """(a) an exception inside the loop (here: the caller's callback) aborts the resident state in order - the
+    generators' stream is joined before the noise buffers are released - and the very next nowcast gives the stock
+    result; (b) a failure while the resident state is being built (here: injected) does not abort the nowcast: the
+    reference's own update runs (try_create returns None with a warning)."""
+    from pysteps import nowcasts
+
+    from pysteps_amd import register
+    from pysteps_amd.nowcasts import steps_resident
+    from test_callers_gpu import _ensemble_close, _steps_kwargs
+
+    frames, V = _steps_inputs(128, 128)
+    kw = _steps_kwargs()
+    kw["probmatching_method"] = "cdf"
+    steps = nowcasts.get_method("steps")
+    want = steps(frames, V, 2, extrap_method="semilagrangian", **kw)
+
+    class Boom(Exception):
+        pass
+
+    seen = []
+
+    def callback(fields):
+        seen.append(fields.shape)
+        raise Boom
+
+    orig_init = steps_resident.ResidentSteps.__init__
+    try:
+        register.register(patch_main_loop=True)
+        with pytest.raises(Boom):
+            steps(frames, V, 2, extrap_method="semilagrangian_hip", callback=callback, **kw)
+        assert seen
+        got = steps(frames, V, 2, extrap_method="semilagrangian_hip", **kw)
+        assert _ensemble_close(got, want) < 1e-4
+
+        def failing(self, *a, **k):
+            orig_init(self, *a, **k)
+            raise MemoryError("injected: no room for the device state")
+
+        steps_resident.ResidentSteps.__init__ = failing
+        with pytest.warns(RuntimeWarning, match="resident STEPS update is not used"):
+            late = steps(frames, V, 2, extrap_method="semilagrangian_hip", **kw)
+        assert _ensemble_close(late, want) < 1e-4
+    finally:
+        steps_resident.ResidentSteps.__init__ = orig_init
+        register.unpatch_main_loop()
