@@ -832,6 +832,12 @@ def main():
             line["config"]["steps_e2e"] = e2e
         except Exception as exc:  # never takes the headline down
             line["config"]["steps_loop"] = {"note": "%s: %s" % (type(exc).__name__, exc)}
+    # the three figures every line carries under the same keys (see main_members): this line's `value` is
+    # lk_semilag_value (BASELINE config 3); the other two are what one GPU of an N > 1 run does
+    line["lk_semilag_value"] = value
+    line["advection_value"] = line["config"].get("config4_one_gpu", {}).get("value")
+    line["member_loop_value"] = line["config"].get("steps_loop", {}).get("value")
+    line["config"]["workload"] += "; `value` = lk_semilag_value"
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(frames_d, vel_d, K, args.cpu_sample_steps, T, have_lk)
     print(json.dumps(line))
@@ -941,6 +947,19 @@ def main_members(args, dist, dense_lk):
         kernel_ms = sum(a.elapsed_ms(b) for row in ev for a, b in row) / (args.steps * T)  # one batched launch
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * m * n * T / (ms_per_step * 1e-3) / 1e6
+    # the same three figures under the same keys in EVERY line (N = 1 included), so that lines of different N
+    # can be laid side by side: member_loop_value (update + advection), advection_value (advection alone),
+    # lk_semilag_value (BASELINE config 3, N = 1 only).  `value` of this line is member_loop_value
+    # (advection_value with --advection-only); its N = 1 twin is `--gpus 1 --force-members-path`
+    advection_value = value if args.advection_only else None
+    if not args.advection_only:
+        try:
+            adv_step = members_workload(precip_d, vel_d, len(mine), mine.start, n_total, T, K)
+            adv_el = time_steps(adv_step, dist, 2, 1)
+            advection_value = n_total * m * n * T / (adv_el / 2) / 1e6
+            del adv_step
+        except Exception:
+            advection_value = None
     # stateful single-step call: D read + write 16, three velocity passes 8 each
     # (increment rebuild, midpoint, end point) for n_iter = 1, field 4, store 4 -> 48 B / px / member
     b_alg = (24 + 16 * K + 8) if K > 0 else 32
@@ -963,11 +982,15 @@ def main_members(args, dist, dense_lk):
             "vs_baseline": None,
             "dtype": "f32 advection, f64 member update (the reference's dtypes)",
             "data": "synthetic",
+            "member_loop_value": None if args.advection_only else value,
+            "advection_value": advection_value,
+            "lk_semilag_value": None,
             "single_gpu_base": base,
             "weak_scaling_efficiency": value / (dist.world * base["value"]),
             "config": {
                 "workload": "%dx%d, %d-member STEPS ensemble (BASELINE config 4), %d members per GPU, %d lead times, %s, "
-                            "BPS velocity perturbations, n_iter=%d" % (m, n, n_total, per, T, what, K),
+                            "BPS velocity perturbations, n_iter=%d; `value` = %s" % (
+                                m, n, n_total, per, T, what, K, "advection_value" if args.advection_only else "member_loop_value"),
                 "sharding": "members partitioned over ranks (random streams and perturbators from the ensemble's seed chain), "
                             "motion field from %s on rank 0, [precip|u|v] in ONE RCCL broadcast before the timed region, no "
                             "data-path collective" % ("dense LK" if dense_lk is not None else "the synthetic truth"),
