@@ -202,6 +202,11 @@ def test_elementwise_pieces_bit_identical_with_numpy():
     np.testing.assert_allclose(d.to_host(), want, rtol=0, atol=1e-14)
 
 
+# fraction of the pixels of one update that may differ by more than 1e-9 of the field's range from the reference's
+# update (a threshold or a rank decided differently); observed on MI355X: see profiles/r04/*_update_flips_seen.jsonl
+FLIP_BAR = 1e-5  # observed: 0 in all 8 configurations x 4 updates (median difference <= 2e-16 of the range)
+
+
 def _steps_inputs(m, n):
     from tools import synth
 
@@ -221,7 +226,7 @@ CONFIGS = {
 @pytest.mark.parametrize("name", sorted(CONFIGS) + ["incremental_cdf/spatial", "composite_shape/spatial"])
 def test_update_beside_the_reference_update(ref_pysteps, name, monkeypatch):
     """ResidentSteps.update() and StepsNowcaster.__update_state advance the same initial state side by
-    side: the fields of every member and step agree to 1e-9 of the field's range on all but 1e-3 of
+    side: the fields of every member and step agree to 1e-9 of the field's range on all but 1e-5 of
     the pixels (the ones a threshold / a rank decided differently), NaN masks identical, and the host
     generators end where the device generators end."""
     from pysteps import nowcasts
@@ -273,9 +278,18 @@ def test_update_beside_the_reference_update(ref_pysteps, name, monkeypatch):
     finally:
         steps_mod.nowcast_main_loop = orig
     assert len(report) == 4
+    try:  # what was seen, for the bars below (gpurun_out/ travels back from the GPU box)
+        import json
+        import os
+
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/update_flips_seen.jsonl", "a") as fh:
+            fh.write(json.dumps({"case": name, "spatial": "PYSTEPS_HIP_RESIDENT_DOMAIN" in os.environ, "report": report}) + "\n")
+    except OSError:
+        pass
     for flipped, median in report:
-        assert flipped <= 1e-3, report
-        assert median <= 1e-12, report
+        assert flipped <= FLIP_BAR, report
+        assert median <= 1e-14, report
 
 
 @pytest.mark.parametrize("timesteps,vel_pert", [(3, "bps"), ([0.5, 1.0, 2.5], None)])
