@@ -144,6 +144,129 @@ __global__ __launch_bounds__(64) void outliers_local(const double2 *__restrict__
   flags[i] = out ? 1 : 0;
 }
 
+// The same test with every lane's keys SORTED once (register sorting network), for up to 64 x KPER
+// vectors.  outliers_local above rescans the owner lane's entries after every extraction - a single
+// active lane and two dependent LDS round trips, 31 times per vector; here the owner pops the next key
+// of its sorted list (one LDS read).  Extraction order, sums and flags are those of outliers_local.
+template <int N>
+__device__ __forceinline__ void sort_keys_ascending(unsigned long long (&a)[N]) {
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          const unsigned long long x = a[i], y = a[l];
+          const bool swap = up ? (x > y) : (x < y);
+          a[i] = swap ? y : x;
+          a[l] = swap ? x : y;
+        }
+      }
+    }
+  }
+}
+
+template <int KPER>
+__global__ __launch_bounds__(64) void outliers_local_sorted(const double2 *__restrict__ xy,
+                                                            const double2 *__restrict__ uv, int n_host,
+                                                            const int *__restrict__ n_dev, int k, double thr,
+                                                            unsigned char *__restrict__ flags) {
+  __shared__ unsigned long long keys[KPER * 64];  // keys[q * 64 + lane]: the lane's q-th smallest key
+  __shared__ double2 s_nb[64];
+  const int n = n_dev ? *n_dev : n_host;
+  const int i = blockIdx.x, lane = threadIdx.x;
+  if (i >= n) return;
+  if (n < 2) {
+    if (lane == 0) flags[i] = 0;
+    return;
+  }
+  const double2 me = xy[i], mine = uv[i];
+  constexpr unsigned long long kGone = ~0ull;
+  unsigned long long mykeys[KPER];
+  double2 p[KPER];
+#pragma unroll
+  for (int q = 0; q < KPER; ++q) {  // (all loads in flight together)
+    const int j = q * 64 + lane;
+    p[q] = j < n ? xy[j] : make_double2(0.0, 0.0);
+  }
+#pragma unroll
+  for (int q = 0; q < KPER; ++q) {
+    const int j = q * 64 + lane;
+    const double dx = p[q].x - me.x, dy = p[q].y - me.y;
+    const float d = static_cast<float>(dx * dx + dy * dy);
+    mykeys[q] = j < n ? (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | static_cast<unsigned>(j) : kGone;
+  }
+  sort_keys_ascending<KPER>(mykeys);
+#pragma unroll
+  for (int q = 0; q < KPER; ++q) keys[q * 64 + lane] = mykeys[q];
+  unsigned long long best = mykeys[0];
+  int next = 1;  // position of the lane's next key
+  double sa = 0.0, sb = 0.0, saa = 0.0, sab = 0.0, sbb = 0.0;
+  int cnt = 0;
+  const int kk = min(n, k + 1);  // nearest hits incl. the vector itself
+  int mine_j = -1;
+  for (int t0 = 0; t0 < kk; t0 += 64) {
+    const int tn = min(64, kk - t0);
+    for (int t = 0; t < tn; ++t) {
+      const unsigned long long g = wave_min_u64(best);
+      const int j = static_cast<int>(g & 0xffffffffull);
+      if (lane == t) mine_j = j;
+      if ((j & 63) == lane) {  // the owner moves on to its next key
+        best = next < KPER ? keys[next * 64 + lane] : kGone;
+        ++next;
+      }
+    }
+    if (lane < tn) {
+      const double2 q = uv[mine_j];
+      s_nb[lane] = make_double2(q.x - mine.x, q.y - mine.y);
+    }
+    __syncthreads();
+    if (lane == 0) {
+      for (int t = (t0 == 0 ? 1 : 0); t < tn; ++t) {  // the first hit is the vector itself (or a duplicate position): dropped
+        const double a = s_nb[t].x, b = s_nb[t].y;
+        sa += a;
+        sb += b;
+        saa += a * a;
+        sab += a * b;
+        sbb += b * b;
+        ++cnt;
+      }
+    }
+    __syncthreads();
+  }
+  if (lane != 0) return;
+  bool out = false;
+  if (cnt >= 2) {
+    const double ma = sa / cnt, mb = sb / cnt;  // neighbour mean relative to this vector
+    const double dof = cnt - 1;
+    const double caa = (saa - sa * ma) / dof, cab = (sab - sa * mb) / dof,
+                 cbb = (sbb - sb * mb) / dof;
+    const double det = caa * cbb - cab * cab;
+    if (det != 0.0 && isfinite(det)) {
+      const double zu = -ma, zv = -mb;  // this vector minus the neighbour mean
+      const double md2 = (zu * zu * cbb - 2.0 * zu * zv * cab + zv * zv * caa) / det;
+      out = sqrt(md2) > thr;
+    }
+  }
+  flags[i] = out ? 1 : 0;
+}
+
+// picks the kernel by the number of vectors the launch may see
+static void launch_outliers(int rows, size_t cap_for_lds, hipStream_t stream, const double2 *xy, const double2 *uv, int n_host,
+                            const int *n_dev, int k, double thr, unsigned char *flags) {
+  if (rows <= 16 * 64) {
+    hipLaunchKernelGGL(outliers_local_sorted<16>, dim3(rows), dim3(64), 0, stream, xy, uv, n_host, n_dev, k, thr, flags);
+  } else if (rows <= 32 * 64) {
+    hipLaunchKernelGGL(outliers_local_sorted<32>, dim3(rows), dim3(64), 0, stream, xy, uv, n_host, n_dev, k, thr, flags);
+  } else {
+    hipLaunchKernelGGL(outliers_local, dim3(rows), dim3(64), cap_for_lds * sizeof(unsigned long long), stream, xy, uv, n_host,
+                       n_dev, k, thr, flags);
+  }
+}
+
 }  // namespace
 }  // namespace psh
 
@@ -152,10 +275,8 @@ namespace psh {
 hipError_t launch_outliers_pooled(const double *xy_dev, const double *uv_dev, const int *count_dev,
                                   int capacity, int k, double thr, unsigned char *flags_dev,
                                   hipStream_t stream) {
-  const size_t lds = static_cast<size_t>(capacity) * sizeof(unsigned long long);
-  hipLaunchKernelGGL(outliers_local, dim3(capacity), dim3(64), lds, stream,
-                     reinterpret_cast<const double2 *>(xy_dev), reinterpret_cast<const double2 *>(uv_dev), 0,
-                     count_dev, k, thr, flags_dev);
+  launch_outliers(capacity, static_cast<size_t>(capacity), stream, reinterpret_cast<const double2 *>(xy_dev),
+                  reinterpret_cast<const double2 *>(uv_dev), 0, count_dev, k, thr, flags_dev);
   return hipGetLastError();
 }
 }  // namespace psh
@@ -188,9 +309,7 @@ extern "C" int psh_outliers_local_host(const double *xy, const double *values, i
   auto run = [&]() -> int {
     PSH_HIP(hipMemcpyAsync(d_xy, xy, vec_bytes, hipMemcpyHostToDevice, c.stream));
     PSH_HIP(hipMemcpyAsync(d_uv, values, vec_bytes, hipMemcpyHostToDevice, c.stream));
-    const size_t lds = static_cast<size_t>(n) * sizeof(unsigned long long);
-    hipLaunchKernelGGL(psh::outliers_local, dim3(n), dim3(64), lds, c.stream, d_xy, d_uv, n, nullptr, k, thr,
-                       d_fl);
+    psh::launch_outliers(n, static_cast<size_t>(n), c.stream, d_xy, d_uv, n, nullptr, k, thr, d_fl);
     PSH_HIP(hipGetLastError());
     PSH_HIP(hipMemcpyAsync(flags, d_fl, static_cast<size_t>(n), hipMemcpyDeviceToHost, c.stream));
     PSH_HIP(hipStreamSynchronize(c.stream));
