@@ -233,6 +233,15 @@ int psh_idw_host(const double *xy, const double *values, int L, int m, int n, do
                  double dx, double y0, double dy, int k, double power, double dist_offset,
                  double *out);
 
+/* Radial-basis-function interpolant on a regular grid (pysteps/utils/interpolate.py:117-170 rbfinterp2d, which
+ * wraps scipy.interpolate.Rbf): out(x) = sum_j weights_j phi(|x - xy_j|) for two variables at once.  The
+ * weights come from the host (SciPy's own N x N solve); this is the N x m x n evaluation.  xy_dev (N,2) and
+ * weights_dev (N,2) float64, out_dev (2,m,n) float64 at x = x0 + dx i, y = y0 + dy j; function: 0 multiquadric,
+ * 1 inverse, 2 gaussian, 3 linear, 4 cubic, 5 quintic, 6 thin_plate; epsilon: Rbf's shape parameter.
+ * Asynchronous on the library stream. */
+int psh_rbf_eval_dev(const double *xy_dev, const double *weights_dev, int N, int m, int n, double x0, double dx,
+                     double y0, double dy, int function, double epsilon, double *out_dev);
+
 /* ---- dense Lucas-Kanade: image front end ----------------------------------- *
  * The NumPy + OpenCV stages of pysteps/motion/lucaskanade.py:205-242, per frame /
  * frame pair.  OpenCV is a third-party dependency of the reference (not in its

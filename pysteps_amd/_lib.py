@@ -67,6 +67,8 @@ SIGNATURES = {
     "psh_event_destroy": (c_int, [c_void_p]),
     "psh_event_record": (c_int, [c_void_p]),
     "psh_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "psh_rbf_eval_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_double, c_double, c_int,
+                                 c_double, c_void_p]),
     "psh_fft_rfft2_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "psh_fft_irfft2_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "psh_fft_c2c2_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),

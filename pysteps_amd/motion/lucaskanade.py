@@ -226,21 +226,26 @@ def _reference_dense_lk():
 
 def _dense_with_reference_interpolator(input_images, lk_kwargs, fd_kwargs, interp_method, interp_kwargs,
                                        nr_std_outlier, k_outlier, size_opening, decl_scale, verbose):
-    """Another interpolation method (``"rbfinterp2d"``, pysteps/utils/interpolate.py:117-170, wraps
-    scipy.interpolate.Rbf): the sparse stage - features, tracking, outlier removal - runs on the HIP
-    path, the vectors are declustered here and handed to the reference's interpolation function
-    looked up by name, exactly as pysteps/motion/lucaskanade.py:199,264-274 does."""
+    """Another interpolation method: the sparse stage - features, tracking, outlier removal - runs on the HIP
+    path, the vectors are declustered here and handed to the interpolation function, exactly as
+    pysteps/motion/lucaskanade.py:199,264-274 does.  ``"rbfinterp2d"`` (pysteps/utils/interpolate.py:117-170, wraps
+    scipy.interpolate.Rbf) is this package's: SciPy's weights, the grid evaluation on the device; any other name is
+    looked up in the reference's table."""
     if isinstance(input_images, DeviceArray):
         raise NotImplementedError(
             "pysteps_amd dense_lucaskanade: interp_method=%r returns a host array; pass NumPy frames" % (interp_method,)
         )
-    try:
-        from pysteps import utils as ref_utils  # noqa: PLC0415
-    except Exception as exc:
-        raise NotImplementedError(
-            "pysteps_amd dense_lucaskanade: interp_method=%r needs pysteps' interpolation functions" % (interp_method,)
-        ) from exc
-    interpolation_method = ref_utils.get_method(interp_method)  # ValueError for unknown names, as the reference
+    if interp_method == "rbfinterp2d":
+        # SciPy's own weights, the grid evaluation on the device (utils/interpolate.py, csrc/rbf.hip)
+        from ..utils.interpolate import rbfinterp2d as interpolation_method  # noqa: PLC0415
+    else:
+        try:
+            from pysteps import utils as ref_utils  # noqa: PLC0415
+        except Exception as exc:
+            raise NotImplementedError(
+                "pysteps_amd dense_lucaskanade: interp_method=%r needs pysteps' interpolation functions" % (interp_method,)
+            ) from exc
+        interpolation_method = ref_utils.get_method(interp_method)  # ValueError for unknown names, as the reference
     xy, uv = dense_lucaskanade(
         input_images, lk_kwargs, "shitomasi", fd_kwargs, "idwinterp2d", None, False, nr_std_outlier, k_outlier,
         size_opening, decl_scale, verbose,

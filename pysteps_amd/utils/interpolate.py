@@ -4,6 +4,11 @@
 (interpolate.py:26-114) including the input checks and trivial cases its
 ``prepare_interpolator`` decorator performs (decorators.py:153-250); the k-NN search
 and the weighting run in the HIP kernel ``csrc/idw.hip`` through ``psh_idw_*``.
+
+``rbfinterp2d`` (interpolate.py:117-170, a wrapper of ``scipy.interpolate.Rbf``): the weights
+are SciPy's own dense solve on the host (N x N, N = number of sparse vectors), the evaluation
+of the interpolant at every grid node - where the reference spends its time - runs in
+``csrc/rbf.hip`` through ``psh_rbf_eval_dev``.
 """
 
 import ctypes
@@ -14,7 +19,7 @@ import numpy as np
 from .. import _lib
 from ..device import DeviceArray
 
-__all__ = ["idwinterp2d"]
+__all__ = ["idwinterp2d", "rbfinterp2d"]
 
 
 def _reference_idw():
@@ -142,4 +147,96 @@ def idwinterp2d(xy_coord, values, xgrid, ygrid, power=0.5, k=20, dist_offset=0.5
         )
         _lib.check(rc, "psh_idw_host")
         out[c0:c0 + width] = buf[:width]
+    return out.squeeze()
+
+
+_RBF_FUNCTIONS = {"multiquadric": 0, "inverse": 1, "gaussian": 2, "linear": 3, "cubic": 4, "quintic": 5, "thin_plate": 6}
+
+
+def _reference_rbf():
+    try:
+        from pysteps.utils.interpolate import rbfinterp2d as ref  # noqa: PLC0415
+    except Exception:
+        return None
+    return None if ref is rbfinterp2d else ref
+
+
+def rbfinterp2d(xy_coord, values, xgrid, ygrid, **kwargs):
+    """Radial basis function interpolation of a sparse (multivariate) array.
+
+    Parameters and return value as in the reference (interpolate.py:117-170 with the preamble of
+    decorators.py:153-250): ``(ygrid.size, xgrid.size)`` for 1-d ``values`` or ``(m, ygrid.size,
+    xgrid.size)`` float64; keyword arguments are those of ``scipy.interpolate.Rbf`` (``function``,
+    ``epsilon``, ``smooth``; ``nchunks`` / ``hkey`` are accepted - the result does not depend on the
+    chunking the reference uses to bound memory).  A callable ``function``, a ``norm`` other than the
+    Euclidean one, coordinates that are not 2-d or an irregular grid go to the reference.
+    """
+    xy_coord, values = _check_inputs(xy_coord, values)
+    xgrid, ygrid = np.asarray(xgrid), np.asarray(ygrid)
+    grid_shape = (ygrid.size, xgrid.size)
+    nvar = 1 if values.ndim == 1 else values.shape[1]
+    nsamples = values.shape[0]
+
+    # trivial cases of the decorator (decorators.py:200-208)
+    if nsamples == 1:
+        out = np.ones((nvar,) + grid_shape)
+        for i, v in enumerate(np.atleast_1d(values[0, ...])):
+            out[i, ...] *= v
+        return out.squeeze()
+    if values.max() == values.min():
+        return np.ones((nvar,) + grid_shape) * values.ravel()[0]
+
+    deprecated = [arg for arg in ("rbfunction", "k") if arg in kwargs]
+    if deprecated:  # interpolate.py:151-159
+        warnings.warn("rbfinterp2d: The following keyword arguments are deprecated:\n" + str(deprecated), DeprecationWarning)
+    rbf_kwargs = {k: v for k, v in kwargs.items() if k not in ("nchunks", "hkey")}
+    function = rbf_kwargs.get("function", "multiquadric")
+    ax, ay = _regular_axis(xgrid, "xgrid"), _regular_axis(ygrid, "ygrid")
+    why = None
+    if ax is None or ay is None or xy_coord.shape[1] != 2:
+        why = "irregular grid or coordinates that are not 2-d"
+    elif values.ndim == 1 and _reference_rbf() is not None:
+        # (the reference moves the LAST axis of the Rbf result to the front, interpolate.py:169 - for 1-d values
+        # that is a transposition, per grid chunk, and an error on non-square chunks: its behaviour there is its own)
+        why = "1-d values (the reference's own axis handling applies)"
+    elif not isinstance(function, str) or function not in _RBF_FUNCTIONS:
+        why = "function=%r (the kernel knows %s)" % (function, ", ".join(sorted(_RBF_FUNCTIONS)))
+    elif "norm" in rbf_kwargs and rbf_kwargs["norm"] not in (None, "euclidean"):
+        why = "norm=%r (the kernel evaluates Euclidean distances)" % (rbf_kwargs["norm"],)
+    elif any(k not in ("function", "epsilon", "smooth", "norm", "mode", "rbfunction", "k") for k in rbf_kwargs):
+        why = "keyword arguments %r" % sorted(rbf_kwargs)
+    if why is not None:  # outside the kernel's limits: the reference takes the call
+        ref = _reference_rbf()
+        if ref is None:
+            raise NotImplementedError(
+                "pysteps_amd rbfinterp2d: %s is not implemented on the HIP path and pysteps is not importable" % why
+            )
+        warnings.warn("pysteps_amd rbfinterp2d: %s -> delegating to the reference CPU path" % why)
+        return ref(xy_coord, values, xgrid, ygrid, **kwargs)
+
+    # the weights: SciPy's own solve, with the keyword arguments the reference would hand it (interpolate.py:161-167)
+    from scipy.interpolate import Rbf  # noqa: PLC0415
+
+    solve_kwargs = {k: v for k, v in rbf_kwargs.items() if k in ("function", "epsilon", "smooth", "norm", "rbfunction", "k")}
+    solve_kwargs["mode"] = "1-D" if values.ndim == 1 else "N-D"
+    rbfi = Rbf(*np.split(xy_coord, xy_coord.shape[1], 1), values, **solve_kwargs)
+    nodes = np.asarray(rbfi.nodes, dtype=np.float64).reshape(nsamples, nvar)
+    epsilon = float(rbfi.epsilon) if rbfi.epsilon is not None else 1.0
+
+    lib = _lib.lib()
+    m, n = grid_shape
+    xy_d = DeviceArray.from_host(np.ascontiguousarray(xy_coord, dtype=np.float64))
+    out = np.empty((nvar, m, n))
+    buf = DeviceArray((2, m, n), np.float64)
+    for c0 in range(0, nvar, 2):
+        width = min(2, nvar - c0)
+        pair = np.zeros((nsamples, 2))
+        pair[:, :width] = nodes[:, c0:c0 + width]
+        w_d = DeviceArray.from_host(pair)
+        _lib.check(
+            lib.psh_rbf_eval_dev(xy_d.ptr, w_d.ptr, nsamples, m, n, ax[0], ax[1], ay[0], ay[1],
+                                 _RBF_FUNCTIONS[function], epsilon, buf.ptr),
+            "psh_rbf_eval_dev",
+        )
+        out[c0:c0 + width] = buf.to_host()[:width]
     return out.squeeze()
