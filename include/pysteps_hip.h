@@ -53,7 +53,7 @@ int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hb
  * plane per component with DPP column sharing, 3 three pixels per lane with dwordx4 gathers
  * (interp_order 0/1, >= 192 columns, finite motion fields), 2 / 4 workgroup LDS-staged tiles, 8 per-wave
  * LDS staging of the sampling boxes through LDS-DMA (bit-identical with 0), 6 two rows per lane;
- * "idw_variant": 0 two-level pre-pass (64x64 supertile lists, one wave per 8x8 tile; default),
+ * "idw_variant": 0 two-level pre-pass (64x64 supertile lists, one wave per 16x8 tile, two pixels per lane; default),
  * 1 one pre-pass per 16x16 tile;
  * "members_variant": members per thread of the member-batched step on packed planes: 2 (default: the two
  * trajectories' gathers overlap) or 1;
@@ -563,12 +563,17 @@ int psh_lerp_dev(const double *a_dev, const double *b_dev, double w, double *out
  *                     behind everything queued on the library stream so far (the noise of the next time
  *                     step beside the member loop): psh_rng_wait() makes the library stream wait for it
  *                     and has to be called before out_dev is read or freed
+ *  psh_rng_check      PSH_EHIP when a draw that has COMPLETED found fewer accepted attempts in its window than
+ *                     it needed (a > 10 sigma event; the tail of that draw is unwritten); reads one pinned host
+ *                     word, no device work - meant to be called once per time step after a wait the caller has
+ *                     anyway.  The flag stays raised; get_state reports the same condition
  *  psh_rng_get_state  waits for the draws and returns the generators' states in get_state() form
  *                     (RandomState.set_state() then continues the stream on the host) */
 int psh_rng_create(int n_streams, const uint32_t *keys_host, const int *pos_host, const int *has_gauss_host,
                    const double *gauss_host, size_t max_draw, int n_draws_hint, void **handle_out);
 int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, int side);
 int psh_rng_wait(void *handle);
+int psh_rng_check(void *handle);
 int psh_rng_get_state(void *handle, uint32_t *keys_host, int *pos_host, int *has_gauss_host, double *gauss_host);
 int psh_rng_destroy(void *handle);
 

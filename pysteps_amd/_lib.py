@@ -103,6 +103,7 @@ SIGNATURES = {
     "psh_rng_create": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
     "psh_rng_randn_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_int]),
     "psh_rng_wait": (c_int, [c_void_p]),
+    "psh_rng_check": (c_int, [c_void_p]),
     "psh_rng_get_state": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "psh_rng_destroy": (c_int, [c_void_p]),
     "psh_lk_greedy_host": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),

@@ -414,18 +414,15 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
 // third of the kernel, and the ring of undecided vectors is as thick as four half-diagonals of
 // the tile.  Here the scan over all L is done once per 64x64 SUPERTILE (idw_coarse: the same
 // bracket and ordered compaction, into a global list of typically 30-60 vectors), and the
-// fine pass runs one WAVE per 8x8 tile (one pixel per lane, no workgroup barriers that span
-// waves): it brackets the k-th centre distance of its own tile from the supertile's list, so
-// the ring is 2.7 times thinner and fewer vectors need the per-pixel selection.
+// fine pass runs one WAVE per small tile (no workgroup barriers that span waves): it brackets the k-th centre distance of its own tile from the supertile's list, so
+// the ring is thinner and fewer vectors need the per-pixel selection.
 // Exactness: a pixel q of a supertile with centre c and half-diagonal H has its k-th neighbour
 // within R_hi + H of q, hence within R_hi + 2H of c - the supertile list holds every vector any
 // of its pixels can need, and a fine tile's k-th centre distance computed from the list is the
 // true one (vectors outside the list are farther than R_hi + H from any fine centre).
 constexpr int kSuper = 64;      // supertile edge in pixels
 constexpr int kSuperCap = 256;  // vectors kept per supertile (4 KiB of float4)
-constexpr int kFine = 8;        // fine tile edge: 64 pixels, one per lane
 constexpr int kFineCap = 96;    // vectors per fine tile in LDS
-constexpr int kFineBins = 256;
 
 struct SuperHeader {
   int count;        // vectors in the list, or > kSuperCap: overflow (brute force in the fine pass)
@@ -535,331 +532,26 @@ __global__ __launch_bounds__(kThreads) void idw_coarse(const float2 *__restrict_
   }
 }
 
-template <int KMAX>
-__global__ __launch_bounds__(64) void idw_fine(const float2 *__restrict__ xy, const float2 *__restrict__ uv,
-                                               int L, int k, int m, int n, float x0, float dx_grid,
-                                               float y0, float dy_grid, float inv_res, float power,
-                                               float offset, float *__restrict__ out, int supers_x,
-                                               const SuperHeader *__restrict__ headers,
-                                               const float4 *__restrict__ lists, int tiles_x, int n_tiles,
-                                               int tiles_per_xcd, const IdwDyn *__restrict__ dyn) {
-  __shared__ int s_hist[kFineBins];
-  __shared__ float4 s_cand[kFineCap];  // [certain | undecided], each group in index order
-  const int b = blockIdx.x;
-  const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;  // XCD-contiguous tiles
-  if (tile >= n_tiles) return;
-  const int tx = (tile % tiles_x) * kFine, ty = (tile / tiles_x) * kFine;
-  const int lane = threadIdx.x;
-  const int ix = tx + (lane % kFine), iy = ty + (lane / kFine);
-  const bool live = ix < n && iy < m;
-  if (dyn) {
-    L = dyn->L;
-    k = min(k, L);
-    if (dyn->mode != 0) {  // the interpolator's trivial cases (decorators.py:199-208): constant field
-      if (live) {
-        out[static_cast<size_t>(iy) * n + ix] = dyn->cu;
-        out[static_cast<size_t>(m) * n + static_cast<size_t>(iy) * n + ix] = dyn->cv;
-      }
-      return;
-    }
-  }
-  const float px = x0 + dx_grid * static_cast<float>(ix);
-  const float py = y0 + dy_grid * static_cast<float>(iy);
-  const size_t plane = static_cast<size_t>(m) * n;
-  const int sup = (ty / kSuper) * supers_x + tx / kSuper;
-  const SuperHeader hdr = headers[sup];
-  const float4 *list = lists + static_cast<size_t>(sup) * kSuperCap;
-  const int n_s = hdr.count;
-
-  bool brute = k >= L || n_s > kSuperCap;
-  int n_sure = 0, n_ring = 0;
-  if (!brute) {
-    const int wx = min(kFine, n - tx), wy = min(kFine, m - ty);
-    const float cx = x0 + dx_grid * (static_cast<float>(tx) + 0.5f * static_cast<float>(wx - 1));
-    const float cy = y0 + dy_grid * (static_cast<float>(ty) + 0.5f * static_cast<float>(wy - 1));
-    const float hx = 0.5f * fabsf(dx_grid) * static_cast<float>(wx - 1);
-    const float hy = 0.5f * fabsf(dy_grid) * static_cast<float>(wy - 1);
-    const float half_diag = sqrtf(hx * hx + hy * hy);
-    // every listed vector is within reach + H of any point of the supertile
-    const float bin_w = (hdr.reach + hdr.half_diag) * (1.001f / static_cast<float>(kFineBins));
-    constexpr int kPerLane = kSuperCap / 64;
-    float dc[kPerLane];
-#pragma unroll
-    for (int q = 0; q < kFineBins / 64; ++q) s_hist[q * 64 + lane] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < kPerLane; ++j) {
-      const int i = j * 64 + lane;
-      dc[j] = INFINITY;
-      if (i < n_s) {
-        const float4 c = list[i];
-        const float ddx = c.x - cx, ddy = c.y - cy;
-        dc[j] = sqrtf(ddx * ddx + ddy * ddy);
-        atomicAdd(&s_hist[min(static_cast<int>(dc[j] / bin_w), kFineBins - 1)], 1);
-      }
-    }
-    __syncthreads();
-    constexpr int kPer = kFineBins / 64;
-    int tot = 0;
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) tot += s_hist[lane * kPer + q];
-    int incl = tot;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int up = __shfl_up(incl, d);
-      if (lane >= d) incl += up;
-    }
-    int run = incl - tot;
-    int first = kFineBins;
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-      run += s_hist[lane * kPer + q];
-      if (run >= k && first == kFineBins) first = lane * kPer + q;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) first = min(first, __shfl_xor(first, d));
-    // R_lo < (k-th smallest centre distance) <= R_hi; the last bin is open-ended
-    const float r_hi = first >= kFineBins - 1 ? INFINITY : static_cast<float>(first + 1) * bin_w;
-    const float r_lo = static_cast<float>(min(first, kFineBins - 1)) * bin_w;
-    const float reach = r_hi + 2.f * half_diag + 1e-3f * (r_hi + half_diag);
-    const float sure_below = r_lo - 2.f * half_diag - 1e-3f * (r_lo + half_diag);
-    int at = 0;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-      for (int j = 0; j < kPerLane; ++j) {
-        if (j * 64 >= n_s) break;
-        const bool sure = dc[j] <= sure_below;
-        const bool keep = pass == 0 ? sure : (!sure && dc[j] <= reach);
-        const unsigned long long mask = __ballot(keep);
-        const int slot = at + __popcll(mask & ((1ull << lane) - 1ull));
-        if (keep && slot < kFineCap) s_cand[slot] = list[j * 64 + lane];
-        at += __popcll(mask);
-      }
-      if (pass == 0) n_sure = at;
-    }
-    n_ring = at - n_sure;
-    brute = at > kFineCap;  // pathological clustering: exact brute force
-    __syncthreads();
-  }
-  if (!live) return;
-  float ou, ov;
-  if (brute) {
-    idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
-  } else {
-    float sw = 0.f, su = 0.f, sv = 0.f;
-    for (int i = 0; i < n_sure; ++i) {  // in every pixel's neighbourhood: no selection
-      const float4 c = s_cand[i];       // same address in every lane: LDS broadcast
-      const float w = idw_weight(fast_sqrt(dist2(c.x, c.y, px, py)) * inv_res, power, offset);
-      sw += w;
-      su += w * c.z;
-      sv += w * c.w;
-    }
-    const int need = k - n_sure;  // >= 1: fewer than k vectors lie strictly inside R_lo
-    if (need <= 8) {              // tile-uniform branch: small selection sets are much cheaper
-      add_nearest<8>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
-    } else {
-      add_nearest<KMAX>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
-    }
-    ou = su / sw;
-    ov = sv / sw;
-  }
-  out[static_cast<size_t>(iy) * n + ix] = ou;
-  out[plane + static_cast<size_t>(iy) * n + ix] = ov;
-}
-
-// ---- fine pass, second form (default) -------------------------------------------------------
-// idw_fine above spends about half of its instructions before the first weight is computed: an
-// LDS histogram of up to 256 centre distances (IEEE square roots and divisions, LDS atomics), a
-// prefix scan over the bins and two ballot sweeps over four list chunks.  The supertile lists are
-// short (30-60 vectors), so here the k-th smallest centre distance of the tile is found EXACTLY
-// - and without LDS - by bisection on the bit patterns of the squared distances (a non-negative
-// float orders like its bits): 25 rounds of one compare + ballot + scalar popcount fix the value
-// up to its 6 lowest mantissa bits.  Squared distances are classified against squared radii (no
-// square root per vector), the two groups are compacted into LDS with one ballot each, and a
-// small ring (<= 8 vectors, the rule at the reference's density) is ranked pairwise in registers
-// instead of going through the replace-the-maximum set.  The per-pixel arithmetic (dist2, the
-// weight, the order of the sums: certain vectors in index order, then the chosen ring vectors in
-// index order) is that of idw_fine; a vector that sits within the safety margin of a class
-// boundary may change class between the two kernels, which only changes the order of summation
-// (last-bit differences, same neighbour sets).
-template <int KMAX>
-__global__ __launch_bounds__(64) void idw_fine2(const float2 *__restrict__ xy, const float2 *__restrict__ uv,
-                                                int L, int k, int m, int n, float x0, float dx_grid,
-                                                float y0, float dy_grid, float inv_res, float power,
-                                                float offset, float *__restrict__ out, int supers_x,
-                                                const SuperHeader *__restrict__ headers,
-                                                const float4 *__restrict__ lists, int tiles_x, int n_tiles,
-                                                int tiles_per_xcd, const IdwDyn *__restrict__ dyn) {
-  __shared__ float4 s_cand[kFineCap];  // [certain | undecided], each group in index order
-  const int b = blockIdx.x;
-  const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;  // XCD-contiguous tiles
-  if (tile >= n_tiles) return;
-  const int tx = (tile % tiles_x) * kFine, ty = (tile / tiles_x) * kFine;
-  const int lane = threadIdx.x;
-  const int ix = tx + (lane % kFine), iy = ty + (lane / kFine);
-  const bool live = ix < n && iy < m;
-  if (dyn) {
-    L = dyn->L;
-    k = min(k, L);
-    if (dyn->mode != 0) {  // the interpolator's trivial cases (decorators.py:199-208): constant field
-      if (live) {
-        out[static_cast<size_t>(iy) * n + ix] = dyn->cu;
-        out[static_cast<size_t>(m) * n + static_cast<size_t>(iy) * n + ix] = dyn->cv;
-      }
-      return;
-    }
-  }
-  const float px = x0 + dx_grid * static_cast<float>(ix);
-  const float py = y0 + dy_grid * static_cast<float>(iy);
-  const size_t plane = static_cast<size_t>(m) * n;
-  const int sup = (ty / kSuper) * supers_x + tx / kSuper;
-  const SuperHeader hdr = headers[sup];
-  const float4 *list = lists + static_cast<size_t>(sup) * kSuperCap;
-  const int n_s = __builtin_amdgcn_readfirstlane(hdr.count);
-
-  bool brute = k >= L || n_s > kSuperCap || n_s < k;
-  int n_sure = 0, n_ring = 0;
-  if (!brute) {
-    const int wx = min(kFine, n - tx), wy = min(kFine, m - ty);
-    const float cx = x0 + dx_grid * (static_cast<float>(tx) + 0.5f * static_cast<float>(wx - 1));
-    const float cy = y0 + dy_grid * (static_cast<float>(ty) + 0.5f * static_cast<float>(wy - 1));
-    const float hx = 0.5f * fabsf(dx_grid) * static_cast<float>(wx - 1);
-    const float hy = 0.5f * fabsf(dy_grid) * static_cast<float>(wy - 1);
-    const float half_diag = sqrtf(hx * hx + hy * hy);
-    constexpr int kPerLane = kSuperCap / 64;
-    const int chunks = (n_s + 63) >> 6;  // (uniform)
-    float4 c[kPerLane];
-    unsigned key[kPerLane];  // bits of the squared centre distance; missing entries: +inf
-#pragma unroll
-    for (int j = 0; j < kPerLane; ++j) {
-      key[j] = 0x7f800000u;
-      c[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < chunks) {
-        const int i = j * 64 + lane;
-        if (i < n_s) {
-          c[j] = list[i];
-          key[j] = __float_as_uint(dist2(c[j].x, c[j].y, cx, cy));
-        }
-      }
-    }
-    // k-th smallest key: the largest T with fewer than k keys below it, built from the top bit
-    unsigned T = 0u;
-#pragma unroll
-    for (int bit = 30; bit >= 6; --bit) {
-      const unsigned t = T | (1u << bit);
-      int below = 0;
-#pragma unroll
-      for (int j = 0; j < kPerLane; ++j)
-        if (j < chunks) below += __popcll(__ballot(key[j] < t));
-      if (below < k) T = t;
-    }
-    // T <= (k-th smallest squared distance) < T + 64 ulp
-    const float r_lo = fast_sqrt(__uint_as_float(T)) * (1.f - 1e-6f);
-    const float r_hi = fast_sqrt(__uint_as_float(T + 64u)) * (1.f + 1e-6f);
-    const float reach = r_hi + 2.f * half_diag + 1e-3f * (r_hi + half_diag);
-    const float sure_below = r_lo - 2.f * half_diag - 1e-3f * (r_lo + half_diag);
-    const float reach2 = reach * reach;
-    const float sure2 = sure_below > 0.f ? sure_below * sure_below : -1.f;
-    // certain vectors first, then the undecided ring, each in list (= index) order
-    unsigned long long sure_mask[kPerLane], ring_mask[kPerLane];
-    int tot_sure = 0, tot_ring = 0;
-#pragma unroll
-    for (int j = 0; j < kPerLane; ++j) {
-      sure_mask[j] = ring_mask[j] = 0ull;
-      if (j < chunks) {
-        const float d2 = __uint_as_float(key[j]);
-        const bool sure = d2 <= sure2;
-        sure_mask[j] = __ballot(sure);
-        ring_mask[j] = __ballot(!sure && d2 <= reach2);
-        tot_sure += __popcll(sure_mask[j]);
-        tot_ring += __popcll(ring_mask[j]);
-      }
-    }
-    n_sure = tot_sure;
-    n_ring = tot_ring;
-    brute = n_sure + n_ring > kFineCap;  // pathological clustering: exact brute force
-    if (!brute) {
-      const unsigned long long lt = (1ull << lane) - 1ull;
-      int at_sure = 0, at_ring = n_sure;
-#pragma unroll
-      for (int j = 0; j < kPerLane; ++j) {
-        if (j < chunks) {
-          const bool sure = (sure_mask[j] >> lane) & 1ull, ring = (ring_mask[j] >> lane) & 1ull;
-          const int slot = sure ? at_sure + __popcll(sure_mask[j] & lt) : at_ring + __popcll(ring_mask[j] & lt);
-          if (sure || ring) s_cand[slot] = c[j];
-          at_sure += __popcll(sure_mask[j]);
-          at_ring += __popcll(ring_mask[j]);
-        }
-      }
-    }
-    __syncthreads();  // (one wave: orders the LDS writes before the broadcast reads)
-  }
-  if (!live) return;
-  float ou, ov;
-  if (brute) {
-    idw_pixel_global<KMAX>(xy, uv, L, k, px, py, inv_res, power, offset, ou, ov);
-  } else {
-    float sw = 0.f, su = 0.f, sv = 0.f;
-    for (int i = 0; i < n_sure; ++i) {  // in every pixel's neighbourhood: no selection
-      const float4 c = s_cand[i];       // same address in every lane: LDS broadcast
-      const float w = idw_weight(fast_sqrt(dist2(c.x, c.y, px, py)) * inv_res, power, offset);
-      sw += w;
-      su += w * c.z;
-      sv += w * c.w;
-    }
-    const int need = k - n_sure;  // >= 1: fewer than k vectors lie strictly inside R_lo
-    if (n_ring <= 8) {
-      // small ring: every member ranks itself among the others (ties: lower index first, as the
-      // second sweep of add_nearest takes them), the `need` first of that order are added
-      float d2[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        d2[j] = INFINITY;
-        if (j < n_ring) {
-          const float4 c = s_cand[n_sure + j];
-          d2[j] = dist2(c.x, c.y, px, py);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j < n_ring) {
-          int rank = 0;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            if (i != j && i < n_ring) rank += (d2[i] < d2[j] || (i < j && d2[i] == d2[j])) ? 1 : 0;
-          }
-          if (rank < need) {
-            const float4 c = s_cand[n_sure + j];
-            const float w = idw_weight(fast_sqrt(d2[j]) * inv_res, power, offset);
-            sw += w;
-            su += w * c.z;
-            sv += w * c.w;
-          }
-        }
-      }
-    } else if (need <= 8) {
-      add_nearest<8>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
-    } else {
-      add_nearest<KMAX>(s_cand, n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
-    }
-    ou = su / sw;
-    ov = sv / sw;
-  }
-  out[static_cast<size_t>(iy) * n + ix] = ou;
-  out[plane + static_cast<size_t>(iy) * n + ix] = ov;
-}
-
-// ---- fine pass, third form (default): two pixels per lane --------------------------------------
-// Counters of idw_fine2 (profiles/r04): the pass is bound by instruction issue - one wave-wide
-// VALU instruction occupies a SIMD for four cycles on this chip whatever its type, the sum loop is a
-// chain of dependent operations behind an LDS read, and every wave repeats the tile prologue.  Here
-// a wave owns a 16 x 8 tile and a lane the two pixels (x, y), (x + 8, y): the per-vector arithmetic of
-// the pair runs in packed FP32 instructions (v_pk_add / v_pk_mul / v_pk_fma_f32: IEEE per
-// component, so each pixel's operations and their order are those of idw_fine), only the two
-// transcendentals stay scalar; two vectors are in flight per loop iteration (four independent chains),
-// and the prologue is paid once per 128 pixels.  The tile's half diagonal grows from 4.9 to 8.3 pixels,
-// so the undecided ring holds ~1.7 times as many vectors - small against what the packing saves.
+// ---- fine pass: one wave per 16 x 8 tile, two pixels per lane ----------------------------------
+// The supertile lists are short (30-60 vectors), so the k-th smallest centre distance of the tile is
+// found EXACTLY - and without LDS - by bisection on the bit patterns of the squared distances (a
+// non-negative float orders like its bits): 25 rounds of one compare + ballot + scalar popcount fix
+// the value up to its 6 lowest mantissa bits.  Squared distances are classified against squared
+// radii (no square root per vector), the certain and the undecided vectors are compacted into LDS with
+// one ballot each, and a small ring (<= 8 vectors, the rule at the reference's density) is ranked
+// pairwise in registers instead of going through the replace-the-maximum set.  Per pixel: dist2, the
+// weight, the sums in the order "certain vectors in index order, then the chosen ring vectors in index
+// order".
+// The pass is bound by instruction issue (counters of the one-pixel-per-lane forms of rounds 2-4,
+// profiles/r04/d_idw_fine_pmc.csv, deleted after the comparison in e_idw_ab.txt): one wave-wide VALU
+// instruction occupies a SIMD for four cycles on this chip whatever its type, the sum loop is a chain
+// of dependent operations behind an LDS read, and every wave repeats the tile prologue.  So a wave owns
+// a 16 x 8 tile and a lane the two pixels (x, y), (x + 8, y): the per-vector arithmetic of the pair
+// runs in packed FP32 instructions (v_pk_add / v_pk_mul / v_pk_fma_f32: IEEE per component, each
+// pixel's operations and their order unchanged), only the two transcendentals stay scalar; two vectors
+// are in flight per loop iteration (four independent chains), and the prologue is paid once per 128
+// pixels.  Against an 8 x 8 tile the half diagonal grows from 4.9 to 8.3 pixels, so the undecided ring
+// holds ~1.7 times as many vectors - small against what the packing saves.
 typedef float float2v __attribute__((ext_vector_type(2)));
 constexpr int kFineW = 16, kFineH = 8;
 
@@ -1096,8 +788,8 @@ __global__ __launch_bounds__(64) void idw_fine3(const float2 *__restrict__ xy, c
 
 }  // namespace
 
-// 0 = two-level, two pixels per lane (default), 3 = two-level, bisection fine pass, 2 = two-level with the histogram
-// fine pass, 1 = one pre-pass per 16x16 tile
+// 0 = two-level (default), 1 = one pre-pass per 16x16 tile (kept as the independent second
+// implementation tests/test_idw_gpu.py compares with)
 static int g_idw_variant = [] {
   const char *e = std::getenv("PYSTEPS_HIP_IDW_VARIANT");
   return e ? std::atoi(e) : 0;
@@ -1127,23 +819,13 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
       hipError_t e = hipMemsetAsync(headers, 0, n_super * sizeof(SuperHeader), stream);
       if (e != hipSuccess) return e;
     }
-    const bool two_px = g_idw_variant != 2 && g_idw_variant != 3;
-    const int tile_w = two_px ? kFineW : kFine, tile_h = two_px ? kFineH : kFine;
-    const int tiles_x = (a.n + tile_w - 1) / tile_w, tiles_y = (a.m + tile_h - 1) / tile_h;
+    const int tiles_x = (a.n + kFineW - 1) / kFineW, tiles_y = (a.m + kFineH - 1) / kFineH;
     const int n_tiles = tiles_x * tiles_y;
     const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
     const dim3 grid(tiles_per_xcd * kNumXcd), block(64);
-#define PSH_IDW_FINE_ARGS                                                                              \
-  grid, block, 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0, a.dx, a.y0, a.dy, a.inv_res, a.power, a.offset, \
-      a.out, supers_x, headers, lists, tiles_x, n_tiles, tiles_per_xcd, a.dyn
-#define PSH_IDW_FINE(KMAX)                                          \
-  if (g_idw_variant == 2) {                                         \
-    hipLaunchKernelGGL((idw_fine<KMAX>), PSH_IDW_FINE_ARGS);        \
-  } else if (g_idw_variant == 3) {                                  \
-    hipLaunchKernelGGL((idw_fine2<KMAX>), PSH_IDW_FINE_ARGS);       \
-  } else {                                                          \
-    hipLaunchKernelGGL((idw_fine3<KMAX>), PSH_IDW_FINE_ARGS);       \
-  }
+#define PSH_IDW_FINE(KMAX)                                                                                           \
+  hipLaunchKernelGGL((idw_fine3<KMAX>), grid, block, 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0, a.dx, a.y0, a.dy, \
+                     a.inv_res, a.power, a.offset, a.out, supers_x, headers, lists, tiles_x, n_tiles, tiles_per_xcd, a.dyn)
     if (k_eff <= 8) {
       PSH_IDW_FINE(8);
     } else if (k_eff <= 20) {
@@ -1152,7 +834,6 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
       PSH_IDW_FINE(32);
     }
 #undef PSH_IDW_FINE
-#undef PSH_IDW_FINE_ARGS
     return hipGetLastError();
   }
   const int tiles_x = (a.n + kTile - 1) / kTile;

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(kTileThreads) void polar_count(const uint32_t *__re
 // out first; the state a draw without new attempts leaves behind
 __global__ __launch_bounds__(1024) void polar_scan(unsigned *__restrict__ tile_counts, unsigned ntiles,
                                                    const RngDyn *__restrict__ dyn_in, RngDyn *__restrict__ dyn_out,
-                                                   unsigned long long count, double *__restrict__ out) {
+                                                   unsigned long long count, double *__restrict__ out,
+                                                   int *__restrict__ err_flag) {
   __shared__ unsigned s_wave[16];
   __shared__ unsigned s_carry;
   const unsigned b = blockIdx.x;
@@ -297,7 +298,10 @@ __global__ __launch_bounds__(1024) void polar_scan(unsigned *__restrict__ tile_c
       o.has_gauss = 0;
       o.gauss = 0.0;
     }
-    if (need > s_carry) o.err = 1;  // window too short: the values of this draw are incomplete
+    if (need > s_carry) {  // window too short: the values of this draw are incomplete
+      o.err = 1;
+      *err_flag = 1;  // (pinned host word: psh_rng_check() reads it without touching the device)
+    }
     dyn_out[b] = o;  // polar_write's closing attempt overwrites pos / gauss when need > 0
   }
 }
@@ -386,6 +390,7 @@ struct Rng {
   hipStream_t stream = nullptr;  // own stream: draws can run beside the main stream
   hipEvent_t ready = nullptr, fence = nullptr;
   bool on_side = false;  // the last draw ran on `stream` and has not been joined yet
+  int *err_flag = nullptr;  // pinned host word the scan kernel raises when a stream's window ran short
 };
 
 unsigned long long window_for(unsigned long long pairs) {
@@ -426,6 +431,7 @@ void rng_free(Rng *r) {
   if (r->dyn) (void)hipFree(r->dyn);
   if (r->tiles) (void)hipFree(r->tiles);
   if (r->bases) (void)hipFree(r->bases);
+  if (r->err_flag) (void)hipHostFree(r->err_flag);
   if (r->ready) (void)hipEventDestroy(r->ready);
   if (r->fence) (void)hipEventDestroy(r->fence);
   if (r->stream) (void)hipStreamDestroy(r->stream);
@@ -468,6 +474,8 @@ extern "C" int psh_rng_create(int n_streams, const uint32_t *keys_host, const in
     PSH_HIP(hipMalloc(reinterpret_cast<void **>(&r->rings), static_cast<size_t>(n_streams) * r->ring_words * 4));
     PSH_HIP(hipMalloc(reinterpret_cast<void **>(&r->dyn), 2 * static_cast<size_t>(n_streams) * sizeof(psh::RngDyn)));
     PSH_HIP(hipMalloc(reinterpret_cast<void **>(&r->tiles), static_cast<size_t>(n_streams) * r->max_tiles * 4));
+    PSH_HIP(hipHostMalloc(reinterpret_cast<void **>(&r->err_flag), sizeof(int), hipHostMallocDefault));
+    *r->err_flag = 0;
     PSH_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
     PSH_HIP(hipEventCreateWithFlags(&r->ready, hipEventDisableTiming));
     PSH_HIP(hipEventCreateWithFlags(&r->fence, hipEventDisableTiming));
@@ -545,7 +553,8 @@ extern "C" int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, in
   // k - ring_blocks, which has to lie below every stream's position
   auto blocks_wanted = [&]() { return static_cast<unsigned long long>((r->hi + 4.0 * static_cast<double>(window)) / psh::kMtN) + 2; };
   auto fits = [&](unsigned long long want) {
-    return want <= r->ring_blocks || static_cast<double>(want - r->ring_blocks) * psh::kMtN <= r->lo;
+    // (one block of slack: get_state reads the block that holds word pos - 1)
+    return want <= r->ring_blocks || static_cast<double>(want - r->ring_blocks + 1) * psh::kMtN <= r->lo;
   };
   unsigned long long want_blocks = blocks_wanted();
   if (want_blocks > r->produced_blocks && !fits(want_blocks)) {
@@ -591,7 +600,7 @@ extern "C" int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, in
   hipLaunchKernelGGL(psh::polar_count, dim3(ntiles, r->streams), dim3(psh::kTileThreads), 0, s, r->rings, r->ring_words, din,
                      window, ntiles, r->tiles);
   hipLaunchKernelGGL(psh::polar_scan, dim3(r->streams), dim3(1024), 0, s, r->tiles, ntiles, din, dout,
-                     static_cast<unsigned long long>(count), out_dev);
+                     static_cast<unsigned long long>(count), out_dev, r->err_flag);
   hipLaunchKernelGGL(psh::polar_write, dim3(ntiles, r->streams), dim3(psh::kTileThreads), 0, s, r->rings, r->ring_words, din, dout,
                      window, ntiles, r->tiles, static_cast<unsigned long long>(count), out_dev);
   PSH_HIP(hipGetLastError());
@@ -623,6 +632,15 @@ extern "C" int psh_rng_wait(void *handle) {
     PSH_HIP(hipStreamWaitEvent(c.stream, r->ready, 0));
     r->on_side = false;
   }
+  return PSH_OK;
+}
+
+extern "C" int psh_rng_check(void *handle) {
+  PSH_REQUIRE_INIT();
+  psh::Rng *r = static_cast<psh::Rng *>(handle);
+  if (!r) return fail(PSH_EINVAL, "rng_check: NULL handle");
+  if (*static_cast<volatile int *>(r->err_flag))
+    return fail(PSH_EHIP, "rng: a stream ran out of accepted attempts inside its window (a > 10 sigma event): the draw is incomplete");
   return PSH_OK;
 }
 

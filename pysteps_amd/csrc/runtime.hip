@@ -250,9 +250,7 @@ int psh_set_option(const char *key, int value) {
     return PSH_OK;
   }
   if (std::strcmp(key, "idw_variant") == 0) {
-    if (value < 0 || value > 3)
-      return fail(PSH_EINVAL, "idw_variant must be 0 (two-level, two pixels per lane), 3 (two-level, bisection fine pass), "
-                              "2 (two-level, histogram fine pass) or 1 (pre-pass per 16x16 tile)");
+    if (value < 0 || value > 1) return fail(PSH_EINVAL, "idw_variant must be 0 (two-level) or 1 (pre-pass per 16x16 tile)");
     psh::set_idw_variant(value);
     return PSH_OK;
   }

@@ -71,6 +71,10 @@ class DeviceRandomStates:
         """Make the library stream wait for a ``side=True`` draw."""
         _lib.check(self._lib.psh_rng_wait(self._h), "psh_rng_wait")
 
+    def check(self):
+        """Raise when a draw that has completed came out short (no device work, see ``psh_rng_check``)."""
+        _lib.check(self._lib.psh_rng_check(self._h), "psh_rng_check")
+
     def get_states(self):
         """The generators' states in ``RandomState.get_state()`` form (waits for the queued draws)."""
         k = np.empty((self.n, 624), dtype=np.uint32)

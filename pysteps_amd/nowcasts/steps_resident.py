@@ -19,12 +19,23 @@ patched in one by one (round 2) every call still crossed PCIe twice.
 It is built from the ``state`` / ``params`` dictionaries the reference hands to ``nowcast_main_loop``
 (steps.py:1014-1055) - the drop-in point is the loop (``register(patch_main_loop=True)``), not a fork
 of the nowcaster - and :func:`try_create` declines (returns None, the reference's own update function
-runs) whenever an option is set that the chain does not implement: spectral domain, ``use_full_fft``
-filters, non power-of-two grids, the ``sprog`` mask, no noise.
+runs) whenever an option is set that the chain does not implement: ``domain="spectral"``, ``use_full_fft``
+filters, no noise, grid sides beyond the FFT kernels (any side up to 4096 is fine, powers of two up to
+8192), more than 16 cascade levels or AR order above 8.  ``mask_method`` None / ``"incremental"`` /
+``"obs"`` / ``"sprog"`` and ``probmatching_method`` None / ``"cdf"`` / ``"mean"`` are implemented.  A failure
+while the device state is being built (out of memory, a generator the device streams do not reproduce)
+also ends in the reference's update, with a warning.
 
-Parity: every element-wise step is the reference's arithmetic, operation by operation (csrc/steps_loop.hip);
-the transforms agree with numpy.fft to ~1e-16; the random stream is NumPy's up to the rounding of
-``log`` (csrc/cr_log.h).  tests/test_steps_resident_gpu.py runs the real ``nowcasts.steps`` both ways.
+Parity - what a caller who patches the main loop gets.  The DEFAULT update keeps the AR history as spectra
+(two transforms per member update instead of nine; the level variances come from Parseval's identity):
+its fields are those of the reference's spatial chain up to rounding - not bit for bit: held in
+tests/test_steps_resident_gpu.py to identical NaN masks, at most 1e-5 of the pixels decided differently by
+a threshold or a rank (observed: none), median difference <= 1e-14 of the field's range, generator states
+equal, and end to end to 1e-4 relative L2 against the stock ``nowcasts.steps`` (observed 8e-8).
+``PYSTEPS_HIP_RESIDENT_DOMAIN=spatial`` selects the chain of the reference's spatial operators instead,
+whose element-wise steps are the reference's arithmetic operation by operation (csrc/steps_loop.hip,
+bit-identical with ``iterate_ar_model`` + ``recompose_fft``).  In both the transforms agree with numpy.fft
+to ~1e-16 and the random stream is NumPy's up to the rounding of ``log`` (csrc/cr_log.h).
 """
 
 import ctypes
@@ -339,6 +350,9 @@ class ResidentSteps:
         """One ``__update_state``: float64 DeviceArray ``(n_members, m, n)`` of the members' new fields."""
         lib, m, n, plane = self._lib, self.m, self.n, self.plane
         slot = self.done & 1
+        # the draws of the time steps whose fields the caller has read back are complete: a short one
+        # (stale values in the tail of its buffer) stops the nowcast here, not at finish()
+        self.rng.check()
         if not self._white_ready:
             self._draw(slot)
         self.rng.wait()
@@ -398,6 +412,7 @@ class ResidentSteps:
             # ONE wait per time step: a member the bucket pass declined (thousands of tied wet values) is
             # matched by the reference's function from its kept field, its mask update is redone
             status = self.pm_status.to_host()
+            self.rng.check()  # (this time step's draw is behind that wait)
             for j in range(self.B):
                 if status[j] == 0:
                     continue

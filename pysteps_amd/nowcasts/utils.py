@@ -166,17 +166,23 @@ def bps_perturbators(velocity_pert_gen, velocity):
                         p_perp=tuple(vp["p_perp"]), vsf=float(vp["vsf"]), time_scale=scale))
     if not out:
         return None
-    # EVERY generator against its closed form on this motion field, on a regular sub-grid (~256 x 256
-    # samples: a perturbator built from another motion field differs everywhere, and one evaluation
-    # on the full 4096^2 grid costs 0.4 s of a 1.2 s main loop)
+    # EVERY generator against its closed form on this motion field, on a sub-grid of ~512 x 512 samples
+    # whose offset is drawn anew on every call (a perturbator built from another - shifted, filtered -
+    # motion field differs everywhere; one evaluation on the full 4096^2 grid costs 0.4 s of a 1.2 s
+    # main loop).  The closed form follows noise/motion.py:129-133 in the velocity's own dtype: a float32
+    # motion field is normalised in float32 there
     vel = np.asarray(velocity)
     if vel.ndim != 3 or vel.shape[0] != 2:
         return None
-    step = max(1, min(vel.shape[1:]) // 256)
-    sub = (slice(None), slice(None, None, step), slice(None, None, step))
-    vel = np.asarray(vel[sub], dtype=np.float64)
+    step = max(1, min(vel.shape[1:]) // 512)
+    oy, ox = (int(v) for v in np.random.default_rng().integers(0, step, size=2))
+    sub = (slice(None), slice(oy, None, step), slice(ox, None, step))
+    vel = np.ascontiguousarray(vel[sub])
+    if vel.dtype.kind != "f":
+        vel = vel.astype(np.float64)
+    rtol = 1e-9 if vel.dtype.itemsize >= 8 else 1e-6
     norm = np.linalg.norm(vel, axis=0)
-    unit = np.where(norm > 1e-12, vel / np.where(norm > 1e-12, norm, 1.0), 0.0)
+    unit = np.where(norm > 1e-12, vel / np.where(norm > 1e-12, norm, 1.0), 0.0).astype(np.float64)
     perp = np.stack([-unit[1], unit[0]])
     t = 1.5
     for fn, p in zip(velocity_pert_gen, out):
@@ -189,7 +195,7 @@ def bps_perturbators(velocity_pert_gen, velocity):
             if np.shape(vp["V_par"]) != np.shape(velocity) or np.shape(vp["V_perp"]) != np.shape(velocity):
                 return None
             thin = dict(vp, V_par=np.asarray(vp["V_par"])[sub], V_perp=np.asarray(vp["V_perp"])[sub])
-            if not np.allclose(fn(t, vp=thin), closed, rtol=1e-9, atol=1e-12):
+            if not np.allclose(fn(t, vp=thin), closed, rtol=rtol, atol=1e-12):
                 return None
         except Exception:
             return None

@@ -212,7 +212,12 @@ def register(override=False, patch_main_loop=False, fft=True, probmatching=False
     (:func:`pysteps_amd.nowcasts.utils.nowcast_main_loop`) in the nowcast modules: with
     ``extrap_method="semilagrangian_hip"`` all ensemble members are then advected by one kernel
     launch per time step and their trajectories stay in HBM; any other extrapolator runs exactly as
-    before.  :func:`unpatch_main_loop` restores the reference loop."""
+    before.  With that loop ``nowcasts.steps`` also runs its member update on device-resident state
+    (:mod:`pysteps_amd.nowcasts.steps_resident`).  Parity level of that update: the default keeps the AR
+    history as spectra and reproduces the reference's fields up to rounding, not bit for bit (identical NaN
+    masks, no pixel decided differently by a threshold or a rank in the tests, 8e-8 relative L2 end to end);
+    ``PYSTEPS_HIP_RESIDENT_DOMAIN=spatial`` selects the chain of spatial operators whose element-wise steps
+    are bit-identical with the reference's.  :func:`unpatch_main_loop` restores the reference loop."""
     import pysteps.extrapolation.interface as ext_if  # noqa: PLC0415
     import pysteps.motion.interface as mot_if  # noqa: PLC0415
 

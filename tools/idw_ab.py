@@ -1,4 +1,5 @@
-"""IDW fine-pass variants side by side (development aid): time per call and the difference of the
+"""IDW variants side by side (development aid; the round-4 comparison of the fine passes in
+profiles/r04/e_idw_ab.txt was made with this script when variants 2 and 3 still existed): time per call and the difference of the
 fields, plus the difference from the cKDTree oracle on a sample of pixels.
 
     python tools/idw_ab.py [size] [L]
@@ -21,7 +22,7 @@ for L in Ls:
     uv = rng.normal(0, 2, (L, 2))
     fields = {}
     for k in (20, 5):
-        for variant in (2, 3, 0):
+        for variant in (1, 0):
             _lib.check(lib.psh_set_option(b"idw_variant", variant))
             out = idw_to_device(xy, uv, m, n, k=k)
             synchronize()
@@ -33,7 +34,7 @@ for L in Ls:
             ms = e0.elapsed_ms(e1) / 5
             fields[variant] = out.to_host()
             print("L=%d k=%d variant %d: %.3f ms/call (incl. upload)" % (L, k, variant, ms))
-        d = np.abs(fields[0] - fields[2])
+        d = np.abs(fields[0] - fields[1])
         print("   variants differ: max abs %.3e, fraction of pixels %.3e" % (d.max(), np.mean(d > 0)))
         # oracle on a pixel sample (float64 cKDTree, reference formula)
         from scipy.spatial import cKDTree
