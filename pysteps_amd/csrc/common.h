@@ -185,7 +185,12 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
 size_t lk_prepare_ws_bytes(int m, int n, bool f64);
 int lk_prepare_on(hipStream_t stream, void *ws, const void *frame_dev, bool f64, int m, int n, int size_opening,
                   int buffer_mask, float *clean_dev, unsigned char *track_u8_dev, unsigned char *feature_u8_dev,
-                  float *stats_dev, unsigned *slots_cleared = nullptr);
+                  float *stats_dev, unsigned *slots_cleared = nullptr, unsigned long long *keepbits = nullptr);
+// clean_dev == nullptr (float32 frames only): the cleaned frame is not stored; keepbits (lk_keepbits_bytes(m, n)
+// of device memory) receives one bit per pixel - "keeps its value" (finite and not removed by the opening) - and
+// the renderings are made from the frame and these bits.  The corner passes then take the FRAME as clean_dev:
+// they only read its NaN pattern, which the cleaning does not change
+size_t lk_keepbits_bytes(int m, int n);
 // Statistic slots of one frame (lk.hip): lk_slot_bytes() of zero-filled device memory that the frame passes and
 // the corner passes of the SAME frame fold their minima / maxima into instead of going through a
 // single-workgroup finishing kernel; a caller that passes none gets them cleared by a fill launch

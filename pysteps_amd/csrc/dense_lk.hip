@@ -67,7 +67,9 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   auto frame_ptr = [&](int t) { return reinterpret_cast<const char *>(frames_dev) + static_cast<size_t>(t) * frame_bytes; };
   for (int t = 0; t < nframes; ++t) {
     const bool want_feat = t < nframes - 1;
-    if (int rc = clean[t].alloc(plane * sizeof(float))) return rc;
+    // float32 frames: no cleaned copy in memory (one keep bit per pixel instead; the corner passes read the
+    // NaN pattern from the frame itself).  float64 frames keep the float32 copy their passes write
+    if (int rc = clean[t].alloc(f64 ? plane * sizeof(float) : psh::lk_keepbits_bytes(m, n))) return rc;
     if (int rc = trk[t].alloc(plane)) return rc;
     if (want_feat)
       if (int rc = feat[t].alloc(plane)) return rc;
@@ -101,10 +103,12 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   if (nframes > 1)
     if (int rc = ws_side.alloc(psh::lk_prepare_ws_bytes(m, n, f64))) return rc;
   auto prepare = [&](int t, hipStream_t stream, void *ws) {
-    return psh::lk_prepare_on(stream, ws, frame_ptr(t), f64, m, n, prm->size_opening, prm->buffer_mask, clean[t].as<float>(),
-                              trk[t].as<unsigned char>(), t < nframes - 1 ? feat[t].as<unsigned char>() : nullptr,
-                              stats[t].as<float>(), f64 ? nullptr : frame_slots(t));
+    return psh::lk_prepare_on(stream, ws, frame_ptr(t), f64, m, n, prm->size_opening, prm->buffer_mask,
+                              f64 ? clean[t].as<float>() : nullptr, trk[t].as<unsigned char>(),
+                              t < nframes - 1 ? feat[t].as<unsigned char>() : nullptr, stats[t].as<float>(),
+                              f64 ? nullptr : frame_slots(t), f64 ? nullptr : clean[t].as<unsigned long long>());
   };
+  auto nan_pattern = [&](int t) { return f64 ? clean[t].as<float>() : reinterpret_cast<const float *>(frame_ptr(t)); };
   if (int rc = prepare(0, c.stream, ws_main.p)) return rc;
 
   // ---- per frame pair: features, tracking, pooling (:207-242) ---------------------------
@@ -140,7 +144,7 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
     };
     int walk_stats[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)build_pyramids(&fork);  // queued behind the frame passes on the side stream
-    const int rc1 = psh::lk_corners_resident(feat[t].as<unsigned char>(), clean[t].as<float>(),
+    const int rc1 = psh::lk_corners_resident(feat[t].as<unsigned char>(), nan_pattern(t),
                                              stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
                                              prm->quality_level, prm->min_distance, prm->max_corners, d_pts, d_npts,
                                              nullptr, nullptr, trace ? walk_stats : nullptr, frame_slots(t));

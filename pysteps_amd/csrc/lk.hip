@@ -166,14 +166,16 @@ __global__ __launch_bounds__(256) void lk_stats1(const float *__restrict__ img, 
     mn = fminf(mn, fin ? v : INFINITY);
     bad += fin ? 0.f : 1.f;
   };
-  // 16-byte loads, two in flight per thread (a streaming read is bound by bytes in flight)
+  // 16-byte loads, four in flight per thread (a streaming read is bound by bytes in flight)
   const size_t n4 = (reinterpret_cast<uintptr_t>(img) % 16 == 0) ? npx / 4 : 0;
   const float4 *img4 = reinterpret_cast<const float4 *>(img);
   size_t i = first;
-  for (; i + stride < n4; i += 2 * stride) {
-    const float4 a = img4[i], b = img4[i + stride];
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = img4[i], b = img4[i + stride], c = img4[i + 2 * stride], d = img4[i + 3 * stride];
     take(a.x), take(a.y), take(a.z), take(a.w);
     take(b.x), take(b.y), take(b.z), take(b.w);
+    take(c.x), take(c.y), take(c.z), take(c.w);
+    take(d.x), take(d.y), take(d.z), take(d.w);
   }
   for (; i < n4; i += stride) {
     const float4 a = img4[i];
@@ -221,185 +223,45 @@ __global__ __launch_bounds__(kFinalThreads) void lk_stats1_final(const float *__
 // ---- pass 2: binary opening (3x3 cross) + statistics of the cleaned frame ------
 // field = (filled > min).  Opening = erode then dilate with the plus-shaped 3x3
 // element, image border neutral.  Pixels of the field that the opening removes
-// are set to the minimum (images.py:78-81).  64x4 tile + 2-pixel halo in LDS.
-constexpr int kOpenTX = 64, kOpenTY = 16;  // 4 pixels per thread: halo overhead 1.33x
-
-__global__ __launch_bounds__(256) void lk_open(const float *__restrict__ img, int m, int n,
-                                               int size_opening, int buffer_mask,
-                                               const float *__restrict__ stats,
-                                               float *__restrict__ clean,
-                                               float *__restrict__ partial, Band band) {
-  __shared__ unsigned char fld[kOpenTY + 4][kOpenTX + 4];  // 1 = in field, 2 = outside the image
-  __shared__ unsigned char ero[kOpenTY + 2][kOpenTX + 2];
-  __shared__ float red[3][4];
-  const float mn = stats[kMinAll];
-  const int x0 = blockIdx.x * kOpenTX, y0 = blockIdx.y * kOpenTY;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < (kOpenTY + 4) * (kOpenTX + 4); i += 256) {
-    const int ly = i / (kOpenTX + 4), lx = i % (kOpenTX + 4);
-    const int y = y0 + ly - 2, x = x0 + lx - 2;
-    unsigned char f = 2;
-    if (x >= 0 && x < n && y >= 0 && y < m) {
-      const float v = img[static_cast<size_t>(y) * n + x];
-      f = (isfinite(v) && v > mn) ? 1 : 0;  // masked pixels are filled with the minimum
-    }
-    fld[ly][lx] = f;
-  }
-  __syncthreads();
-  for (int i = tid; i < (kOpenTY + 2) * (kOpenTX + 2); i += 256) {
-    const int ly = i / (kOpenTX + 2), lx = i % (kOpenTX + 2);
-    // erosion at (y0+ly-1, x0+lx-1); outside-image taps are neutral (count as set);
-    // the eroded value of an outside-image pixel is never used by the dilation
-    const int cy = ly + 1, cx = lx + 1;
-    const bool e = fld[cy][cx] == 1 && fld[cy - 1][cx] != 0 && fld[cy + 1][cx] != 0 &&
-                   fld[cy][cx - 1] != 0 && fld[cy][cx + 1] != 0;
-    ero[ly][lx] = e ? 1 : 0;
-  }
-  __syncthreads();
-  float mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
-  // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
-  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
-  for (int i = tid; i < kOpenTX * kOpenTY; i += 256) {
-    const int lx = i % kOpenTX, ly = i / kOpenTX;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x >= n || y >= m) continue;
-    float v = img[static_cast<size_t>(y) * n + x];
-    if (size_opening > 0 && isfinite(v) && v > mn) {
-      const int cy = ly + 1, cx = lx + 1;
-      const bool opened = ero[cy][cx] | ero[cy - 1][cx] | ero[cy + 1][cx] | ero[cy][cx - 1] |
-                          ero[cy][cx + 1];
-      if (!opened) v = mn;
-    }
-    clean[static_cast<size_t>(y) * n + x] = v;
-    if (isfinite(v) && y >= band.lo && y < band.hi) {
-      mx_all = fmaxf(mx_all, v);
-      if (y + band.y_org >= first_row) {
-        mn_feat = fminf(mn_feat, v);
-        mx_feat = fmaxf(mx_feat, v);
-      }
-    }
-  }
-  mx_all = wave_max(mx_all);
-  mn_feat = wave_min(mn_feat);
-  mx_feat = wave_max(mx_feat);
-  if ((tid & 63) == 0) {
-    red[0][tid >> 6] = mx_all;
-    red[1][tid >> 6] = mn_feat;
-    red[2][tid >> 6] = mx_feat;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const int b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
-    partial[b] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    partial[nb + b] = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
-    partial[2 * nb + b] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
-  }
-}
-
-// The same pass with 16-byte accesses (n a multiple of 4, 16-byte aligned planes): the haloed
-// field tile is fetched as float4 columns [x0 - 4, x0 + 68) and each thread opens and stores
-// four neighbouring pixels - a quarter of the vector memory instructions of lk_open.
-__global__ __launch_bounds__(256) void lk_open_vec(const float *__restrict__ img, int m, int n,
-                                                   int size_opening, int buffer_mask,
-                                                   const float *__restrict__ stats,
-                                                   float *__restrict__ clean,
-                                                   float *__restrict__ partial, Band band) {
-  constexpr int kW4 = kOpenTX / 4 + 2;  // float4 columns of the haloed tile
-  __shared__ unsigned char fld[kOpenTY + 4][kW4 * 4];  // column c <-> image x0 - 4 + c
-  __shared__ unsigned char ero[kOpenTY + 2][kOpenTX + 2];
-  __shared__ float red[3][4];
-  const float mn = stats[kMinAll];
-  const int x0 = blockIdx.x * kOpenTX, y0 = blockIdx.y * kOpenTY;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < (kOpenTY + 4) * kW4; i += 256) {
-    const int ly = i / kW4, c4 = i % kW4;
-    const int y = y0 + ly - 2, x = x0 - 4 + 4 * c4;
-    uchar4 f = make_uchar4(2, 2, 2, 2);
-    if (x >= 0 && x < n && y >= 0 && y < m) {  // n % 4 == 0: a float4 is inside or outside as a whole
-      const float4 v = *reinterpret_cast<const float4 *>(img + static_cast<size_t>(y) * n + x);
-      f.x = (isfinite(v.x) && v.x > mn) ? 1 : 0;  // masked pixels are filled with the minimum
-      f.y = (isfinite(v.y) && v.y > mn) ? 1 : 0;
-      f.z = (isfinite(v.z) && v.z > mn) ? 1 : 0;
-      f.w = (isfinite(v.w) && v.w > mn) ? 1 : 0;
-    }
-    *reinterpret_cast<uchar4 *>(&fld[ly][4 * c4]) = f;
-  }
-  __syncthreads();
-  for (int i = tid; i < (kOpenTY + 2) * (kOpenTX + 2); i += 256) {
-    const int ly = i / (kOpenTX + 2), lx = i % (kOpenTX + 2);
-    // erosion at (y0+ly-1, x0+lx-1); outside-image taps are neutral (count as set)
-    const int cy = ly + 1, cx = lx + 3;
-    const bool e = fld[cy][cx] == 1 && fld[cy - 1][cx] != 0 && fld[cy + 1][cx] != 0 &&
-                   fld[cy][cx - 1] != 0 && fld[cy][cx + 1] != 0;
-    ero[ly][lx] = e ? 1 : 0;
-  }
-  __syncthreads();
-  float mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
-  // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
-  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
-  {
-    const int lx = (tid % (kOpenTX / 4)) * 4, ly = tid / (kOpenTX / 4);
-    const int x = x0 + lx, y = y0 + ly;
-    if (x < n && y < m) {
-      float4 v4 = *reinterpret_cast<const float4 *>(img + static_cast<size_t>(y) * n + x);
-      float v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (size_opening > 0 && isfinite(v[j]) && v[j] > mn) {
-          const int cy = ly + 1, cx = lx + j + 1;
-          const bool opened = ero[cy][cx] | ero[cy - 1][cx] | ero[cy + 1][cx] | ero[cy][cx - 1] |
-                              ero[cy][cx + 1];
-          if (!opened) v[j] = mn;
-        }
-        if (isfinite(v[j]) && y >= band.lo && y < band.hi) {
-          mx_all = fmaxf(mx_all, v[j]);
-          if (y + band.y_org >= first_row) {
-            mn_feat = fminf(mn_feat, v[j]);
-            mx_feat = fmaxf(mx_feat, v[j]);
-          }
-        }
-      }
-      *reinterpret_cast<float4 *>(clean + static_cast<size_t>(y) * n + x) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-  }
-  mx_all = wave_max(mx_all);
-  mn_feat = wave_min(mn_feat);
-  mx_feat = wave_max(mx_feat);
-  if ((tid & 63) == 0) {
-    red[0][tid >> 6] = mx_all;
-    red[1][tid >> 6] = mn_feat;
-    red[2][tid >> 6] = mx_feat;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const int b = blockIdx.y * gridDim.x + blockIdx.x, nb = gridDim.x * gridDim.y;
-    partial[b] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    partial[nb + b] = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
-    partial[2 * nb + b] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
-  }
-}
-
-// The same pass with the morphology done on BIT MASKS (default).  The two LDS kernels above spend
-// their time in byte-sized LDS reads (11 per pixel); here a wave owns 64 image columns (the outer
-// two on each side are halo, 60 are written) and 16 output rows: it loads its 20 rows first (all
-// loads in flight together), turns every row into two 64-bit masks with one ballot each - F: field
-// pixel set, N: position outside the image (neutral for the erosion) - and the 3x3 cross becomes
-// shifts and ANDs / ORs of scalar registers:
-//    A = F | N;  E_y = F_y & (A_y << 1) & (A_y >> 1) & A_{y-1} & A_{y+1};
-//    O_y = E_y | (E_y << 1) | (E_y >> 1) | E_{y-1} | E_{y+1}
-// A lane then only keeps or replaces its own 16 values.  4 waves (64 output rows) per workgroup.
-constexpr int kOpenRowsW = 16;        // output rows per wave
+// are set to the minimum (images.py:78-81).
+// The morphology is done on BIT MASKS (rounds 1-2 staged tiles in LDS and spent the pass in
+// byte-sized LDS reads, 11 per pixel): a wave owns 64 image columns (the outer two on each side are
+// halo, 60 are written) and 32 output rows.  It loads its 36 rows first (all loads in flight together)
+// and turns every row into two 64-bit masks with one compare each - FIN: finite, F: above the minimum.
+// Rounds 3-4 then walked the rows with the masks in SCALAR registers: 1090 scalar instructions per wave,
+// the scalar pipe 62 % busy, 48 us at 4096^2 (profiles/r04/g_prep_pmc.csv).  Here the masks are
+// TRANSPOSED: row q's masks are moved into lane q, and the 3x3 cross becomes a handful of 64-bit
+// VALU operations for all rows at once - columns by shifts inside the word, rows by DPP moves between lanes:
+//    A = F | N (N: outside the image, neutral for the erosion);
+//    E_y = F_y & (A_y << 1) & (A_y >> 1) & A_{y-1} & A_{y+1};
+//    O_y = E_y | (E_y << 1) | (E_y >> 1) | E_{y-1} | E_{y+1};   removed = F & ~O;   keep = FIN & ~removed
+// Lane o ends up with the words of OUTPUT row o.  The keep words go to memory straight from the lanes; for
+// the statistics one mask per row (kept pixels of the written columns) comes back to scalar registers by
+// v_readlane and selects the values that count: a removed pixel becomes the minimum, which is below every
+// finite value, so max / min over the cleaned row = max / min over the kept values, folded with the minimum
+// if the row lost a pixel (a per-row flag from the transposed side).
+constexpr int kOpenRowsW = 16;        // float64 twin: output rows per wave
 constexpr int kOpenColsW = 60;        // output columns per wave (64 lanes - 2 x 2 halo)
 constexpr int kOpenRowsWG = 4 * kOpenRowsW;
+constexpr int kOpenRows32 = 32;       // this kernel: output rows per wave
+constexpr int kOpenRowsWG32 = 4 * kOpenRows32;
+
+__device__ __forceinline__ unsigned long long next_lane_u64(unsigned long long v) {  // lane i gets lane i + 1's word
+  const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x130, 0xf, 0xf, true));
+  const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v >> 32), 0x130, 0xf, 0xf, true));
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
 
 // slots != nullptr: minimum and NaN count are read from the statistic slots (lk_stats1 wrote them), the
-// results go there too, and workgroup (0, 0) writes the two input statistics into stats[] for later readers
+// results go there too, and workgroup (0, 0) writes the two input statistics into stats[] for later readers.
+// clean == nullptr: the cleaned frame is not stored, keepbits gets one word per (row, strip) instead
 __global__ __launch_bounds__(256) void lk_open_bits(const float *__restrict__ img, int m, int n,
                                                     int size_opening, int buffer_mask,
                                                     float *__restrict__ stats,
                                                     float *__restrict__ clean,
                                                     float *__restrict__ partial, Band band,
-                                                    unsigned *__restrict__ slots) {
+                                                    unsigned *__restrict__ slots,
+                                                    unsigned long long *__restrict__ keepbits) {
   __shared__ float red[3][4];
   const float mn = slots ? slots_min(slots, kSlMin) : stats[kMinAll];
   const float nan_count = slots ? slots_count(slots, kSlNan) : stats[kNanCount];
@@ -407,69 +269,95 @@ __global__ __launch_bounds__(256) void lk_open_bits(const float *__restrict__ im
     stats[kMinAll] = mn;
     stats[kNanCount] = nan_count;
   }
-  // (readfirstlane: the wave index is the same in every lane - row tests and masks stay scalar)
+  // (readfirstlane: the wave index is the same in every lane - row arithmetic stays scalar)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int x = blockIdx.x * kOpenColsW - 2 + lane;
-  const int yb = blockIdx.y * kOpenRowsWG + wave * kOpenRowsW;  // first output row of the wave
+  const int yb = blockIdx.y * kOpenRowsWG32 + wave * kOpenRows32;  // first output row of the wave
   const bool col_in = x >= 0 && x < n;
-  constexpr int kLoad = kOpenRowsW + 4;
-  float v[kLoad];
-#pragma unroll
-  for (int q = 0; q < kLoad; ++q) {
-    const int y = yb - 2 + q;
-    v[q] = (col_in && y >= 0 && y < m) ? img[static_cast<size_t>(y) * n + x] : 0.f;
-  }
-  // Everything that is the same for a whole row stays in scalar registers: per pixel the VALUs only
-  // see two compares (finite, above the minimum), the selects by wave mask (v_cndmask with the mask as
-  // its condition: __builtin_amdgcn_inverse_ballot_w64) and the three running statistics.  The rows are
-  // walked with rolling masks (row q enters, its erosion is known one row later, the opening of row
-  // q - 2 one row after that): a dozen 64-bit masks live at a time instead of eighty.
-  const unsigned long long colmask = __ballot(col_in);
+  constexpr int kLoad = kOpenRows32 + 4;
   float mx_all = -INFINITY, mn_feat = INFINITY, mx_feat = -INFINITY;
-  // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
-  const int first_row = buffer_mask > 0 ? (nan_count > 0.f ? 2 : 1) : 0;
-  const bool writer = lane >= 2 && lane < 2 + kOpenColsW && col_in;
-  const unsigned long long wmask = __ballot(writer);
-  unsigned long long A1 = 0ull, A2 = 0ull;                  // A of rows q - 1, q - 2
-  unsigned long long F1 = 0ull, F2 = 0ull;                  // F of rows q - 1, q - 2
-  unsigned long long FIN1 = 0ull, FIN2 = 0ull;              // finite pixels of rows q - 1, q - 2
-  unsigned long long E1 = 0ull, E2 = 0ull;                  // erosion of rows q - 2, q - 3
+  if (yb < m) {  // (uniform)
+    // every load is inside the image (clamped row and column): what lies outside is masked on the
+    // transposed side, no load waits for a branch
+    const float *colp = img + min(max(x, 0), n - 1);
+    float v[kLoad];
 #pragma unroll
-  for (int q = 0; q < kLoad; ++q) {
-    const int yq = yb - 2 + q;
-    const bool row_in = yq >= 0 && yq < m;  // (uniform)
-    const unsigned long long FIN0 = row_in ? (__ballot(isfinite(v[q])) & colmask) : 0ull;
-    const unsigned long long F0 = row_in ? (__ballot(v[q] > mn) & FIN0) : 0ull;  // masked pixels are filled with the minimum
-    const unsigned long long A0 = row_in ? (F0 | ~colmask) : ~0ull;  // outside the image: neutral for the erosion
-    const unsigned long long E0 = F1 & (A1 << 1) & (A1 >> 1) & A2 & A0;  // erosion of row q - 1 (valid from q = 2 on)
-    if (q >= 4) {
-      // output row q - 2: the dilation of the erosions of rows q - 3, q - 2, q - 1
-      const int y = yq - 2;
-      if (y < m) {  // (uniform)
-        const unsigned long long O = E1 | (E1 << 1) | (E1 >> 1) | E2 | E0;
-        const unsigned long long removed = size_opening > 0 ? (F2 & ~O) : 0ull;  // field pixels the opening takes away
-        const float val = __builtin_amdgcn_inverse_ballot_w64(removed) ? mn : v[q - 2];
-        // (a removed pixel was finite and the minimum is: val is finite exactly where the input was)
-        const unsigned long long counted = wmask & FIN2;
-        if (y >= band.lo && y < band.hi) {  // (uniform)
-          const float hi = __builtin_amdgcn_inverse_ballot_w64(counted) ? val : -INFINITY;
-          mx_all = max_plain(mx_all, hi);
-          if (y + band.y_org >= first_row) {  // (uniform)
-            mn_feat = min_plain(mn_feat, __builtin_amdgcn_inverse_ballot_w64(counted) ? val : INFINITY);
-            mx_feat = max_plain(mx_feat, hi);
-          }
-        }
-        if (writer) clean[static_cast<size_t>(y) * n + x] = val;
+    for (int q = 0; q < kLoad; ++q) v[q] = colp[static_cast<size_t>(min(max(yb - 2 + q, 0), m - 1)) * n];
+    unsigned f_lo = 0, f_hi = 0, fin_lo = 0, fin_hi = 0;  // lane q: masks of loaded row q
+#pragma unroll
+    for (int q = 0; q < kLoad; ++q) {
+      const unsigned long long fin = __ballot(isfinite(v[q]));
+      const unsigned long long f = __ballot(v[q] > mn);
+      const bool mine = lane == q;  // (what v_writelane_b32 does; no builtin for it in this compiler)
+      fin_lo = mine ? static_cast<unsigned>(fin) : fin_lo;
+      fin_hi = mine ? static_cast<unsigned>(fin >> 32) : fin_hi;
+      f_lo = mine ? static_cast<unsigned>(f) : f_lo;
+      f_hi = mine ? static_cast<unsigned>(f >> 32) : f_hi;
+    }
+    // ---- transposed side: lane q works on loaded row q = image row yb - 2 + q ----
+    const unsigned long long colmask = __ballot(col_in);
+    const unsigned long long wmask = __ballot(lane >= 2 && lane < 2 + kOpenColsW && col_in);  // written columns
+    const int yq = yb - 2 + lane;
+    const bool row_in = lane < kLoad && yq >= 0 && yq < m;
+    const unsigned long long FIN = row_in ? (((static_cast<unsigned long long>(fin_hi) << 32) | fin_lo) & colmask) : 0ull;
+    const unsigned long long F = ((static_cast<unsigned long long>(f_hi) << 32) | f_lo) & FIN;  // masked pixels are filled with the minimum
+    const unsigned long long A = row_in ? (F | ~colmask) : ~0ull;  // outside the image: neutral for the erosion
+    const unsigned long long HE = F & (A << 1) & (A >> 1);
+    const unsigned long long E1 = next_lane_u64(HE) & A & next_lane_u64(next_lane_u64(A));  // erosion of row q + 1
+    const unsigned long long HO1 = E1 | (E1 << 1) | (E1 >> 1);
+    const unsigned long long O2 = next_lane_u64(HO1) | E1 | next_lane_u64(next_lane_u64(E1));  // opening of row q + 2
+    const unsigned long long F2 = next_lane_u64(next_lane_u64(F)), FIN2 = next_lane_u64(next_lane_u64(FIN));
+    // lane o now holds OUTPUT row o = image row yb + o
+    const int y = yb + lane;
+    const bool out_row = lane < kOpenRows32 && y < m;
+    const unsigned long long removed = size_opening > 0 ? (F2 & ~O2) : 0ull;  // field pixels the opening takes away
+    const unsigned long long keep = FIN2 & ~removed;
+    if (!clean && out_row) {
+      // one word per (row, strip): which pixels KEEP their value (finite and not removed; every other pixel
+      // of the cleaned frame is the minimum) - lk_to_u8_bits reads the frame itself beside these words;
+      // bit = lane of the column (2 .. 61 are the strip's pixels)
+      keepbits[static_cast<size_t>(y) * gridDim.x + blockIdx.x] = keep;
+    }
+    // shitomasi.py:140 masks row 0 always and row 1 when anything is masked
+    const int first_row = buffer_mask > 0 ? (nan_count > 0.f ? 2 : 1) : 0;
+    const bool counted_row = out_row && y >= band.lo && y < band.hi;
+    const unsigned long long kept_counted = counted_row ? (keep & wmask) : 0ull;  // their values count as they are
+    const unsigned k_lo = static_cast<unsigned>(kept_counted), k_hi = static_cast<unsigned>(kept_counted >> 32);
+    const unsigned r_lo = static_cast<unsigned>(removed), r_hi = static_cast<unsigned>(removed >> 32);
+    // rows that lost a counted pixel: the minimum is among their values
+    const unsigned long long lost_rows = __ballot(counted_row && (removed & wmask) != 0ull);
+    // rows 0 and 1 of the wave may lie above first_row: their statistics are kept apart
+    float mx0 = -INFINITY, mn0 = INFINITY, mx1 = -INFINITY, mn1 = INFINITY, mxr = -INFINITY, mnr = INFINITY;
+    const bool writer = lane >= 2 && lane < 2 + kOpenColsW && col_in;
+#pragma unroll
+    for (int o = 0; o < kOpenRows32; ++o) {
+      const unsigned long long K = (static_cast<unsigned long long>(__builtin_amdgcn_readlane(k_hi, o)) << 32) |
+                                   static_cast<unsigned>(__builtin_amdgcn_readlane(k_lo, o));
+      const bool kept = __builtin_amdgcn_inverse_ballot_w64(K);
+      const float hi = kept ? v[o + 2] : -INFINITY, lo = kept ? v[o + 2] : INFINITY;
+      if (o == 0) {
+        mx0 = max_plain(mx0, hi), mn0 = min_plain(mn0, lo);
+      } else if (o == 1) {
+        mx1 = max_plain(mx1, hi), mn1 = min_plain(mn1, lo);
+      } else {
+        mxr = max_plain(mxr, hi), mnr = min_plain(mnr, lo);
+      }
+      if (clean) {  // (uniform) the entry points that return the cleaned frame
+        const unsigned long long R = (static_cast<unsigned long long>(__builtin_amdgcn_readlane(r_hi, o)) << 32) |
+                                     static_cast<unsigned>(__builtin_amdgcn_readlane(r_lo, o));
+        const float val = __builtin_amdgcn_inverse_ballot_w64(R) ? mn : v[o + 2];
+        if (writer && yb + o < m) clean[static_cast<size_t>(yb + o) * n + x] = val;
       }
     }
-    E2 = E1;
-    E1 = E0;
-    A2 = A1;
-    A1 = A0;
-    F2 = F1;
-    F1 = F0;
-    FIN2 = FIN1;
-    FIN1 = FIN0;
+    const bool feat0 = yb + band.y_org >= first_row, feat1 = yb + 1 + band.y_org >= first_row;  // (uniform)
+    mx_all = max_plain(max_plain(mx0, mx1), mxr);
+    mx_feat = max_plain(max_plain(feat0 ? mx0 : -INFINITY, feat1 ? mx1 : -INFINITY), mxr);
+    mn_feat = min_plain(min_plain(feat0 ? mn0 : INFINITY, feat1 ? mn1 : INFINITY), mnr);
+    if (lost_rows != 0ull) mx_all = max_plain(mx_all, mn);
+    if ((lost_rows & ~((feat0 ? 0ull : 1ull) | (feat1 ? 0ull : 2ull))) != 0ull) {
+      mx_feat = max_plain(mx_feat, mn);
+      mn_feat = min_plain(mn_feat, mn);
+    }
   }
   mx_all = wave_max(mx_all);
   mn_feat = wave_min(mn_feat);
@@ -563,6 +451,77 @@ __global__ __launch_bounds__(256) void lk_to_u8(const float *__restrict__ clean,
       for (int j = 0; j < 4 && i + j < npx; ++j) {
         trk[i + j] = t[j];
         if (feat) feat[i + j] = f[j];
+      }
+    }
+  }
+}
+
+// The same rendering from the FRAME and the keep bits of lk_open_bits (the resident estimate: the cleaned
+// frame is never stored - 8 of the 18 bytes per pixel the three passes moved).  A thread renders four
+// adjacent pixels of kU8Rows rows; all its loads are issued before the first value is used.  VEC: rows
+// are 16-byte aligned (n % 4 == 0, aligned pointers).
+constexpr int kU8Rows = 4;
+template <bool VEC>
+__global__ __launch_bounds__(256) void lk_to_u8_bits(const float *__restrict__ img,
+                                                     const unsigned long long *__restrict__ keepbits, int nstrips,
+                                                     int m, int n, int buffer_mask, float *__restrict__ stats,
+                                                     unsigned char *__restrict__ trk, unsigned char *__restrict__ feat,
+                                                     const unsigned *__restrict__ slots) {
+  const float fill = stats[kMinAll], hi = slots_max(slots, kSlMaxAll);
+  const float flo = slots_min(slots, kSlMinFeat), fhi = slots_max(slots, kSlMaxFeat);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    stats[kMaxAll] = hi;
+    stats[kMinFeat] = flo;
+    stats[kMaxFeat] = fhi;
+  }
+  const int first_row = buffer_mask > 0 ? (stats[kNanCount] > 0.f ? 2 : 1) : 0;
+  // the two renderings differ only when the hidden rows hold an extreme of the frame: as a rule one
+  // division per pixel instead of two (uniform)
+  const bool same_scale = flo == fill && fhi == hi;
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int y0 = blockIdx.y * kU8Rows;
+  if (x >= n) return;
+  const int strip = x / kOpenColsW, shift = x - strip * kOpenColsW + 2;  // (60 % 4 == 0: the four pixels share a word)
+  float v[kU8Rows][4];
+  unsigned long long w[kU8Rows];
+#pragma unroll
+  for (int r = 0; r < kU8Rows; ++r) {
+    const int y = min(y0 + r, m - 1);
+    const float *row = img + static_cast<size_t>(y) * n + x;
+    w[r] = keepbits[static_cast<size_t>(y) * nstrips + strip];
+    if (VEC) {
+      const float4 q = *reinterpret_cast<const float4 *>(row);
+      v[r][0] = q.x, v[r][1] = q.y, v[r][2] = q.z, v[r][3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[r][j] = x + j < n ? row[j] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kU8Rows; ++r) {
+    const int y = y0 + r;
+    if (y >= m) break;
+    const unsigned keep = static_cast<unsigned>(w[r] >> shift);
+    unsigned t = 0, f = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool k = (keep >> j) & 1u;
+      const float val = k ? v[r][j] : fill;
+      t |= static_cast<unsigned>(quantise(val, fill, hi)) << (8 * j);
+      if (!same_scale) f |= static_cast<unsigned>(quantise(y >= first_row ? val : fill, flo, fhi)) << (8 * j);
+    }
+    // (same bounds: the feature rendering IS the tracking rendering, hidden rows are the minimum = 0)
+    if (same_scale) f = y >= first_row ? t : 0u;
+    const size_t at = static_cast<size_t>(y) * n + x;
+    if (VEC) {
+      *reinterpret_cast<unsigned *>(trk + at) = t;
+      if (feat) *reinterpret_cast<unsigned *>(feat + at) = f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (x + j >= n) break;
+        trk[at + j] = static_cast<unsigned char>(t >> (8 * j));
+        if (feat) feat[at + j] = static_cast<unsigned char>(f >> (8 * j));
       }
     }
   }
@@ -1083,31 +1042,113 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
 }
 
 // ---- Gaussian pyramid level: cv::pyrDown for 8U ---------------------------------
-__global__ __launch_bounds__(256) void lk_pyrdown(const unsigned char *__restrict__ src, int m,
-                                                  int n, unsigned char *__restrict__ dst, int om,
-                                                  int on) {
-  // 32x8 output tile <- (67 x 19) input window
-  constexpr int TX = 32, TY = 8;
-  __shared__ unsigned short rows[2 * TY + 3][TX];  // horizontally filtered, decimated rows
-  const int ox0 = blockIdx.x * TX, oy0 = blockIdx.y * TY;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < (2 * TY + 3) * TX; i += 256) {
-    const int ry = i / TX, ox = ox0 + (i % TX);
-    const int y = reflect101(2 * oy0 + ry - 2, m);
-    const unsigned char *row = src + static_cast<size_t>(y) * n;
-    const int xc = 2 * min(ox, on - 1);
-    const int v = row[reflect101(xc - 2, n)] + 4 * row[reflect101(xc - 1, n)] + 6 * row[xc] +
-                  4 * row[reflect101(xc + 1, n)] + row[reflect101(xc + 2, n)];
-    rows[ry][i % TX] = static_cast<unsigned short>(v);
+// out(oy, ox) = (sum_{i,j} w_i w_j src(2 oy + i - 2, 2 ox + j - 2) + 128) >> 8, w = [1 4 6 4 1], reflect-101.
+// (Rounds 1-3: a 32 x 8 tile through LDS with five byte loads per filtered value - 0.06 of the HBM
+// rate.)  A lane owns FOUR adjacent output columns and walks kPyrRows output rows: per input row it
+// loads the 16 bytes [2 ox - 4, 2 ox + 12) with ONE dwordx4 (the eleven taps of its four outputs sit at
+// bytes 2 .. 12), filters them horizontally in registers, keeps the last rows' sums for the vertical
+// filter and stores one dword per output row; all rows of a half are loaded before the first is used.
+// Lanes whose window leaves the image (the first and the last few columns) or an image whose rows are
+// not dword-aligned assemble the window from byte loads at reflected columns.  Both images of a
+// pair in one launch (blockIdx.z).
+constexpr int kPyrRows = 8;  // output rows per wave: 2 * 8 + 3 input rows
+
+struct PyrPair {
+  const unsigned char *src[2];
+  unsigned char *dst[2];
+};
+
+// kPyrRows output rows of one lane's four columns.  FAST: one dwordx4 per input row; otherwise the same 16
+// bytes are assembled from eleven byte loads at the reflected columns off[] (the same for every row).  The
+// two routes are separate straight-line bodies: a branch per row would put a wait behind every load
+template <bool FAST>
+__device__ __forceinline__ void pyr_rows(const unsigned char *__restrict__ src, unsigned char *__restrict__ dst, int m,
+                                         int n, int om, int on, int ox, int oy0, int wx, const int (&off)[11]) {
+  auto window = [&](const unsigned char *row) -> uint4 {
+    if (FAST) return *reinterpret_cast<const uint4 *>(row + wx);
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) w[(k + 2) >> 2] |= static_cast<unsigned>(row[off[k]]) << (8 * ((k + 2) & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  auto hrow = [&](const uint4 d, int h[4]) {
+    // bytes 2 .. 12 of the window: b[k] = byte k + 2
+    const unsigned w[4] = {d.x, d.y, d.z, d.w};
+    auto b = [&](int k) -> int { return static_cast<int>((w[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 0xffu); };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = b(2 * j) + b(2 * j + 4) + 4 * (b(2 * j + 1) + b(2 * j + 3)) + 6 * b(2 * j + 2);
+  };
+  auto row_ptr = [&](int y) { return src + static_cast<size_t>(reflect101(y, m)) * n; };  // (scalar)
+  const bool store4 = (on & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0 && ox + 3 < on;
+  constexpr int kHalf = kPyrRows / 2, kIn = 2 * kHalf + 3;
+  int h[kIn][4];  // horizontally filtered rows of one half: 4 output rows need 11
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int oyh = oy0 + half * kHalf;
+    if (oyh >= om) break;  // (uniform)
+    // rows 2 oyh - 2 .. 2 oyh + 2 kHalf: the first three are the last three of the previous half
+    const int keep = half == 0 ? 0 : 3;
+    if (half != 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h[q][j] = h[kIn - 3 + q][j];
+    }
+    uint4 d[kIn];
+#pragma unroll
+    for (int q = keep; q < kIn; ++q) d[q] = window(row_ptr(2 * oyh - 2 + q));
+#pragma unroll
+    for (int q = keep; q < kIn; ++q) hrow(d[q], h[q]);
+#pragma unroll
+    for (int i = 0; i < kHalf; ++i) {
+      const int oy = oyh + i;
+      if (oy >= om) break;  // (uniform)
+      unsigned packed = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int v = h[2 * i][j] + 4 * h[2 * i + 1][j] + 6 * h[2 * i + 2][j] + 4 * h[2 * i + 3][j] + h[2 * i + 4][j];
+        packed |= static_cast<unsigned>((v + 128) >> 8) << (8 * j);
+      }
+      unsigned char *out = dst + static_cast<size_t>(oy) * on + ox;
+      if (store4) {
+        *reinterpret_cast<unsigned *>(out) = packed;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ox + j < on) out[j] = static_cast<unsigned char>(packed >> (8 * j));
+      }
+    }
   }
-  __syncthreads();
-  const int lx = tid % TX, ly = tid / TX;
-  const int ox = ox0 + lx, oy = oy0 + ly;
-  if (ox < on && oy < om) {
-    const int r = 2 * ly;
-    const int v = rows[r][lx] + 4 * rows[r + 1][lx] + 6 * rows[r + 2][lx] + 4 * rows[r + 3][lx] +
-                  rows[r + 4][lx];
-    dst[static_cast<size_t>(oy) * on + ox] = static_cast<unsigned char>((v + 128) >> 8);
+}
+
+__global__ __launch_bounds__(256) void lk_pyrdown(PyrPair pair, int m, int n, int om, int on) {
+  const unsigned char *__restrict__ src = pair.src[blockIdx.z];
+  unsigned char *__restrict__ dst = pair.dst[blockIdx.z];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ox = (blockIdx.x * 64 + lane) * 4;  // first of the lane's output columns
+  const int oy0 = (blockIdx.y * 4 + wave) * kPyrRows;
+  if (oy0 >= om) return;  // (uniform; no barrier below)
+  const int wx = 2 * ox - 4;  // first byte of the 16-byte window
+  const bool rows_aligned = (n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0;
+  const bool fast = rows_aligned && wx >= 0 && wx + 16 <= n;
+  int off[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (fast) {
+    pyr_rows<true>(src, dst, m, n, om, on, ox, oy0, wx, off);
+  } else if (ox < on) {
+    // columns >= on are never stored, their taps only have to stay inside the row
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      int i = wx + 2 + k;
+      if (n < 16) {
+        i = reflect101(i, n);
+      } else {
+        i = i < 0 ? -i : i;
+        i = i >= n ? 2 * n - 2 - i : i;
+        i = min(max(i, 0), n - 1);
+      }
+      off[k] = i;
+    }
+    pyr_rows<false>(src, dst, m, n, om, on, ox, oy0, wx, off);
   }
 }
 
@@ -1642,27 +1683,13 @@ __global__ __launch_bounds__(256) void lk_pool_append(const float2 *__restrict__
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-// 0 = bit-mask opening (default), 1 = the LDS kernels (lk_open_vec / lk_open)
-static int g_lk_open_variant = [] {
-  const char *e = std::getenv("PYSTEPS_HIP_LK_OPEN_VARIANT");
-  return e ? std::atoi(e) : 0;
-}();
-dim3 lk_open_grid(int m, int n) {
-  if (g_lk_open_variant == 0) return dim3((n + kOpenColsW - 1) / kOpenColsW, (m + kOpenRowsWG - 1) / kOpenRowsWG);
-  return dim3((n + kOpenTX - 1) / kOpenTX, (m + kOpenTY - 1) / kOpenTY);
-}
+dim3 lk_open_grid(int m, int n) { return dim3((n + kOpenColsW - 1) / kOpenColsW, (m + kOpenRowsWG32 - 1) / kOpenRowsWG32); }
+// clean == nullptr: the cleaned frame is not stored, keepbits (m x grid.x words) is written instead
 void launch_lk_open(dim3 grid, hipStream_t stream, const float *img, int m, int n, int size_opening, int buffer_mask,
-                    float *stats, float *clean, float *part, Band band, unsigned *slots = nullptr) {
-  if (g_lk_open_variant == 0) {
-    hipLaunchKernelGGL(lk_open_bits, grid, dim3(256), 0, stream, img, m, n, size_opening, buffer_mask, stats, clean,
-                       part, band, slots);
-  } else if (n % 4 == 0 && reinterpret_cast<uintptr_t>(img) % 16 == 0 && reinterpret_cast<uintptr_t>(clean) % 16 == 0) {
-    hipLaunchKernelGGL(lk_open_vec, grid, dim3(256), 0, stream, img, m, n, size_opening, buffer_mask, stats, clean, part,
-                       band);
-  } else {
-    hipLaunchKernelGGL(lk_open, grid, dim3(256), 0, stream, img, m, n, size_opening, buffer_mask, stats, clean, part,
-                       band);
-  }
+                    float *stats, float *clean, float *part, Band band, unsigned *slots = nullptr,
+                    unsigned long long *keepbits = nullptr) {
+  hipLaunchKernelGGL(lk_open_bits, grid, dim3(256), 0, stream, img, m, n, size_opening, buffer_mask, stats, clean, part,
+                     band, slots, keepbits);
 }
 
 constexpr int kCrnRows = 32;  // output rows per wave of the response pass (16 and 64 measured slower: 84 / 84 vs 77 us)
@@ -1727,43 +1754,51 @@ size_t lk_prepare_ws_bytes(int m, int n, bool f64) {
   return kSlotBytes + sizeof(float) * (2 * static_cast<size_t>(kRedBlocks) + 3 * static_cast<size_t>(ogrid.x * ogrid.y));
 }
 size_t lk_slot_bytes() { return kSlotBytes; }
+size_t lk_keepbits_bytes(int m, int n) { return static_cast<size_t>(m) * lk_open_grid(m, n).x * sizeof(unsigned long long); }
 
 int lk_prepare_on(hipStream_t stream, void *ws, const void *frame_dev, bool f64, int m, int n, int size_opening,
                   int buffer_mask, float *clean_dev, unsigned char *track_u8_dev, unsigned char *feature_u8_dev,
-                  float *stats_dev, unsigned *slots_cleared) {
+                  float *stats_dev, unsigned *slots_cleared, unsigned long long *keepbits) {
   if (m <= 0 || n <= 0) return fail(PSH_EINVAL, "lk_prepare: invalid shape (%d,%d)", m, n);
-  if (!frame_dev || !clean_dev || !track_u8_dev || !stats_dev || !ws) return fail(PSH_EINVAL, "lk_prepare: NULL pointer");
+  if (!frame_dev || !track_u8_dev || !stats_dev || !ws) return fail(PSH_EINVAL, "lk_prepare: NULL pointer");
+  if (!clean_dev && (f64 || !keepbits)) return fail(PSH_EINVAL, "lk_prepare: NULL pointer");
   if (size_opening != 0 && size_opening != 3)
     return fail(PSH_EUNSUPPORTED, "lk_prepare: size_opening %d not implemented (0 or 3)", size_opening);
   const size_t npx = static_cast<size_t>(m) * n;
   if (!f64) {
     const float *frame = static_cast<const float *>(frame_dev);
     const dim3 ogrid = lk_open_grid(m, n);
-    const int nb_open = ogrid.x * ogrid.y;
     unsigned *own_slots = static_cast<unsigned *>(ws);
     float *part1 = reinterpret_cast<float *>(static_cast<char *>(ws) + kSlotBytes);
     float *part2 = part1 + 2 * kRedBlocks;
-    const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
-    if (g_lk_open_variant == 0) {
-      // statistics through the slots: every pass folds its results into them, the next pass reads them
-      // back - three launches, no single-workgroup kernel in between
-      unsigned *slots = slots_cleared;
-      if (!slots) {
-        slots = own_slots;
-        const hipError_t e = hipMemsetAsync(slots, 0, kSlotBytes, stream);
-        if (e != hipSuccess) return fail(PSH_EHIP, "lk_prepare: clearing the statistic slots failed: %s", hipGetErrorString(e));
-      }
-      hipLaunchKernelGGL(lk_stats1, dim3(kRedBlocks), dim3(256), 0, stream, frame, npx, part1, slots);
+    // statistics through the slots: every pass folds its results into them, the next pass reads them
+    // back - three launches, no single-workgroup kernel in between
+    unsigned *slots = slots_cleared;
+    if (!slots) {
+      slots = own_slots;
+      const hipError_t e = hipMemsetAsync(slots, 0, kSlotBytes, stream);
+      if (e != hipSuccess) return fail(PSH_EHIP, "lk_prepare: clearing the statistic slots failed: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(lk_stats1, dim3(kRedBlocks), dim3(256), 0, stream, frame, npx, part1, slots);
+    if (clean_dev) {
       launch_lk_open(ogrid, stream, frame, m, n, size_opening, buffer_mask, stats_dev, clean_dev, part2, Band{0, 0, m}, slots);
+      const int qgrid = static_cast<int>(std::min<size_t>((npx / 4 + 255) / 256 + 1, 4096));
       hipLaunchKernelGGL(lk_to_u8, dim3(qgrid), dim3(256), 0, stream, clean_dev, m, n, buffer_mask, stats_dev, track_u8_dev,
                          feature_u8_dev, 0, static_cast<const unsigned *>(slots));
     } else {
-      hipLaunchKernelGGL(lk_stats1, dim3(kRedBlocks), dim3(256), 0, stream, frame, npx, part1, static_cast<unsigned *>(nullptr));
-      hipLaunchKernelGGL(lk_stats1_final, dim3(1), dim3(kFinalThreads), 0, stream, part1, kRedBlocks, stats_dev);
-      launch_lk_open(ogrid, stream, frame, m, n, size_opening, buffer_mask, stats_dev, clean_dev, part2, Band{0, 0, m});
-      hipLaunchKernelGGL(lk_open_final, dim3(1), dim3(kFinalThreads), 0, stream, part2, nb_open, stats_dev);
-      hipLaunchKernelGGL(lk_to_u8, dim3(qgrid), dim3(256), 0, stream, clean_dev, m, n, buffer_mask, stats_dev, track_u8_dev,
-                         feature_u8_dev, 0, static_cast<const unsigned *>(nullptr));
+      // the resident estimate: no cleaned frame in memory, the renderings come from the frame and the keep bits
+      launch_lk_open(ogrid, stream, frame, m, n, size_opening, buffer_mask, stats_dev, nullptr, part2, Band{0, 0, m}, slots,
+                     keepbits);
+      const dim3 qgrid((n + 1023) / 1024, (m + kU8Rows - 1) / kU8Rows);
+      const bool vec = n % 4 == 0 && reinterpret_cast<uintptr_t>(frame) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(track_u8_dev) % 4 == 0 && reinterpret_cast<uintptr_t>(feature_u8_dev) % 4 == 0;
+      if (vec) {
+        hipLaunchKernelGGL(lk_to_u8_bits<true>, qgrid, dim3(256), 0, stream, frame, keepbits, static_cast<int>(ogrid.x), m, n,
+                           buffer_mask, stats_dev, track_u8_dev, feature_u8_dev, static_cast<const unsigned *>(slots));
+      } else {
+        hipLaunchKernelGGL(lk_to_u8_bits<false>, qgrid, dim3(256), 0, stream, frame, keepbits, static_cast<int>(ogrid.x), m, n,
+                           buffer_mask, stats_dev, track_u8_dev, feature_u8_dev, static_cast<const unsigned *>(slots));
+      }
     }
   } else {
     // everything that decides a grey level is computed in double, like the reference does for such input
@@ -2390,11 +2425,13 @@ static int lk_pyramids_on(hipStream_t stream, const unsigned char *prev_u8_dev, 
     unsigned char *Jl = l ? reinterpret_cast<unsigned char *>(base + off_j[l]) : const_cast<unsigned char *>(next_u8_dev);
     short2 *dl = need_deriv ? reinterpret_cast<short2 *>(base + off_d[l]) : nullptr;
     if (l) {
-      const dim3 g((cols[l] + 31) / 32, (rows[l] + 7) / 8);
-      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, stream, ps->pyr.lv[l - 1].I, rows[l - 1],
-                         cols[l - 1], Il, rows[l], cols[l]);
-      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, stream, ps->pyr.lv[l - 1].J, rows[l - 1],
-                         cols[l - 1], Jl, rows[l], cols[l]);
+      const dim3 g((cols[l] + 255) / 256, (rows[l] + 4 * psh::kPyrRows - 1) / (4 * psh::kPyrRows), 2);
+      psh::PyrPair pair;
+      pair.src[0] = ps->pyr.lv[l - 1].I;
+      pair.src[1] = ps->pyr.lv[l - 1].J;
+      pair.dst[0] = Il;
+      pair.dst[1] = Jl;
+      hipLaunchKernelGGL(psh::lk_pyrdown, g, dim3(256), 0, stream, pair, rows[l - 1], cols[l - 1], rows[l], cols[l]);
     }
     if (need_deriv) {
       const dim3 sg((cols[l] + 63) / 64, (rows[l] + 3) / 4);
