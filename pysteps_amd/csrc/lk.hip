@@ -1453,11 +1453,13 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
                                                      int max_count, float eps2, float min_eig_thr,
                                                      float2 *__restrict__ next_pts,
                                                      unsigned char *__restrict__ status) {
-  __shared__ short sI[kMaxWin * kMaxWin];
-  __shared__ short sGx[kMaxWin * kMaxWin];
-  __shared__ short sGy[kMaxWin * kMaxWin];
   __shared__ long long red[3][4];
   __shared__ long long red_b[2][2][4];  // iteration sums of the four waves, two buffers in turn
+  // the template patch of the lane's column - value and the two gradients of its ROWS window rows - stays
+  // in registers (rounds 2-4 kept it in LDS and read it back row by row in every iteration: three reads and
+  // a wait per row); rows and lanes outside the window hold zero gradients, so the iteration needs no
+  // per-row branch and no execution mask
+  int rI[ROWS], rGx[ROWS], rGy[ROWS];
   const int p = blockIdx.x;
   if (npts_dev) npts = min(npts, *npts_dev);  // count in device memory: see lk_track
   if (p >= npts) return;
@@ -1493,7 +1495,9 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
     lk_weights(px - static_cast<float>(ipx), py - static_cast<float>(ipy), w00, w01, w10, w11);
     // ---- template patch + spatial gradient matrix -------------------------------
     int s11 = 0, s12 = 0, s22 = 0;  // per-thread partial sums fit 32 bits (|g| <= 16 * 255)
-    __syncthreads();  // previous level's readers are done with the LDS patch
+    __syncthreads();  // previous level's readers are done with red[]
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) rI[r] = rGx[r] = rGy[r] = 0;
     {
       // lanes 0 .. win_w + 2 LOAD image columns ipx - 1 .. ipx + win_w + 1; everything a lane then
       // works on belongs to the column one to the right, xd = ipx + lane, assembled from lanes
@@ -1543,10 +1547,9 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
             const int gx = descale(bilin24(static_cast<short>(g00), static_cast<short>(g01), static_cast<short>(g10),
                                            static_cast<short>(g11), w00, w01, w10, w11), 14);
             const int gy = descale(bilin24(g00 >> 16, g01 >> 16, g10 >> 16, g11 >> 16, w00, w01, w10, w11), 14);
-            const int i = (row_first + r) * win_w + lane;
-            sI[i] = static_cast<short>(ival);
-            sGx[i] = static_cast<short>(gx);
-            sGy[i] = static_cast<short>(gy);
+            rI[r] = static_cast<short>(ival);
+            rGx[r] = static_cast<short>(gx);
+            rGy[r] = static_cast<short>(gy);
             s11 += gx * gx;
             s12 += gx * gy;
             s22 += gy * gy;
@@ -1583,26 +1586,33 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
         break;
       }
       lk_weights(qx - static_cast<float>(inx), qy - static_cast<float>(iny), w00, w01, w10, w11);
-      const int xa = reflect101(inx + lane, L.cols);
+      // image rows iny + row_first ... + ROWS of the next frame, one byte per lane and row.  As a rule the
+      // whole block lies inside the (stored) image: one base address, no reflection, straight-line loads;
+      // near a border every row and column is reflected (rows past the wave's share repeat its last one:
+      // their gradients are zero)
+      const int y0 = iny + row_first;
+      const bool inside = row_count > 0 && inx >= 0 && inx + 63 < L.cols && y0 >= 0 && y0 + ROWS < L.rows &&
+                          y0 >= L.row_org && y0 + ROWS - L.row_org < L.rows_stored;  // (uniform)
       int tj[ROWS + 1];
+      if (inside) {
+        const unsigned char *base = L.J + static_cast<size_t>(y0 - L.row_org) * L.cols + (inx + lane);
 #pragma unroll
-      for (int r = 0; r <= ROWS; ++r) {
-        tj[r] = 0;
-        if (r <= row_count && load_lane)
-          tj[r] = L.J[stored_row(L, reflect101(iny + row_first + r, L.rows)) * L.cols + xa];
+        for (int r = 0; r <= ROWS; ++r) tj[r] = base[static_cast<size_t>(r) * L.cols];
+      } else {
+        const int xa = reflect101(inx + lane, L.cols);
+#pragma unroll
+        for (int r = 0; r <= ROWS; ++r)
+          tj[r] = L.J[stored_row(L, reflect101(y0 + min(r, max(row_count, 0)), L.rows)) * L.cols + xa];
       }
       int c1 = 0, c2 = 0;  // |diff * g| < 2^26, <= 16 samples per thread
+      int right = from_next_lane(tj[0]);
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
-        if (r < row_count) {
-          const int j01 = from_next_lane(tj[r]), j11 = from_next_lane(tj[r + 1]);
-          if (sample_lane) {
-            const int i = (row_first + r) * win_w + lane;
-            const int diff = descale(bilin24(tj[r], j01, tj[r + 1], j11, w00, w01, w10, w11), 14 - 5) - sI[i];
-            c1 += diff * sGx[i];
-            c2 += diff * sGy[i];
-          }
-        }
+        const int right_below = from_next_lane(tj[r + 1]);
+        const int diff = descale(bilin24(tj[r], right, tj[r + 1], right_below, w00, w01, w10, w11), 14 - 5) - rI[r];
+        c1 += __mul24(diff, rGx[r]);  // (|diff| < 2^14, |g| < 2^15)
+        c2 += __mul24(diff, rGy[r]);
+        right = right_below;
       }
       const long long b1 = wave_sum_split_i64(c1), b2 = wave_sum_split_i64(c2);
       // (the buffer written now was last read two barriers ago: one barrier per iteration is enough)
