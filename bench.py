@@ -252,18 +252,19 @@ def pmc_traffic(workload):
         return None
 
 
-N_SIMD = 1024  # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md)
+N_SIMD = 1024  # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles (profiles/r04/a_valu_probe.txt)
 # algorithmic bytes per pixel of the streaming image passes of the motion estimate (what each pass has
-# to read and write once): float32 frame in / cleaned frame out / uint8 renderings / float32 response
+# to read and write once): float32 frame in / keep bits / uint8 renderings / float32 response
 LK_PASS_BYTES = {
     "lk_stats1": (4.0, "frame read"),
-    "lk_open_bits": (8.0, "frame read + cleaned frame written"),
-    "lk_to_u8": (5.5, "cleaned frame read + tracking rendering written (+ feature rendering for the first frame of a pair)"),
+    "lk_open_bits": (4.0 + 8.0 / 60.0, "frame read + one keep word per 60 pixels written (no cleaned frame)"),
+    "lk_to_u8_bits": (4.0 + 8.0 / 60.0 + 1.5,
+                      "frame + keep words read, tracking rendering written (+ feature rendering for the first frame of a pair)"),
     "lk_corner_response_cols": (5.0, "uint8 rendering read + float32 response written"),
     "lk_corner_select": (4.0, "response read"),
     "lk_pyrdown": (1.25 * 1.333, "per frame: every level read once, the next one written (geometric series)"),
 }
-LK_CALLS_PER_PAIR = {"lk_stats1": 2, "lk_open_bits": 2, "lk_to_u8": 2, "lk_corner_response_cols": 1, "lk_corner_select": 1,
+LK_CALLS_PER_PAIR = {"lk_stats1": 2, "lk_open_bits": 2, "lk_to_u8_bits": 2, "lk_corner_response_cols": 1, "lk_corner_select": 1,
                      "lk_pyrdown": 2}
 
 

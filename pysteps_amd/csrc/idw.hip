@@ -458,14 +458,36 @@ __global__ __launch_bounds__(kThreads) void idw_coarse(const float2 *__restrict_
   const float hx = 0.5f * fabsf(dx_grid) * static_cast<float>(wx - 1);
   const float hy = 0.5f * fabsf(dy_grid) * static_cast<float>(wy - 1);
   const float half_diag = sqrtf(hx * hx + hy * hy);
-  const float bin_w = dmax / static_cast<float>(kBins);
+  // (a multiplication instead of the division by the bin width: a vector that lands in the neighbouring bin
+  // moves the bracket by one bin at most, and `reach` carries a 1e-3 margin; the lists stay supersets of what
+  // the fine pass needs, in index order - the field does not change)
+  const float bin_w = dmax / static_cast<float>(kBins), inv_bin_w = static_cast<float>(kBins) / dmax;
   for (int i = tid; i < kBins; i += kThreads) s_hist[i] = 0;
   __syncthreads();
-  for (int i = tid; i < L; i += kThreads) {
+  // each wave owns a contiguous quarter of the vectors (ordered compaction below) and keeps its vectors'
+  // positions and squared centre distances in registers: the list is read once
+  const int wave = tid >> 6, lane = tid & 63;
+  const int per_wave = (L + 3) / 4;
+  const int i_begin = wave * per_wave, i_end = min(L, i_begin + per_wave);
+  constexpr int kKeep = 8;  // 64 x 8 vectors per wave in registers (L <= 2048); longer lists re-read the rest
+  float2 pk[kKeep];
+  float d2k[kKeep];
+#pragma unroll
+  for (int q = 0; q < kKeep; ++q) {
+    const int i = i_begin + q * 64 + lane;
+    d2k[q] = INFINITY;
+    pk[q] = make_float2(0.f, 0.f);
+    if (i < i_end) {
+      pk[q] = xy[i];
+      const float ddx = pk[q].x - cx, ddy = pk[q].y - cy;
+      d2k[q] = ddx * ddx + ddy * ddy;
+      atomicAdd(&s_hist[min(static_cast<int>(sqrtf(d2k[q]) * inv_bin_w), kBins - 1)], 1);
+    }
+  }
+  for (int i = i_begin + kKeep * 64 + lane; i < i_end; i += 64) {
     const float2 p = xy[i];
     const float ddx = p.x - cx, ddy = p.y - cy;
-    const int bin = min(static_cast<int>(sqrtf(ddx * ddx + ddy * ddy) / bin_w), kBins - 1);
-    atomicAdd(&s_hist[bin], 1);
+    atomicAdd(&s_hist[min(static_cast<int>(sqrtf(ddx * ddx + ddy * ddy) * inv_bin_w), kBins - 1)], 1);
   }
   __syncthreads();
   if (tid < 64) {
@@ -490,20 +512,23 @@ __global__ __launch_bounds__(kThreads) void idw_coarse(const float2 *__restrict_
   }
   __syncthreads();
   const float reach = s_radius + 2.f * half_diag + 1e-3f * (s_radius + half_diag);
-  // ordered compaction, as in idw_knn: each wave owns a contiguous quarter of the vectors
-  const int wave = tid >> 6, lane = tid & 63;
-  const int per_wave = (L + 3) / 4;
-  const int i_begin = wave * per_wave, i_end = min(L, i_begin + per_wave);
-  auto wanted = [&](int i, float2 &p) {
+  const float reach2 = reach * reach;
+  auto wanted_tail = [&](int i, float2 &p) {
     if (i >= i_end) return false;
     p = xy[i];
     const float ddx = p.x - cx, ddy = p.y - cy;
-    return sqrtf(ddx * ddx + ddy * ddy) <= reach;
+    return ddx * ddx + ddy * ddy <= reach2;
   };
+  unsigned long long maskk[kKeep];
   int mine = 0;
-  for (int i0 = i_begin; i0 < i_end; i0 += 64) {
+#pragma unroll
+  for (int q = 0; q < kKeep; ++q) {
+    maskk[q] = __ballot(d2k[q] <= reach2);
+    mine += __popcll(maskk[q]);
+  }
+  for (int i0 = i_begin + kKeep * 64; i0 < i_end; i0 += 64) {
     float2 p;
-    mine += __popcll(__ballot(wanted(i0 + lane, p)));
+    mine += __popcll(__ballot(wanted_tail(i0 + lane, p)));
   }
   if (lane == 0) s_wave_count[wave] = mine;
   __syncthreads();
@@ -520,9 +545,18 @@ __global__ __launch_bounds__(kThreads) void idw_coarse(const float2 *__restrict_
   }
   if (n_cand > kSuperCap) return;
   float4 *dst = lists + static_cast<size_t>(sup) * kSuperCap;
-  for (int i0 = i_begin; i0 < i_end; i0 += 64) {
+#pragma unroll
+  for (int q = 0; q < kKeep; ++q) {
+    if (maskk[q] == 0ull) continue;  // (uniform)
+    if ((maskk[q] >> lane) & 1ull) {
+      const float2 val = uv[i_begin + q * 64 + lane];
+      dst[base + __popcll(maskk[q] & ((1ull << lane) - 1ull))] = make_float4(pk[q].x, pk[q].y, val.x, val.y);
+    }
+    base += __popcll(maskk[q]);
+  }
+  for (int i0 = i_begin + kKeep * 64; i0 < i_end; i0 += 64) {
     float2 p = make_float2(0.f, 0.f);
-    const bool keep = wanted(i0 + lane, p);
+    const bool keep = wanted_tail(i0 + lane, p);
     const unsigned long long mask = __ballot(keep);
     if (keep) {
       const float2 val = uv[i0 + lane];
