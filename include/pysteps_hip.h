@@ -536,6 +536,24 @@ int psh_steps_spectral_ar_dev(void *cascades_dev, int nlevels, int p, int m, int
                               const void *noise_spec_dev, const double *filter_dev, const double *weights_dev,
                               const double *sums_dev, const double *noise_std_host, const double *mu_host,
                               const double *sigma_host, void *field_spec_dev);
+/* The reference's OWN domain="spectral" member update (nowcasts/steps.py:1116-1166 with params["domain"] == "spectral";
+ * noise/fftgenerators.py:407-437, cascade/decomposition.py:195-262 with spectral input and output, recompose_fft:284-300):
+ * the state is spectral there (per level the coefficients where the band-pass weight exceeds 1e-12), the noise a field
+ * of unit phasors exp(i theta), theta (m, n/2+1) float64 from RandomState.uniform(0, 2 pi) (psh_rng_uniform_dev).
+ *   cascades (nlevels, p, m, n/2+1) complex128 rings of FULL half-spectrum planes (slot `head` = oldest, overwritten;
+ *   entries outside a level's mask are not touched);  inv_std_noise = 1 / spectral.std(F with F[0,0] = 0),
+ *   inv_std_levels[k] = 1 / spectral.std(F / std_noise * W_k) - constants of a nowcast since |exp(i theta)| = 1;
+ *   field_spec = sum_k mask_k (sigma_k X_k + mu_k)   (field = irfft2(field_spec)) */
+int psh_steps_phase_ar_dev(void *cascades_dev, int nlevels, int p, int m, int n, int head, const double *phi_host,
+                           const double *theta_dev, const double *filter_dev, const double *weights_dev,
+                           double inv_std_noise, const double *inv_std_levels_host, const double *noise_std_host,
+                           const double *mu_host, const double *sigma_host, void *field_spec_dev);
+/* level planes from the reference's compact spectral arrays (cascade/decomposition.py:233-236: field[weights > 1e-12],
+ * row-major): psh_mask_row_offsets_dev -> offsets (m + 1) int32 of one level's weights plane (m <= 8192);
+ * psh_expand_compact_c128_dev -> dst (m, nc) complex128 = src scattered to the kept coefficients, zero elsewhere */
+int psh_mask_row_offsets_dev(const double *weights_dev, int m, int nc, int *offsets_dev);
+int psh_expand_compact_c128_dev(const double *weights_dev, int m, int nc, const int *offsets_dev, const void *src_dev,
+                                void *dst_dev);
 int psh_field_min_key_dev(const double *field_dev, size_t n, unsigned long long *min_key_dev);
 int psh_steps_mask_dev(double *field_dev, size_t n, const double *grey_mask_dev, const unsigned char *keep_mask_dev,
                        const unsigned long long *min_key_dev);
@@ -563,6 +581,10 @@ int psh_lerp_dev(const double *a_dev, const double *b_dev, double w, double *out
  *                     behind everything queued on the library stream so far (the noise of the next time
  *                     step beside the member loop): psh_rng_wait() makes the library stream wait for it
  *                     and has to be called before out_dev is read or freed
+ *  psh_rng_uniform_dev  out (n_streams, count) float64: the next `count` values of every stream, like
+ *                     `uniform(low, high, count)` (low + (high - low) * random_sample(): two words per value);
+ *                     same stream rules as psh_rng_randn_dev.  What the spectral-domain noise generator draws
+ *                     (pysteps/noise/fftgenerators.py:407)
  *  psh_rng_check      PSH_EHIP when a draw that has COMPLETED found fewer accepted attempts in its window than
  *                     it needed (a > 10 sigma event; the tail of that draw is unwritten); reads one pinned host
  *                     word, no device work - meant to be called once per time step after a wait the caller has
@@ -572,6 +594,7 @@ int psh_lerp_dev(const double *a_dev, const double *b_dev, double w, double *out
 int psh_rng_create(int n_streams, const uint32_t *keys_host, const int *pos_host, const int *has_gauss_host,
                    const double *gauss_host, size_t max_draw, int n_draws_hint, void **handle_out);
 int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, int side);
+int psh_rng_uniform_dev(void *handle, size_t count, double low, double high, double *out_dev, int side);
 int psh_rng_wait(void *handle);
 int psh_rng_check(void *handle);
 int psh_rng_get_state(void *handle, uint32_t *keys_host, int *pos_host, int *has_gauss_host, double *gauss_host);

@@ -94,6 +94,10 @@ SIGNATURES = {
     "psh_steps_spectral_sums_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_steps_spectral_ar_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psh_steps_phase_ar_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psh_mask_row_offsets_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "psh_expand_compact_c128_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "psh_field_min_key_dev": (c_int, [c_void_p, c_size_t, c_void_p]),
     "psh_steps_mask_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "psh_steps_mean_shift_dev": (c_int, [c_void_p, c_size_t, c_double, c_double]),
@@ -102,6 +106,7 @@ SIGNATURES = {
     "psh_lerp_dev": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_size_t]),
     "psh_rng_create": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, POINTER(c_void_p)]),
     "psh_rng_randn_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_int]),
+    "psh_rng_uniform_dev": (c_int, [c_void_p, c_size_t, c_double, c_double, c_void_p, c_int]),
     "psh_rng_wait": (c_int, [c_void_p]),
     "psh_rng_check": (c_int, [c_void_p]),
     "psh_rng_get_state": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -365,6 +365,35 @@ __global__ __launch_bounds__(kTileThreads) void polar_write(const uint32_t *__re
   }
 }
 
+// RandomState.uniform: value t of a draw reads words pos + 2 t, pos + 2 t + 1
+__global__ __launch_bounds__(kTileThreads) void uniform_write(const uint32_t *__restrict__ rings, size_t ring_words,
+                                                              const RngDyn *__restrict__ dyn_in, RngDyn *__restrict__ dyn_out,
+                                                              unsigned long long count, double low, double range,
+                                                              double *__restrict__ out) {
+#pragma clang fp contract(off)
+  const unsigned b = blockIdx.y;
+  const RngDyn in = dyn_in[b];
+  const uint32_t *ring = rings + static_cast<size_t>(b) * ring_words;
+  const size_t base = static_cast<size_t>(in.pos % ring_words);
+  double *dst = out + static_cast<size_t>(b) * count;
+  const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * kTileThreads;
+  for (unsigned long long t = static_cast<unsigned long long>(blockIdx.x) * kTileThreads + threadIdx.x; t < count; t += stride) {
+    size_t at = base + static_cast<size_t>((2 * t) % ring_words);
+    if (at >= ring_words) at -= ring_words;
+    const size_t at1 = at + 1 >= ring_words ? at + 1 - ring_words : at + 1;
+    const uint32_t w0 = mt_temper(ring[at]), w1 = mt_temper(ring[at1]);
+    const double d = (static_cast<double>(w0 >> 5) * 67108864.0 + static_cast<double>(w1 >> 6)) / 9007199254740992.0;
+    dst[t] = low + range * d;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    RngDyn o = in;
+    o.pos = in.pos + 2 * count;
+    dyn_out[b] = o;
+  }
+}
+
+
+
 struct Rng {
   int streams = 0;
   size_t max_draw = 0;
@@ -524,15 +553,11 @@ extern "C" int psh_rng_create(int n_streams, const uint32_t *keys_host, const in
   return PSH_OK;
 }
 
-extern "C" int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, int side) {
-  PSH_REQUIRE_INIT();
-  psh::Rng *r = static_cast<psh::Rng *>(handle);
-  if (!r || (!out_dev && count)) return fail(PSH_EINVAL, "rng_randn: NULL pointer");
-  if (count > r->max_draw) return fail(PSH_EINVAL, "rng_randn: %zu values per stream, the handle was made for %zu", count, r->max_draw);
-  if (count == 0) return PSH_OK;
+// Everything a draw needs before its own kernels: the stream it runs on (the library stream, or the
+// handle's own one behind everything queued so far - psh_rng_wait() joins it) and the raw words up to
+// `words_max` beyond the furthest position a stream can be at (lock held)
+static int rng_prepare(psh::Rng *r, int side, double words_max, hipStream_t *stream_out) {
   psh::Context &c = psh::ctx();
-  std::lock_guard<std::recursive_mutex> lock(c.mu);
-  PSH_HIP(hipSetDevice(c.device));
   // which stream: the library stream, or the handle's own one behind everything queued so far
   // (whoever used out_dev before) - psh_rng_wait() joins it
   hipStream_t s = c.stream;
@@ -545,13 +570,9 @@ extern "C" int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, in
     PSH_HIP(hipStreamWaitEvent(r->stream, r->fence, 0));
     s = r->stream;
   }
-  const unsigned long long pairs_max = (count + 1) / 2;  // no cached value
-  const unsigned long long pairs_min = count / 2;        // every stream has one
-  const unsigned long long window = psh::window_for(pairs_max);
-  const unsigned ntiles = static_cast<unsigned>((window + psh::kTileAttempts - 1) / psh::kTileAttempts);
-  // words this draw may read: up to hi + 4 window; the slot of block k is the slot of block
+  // words this draw may read: up to hi + words_max; the slot of block k is the slot of block
   // k - ring_blocks, which has to lie below every stream's position
-  auto blocks_wanted = [&]() { return static_cast<unsigned long long>((r->hi + 4.0 * static_cast<double>(window)) / psh::kMtN) + 2; };
+  auto blocks_wanted = [&]() { return static_cast<unsigned long long>((r->hi + words_max) / psh::kMtN) + 2; };
   auto fits = [&](unsigned long long want) {
     // (one block of slack: get_state reads the block that holds word pos - 1)
     return want <= r->ring_blocks || static_cast<double>(want - r->ring_blocks + 1) * psh::kMtN <= r->lo;
@@ -595,6 +616,25 @@ extern "C" int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, in
     }
     r->produced_blocks = want_blocks;
   }
+  *stream_out = s;
+  return PSH_OK;
+}
+
+extern "C" int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, int side) {
+  PSH_REQUIRE_INIT();
+  psh::Rng *r = static_cast<psh::Rng *>(handle);
+  if (!r || (!out_dev && count)) return fail(PSH_EINVAL, "rng_randn: NULL pointer");
+  if (count > r->max_draw) return fail(PSH_EINVAL, "rng_randn: %zu values per stream, the handle was made for %zu", count, r->max_draw);
+  if (count == 0) return PSH_OK;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const unsigned long long pairs_max = (count + 1) / 2;  // no cached value
+  const unsigned long long pairs_min = count / 2;        // every stream has one
+  const unsigned long long window = psh::window_for(pairs_max);
+  const unsigned ntiles = static_cast<unsigned>((window + psh::kTileAttempts - 1) / psh::kTileAttempts);
+  hipStream_t s = nullptr;
+  if (int rc = rng_prepare(r, side, 4.0 * static_cast<double>(window), &s)) return rc;
   const psh::RngDyn *din = r->dyn + static_cast<size_t>(r->parity) * r->streams;
   psh::RngDyn *dout = r->dyn + static_cast<size_t>(r->parity ^ 1) * r->streams;
   hipLaunchKernelGGL(psh::polar_count, dim3(ntiles, r->streams), dim3(psh::kTileThreads), 0, s, r->rings, r->ring_words, din,
@@ -614,6 +654,38 @@ extern "C" int psh_rng_randn_dev(void *handle, size_t count, double *out_dev, in
   };
   r->hi += 4.0 * std::min(static_cast<double>(window), attempts(pairs_max, 1.0));
   r->lo += 4.0 * attempts(pairs_min, -1.0);
+  if (side) {
+    PSH_HIP(hipEventRecord(r->ready, r->stream));
+    r->on_side = true;
+  }
+  return PSH_OK;
+}
+
+// `count` values of RandomState.uniform(low, high) per stream (numpy/random/src/distributions/distributions.c
+// random_uniform: low + (high - low) * next_double, two words per value, no rejection: the streams advance by
+// exactly 2 count words; a cached normal value stays cached)
+extern "C" int psh_rng_uniform_dev(void *handle, size_t count, double low, double high, double *out_dev, int side) {
+  PSH_REQUIRE_INIT();
+  psh::Rng *r = static_cast<psh::Rng *>(handle);
+  if (!r || (!out_dev && count)) return fail(PSH_EINVAL, "rng_uniform: NULL pointer");
+  if (count > r->max_draw) return fail(PSH_EINVAL, "rng_uniform: %zu values per stream, the handle was made for %zu", count, r->max_draw);
+  if (count == 0) return PSH_OK;
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  hipStream_t s = nullptr;
+  const double words = 2.0 * static_cast<double>(count);
+  if (int rc = rng_prepare(r, side, words, &s)) return rc;
+  const psh::RngDyn *din = r->dyn + static_cast<size_t>(r->parity) * r->streams;
+  psh::RngDyn *dout = r->dyn + static_cast<size_t>(r->parity ^ 1) * r->streams;
+  const unsigned blocks = static_cast<unsigned>(std::min<size_t>((count + psh::kTileThreads - 1) / psh::kTileThreads, 2048));
+  hipLaunchKernelGGL(psh::uniform_write, dim3(blocks, r->streams), dim3(psh::kTileThreads), 0, s, r->rings, r->ring_words, din, dout,
+                     static_cast<unsigned long long>(count), low, high - low, out_dev);
+  PSH_HIP(hipGetLastError());
+  r->parity ^= 1;
+  r->drawn = true;
+  r->hi += words;
+  r->lo += words;
   if (side) {
     PSH_HIP(hipEventRecord(r->ready, r->stream));
     r->on_side = true;

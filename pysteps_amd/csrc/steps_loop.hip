@@ -360,6 +360,141 @@ __global__ __launch_bounds__(kThreads) void spectral_ar(double2 *__restrict__ ca
   }
 }
 
+// ---- the reference's own domain="spectral" (steps.py:122-126, 1150-1166) ----------------------------------
+// There the state IS spectral: the AR history of level k lives on the coefficients where the band-pass
+// weight exceeds 1e-12 ("compact" arrays), the noise is a field of unit phasors exp(i theta) with theta drawn
+// by RandomState.uniform (fftgenerators.py:407-418), filtered, standardised and decomposed without a
+// transform, and one irfft2 per member update turns the recomposed spectrum into the field.  Here the history
+// is kept as full half-spectrum planes (entries outside a level's mask are never read), one kernel does
+// noise -> levels -> AR(p) -> recomposition per coefficient:
+//   N = cos(theta) + i sin(theta)  (column 0 mirrored: theta[m - r, 0] = -theta[r, 0]);  y = N F, y[0, 0] = 0
+//   y /= std(y)                      (a complex array divided by a real scalar: NumPy multiplies by the reciprocal)
+//   e_k = (y W_k - mean_k) / std_k   (mean_k = 0: y has no DC;  std_k by Parseval - both standard deviations only
+//                                     depend on |N| = 1, F and W_k: constants of the nowcast, computed once on the host)
+//   x_k <- phi_k1 x_k[-1] + ... + phi_kp x_k[-p] + phi_k,p+1 (noise_std_k e_k)        on mask_k = {W_k > 1e-12}
+//   R   = sum_k mask_k (sigma_k x_k + mu_k)
+// The arithmetic follows the reference's sequence of element-wise operations; cos / sin come from the device
+// library (NumPy's from libm): parity to rounding, not bit for bit.
+struct PhaseAr {
+  double phi[kMaxLevels][kMaxOrder + 1];
+  double inv_std[kMaxLevels];  // 1 / std_k
+  double noise_std[kMaxLevels];
+  double mu[kMaxLevels], sigma[kMaxLevels];
+  double inv_stdn;             // 1 / std(y)
+  int nlevels, p, head, m, nc;
+};
+
+__global__ __launch_bounds__(kThreads) void spectral_phase_ar(double2 *__restrict__ cascades, const double *__restrict__ theta,
+                                                              const double *__restrict__ filt, const double *__restrict__ weights,
+                                                              PhaseAr a, double2 *__restrict__ out) {
+#pragma clang fp contract(off)
+  const size_t plane = static_cast<size_t>(a.m) * a.nc;
+  const int first_mirrored = a.m / 2 + 1;  // rows of column 0 that repeat an earlier row's phase with the opposite sign
+  for (int r = blockIdx.x; r < a.m; r += gridDim.x) {
+    for (int c = threadIdx.x; c < a.nc; c += kThreads) {
+      const size_t i = static_cast<size_t>(r) * a.nc + c;
+      const bool mirrored = c == 0 && r >= first_mirrored;
+      const double t = mirrored ? -theta[static_cast<size_t>(a.m - r) * a.nc] : theta[i];
+      double sn, cs;
+      sincos(t, &sn, &cs);
+      const double f = filt[i];
+      double2 y = i == 0 ? make_double2(0.0, 0.0) : make_double2(cs * f, sn * f);
+      y.x *= a.inv_stdn;
+      y.y *= a.inv_stdn;
+      double2 total = make_double2(0.0, 0.0);
+      for (int k = 0; k < a.nlevels; ++k) {
+        const double w = weights[static_cast<size_t>(k) * plane + i];
+        if (!(w > 1e-12)) continue;  // not a coefficient of this level
+        double2 e = make_double2(y.x * w, y.y * w);
+        e.x *= a.inv_std[k];
+        e.y *= a.inv_std[k];
+        e.x *= a.noise_std[k];
+        e.y *= a.noise_std[k];
+        double2 *lvl = cascades + static_cast<size_t>(k) * a.p * plane;
+        double2 acc = make_double2(0.0, 0.0);
+        for (int j = 0; j < a.p; ++j) {  // x[-1-j] sits in slot (head + p - 1 - j) mod p
+          int slot = a.head + a.p - 1 - j;
+          if (slot >= a.p) slot -= a.p;
+          const double2 x = lvl[static_cast<size_t>(slot) * plane + i];
+          acc.x += a.phi[k][j] * x.x;
+          acc.y += a.phi[k][j] * x.y;
+        }
+        acc.x += a.phi[k][a.p] * e.x;
+        acc.y += a.phi[k][a.p] * e.y;
+        lvl[static_cast<size_t>(a.head) * plane + i] = acc;
+        total.x += acc.x * a.sigma[k] + a.mu[k];
+        total.y += acc.y * a.sigma[k];
+      }
+      out[i] = total;
+    }
+  }
+}
+
+// ---- compact spectral arrays <-> full half-spectrum planes -------------------------------------------------
+// decomposition.py:233-236 stores level k as field[weights_k > 1e-12] (row-major).  mask_row_counts + one scan
+// give the position of every row's first kept coefficient; expand_compact walks a row with ballots.
+__global__ __launch_bounds__(kThreads) void mask_row_counts(const double *__restrict__ w, int nc, int *__restrict__ counts) {
+  __shared__ int s_part[kThreads / 64];
+  const double *row = w + static_cast<size_t>(blockIdx.x) * nc;
+  int mine = 0;
+  for (int c0 = 0; c0 < nc; c0 += kThreads) {
+    const int c = c0 + threadIdx.x;
+    mine += __popcll(__ballot(c < nc && row[c] > 1e-12));
+  }
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int q = 0; q < kThreads / 64; ++q) t += s_part[q];
+    counts[blockIdx.x] = t;
+  }
+}
+// exclusive scan of m counts in place, total behind them (one workgroup; m <= 8192)
+__global__ __launch_bounds__(kThreads) void scan_rows(int *__restrict__ counts, int m) {
+  __shared__ int s_carry, s_wave[kThreads / 64];
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < m; i0 += kThreads) {
+    const int i = i0 + threadIdx.x;
+    const int v = i < m ? counts[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d);
+      if ((threadIdx.x & 63) >= d) incl += up;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int before = s_carry;
+    for (int q = 0; q < static_cast<int>(threadIdx.x >> 6); ++q) before += s_wave[q];
+    if (i < m) counts[i] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == kThreads - 1) s_carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[m] = s_carry;
+}
+__global__ __launch_bounds__(kThreads) void expand_compact(const double *__restrict__ w, int nc, const int *__restrict__ offsets,
+                                                           const double2 *__restrict__ src, double2 *__restrict__ dst) {
+  __shared__ int s_part[kThreads / 64];
+  const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double *row = w + static_cast<size_t>(r) * nc;
+  double2 *out = dst + static_cast<size_t>(r) * nc;
+  int base = offsets[r];
+  for (int c0 = 0; c0 < nc; c0 += kThreads) {
+    const int c = c0 + threadIdx.x;
+    const bool kept = c < nc && row[c] > 1e-12;
+    const unsigned long long mask = __ballot(kept);
+    if (lane == 0) s_part[wave] = __popcll(mask);
+    __syncthreads();
+    int at = base;
+    for (int q = 0; q < wave; ++q) at += s_part[q];
+    if (c < nc) out[c] = kept ? src[at + __popcll(mask & ((1ull << lane) - 1ull))] : make_double2(0.0, 0.0);
+    for (int q = 0; q < kThreads / 64; ++q) base += s_part[q];
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void field_min_key(const double *__restrict__ field, size_t n,
                                                           unsigned long long *__restrict__ min_out) {
   const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
@@ -564,6 +699,71 @@ extern "C" int psh_field_min_key_dev(const double *field_dev, size_t n, unsigned
   // (few workgroups: every wave ends with an atomic on one address)
   hipLaunchKernelGGL(psh::field_min_key, dim3(std::min<unsigned>(psh::grid_for(n), 1024u)), dim3(psh::kThreads), 0, c.stream, field_dev, n,
                      min_key_dev);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+extern "C" int psh_steps_phase_ar_dev(void *cascades_dev, int nlevels, int p, int m, int n, int head, const double *phi_host,
+                                      const double *theta_dev, const double *filter_dev, const double *weights_dev,
+                                      double inv_std_noise, const double *inv_std_levels_host, const double *noise_std_host,
+                                      const double *mu_host, const double *sigma_host, void *field_spec_dev) {
+  PSH_REQUIRE_INIT();
+  if (!cascades_dev || !phi_host || !theta_dev || !filter_dev || !weights_dev || !inv_std_levels_host || !noise_std_host || !mu_host ||
+      !sigma_host || !field_spec_dev)
+    return fail(PSH_EINVAL, "steps_phase_ar: NULL pointer");
+  if (nlevels < 1 || nlevels > psh::kMaxLevels || p < 1 || p > psh::kMaxOrder)
+    return fail(PSH_EUNSUPPORTED, "steps_phase_ar: 1..%d cascade levels, AR order 1..%d", psh::kMaxLevels, psh::kMaxOrder);
+  if (m <= 0 || n <= 1 || head < 0 || head >= p) return fail(PSH_EINVAL, "steps_phase_ar: invalid shape or ring head");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  psh::PhaseAr a;
+  for (int k = 0; k < psh::kMaxLevels; ++k) {
+    for (int j = 0; j <= psh::kMaxOrder; ++j) a.phi[k][j] = (k < nlevels && j <= p) ? phi_host[static_cast<size_t>(k) * (p + 1) + j] : 0.0;
+    a.inv_std[k] = k < nlevels ? inv_std_levels_host[k] : 0.0;
+    a.noise_std[k] = k < nlevels ? noise_std_host[k] : 0.0;
+    a.mu[k] = k < nlevels ? mu_host[k] : 0.0;
+    a.sigma[k] = k < nlevels ? sigma_host[k] : 0.0;
+  }
+  a.inv_stdn = inv_std_noise;
+  a.nlevels = nlevels;
+  a.p = p;
+  a.head = head;
+  a.m = m;
+  a.nc = n / 2 + 1;
+  hipLaunchKernelGGL(psh::spectral_phase_ar, dim3(std::min(m, 4096)), dim3(psh::kThreads), 0, c.stream, static_cast<double2 *>(cascades_dev),
+                     theta_dev, filter_dev, weights_dev, a, static_cast<double2 *>(field_spec_dev));
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+// Level planes from the reference's compact spectral arrays (decomposition.py:233-236: field[weights > 1e-12]).
+//   psh_mask_row_offsets_dev     offsets (m + 1) int32: position of every row's first kept coefficient in the compact
+//                                array of this level, the number of kept coefficients behind them
+//   psh_expand_compact_c128_dev  dst (m, nc) complex128 = src scattered to the kept coefficients, zero elsewhere
+extern "C" int psh_mask_row_offsets_dev(const double *weights_dev, int m, int nc, int *offsets_dev) {
+  PSH_REQUIRE_INIT();
+  if (!weights_dev || !offsets_dev) return fail(PSH_EINVAL, "mask_row_offsets: NULL pointer");
+  if (m <= 0 || m > 8192 || nc <= 0) return fail(PSH_EUNSUPPORTED, "mask_row_offsets: 1..8192 rows");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  hipLaunchKernelGGL(psh::mask_row_counts, dim3(m), dim3(psh::kThreads), 0, c.stream, weights_dev, nc, offsets_dev);
+  hipLaunchKernelGGL(psh::scan_rows, dim3(1), dim3(psh::kThreads), 0, c.stream, offsets_dev, m);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
+extern "C" int psh_expand_compact_c128_dev(const double *weights_dev, int m, int nc, const int *offsets_dev, const void *src_dev,
+                                           void *dst_dev) {
+  PSH_REQUIRE_INIT();
+  if (!weights_dev || !offsets_dev || !src_dev || !dst_dev) return fail(PSH_EINVAL, "expand_compact: NULL pointer");
+  if (m <= 0 || nc <= 0) return fail(PSH_EINVAL, "expand_compact: invalid shape");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  hipLaunchKernelGGL(psh::expand_compact, dim3(m), dim3(psh::kThreads), 0, c.stream, weights_dev, nc, offsets_dev,
+                     static_cast<const double2 *>(src_dev), static_cast<double2 *>(dst_dev));
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }

@@ -67,6 +67,18 @@ class DeviceRandomStates:
         _lib.check(self._lib.psh_rng_randn_dev(self._h, count, out.ptr, 1 if side else 0), "psh_rng_randn_dev")
         return out
 
+    def uniform(self, low, high, *shape, out=None, side=False):
+        """The next ``prod(shape)`` values of ``uniform(low, high)`` of every generator (two words per value, like
+        ``RandomState.uniform``): a float64 DeviceArray ``(n_generators, *shape)``."""
+        count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        if out is None:
+            out = DeviceArray((self.n,) + tuple(int(s) for s in shape), np.float64)
+        elif out.dtype != np.float64 or out.size != self.n * count:
+            raise ValueError("out must be a float64 DeviceArray of n_generators * prod(shape) values")
+        _lib.check(self._lib.psh_rng_uniform_dev(self._h, count, float(low), float(high), out.ptr, 1 if side else 0),
+                   "psh_rng_uniform_dev")
+        return out
+
     def wait(self):
         """Make the library stream wait for a ``side=True`` draw."""
         _lib.check(self._lib.psh_rng_wait(self._h), "psh_rng_wait")

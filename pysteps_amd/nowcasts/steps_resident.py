@@ -19,10 +19,13 @@ patched in one by one (round 2) every call still crossed PCIe twice.
 It is built from the ``state`` / ``params`` dictionaries the reference hands to ``nowcast_main_loop``
 (steps.py:1014-1055) - the drop-in point is the loop (``register(patch_main_loop=True)``), not a fork
 of the nowcaster - and :func:`try_create` declines (returns None, the reference's own update function
-runs) whenever an option is set that the chain does not implement: ``domain="spectral"``, ``use_full_fft``
-filters, no noise, grid sides beyond the FFT kernels (any side up to 4096 is fine, powers of two up to
-8192), more than 16 cascade levels or AR order above 8.  ``mask_method`` None / ``"incremental"`` /
-``"obs"`` / ``"sprog"`` and ``probmatching_method`` None / ``"cdf"`` / ``"mean"`` are implemented.  A failure
+runs) whenever an option is set that the chain does not implement: ``use_full_fft`` filters, no noise, grid
+sides beyond the FFT kernels (any side up to 4096 is fine, powers of two up to 8192), more than 16 cascade
+levels or AR order above 8, ``domain="spectral"`` together with the S-PROG mask.  ``mask_method`` None /
+``"incremental"`` / ``"obs"`` / ``"sprog"`` and ``probmatching_method`` None / ``"cdf"`` / ``"mean"`` are
+implemented, and so is the reference's own ``domain="spectral"`` (round 4: the state is spectral THERE - per level
+the coefficients where the band-pass weight exceeds 1e-12 -, the noise a field of unit phasors with phases from
+``RandomState.uniform``; `csrc/steps_loop.hip` ``spectral_phase_ar``, one irfft2 per member update).  A failure
 while the device state is being built (out of memory, a generator the device streams do not reproduce)
 also ends in the reference's update, with a warning.
 
@@ -35,7 +38,9 @@ equal, and end to end to 1e-4 relative L2 against the stock ``nowcasts.steps`` (
 ``PYSTEPS_HIP_RESIDENT_DOMAIN=spatial`` selects the chain of the reference's spatial operators instead,
 whose element-wise steps are the reference's arithmetic operation by operation (csrc/steps_loop.hip,
 bit-identical with ``iterate_ar_model`` + ``recompose_fft``).  In both the transforms agree with numpy.fft
-to ~1e-16 and the random stream is NumPy's up to the rounding of ``log`` (csrc/cr_log.h).
+to ~1e-16 and the random stream is NumPy's up to the rounding of ``log`` (csrc/cr_log.h).  With the reference's
+``domain="spectral"`` the phases are NumPy's bit for bit, ``cos`` / ``sin`` come from the device library and the
+two standard deviations of the noise are taken as the constants they are (|exp(i theta)| = 1): the same bars.
 """
 
 import ctypes
@@ -142,8 +147,11 @@ class ResidentSteps:
             raise _Declined
         m, n = (int(s) for s in shape)
         p = params
-        if p["noise_method"] is None or p["domain"] != "spatial" or not hip_fft.supported_shape((m, n)):
+        if p["noise_method"] is None or p["domain"] not in ("spatial", "spectral") or not hip_fft.supported_shape((m, n)):
             raise _Declined
+        self.ref_spectral = p["domain"] == "spectral"  # the reference's own spectral domain (steps.py:122-126)
+        if self.ref_spectral and p["mask_method"] == "sprog":
+            raise _Declined  # (the deterministic S-PROG model in the spectral domain is not built)
         if not _is_fn(p["generate_noise"], "noise.fftgenerators", "generate_noise_2d_fft_filter"):
             raise _Declined
         if not _is_fn(p["decomp_method"], "cascade.decomposition", "decomposition_fft"):
@@ -174,9 +182,24 @@ class ResidentSteps:
         if not isinstance(cascades, DeviceArray) and len(cascades) != self.B:
             raise _Declined
         resident_cascades = isinstance(cascades, DeviceArray)  # state that never was on the host (bench.py)
-        if resident_cascades and (cascades.shape != (self.B, self.L, self.p, m, n) or cascades.dtype != np.float64):
+        if resident_cascades and (self.ref_spectral or cascades.shape != (self.B, self.L, self.p, m, n)
+                                  or cascades.dtype != np.float64):
             raise _Declined
+        level_masks = None
+        if self.ref_spectral:
+            # decomposition.py:233-236: level k lives on the coefficients where its weight exceeds 1e-12
+            level_masks = np.asarray(weights) > 1e-12
+            counts = [int(level_masks[k].sum()) for k in range(self.L)]
         for j in range(self.B):
+            if self.ref_spectral:
+                d = decomp[j]
+                if (not d.get("normalized", False) or d.get("domain") != "spectral" or not d.get("compact_output", False)
+                        or np.shape(d.get("weight_masks")) != (self.L, m, n // 2 + 1)
+                        or not np.array_equal(np.asarray(d["weight_masks"], dtype=bool), level_masks)):
+                    raise _Declined
+                if len(cascades[j]) != self.L or any(np.shape(cascades[j][k]) != (self.p, counts[k]) for k in range(self.L)):
+                    raise _Declined
+                continue
             if not resident_cascades and (len(cascades[j]) != self.L or any(np.shape(c) != (self.p, m, n) for c in cascades[j])):
                 raise _Declined
             if not decomp[j].get("normalized", False) or decomp[j].get("domain") != "spatial":
@@ -227,13 +250,48 @@ class ResidentSteps:
         # field apart from two standardisations that need second moments only (Parseval) - two transforms per
         # member update instead of nine (csrc/steps_loop.hip).  PYSTEPS_HIP_RESIDENT_DOMAIN=spatial keeps the
         # level fields and the chain of the reference's spatial operators (bit-identical element-wise part).
-        self.spectral = (os.environ.get("PYSTEPS_HIP_RESIDENT_DOMAIN", "spectral") != "spatial"
+        self.spectral = (not self.ref_spectral and os.environ.get("PYSTEPS_HIP_RESIDENT_DOMAIN", "spectral") != "spatial"
                          and _self_conjugate_columns_symmetric(weights, n) and _self_conjugate_columns_symmetric(F["field"], n))
         nc = n // 2 + 1
         # AR history: (B, L, p, m, n); slot s of the ring holds x[s] of the reference's series at start.  With the
         # spectral form a level field only passes through ONE staging plane on its way to its spectrum: the
         # device never holds the spatial history and its spectra together (8 B L p m n bytes less at the peak).
-        if self.spectral:
+        if self.ref_spectral:
+            # the reference's compact arrays, scattered into full half-spectrum planes on the device (the level's mask
+            # is read off the resident weights); the two standard deviations of the noise (fftgenerators.py:435-437, decomposition.py:
+            # 219-220 through utils/spectral.py:208-238) only see |exp(i theta)| = 1: constants of the nowcast
+            spectra = DeviceArray((self.B, self.L, self.p, m, nc), np.complex128)
+            stage = DeviceArray((self.p, max(counts)), np.complex128)
+            offsets = DeviceArray((self.L, m + 1), np.int32)
+            wplane = m * nc * 8
+            for k in range(self.L):
+                _lib.check(self._lib.psh_mask_row_offsets_dev(self.weights.ptr + k * wplane, m, nc, offsets.view(k).ptr),
+                           "psh_mask_row_offsets_dev")
+            for j in range(self.B):
+                for k in range(self.L):
+                    src = np.ascontiguousarray(cascades[j][k], dtype=np.complex128)  # (p, counts[k])
+                    _lib.check(self._lib.psh_memcpy_h2d(stage.ptr, src.ctypes.data, src.nbytes), "h2d")
+                    for slot in range(self.p):
+                        q = (j * self.L + k) * self.p + slot
+                        _lib.check(self._lib.psh_expand_compact_c128_dev(self.weights.ptr + k * wplane, m, nc, offsets.view(k).ptr,
+                                                                         stage.ptr + slot * counts[k] * 16,
+                                                                         spectra.ptr + q * m * nc * 16), "psh_expand_compact_c128_dev")
+                    _lib.check(self._lib.psh_sync(), "sync")  # `src` may go, the staging block is reused
+            self.cascades = spectra
+            self.field_spec = DeviceArray((m, nc), np.complex128)
+
+            def spectral_std(x):  # utils/spectral.py:231-238 for a REAL array of moduli
+                res = np.sum(x ** 2) - x[0, 0] ** 2
+                res += np.sum(x[:, 1:] ** 2) if n % 2 == 1 else np.sum(x[:, 1:-1] ** 2)
+                return np.sqrt(res / (m * n) ** 2)
+
+            f0 = np.array(F["field"], dtype=np.float64)
+            f0[0, 0] = 0.0
+            self.inv_std_noise = 1.0 / spectral_std(f0)  # (NumPy divides a complex array by a real scalar this way)
+            f0 *= self.inv_std_noise
+            w = np.asarray(weights, dtype=np.float64)
+            self.inv_std_levels, self._inv_std_levels_p = _c_doubles([1.0 / spectral_std(f0 * w[k]) for k in range(self.L)])
+        elif self.spectral:
             spectra = DeviceArray((self.B, self.L, self.p, m, nc), np.complex128)
             stage = None if resident_cascades else DeviceArray((m, n), np.float64)
             for j in range(self.B):
@@ -335,16 +393,25 @@ class ResidentSteps:
         self.pre = DeviceArray((self.B, m, n), np.float64) if self.pm_method == "cdf" else None
         self.pm_status = DeviceArray((max(self.B, 2),), np.int32) if self.pm_method == "cdf" else None
         self.min_key = DeviceArray((8,), np.uint64)
-        self.eps = DeviceArray((self.L, m, n), np.float64)  # cascade of one member's noise field
-        self.eps_stats = DeviceArray((self.L, 2), np.float64)  # (mean, std) of its levels
-        self.noise = DeviceArray((m, n), np.float64)
-        self.rng = DeviceRandomStates(gens, self.plane, n_draws=min(self.n_updates, 4096))
-        self.white = [DeviceArray((self.B, m, n), np.float64), DeviceArray((self.B, m, n), np.float64)]
+        self.eps = self.eps_stats = self.noise = None
+        if not (self.spectral or self.ref_spectral):  # the chain of spatial operators only
+            self.eps = DeviceArray((self.L, m, n), np.float64)  # cascade of one member's noise field
+            self.eps_stats = DeviceArray((self.L, 2), np.float64)  # (mean, std) of its levels
+            self.noise = DeviceArray((m, n), np.float64)
+        if self.ref_spectral:  # phases (m, n/2+1) per member instead of white noise (m, n)
+            self.rng = DeviceRandomStates(gens, m * nc, n_draws=min(self.n_updates, 4096))
+            self.white = [DeviceArray((self.B, m, nc), np.float64), DeviceArray((self.B, m, nc), np.float64)]
+        else:
+            self.rng = DeviceRandomStates(gens, self.plane, n_draws=min(self.n_updates, 4096))
+            self.white = [DeviceArray((self.B, m, n), np.float64), DeviceArray((self.B, m, n), np.float64)]
         self._white_ready = False
 
     # ------------------------------------------------------------------
     def _draw(self, slot):
-        self.rng.randn(self.m, self.n, out=self.white[slot], side=True)
+        if self.ref_spectral:  # fftgenerators.py:407: theta = randstate.uniform(low=0.0, high=2.0 * np.pi, size=(m, n/2+1))
+            self.rng.uniform(0.0, 2.0 * np.pi, self.m, self.n // 2 + 1, out=self.white[slot], side=True)
+        else:
+            self.rng.randn(self.m, self.n, out=self.white[slot], side=True)
 
     def update(self):
         """One ``__update_state``: float64 DeviceArray ``(n_members, m, n)`` of the members' new fields."""
@@ -373,7 +440,17 @@ class ResidentSteps:
         for j in range(self.B):
             result = out.view(j)
             field = self.pre.view(j) if self.pre is not None else result  # what the matching reads
-            if self.spectral:
+            if self.ref_spectral:
+                # phases -> unit phasors -> filter, standardisation, levels, AR step, recomposition per coefficient; ONE transform
+                nc = n // 2 + 1
+                casc = self.cascades.ptr + j * self.L * self.p * m * nc * 16
+                _lib.check(lib.psh_steps_phase_ar_dev(casc, self.L, self.p, m, n, self.head, self._phi_p, white.view(j).ptr,
+                                                      self.noise_filter.ptr, self.weights.ptr, self.inv_std_noise,
+                                                      self._inv_std_levels_p, self._noise_std_p, self.mu[j].ctypes.data,
+                                                      self.sigma[j].ctypes.data, self.field_spec.ptr), "psh_steps_phase_ar_dev")
+                _lib.check(lib.psh_fft_irfft2_dev(self.field_spec.ptr, m, n, field.ptr), "psh_fft_irfft2_dev")
+                _lib.check(lib.psh_field_min_key_dev(field.ptr, plane, self.min_key.ptr), "psh_field_min_key_dev")
+            elif self.spectral:
                 # rfft2(white); level variances by Parseval; AR step + recomposition on the spectra; ONE inverse transform
                 nc = n // 2 + 1
                 casc = self.cascades.ptr + j * self.L * self.p * m * nc * 16

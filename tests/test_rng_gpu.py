@@ -178,3 +178,35 @@ def test_chunked_production_by_jump_ahead(shape, hint, draws):
             _check_values(got[j], rs.randn(*shape))
         for a, rs in zip(dev.get_states(), host):
             _same_state(a, rs.get_state())
+
+
+@pytest.mark.parametrize("shape", [(64, 33), (101, 51), (1,), (1024, 513)])
+def test_uniform_bit_identical_with_numpy(shape):
+    """RandomState.uniform(low, high, size) - what the spectral-domain noise generator draws
+    (pysteps/noise/fftgenerators.py:407): integer arithmetic on two words per value and one
+    multiplication + addition, so the values are NumPy's bit for bit; draws of both kinds interleave on
+    one stream (a cached normal value survives a uniform draw) and the host generators continue it."""
+    from pysteps_amd.noise.randstate import DeviceRandomStates
+
+    host = _steps_chain(7, 3)
+    host[1].standard_normal()  # a cached value
+    host[2].random_sample(5)
+    twin = [np.random.RandomState() for _ in host]
+    for t, h in zip(twin, host):
+        t.set_state(h.get_state())
+    count = int(np.prod(shape))
+    dev = DeviceRandomStates(twin, count, n_draws=4)
+    for draw in range(4):
+        if draw == 2:
+            got = dev.randn(*shape).to_host()
+            for j, rs in enumerate(host):
+                _check_values(got[j], rs.randn(*shape))
+        else:
+            got = dev.uniform(0.0, 2.0 * np.pi, *shape).to_host()
+            for j, rs in enumerate(host):
+                np.testing.assert_array_equal(got[j], rs.uniform(low=0.0, high=2.0 * np.pi, size=shape))
+        for a, rs in zip(dev.get_states(), host):
+            _same_state(a, rs.get_state())
+    dev.sync_back()
+    for t, rs in zip(twin, host):
+        np.testing.assert_array_equal(t.randint(0, 1 << 30, 5), rs.randint(0, 1 << 30, 5))

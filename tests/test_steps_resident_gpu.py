@@ -220,6 +220,11 @@ CONFIGS = {
     "nomask_mean": dict(mask_method=None, probmatching_method="mean"),
     "ar1_8levels": dict(mask_method="incremental", probmatching_method="cdf", ar_order=1, n_cascade_levels=8),
     "sprog_cdf": dict(mask_method="sprog", probmatching_method="cdf"),  # deterministic AR model + percentile mask per step
+    # the reference's own spectral domain (steps.py:122-126): compact spectral state, phases from RandomState.uniform
+    "refspectral_incremental_cdf": dict(mask_method="incremental", probmatching_method="cdf", domain="spectral"),
+    "refspectral_composite_obs": dict(mask_method="obs", probmatching_method="mean", domain="spectral", shape=(150, 190)),
+    "refspectral_ar1_odd": dict(mask_method=None, probmatching_method=None, domain="spectral", ar_order=1, n_cascade_levels=8,
+                                shape=(127, 95)),
 }
 
 
@@ -244,7 +249,7 @@ def test_update_beside_the_reference_update(ref_pysteps, name, monkeypatch):
     m, n = cfg.pop("shape", (128, 128))
     frames, V = _steps_inputs(m, n)
     frames = frames[-(ar_order + 1):]
-    if name == "obs_none":
+    if name in ("obs_none", "refspectral_composite_obs"):
         frames = frames.copy()
         frames[:, :9, :] = np.nan  # a domain mask (steps.py:1217)
     kw = dict(n_ens_members=3, n_cascade_levels=6, precip_thr=-10.0, kmperpixel=1.0, timestep=5.0, seed=24, vel_pert_method=None,
@@ -292,8 +297,8 @@ def test_update_beside_the_reference_update(ref_pysteps, name, monkeypatch):
         assert median <= 1e-14, report
 
 
-@pytest.mark.parametrize("timesteps,vel_pert", [(3, "bps"), ([0.5, 1.0, 2.5], None)])
-def test_steps_end_to_end_resident_loop_runs_and_matches(ref_pysteps, timesteps, vel_pert):
+@pytest.mark.parametrize("timesteps,vel_pert,domain", [(3, "bps", "spatial"), ([0.5, 1.0, 2.5], None, "spatial"), (3, "bps", "spectral")])
+def test_steps_end_to_end_resident_loop_runs_and_matches(ref_pysteps, timesteps, vel_pert, domain):
     """the real nowcasts.steps with register(patch_main_loop=True): the resident update is what runs
     (counted), the result matches the stock run with the stock operators"""
     from pysteps import nowcasts
@@ -306,6 +311,7 @@ def test_steps_end_to_end_resident_loop_runs_and_matches(ref_pysteps, timesteps,
     kw = _steps_kwargs()
     kw["vel_pert_method"] = vel_pert
     kw["probmatching_method"] = "cdf"
+    kw["domain"] = domain
     steps = nowcasts.get_method("steps")
     want = steps(frames, V, timesteps, extrap_method="semilagrangian", **kw)
     calls = []
@@ -329,7 +335,7 @@ def test_steps_end_to_end_resident_loop_runs_and_matches(ref_pysteps, timesteps,
 
 
 def test_declined_options_take_the_reference_update(ref_pysteps):
-    """spectral domain: try_create returns None and the reference's own function runs"""
+    """spectral domain with the S-PROG mask: try_create returns None and the reference's own function runs"""
     from pysteps import nowcasts
 
     from pysteps_amd import register
@@ -347,8 +353,8 @@ def test_declined_options_take_the_reference_update(ref_pysteps):
         register.register(patch_main_loop=True)
         steps_resident.ResidentSteps.__init__ = spy
         out = nowcasts.get_method("steps")(frames, V, 2, n_ens_members=2, n_cascade_levels=6, precip_thr=-10.0, kmperpixel=1.0,
-                                           timestep=5.0, seed=1, domain="spectral", extrap_method="semilagrangian_hip",
-                                           num_workers=1)
+                                           timestep=5.0, seed=1, domain="spectral", mask_method="sprog",
+                                           extrap_method="semilagrangian_hip", num_workers=1)
     finally:
         steps_resident.ResidentSteps.__init__ = orig
         register.unpatch_main_loop()

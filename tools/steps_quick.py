@@ -38,13 +38,14 @@ ap.add_argument("--stock-steps", type=int, default=None)
 ap.add_argument("--no-stock", action="store_true")
 ap.add_argument("--levels", type=int, default=6)
 ap.add_argument("--no-resident", action="store_true", help="round-2 state: device operators, host member loop")
+ap.add_argument("--domain", default="spatial", choices=["spatial", "spectral"], help="nowcasts.steps(domain=...)")
 ap.add_argument("--profile", action="store_true", help="cProfile of the device run (host side), top of the list to stderr")
 args = ap.parse_args()
 size, members, timesteps = args.size, args.members, args.timesteps
 frames = synth.steps_frames(size, size, 3)
 V = synth.true_velocity(size, size).astype(np.float64)
 kw = dict(n_cascade_levels=args.levels, precip_thr=-10.0, kmperpixel=1.0, timestep=5.0, seed=42, vel_pert_method="bps",
-          mask_method="incremental", probmatching_method="cdf", num_workers=1, measure_time=True)
+          mask_method="incremental", probmatching_method="cdf", num_workers=1, measure_time=True, domain=args.domain)
 steps = nowcasts.get_method("steps")
 
 
@@ -55,7 +56,7 @@ def run(n_members, n_steps, **extra):
     return out, dict(total_s=time.perf_counter() - t, init_s=init_s, loop_s=loop_s)
 
 
-report = {"shape": [size, size], "members": members, "timesteps": timesteps, "cascade_levels": args.levels}
+report = {"shape": [size, size], "members": members, "timesteps": timesteps, "cascade_levels": args.levels, "domain": args.domain}
 want = None
 if not args.no_stock:
     sm = args.stock_members or members
