@@ -543,7 +543,8 @@ int psh_steps_spectral_ar_dev(void *cascades_dev, int nlevels, int p, int m, int
  *   cascades (nlevels, p, m, n/2+1) complex128 rings of FULL half-spectrum planes (slot `head` = oldest, overwritten;
  *   entries outside a level's mask are not touched);  inv_std_noise = 1 / spectral.std(F with F[0,0] = 0),
  *   inv_std_levels[k] = 1 / spectral.std(F / std_noise * W_k) - constants of a nowcast since |exp(i theta)| = 1;
- *   field_spec = sum_k mask_k (sigma_k X_k + mu_k)   (field = irfft2(field_spec)) */
+ *   field_spec = sum_k mask_k (sigma_k X_k + mu_k)   (field = irfft2(field_spec));
+ *   theta_dev == NULL: no innovation term (the deterministic model behind the S-PROG mask, steps.py:1089-1114) */
 int psh_steps_phase_ar_dev(void *cascades_dev, int nlevels, int p, int m, int n, int head, const double *phi_host,
                            const double *theta_dev, const double *filter_dev, const double *weights_dev,
                            double inv_std_noise, const double *inv_std_levels_host, const double *noise_std_host,

@@ -393,14 +393,17 @@ __global__ __launch_bounds__(kThreads) void spectral_phase_ar(double2 *__restric
   for (int r = blockIdx.x; r < a.m; r += gridDim.x) {
     for (int c = threadIdx.x; c < a.nc; c += kThreads) {
       const size_t i = static_cast<size_t>(r) * a.nc + c;
-      const bool mirrored = c == 0 && r >= first_mirrored;
-      const double t = mirrored ? -theta[static_cast<size_t>(a.m - r) * a.nc] : theta[i];
-      double sn, cs;
-      sincos(t, &sn, &cs);
-      const double f = filt[i];
-      double2 y = i == 0 ? make_double2(0.0, 0.0) : make_double2(cs * f, sn * f);
-      y.x *= a.inv_stdn;
-      y.y *= a.inv_stdn;
+      double2 y = make_double2(0.0, 0.0);
+      if (theta) {  // (uniform) nullptr: the deterministic model of the S-PROG mask, no innovation term (steps.py:1089-1097)
+        const bool mirrored = c == 0 && r >= first_mirrored;
+        const double t = mirrored ? -theta[static_cast<size_t>(a.m - r) * a.nc] : theta[i];
+        double sn, cs;
+        sincos(t, &sn, &cs);
+        const double f = filt[i];
+        if (i != 0) y = make_double2(cs * f, sn * f);
+        y.x *= a.inv_stdn;
+        y.y *= a.inv_stdn;
+      }
       double2 total = make_double2(0.0, 0.0);
       for (int k = 0; k < a.nlevels; ++k) {
         const double w = weights[static_cast<size_t>(k) * plane + i];
@@ -419,8 +422,10 @@ __global__ __launch_bounds__(kThreads) void spectral_phase_ar(double2 *__restric
           acc.x += a.phi[k][j] * x.x;
           acc.y += a.phi[k][j] * x.y;
         }
-        acc.x += a.phi[k][a.p] * e.x;
-        acc.y += a.phi[k][a.p] * e.y;
+        if (theta) {
+          acc.x += a.phi[k][a.p] * e.x;
+          acc.y += a.phi[k][a.p] * e.y;
+        }
         lvl[static_cast<size_t>(a.head) * plane + i] = acc;
         total.x += acc.x * a.sigma[k] + a.mu[k];
         total.y += acc.y * a.sigma[k];
@@ -708,9 +713,10 @@ extern "C" int psh_steps_phase_ar_dev(void *cascades_dev, int nlevels, int p, in
                                       double inv_std_noise, const double *inv_std_levels_host, const double *noise_std_host,
                                       const double *mu_host, const double *sigma_host, void *field_spec_dev) {
   PSH_REQUIRE_INIT();
-  if (!cascades_dev || !phi_host || !theta_dev || !filter_dev || !weights_dev || !inv_std_levels_host || !noise_std_host || !mu_host ||
-      !sigma_host || !field_spec_dev)
+  if (!cascades_dev || !phi_host || !weights_dev || !mu_host || !sigma_host || !field_spec_dev)
     return fail(PSH_EINVAL, "steps_phase_ar: NULL pointer");
+  if (theta_dev && (!filter_dev || !inv_std_levels_host || !noise_std_host))
+    return fail(PSH_EINVAL, "steps_phase_ar: phases without the noise filter and its constants");
   if (nlevels < 1 || nlevels > psh::kMaxLevels || p < 1 || p > psh::kMaxOrder)
     return fail(PSH_EUNSUPPORTED, "steps_phase_ar: 1..%d cascade levels, AR order 1..%d", psh::kMaxLevels, psh::kMaxOrder);
   if (m <= 0 || n <= 1 || head < 0 || head >= p) return fail(PSH_EINVAL, "steps_phase_ar: invalid shape or ring head");
@@ -720,8 +726,8 @@ extern "C" int psh_steps_phase_ar_dev(void *cascades_dev, int nlevels, int p, in
   psh::PhaseAr a;
   for (int k = 0; k < psh::kMaxLevels; ++k) {
     for (int j = 0; j <= psh::kMaxOrder; ++j) a.phi[k][j] = (k < nlevels && j <= p) ? phi_host[static_cast<size_t>(k) * (p + 1) + j] : 0.0;
-    a.inv_std[k] = k < nlevels ? inv_std_levels_host[k] : 0.0;
-    a.noise_std[k] = k < nlevels ? noise_std_host[k] : 0.0;
+    a.inv_std[k] = (theta_dev && k < nlevels) ? inv_std_levels_host[k] : 0.0;
+    a.noise_std[k] = (theta_dev && k < nlevels) ? noise_std_host[k] : 0.0;
     a.mu[k] = k < nlevels ? mu_host[k] : 0.0;
     a.sigma[k] = k < nlevels ? sigma_host[k] : 0.0;
   }

@@ -21,7 +21,7 @@ It is built from the ``state`` / ``params`` dictionaries the reference hands to 
 of the nowcaster - and :func:`try_create` declines (returns None, the reference's own update function
 runs) whenever an option is set that the chain does not implement: ``use_full_fft`` filters, no noise, grid
 sides beyond the FFT kernels (any side up to 4096 is fine, powers of two up to 8192), more than 16 cascade
-levels or AR order above 8, ``domain="spectral"`` together with the S-PROG mask.  ``mask_method`` None /
+levels or AR order above 8.  ``mask_method`` None /
 ``"incremental"`` / ``"obs"`` / ``"sprog"`` and ``probmatching_method`` None / ``"cdf"`` / ``"mean"`` are
 implemented, and so is the reference's own ``domain="spectral"`` (round 4: the state is spectral THERE - per level
 the coefficients where the band-pass weight exceeds 1e-12 -, the noise a field of unit phasors with phases from
@@ -150,8 +150,6 @@ class ResidentSteps:
         if p["noise_method"] is None or p["domain"] not in ("spatial", "spectral") or not hip_fft.supported_shape((m, n)):
             raise _Declined
         self.ref_spectral = p["domain"] == "spectral"  # the reference's own spectral domain (steps.py:122-126)
-        if self.ref_spectral and p["mask_method"] == "sprog":
-            raise _Declined  # (the deterministic S-PROG model in the spectral domain is not built)
         if not _is_fn(p["generate_noise"], "noise.fftgenerators", "generate_noise_2d_fft_filter"):
             raise _Declined
         if not _is_fn(p["decomp_method"], "cascade.decomposition", "decomposition_fft"):
@@ -223,10 +221,15 @@ class ResidentSteps:
                 raise _Declined
         elif p["mask_method"] == "sprog":
             det, det_d = state.get("precip_m"), state.get("precip_m_d")
-            if (det is None or not isinstance(det_d, dict) or len(det) != self.L
-                    or any(np.shape(c) != (phi.shape[1] - 1, m, n) for c in det)
-                    or not det_d.get("normalized", False) or det_d.get("domain") != "spatial" or p.get("war") is None
-                    or _percentile_index(m * n, float(p["war"])) is None):
+            if (det is None or not isinstance(det_d, dict) or len(det) != self.L or not det_d.get("normalized", False)
+                    or p.get("war") is None or _percentile_index(m * n, float(p["war"])) is None):
+                raise _Declined
+            if self.ref_spectral:
+                if (det_d.get("domain") != "spectral" or not det_d.get("compact_output", False)
+                        or any(np.shape(det[k]) != (phi.shape[1] - 1, counts[k]) for k in range(self.L))
+                        or not np.array_equal(np.asarray(det_d.get("weight_masks"), dtype=bool), level_masks)):
+                    raise _Declined
+            elif det_d.get("domain") != "spatial" or any(np.shape(c) != (phi.shape[1] - 1, m, n) for c in det):
                 raise _Declined
         if p["probmatching_method"] == "cdf":
             tgt = p["precip"]
@@ -267,16 +270,21 @@ class ResidentSteps:
             for k in range(self.L):
                 _lib.check(self._lib.psh_mask_row_offsets_dev(self.weights.ptr + k * wplane, m, nc, offsets.view(k).ptr),
                            "psh_mask_row_offsets_dev")
-            for j in range(self.B):
+
+            def expand(levels, dst_ptr):  # levels: L compact arrays (p, counts[k]) -> (L, p, m, nc) planes at dst_ptr
                 for k in range(self.L):
-                    src = np.ascontiguousarray(cascades[j][k], dtype=np.complex128)  # (p, counts[k])
+                    src = np.ascontiguousarray(levels[k], dtype=np.complex128)
                     _lib.check(self._lib.psh_memcpy_h2d(stage.ptr, src.ctypes.data, src.nbytes), "h2d")
                     for slot in range(self.p):
-                        q = (j * self.L + k) * self.p + slot
                         _lib.check(self._lib.psh_expand_compact_c128_dev(self.weights.ptr + k * wplane, m, nc, offsets.view(k).ptr,
                                                                          stage.ptr + slot * counts[k] * 16,
-                                                                         spectra.ptr + q * m * nc * 16), "psh_expand_compact_c128_dev")
+                                                                         dst_ptr + (k * self.p + slot) * m * nc * 16),
+                                   "psh_expand_compact_c128_dev")
                     _lib.check(self._lib.psh_sync(), "sync")  # `src` may go, the staging block is reused
+
+            for j in range(self.B):
+                expand(cascades[j], spectra.ptr + j * self.L * self.p * m * nc * 16)
+            self._expand_compact = expand
             self.cascades = spectra
             self.field_spec = DeviceArray((m, nc), np.complex128)
 
@@ -351,19 +359,21 @@ class ResidentSteps:
             # recomposed field thresholded at the percentile that keeps the observed wet-area ratio is the
             # mask of EVERY member at that time step
             det, det_d = state.get("precip_m"), state.get("precip_m_d")
-            if (det is None or not isinstance(det_d, dict) or len(det) != self.L or any(np.shape(c) != (self.p, m, n) for c in det)
-                    or not det_d.get("normalized", False) or det_d.get("domain") != "spatial" or p.get("war") is None):
-                raise _Declined
             self.war = float(p["war"])
             self.det_index = _percentile_index(self.plane, self.war)
             if self.det_index is None:
                 raise _Declined  # (the reference's own index arithmetic runs off the end there)
-            self.det = DeviceArray.from_host(np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.float64) for c in det])))
+            if self.ref_spectral:
+                self.det = DeviceArray((self.L, self.p, m, nc), np.complex128)
+                self._expand_compact(det, self.det.ptr)
+            else:
+                self.det = DeviceArray.from_host(np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.float64) for c in det])))
             self.det_head = 0
             self.det_mu = np.ascontiguousarray(det_d["means"], dtype=np.float64)
             self.det_sigma = np.ascontiguousarray(det_d["stds"], dtype=np.float64)
             self.det_field = DeviceArray((m, n), np.float64)
             self.keep = DeviceArray((m, n), np.uint8)
+        self._expand_compact = None  # (releases the staging block of the compact uploads)
         self.target = None
         if self.pm_method == "cdf":
             tgt = p["precip"]
@@ -522,9 +532,15 @@ class ResidentSteps:
         import ctypes  # noqa: PLC0415
 
         lib, plane = self._lib, self.plane
-        _lib.check(lib.psh_steps_ar_recompose_dev(self.det.ptr, self.L, self.p, plane, self.det_head, self._phi_p, None, None,
-                                                  self.det_mu.ctypes.data, self.det_sigma.ctypes.data, self.det_field.ptr, None),
-                   "psh_steps_ar_recompose_dev")
+        if self.ref_spectral:  # the same AR step without innovation on the compact spectral levels, one transform
+            _lib.check(lib.psh_steps_phase_ar_dev(self.det.ptr, self.L, self.p, self.m, self.n, self.det_head, self._phi_p, None, None,
+                                                  self.weights.ptr, 0.0, None, None, self.det_mu.ctypes.data,
+                                                  self.det_sigma.ctypes.data, self.field_spec.ptr), "psh_steps_phase_ar_dev")
+            _lib.check(lib.psh_fft_irfft2_dev(self.field_spec.ptr, self.m, self.n, self.det_field.ptr), "psh_fft_irfft2_dev")
+        else:
+            _lib.check(lib.psh_steps_ar_recompose_dev(self.det.ptr, self.L, self.p, plane, self.det_head, self._phi_p, None, None,
+                                                      self.det_mu.ctypes.data, self.det_sigma.ctypes.data, self.det_field.ptr, None),
+                       "psh_steps_ar_recompose_dev")
         self.det_head = (self.det_head + 1) % self.p
         thr = ctypes.c_double()
         rc = lib.psh_order_statistic_dev(self.det_field.ptr, plane, self.det_index, ctypes.byref(thr))

@@ -223,6 +223,7 @@ CONFIGS = {
     # the reference's own spectral domain (steps.py:122-126): compact spectral state, phases from RandomState.uniform
     "refspectral_incremental_cdf": dict(mask_method="incremental", probmatching_method="cdf", domain="spectral"),
     "refspectral_composite_obs": dict(mask_method="obs", probmatching_method="mean", domain="spectral", shape=(150, 190)),
+    "refspectral_sprog_cdf": dict(mask_method="sprog", probmatching_method="cdf", domain="spectral"),
     "refspectral_ar1_odd": dict(mask_method=None, probmatching_method=None, domain="spectral", ar_order=1, n_cascade_levels=8,
                                 shape=(127, 95)),
 }
@@ -335,7 +336,8 @@ def test_steps_end_to_end_resident_loop_runs_and_matches(ref_pysteps, timesteps,
 
 
 def test_declined_options_take_the_reference_update(ref_pysteps):
-    """spectral domain with the S-PROG mask: try_create returns None and the reference's own function runs"""
+    """a noise generator the resident chain does not implement (short-space Fourier transform): try_create
+    returns None and the reference's own function runs"""
     from pysteps import nowcasts
 
     from pysteps_amd import register
@@ -353,7 +355,7 @@ def test_declined_options_take_the_reference_update(ref_pysteps):
         register.register(patch_main_loop=True)
         steps_resident.ResidentSteps.__init__ = spy
         out = nowcasts.get_method("steps")(frames, V, 2, n_ens_members=2, n_cascade_levels=6, precip_thr=-10.0, kmperpixel=1.0,
-                                           timestep=5.0, seed=1, domain="spectral", mask_method="sprog",
+                                           timestep=5.0, seed=1, noise_method="ssft",
                                            extrap_method="semilagrangian_hip", num_workers=1)
     finally:
         steps_resident.ResidentSteps.__init__ = orig
