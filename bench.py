@@ -304,7 +304,8 @@ def roofline_lk(frames_d, m, n, pairs):
                                "alg_bytes_per_step": total_bytes, "achieved": total_bytes / (total_ns * 1e-9) / 1e9,
                                "frac": total_bytes / (total_ns * 1e-9) / 1e9 / HBM_PEAK_GBS, "per_kernel": passes}
     valu = {}
-    for name in ("idw_fine3", "idw_coarse", "lk_corner_response_cols", "lk_track_rows", "outliers_local"):
+    for name in ("idw_fine3", "idw_coarse", "lk_corner_response_cols", "lk_track_rows", "lk_open_bits", "lk_to_u8_bits",
+                 "outliers_local_sorted"):
         c = counters.get(name)
         if not c or "SQ_INSTS_VALU" not in c or "GRBM_GUI_ACTIVE" not in c:
             continue

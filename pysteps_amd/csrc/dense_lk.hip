@@ -20,6 +20,10 @@
 namespace {
 
 // RAII for psh_malloc blocks (stream-ordered free)
+__global__ __launch_bounds__(256) void zero_dwords(unsigned *__restrict__ p, size_t n) {
+  for (size_t i = threadIdx.x; i < n; i += 256) p[i] = 0u;
+}
+
 struct DevBlock {
   void *p = nullptr;
   ~DevBlock() {
@@ -96,7 +100,11 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
   double *d_pxy = reinterpret_cast<double *>(pbase), *d_puv = reinterpret_cast<double *>(pbase + off_uv);
   int *d_pcnt = reinterpret_cast<int *>(pbase + off_cnt);
   unsigned char *d_pfl = reinterpret_cast<unsigned char *>(pbase + off_fl);
-  PSH_HIP(hipMemsetAsync(pbase + off_cnt, 0, off_slots + slot_bytes * nframes - off_cnt, c.stream));
+  // (a kernel of its own instead of hipMemsetAsync: the runtime's fill comes with ~6 us of dispatch gap in front
+  // of it, and it is the first thing on the estimate's critical path; all offsets are multiples of 256 bytes)
+  hipLaunchKernelGGL(zero_dwords, dim3(1), dim3(256), 0, c.stream, reinterpret_cast<unsigned *>(pbase + off_cnt),
+                     (off_slots + slot_bytes * nframes - off_cnt) / 4);
+  PSH_HIP(hipGetLastError());
   auto frame_slots = [&](int t) { return reinterpret_cast<unsigned *>(pbase + off_slots + slot_bytes * t); };
   DevBlock ws_main, ws_side;  // allocated before any fork, released after the last join
   if (int rc = ws_main.alloc(psh::lk_prepare_ws_bytes(m, n, f64))) return rc;
