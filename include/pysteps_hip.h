@@ -132,6 +132,13 @@ int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *
 int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
                     const double *steps_host, int T, int n_iter, int interp_order,
                     float outval, double *disp_dev, int resume, float *out_dev);
+/* The same with the motion field ALSO given as (m, n, 2) {u, v} pairs (velocity_uv_dev, 16-byte aligned; NULL: as
+ * above) - the layout the kernel gathers from; without it every call interleaves the two planes first (0.04 ms at
+ * 4096^2).  psh_dense_lk_uv_dev writes such a copy from its interpolation kernel.  The two arrays have to hold the
+ * same field: the planes are still read where the pairs are not (other kernel variants, interp_order != 1). */
+int psh_semilag_uv_dev(const float *precip_dev, const float *velocity_dev, const float *velocity_uv_dev, int m, int n,
+                       const double *steps_host, int T, int n_iter, int interp_order, float outval, double *disp_dev,
+                       int resume, float *out_dev);
 
 /* Row-band form for output tiling across GPUs (BASELINE config 5: every rank holds the whole
  * input - it is tiny next to 288 GB - and advects only its band): pixels of rows
@@ -374,6 +381,10 @@ typedef struct psh_lk_params {
 int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int n, const psh_lk_params *params,
                      float *field_dev, double *xy_host, double *uv_host, int capacity,
                      int *count_out);
+/* ... with the dense field once more as (m, n, 2) {u, v} pairs in field_uv_dev (may be NULL; needs field_dev) */
+int psh_dense_lk_uv_dev(const float *frames_dev, int nframes, int m, int n, const psh_lk_params *params,
+                        float *field_dev, float *field_uv_dev, double *xy_host, double *uv_host, int capacity,
+                        int *count_out);
 
 /* ---- sparse vector QC: local Mahalanobis outlier test ----------------------- *
  * The form of pysteps/utils/cleansing.py:124-249 (detect_outliers) used by dense LK

@@ -152,7 +152,11 @@ SIGNATURES = {
     "psh_nonfinite_count_f64_dev": (c_int, [c_void_p, c_size_t, POINTER(c_double)]),
     "psh_field_stats_dev": (c_int, [c_void_p, c_size_t, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "psh_dense_lk_dev": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(LkParams), c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),
+    "psh_dense_lk_uv_dev": (c_int, [c_void_p, c_int, c_int, c_int, POINTER(LkParams), c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    POINTER(c_int)]),
     "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
+    "psh_semilag_uv_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
+                                   c_void_p]),
     "psh_semilag_rows_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),
 }

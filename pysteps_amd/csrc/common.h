@@ -143,6 +143,7 @@ struct IdwArgs {
   const float *xy;  // (L,2) device: x, y of the sparse vectors
   const float *uv;  // (L,2) device: values
   float *out;       // (2,m,n) device
+  float *out_uv = nullptr;  // (m,n,2) device, optional: the same field as {u,v} pairs (two-level kernels only)
   int L, k, m, n;
   float x0, dx, y0, dy;  // target grid: x = x0 + dx*i (i<n), y = y0 + dy*j (j<m)
   float inv_res, power, offset, dmax;
@@ -153,7 +154,7 @@ struct IdwArgs {
 };
 hipError_t launch_idw(const IdwArgs &a, hipStream_t stream);
 int idw_resident(const float *xy_dev, const float *values_dev, int capacity, const IdwDyn *dyn_dev, int m, int n,
-                 int k, double power, double dist_offset, float *out_dev);
+                 int k, double power, double dist_offset, float *out_dev, float *out_uv_dev = nullptr);
 size_t idw_scratch_bytes(int m, int n);
 void set_idw_variant(int v);
 

@@ -38,10 +38,23 @@ struct DevBlock {
 
 }  // namespace
 
+extern "C" int psh_dense_lk_uv_dev(const float *frames_dev, int nframes, int m, int n, const psh_lk_params *prm,
+                                   float *field_dev, float *field_uv_dev, double *xy_host, double *uv_host, int capacity,
+                                   int *count_out);
+
 extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int n,
                                 const psh_lk_params *prm, float *field_dev, double *xy_host,
                                 double *uv_host, int capacity, int *count_out) {
+  return psh_dense_lk_uv_dev(frames_dev, nframes, m, n, prm, field_dev, nullptr, xy_host, uv_host, capacity, count_out);
+}
+
+// field_uv_dev (may be NULL; needs field_dev): the dense field once more as (m, n, 2) {u, v} pairs, written by the
+// interpolation kernel itself - what psh_semilag_uv_dev takes instead of interleaving the planes on every call
+extern "C" int psh_dense_lk_uv_dev(const float *frames_dev, int nframes, int m, int n, const psh_lk_params *prm,
+                                   float *field_dev, float *field_uv_dev, double *xy_host, double *uv_host, int capacity,
+                                   int *count_out) {
   PSH_REQUIRE_INIT();
+  if (field_uv_dev && !field_dev) return psh::fail(PSH_EINVAL, "dense_lk: the interleaved field without the field itself");
   if (!frames_dev || !prm) return psh::fail(PSH_EINVAL, "dense_lk: NULL pointer");
   if (nframes < 1 || m <= 0 || n <= 0) return psh::fail(PSH_EINVAL, "dense_lk: invalid shape");
   if (!field_dev && !(xy_host && uv_host && count_out))
@@ -190,7 +203,7 @@ extern "C" int psh_dense_lk_dev(const float *frames_dev, int nframes, int m, int
     PSH_HIP(psh::launch_vectors_finish(d_pxy, d_puv, d_pfl, d_pcnt, capacity_dev, prm->decl_scale, m, n, d_xy, d_uv,
                                        d_dyn, c.stream));
     if (int rc = psh::idw_resident(d_xy, d_uv, capacity_dev, d_dyn, m, n, prm->idw_k, prm->idw_power,
-                                   prm->idw_dist_offset, field_dev))
+                                   prm->idw_dist_offset, field_dev, field_uv_dev))
       return rc;
     mark("dense field queued");
     if (count_out) {  // the caller asks how many vectors the field was made from: one 4-byte copy

@@ -648,7 +648,10 @@ __global__ __launch_bounds__(64) void idw_fine3(const float2 *__restrict__ xy, c
                                                 float offset, float *__restrict__ out, int supers_x,
                                                 const SuperHeader *__restrict__ headers,
                                                 const float4 *__restrict__ lists, int tiles_x, int n_tiles,
-                                                int tiles_per_xcd, const IdwDyn *__restrict__ dyn) {
+                                                int tiles_per_xcd, const IdwDyn *__restrict__ dyn,
+                                                float2 *__restrict__ out_uv) {
+  // out_uv (may be nullptr): the same field once more as {u, v} pairs per pixel - the layout the extrapolator
+  // gathers the motion field from (semilag.hip pack_velocity), written here instead of by a pass of its own
   __shared__ float4 s_cand[kFineCap];  // [certain | undecided], each group in index order
   const int b = blockIdx.x;
   const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;  // XCD-contiguous tiles
@@ -667,10 +670,12 @@ __global__ __launch_bounds__(64) void idw_fine3(const float2 *__restrict__ xy, c
       if (live_a) {
         out[at_a] = cu;
         out[plane + at_a] = cv;
+        if (out_uv) out_uv[at_a] = make_float2(cu, cv);
       }
       if (live_b) {
         out[at_a + 8] = cu;
         out[plane + at_a + 8] = cv;
+        if (out_uv) out_uv[at_a + 8] = make_float2(cu, cv);
       }
       return;
     }
@@ -814,9 +819,11 @@ __global__ __launch_bounds__(64) void idw_fine3(const float2 *__restrict__ xy, c
   }
   out[at_a] = o_u.x;
   out[plane + at_a] = o_v.x;
+  if (out_uv) out_uv[at_a] = make_float2(o_u.x, o_v.x);
   if (live_b) {
     out[at_a + 8] = o_u.y;
     out[plane + at_a + 8] = o_v.y;
+    if (out_uv) out_uv[at_a + 8] = make_float2(o_u.y, o_v.y);
   }
 }
 
@@ -859,7 +866,8 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
     const dim3 grid(tiles_per_xcd * kNumXcd), block(64);
 #define PSH_IDW_FINE(KMAX)                                                                                           \
   hipLaunchKernelGGL((idw_fine3<KMAX>), grid, block, 0, stream, xy, uv, a.L, a.k, a.m, a.n, a.x0, a.dx, a.y0, a.dy, \
-                     a.inv_res, a.power, a.offset, a.out, supers_x, headers, lists, tiles_x, n_tiles, tiles_per_xcd, a.dyn)
+                     a.inv_res, a.power, a.offset, a.out, supers_x, headers, lists, tiles_x, n_tiles, tiles_per_xcd, a.dyn, \
+                     reinterpret_cast<float2 *>(a.out_uv))
     if (k_eff <= 8) {
       PSH_IDW_FINE(8);
     } else if (k_eff <= 20) {
@@ -870,6 +878,7 @@ hipError_t launch_idw(const IdwArgs &a, hipStream_t stream) {
 #undef PSH_IDW_FINE
     return hipGetLastError();
   }
+  if (a.out_uv) return hipErrorInvalidValue;  // (only the two-level kernels write the interleaved copy)
   const int tiles_x = (a.n + kTile - 1) / kTile;
   const int tiles_y = (a.m + kTile - 1) / kTile;
   const int n_tiles = tiles_x * tiles_y;
@@ -949,7 +958,7 @@ extern "C" int psh_idw_dev(const float *xy_dev, const float *values_dev, int L, 
 // the samples is known on the host, the call only queues kernels.  k <= 0: every sample.
 namespace psh {
 int idw_resident(const float *xy_dev, const float *values_dev, int capacity, const IdwDyn *dyn_dev, int m, int n,
-                 int k, double power, double dist_offset, float *out_dev) {
+                 int k, double power, double dist_offset, float *out_dev, float *out_uv_dev) {
   if (!xy_dev || !values_dev || !dyn_dev || !out_dev) return fail(PSH_EINVAL, "idw: NULL pointer");
   if (capacity <= 0 || m <= 0 || n <= 0) return fail(PSH_EINVAL, "idw: invalid shape");
   if (k > 32) return fail(PSH_EUNSUPPORTED, "idw: k=%d > 32 is not implemented", k);
@@ -960,6 +969,7 @@ int idw_resident(const float *xy_dev, const float *values_dev, int capacity, con
   a.xy = xy_dev;
   a.uv = values_dev;
   a.out = out_dev;
+  a.out_uv = out_uv_dev;
   a.L = capacity;
   a.k = k <= 0 ? 0x7fffffff : k;
   a.m = m;

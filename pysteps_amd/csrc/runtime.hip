@@ -452,10 +452,26 @@ int psh_event_elapsed_ms(void *start, void *stop, float *ms) {
 // semi-Lagrangian extrapolation
 // ---------------------------------------------------------------------------
 
+static int semilag_rows(const float *precip_dev, const float *velocity_dev, const float *velocity_uv_dev, int m, int n,
+                        const double *steps_host, int T, int n_iter, int interp_order, float outval, double *disp_dev,
+                        int resume, int row_begin, int row_count, float *out_dev);
+
 int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
                          const double *steps_host, int T, int n_iter, int interp_order,
                          float outval, double *disp_dev, int resume, int row_begin, int row_count,
-                         float *out_dev);
+                         float *out_dev) {
+  return semilag_rows(precip_dev, velocity_dev, nullptr, m, n, steps_host, T, n_iter, interp_order, outval, disp_dev, resume,
+                      row_begin, row_count, out_dev);
+}
+
+// velocity_uv_dev (may be NULL): the {u, v}-interleaved (m, n, 2) copy of velocity_dev that the kernel gathers from,
+// given by the caller (psh_dense_lk_uv_dev writes one) instead of being made by a pass over the planes on every call
+int psh_semilag_uv_dev(const float *precip_dev, const float *velocity_dev, const float *velocity_uv_dev, int m, int n,
+                       const double *steps_host, int T, int n_iter, int interp_order, float outval, double *disp_dev,
+                       int resume, float *out_dev) {
+  return semilag_rows(precip_dev, velocity_dev, velocity_uv_dev, m, n, steps_host, T, n_iter, interp_order, outval, disp_dev,
+                      resume, 0, m, out_dev);
+}
 
 int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
                     const double *steps_host, int T, int n_iter, int interp_order,
@@ -464,10 +480,9 @@ int psh_semilag_dev(const float *precip_dev, const float *velocity_dev, int m, i
                               outval, disp_dev, resume, 0, m, out_dev);
 }
 
-int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
-                         const double *steps_host, int T, int n_iter, int interp_order,
-                         float outval, double *disp_dev, int resume, int row_begin, int row_count,
-                         float *out_dev) {
+static int semilag_rows(const float *precip_dev, const float *velocity_dev, const float *velocity_uv_dev, int m, int n,
+                        const double *steps_host, int T, int n_iter, int interp_order, float outval, double *disp_dev,
+                        int resume, int row_begin, int row_count, float *out_dev) {
   PSH_REQUIRE_INIT();
   if (row_begin < 0 || row_count <= 0 || row_begin + row_count > m)
     return fail(PSH_EINVAL, "semilag: row band [%d, %d) outside the %d-row image", row_begin,
@@ -545,11 +560,14 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
     // and, for bilinear resampling over several lead times, the row-pair copy of the field behind it
     const size_t plane = static_cast<size_t>(m) * n;
     const bool pairs = psh::semilag_wants_field_pairs(a);
-    int rc = psh_malloc(&packed_blk, (pairs ? 4 : 2) * plane * sizeof(float));
+    const bool own_uv = velocity_uv_dev == nullptr || reinterpret_cast<uintptr_t>(velocity_uv_dev) % 16 != 0;
+    int rc = PSH_OK;
+    if (own_uv || pairs) rc = psh_malloc(&packed_blk, ((own_uv ? 2 : 0) + (pairs ? 2 : 0)) * plane * sizeof(float));
     if (rc == PSH_OK) {
-      hipError_t pe = psh::launch_pack_velocity(velocity_dev, static_cast<float *>(packed_blk), plane, c.stream);
+      hipError_t pe = hipSuccess;
+      if (own_uv) pe = psh::launch_pack_velocity(velocity_dev, static_cast<float *>(packed_blk), plane, c.stream);
       if (pe == hipSuccess && pairs) {
-        float *pp = static_cast<float *>(packed_blk) + 2 * plane;
+        float *pp = static_cast<float *>(packed_blk) + (own_uv ? 2 : 0) * plane;
         pe = psh::launch_pack_field_rows(precip_dev, pp, m, n, c.stream);
         a.field_pairs = pp;
       }
@@ -560,7 +578,7 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
       if (spline_blk) (void)psh_free(spline_blk);
       return rc;
     }
-    a.vel_packed = static_cast<const float *>(packed_blk);
+    a.vel_packed = own_uv ? static_cast<const float *>(packed_blk) : velocity_uv_dev;
   }
   const hipError_t le = psh::launch_semilag(a, c.stream);
   if (spline_blk) (void)psh_free(spline_blk);  // stream-ordered: the launch above is queued first

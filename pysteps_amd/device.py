@@ -13,12 +13,16 @@ from . import _lib
 
 
 class DeviceArray:
-    __slots__ = ("ptr", "shape", "dtype", "_owner", "_keep", "__weakref__")
+    # uv_pairs: for a (2, m, n) float32 motion field made by dense_lucaskanade, the same field as (m, n, 2) {u, v}
+    # pairs (written by the interpolation kernel) - the layout the extrapolator gathers from, so that it need not
+    # interleave the planes on every call.  Whoever writes into the array's memory through `ptr` sets it to None.
+    __slots__ = ("ptr", "shape", "dtype", "_owner", "_keep", "uv_pairs", "__weakref__")
 
     def __init__(self, shape, dtype=np.float32, ptr=None, owner=None):
         self.shape = tuple(int(s) for s in np.atleast_1d(shape))
         self.dtype = np.dtype(dtype)
         self._keep = None  # objects that must outlive work queued on this array
+        self.uv_pairs = None
         if ptr is None:
             p = ctypes.c_void_p()
             _lib.check(_lib.lib().psh_malloc(ctypes.byref(p), self.nbytes), "psh_malloc")
@@ -91,6 +95,7 @@ class DeviceArray:
         return DeviceArray(self.shape[1:], self.dtype, ptr=self.ptr + index * stride, owner=self)
 
     def fill_bytes(self, byte_value=0):
+        self.uv_pairs = None
         _lib.check(_lib.lib().psh_memset(self.ptr, int(byte_value), self.nbytes), "memset")
         return self
 

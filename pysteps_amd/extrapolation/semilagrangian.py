@@ -300,12 +300,17 @@ def _run_device(lib, precip, velocity, steps, outval, displacement_prev, n_iter,
     elif return_displacement:
         disp = DeviceArray((2, m, n), np.float64)
     out = None if precip is None else DeviceArray((T, m, n), np.float32)
-    rc = lib.psh_semilag_dev(
-        None if precip is None else precip.ptr, velocity.ptr, m, n, steps.ctypes.data, T,
-        n_iter, int(interp_order), float(outval) if precip is not None else float("nan"),
+    # a motion field that comes with its {u, v}-interleaved twin (dense_lucaskanade on resident frames) is
+    # gathered from that twin directly
+    pairs = getattr(velocity, "uv_pairs", None)
+    if pairs is not None and (pairs.shape != (m, n, 2) or pairs.dtype != np.float32):
+        pairs = None
+    rc = lib.psh_semilag_uv_dev(
+        None if precip is None else precip.ptr, velocity.ptr, None if pairs is None else pairs.ptr, m, n,
+        steps.ctypes.data, T, n_iter, int(interp_order), float(outval) if precip is not None else float("nan"),
         None if disp is None else disp.ptr, resume, None if out is None else out.ptr,
     )
-    _lib.check(rc, "psh_semilag_dev")
+    _lib.check(rc, "psh_semilag_uv_dev")
     if precip is None:
         return None, disp
     return (out, disp) if return_displacement else out

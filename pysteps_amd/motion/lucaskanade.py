@@ -195,12 +195,17 @@ def _dense_lk_native(frames, on_device, dense, size_opening, buffer_mask, max_co
         field = DeviceArray((2, m, n), np.float32)
         # resident frames in, resident field out: the call only queues kernels (no count asked for,
         # so nothing waits for the device); host callers get the sample count with the field
-        rc = lib.psh_dense_lk_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), field.ptr, None, None, 0,
-                                  None if on_device else ctypes.byref(count))
+        # (a resident field also gets its {u, v}-interleaved twin, written by the interpolation kernel: the
+        # extrapolator gathers from that layout and would otherwise interleave the planes on every call)
+        pairs = DeviceArray((m, n, 2), np.float32) if on_device else None
+        rc = lib.psh_dense_lk_uv_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), field.ptr,
+                                     None if pairs is None else pairs.ptr, None, None, 0,
+                                     None if on_device else ctypes.byref(count))
         if rc == _lib.PSH_EUNSUPPORTED:
             return None
-        _lib.check(rc, "psh_dense_lk_dev")
+        _lib.check(rc, "psh_dense_lk_uv_dev")
         if on_device:
+            field.uv_pairs = pairs
             return field
         if count.value == 0:
             return np.zeros((2, m, n))

@@ -586,3 +586,27 @@ def test_input_checks_run_on_the_device_with_the_reference_messages(extrapolate)
 
     with pytest.raises(ValueError, match="all be NumPy arrays or all be DeviceArrays"):
         extrapolate(DeviceArray.from_host(p), v, 1)
+
+
+@pytest.mark.gpu
+def test_interleaved_motion_field_twin_is_the_field_and_gives_the_same_advection():
+    """dense_lucaskanade on resident frames returns the motion field with its {u, v}-interleaved twin (written by
+    the interpolation kernel); the twin holds the same numbers, and extrapolate() gathering from it gives the
+    bytes it gives from the planes."""
+    from pysteps_amd.device import DeviceArray
+    from pysteps_amd.extrapolation.semilagrangian import extrapolate
+    from pysteps_amd.motion.lucaskanade import dense_lucaskanade
+    from tools import synth
+
+    for m, n in ((256, 320), (130, 203)):
+        frames = synth.steps_frames(m, n, 2).astype(np.float32)
+        V = dense_lucaskanade(DeviceArray.from_host(frames))
+        assert V.uv_pairs is not None and V.uv_pairs.shape == (m, n, 2)
+        planes, pairs = V.to_host(), V.uv_pairs.to_host()
+        np.testing.assert_array_equal(pairs[..., 0], planes[0])
+        np.testing.assert_array_equal(pairs[..., 1], planes[1])
+        R = DeviceArray.from_host(frames[-1])
+        with_twin = extrapolate(R, V, 4).to_host()
+        V.uv_pairs = None
+        without = extrapolate(R, V, 4).to_host()
+        np.testing.assert_array_equal(with_twin, without)
