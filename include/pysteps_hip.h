@@ -429,6 +429,9 @@ int psh_vectors_finish_host(const double *xy, const double *values, const unsign
  *  psh_fft_c2c2_dev    in (m,n) c128          -> out (m,n) c128, inverse != 0: ifft2 (in == out allowed) */
 int psh_fft_rfft2_dev(const double *in_dev, int m, int n, void *out_dev);
 int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_dev);
+/* ... with np.min of the result as the order-preserving key psh_steps_mask_dev reads (psh_field_min_key_dev's
+ * result without its sweep over the field): the row pass of the transform folds its outputs in */
+int psh_fft_irfft2_min_dev(const void *in_dev, int m, int n, double *out_dev, unsigned long long *min_key_dev);
 int psh_fft_c2c2_dev(const void *in_dev, int m, int n, int inverse, void *out_dev);
 
 /* ---- spectral building blocks of the STEPS member loop (csrc/cascade.hip) -------- *

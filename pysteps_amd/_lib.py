@@ -71,6 +71,7 @@ SIGNATURES = {
                                  c_double, c_void_p]),
     "psh_fft_rfft2_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "psh_fft_irfft2_dev": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "psh_fft_irfft2_min_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "psh_fft_c2c2_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_cascade_decompose_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                           POINTER(c_double), POINTER(c_double), POINTER(c_double)]),

@@ -137,7 +137,7 @@ struct IdwDyn {
 bool fft_shape_supported(int m, int n);
 void fft_release();  // frees the twiddle tables (psh_shutdown)
 int fft_irfft2_weighted(const void *spec_dev, const double *weights_dev, int m, int n, double *out_dev,
-                        void *scratch_dev);
+                        void *scratch_dev, unsigned long long *min_key_dev = nullptr);
 
 struct IdwArgs {
   const float *xy;  // (L,2) device: x, y of the sparse vectors

@@ -311,8 +311,16 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_r2c(const double *__rest
 }
 
 // ---- half spectra -> real rows (numpy irfft: the imaginary parts of bins 0 and n/2 are ignored) --
+// min_out (may be nullptr): np.min of the whole output as an order-preserving key (NaN -> 0, the smallest key), folded
+// in with one atomic per wave - the STEPS member update needs the field's minimum right after the transform
+// (steps_loop.hip field_min_key: a sweep of its own over 8 B per pixel otherwise)
+__device__ __forceinline__ unsigned long long fft_min_key(double v) {
+  if (v != v) return 0ull;
+  const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(v));
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
 __global__ __launch_bounds__(kFftThreads) void fft_rows_c2r(const double2 *__restrict__ in, int m, Dft d, double scale,
-                                                            double *__restrict__ out) {
+                                                            double *__restrict__ out, unsigned long long *__restrict__ min_out) {
   extern __shared__ double2 z[];
   const int n = d.n, len = 1 << d.logm;
   const int ra = 2 * blockIdx.x, rb = min(ra + 1, m - 1);
@@ -335,10 +343,25 @@ __global__ __launch_bounds__(kFftThreads) void fft_rows_c2r(const double2 *__res
   __syncthreads();
   dft_lds<true>(z, 0, 1, d);
   double *oa = out + static_cast<size_t>(ra) * n, *ob = out + static_cast<size_t>(rb) * n;
+  unsigned long long key = ~0ull;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const double2 v = dft_out<true>(d, z, 0, i);
-    oa[i] = v.x * scale;
-    if (ra + 1 < m) ob[i] = v.y * scale;
+    const double a = v.x * scale, b = v.y * scale;
+    oa[i] = a;
+    if (ra + 1 < m) ob[i] = b;
+    if (min_out) {
+      const unsigned long long ka = fft_min_key(a), kb = ra + 1 < m ? fft_min_key(b) : ~0ull;
+      key = ka < key ? ka : key;
+      key = kb < key ? kb : key;
+    }
+  }
+  if (min_out) {  // (uniform)
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      const unsigned long long o = __shfl_xor(key, s);
+      key = o < key ? o : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key < __hip_atomic_load(min_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(min_out, key);
   }
 }
 
@@ -709,7 +732,7 @@ void fft_release() {  // psh_shutdown: the tables belong to the device that is b
 // left untouched (the column pass writes into `scratch`, (m, n/2+1) complex128).  Lock held.
 namespace psh {
 int fft_irfft2_weighted(const void *spec_dev, const double *weights_dev, int m, int n, double *out_dev,
-                        void *scratch_dev) {
+                        void *scratch_dev, unsigned long long *min_key_dev) {
   Dft rows, cols;
   if (int rc = check_shape("irfft2", m, n, &rows, &cols)) return rc;
   Context &c = ctx();
@@ -722,7 +745,7 @@ int fft_irfft2_weighted(const void *spec_dev, const double *weights_dev, int m, 
   if (int rc = allow_lds(fft_rows_c2r, lds)) return rc;
   hipLaunchKernelGGL(fft_rows_c2r, dim3((m + 1) / 2), dim3(fft_threads(len)), lds, c.stream,
                      static_cast<const double2 *>(scratch_dev), m, rows,
-                     1.0 / (static_cast<double>(m) * static_cast<double>(n)), out_dev);
+                     1.0 / (static_cast<double>(m) * static_cast<double>(n)), out_dev, min_key_dev);
   PSH_HIP(hipGetLastError());
   return PSH_OK;
 }
@@ -748,6 +771,24 @@ extern "C" int psh_fft_irfft2_dev(const void *in_dev, int m, int n, double *out_
   void *scratch = nullptr;
   if (int rc = psh_malloc(&scratch, static_cast<size_t>(m) * (n / 2 + 1) * sizeof(double2))) return rc;
   const int rc = psh::fft_irfft2_weighted(in_dev, nullptr, m, n, out_dev, scratch);
+  (void)psh_free(scratch);  // stream-ordered
+  return rc;
+}
+
+// ... and np.min of the result as the order-preserving key psh_steps_mask_dev reads (what psh_field_min_key_dev
+// computes in a sweep of its own): *min_key_dev is set to the identity first, the row pass folds its outputs in
+extern "C" int psh_fft_irfft2_min_dev(const void *in_dev, int m, int n, double *out_dev, unsigned long long *min_key_dev) {
+  PSH_REQUIRE_INIT();
+  if (!in_dev || !out_dev || !min_key_dev) return fail(PSH_EINVAL, "irfft2_min: NULL pointer");
+  if (!psh::fft_shape_supported(m, n))
+    return fail(PSH_EUNSUPPORTED, "irfft2: (%d,%d) - sides: powers of two up to 8192 or any length up to 4096", m, n);
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  void *scratch = nullptr;
+  if (int rc = psh_malloc(&scratch, static_cast<size_t>(m) * (n / 2 + 1) * sizeof(double2))) return rc;
+  PSH_HIP(hipMemsetAsync(min_key_dev, 0xff, sizeof(unsigned long long), c.stream));
+  const int rc = psh::fft_irfft2_weighted(in_dev, nullptr, m, n, out_dev, scratch, min_key_dev);
   (void)psh_free(scratch);  // stream-ordered
   return rc;
 }

@@ -458,8 +458,8 @@ class ResidentSteps:
                                                       self.noise_filter.ptr, self.weights.ptr, self.inv_std_noise,
                                                       self._inv_std_levels_p, self._noise_std_p, self.mu[j].ctypes.data,
                                                       self.sigma[j].ctypes.data, self.field_spec.ptr), "psh_steps_phase_ar_dev")
-                _lib.check(lib.psh_fft_irfft2_dev(self.field_spec.ptr, m, n, field.ptr), "psh_fft_irfft2_dev")
-                _lib.check(lib.psh_field_min_key_dev(field.ptr, plane, self.min_key.ptr), "psh_field_min_key_dev")
+                # (the transform's last pass also takes the field's minimum: no sweep of its own)
+                _lib.check(lib.psh_fft_irfft2_min_dev(self.field_spec.ptr, m, n, field.ptr, self.min_key.ptr), "psh_fft_irfft2_min_dev")
             elif self.spectral:
                 # rfft2(white); level variances by Parseval; AR step + recomposition on the spectra; ONE inverse transform
                 nc = n // 2 + 1
@@ -471,8 +471,8 @@ class ResidentSteps:
                                                          self.noise_filter.ptr, self.weights.ptr, self.level_sums.ptr,
                                                          self._noise_std_p, self.mu[j].ctypes.data, self.sigma[j].ctypes.data,
                                                          self.field_spec.ptr), "psh_steps_spectral_ar_dev")
-                _lib.check(lib.psh_fft_irfft2_dev(self.field_spec.ptr, m, n, field.ptr), "psh_fft_irfft2_dev")
-                _lib.check(lib.psh_field_min_key_dev(field.ptr, plane, self.min_key.ptr), "psh_field_min_key_dev")
+                # (the transform's last pass also takes the field's minimum: no sweep of its own)
+                _lib.check(lib.psh_fft_irfft2_min_dev(self.field_spec.ptr, m, n, field.ptr, self.min_key.ptr), "psh_fft_irfft2_min_dev")
             else:
                 # fftgenerators.py:400-433 (the filter part), decomposition.py:77-262 with normalize=True
                 _lib.check(lib.psh_noise_filter_dev(white.view(j).ptr, self.noise_filter.ptr, m, n, self.noise.ptr), "psh_noise_filter_dev")
