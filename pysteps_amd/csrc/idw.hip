@@ -596,17 +596,21 @@ __device__ __forceinline__ void idw_accumulate2(const float4 c, const float2v px
   const float dy = c.y - py;
   const float dy2 = dy * dy;
   const float2v d2 = __builtin_elementwise_fma(dx, dx, float2v{dy2, dy2});  // = dist2() per component
-  const float2v d = float2v{fast_sqrt(d2.x), fast_sqrt(d2.y)} * inv_res;
+  const float2v root = float2v{fast_sqrt(d2.x), fast_sqrt(d2.y)};
   float2v w;
   if constexpr (HALF) {
-    const float2v t = d + offset;
+    // (d / res + offset and the two weighted sums as fused multiply-adds: three packed instructions less per
+    // vector than the multiply-then-add forms - every wave64 instruction costs the SIMD four cycles here - and
+    // one rounding less each; nothing in the kernel compares these values for equality)
+    const float2v t = __builtin_elementwise_fma(root, float2v{inv_res, inv_res}, float2v{offset, offset});
     w = float2v{__builtin_amdgcn_rsqf(t.x), __builtin_amdgcn_rsqf(t.y)};
   } else {
+    const float2v d = root * inv_res;
     w = float2v{idw_weight(d.x, power, offset), idw_weight(d.y, power, offset)};
   }
   sw += w;
-  su += w * c.z;
-  sv += w * c.w;
+  su = __builtin_elementwise_fma(w, float2v{c.z, c.z}, su);
+  sv = __builtin_elementwise_fma(w, float2v{c.w, c.w}, sv);
 }
 
 // the `need` nearest of a ring of <= 8 vectors for one pixel: every member ranks itself among the

@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 python tools/lk_bitcheck.py $TAG > $OUT/bitcheck.log 2>&1
 tail -2 $OUT/bitcheck.log
-cp profiles/r04/f_lk_bitcheck_base_idw3.json gpurun_out/lk_bitcheck_base.json; if [ -f gpurun_out/lk_bitcheck_base.json ]; then python tools/lk_bitcheck.py --diff base $TAG | tee $OUT/bitcheck_diff.txt | head -40; fi
+cp profiles/r04/j_lk_bitcheck_base_idw_fma.json gpurun_out/lk_bitcheck_base.json; if [ -f gpurun_out/lk_bitcheck_base.json ]; then python tools/lk_bitcheck.py --diff base $TAG | tee $OUT/bitcheck_diff.txt | head -40; fi
 BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-members-leg --no-spectral --no-steps-loop"
 for v in $VALS; do
   if [ "$v" = "-" ]; then unset $VAR; else export $VAR=$v; fi
