@@ -49,10 +49,13 @@ constexpr int kRowsPerPass = kThreads / kTile;
 constexpr int kBins = 1024;  // centre-distance histogram: bin width = reach / 1024
 constexpr int kCandCap = 512;  // candidates kept in LDS per tile (8 KiB, twice: raw + classified)
 
+// (one copy of powf in the binary: inlined at every weight it made the fine pass 105 KB of code, most of it for a
+// power nobody uses - the instruction cache is shared between the waves of two compute units)
+__device__ __noinline__ float idw_pow_weight(float t, float power) { return powf(t, -power); }
 __device__ __forceinline__ float idw_weight(float d, float power, float offset) {
   const float t = d + offset;
   // power 0.5 is the reference default: 1/sqrt(t) as one v_rsq_f32 (1 ulp)
-  return power == 0.5f ? __builtin_amdgcn_rsqf(t) : powf(t, -power);
+  return power == 0.5f ? __builtin_amdgcn_rsqf(t) : idw_pow_weight(t, power);
 }
 
 // distance from its square: one v_sqrt_f32 (1 ulp) instead of the IEEE sequence
@@ -613,35 +616,50 @@ __device__ __forceinline__ void idw_accumulate2(const float4 c, const float2v px
   sv = __builtin_elementwise_fma(w, float2v{c.w, c.w}, sv);
 }
 
-// the `need` nearest of a ring of <= 8 vectors for one pixel: every member ranks itself among the
-// others (ties: lower index first, as the second sweep of add_nearest takes them)
-__device__ __forceinline__ void idw_small_ring(const float4 *ring, int n_ring, int need, float px, float py,
-                                               float inv_res, float power, float offset, float &sw, float &su,
-                                               float &sv) {
-  float d2[8];
+// the `need` nearest of a ring of <= 8 vectors: every member ranks itself among the others (ties: lower index
+// first, as the second sweep of add_nearest takes them) - for the lane's TWO pixels: distances and weights in packed instructions, the ranks per component (a
+// compare has no packed form); a vector that is not among a pixel's `need` nearest enters its sums with weight zero
+template <bool HALF>
+__device__ __forceinline__ void idw_small_ring2(const float4 *ring, int n_ring, int need, const float2v px, float py,
+                                                float inv_res, float power, float offset, float2v &sw, float2v &su,
+                                                float2v &sv) {
+  float2v d2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    d2[j] = INFINITY;
-    if (j < n_ring) {
+    d2[j] = float2v{INFINITY, INFINITY};
+    if (j < n_ring) {  // (uniform)
       const float4 c = ring[j];
-      d2[j] = dist2(c.x, c.y, px, py);
+      const float2v dx = float2v{c.x, c.x} - px;
+      const float dy = c.y - py;
+      const float dy2 = dy * dy;
+      d2[j] = __builtin_elementwise_fma(dx, dx, float2v{dy2, dy2});  // = dist2() per component
     }
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     if (j >= n_ring) break;  // (uniform)
-    int rank = 0;
+    int rank_a = 0, rank_b = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      if (i != j) rank += (d2[i] < d2[j] || (i < j && d2[i] == d2[j])) ? 1 : 0;  // (missing members: +inf)
+      if (i == j) continue;
+      // (missing members: +inf; ties go to the lower index)
+      rank_a += (i < j ? d2[i].x <= d2[j].x : d2[i].x < d2[j].x) ? 1 : 0;
+      rank_b += (i < j ? d2[i].y <= d2[j].y : d2[i].y < d2[j].y) ? 1 : 0;
     }
-    if (rank < need) {
-      const float4 c = ring[j];
-      const float w = idw_weight(fast_sqrt(d2[j]) * inv_res, power, offset);
-      sw += w;
-      su += w * c.z;
-      sv += w * c.w;
+    const float4 c = ring[j];
+    const float2v root = float2v{fast_sqrt(d2[j].x), fast_sqrt(d2[j].y)};
+    float2v w;
+    if constexpr (HALF) {
+      const float2v t = __builtin_elementwise_fma(root, float2v{inv_res, inv_res}, float2v{offset, offset});
+      w = float2v{__builtin_amdgcn_rsqf(t.x), __builtin_amdgcn_rsqf(t.y)};
+    } else {
+      const float2v d = root * inv_res;
+      w = float2v{idw_weight(d.x, power, offset), idw_weight(d.y, power, offset)};
     }
+    w = float2v{rank_a < need ? w.x : 0.f, rank_b < need ? w.y : 0.f};
+    sw += w;
+    su = __builtin_elementwise_fma(w, float2v{c.z, c.z}, su);
+    sv = __builtin_elementwise_fma(w, float2v{c.w, c.w}, sv);
   }
 }
 
@@ -803,11 +821,17 @@ __global__ __launch_bounds__(64) void idw_fine3(const float2 *__restrict__ xy, c
       sum_certain(std::false_type{});
     }
     const int need = k - n_sure;  // >= 1: fewer than k vectors lie strictly inside R_lo
-    // the ring, pixel by pixel (scalar copies of the sums: vector elements cannot be passed by reference)
+    // the ring: a small one (the rule) for both pixels at once, else pixel by pixel (scalar copies of the sums:
+    // vector elements cannot be passed by reference)
+    if (n_ring <= 8) {
+      if (power == 0.5f) {
+        idw_small_ring2<true>(s_cand + n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
+      } else {
+        idw_small_ring2<false>(s_cand + n_sure, n_ring, need, px, py, inv_res, power, offset, sw, su, sv);
+      }
+    }
     float wa = sw.x, ua = su.x, va = sv.x, wb = sw.y, ub = su.y, vb = sv.y;
     if (n_ring <= 8) {
-      idw_small_ring(s_cand + n_sure, n_ring, need, px.x, py, inv_res, power, offset, wa, ua, va);
-      idw_small_ring(s_cand + n_sure, n_ring, need, px.y, py, inv_res, power, offset, wb, ub, vb);
     } else if (need <= 8) {
       add_nearest<8>(s_cand, n_sure, n_ring, need, px.x, py, inv_res, power, offset, wa, ua, va);
       add_nearest<8>(s_cand, n_sure, n_ring, need, px.y, py, inv_res, power, offset, wb, ub, vb);
@@ -818,8 +842,11 @@ __global__ __launch_bounds__(64) void idw_fine3(const float2 *__restrict__ xy, c
     sw = float2v{wa, wb};
     su = float2v{ua, ub};
     sv = float2v{va, vb};
-    o_u = float2v{su.x / sw.x, su.y / sw.y};
-    o_v = float2v{sv.x / sw.x, sv.y / sw.y};
+    // (one reciprocal per pixel - v_rcp_f32, 1 ulp - and two products instead of two IEEE divisions: ~40 of the
+    // ~700 instructions a tile costs; the sums themselves carry more rounding than that)
+    const float2v inv = float2v{__builtin_amdgcn_rcpf(sw.x), __builtin_amdgcn_rcpf(sw.y)};
+    o_u = su * inv;
+    o_v = sv * inv;
   }
   out[at_a] = o_u.x;
   out[plane + at_a] = o_v.x;
