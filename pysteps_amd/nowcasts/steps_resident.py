@@ -91,6 +91,15 @@ def _percentile_index(count, pct):
     return None if i >= count - 1 else i
 
 
+def _spectral_std_of_moduli(x, m, n):
+    """``pysteps.utils.spectral.std(X, (m, n))`` (utils/spectral.py:231-238) for a half spectrum whose MODULI are the
+    real array ``x``: the phase noise of the spectral domain has unit modulus, so the standard deviations of the
+    filtered noise and of its cascade levels are functions of the filters alone."""
+    res = np.sum(x ** 2) - x[0, 0] ** 2
+    res += np.sum(x[:, 1:] ** 2) if n % 2 == 1 else np.sum(x[:, 1:-1] ** 2)
+    return np.sqrt(res / (m * n) ** 2)
+
+
 def _self_conjugate_columns_symmetric(planes, n):
     """The spectral form of the update reads level variances off the spectrum (Parseval), which needs every product
     ``spectrum x weights`` to stay Hermitian: a real filter has to take the same value at (ky, kx) and (-ky, kx) on the
@@ -288,10 +297,8 @@ class ResidentSteps:
             self.cascades = spectra
             self.field_spec = DeviceArray((m, nc), np.complex128)
 
-            def spectral_std(x):  # utils/spectral.py:231-238 for a REAL array of moduli
-                res = np.sum(x ** 2) - x[0, 0] ** 2
-                res += np.sum(x[:, 1:] ** 2) if n % 2 == 1 else np.sum(x[:, 1:-1] ** 2)
-                return np.sqrt(res / (m * n) ** 2)
+            def spectral_std(x):
+                return _spectral_std_of_moduli(x, m, n)
 
             f0 = np.array(F["field"], dtype=np.float64)
             f0[0, 0] = 0.0

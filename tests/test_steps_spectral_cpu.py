@@ -76,3 +76,31 @@ def test_filters_that_break_the_hermitian_symmetry_are_recognised():
     _, fa = oss.update_spatial(white, f, w, levels, phi, ns, mu, sg)
     _, fb = oss.update_spectral(white, f, w, np.fft.rfft2(levels), phi, ns, mu, sg)
     assert np.max(np.abs(fa - fb)) > 1e-6 * np.ptp(fa)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (37, 53), (48, 31)])
+def test_spectral_std_of_unit_phasor_noise_is_a_constant_of_the_filters(ref_pysteps, shape):
+    """The reference's domain="spectral" noise is exp(i theta) x filter (fftgenerators.py:407-437): its spectral
+    standard deviation (utils/spectral.py:208-238), and that of every cascade level, does not depend on the phases.
+    `_spectral_std_of_moduli` - what the resident update computes once per nowcast - equals the reference's function
+    on the complex field for any phases."""
+    from pysteps.utils import spectral
+
+    from pysteps_amd.nowcasts.steps_resident import _spectral_std_of_moduli
+
+    m, n = shape
+    rng = np.random.default_rng(5)
+    filt = rng.uniform(0.0, 3.0, (m, n // 2 + 1))
+    weights = rng.uniform(0.0, 1.0, (m, n // 2 + 1))
+    filt[0, 0] = 0.0
+    want_level = None
+    for _ in range(3):
+        theta = rng.uniform(0.0, 2.0 * np.pi, filt.shape)
+        noise = (np.cos(theta) + 1j * np.sin(theta)) * filt
+        got = _spectral_std_of_moduli(filt, m, n)
+        assert abs(got - spectral.std(noise, (m, n))) <= 1e-14 * got
+        level = spectral.std(noise / spectral.std(noise, (m, n)) * weights, (m, n))
+        mine = _spectral_std_of_moduli(filt * (1.0 / got) * weights, m, n)
+        assert abs(mine - level) <= 1e-14 * level
+        want_level = level if want_level is None else want_level
+        assert abs(level - want_level) <= 1e-14 * level
