@@ -104,3 +104,51 @@ def test_spectral_std_of_unit_phasor_noise_is_a_constant_of_the_filters(ref_pyst
         assert abs(mine - level) <= 1e-14 * level
         want_level = level if want_level is None else want_level
         assert abs(level - want_level) <= 1e-14 * level
+
+
+def test_restatement_of_the_reference_spectral_domain_update_is_the_reference(ref_pysteps):
+    """oracle.steps_spectral.update_reference_spectral_domain against the REAL StepsNowcaster.__update_state of
+    nowcasts.steps(domain="spectral"): no mask, no probability matching, so that the fields the function returns are
+    the recomposed fields - identical to the last bit (same NumPy operations in the same order), and the generator
+    ends where the reference's ends."""
+    import copy
+
+    from pysteps import nowcasts
+    from pysteps.nowcasts import steps as steps_mod
+    from tools import synth
+
+    m, n = 48, 40
+    frames = synth.steps_frames(m, n, 3)
+    V = synth.true_velocity(m, n).astype(np.float64)
+    seen = []
+
+    def side_by_side(precip, velocity, state, timesteps, extrap_method, func, params=None, num_ensemble_members=1, **_):
+        L = params["n_cascade_levels"]
+        gens = [copy.deepcopy(g) for g in state["randgen_prec"]]
+        levels = [[np.array(c, dtype=complex) for c in state["precip_cascades"][j]] for j in range(num_ensemble_members)]
+        weights = np.asarray(params["filter"]["weights_2d"])
+        phi = np.asarray(params["phi"])
+        for _t in range(3):
+            want, state = func(state, params)
+            for j in range(num_ensemble_members):
+                d = state["precip_decomp"][j]
+                got = oss.update_reference_spectral_domain(gens[j], precip.shape, params["pert_gen"]["field"], weights, levels[j], phi,
+                                                           np.asarray(params["noise_std_coeffs"]), d["means"], d["stds"])
+                got[params["domain_mask"]] = np.nan
+                seen.append(float(np.nanmax(np.abs(got - want[j]))))
+                assert np.array_equal(np.isnan(got), np.isnan(want[j]))
+                for k in range(L):
+                    assert np.array_equal(levels[j][k], state["precip_cascades"][j][k])
+        for g, h in zip(gens, state["randgen_prec"]):
+            assert g.randint(0, 1 << 30) == h.randint(0, 1 << 30)
+        return np.zeros((num_ensemble_members, timesteps) + precip.shape)
+
+    orig = steps_mod.nowcast_main_loop
+    try:
+        steps_mod.nowcast_main_loop = side_by_side
+        nowcasts.get_method("steps")(frames, V, 2, n_ens_members=2, n_cascade_levels=5, precip_thr=-10.0, kmperpixel=1.0, timestep=5.0,
+                                     seed=11, domain="spectral", mask_method=None, probmatching_method=None, vel_pert_method=None,
+                                     num_workers=1)
+    finally:
+        steps_mod.nowcast_main_loop = orig
+    assert len(seen) == 6 and max(seen) == 0.0, seen
