@@ -49,7 +49,7 @@ def parse_args():
                     help="run the N > 1 code path (RCCL communicator, broadcast, member shard) at any world size")
     ap.add_argument("--no-members-leg", action="store_true", help="skip the config-4 single-GPU reference leg")
     ap.add_argument("--members-per-gpu", type=int, default=6, help="STEPS members per GPU (config 4: 48 on 8 GPUs)")
-    ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    ap.add_argument("--cpu-sample-steps", type=int, default=6)
     ap.add_argument("--workload", choices=("default", "config5"), default="default",
                     help="config5: 8192^2 x 36 lead times, row bands over the ranks (banded LK + tiled semilag, RCCL collectives)")
     ap.add_argument("--no-steps-loop", action="store_true", help="skip the STEPS member-loop leg of the N = 1 line")
