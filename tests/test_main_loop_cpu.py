@@ -195,3 +195,29 @@ def test_percentile_index_is_numpys_argmin():
         want = None if i >= count - 1 else i  # the reference reads precip_s[i + 1]
         assert steps_resident._percentile_index(count, pct) == want, (count, pct)
     assert steps_resident._percentile_index(16, 1.5) is None and steps_resident._percentile_index(1, 0.5) is None
+
+
+def test_bps_generators_float32_motion_and_local_differences(ref_pysteps):
+    """A float32 motion field is normalised in float32 by initialize_bps (noise/motion.py:129-133): the closed form
+    is checked in that dtype and the generators are recognised (round 3 compared a float64 closed form at 1e-9 and
+    always fell back).  A perturbator built from a motion field that differs from this one in a small patch only is
+    declined: the sample's offset is drawn anew per call, so a handful of calls see every pixel of a small grid."""
+    from pysteps import noise
+    from pysteps_amd.nowcasts.utils import bps_perturbators
+    from tools import synth
+
+    init, gen = noise.get_method("bps")
+    timestep = 5.0
+    V32 = synth.true_velocity(40, 56).astype(np.float32)
+    gens = [lambda t, vp=init(V32, 1.0, timestep, randstate=np.random.RandomState(j)): gen(vp, t * timestep) for j in range(2)]
+    assert bps_perturbators(gens, V32) is not None
+
+    m, n = 1200, 1100  # step 2 in both directions: a single call samples a quarter of the pixels
+    V = synth.true_velocity(m, n).astype(np.float64)
+    other = V.copy()
+    other[:, 601:603, 501:503] = other[:, 601:603, 501:503][::-1] * 1.5  # a 2 x 2 patch with another direction
+    vp = init(other, 1.0, timestep, randstate=np.random.RandomState(3))
+    closure = [lambda t, vp=vp: gen(vp, t * timestep)]
+    verdicts = [bps_perturbators(closure, V) is None for _ in range(24)]
+    assert any(verdicts)  # (each call hits the patch with probability 1 - (3/4)... >= 1/4: all 24 missing it: < 1e-3)
+    assert bps_perturbators([lambda t, vp=init(V, 1.0, timestep, randstate=np.random.RandomState(3)): gen(vp, t * timestep)], V) is not None
