@@ -334,3 +334,39 @@ def test_tracker_restatement_tracks_like_an_independent_float_lucas_kanade(shift
     assert status.all()
     assert np.max(np.abs(got - twin)) < 1e-3, (got - twin)  # observed: 0.9e-4 ... 1.2e-4 px
     assert np.max(np.abs((got - pts) - np.array(shift))) < 0.03  # observed: <= 0.012 px
+
+
+@pytest.mark.parametrize("min_distance,max_corners,seed", [(10, 1000, 0), (4, 60, 1), (7, 0, 2)])
+def test_corner_selection_equals_a_brute_force_reading(min_distance, max_corners, seed):
+    """goodFeaturesToTrack's selection stage read a second time, without the cell grid: threshold at quality x max,
+    3 x 3 non-maximum suppression by scipy.ndimage.maximum_filter, one-pixel border excluded, candidates in descending
+    (value, address) order, each accepted unless an ALREADY ACCEPTED corner lies closer than min_distance (all pairs
+    compared).  For integral distances the grid of the original finds exactly these corners, in this order."""
+    from scipy import ndimage
+
+    rng = np.random.default_rng(seed)
+    img = gaussian_filter(rng.normal(size=(90, 120)), 2.0)
+    u8 = ((img - img.min()) / (img.max() - img.min()) * 255).astype(np.uint8)
+    allowed = np.ones(u8.shape, dtype=bool)
+    allowed[:, 100:] = False
+    got = lk.good_features_to_track(u8, allowed, max_corners=max_corners, quality=0.01, min_distance=min_distance, block_size=5)
+
+    eig = lk.corner_min_eigenval(u8, 5)
+    thr = np.float32(eig[allowed].max() * 0.01)
+    kept = np.where(eig > thr, eig, np.float32(0))
+    peak = ndimage.maximum_filter(kept, size=3, mode="constant", cval=-np.inf)
+    cand = (kept != 0) & (kept == peak) & allowed
+    cand[[0, -1], :] = False
+    cand[:, [0, -1]] = False
+    ys, xs = np.nonzero(cand)
+    order = sorted(range(len(ys)), key=lambda i: (-float(kept[ys[i], xs[i]]), -(int(ys[i]) * u8.shape[1] + int(xs[i]))))
+    accepted = []
+    for i in order:
+        x, y = int(xs[i]), int(ys[i])
+        if all((x - ax) ** 2 + (y - ay) ** 2 >= min_distance ** 2 for ax, ay in accepted):
+            accepted.append((x, y))
+            if 0 < max_corners == len(accepted):
+                break
+    want = np.array(accepted, dtype=np.float32).reshape(-1, 2)
+    assert len(want) > 5
+    np.testing.assert_array_equal(got, want)
