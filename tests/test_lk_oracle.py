@@ -370,3 +370,24 @@ def test_corner_selection_equals_a_brute_force_reading(min_distance, max_corners
     want = np.array(accepted, dtype=np.float32).reshape(-1, 2)
     assert len(want) > 5
     np.testing.assert_array_equal(got, want)
+
+
+def test_reference_orchestration_around_a_standin_cv2_gives_the_oracle_pipeline(ref_pysteps):
+    """The REAL pysteps.motion.lucaskanade.dense_lucaskanade, run in a process of its own around a stand-in ``cv2``
+    whose five functions are the restated OpenCV algorithms: the sparse vectors are the oracle pipeline's bit for bit
+    and the dense fields identical - rows a4 / a5 (NaN masking, minimum fill, opening field, uint8 renderings, buffer
+    mask with its row quirk, the cv2 call conventions, pooling, outlier test, declustering, interpolation) held
+    against the reference's own code; every one of the five call sites is exercised (tests/helpers/)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "ref_lk_with_standin_cv2.py")
+    run = subprocess.run([sys.executable, helper], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    report = json.loads(run.stdout.strip().splitlines()[-1])
+    assert all(count > 0 for count in report["calls"].values()), report["calls"]
+    for case in ("plain", "nan_three_frames"):
+        r = report[case]
+        assert r["vectors"] > 50 and r["sparse_equal"] and r["dense_max_abs_diff"] == 0.0, r
