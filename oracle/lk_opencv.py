@@ -22,6 +22,16 @@ uniform-shift recovery < 0.1 % rel. RMSE like pysteps/tests/test_motion.py:154-2
 zeros -> zero motion, NaN vs masked equivalence) and re-validation against real
 cv2 is required whenever a box with OpenCV is available.
 
+What IS pinned (tests/test_lk_oracle.py, all on the CPU):
+* the NumPy glue and the orchestration - the REAL reference ``dense_lucaskanade`` run around a stand-in ``cv2``
+  whose five functions are the ones below gives this module's pipeline bit for bit (sparse vectors equal, dense
+  fields identical; tests/helpers/ref_lk_with_standin_cv2.py);
+* every restated algorithm against a second, independent reading built from SciPy: opening and mask dilation
+  (binary_erosion / binary_dilation), pyrDown and Scharr (correlate1d, mirror), cornerMinEigenVal (sobel +
+  uniform_filter), the selection stage of goodFeaturesToTrack (maximum_filter + all-pairs distances, identical
+  lists), the pyramidal tracker (float64 Lucas-Kanade with map_coordinates: 1e-4 px).
+Two authors and the reference's own glue - not OpenCV itself: the header stays "unpinned at the OpenCV boundary".
+
 Deliberate choices where OpenCV's own result is build dependent (SIMD summation
 order): window sums (A11, A12, A22, b1, b2) are accumulated exactly in integers
 and converted once; the 5x5 box sums of the corner response are accumulated in
