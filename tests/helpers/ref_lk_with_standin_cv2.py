@@ -89,4 +89,12 @@ for name, (m, n, nframes, nan) in {"plain": (96, 128, 2, False), "nan_three_fram
         "dense_scale": float(np.max(np.abs(want))),
     }
 report["calls"] = calls
+if len(sys.argv) > 1:
+    # (for the GPU test: frames and what the reference made of them with its default options, to hold the device
+    # path against the reference's own orchestration directly)
+    frames = synth.steps_frames(192, 224, 3).astype(np.float64)
+    frames[:, 100:120, :30] = np.nan
+    xy, uv = ref_dense(frames.copy(), dense=False, verbose=False)
+    field = ref_dense(frames.copy(), verbose=False)
+    np.savez(sys.argv[1], frames=frames, xy=xy, uv=uv, field=np.asarray(field))
 print(json.dumps(report))

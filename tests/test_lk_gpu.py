@@ -575,3 +575,29 @@ def test_corner_options_match_oracle(lkmod, max_corners, min_distance):
     got = lkmod.detect_corners(_prep(lkmod, img), max_corners=max_corners, min_distance=min_distance)
     assert len(want) > 100
     assert np.array_equal(got, want)
+
+
+def test_device_path_against_the_reference_orchestration_around_a_standin_cv2(dense_lk, ref_pysteps, tmp_path):
+    """The device ``dense_lucaskanade`` against the REAL reference function (default options, three frames with a NaN
+    block), the reference run in a process of its own around a stand-in ``cv2`` made of the restated OpenCV algorithms
+    (tests/helpers/ref_lk_with_standin_cv2.py): vectors within 1e-2 px, dense field within 1e-3 relative L2 - the
+    bars of the oracle comparison, here with the reference's own glue on the other side."""
+    import os
+    import subprocess
+    import sys
+
+    helper = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "ref_lk_with_standin_cv2.py")
+    out = str(tmp_path / "ref_lk.npz")
+    run = subprocess.run([sys.executable, helper, out], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-2000:]
+    ref = np.load(out)
+    frames, wxy, wuv, want = ref["frames"], ref["xy"], ref["uv"], ref["field"]
+    gxy, guv = dense_lk(frames, dense=False)
+    assert abs(len(gxy) - len(wxy)) <= max(3, 0.03 * len(wxy))
+    wmap = {}
+    for p, v in zip(wxy.astype(int), wuv):
+        wmap.setdefault(tuple(p), []).append(v)
+    d = [min(np.abs(v - w).max() for w in wmap[tuple(p)]) for p, v in zip(gxy.astype(int), guv) if tuple(p) in wmap]
+    assert len(d) >= 0.95 * len(wxy) and max(d) < 1e-2
+    got = dense_lk(frames)
+    assert got.shape == want.shape and rel_l2(got, want) < 1e-3
