@@ -173,11 +173,10 @@ extern "C" int psh_dense_lk_uv_dev(const float *frames_dev, int nframes, int m, 
     void *pyr = fork.pyr;
     if (trace)
       std::fprintf(stderr,
-                   "dense_lk corner walk: %d chunk(s), %d candidates, %d round(s); us: load %d sort %d "
-                   "coordinates %d block tests %d survivors %d (cells %d first round %d later rounds %d append %d) total %d\n",
+                   "dense_lk corner walk: %d chunk(s), %d candidates, %d evaluation(s) of the first wave; us: load %d sort %d "
+                   "coordinates %d block tests %d survivors %d (cells %d - evaluations %d append %d) total %d\n",
                    walk_stats[0], walk_stats[1], walk_stats[2], walk_stats[3], walk_stats[4], walk_stats[5],
-                   walk_stats[6], walk_stats[7], walk_stats[9], walk_stats[10], walk_stats[11], walk_stats[12],
-                   walk_stats[8]);
+                   walk_stats[6], walk_stats[7], walk_stats[9], walk_stats[11], walk_stats[12], walk_stats[8]);
     if (rc1 || rcj || fork.rc || !pyr) {
       if (pyr) (void)psh_lk_pyramids_free(pyr);
       return fork.rc ? fork.rc : rc1 ? rc1 : rcj ? rcj : psh::fail(PSH_EHIP, "dense_lk: pyramids were not built");

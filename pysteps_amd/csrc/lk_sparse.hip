@@ -320,7 +320,6 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
   __shared__ short s_bnext[kOrdThreads];
   __shared__ uint2 s_bxy[kOrdThreads];  // x | y << 16, x cell | y cell << 16
   __shared__ unsigned char s_state[kOrdThreads];
-  __shared__ int s_more[3];
   // second key buffer of the counting sort; afterwards the same memory holds, for the ordered chunk,
   // x | y << 16 (s_xy) and x cell | y cell << 16 (s_cl): the divisions are done once per chunk
   __shared__ CornerKey s_tmp[kChunkCap];
@@ -607,16 +606,42 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
       }
       enum : unsigned char { kUndecided = 0, kAccepted = 1, kRejected = 2 };
       s_state[tid] = mine ? (use_grid ? kUndecided : kAccepted) : kRejected;
-      if (tid < 3) s_more[tid] = 0;
       __syncthreads();
       sub_lap(0);
       if (use_grid) {
+        // No barrier between the rounds: a wave keeps re-evaluating its undecided candidates until none is left
+        // (the states live in LDS, which has no cache - a volatile read sees what any wave of the workgroup has
+        // written).  A candidate only waits for EARLIER candidates, the earliest undecided one never waits, and
+        // the lanes of a wave advance together: every wave terminates, the fixed point is the one the rounds with
+        // workgroup barriers reached (seven of them at ~2 us each on the bench frames).
+        volatile unsigned char *state = s_state;
         bool undecided = mine;
-        int round = 0;
-        for (;;) {
-          ++st_batches;  // (rounds of the fixed point)
-          if (undecided) {
+        // the earlier neighbours that were still undecided at the full evaluation: all a later evaluation has to look at
+        // (an accepted one was a rejection on the spot, a rejected one never matters again); more than two: evaluate in full
+        int waits_for[2] = {-1, -1};
+        bool memo = false;
+        while (__ballot(undecided) != 0ull) {
+          ++st_batches;  // (evaluations of this wave)
+          if (undecided && memo) {
             bool rejected = false, blocked = false;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              if (waits_for[k] >= 0) {
+                const unsigned char st = state[waits_for[k]];
+                rejected = rejected || st == kAccepted;
+                blocked = blocked || st == kUndecided;
+              }
+            }
+            if (rejected) {
+              state[tid] = kRejected;
+              undecided = false;
+            } else if (!blocked) {
+              state[tid] = kAccepted;
+              undecided = false;
+            }
+          } else if (undecided) {
+            bool rejected = false, blocked = false;
+            int n_wait = 0;
             unsigned want[9];
             int head[9];
 #pragma unroll
@@ -633,35 +658,36 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
                 if (q < 0) continue;
                 any = true;
                 const uint2 a = s_bxy[q];
-                const unsigned char st = s_state[q];
+                const unsigned char st = state[q];
                 head[nb] = s_bnext[q];
                 const unsigned dx = static_cast<unsigned>(abs(x - static_cast<int>(a.x & 0xffffu)));
                 const unsigned dy = static_cast<unsigned>(abs(y - static_cast<int>(a.x >> 16)));
                 // (q >= tid: later in the walk, or the candidate itself)
                 if (q < tid && a.y == want[nb] && dx * dx + dy * dy < md2_ceil) {  // neighbouring cells: < 2^31
                   rejected = rejected || st == kAccepted;
-                  blocked = blocked || st == kUndecided;
+                  if (st == kUndecided) {
+                    blocked = true;
+                    if (n_wait < 2) waits_for[n_wait] = q;
+                    ++n_wait;
+                  }
                 }
               }
               if (!any || rejected) break;
             }
             if (rejected) {
-              s_state[tid] = kRejected;
+              state[tid] = kRejected;
               undecided = false;
             } else if (!blocked) {
-              s_state[tid] = kAccepted;
+              state[tid] = kAccepted;
               undecided = false;
+            } else {
+              memo = n_wait <= 2;
+              if (!memo) waits_for[0] = waits_for[1] = -1;
             }
           }
-          // "anyone still undecided?" through three rotating LDS flags (this round's is set before the
-          // barrier and read behind it; the next round's was last read two barriers ago and is cleared now)
-          if (tid == 0) s_more[(round + 1) % 3] = 0;
-          if (__ballot(undecided) != 0ull && lane == 0) s_more[round % 3] = 1;
-          __syncthreads();
-          const int more = s_more[round % 3];
-          ++round;
-          if (!more) break;
         }
+        __syncthreads();
+        sub_lap(2);  // (all evaluations)
       }
       // ---- the accepted survivors, in walking order, behind the corners so far (those beyond
       // max_corners are dropped: acceptance only depends on earlier candidates) -------------------
@@ -683,7 +709,7 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
         }
         nacc = min(nacc + total, max_corners);
         __syncthreads();
-        sub_lap(3);  // (rounds + appending; a timer per round would cost more than the round)
+        sub_lap(3);  // (appending)
       }
       lap(tk_batch);
     }
