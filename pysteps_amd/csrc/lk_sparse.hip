@@ -685,6 +685,9 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
               if (!memo) waits_for[0] = waits_for[1] = -1;
             }
           }
+          // (a wave that still waits gives the SIMD to the waves it waits for: the issue arbiter must never have to
+          // choose a spinning wave over the one whose decision would release it)
+          if (__ballot(undecided) != 0ull) __builtin_amdgcn_s_sleep(2);
         }
         __syncthreads();
         sub_lap(2);  // (all evaluations)
