@@ -93,11 +93,14 @@ static int ensure_pinned(size_t nbytes) {
 // A fresh 4 KiB pinned slot + its device twin per call, so that back-to-back asynchronous calls
 // never overwrite constants a queued kernel still has to read; the ring synchronises with the
 // stream only when it wraps (every 64 calls).
+constexpr size_t kConstSlots = 64;
+
 int const_slot(float **host, const float **dev) {
   Context &c = ctx();
   static size_t slot = 0;
-  const size_t n_slots = 64;
-  if (int rc = ensure_scratch(n_slots * kConstSlotFloats * sizeof(float))) return rc;
+  const size_t n_slots = kConstSlots;
+  // one more device slot than the ring hands out: the extrapolator's private one (semilag_factor_slot)
+  if (int rc = ensure_scratch((n_slots + 1) * kConstSlotFloats * sizeof(float))) return rc;
   if (int rc = ensure_pinned(n_slots * kConstSlotFloats * sizeof(float))) return rc;
   if (slot == n_slots) {  // ring wrapped: make sure the oldest slots are consumed
     PSH_HIP(hipStreamSynchronize(c.stream));
@@ -106,6 +109,15 @@ int const_slot(float **host, const float **dev) {
   *host = static_cast<float *>(c.pinned) + slot * kConstSlotFloats;
   *dev = static_cast<float *>(c.scratch) + slot * kConstSlotFloats;
   ++slot;
+  return PSH_OK;
+}
+
+// The device slot behind the ring: only the extrapolator writes it (its per-step scale factors, kept from
+// call to call while they do not change).  No ring user can overwrite it however many slots are taken in
+// between; it moves only when the scratch block is reallocated (g_scratch_generation).
+static int semilag_factor_slot(const float **dev) {
+  if (int rc = ensure_scratch((kConstSlots + 1) * kConstSlotFloats * sizeof(float))) return rc;
+  *dev = static_cast<float *>(ctx().scratch) + kConstSlots * kConstSlotFloats;
   return PSH_OK;
 }
 
@@ -506,8 +518,10 @@ static int semilag_rows(const float *precip_dev, const float *velocity_dev, cons
   if (static_cast<size_t>(T) > psh::kConstSlotFloats)
     return fail(PSH_EUNSUPPORTED, "semilag: at most %zu lead steps per call", psh::kConstSlotFloats);
   // ... unless they are the factors of the previous call (a nowcast advects by the same increments call after
-  // call): the slot that holds them is the most recent one of the ring, nothing has overwritten it, and the copy
-  // with its dispatch gap (~10 us in front of the kernel) is skipped
+  // call): they live in a device slot of their own that no other entry point writes (the ring's slots are
+  // recycled after 64 calls of ANY ring user: masks, cascades, member loops), so the copy with its dispatch gap
+  // (~10 us in front of the kernel) is skipped.  A changed vector overwrites the slot in stream order: every
+  // kernel that read the old factors was queued before the copy.
   static std::vector<float> last_scales;
   static const float *last_dev = nullptr;
   static unsigned long long last_generation = 0;
@@ -520,7 +534,9 @@ static int semilag_rows(const float *precip_dev, const float *velocity_dev, cons
     d = last_dev;
   } else {
     float *h = nullptr;
-    if (int rc = psh::const_slot(&h, &d)) return rc;
+    const float *ring_dev = nullptr;  // only the pinned half of the ring slot is used (staging)
+    if (int rc = psh::const_slot(&h, &ring_dev)) return rc;
+    if (int rc = psh::semilag_factor_slot(&d)) return rc;
     std::memcpy(h, scales.data(), scales.size() * sizeof(float));
     PSH_HIP(hipMemcpyAsync(const_cast<float *>(d), h, T * sizeof(float), hipMemcpyHostToDevice, c.stream));
     last_scales = scales;

@@ -15,7 +15,9 @@ from . import _lib
 class DeviceArray:
     # uv_pairs: for a (2, m, n) float32 motion field made by dense_lucaskanade, the same field as (m, n, 2) {u, v}
     # pairs (written by the interpolation kernel) - the layout the extrapolator gathers from, so that it need not
-    # interleave the planes on every call.  Whoever writes into the array's memory through `ptr` sets it to None.
+    # interleave the planes on every call.  Whoever writes into the array's memory through `ptr` sets it to None;
+    # the handles a writer would go through drop it themselves: view() (a child array's writes are invisible to
+    # the parent), fill_bytes() and free().
     __slots__ = ("ptr", "shape", "dtype", "_owner", "_keep", "uv_pairs", "__weakref__")
 
     def __init__(self, shape, dtype=np.float32, ptr=None, owner=None):
@@ -92,6 +94,7 @@ class DeviceArray:
         if self.ndim < 2 or not (0 <= index < self.shape[0]):
             raise IndexError("view index out of range")
         stride = self.nbytes // self.shape[0]
+        self.uv_pairs = None  # a plane handed out may be written through: the planes are the truth from here on
         return DeviceArray(self.shape[1:], self.dtype, ptr=self.ptr + index * stride, owner=self)
 
     def fill_bytes(self, byte_value=0):
@@ -104,6 +107,7 @@ class DeviceArray:
             _lib.check(_lib.lib().psh_free(self.ptr), "psh_free")
         self.ptr = 0
         self._owner = None
+        self.uv_pairs = None
 
     def __del__(self):
         try:

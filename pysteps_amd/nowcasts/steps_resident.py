@@ -133,9 +133,15 @@ def try_create(func, state, params, shape, n_updates):
     except (RuntimeError, MemoryError, ValueError) as exc:
         # the device could not take the state (out of memory, a random generator the device streams do not
         # reproduce, a HIP error while uploading): whatever was allocated is released with the half-built
-        # object and the reference's own update runs - a nowcast never fails because the fast path declined late
+        # object and the reference's own update runs - a nowcast never fails because the fast path declined late.
+        # PYSTEPS_HIP_STRICT=1 (the test suite sets it): a failure while the state is built is an error, so that a
+        # programming mistake in the constructor cannot hide behind the fallback as a mere slowdown
         import gc
+        import os
         import warnings
+
+        if os.environ.get("PYSTEPS_HIP_STRICT", "0") not in ("", "0"):
+            raise
 
         gc.collect()
         warnings.warn("pysteps_amd: the resident STEPS update is not used (%s: %s); the reference's update runs"
@@ -580,7 +586,13 @@ class ResidentSteps:
         """The loop ended by an exception: join the generators' own stream BEFORE the noise buffers go back to
         the block cache (a queued draw may still be writing them: a later allocation of that size would receive
         a buffer that is being filled), hand the host generators their streams back if the device still
-        answers, release the device state.  Never raises."""
+        answers, release the device state.  Never raises.
+
+        The host generators come back ONE draw ahead of the last completed update when the loop was not at its
+        end: update() queues the next time step's draw beside the update it runs (``_draw(slot ^ 1)``), and a
+        MT19937 stream cannot be wound back.  A caller that catches the exception and goes on drawing from the
+        same ``RandomState`` objects continues a valid stream, but not the one the reference would continue -
+        re-seed (or keep copies made with ``get_state()`` before the nowcast) where stream parity matters."""
         try:
             if getattr(self, "rng", None) is not None:
                 try:

@@ -166,17 +166,18 @@ def bps_perturbators(velocity_pert_gen, velocity):
                         p_perp=tuple(vp["p_perp"]), vsf=float(vp["vsf"]), time_scale=scale))
     if not out:
         return None
-    # EVERY generator against its closed form on this motion field, on a sub-grid of ~512 x 512 samples
-    # whose offset is drawn anew on every call (a perturbator built from another - shifted, filtered -
-    # motion field differs everywhere; one evaluation on the full 4096^2 grid costs 0.4 s of a 1.2 s
-    # main loop).  The closed form follows noise/motion.py:129-133 in the velocity's own dtype: a float32
-    # motion field is normalised in float32 there
+    # EVERY generator against its closed form on this motion field, on a jittered lattice of ~512 x 512 samples:
+    # one sample per cell of `step` x `step` pixels at a position inside the cell that is a FIXED pseudo-random
+    # function of the cell (seeded generator: the same inputs get the same verdict on every call and in every
+    # process - round-4 advisor), so that neither a shifted / filtered motion field (differs everywhere) nor a
+    # difference confined to the rows or columns of one residue class goes unseen.  One evaluation on the full
+    # 4096^2 grid would cost 0.4 s of a 1.2 s main loop.  The closed form follows noise/motion.py:129-133 in the
+    # velocity's own dtype: a float32 motion field is normalised in float32 there
     vel = np.asarray(velocity)
     if vel.ndim != 3 or vel.shape[0] != 2:
         return None
     step = max(1, min(vel.shape[1:]) // 512)
-    oy, ox = (int(v) for v in np.random.default_rng().integers(0, step, size=2))
-    sub = (slice(None), slice(oy, None, step), slice(ox, None, step))
+    sub = _jittered_lattice(vel.shape[1], vel.shape[2], step)
     vel = np.ascontiguousarray(vel[sub])
     if vel.dtype.kind != "f":
         vel = vel.astype(np.float64)
@@ -200,6 +201,18 @@ def bps_perturbators(velocity_pert_gen, velocity):
         except Exception:
             return None
     return out
+
+
+def _jittered_lattice(m, n, step):
+    """Index (slice(None), rows, cols) of one pixel per ``step`` x ``step`` cell of an (m, n) grid; the position
+    inside a cell comes from a generator with a fixed seed (deterministic, see bps_perturbators)."""
+    if step <= 1:
+        return (slice(None), slice(None), slice(None))
+    cy, cx = -(-m // step), -(-n // step)
+    rng = np.random.default_rng(0x5EED)
+    iy = np.minimum(np.arange(cy)[:, None] * step + rng.integers(0, step, size=(cy, cx)), m - 1)
+    ix = np.minimum(np.arange(cx)[None, :] * step + rng.integers(0, step, size=(cy, cx)), n - 1)
+    return (slice(None), iy, ix)
 
 
 def _batched_options(extrap_kwargs):

@@ -53,6 +53,45 @@ def test_members_match_per_member_oracle(perturb, n_iter):
         assert np.max(np.abs(gd[j] - D[j])) < 1e-4
 
 
+def test_members_4096_config4_vs_per_member_oracle():
+    """BASELINE config 4's resident member advection at full size (4096^2, perturbed motion, two members,
+    two time steps with the displacement carried over) against per-member calls of the SciPy oracle;
+    the bars are the regression bars of the small cases, what was seen goes to gpurun_out/."""
+    from oracle import semilag as osl
+    from pysteps_amd.extrapolation.ensemble import EnsembleAdvector
+    from tools import synth
+
+    B, m, n = 2, 4096, 4096
+    members = np.stack([synth.rain_field_db(m, n, seed=70 + j) for j in range(B)])
+    members[1, 100:140, 3000:3100] = np.nan
+    V = synth.true_velocity(m, n)
+    perts = _perturbators(B, 11)
+    adv = EnsembleAdvector(V, B, perts, n_iter=1)
+    D = [None] * B
+    seen = []
+    for dt, t_total in [(1.0, 5.0), (1.0, 10.0)]:
+        got = adv.step(members, dt, t_total)
+        for j in range(B):
+            Vj = V.astype(np.float64) + _generate_bps(V.astype(np.float64), perts[j], t_total)
+            want, D[j] = osl.extrapolate(members[j], Vj, [dt], allow_nonfinite_values=True, n_iter=1,
+                                         return_displacement=True, displacement_prev=D[j])
+            assert nan_mismatch(got[j], want[0]) <= 8
+            seen.append(rel_l2(got[j], want[0]))
+            assert seen[-1] < 5e-6  # observed 2e-7 .. 1e-6; north_star's contract is 1e-4
+    gd = adv.displacement.to_host()
+    dmax = max(float(np.max(np.abs(gd[j] - D[j]))) for j in range(B))
+    assert dmax < 1e-5
+    try:
+        import json
+        import os
+
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/members_4096_seen.json", "w") as fh:
+            json.dump({"rel_l2": seen, "disp_max_abs": dmax}, fh)
+    except OSError:
+        pass
+
+
 def test_members_equal_single_member_calls():
     """Without perturbation the batched kernel reproduces the fused single-field kernel."""
     from pysteps_amd.extrapolation import get_method

@@ -201,7 +201,8 @@ def test_bps_generators_float32_motion_and_local_differences(ref_pysteps):
     """A float32 motion field is normalised in float32 by initialize_bps (noise/motion.py:129-133): the closed form
     is checked in that dtype and the generators are recognised (round 3 compared a float64 closed form at 1e-9 and
     always fell back).  A perturbator built from a motion field that differs from this one in a small patch only is
-    declined: the sample's offset is drawn anew per call, so a handful of calls see every pixel of a small grid."""
+    declined, deterministically: one pixel per cell of the sampling lattice is looked at, at a fixed pseudo-random
+    position inside the cell (round-4 advisor: the verdict must not depend on the call)."""
     from pysteps import noise
     from pysteps_amd.nowcasts.utils import bps_perturbators
     from tools import synth
@@ -212,12 +213,18 @@ def test_bps_generators_float32_motion_and_local_differences(ref_pysteps):
     gens = [lambda t, vp=init(V32, 1.0, timestep, randstate=np.random.RandomState(j)): gen(vp, t * timestep) for j in range(2)]
     assert bps_perturbators(gens, V32) is not None
 
-    m, n = 1200, 1100  # step 2 in both directions: a single call samples a quarter of the pixels
+    m, n = 1200, 1100  # cells of 2 x 2 pixels, one sample in each (the jittered lattice of bps_perturbators)
     V = synth.true_velocity(m, n).astype(np.float64)
     other = V.copy()
-    other[:, 601:603, 501:503] = other[:, 601:603, 501:503][::-1] * 1.5  # a 2 x 2 patch with another direction
+    other[:, 600:602, 500:502] = other[:, 600:602, 500:502][::-1] * 1.5  # one whole cell with another direction
     vp = init(other, 1.0, timestep, randstate=np.random.RandomState(3))
     closure = [lambda t, vp=vp: gen(vp, t * timestep)]
-    verdicts = [bps_perturbators(closure, V) is None for _ in range(24)]
-    assert any(verdicts)  # (each call hits the patch with probability 1 - (3/4)... >= 1/4: all 24 missing it: < 1e-3)
+    verdicts = [bps_perturbators(closure, V) is None for _ in range(3)]
+    assert all(verdicts)  # the cell's sample sees it, and the verdict does not change from call to call
+    # residue classes: a difference on the even rows only is seen too (a plain strided sub-grid at an odd offset misses it)
+    rows = V.copy()
+    rows[:, ::2, :] *= 1.0 + 1e-3 * np.sign(rows[::-1, ::2, :])
+    rows[0, ::2, :] += 0.05
+    vp_rows = init(rows, 1.0, timestep, randstate=np.random.RandomState(3))
+    assert bps_perturbators([lambda t, vp=vp_rows: gen(vp, t * timestep)], V) is None
     assert bps_perturbators([lambda t, vp=init(V, 1.0, timestep, randstate=np.random.RandomState(3)): gen(vp, t * timestep)], V) is not None

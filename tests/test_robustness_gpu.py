@@ -99,3 +99,26 @@ def test_resident_probmatch_falls_back_when_the_bucket_pass_declines(ref_pysteps
     untied[:100] = False
     np.testing.assert_array_equal(g[untied], want[untied])
     np.testing.assert_array_equal(np.sort(g[~untied]), np.sort(want[~untied]))
+
+
+def test_cached_step_factors_survive_a_wrapped_constant_ring():
+    """Round-4 advisor: the extrapolator keeps the device copy of its step factors while they do not change.
+    More than 64 calls of other entry points that take constant slots (here: dilated masks) between two
+    extrapolations with equal time steps must not change what the second one advects with."""
+    from pysteps_amd.device import DeviceArray
+    from pysteps_amd.extrapolation import get_method
+    from pysteps_amd.nowcasts.utils import compute_dilated_mask
+    from tools import synth
+
+    m, n = 128, 160
+    p = synth.rain_field_db(m, n, seed=5)
+    v = synth.true_velocity(m, n)
+    steps = [0.5, 1.0, 2.5, 3.0]
+    ex = get_method("semilagrangian")
+    first = ex(p, v, steps)
+    mask = DeviceArray.from_host((p > -10).astype(np.uint8))
+    kr = np.ones((3, 3), dtype=np.uint8)
+    for _ in range(70):  # the ring has 64 slots: the one the factors used to share is overwritten by taps
+        compute_dilated_mask(mask, kr, 4)
+    second = ex(p, v, steps)
+    assert np.array_equal(first, second, equal_nan=True)

@@ -207,10 +207,16 @@ def test_elementwise_pieces_bit_identical_with_numpy():
 FLIP_BAR = 1e-5  # observed: 0 in all 8 configurations x 4 updates (median difference <= 2e-16 of the range)
 
 
+_INPUTS = {}
+
+
 def _steps_inputs(m, n):
     from tools import synth
 
-    return synth.steps_frames(m, n, 3), synth.true_velocity(m, n).astype(np.float64)
+    if (m, n) not in _INPUTS:  # the 4096^2 frames take ~10 s to make and two cases use them
+        _INPUTS.clear()
+        _INPUTS[(m, n)] = (synth.steps_frames(m, n, 3), synth.true_velocity(m, n).astype(np.float64))
+    return _INPUTS[(m, n)]
 
 
 CONFIGS = {
@@ -226,6 +232,12 @@ CONFIGS = {
     "refspectral_sprog_cdf": dict(mask_method="sprog", probmatching_method="cdf", domain="spectral"),
     "refspectral_ar1_odd": dict(mask_method=None, probmatching_method=None, domain="spectral", ar_order=1, n_cascade_levels=8,
                                 shape=(127, 95)),
+    # BASELINE config 4 at its own size: 4096^2 x 6 levels x AR(2), one member, two updates (the first one reads the
+    # initial AR history, the second the state the first one left), in both domains.  The kernels whose behaviour
+    # changes with size are the ones exercised: pm2_* partitions at 16.7 M values, FFT column tiles at 4096.
+    "zz_baseline_4096": dict(mask_method="incremental", probmatching_method="cdf", shape=(4096, 4096), n_ens_members=1, timesteps=1),
+    "zz_refspectral_baseline_4096": dict(mask_method="incremental", probmatching_method="cdf", domain="spectral", shape=(4096, 4096),
+                                         n_ens_members=1, timesteps=1),
 }
 
 
@@ -248,6 +260,7 @@ def test_update_beside_the_reference_update(ref_pysteps, name, monkeypatch):
     cfg = dict(CONFIGS[name])
     ar_order = cfg.pop("ar_order", 2)
     m, n = cfg.pop("shape", (128, 128))
+    timesteps = cfg.pop("timesteps", 3)
     frames, V = _steps_inputs(m, n)
     frames = frames[-(ar_order + 1):]
     if name in ("obs_none", "refspectral_composite_obs"):
@@ -280,10 +293,10 @@ def test_update_beside_the_reference_update(ref_pysteps, name, monkeypatch):
     orig = steps_mod.nowcast_main_loop
     try:
         steps_mod.nowcast_main_loop = side_by_side
-        nowcasts.get_method("steps")(frames, V, 3, **kw)
+        nowcasts.get_method("steps")(frames, V, timesteps, **kw)
     finally:
         steps_mod.nowcast_main_loop = orig
-    assert len(report) == 4
+    assert len(report) == timesteps + 1
     try:  # what was seen, for the bars below (gpurun_out/ travels back from the GPU box)
         import json
         import os
@@ -396,7 +409,7 @@ def test_sharded_driver_runs_through_rccl_at_world_size_one():
     assert line["ranks"] == 1 and line["members_of_rank0"] == [0, 1, 2] and line["result_of_rank0"] == [3, 2, 256, 256]
 
 
-def test_a_failing_callback_leaves_the_library_usable_and_a_late_failure_falls_back(ref_pysteps):
+def test_a_failing_callback_leaves_the_library_usable_and_a_late_failure_falls_back(ref_pysteps, monkeypatch):
     """(a) an exception inside the loop (here: the caller's callback) aborts the resident state in order - the
     generators' stream is joined before the noise buffers are released - and the very next nowcast gives the stock
     result; (b) a failure while the resident state is being built (here: injected) does not abort the nowcast: the
@@ -436,6 +449,9 @@ def test_a_failing_callback_leaves_the_library_usable_and_a_late_failure_falls_b
             raise MemoryError("injected: no room for the device state")
 
         steps_resident.ResidentSteps.__init__ = failing
+        with pytest.raises(MemoryError):  # under test (PYSTEPS_HIP_STRICT=1, tests/conftest.py) a late failure is an error
+            steps(frames, V, 2, extrap_method="semilagrangian_hip", **kw)
+        monkeypatch.setenv("PYSTEPS_HIP_STRICT", "0")  # production: the reference's update takes over, with a warning
         with pytest.warns(RuntimeWarning, match="resident STEPS update is not used"):
             late = steps(frames, V, 2, extrap_method="semilagrangian_hip", **kw)
         assert _ensemble_close(late, want) < 1e-4
