@@ -26,6 +26,7 @@
 //    i+1 by DPP (v_cndmask_b32_dpp) unless the neighbour's trajectory sits elsewhere.
 //  * No LDS (default variant), no MFMA: the gather footprint moves with D and there is no
 //    dense contraction.  The kernel is bound by the CU's vector-memory pipeline.
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -898,6 +899,411 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
   }
 }
 
+// ---- workgroup window (variant 9) ----------------------------------------------------------------
+// The gather kernels above are bound by the CU's vector-memory pipeline: five wave64 dwordx4 gathers per
+// pixel and lead step return 80 B per lane through a 64 B/clk path, whatever the caches
+// hold.  Here a workgroup of four waves owns a 64 x 16 tile (four rows per lane) and keeps a WINDOW of the
+// {u,v} plane and of the field plane - 96 x 40 texels around the tile's current sample positions - in LDS
+// ACROSS lead steps: a sampling pass is LDS reads (4 x 8 B + 4 x 4 B per sample, conflict-free for
+// neighbouring pixels) and arithmetic, nothing else.  The trajectory is carried relative to the window
+// (pre-scaled column offset, row offset), so the two unsigned compares that prove "all four taps inside
+// the window" replace the image-interior test and the LDS address is one multiply-add.
+//  * A wave whose samples are not all inside the window (border of the image, extreme deformation, a
+//    lost trajectory) takes that pass through the gathers of the packed kernel - wave by wave, pass by
+//    pass, same values, same blend order: results are bit-identical to every other variant.
+//  * Once per lead step the waves agree (one s_barrier) on whether the window has to move: a wave asks
+//    for it when the corner samples of its patch come closer to the window's edge than the distance the
+//    next step covers.  The new window is placed with its slack AHEAD of the motion (it then lasts
+//    slack / speed lead steps: ~5 at 6 px per step), filled by coalesced dwordx4 loads + ds_write_b128,
+//    and the lanes re-base their offsets.  Window traffic per pixel and lead step: ~0.6 vector-memory
+//    instructions instead of 5.
+constexpr int kWinRows = 4;   // image rows per lane
+// WAVES waves per workgroup (a 64 x 4 WAVES tile), window of WW x WH texels (WW a multiple of 4)
+template <int WAVES, int WW, int WH>
+struct WinCfg {
+  static constexpr int kWaves = WAVES, kW = WW, kH = WH;
+  static constexpr int kTileY = kWinRows * WAVES;
+  static constexpr unsigned kPitch8 = WW * 8u;        // bytes per window row of {u,v} pairs
+  static constexpr int kItemsUV = WH * (WW / 2);      // 16-byte items of the {u,v} window
+  static constexpr int kItemsP = WH * (WW / 4);       // ... of the field window
+  static constexpr int kThreads = kTileX * WAVES;
+  static constexpr unsigned kCtlVel = 16u * WAVES, kCtlFlag = kCtlVel + 8u;  // byte offsets in the control block
+  static constexpr int kCtlWords = 4 * WAVES + 2 + 3 + 3;
+};
+using Win4 = WinCfg<4, 96, 40>;  // 45 KiB of LDS: three workgroups (12 waves) per CU
+using Win8 = WinCfg<8, 96, 64>;  // 72 KiB: two workgroups (16 waves) per CU, the window lasts about twice as long
+
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) int lds_int;
+
+struct Window {
+  unsigned uv, p;  // LDS byte addresses of the two planes
+  unsigned ctl;    // ... of the control words: box[waves][4], vel[2], flag[3]
+  int ox, oy;      // image position of the window's first texel (uniform over the workgroup)
+  unsigned long long *stats;  // debug counters (nullptr): [0] passes through the window, [1] through the gathers, [2] fills
+};
+
+// LDS traffic only: the nontemporal output stores of the lead step stay in flight across the barrier
+__device__ __forceinline__ void win_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ void win_count(const Window &W, int which) {
+  if (W.stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(W.stats + which, 1ull);
+}
+
+template <class C, int WHAT, bool GEN>
+__device__ __forceinline__ void win_sample(const Fields &F, const Window &W, const int (&dx8)[kWinRows],
+                                           const int (&dy)[kWinRows], const float (&fx)[kWinRows],
+                                           const float (&fy)[kWinRows], int m, int n, float outval,
+                                           float (&su)[kWinRows], float (&sv)[kWinRows], float (&sp)[kWinRows]) {
+  constexpr bool kWithP = (WHAT & kPrecip) != 0;
+  // all four taps of all four samples inside the window: one unsigned maximum per axis (a negative offset is a huge one)
+  unsigned mx = static_cast<unsigned>(dx8[0]), my = static_cast<unsigned>(dy[0]);
+#pragma unroll
+  for (int j = 1; j < kWinRows; ++j) {
+    mx = max(mx, static_cast<unsigned>(dx8[j]));
+    my = max(my, static_cast<unsigned>(dy[j]));
+  }
+  const bool ok = mx <= (C::kW - 2) * 8u && my <= static_cast<unsigned>(C::kH - 2);
+  if (__builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true)) {
+    win_count(W, 0);
+    // every read is issued before the first blend
+    f32x2 t0[kWinRows], t1[kWinRows], b0[kWinRows], b1[kWinRows];
+    float pa[kWinRows], pb[kWinRows], pc[kWinRows], pd[kWinRows];
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      const unsigned a = __umul24(static_cast<unsigned>(dy[j]), C::kPitch8) + static_cast<unsigned>(dx8[j]);
+      const lds_f32x2 *q = (const lds_f32x2 *)(size_t)(W.uv + a);
+      t0[j] = q[0], t1[j] = q[1], b0[j] = q[C::kW], b1[j] = q[C::kW + 1];
+      if (kWithP) {
+        const lds_f32 *r = (const lds_f32 *)(size_t)(W.p + (a >> 1));
+        pa[j] = r[0], pb[j] = r[1], pc[j] = r[C::kW], pd[j] = r[C::kW + 1];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      const Weights w = make_weights(fx[j], fy[j]);
+      f32x2 acc = t0[j] * w.w00;  // the order of sample_interior_packed
+      acc = __builtin_elementwise_fma(f32x2{w.w01, w.w01}, t1[j], acc);
+      acc = __builtin_elementwise_fma(f32x2{w.w10, w.w10}, b0[j], acc);
+      acc = __builtin_elementwise_fma(f32x2{w.w11, w.w11}, b1[j], acc);
+      su[j] = acc.x;
+      sv[j] = acc.y;
+      if (kWithP) sp[j] = blend(w, pa[j], pb[j], pc[j], pd[j]);
+    }
+  } else {
+    win_count(W, 1);
+    int X[kWinRows], Y[kWinRows];
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      X[j] = W.ox + (dx8[j] >> 3);
+      Y[j] = W.oy + dy[j];
+    }
+    Stage S;
+    S.fetch = nullptr;
+    S.lds = S.lds_v = S.lds_p = 0;
+    S.buf = nullptr;
+    S.red = nullptr;
+    S.x0 = S.y0 = S.parity = 0;
+    sample_at<kWinRows, 1, WHAT, kModePacked, GEN>(F, S, X, Y, fx, fy, m, n, outval, su, sv, sp);
+  }
+}
+
+// Once per lead step, every wave of the workgroup: publish the box of the patch's corner samples, ask for
+// a new window if they are about to leave this one, agree at a barrier, and if anybody asked: place the
+// window ahead of the motion, re-base the offsets, fill it.  `phase` cycles through three flag words so
+// that clearing the next one never races with a wave that still has to read it.
+template <class C>
+__device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase, bool force, int (&dx8)[kWinRows],
+                                           int (&dy)[kWinRows], float vx_lane, float vy_lane, float move_scale, int m,
+                                           int n) {
+  const int lane = threadIdx.x & 63, wave = rfl(static_cast<int>(threadIdx.x >> 6));
+  lds_int *ctl = (lds_int *)(size_t)W.ctl;
+  const int xa = __builtin_amdgcn_readlane(dx8[0], 0), xb = __builtin_amdgcn_readlane(dx8[0], 63);
+  const int xc = __builtin_amdgcn_readlane(dx8[kWinRows - 1], 0), xd = __builtin_amdgcn_readlane(dx8[kWinRows - 1], 63);
+  const int ya = __builtin_amdgcn_readlane(dy[0], 0), yb = __builtin_amdgcn_readlane(dy[0], 63);
+  const int yc = __builtin_amdgcn_readlane(dy[kWinRows - 1], 0), yd = __builtin_amdgcn_readlane(dy[kWinRows - 1], 63);
+  const int lo8 = smin(smin(xa, xb), smin(xc, xd)), hi8 = smax(smax(xa, xb), smax(xc, xd));
+  const int loy = smin(smin(ya, yb), smin(yc, yd)), hiy = smax(smax(ya, yb), smax(yc, yd));
+  // the wave's direction of travel and the distance one lead step covers (half increment of the first pixel;
+  // a lost trajectory - NaN - asks for nothing)
+  const float vx = __builtin_amdgcn_readfirstlane(vx_lane), vy = __builtin_amdgcn_readfirstlane(vy_lane);
+  const float mx = fabsf(vx) < 64.f ? fabsf(vx) * move_scale + 2.f : 2.f, my = fabsf(vy) < 64.f ? fabsf(vy) * move_scale + 2.f : 2.f;
+  const int gx = rfl(static_cast<int>(mx)), gy = rfl(static_cast<int>(my));
+  // a positive velocity moves the samples towards lower coordinates (retreat)
+  const int need_lx = vx > 0.f ? gx : 1, need_hx = vx > 0.f ? 1 : gx;
+  const int need_ly = vy > 0.f ? gy : 1, need_hy = vy > 0.f ? 1 : gy;
+  const bool near = force || lo8 < need_lx * 8 || hi8 > (C::kW - 2 - need_hx) * 8 || loy < need_ly || hiy > C::kH - 2 - need_hy;
+  if (lane == 0) {
+    if (near) ctl[C::kCtlFlag / 4 + phase] = 1;
+    ctl[wave * 4 + 0] = lo8;
+    ctl[wave * 4 + 1] = hi8;
+    ctl[wave * 4 + 2] = loy;
+    ctl[wave * 4 + 3] = hiy;
+    if (wave == 0) {
+      ctl[C::kCtlVel / 4 + 0] = __float_as_int(vx);
+      ctl[C::kCtlVel / 4 + 1] = __float_as_int(vy);
+      ctl[C::kCtlFlag / 4 + (phase == 2 ? 0 : phase + 1)] = 0;
+    }
+  }
+  win_barrier();
+  if (rfl(ctl[C::kCtlFlag / 4 + phase]) == 0) return;
+  int ulo8 = 0x7fffffff, uhi8 = -0x7fffffff, uloy = 0x7fffffff, uhiy = -0x7fffffff;
+#pragma unroll
+  for (int w = 0; w < C::kWaves; ++w) {
+    ulo8 = min(ulo8, ctl[w * 4 + 0]);
+    uhi8 = max(uhi8, ctl[w * 4 + 1]);
+    uloy = min(uloy, ctl[w * 4 + 2]);
+    uhiy = max(uhiy, ctl[w * 4 + 3]);
+  }
+  const float wvx = __int_as_float(ctl[C::kCtlVel / 4 + 0]), wvy = __int_as_float(ctl[C::kCtlVel / 4 + 1]);
+  // first and last texel the tile touches now (right / lower tap included), relative to the current origin
+  const int bx0 = ulo8 >> 3, bx1 = (uhi8 >> 3) + 1, by0 = uloy, by1 = uhiy + 1;
+  const int slack_x = max(C::kW - (bx1 - bx0 + 1), 0), slack_y = max(C::kH - (by1 - by0 + 1), 0);
+  // texels kept on the low side: all the slack but two where the motion goes that way, two where it comes
+  // from, half of it in calm air
+  const int keep_x = wvx > 0.125f ? max(slack_x - 2, 0) : (wvx < -0.125f ? min(slack_x, 2) : slack_x / 2);
+  const int keep_y = wvy > 0.125f ? max(slack_y - 2, 0) : (wvy < -0.125f ? min(slack_y, 2) : slack_y / 2);
+  const int nox = rfl(min(max((W.ox + bx0 - keep_x) & ~3, 0), n - C::kW));  // 16-byte aligned rows of both planes
+  const int noy = rfl(min(max(W.oy + by0 - keep_y, 0), m - C::kH));
+  // (a tile parked at the image border keeps asking: the window it would get is the one it has)
+  if (!force && nox == W.ox && noy == W.oy) return;
+  win_count(W, 2);
+  const int ddx8 = (nox - W.ox) * 8, ddy = noy - W.oy;
+#pragma unroll
+  for (int j = 0; j < kWinRows; ++j) {
+    dx8[j] -= ddx8;
+    dy[j] -= ddy;
+  }
+  W.ox = nox;
+  W.oy = noy;
+  // every wave is past the barrier: nobody reads the old window any more
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));  // opaque: the item addresses below are not loop invariants worth 40 registers
+  constexpr int kRoundsUV = (C::kItemsUV + C::kThreads - 1) / C::kThreads, kRoundsP = (C::kItemsP + C::kThreads - 1) / C::kThreads;
+  // (threads past the last item repeat it: the same bytes to the same place, and no exec-masked rounds)
+  u32x4 buv[kRoundsUV], bp[kRoundsP];
+  const unsigned org = static_cast<unsigned>(noy) * static_cast<unsigned>(n) + static_cast<unsigned>(nox);
+#pragma unroll
+  for (int k = 0; k < kRoundsUV; ++k) {
+    const int item = min(tid + C::kThreads * k, C::kItemsUV - 1);
+    const int row = item / (C::kW / 2), c = item - row * (C::kW / 2);
+    buv[k] = __builtin_amdgcn_raw_buffer_load_b128(F.ruv, static_cast<int>((org + row * n + 2 * c) << 3), 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < kRoundsP; ++k) {
+    const int item = min(tid + C::kThreads * k, C::kItemsP - 1);
+    const int row = item / (C::kW / 4), c = item - row * (C::kW / 4);
+    bp[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rp, static_cast<int>((org + row * n + 4 * c) << 2), 0, 0);
+  }
+#pragma unroll
+  for (int k = 0; k < kRoundsUV; ++k)
+    *(lds_u32x4 *)(size_t)(W.uv + 16u * min(tid + C::kThreads * k, C::kItemsUV - 1)) = buv[k];
+#pragma unroll
+  for (int k = 0; k < kRoundsP; ++k)
+    *(lds_u32x4 *)(size_t)(W.p + 16u * min(tid + C::kThreads * k, C::kItemsP - 1)) = bp[k];
+  win_barrier();
+}
+
+// retreat() on the pre-scaled column offset (8 bytes per pixel): same t, same floor, same fraction
+__device__ __forceinline__ void retreat8(int &P8, float &f, float w) {
+  const float t = f - w;
+  int k;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k) : "v"(t));
+  P8 += k * 8;
+  f = __builtin_amdgcn_fractf(t);
+}
+
+template <class C, bool GEN>
+__global__ __launch_bounds__(C::kThreads, C::kWaves == 4 ? 3 : 4) void semilag_window(
+    const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vel_packed,
+    float *__restrict__ out, double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m,
+    int n, int T, int n_iter, int resume, float outval, int row0, int rows, int bmode, int tiles_x, int n_tiles,
+    int tiles_per_xcd, unsigned long long *__restrict__ stats) {
+  const int b = blockIdx.x;
+  const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
+  if (tile >= n_tiles) return;  // the whole workgroup
+  const int lane = threadIdx.x & (kTileX - 1);
+  const int xt = (tile % tiles_x) * kTileX + lane;
+  const int yt = row0 + (tile / tiles_x) * C::kTileY + static_cast<int>(threadIdx.x / kTileX) * kWinRows;
+  const int x = min(xt, n - 1);
+  const size_t plane = static_cast<size_t>(m) * n;
+  Fields F;
+  F.u0 = vel;
+  F.v0 = vel + plane;
+  F.p0 = precip;
+  const int plane_bytes = static_cast<int>(plane * sizeof(float));
+  F.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel), 0, plane_bytes, 0x00020000);
+  F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
+  F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(precip), 0, plane_bytes, 0x00020000);
+  F.ruv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel_packed), 0, 2 * plane_bytes, 0x00020000);
+  F.rpp = F.ruv;  // (no row-pair field plane in this kernel)
+  F.row_bytes = n * static_cast<int>(sizeof(float));
+  F.coef = nullptr;
+  F.cpad = 0;
+  F.minval = 0.f;
+  F.bmode = bmode;
+
+  __shared__ __attribute__((aligned(16))) float win_uv[C::kW * C::kH * 2];
+  __shared__ __attribute__((aligned(16))) float win_p[C::kW * C::kH];
+  __shared__ __attribute__((aligned(16))) int win_ctl[C::kCtlWords];
+  Window W;
+  W.uv = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_uv));
+  W.p = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_p));
+  W.ctl = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_ctl));
+  W.ox = W.oy = 0;
+  W.stats = stats;
+  if (threadIdx.x < 3) win_ctl[C::kCtlFlag / 4 + threadIdx.x] = 0;
+
+  int y[kWinRows], dx8[kWinRows], dy[kWinRows];
+  float fx[kWinRows], fy[kWinRows], vix[kWinRows], viy[kWinRows], su[kWinRows], sv[kWinRows], sp[kWinRows];
+  bool live[kWinRows];
+  unsigned opix[kWinRows];
+#pragma unroll
+  for (int j = 0; j < kWinRows; ++j) {
+    live[j] = xt < n && yt + j < row0 + rows;
+    y[j] = min(yt + j, m - 1);
+    opix[j] = static_cast<unsigned>(__mul24(y[j] - row0, n) + x) << 2;
+    int px = x, py = y[j];
+    fx[j] = fy[j] = sp[j] = 0.f;
+    if (resume) {
+      split_displacement(disp[static_cast<size_t>(y[j]) * n + x], px, fx[j]);
+      split_displacement(disp[plane + static_cast<size_t>(y[j]) * n + x], py, fy[j]);
+    }
+    dx8[j] = px * 8;  // relative to the origin (0, 0) until the first window is placed
+    dy[j] = py;
+    vix[j] = viy[j] = 0.f;
+  }
+  const float move_scale = 2.5f * static_cast<float>(n_iter);  // lead step = n_iter sub-steps of two half increments, + 25 %
+  if (!resume) {
+    // first increment is NOT divided by n_iter (semilagrangian.py:202)
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      const unsigned pix = static_cast<unsigned>(__mul24(y[j], n) + x) << 2;
+      vix[j] = ld(F.u0, pix) * first_scale;
+      viy[j] = ld(F.v0, pix) * first_scale;
+    }
+  }
+  __syncthreads();  // the flag words are cleared
+  int phase = 0;
+  win_update<C>(F, W, phase, true, dx8, dy, 0.5f * vix[0], 0.5f * viy[0], move_scale, m, n);
+  phase = 1;
+  if (resume) {
+    win_sample<C, kVel, GEN>(F, W, dx8, dy, fx, fy, m, n, outval, su, sv, sp);
+    const float s0 = scale[0];
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      vix[j] = su[j] * s0;
+      viy[j] = sv[j] * s0;
+    }
+  }
+  const float lostval = (bmode == kModeNearest || bmode == kModeGridConstant) ? __builtin_nanf("") : outval;
+  // the increment is only ever used halved (midpoint rule): carry Vi / 2 (exact)
+#pragma unroll
+  for (int j = 0; j < kWinRows; ++j) {
+    vix[j] *= 0.5f;
+    viy[j] *= 0.5f;
+  }
+
+  for (int t = 0; t < T; ++t) {
+    const float s = scale[t];
+    const float half_s = 0.5f * s;
+    for (int k = 0; k < n_iter; ++k) {
+      int mx8[kWinRows], my[kWinRows];
+      float gx[kWinRows], gy[kWinRows];
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) {
+        mx8[j] = dx8[j];
+        my[j] = dy[j];
+        gx[j] = fx[j];
+        gy[j] = fy[j];
+        retreat8(mx8[j], gx[j], vix[j]);  // midpoint rule (:213), vix = Vi / 2
+        retreat(my[j], gy[j], viy[j]);
+      }
+      win_sample<C, kVel, GEN>(F, W, mx8, my, gx, gy, m, n, outval, su, sv, sp);
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) {
+        retreat8(dx8[j], fx[j], su[j] * s);
+        retreat(dy[j], fy[j], sv[j] * s);
+      }
+      if (k == n_iter - 1) {
+        win_sample<C, kVel | kPrecip, GEN>(F, W, dx8, dy, fx, fy, m, n, outval, su, sv, sp);
+      } else {
+        win_sample<C, kVel, GEN>(F, W, dx8, dy, fx, fy, m, n, outval, su, sv, sp);
+      }
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) {
+        vix[j] = su[j] * half_s;
+        viy[j] = sv[j] * half_s;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      sp[j] = lost(fx[j], fy[j]) ? lostval : sp[j];
+      if (live[j]) __builtin_nontemporal_store(sp[j], reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
+    }
+    out += static_cast<size_t>(rows) * n;
+    if (t + 1 < T) {
+      win_update<C>(F, W, phase, false, dx8, dy, vix[0], viy[0], move_scale, m, n);
+      phase = phase == 2 ? 0 : phase + 1;
+    }
+  }
+
+  if (disp != nullptr) {
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      if (!live[j]) continue;
+      disp[static_cast<size_t>(y[j]) * n + x] =
+          static_cast<double>(W.ox + (dx8[j] >> 3) - x) + static_cast<double>(fx[j]);
+      disp[plane + static_cast<size_t>(y[j]) * n + x] =
+          static_cast<double>(W.oy + dy[j] - y[j]) + static_cast<double>(fy[j]);
+    }
+  }
+}
+
+bool semilag_window_eligible(const SemilagArgs &a) {
+  return a.precip != nullptr && a.vel_packed != nullptr && a.order == 1 && a.n_iter >= 1 && a.n % 4 == 0 &&
+         a.n >= Win8::kW && a.m >= Win8::kH && reinterpret_cast<uintptr_t>(a.vel_packed) % 16 == 0 &&
+         reinterpret_cast<uintptr_t>(a.precip) % 16 == 0;
+}
+
+// debug counters of the window kernels (PYSTEPS_HIP_SL_STATS=1): printed after every launch, which then waits
+static unsigned long long *g_win_stats = nullptr;
+
+template <class C>
+static hipError_t launch_window(const SemilagArgs &a, hipStream_t stream) {
+  const int tiles_x = (a.n + kTileX - 1) / kTileX;
+  const int tiles_y = (a.rows + C::kTileY - 1) / C::kTileY;
+  const int n_tiles = tiles_x * tiles_y;
+  const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
+  const dim3 grid(tiles_per_xcd * kNumXcd), block(C::kThreads);
+  static const bool want_stats = std::getenv("PYSTEPS_HIP_SL_STATS") != nullptr;
+  if (want_stats) {
+    if (g_win_stats == nullptr && hipMalloc(&g_win_stats, 4 * sizeof(unsigned long long)) != hipSuccess) g_win_stats = nullptr;
+    if (g_win_stats != nullptr) (void)hipMemsetAsync(g_win_stats, 0, 4 * sizeof(unsigned long long), stream);
+  }
+  if (a.bmode != 0) {
+    hipLaunchKernelGGL((semilag_window<C, true>), grid, block, 0, stream, a.precip, a.vel, a.vel_packed, a.out, a.disp,
+                       a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x,
+                       n_tiles, tiles_per_xcd, g_win_stats);
+  } else {
+    hipLaunchKernelGGL((semilag_window<C, false>), grid, block, 0, stream, a.precip, a.vel, a.vel_packed, a.out, a.disp,
+                       a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x,
+                       n_tiles, tiles_per_xcd, g_win_stats);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess && want_stats && g_win_stats != nullptr) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (hipMemcpyAsync(h, g_win_stats, sizeof(h), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        hipStreamSynchronize(stream) == hipSuccess)
+      std::fprintf(stderr, "semilag_window<%d waves>: %dx%d T=%d: wave-passes through the window %llu, through the gathers %llu, "
+                   "window fills %llu (of %d workgroups x %d lead steps)\n", C::kWaves, a.m, a.n, a.T, h[0], h[1], h[2],
+                   n_tiles, a.T);
+  }
+  return e;
+}
+
 template <int NPX, int MODE>
 static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   constexpr int kWaves = waves_of<MODE>();
@@ -958,6 +1364,8 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
   // LDS staging needs 16-byte aligned rows (n % 4 == 0)
   const bool aligned = (a.n % 4 == 0) && (reinterpret_cast<uintptr_t>(a.vel) % 16 == 0) &&
                        (a.precip == nullptr || reinterpret_cast<uintptr_t>(a.precip) % 16 == 0);
+  if (g_semilag_variant == 9 && semilag_window_eligible(a)) return launch_window<Win4>(a, stream);
+  if (g_semilag_variant == 10 && semilag_window_eligible(a)) return launch_window<Win8>(a, stream);
   if (g_semilag_variant == 3 && semilag_wide_eligible(a)) return launch_semilag_wide(a, stream);
   if ((g_semilag_variant == 2 || g_semilag_variant == 4) && a.bmode == 0 && aligned && a.n >= 64 && a.m >= 16 && a.order != 3) {
     if (g_semilag_variant == 2) return launch_variant<2, kModeStaged>(a, stream);
@@ -983,7 +1391,8 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
 // sampling pass of a 4096^2 step: they pay off from ~8 sampling steps on.  Shorter calls - the
 // single-step calls of a generic nowcast loop - take the planar kernel (bit-identical results).
 bool semilag_wants_packed(const SemilagArgs &a) {
-  return (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 6 || g_semilag_variant == 8) &&
+  return (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 6 || g_semilag_variant == 8 ||
+          g_semilag_variant == 9 || g_semilag_variant == 10) &&
          static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29) &&
          static_cast<long long>(a.T) * (a.n_iter > 0 ? a.n_iter : 1) >= 8;
 }

@@ -359,7 +359,7 @@ def test_device_resident_path(extrapolate):
     assert np.array_equal(dev_disp.to_host(), host_disp)  # displacement_prev untouched
 
 
-@pytest.mark.parametrize("variant", [1, 3, 8, 2, 4])
+@pytest.mark.parametrize("variant", [1, 3, 8, 9, 10, 2, 4])
 def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
     """The one-plane-per-component kernel with DPP column sharing (variant 1, the round-1 default),
     the three-pixels-per-lane kernel (variant 3) and the kernel that stages every wave's bounding box
@@ -395,7 +395,7 @@ def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
             assert nan_mismatch(got, want) == 0
             assert np.array_equal(np.isnan(gdisp), np.isnan(wdisp))
             assert np.nanmax(np.abs(gdisp - wdisp)) < 1e-5
-            if variant in (1, 3, 8):
+            if variant in (1, 3, 8, 9, 10):
                 assert np.array_equal(got, want, equal_nan=True) and np.array_equal(gdisp, wdisp, equal_nan=True)
             elif kw.get("interp_order", 1) == 0:
                 assert np.count_nonzero(got != want) <= 1e-4 * got.size
