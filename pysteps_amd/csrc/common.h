@@ -116,9 +116,6 @@ hipError_t launch_pack_field_rows(const float *precip, float *pairs, int m, int 
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
 void set_semilag_variant(int v);
 void set_members_variant(int v);
-// three-pixels-per-lane kernel (semilag_wide.hip): interp_order 0/1, images >= 192 columns
-bool semilag_wide_eligible(const SemilagArgs &a);
-hipError_t launch_semilag_wide(const SemilagArgs &a, hipStream_t stream);
 hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream, int kind = 0,
                             int npad = 0, int pad_edge = 0, float cval = 0.f);
 

@@ -253,12 +253,11 @@ int psh_shutdown(void) {
 int psh_set_option(const char *key, int value) {
   if (!key) return fail(PSH_EINVAL, "psh_set_option: NULL key");
   if (std::strcmp(key, "semilag_variant") == 0) {
-    if (value < 0 || value > 10 || value == 7)
+    if (value != 0 && value != 1 && value != 5 && value != 8 && value != 9 && value != 10 && value != 11)
       return fail(PSH_EINVAL,
                   "semilag_variant must be 0 / 5 (packed planes, dwordx4 gathers with / without the row-pair field "
-                  "plane), 8 (packed {u,v} plane, per-wave LDS staging), 1 (one plane per component, DPP column "
-                  "sharing), 3 (three pixels per lane), 2 or 4 (workgroup LDS staging), 6 (two rows per lane), 9 / 10 (workgroup "
-                  "window kept in LDS across lead steps, 4 / 8 waves per workgroup)");
+                  "plane), 1 (one plane per component, DPP column sharing), 8 (per-wave LDS staging of the packed "
+                  "planes), 9 / 10 (workgroup window kept in LDS across lead steps, 4 / 8 waves per workgroup)");
     psh::set_semilag_variant(value);
     return PSH_OK;
   }

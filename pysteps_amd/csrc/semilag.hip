@@ -45,13 +45,12 @@ namespace {
 using namespace sl;
 
 constexpr int kTileX = 64;
-// kernel flavours: direct gathers (one pixel per lane), LDS-staged tiles, direct gathers with
-// two horizontally adjacent pixels per lane
+// kernel flavours: kModeDirect: one plane per component, DPP column sharing (short calls, no packed plane);
 // kModePacked: {u,v} interleaved velocity plane; kModePacked2: that plus the row-pair field plane
 // kModeWave: packed velocity plane, every WAVE stages the bounding box of its own samples in LDS
-enum : int { kModeDirect = 0, kModeStaged = 1, kModePairX = 2, kModePacked = 3, kModePacked2 = 4, kModeWave = 5 };
+enum : int { kModeDirect = 0, kModePacked = 3, kModePacked2 = 4, kModeWave = 5 };
 constexpr bool is_wave(int mode) { return mode == kModeWave; }
-constexpr int kWavesPerBlock = 4;   // LDS-staged variants: 4 waves (rows) per workgroup
+constexpr int kWavesPerBlock = 4;   // kModeWave: 4 waves per workgroup
 // the direct kernel runs 8 rows per workgroup: the tap row below a wave's pixels is the row the next
 // wave samples, more rows per workgroup = more of that reuse in the CU's L1 (1.55 -> 1.50 ms)
 constexpr int kDirectWaves = 8;
@@ -306,131 +305,12 @@ __device__ __forceinline__ void sample_velocity_border(const Fields &F, int X, i
   sv = blend(w, e, f, g, h);
 }
 
-// ---- LDS-staged path ------------------------------------------------------------
-// The L1 (TCP) is the unit the direct gathers saturate: a dword per
-// lane costs it ~3x more per byte than a 16-byte-per-lane stream.  Here the workgroup
-// (64x16 pixels, 4 rows per thread) first reduces the bounding box of all its sample
-// positions (packed 16-bit min/max through the wave, 4-wave combine in LDS), fetches
-// that box - tile plus the halo the displacement field needs - ONCE per plane with
-// aligned, fully coalesced dwordx4 loads into LDS, and then takes the four taps of
-// every pixel from LDS.  Boxes that touch the image border or exceed the LDS budget
-// (strong deformation) fall back to the direct path, block-uniformly.
-constexpr int kStageCap = 1792;  // floats per plane (7 KiB); 3 planes -> 21 KiB per workgroup
-
 struct WaveFetch;
 struct Stage {
   const WaveFetch *fetch;  // kModeWave: per-lane constants of the staged fetch
   unsigned lds;            // kModeWave: LDS byte address of the wave's region (scalar)
   unsigned lds_v, lds_p;   // ... and of its two planes, as opaque lane values (address arithmetic on VALU)
-  float *buf;    // [3][kStageCap]
-  int *red;      // [2][8] packed per-wave bounding boxes, double buffered
-  int x0, y0;    // tile origin: positions are reduced relative to it in 16 bits
-  int parity;
 };
-
-typedef short short2v __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ int pk_min(int a, int b) {
-  const short2v r = __builtin_elementwise_min(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b));
-  return __builtin_bit_cast(int, r);
-}
-__device__ __forceinline__ int pk_max(int a, int b) {
-  const short2v r = __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b));
-  return __builtin_bit_cast(int, r);
-}
-__device__ __forceinline__ int pk(int x, int y) {
-  return (min(max(y, -32768), 32767) << 16) | (min(max(x, -32768), 32767) & 0xffff);
-}
-
-// Wave-wide reduction of an idempotent packed min/max in six DPP steps (pure VALU,
-// no LDS round trips): xor-1 and xor-2 inside each quad, half-mirror and mirror
-// inside each row of 16, then row_bcast15 / row_bcast31 across the four rows.
-// Afterwards lane 63 holds the result for the whole wave.
-template <bool IS_MIN>
-__device__ __forceinline__ int wave_reduce_pk(int v) {
-#define PSH_STEP(CTRL, ROWMASK)                                                            \
-  {                                                                                         \
-    const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false);            \
-    v = IS_MIN ? pk_min(v, o) : pk_max(v, o);                                               \
-  }
-  PSH_STEP(0xB1, 0xf)   // quad_perm:[1,0,3,2]
-  PSH_STEP(0x4E, 0xf)   // quad_perm:[2,3,0,1]
-  PSH_STEP(0x141, 0xf)  // row_half_mirror
-  PSH_STEP(0x140, 0xf)  // row_mirror
-  PSH_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1 and 3
-  PSH_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2 and 3
-#undef PSH_STEP
-  return v;
-}
-
-template <int NPX, int ORDER, bool WITH_P>
-__device__ __forceinline__ bool sample_staged(const Fields &F, Stage &S, const int (&X)[NPX],
-                                              const int (&Y)[NPX], const float (&fx)[NPX],
-                                              const float (&fy)[NPX], int m, int n,
-                                              float (&su)[NPX], float (&sv)[NPX],
-                                              float (&sp)[NPX]) {
-  // ---- bounding box of every sample position of the workgroup -------------------
-  int lo = pk(X[0] - S.x0, Y[0] - S.y0), hi = lo;
-#pragma unroll
-  for (int j = 1; j < NPX; ++j) {
-    const int q = pk(X[j] - S.x0, Y[j] - S.y0);
-    lo = pk_min(lo, q);
-    hi = pk_max(hi, q);
-  }
-  lo = wave_reduce_pk<true>(lo);
-  hi = wave_reduce_pk<false>(hi);
-  int *red = S.red + S.parity * 8;
-  S.parity ^= 1;
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 63) {
-    red[wave] = lo;
-    red[4 + wave] = hi;
-  }
-  __syncthreads();
-  lo = pk_min(pk_min(red[0], red[1]), pk_min(red[2], red[3]));
-  hi = pk_max(pk_max(red[4], red[5]), pk_max(red[6], red[7]));
-  const int lox = static_cast<short>(lo & 0xffff), loy = lo >> 16;
-  const int hix = static_cast<short>(hi & 0xffff), hiy = hi >> 16;
-  const int bx0 = lox + S.x0, by0 = loy + S.y0;
-  const int rx0 = bx0 & ~3;                                  // 16-byte aligned row starts
-  const int W = ((hix + S.x0 + 2 - rx0) + 3) & ~3;           // + right tap, rounded to 4
-  const int H = hiy - loy + 2;                               // + lower tap
-  const bool ok = lox > -32768 && loy > -32768 && hix < 32767 && hiy < 32767 && rx0 >= 0 &&
-                  rx0 + W <= n && by0 >= 0 && by0 + H <= m && W * H <= kStageCap;
-  if (!ok) return false;  // identical in every thread of the workgroup
-  // ---- one coalesced fetch of the box per plane -----------------------------------
-  const int W4 = W >> 2, items = H * W4;
-  float *bu = S.buf, *bv = S.buf + kStageCap, *bp = S.buf + 2 * kStageCap;
-  for (int it = threadIdx.x; it < items; it += kTileX * kWavesPerBlock) {
-    const int row = it / W4, c4 = it - row * W4;
-    const unsigned g = static_cast<unsigned>(__mul24(by0 + row, n) + rx0 + 4 * c4) << 2;
-    const int l = row * W + 4 * c4;
-    *reinterpret_cast<float4 *>(bu + l) =
-        *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(F.u0) + g);
-    *reinterpret_cast<float4 *>(bv + l) =
-        *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(F.v0) + g);
-    if (WITH_P)
-      *reinterpret_cast<float4 *>(bp + l) =
-          *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(F.p0) + g);
-  }
-  __syncthreads();
-  // ---- taps from LDS ---------------------------------------------------------------
-#pragma unroll
-  for (int j = 0; j < NPX; ++j) {
-    const int o = (Y[j] - by0) * W + (X[j] - rx0);
-    const Weights w = make_weights(fx[j], fy[j]);
-    su[j] = blend(w, bu[o], bu[o + 1], bu[o + W], bu[o + W + 1]);
-    sv[j] = blend(w, bv[o], bv[o + 1], bv[o + W], bv[o + W + 1]);
-    if (WITH_P) {
-      if (ORDER == 1) {
-        sp[j] = blend(w, bp[o], bp[o + 1], bp[o + W], bp[o + W + 1]);
-      } else {
-        sp[j] = bp[o + (fy[j] >= 0.5f ? W : 0) + (fx[j] >= 0.5f ? 1 : 0)];
-      }
-    }
-  }
-  return true;
-}
 
 // ---- per-wave LDS staging over the packed planes ------------------------------------------------
 // The direct kernels ask the CU's vector memory pipeline for 16 B per lane and tap row although
@@ -599,17 +479,6 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
                                           const float (&fy)[NPX], int m, int n, float outval,
                                           float (&su)[NPX], float (&sv)[NPX], float (&sp)[NPX]) {
   constexpr bool kWithP = (WHAT & kPrecip) != 0;
-  if (MODE == kModeStaged) {
-    // every thread of the workgroup reaches this call (uniform loop structure)
-    if (sample_staged<NPX, ORDER, kWithP>(F, S, X, Y, fx, fy, m, n, su, sv, sp)) return;
-    // rare (border tiles, extreme deformation): plain clamped gathers, pixel by pixel
-#pragma unroll
-    for (int j = 0; j < NPX; ++j) {
-      if (WHAT & kVel) sample_velocity_border(F, X[j], Y[j], fx[j], fy[j], m, n, su[j], sv[j]);
-      if (kWithP) sp[j] = sample_precip_off_fast<ORDER, GEN>(F.p0, X[j], Y[j], fx[j], fy[j], m, n, outval, F.bmode);
-    }
-    return;
-  }
   bool inside = true, staged = false;
   if (is_wave(MODE)) {
     // the bounding box of the wave's samples answers both questions
@@ -711,21 +580,15 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
   F.minval = minval;
   F.bmode = bmode;
 
-  __shared__ __attribute__((aligned(16))) float
-      stage_buf[MODE == kModeStaged ? 3 * kStageCap : (is_wave(MODE) ? kWavesPerBlock * kWaveLdsFloats : 4)];
-  __shared__ __attribute__((aligned(16))) int stage_red[16];
+  __shared__ __attribute__((aligned(16))) float stage_buf[is_wave(MODE) ? kWavesPerBlock * kWaveLdsFloats : 4];
   Stage S;
-  S.buf = stage_buf + (is_wave(MODE) ? (threadIdx.x >> 6) * kWaveLdsFloats : 0);
-  S.red = stage_red;
-  S.x0 = (tile % tiles_x) * kTileX;
-  S.y0 = row0 + (tile / tiles_x) * (kWaves * NPX);
-  S.parity = 0;
+  float *wave_buf = stage_buf + (is_wave(MODE) ? (threadIdx.x >> 6) * kWaveLdsFloats : 0);
   WaveFetch wave_fetch;
   if (is_wave(MODE)) wave_fetch = make_wave_fetch(n);
   S.fetch = &wave_fetch;
   S.lds = S.lds_v = S.lds_p = 0;
   if (MODE == kModeWave) {
-    S.lds = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)S.buf)));
+    S.lds = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)wave_buf)));
     S.lds_v = S.lds;
     S.lds_p = S.lds + kWaveVelItems * 16u;
     // kept apart from the compiler's constant folding: "base + 4096" does not fit the 8-bit offsets of
@@ -919,9 +782,10 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
 //    instructions instead of 5.
 constexpr int kWinRows = 4;   // image rows per lane
 // WAVES waves per workgroup (a 64 x 4 WAVES tile), window of WW x WH texels (WW a multiple of 4)
-template <int WAVES, int WW, int WH>
+template <int WAVES, int WW, int WH, bool RAW = false>
 struct WinCfg {
   static constexpr int kWaves = WAVES, kW = WW, kH = WH;
+  static constexpr bool kRaw = RAW;  // taps as single ds_read_b64 / ds_read_b32 (2 LDS cycles each; the read2 forms take 8 / 4)
   static constexpr int kTileY = kWinRows * WAVES;
   static constexpr unsigned kPitch8 = WW * 8u;        // bytes per window row of {u,v} pairs
   static constexpr int kItemsUV = WH * (WW / 2);      // 16-byte items of the {u,v} window
@@ -932,6 +796,7 @@ struct WinCfg {
 };
 using Win4 = WinCfg<4, 96, 40>;  // 45 KiB of LDS: three workgroups (12 waves) per CU
 using Win8 = WinCfg<8, 96, 64>;  // 72 KiB: two workgroups (16 waves) per CU, the window lasts about twice as long
+using Win8Raw = WinCfg<8, 96, 64, true>;
 
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) int lds_int;
@@ -971,6 +836,34 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
     // every read is issued before the first blend
     f32x2 t0[kWinRows], t1[kWinRows], b0[kWinRows], b1[kWinRows];
     float pa[kWinRows], pb[kWinRows], pc[kWinRows], pd[kWinRows];
+    if (C::kRaw) {
+      // one ds_read_b64 per {u,v} pair and one ds_read_b32 per field value: the LDS serves those at 2 cycles
+      // per wave-instruction, the two-address forms the compiler would merge them into at 8 and 4
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) {
+        const unsigned a = __umul24(static_cast<unsigned>(dy[j]), C::kPitch8) + static_cast<unsigned>(dx8[j]) + W.uv;
+        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:%c5\n\t"
+                     "ds_read_b64 %3, %4 offset:%c6"
+                     : "=&v"(t0[j]), "=&v"(t1[j]), "=&v"(b0[j]), "=&v"(b1[j])
+                     : "v"(a), "i"(C::kPitch8), "i"(C::kPitch8 + 8));
+        if (kWithP) {
+          const unsigned ap = ((a - W.uv) >> 1) + W.p;
+          asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:%c5\n\t"
+                       "ds_read_b32 %3, %4 offset:%c6"
+                       : "=&v"(pa[j]), "=&v"(pb[j]), "=&v"(pc[j]), "=&v"(pd[j])
+                       : "v"(ap), "i"(C::kPitch8 / 2), "i"(C::kPitch8 / 2 + 4));
+        }
+      }
+      // the reads above are invisible to the compiler's counters: wait for them, and tie every destination to the wait
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) {
+        if (kWithP) {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[j]), "+v"(t1[j]), "+v"(b0[j]), "+v"(b1[j]), "+v"(pa[j]), "+v"(pb[j]), "+v"(pc[j]), "+v"(pd[j]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[j]), "+v"(t1[j]), "+v"(b0[j]), "+v"(b1[j]));
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
       const unsigned a = __umul24(static_cast<unsigned>(dy[j]), C::kPitch8) + static_cast<unsigned>(dx8[j]);
@@ -980,6 +873,7 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
         const lds_f32 *r = (const lds_f32 *)(size_t)(W.p + (a >> 1));
         pa[j] = r[0], pb[j] = r[1], pc[j] = r[C::kW], pd[j] = r[C::kW + 1];
       }
+    }
     }
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
@@ -1003,9 +897,6 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
     Stage S;
     S.fetch = nullptr;
     S.lds = S.lds_v = S.lds_p = 0;
-    S.buf = nullptr;
-    S.red = nullptr;
-    S.x0 = S.y0 = S.parity = 0;
     sample_at<kWinRows, 1, WHAT, kModePacked, GEN>(F, S, X, Y, fx, fy, m, n, outval, su, sv, sp);
   }
 }
@@ -1328,14 +1219,10 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
       PSH_SL_LAUNCH(0, true, false);
     }
   } else if (a.order == 3) {
-    if constexpr (MODE != kModeStaged) {
-      if (a.bmode != 0) {
-        PSH_SL_LAUNCH(3, true, true);
-      } else {
-        PSH_SL_LAUNCH(3, true, false);
-      }
+    if (a.bmode != 0) {
+      PSH_SL_LAUNCH(3, true, true);
     } else {
-      return hipErrorInvalidValue;  // the staged variants are built for order 0/1
+      PSH_SL_LAUNCH(3, true, false);
     }
   } else if (a.bmode != 0) {
     PSH_SL_LAUNCH(1, true, true);
@@ -1348,11 +1235,9 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
 
 }  // namespace
 
-// 0 = one pixel per lane, direct gathers + DPP column sharing (default); 4 / 2 = LDS-staged
-// tiles with 4 / 2 rows per thread (measured equal at 4096^2 x 24, DESIGN.md 3.1: staging cuts
-// the L1 traffic but adds two barriers per sampling pass); 3 = three pixels per lane with
-// dwordx4 gathers (semilag_wide.hip: faster in near-uniform motion, slower once most waves
-// carry a trajectory split).
+// 0 (default): velocity gathered from a packed {u,v} plane and the field from a row-pair plane (dwordx4 gathers);
+// 5: packed velocity only; 1: one plane per component with DPP column sharing (what short calls take anyway);
+// 8: per-wave LDS staging of the packed planes; 9 / 10: workgroup window kept in LDS across lead steps.
 static int g_semilag_variant = [] {
   const char *e = std::getenv("PYSTEPS_HIP_SL_VARIANT");
   return e ? std::atoi(e) : 0;
@@ -1366,17 +1251,8 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
                        (a.precip == nullptr || reinterpret_cast<uintptr_t>(a.precip) % 16 == 0);
   if (g_semilag_variant == 9 && semilag_window_eligible(a)) return launch_window<Win4>(a, stream);
   if (g_semilag_variant == 10 && semilag_window_eligible(a)) return launch_window<Win8>(a, stream);
-  if (g_semilag_variant == 3 && semilag_wide_eligible(a)) return launch_semilag_wide(a, stream);
-  if ((g_semilag_variant == 2 || g_semilag_variant == 4) && a.bmode == 0 && aligned && a.n >= 64 && a.m >= 16 && a.order != 3) {
-    if (g_semilag_variant == 2) return launch_variant<2, kModeStaged>(a, stream);
-    return launch_variant<4, kModeStaged>(a, stream);
-  }
-  // one or two rows per thread measured equal (1.45 ms at 4096^2 x 24): the kernel is not short of
-  // loads in flight
-  if (a.vel_packed != nullptr && a.field_pairs != nullptr && a.order == 1) {
-    if (g_semilag_variant == 6) return launch_variant<2, kModePacked2>(a, stream);  // two rows per lane (experiment)
-    return launch_variant<1, kModePacked2>(a, stream);
-  }
+  if (g_semilag_variant == 11 && semilag_window_eligible(a)) return launch_window<Win8Raw>(a, stream);
+  if (a.vel_packed != nullptr && a.field_pairs != nullptr && a.order == 1) return launch_variant<1, kModePacked2>(a, stream);
   // variant 8: per-wave LDS staging of the packed velocity plane and the plain field plane
   if (a.vel_packed != nullptr && g_semilag_variant == 8 && a.order == 1 && aligned &&
       reinterpret_cast<uintptr_t>(a.vel_packed) % 16 == 0)
@@ -1391,8 +1267,7 @@ hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
 // sampling pass of a 4096^2 step: they pay off from ~8 sampling steps on.  Shorter calls - the
 // single-step calls of a generic nowcast loop - take the planar kernel (bit-identical results).
 bool semilag_wants_packed(const SemilagArgs &a) {
-  return (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 6 || g_semilag_variant == 8 ||
-          g_semilag_variant == 9 || g_semilag_variant == 10) &&
+  return (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 8 || g_semilag_variant >= 9) &&
          static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29) &&
          static_cast<long long>(a.T) * (a.n_iter > 0 ? a.n_iter : 1) >= 8;
 }
@@ -1400,7 +1275,7 @@ bool semilag_wants_packed(const SemilagArgs &a) {
 // velocity only (two dwordx2 for the field), kept for comparison; variant 8 stages the plain field
 // plane through LDS and needs no second copy of it
 bool semilag_wants_field_pairs(const SemilagArgs &a) {
-  return (g_semilag_variant == 0 || g_semilag_variant == 6) && semilag_wants_packed(a) && a.precip != nullptr &&
+  return g_semilag_variant == 0 && semilag_wants_packed(a) && a.precip != nullptr &&
          a.order == 1 && a.T >= 8;
 }
 

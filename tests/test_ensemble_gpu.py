@@ -77,10 +77,10 @@ def test_members_4096_config4_vs_per_member_oracle():
                                          return_displacement=True, displacement_prev=D[j])
             assert nan_mismatch(got[j], want[0]) <= 8
             seen.append(rel_l2(got[j], want[0]))
-            assert seen[-1] < 5e-6  # observed 2e-7 .. 1e-6; north_star's contract is 1e-4
+            assert seen[-1] < 5e-7  # observed 3.4e-8 .. 3.7e-8 (profiles/r05/members_4096_seen.json); the contract is 1e-4
     gd = adv.displacement.to_host()
     dmax = max(float(np.max(np.abs(gd[j] - D[j]))) for j in range(B))
-    assert dmax < 1e-5
+    assert dmax < 1e-5  # observed 2.0e-6
     try:
         import json
         import os

@@ -16,10 +16,27 @@ pytestmark = pytest.mark.gpu
 
 REL_L2_TOL = 1e-4  # the contract (north_star)
 DISP_TOL = 1e-4
-# regression bars at about 5x what MI355X shows (profiles/r05/sl_seen.json: the largest value of every test,
-# written by _seen below through gpurun_out/): a kernel change that costs a digit fails here long before the contract
-REL_L2_SEEN_BAR = 1e-4
-DISP_SEEN_BAR = 1e-4
+# regression bars: 5x what THIS test showed on MI355X in round 5 (tests/golden/sl_seen_r05.json, written from the
+# gpurun_out/sl_seen.jsonl the helpers below append to; summary in profiles/r05/sl_seen.json), never below 5e-7 / 5e-6
+# (values that were exactly equal) and never above the contract: a kernel change that costs a digit fails here long
+# before it reaches 1e-4.  A test that is not in the file yet gets 5x the largest value any test showed.
+_BARS = None
+
+
+def _bar(kind):
+    import json
+    import os
+
+    global _BARS
+    if _BARS is None:
+        with open(os.path.join(os.path.dirname(__file__), "golden", "sl_seen_r05.json")) as fh:
+            _BARS = json.load(fh)["seen"]
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::", 1)[-1]
+    seen = _BARS.get(test, {}).get(kind)
+    if seen is None:
+        seen = max(v[kind] for v in _BARS.values())
+    floor, contract = (5e-7, REL_L2_TOL) if kind == "rel_l2" else (5e-6, DISP_TOL)
+    return min(max(5.0 * seen, floor), contract)
 
 
 def _seen(kind, value):
@@ -39,14 +56,14 @@ def _field_bar(err, note=None, bar=None):
     """rel-L2 of an advected field: the 1e-4 contract and the regression bar."""
     _seen("rel_l2", err)
     assert err < REL_L2_TOL, (err, note)
-    assert err < (REL_L2_SEEN_BAR if bar is None else bar), (err, note)
+    assert err < (_bar("rel_l2") if bar is None else bar), (err, note, "regression bar")
 
 
 def _disp_bar(err, bar=None):
     """largest displacement difference in pixels: contract and regression bar."""
     _seen("disp", err)
     assert err < DISP_TOL, err
-    assert err < (DISP_SEEN_BAR if bar is None else bar), err
+    assert err < (_bar("disp") if bar is None else bar), (err, "regression bar")
 
 
 @pytest.fixture(scope="module")
@@ -359,12 +376,11 @@ def test_device_resident_path(extrapolate):
     assert np.array_equal(dev_disp.to_host(), host_disp)  # displacement_prev untouched
 
 
-@pytest.mark.parametrize("variant", [1, 3, 8, 9, 10, 2, 4])
+@pytest.mark.parametrize("variant", [1, 5, 8, 9, 10])
 def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
-    """The one-plane-per-component kernel with DPP column sharing (variant 1, the round-1 default),
-    the three-pixels-per-lane kernel (variant 3) and the kernel that stages every wave's bounding box
-    in LDS (variant 8) are bit-identical to the default kernel (packed {u,v} plane, dwordx4 gathers);
-    the workgroup-staged kernels (2, 4) agree to rounding."""
+    """Every other kernel of the extrapolator is bit-identical to the default one (packed {u,v} plane and row-pair
+    field plane, dwordx4 gathers): one plane per component with DPP column sharing (1, what short calls take), packed
+    velocity only (5), per-wave LDS staging (8), and the workgroup windows kept in LDS across lead steps (9, 10)."""
     from pysteps_amd import _lib
     from tools import synth
 
@@ -384,8 +400,7 @@ def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
     # long calls (the packed planes): boxes that fit, boxes that do not (shear), a hole in the motion field
     cases.append((pn, v, 12, dict(n_iter=1, allow_nonfinite_values=True)))
     vh = (4.0 * v).astype(np.float32)
-    if variant != 3:  # the three-pixels-per-lane experiment has no rule for trajectories lost in a hole
-        vh[:, 60:66, 100:111] = np.nan
+    vh[:, 60:66, 100:111] = np.nan
     cases.append((pn, vh, 10, dict(n_iter=2, allow_nonfinite_values=True, outval=-15.0)))
     base = [extrapolate(a, b, t, return_displacement=True, **kw) for a, b, t, kw in cases]
     _lib.check(lib.psh_set_option(b"semilag_variant", variant))
@@ -395,12 +410,7 @@ def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
             assert nan_mismatch(got, want) == 0
             assert np.array_equal(np.isnan(gdisp), np.isnan(wdisp))
             assert np.nanmax(np.abs(gdisp - wdisp)) < 1e-5
-            if variant in (1, 3, 8, 9, 10):
-                assert np.array_equal(got, want, equal_nan=True) and np.array_equal(gdisp, wdisp, equal_nan=True)
-            elif kw.get("interp_order", 1) == 0:
-                assert np.count_nonzero(got != want) <= 1e-4 * got.size
-            else:
-                assert rel_l2(got, want) < 1e-6
+            assert np.array_equal(got, want, equal_nan=True) and np.array_equal(gdisp, wdisp, equal_nan=True)
         for name in ("sl_int_T6", "sl_shear_K3", "sl_nan_nan", "sl_resume"):
             c = semilag_golden.case(name)
             out, disp = extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **c["kw"])
