@@ -48,12 +48,13 @@ const char *psh_version(void);
 int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hbm_free,
                     char *name, int name_len);
 
-/* knobs; "semilag_variant": 0 one pixel per lane, velocity gathered from a packed {u,v} plane and the
- * field from a row-pair plane with dwordx4 loads (default), 5 the same without the row-pair plane, 1 one
- * plane per component with DPP column sharing (what calls of fewer than 8 sampling steps take anyway), 8 per-wave
- * LDS staging of the sampling boxes through LDS-DMA, 9 / 10 a window of both planes kept in LDS across lead
- * steps by workgroups of 4 / 8 waves (interp_order 1, n_iter >= 1, >= 96 x 64 images with n % 4 == 0; other
- * calls take the default kernel) - all of them bit-identical with 0;
+/* knobs; "semilag_variant": 0 (default) the workgroup-window kernel - the motion field and the advected field of
+ * a 64 x 32 tile's neighbourhood kept in LDS across lead steps - wherever it applies (interp_order 1 with a field,
+ * n_iter >= 1, images >= 96 x 64 with n % 4 == 0, at least three sampling steps) and the gather kernels elsewhere;
+ * 12 the window kernel for every eligible call; 7 gather kernels only: velocity from a packed {u,v} plane and the field
+ * from a row-pair plane with dwordx4 loads (the default of rounds 2 - 4); 5 the same without the row-pair plane;
+ * 1 one plane per component with DPP column sharing (what calls of fewer than 8 sampling steps take among the gather
+ * kernels) - all of them bit-identical;
  * "idw_variant": 0 two-level pre-pass (64x64 supertile lists, one wave per 16x8 tile, two pixels per lane; default),
  * 1 one pre-pass per 16x16 tile;
  * "members_variant": members per thread of the member-batched step on packed planes: 2 (default: the two

@@ -253,11 +253,11 @@ int psh_shutdown(void) {
 int psh_set_option(const char *key, int value) {
   if (!key) return fail(PSH_EINVAL, "psh_set_option: NULL key");
   if (std::strcmp(key, "semilag_variant") == 0) {
-    if (value != 0 && value != 1 && value != 5 && value != 8 && value != 9 && value != 10 && value != 11)
+    if (value != 0 && value != 1 && value != 5 && value != 7 && value != 12)
       return fail(PSH_EINVAL,
-                  "semilag_variant must be 0 / 5 (packed planes, dwordx4 gathers with / without the row-pair field "
-                  "plane), 1 (one plane per component, DPP column sharing), 8 (per-wave LDS staging of the packed "
-                  "planes), 9 / 10 (workgroup window kept in LDS across lead steps, 4 / 8 waves per workgroup)");
+                  "semilag_variant must be 0 (window kernel where it applies, gather kernels elsewhere), 12 (window kernel "
+                  "for every eligible call), 7 (gather kernels: packed {u,v} plane + row-pair field plane), 5 (packed "
+                  "velocity only) or 1 (one plane per component, DPP column sharing)");
     psh::set_semilag_variant(value);
     return PSH_OK;
   }

@@ -47,10 +47,7 @@ using namespace sl;
 constexpr int kTileX = 64;
 // kernel flavours: kModeDirect: one plane per component, DPP column sharing (short calls, no packed plane);
 // kModePacked: {u,v} interleaved velocity plane; kModePacked2: that plus the row-pair field plane
-// kModeWave: packed velocity plane, every WAVE stages the bounding box of its own samples in LDS
-enum : int { kModeDirect = 0, kModePacked = 3, kModePacked2 = 4, kModeWave = 5 };
-constexpr bool is_wave(int mode) { return mode == kModeWave; }
-constexpr int kWavesPerBlock = 4;   // kModeWave: 4 waves per workgroup
+enum : int { kModeDirect = 0, kModePacked = 3, kModePacked2 = 4 };
 // the direct kernel runs 8 rows per workgroup: the tap row below a wave's pixels is the row the next
 // wave samples, more rows per workgroup = more of that reuse in the CU's L1 (1.55 -> 1.50 ms)
 constexpr int kDirectWaves = 8;
@@ -305,156 +302,6 @@ __device__ __forceinline__ void sample_velocity_border(const Fields &F, int X, i
   sv = blend(w, e, f, g, h);
 }
 
-struct WaveFetch;
-struct Stage {
-  const WaveFetch *fetch;  // kModeWave: per-lane constants of the staged fetch
-  unsigned lds;            // kModeWave: LDS byte address of the wave's region (scalar)
-  unsigned lds_v, lds_p;   // ... and of its two planes, as opaque lane values (address arithmetic on VALU)
-};
-
-// ---- per-wave LDS staging over the packed planes ------------------------------------------------
-// The direct kernels ask the CU's vector memory pipeline for 16 B per lane and tap row although
-// neighbouring lanes and rows want the same bytes again: 80 B per pixel and lead step for 36 B of
-// unique data, and that pipeline (64 B/clk) is the unit the kernel saturates.
-// Here a wave owns 64 x 4 pixels (4 rows per lane).  Per sampling pass it reduces the bounding box
-// of its 256 sample positions (four interleaved v_min/v_max_i32_dpp chains, read back with
-// v_readlane) and fetches the box - the pixels plus the halo the motion's shear needs - with
-// `buffer_load_dwordx4 ... lds`: consecutive lanes carry consecutive 16-byte items, the data goes
-// from the texture path straight into the wave's own LDS region (no VGPRs, no ds_write).  The box
-// has a FIXED pitch of 72 pixels (36 velocity items / 18 field items per row) and at most 7 rows,
-// so which (row, column) a lane fetches in the k-th instruction is a per-lane constant: the
-// instruction's address is that constant + a scalar offset (the box origin), no address
-// arithmetic at all, and the tap rows sit at immediate LDS offsets.  A 72 x 6 box of {u,v} pairs
-// = 4 instructions instead of the 8 dwordx4 gathers of 4 pixels; the field (plain plane, 4
-// pixels per item) 2 instead of 4.  Nothing is shared between waves: no barrier, and the hazard
-// between a pass's LDS reads and the next pass's LDS-DMA writes is a data dependence (the next box is
-// a function of the values read).  A box that does not fit (shear of more than ~6 pixels across
-// the 64 x 4 patch, a lost trajectory parked far away) falls back to the direct gathers, wave by
-// wave and pass by pass; both paths blend the same values in the same order.
-constexpr int kBoxPitch = 72;                           // pixels per box row
-constexpr int kBoxRows = 7;
-constexpr int kWaveVelItems = 256;                      // 16-byte items: kBoxRows * 36 = 252
-constexpr int kWaveFieldItems = 128;                    // kBoxRows * 18 = 126
-constexpr int kWaveLdsFloats = (kWaveVelItems + kWaveFieldItems) * 4;  // 6 KiB per wave
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
-typedef __attribute__((address_space(3))) float lds_f32;
-
-// per-lane constants of the staged fetch: byte offset (relative to the box origin) of the item
-// this lane fetches in the k-th instruction
-struct WaveFetch {
-  unsigned vel[kWaveVelItems / 64];
-  unsigned field[kWaveFieldItems / 64];
-};
-
-__device__ __forceinline__ WaveFetch make_wave_fetch(int n) {
-  WaveFetch w;
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int k = 0; k < kWaveVelItems / 64; ++k) {
-    const int item = lane + 64 * k, row = item / (kBoxPitch / 2), col = item - row * (kBoxPitch / 2);
-    w.vel[k] = static_cast<unsigned>(row * n + 2 * col) << 3;
-  }
-#pragma unroll
-  for (int k = 0; k < kWaveFieldItems / 64; ++k) {
-    const int item = lane + 64 * k, row = item / (kBoxPitch / 4), col = item - row * (kBoxPitch / 4);
-    w.field[k] = static_cast<unsigned>(row * n + 4 * col) << 2;
-  }
-  return w;
-}
-
-// The box is CHOSEN from the four corner samples of the 64 x 4 patch (eight v_readlane + scalar
-// min / max: exact when the motion is affine across the patch) and VERIFIED for every sample by the
-// two differences the LDS address needs anyway, compared against the box while the fetch is in
-// flight.  (A first version reduced the exact bounding box with four interleaved 6-step
-// v_min/v_max_i32_dpp chains per pass: 98 VALU instructions per pixel and lead step instead of 68,
-// 88 % VALU-bound - profiles/r03/i_semilag_wave_pmc.csv.)
-// 0: sampled from LDS; 1: every tap inside the image, but the box does not fit; 2: border wave
-__device__ __forceinline__ int smin(int a, int b) {
-  int r;
-  asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
-  return r;
-}
-__device__ __forceinline__ int smax(int a, int b) {
-  int r;
-  asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
-  return r;
-}
-
-template <int NPX, bool WITH_P>
-__device__ __forceinline__ int sample_wave_staged(const Fields &F, Stage &S, const WaveFetch &wf, const int (&X)[NPX],
-                                                   const int (&Y)[NPX], const float (&fx)[NPX],
-                                                   const float (&fy)[NPX], int m, int n, float (&su)[NPX],
-                                                   float (&sv)[NPX], float (&sp)[NPX]) {
-  const int xa = __builtin_amdgcn_readlane(X[0], 0), xb = __builtin_amdgcn_readlane(X[0], 63);
-  const int xc = __builtin_amdgcn_readlane(X[NPX - 1], 0), xd = __builtin_amdgcn_readlane(X[NPX - 1], 63);
-  const int ya = __builtin_amdgcn_readlane(Y[0], 0), yb = __builtin_amdgcn_readlane(Y[0], 63);
-  const int yc = __builtin_amdgcn_readlane(Y[NPX - 1], 0), yd = __builtin_amdgcn_readlane(Y[NPX - 1], 63);
-  const int rx = smax((smin(smin(xa, xb), smin(xc, xd)) - 1) & ~3, 0);  // one pixel of slack, 16-byte aligned
-  const int by0 = smax(smin(smin(ya, yb), smin(yc, yd)), 0);
-  const int H = smin(smax(smax(ya, yb), smax(yc, yd)) - by0 + 2, kBoxRows);  // lower tap row included
-  // what a sample's offset inside the box may be: all four taps inside the box and inside the image
-  const int dx_max = smin(kBoxPitch - 2, n - 2 - rx), dy_max = smin(H - 2, m - 2 - by0);
-  const int lane = threadIdx.x & 63;
-  const int items_v = H * (kBoxPitch / 2), items_p = H * (kBoxPitch / 4);
-  const int org = by0 * n + rx;
-  const bool fetch = dx_max >= 0 && dy_max >= 0;  // a patch outside the image fetches nothing
-  if (fetch) {
-#pragma unroll
-    for (int k = 0; k < kWaveVelItems / 64; ++k) {
-      if (k * 64 >= items_v) break;
-      if (lane + 64 * k < items_v)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(F.ruv, (lds_void *)(size_t)(S.lds + 1024u * k), 16,
-                                                 static_cast<int>(wf.vel[k]), org << 3, 0, 0);
-    }
-    if (WITH_P) {
-#pragma unroll
-      for (int k = 0; k < kWaveFieldItems / 64; ++k) {
-        if (k * 64 >= items_p) break;
-        if (lane + 64 * k < items_p)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(F.rp, (lds_void *)(size_t)(S.lds + kWaveVelItems * 16u + 1024u * k), 16,
-                                                   static_cast<int>(wf.field[k]), org << 2, 0, 0);
-      }
-    }
-  }
-  int o[NPX];
-  unsigned dx_hi = 0, dy_hi = 0;  // as unsigned numbers: a negative difference is a huge one
-#pragma unroll
-  for (int j = 0; j < NPX; ++j) {
-    const int dx = X[j] - rx, dy = Y[j] - by0;
-    dx_hi = max(dx_hi, static_cast<unsigned>(dx));
-    dy_hi = max(dy_hi, static_cast<unsigned>(dy));
-    o[j] = __mul24(dy, kBoxPitch) + dx;
-  }
-  const bool ok = dx_hi <= static_cast<unsigned>(dx_max) && dy_hi <= static_cast<unsigned>(dy_max);
-  const bool all_ok = fetch && __builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also on the way out: the region is fetched into again
-  if (!all_ok) {
-    bool inside = true;
-#pragma unroll
-    for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(X[j], Y[j], m, n);
-    return inside ? 1 : 2;
-  }
-  // LDS byte addresses: one shift-add per plane on top of the item index; the tap rows are immediates
-  const unsigned vbase = S.lds_v, pbase = S.lds_p;
-#pragma unroll
-  for (int j = 0; j < NPX; ++j) {
-    const lds_f32x2 *lv = (const lds_f32x2 *)(size_t)(vbase + (static_cast<unsigned>(o[j]) << 3));
-    const lds_f32 *lp = (const lds_f32 *)(size_t)(pbase + (static_cast<unsigned>(o[j]) << 2));
-    const f32x2 t0 = lv[0], t1 = lv[1], b0 = lv[kBoxPitch], b1 = lv[kBoxPitch + 1];
-    const Weights w = make_weights(fx[j], fy[j]);
-    f32x2 acc = t0 * w.w00;  // the order of sample_interior_packed
-    acc = __builtin_elementwise_fma(f32x2{w.w01, w.w01}, t1, acc);
-    acc = __builtin_elementwise_fma(f32x2{w.w10, w.w10}, b0, acc);
-    acc = __builtin_elementwise_fma(f32x2{w.w11, w.w11}, b1, acc);
-    su[j] = acc.x;
-    sv[j] = acc.y;
-    if (WITH_P) sp[j] = blend(w, lp[0], lp[1], lp[kBoxPitch], lp[kBoxPitch + 1]);
-  }
-  return 0;
-}
-
 template <int ORDER, bool GEN>
 __device__ __forceinline__ float sample_precip_off_fast(const float *p, int X, int Y, float fx, float fy, int m,
                                                         int n, float outval, int bmode) {
@@ -474,25 +321,17 @@ __device__ __forceinline__ float sample_cubic(const Fields &F, int X, int Y, flo
 enum : int { kVel = 1, kPrecip = 2 };
 
 template <int NPX, int ORDER, int WHAT, int MODE, bool GEN>
-__device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (&X)[NPX],
+__device__ __forceinline__ void sample_at(const Fields &F, const int (&X)[NPX],
                                           const int (&Y)[NPX], const float (&fx)[NPX],
                                           const float (&fy)[NPX], int m, int n, float outval,
                                           float (&su)[NPX], float (&sv)[NPX], float (&sp)[NPX]) {
   constexpr bool kWithP = (WHAT & kPrecip) != 0;
-  bool inside = true, staged = false;
-  if (is_wave(MODE)) {
-    // the bounding box of the wave's samples answers both questions
-    const int st = sample_wave_staged<NPX, kWithP && ORDER == 1>(F, S, *S.fetch, X, Y, fx, fy, m, n, su, sv, sp);
-    staged = st == 0;
-    inside = st != 2;
-  } else {
+  bool inside = true;
 #pragma unroll
-    for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(X[j], Y[j], m, n);
-  }
+  for (int j = 0; j < NPX; ++j) inside = inside && wave_all_interior(X[j], Y[j], m, n);
   // wave-uniform branch: interior waves (almost all of them) skip every clamp
   if (inside) {
-    if (staged) {
-    } else if (MODE == kModePacked || MODE == kModePacked2 || is_wave(MODE)) {
+    if (MODE == kModePacked || MODE == kModePacked2) {
 #pragma unroll
       for (int j = 0; j < NPX; ++j)
         sample_interior_packed<kWithP && ORDER == 1, MODE == kModePacked2>(F, X[j], Y[j], fx[j], fy[j], n, su[j], sv[j],
@@ -530,19 +369,8 @@ __device__ __forceinline__ void sample_at(const Fields &F, Stage &S, const int (
 
 // GEN: the field resampling honours F.bmode (any scipy boundary mode); otherwise the kernel only
 // contains the "constant" rule and none of the folding code
-template <int MODE>
-constexpr int waves_of() {
-  return (MODE == kModeDirect || MODE == kModePacked || MODE == kModePacked2) ? kDirectWaves : kWavesPerBlock;  // kModeWave: 4
-}
-
-// kModeWave: 128 registers at most, so that four workgroups (16 waves) share a CU
-template <int MODE>
-constexpr int min_waves_per_simd() {
-  return is_wave(MODE) ? 4 : 1;
-}
-
 template <int NPX, int ORDER, bool HAS_PRECIP, int MODE, bool GEN>
-__global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>()) void semilag_fused(
+__global__ __launch_bounds__(kTileX *kDirectWaves) void semilag_fused(
     const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vel_packed,
     const float *__restrict__ field_pairs, float *__restrict__ out,
     double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m, int n,
@@ -556,7 +384,7 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
   // active for the cross-lane exchange); only their stores are masked
   const int xt = (tile % tiles_x) * kTileX + (threadIdx.x & (kTileX - 1));
   // row band [row0, row0 + rows) of the image (the whole image unless the output is tiled)
-  constexpr int kWaves = waves_of<MODE>();
+  constexpr int kWaves = kDirectWaves;
   const int yt = row0 + (tile / tiles_x) * (kWaves * NPX) + (threadIdx.x / kTileX) * NPX;
   const int x = min(xt, n - 1);
   const size_t plane = static_cast<size_t>(m) * n;
@@ -569,7 +397,7 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
   F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
   F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(HAS_PRECIP ? precip : vel), 0, plane_bytes,
                                            0x00020000);
-  constexpr bool kPackedVel = MODE == kModePacked || MODE == kModePacked2 || is_wave(MODE);
+  constexpr bool kPackedVel = MODE == kModePacked || MODE == kModePacked2;
   F.ruv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(kPackedVel ? vel_packed : vel), 0, 2 * plane_bytes,
                                             0x00020000);
   F.rpp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(MODE == kModePacked2 ? field_pairs : vel), 0,
@@ -579,22 +407,6 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
   F.cpad = coef_pad;
   F.minval = minval;
   F.bmode = bmode;
-
-  __shared__ __attribute__((aligned(16))) float stage_buf[is_wave(MODE) ? kWavesPerBlock * kWaveLdsFloats : 4];
-  Stage S;
-  float *wave_buf = stage_buf + (is_wave(MODE) ? (threadIdx.x >> 6) * kWaveLdsFloats : 0);
-  WaveFetch wave_fetch;
-  if (is_wave(MODE)) wave_fetch = make_wave_fetch(n);
-  S.fetch = &wave_fetch;
-  S.lds = S.lds_v = S.lds_p = 0;
-  if (MODE == kModeWave) {
-    S.lds = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)wave_buf)));
-    S.lds_v = S.lds;
-    S.lds_p = S.lds + kWaveVelItems * 16u;
-    // kept apart from the compiler's constant folding: "base + 4096" does not fit the 8-bit offsets of
-    // ds_read2 and would be re-added per tap row
-    asm volatile("" : "+v"(S.lds_v), "+v"(S.lds_p));
-  }
 
   // trajectory state per pixel: absolute integer position + fraction, and the increment
   int y[NPX], px[NPX], py[NPX];
@@ -620,7 +432,7 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
       split_displacement(dx, px[j], fx[j]);
       split_displacement(dy, py[j], fy[j]);
     }
-    sample_at<NPX, ORDER, kVel, MODE, GEN>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+    sample_at<NPX, ORDER, kVel, MODE, GEN>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
     const float s0 = scale[0];
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
@@ -667,16 +479,16 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
           retreat(mx[j], gx[j], vix[j]);  // midpoint rule (:213), vix = Vi / 2
           retreat(my[j], gy[j], viy[j]);
         }
-        sample_at<NPX, ORDER, kVel, MODE, GEN>(F, S, mx, my, gx, gy, m, n, outval, su, sv, sp);
+        sample_at<NPX, ORDER, kVel, MODE, GEN>(F, mx, my, gx, gy, m, n, outval, su, sv, sp);
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
           retreat(px[j], fx[j], su[j] * s);
           retreat(py[j], fy[j], sv[j] * s);
         }
         if (HAS_PRECIP && k == n_iter - 1) {
-          sample_at<NPX, ORDER, kVel | kPrecip, MODE, GEN>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+          sample_at<NPX, ORDER, kVel | kPrecip, MODE, GEN>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
         } else {
-          sample_at<NPX, ORDER, kVel, MODE, GEN>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+          sample_at<NPX, ORDER, kVel, MODE, GEN>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
         }
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
@@ -686,7 +498,7 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
       }
     } else {
       if (t > 0 || resume) {
-        sample_at<NPX, ORDER, kVel, MODE, GEN>(F, S, px, py, fx, fy, m, n, outval, su, sv, sp);
+        sample_at<NPX, ORDER, kVel, MODE, GEN>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
           vix[j] = su[j] * s;
@@ -727,10 +539,6 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
       }
     }
     if (HAS_PRECIP) {
-      // kModeWave: the plane of this lead time as a buffer - scalar descriptor + 32-bit lane offset;
-      // four 64-bit lane addresses carried through the loop cost 8 registers this variant does not have
-      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-          out, 0, is_wave(MODE) ? rows * n * static_cast<int>(sizeof(float)) : 0, 0x00020000);
 #pragma unroll
       for (int j = 0; j < NPX; ++j) {
         // Non-finite velocities (allow_nonfinite_values, semilagrangian.py:106-137): a trajectory that
@@ -739,10 +547,7 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
         // the "constant" mode (and the folding modes), with NaN where it interpolates across it.
         sp[j] = lost(fx[j], fy[j]) ? lostval : sp[j];
         // streamed once, never re-read: keep the output out of the L2 ways the input planes live in
-        if (is_wave(MODE)) {
-          if (live[j])
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sp[j]), rout, static_cast<int>(opix[j]), 0, 2 /* nt */);
-        } else if (live[j]) {
+        if (live[j]) {
           __builtin_nontemporal_store(sp[j], reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
         }
       }
@@ -762,256 +567,306 @@ __global__ __launch_bounds__(kTileX *waves_of<MODE>(), min_waves_per_simd<MODE>(
   }
 }
 
-// ---- workgroup window (variant 9) ----------------------------------------------------------------
+// ---- workgroup window ------------------------------------------------------------------------------
 // The gather kernels above are bound by the CU's vector-memory pipeline: five wave64 dwordx4 gathers per
 // pixel and lead step return 80 B per lane through a 64 B/clk path, whatever the caches
-// hold.  Here a workgroup of four waves owns a 64 x 16 tile (four rows per lane) and keeps a WINDOW of the
-// {u,v} plane and of the field plane - 96 x 40 texels around the tile's current sample positions - in LDS
-// ACROSS lead steps: a sampling pass is LDS reads (4 x 8 B + 4 x 4 B per sample, conflict-free for
-// neighbouring pixels) and arithmetic, nothing else.  The trajectory is carried relative to the window
+// hold.  The window kernel below takes that pipeline out of the inner loop.  A workgroup of eight waves
+// owns a 64 x 32 tile (four rows per lane) and keeps a WINDOW of the motion field and of the advected
+// field - 96 x 64 texels around the tile's current sample positions - in LDS ACROSS lead steps: a sampling
+// pass is LDS reads and arithmetic, nothing else.  The trajectory is carried relative to the window
 // (pre-scaled column offset, row offset), so the two unsigned compares that prove "all four taps inside
 // the window" replace the image-interior test and the LDS address is one multiply-add.
 //  * A wave whose samples are not all inside the window (border of the image, extreme deformation, a
-//    lost trajectory) takes that pass through the gathers of the packed kernel - wave by wave, pass by
-//    pass, same values, same blend order: results are bit-identical to every other variant.
+//    lost trajectory) takes that pass through the gathers of the one-plane-per-component path - wave by
+//    wave, pass by pass, same values, same blend order: results are bit-identical to every other kernel.
 //  * Once per lead step the waves agree (one s_barrier) on whether the window has to move: a wave asks
 //    for it when the corner samples of its patch come closer to the window's edge than the distance the
 //    next step covers.  The new window is placed with its slack AHEAD of the motion (it then lasts
 //    slack / speed lead steps: ~5 at 6 px per step), filled by coalesced dwordx4 loads + ds_write_b128,
-//    and the lanes re-base their offsets.  Window traffic per pixel and lead step: ~0.6 vector-memory
-//    instructions instead of 5.
+//    and the lanes re-base their offsets.
+// What round 5 measured on the way (profiles/r05/): an interleaved {u,v} window with the arithmetic of the
+// gather kernel (variants 9 - 11: 73 VALU instructions per pixel and lead step, SIMDs 70 % busy) ran at the
+// gather kernel's speed; the planar window with pair-packed arithmetic below is the one that is kept.
 constexpr int kWinRows = 4;   // image rows per lane
-// WAVES waves per workgroup (a 64 x 4 WAVES tile), window of WW x WH texels (WW a multiple of 4)
-template <int WAVES, int WW, int WH, bool RAW = false>
-struct WinCfg {
-  static constexpr int kWaves = WAVES, kW = WW, kH = WH;
-  static constexpr bool kRaw = RAW;  // taps as single ds_read_b64 / ds_read_b32 (2 LDS cycles each; the read2 forms take 8 / 4)
-  static constexpr int kTileY = kWinRows * WAVES;
-  static constexpr unsigned kPitch8 = WW * 8u;        // bytes per window row of {u,v} pairs
-  static constexpr int kItemsUV = WH * (WW / 2);      // 16-byte items of the {u,v} window
-  static constexpr int kItemsP = WH * (WW / 4);       // ... of the field window
-  static constexpr int kThreads = kTileX * WAVES;
-  static constexpr unsigned kCtlVel = 16u * WAVES, kCtlFlag = kCtlVel + 8u;  // byte offsets in the control block
-  static constexpr int kCtlWords = 4 * WAVES + 2 + 3 + 3;
-};
-using Win4 = WinCfg<4, 96, 40>;  // 45 KiB of LDS: three workgroups (12 waves) per CU
-using Win8 = WinCfg<8, 96, 64>;  // 72 KiB: two workgroups (16 waves) per CU, the window lasts about twice as long
-using Win8Raw = WinCfg<8, 96, 64, true>;
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) int lds_int;
-
-struct Window {
-  unsigned uv, p;  // LDS byte addresses of the two planes
-  unsigned ctl;    // ... of the control words: box[waves][4], vel[2], flag[3]
-  int ox, oy;      // image position of the window's first texel (uniform over the workgroup)
-  unsigned long long *stats;  // debug counters (nullptr): [0] passes through the window, [1] through the gathers, [2] fills
-};
 
 // LDS traffic only: the nontemporal output stores of the lead step stay in flight across the barrier
 __device__ __forceinline__ void win_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __forceinline__ void win_count(const Window &W, int which) {
+__device__ __forceinline__ int smin(int a, int b) {
+  int r;
+  asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+  return r;
+}
+__device__ __forceinline__ int smax(int a, int b) {
+  int r;
+  asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+  return r;
+}
+
+// debug counters of the window kernel (PYSTEPS_HIP_SL_STATS=1): printed after every launch, which then waits
+static unsigned long long *g_win_stats = nullptr;
+
+// ---- planar window, two pixels per packed instruction ---------------------------------------------
+// The window holds u, v and the field as three planes of
+// identical geometry (one LDS address per tap for all of them) and every floating-point operation of the
+// trajectory update, the weights and the three blends runs as ONE v_pk_*_f32 on the two vertically adjacent
+// pixels of a lane: same operations, same order, same rounding per pixel (no contraction in this file) -
+// bit-identical - at about half the instructions.  The once-per-lead-step agreement is reduced to eight
+// v_readlane and scalar compares; boxes are exchanged only when a wave asked for a new window.
+template <int WAVES, int WW, int WH, bool PIPE = false>
+struct Win2Cfg {
+  static constexpr int kWaves = WAVES, kW = WW, kH = WH;
+  static constexpr bool kPipe = PIPE;  // blend the first pixel pair while the reads of the second are in flight
+  static constexpr int kTileY = kWinRows * WAVES;
+  static constexpr unsigned kPitch4 = WW * 4u;          // bytes per window row of one plane
+  static constexpr unsigned kPlaneBytes = WW * WH * 4u;
+  static constexpr int kItems = WH * (WW / 4);          // 16-byte items per plane
+  static constexpr int kThreads = kTileX * WAVES;
+  static constexpr unsigned kCtlVel = 16u * WAVES, kCtlFlag = kCtlVel + 8u;  // byte offsets in the control block
+  static constexpr int kCtlWords = 4 * WAVES + 2 + 3 + 3;
+};
+using Win2x8 = Win2Cfg<8, 96, 64>;
+using Win2x8Pipe = Win2Cfg<8, 96, 64, true>;
+
+struct Window2 {
+  unsigned u, v, p;  // LDS byte addresses of the three planes
+  unsigned ctl;
+  int ox, oy;        // image position of the window's first texel (uniform over the workgroup)
+  // where the corner samples of a patch may be without asking for a new window (pre-scaled columns / rows):
+  // set when a window is placed, from the direction and speed of travel
+  int lo_x4, hi_x4, lo_y, hi_y;
+  unsigned long long *stats;
+};
+
+__device__ __forceinline__ void win2_count(const Window2 &W, int which) {
   if (W.stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(W.stats + which, 1ull);
 }
 
+// two trajectories of a lane (pixels 2q and 2q+1) along one axis: P -= floor stuff exactly as retreat()
+template <int SHIFT>
+__device__ __forceinline__ void retreat2(int &P0, int &P1, f32x2 &f, f32x2 w) {
+  const f32x2 t = f - w;
+  int k0, k1;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k0) : "v"(t.x));
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k1) : "v"(t.y));
+  P0 += k0 << SHIFT;
+  P1 += k1 << SHIFT;
+  f = f32x2{__builtin_amdgcn_fractf(t.x), __builtin_amdgcn_fractf(t.y)};
+}
+
+constexpr int kWinPairs = kWinRows / 2;
+
 template <class C, int WHAT, bool GEN>
-__device__ __forceinline__ void win_sample(const Fields &F, const Window &W, const int (&dx8)[kWinRows],
-                                           const int (&dy)[kWinRows], const float (&fx)[kWinRows],
-                                           const float (&fy)[kWinRows], int m, int n, float outval,
-                                           float (&su)[kWinRows], float (&sv)[kWinRows], float (&sp)[kWinRows]) {
+__device__ __forceinline__ void win2_sample(const Fields &F, const Window2 &W, const int (&dx4)[kWinRows],
+                                            const int (&dy)[kWinRows], const f32x2 (&fx)[kWinPairs],
+                                            const f32x2 (&fy)[kWinPairs], int m, int n, float outval,
+                                            f32x2 (&su)[kWinPairs], f32x2 (&sv)[kWinPairs], f32x2 (&sp)[kWinPairs]) {
   constexpr bool kWithP = (WHAT & kPrecip) != 0;
-  // all four taps of all four samples inside the window: one unsigned maximum per axis (a negative offset is a huge one)
-  unsigned mx = static_cast<unsigned>(dx8[0]), my = static_cast<unsigned>(dy[0]);
+  unsigned mx = static_cast<unsigned>(dx4[0]), my = static_cast<unsigned>(dy[0]);
 #pragma unroll
   for (int j = 1; j < kWinRows; ++j) {
-    mx = max(mx, static_cast<unsigned>(dx8[j]));
+    mx = max(mx, static_cast<unsigned>(dx4[j]));
     my = max(my, static_cast<unsigned>(dy[j]));
   }
-  const bool ok = mx <= (C::kW - 2) * 8u && my <= static_cast<unsigned>(C::kH - 2);
+  const bool ok = mx <= (C::kW - 2) * 4u && my <= static_cast<unsigned>(C::kH - 2);
   if (__builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true)) {
-    win_count(W, 0);
-    // every read is issued before the first blend
-    f32x2 t0[kWinRows], t1[kWinRows], b0[kWinRows], b1[kWinRows];
-    float pa[kWinRows], pb[kWinRows], pc[kWinRows], pd[kWinRows];
-    if (C::kRaw) {
-      // one ds_read_b64 per {u,v} pair and one ds_read_b32 per field value: the LDS serves those at 2 cycles
-      // per wave-instruction, the two-address forms the compiler would merge them into at 8 and 4
+    win2_count(W, 0);
+    // Taps by single-address ds_read_b32 (2 LDS cycles per wave-instruction; the compiler would merge the taps of
+    // one pixel into ds_read2_b32 and then move every value into the pixel-pair registers the packed blends want).
+    // The reads are invisible to the compiler's counters: one s_waitcnt, with every destination tied to it.
+    float ru[kWinRows][4], rv[kWinRows][4], rp[kWinRows][4];
 #pragma unroll
-      for (int j = 0; j < kWinRows; ++j) {
-        const unsigned a = __umul24(static_cast<unsigned>(dy[j]), C::kPitch8) + static_cast<unsigned>(dx8[j]) + W.uv;
-        asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:%c5\n\t"
-                     "ds_read_b64 %3, %4 offset:%c6"
-                     : "=&v"(t0[j]), "=&v"(t1[j]), "=&v"(b0[j]), "=&v"(b1[j])
-                     : "v"(a), "i"(C::kPitch8), "i"(C::kPitch8 + 8));
-        if (kWithP) {
-          const unsigned ap = ((a - W.uv) >> 1) + W.p;
-          asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:%c5\n\t"
-                       "ds_read_b32 %3, %4 offset:%c6"
-                       : "=&v"(pa[j]), "=&v"(pb[j]), "=&v"(pc[j]), "=&v"(pd[j])
-                       : "v"(ap), "i"(C::kPitch8 / 2), "i"(C::kPitch8 / 2 + 4));
-        }
-      }
-      // the reads above are invisible to the compiler's counters: wait for them, and tie every destination to the wait
-#pragma unroll
-      for (int j = 0; j < kWinRows; ++j) {
-        if (kWithP) {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[j]), "+v"(t1[j]), "+v"(b0[j]), "+v"(b1[j]), "+v"(pa[j]), "+v"(pb[j]), "+v"(pc[j]), "+v"(pd[j]));
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0[j]), "+v"(t1[j]), "+v"(b0[j]), "+v"(b1[j]));
-        }
+    for (int j = 0; j < kWinRows; ++j) {
+      const unsigned a = __umul24(static_cast<unsigned>(dy[j]), C::kPitch4) + static_cast<unsigned>(dx4[j]) + W.u;
+#define PSH_TAPS(DST, BASE)                                                                                          \
+  asm volatile("ds_read_b32 %0, %4 offset:%c5\n\tds_read_b32 %1, %4 offset:%c6\n\tds_read_b32 %2, %4 offset:%c7\n\t" \
+               "ds_read_b32 %3, %4 offset:%c8"                                                                       \
+               : "=&v"(DST[j][0]), "=&v"(DST[j][1]), "=&v"(DST[j][2]), "=&v"(DST[j][3])                              \
+               : "v"(a), "i"(BASE), "i"(BASE + 4u), "i"(BASE + C::kPitch4), "i"(BASE + C::kPitch4 + 4u))
+      PSH_TAPS(ru, 0u);
+      PSH_TAPS(rv, C::kPlaneBytes);
+      if (kWithP) PSH_TAPS(rp, 2u * C::kPlaneBytes);
+#undef PSH_TAPS
+    }
+#define PSH_TIE4(A, J) "+v"(A[J][0]), "+v"(A[J][1]), "+v"(A[J][2]), "+v"(A[J][3])
+    if (C::kPipe) {
+      // the LDS returns in order: once at most 15 reads are outstanding (the counter's range) the first pixel pair's
+      // 16 / 24 values are there; its blends run while the second pair's reads complete
+      if (kWithP) {
+        asm volatile("s_waitcnt lgkmcnt(15)" : PSH_TIE4(ru, 0), PSH_TIE4(ru, 1), PSH_TIE4(rv, 0), PSH_TIE4(rv, 1), PSH_TIE4(rp, 0), PSH_TIE4(rp, 1));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(15)" : PSH_TIE4(ru, 0), PSH_TIE4(ru, 1), PSH_TIE4(rv, 0), PSH_TIE4(rv, 1));
       }
     } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(ru, 0), PSH_TIE4(ru, 1), PSH_TIE4(ru, 2), PSH_TIE4(ru, 3), PSH_TIE4(rv, 0), PSH_TIE4(rv, 1));
+    asm volatile("" : PSH_TIE4(rv, 2), PSH_TIE4(rv, 3));
+    if (kWithP) asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1), PSH_TIE4(rp, 2), PSH_TIE4(rp, 3));
+    }
 #pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
-      const unsigned a = __umul24(static_cast<unsigned>(dy[j]), C::kPitch8) + static_cast<unsigned>(dx8[j]);
-      const lds_f32x2 *q = (const lds_f32x2 *)(size_t)(W.uv + a);
-      t0[j] = q[0], t1[j] = q[1], b0[j] = q[C::kW], b1[j] = q[C::kW + 1];
+    for (int q = 0; q < kWinPairs; ++q) {
+      if (C::kPipe && q == 1) {
+        if (kWithP) {
+          // (tied to the first pair's results as well: the wait stays behind their blends)
+          asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(ru, 2), PSH_TIE4(ru, 3), PSH_TIE4(rv, 2), PSH_TIE4(rv, 3), PSH_TIE4(rp, 2), PSH_TIE4(rp, 3), "+v"(su[0]), "+v"(sv[0]), "+v"(sp[0]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(ru, 2), PSH_TIE4(ru, 3), PSH_TIE4(rv, 2), PSH_TIE4(rv, 3), "+v"(su[0]), "+v"(sv[0]));
+        }
+      }
+      f32x2 tu[4], tv[4], tp[4];  // [tap 00, 01, 10, 11], .x = pixel 2q, .y = pixel 2q+1
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        tu[k] = f32x2{ru[2 * q][k], ru[2 * q + 1][k]};
+        tv[k] = f32x2{rv[2 * q][k], rv[2 * q + 1][k]};
+        if (kWithP) tp[k] = f32x2{rp[2 * q][k], rp[2 * q + 1][k]};
+      }
+      // make_weights() and blend() on two pixels at once
+      const f32x2 gx = 1.f - fx[q], gy = 1.f - fy[q];
+      const f32x2 w00 = gy * gx, w01 = gy * fx[q], w10 = fy[q] * gx, w11 = fy[q] * fx[q];
+      f32x2 au = w00 * tu[0];
+      au = __builtin_elementwise_fma(w01, tu[1], au);
+      au = __builtin_elementwise_fma(w10, tu[2], au);
+      su[q] = __builtin_elementwise_fma(w11, tu[3], au);
+      f32x2 av = w00 * tv[0];
+      av = __builtin_elementwise_fma(w01, tv[1], av);
+      av = __builtin_elementwise_fma(w10, tv[2], av);
+      sv[q] = __builtin_elementwise_fma(w11, tv[3], av);
       if (kWithP) {
-        const lds_f32 *r = (const lds_f32 *)(size_t)(W.p + (a >> 1));
-        pa[j] = r[0], pb[j] = r[1], pc[j] = r[C::kW], pd[j] = r[C::kW + 1];
+        f32x2 ap = w00 * tp[0];
+        ap = __builtin_elementwise_fma(w01, tp[1], ap);
+        ap = __builtin_elementwise_fma(w10, tp[2], ap);
+        sp[q] = __builtin_elementwise_fma(w11, tp[3], ap);
       }
     }
-    }
-#pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
-      const Weights w = make_weights(fx[j], fy[j]);
-      f32x2 acc = t0[j] * w.w00;  // the order of sample_interior_packed
-      acc = __builtin_elementwise_fma(f32x2{w.w01, w.w01}, t1[j], acc);
-      acc = __builtin_elementwise_fma(f32x2{w.w10, w.w10}, b0[j], acc);
-      acc = __builtin_elementwise_fma(f32x2{w.w11, w.w11}, b1[j], acc);
-      su[j] = acc.x;
-      sv[j] = acc.y;
-      if (kWithP) sp[j] = blend(w, pa[j], pb[j], pc[j], pd[j]);
-    }
+#undef PSH_TIE4
   } else {
-    win_count(W, 1);
+    win2_count(W, 1);
     int X[kWinRows], Y[kWinRows];
+    float sfx[kWinRows], sfy[kWinRows], ssu[kWinRows], ssv[kWinRows], ssp[kWinRows];
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
-      X[j] = W.ox + (dx8[j] >> 3);
+      X[j] = W.ox + (dx4[j] >> 2);
       Y[j] = W.oy + dy[j];
+      sfx[j] = (j & 1) ? fx[j / 2].y : fx[j / 2].x;
+      sfy[j] = (j & 1) ? fy[j / 2].y : fy[j / 2].x;
+      ssp[j] = 0.f;
     }
-    Stage S;
-    S.fetch = nullptr;
-    S.lds = S.lds_v = S.lds_p = 0;
-    sample_at<kWinRows, 1, WHAT, kModePacked, GEN>(F, S, X, Y, fx, fy, m, n, outval, su, sv, sp);
+    sample_at<kWinRows, 1, WHAT, kModeDirect, GEN>(F, X, Y, sfx, sfy, m, n, outval, ssu, ssv, ssp);
+#pragma unroll
+    for (int q = 0; q < kWinPairs; ++q) {
+      su[q] = f32x2{ssu[2 * q], ssu[2 * q + 1]};
+      sv[q] = f32x2{ssv[2 * q], ssv[2 * q + 1]};
+      if (kWithP) sp[q] = f32x2{ssp[2 * q], ssp[2 * q + 1]};
+    }
   }
 }
 
-// Once per lead step, every wave of the workgroup: publish the box of the patch's corner samples, ask for
-// a new window if they are about to leave this one, agree at a barrier, and if anybody asked: place the
-// window ahead of the motion, re-base the offsets, fill it.  `phase` cycles through three flag words so
-// that clearing the next one never races with a wave that still has to read it.
 template <class C>
-__device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase, bool force, int (&dx8)[kWinRows],
-                                           int (&dy)[kWinRows], float vx_lane, float vy_lane, float move_scale, int m,
-                                           int n) {
+__device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int phase, bool force, int (&dx4)[kWinRows],
+                                            int (&dy)[kWinRows], float vx_lane, float vy_lane, float move_scale, int m,
+                                            int n) {
   const int lane = threadIdx.x & 63, wave = rfl(static_cast<int>(threadIdx.x >> 6));
   lds_int *ctl = (lds_int *)(size_t)W.ctl;
-  const int xa = __builtin_amdgcn_readlane(dx8[0], 0), xb = __builtin_amdgcn_readlane(dx8[0], 63);
-  const int xc = __builtin_amdgcn_readlane(dx8[kWinRows - 1], 0), xd = __builtin_amdgcn_readlane(dx8[kWinRows - 1], 63);
+  const int xa = __builtin_amdgcn_readlane(dx4[0], 0), xb = __builtin_amdgcn_readlane(dx4[0], 63);
+  const int xc = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 0), xd = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 63);
   const int ya = __builtin_amdgcn_readlane(dy[0], 0), yb = __builtin_amdgcn_readlane(dy[0], 63);
   const int yc = __builtin_amdgcn_readlane(dy[kWinRows - 1], 0), yd = __builtin_amdgcn_readlane(dy[kWinRows - 1], 63);
-  const int lo8 = smin(smin(xa, xb), smin(xc, xd)), hi8 = smax(smax(xa, xb), smax(xc, xd));
+  const int lo4 = smin(smin(xa, xb), smin(xc, xd)), hi4 = smax(smax(xa, xb), smax(xc, xd));
   const int loy = smin(smin(ya, yb), smin(yc, yd)), hiy = smax(smax(ya, yb), smax(yc, yd));
-  // the wave's direction of travel and the distance one lead step covers (half increment of the first pixel;
-  // a lost trajectory - NaN - asks for nothing)
-  const float vx = __builtin_amdgcn_readfirstlane(vx_lane), vy = __builtin_amdgcn_readfirstlane(vy_lane);
-  const float mx = fabsf(vx) < 64.f ? fabsf(vx) * move_scale + 2.f : 2.f, my = fabsf(vy) < 64.f ? fabsf(vy) * move_scale + 2.f : 2.f;
-  const int gx = rfl(static_cast<int>(mx)), gy = rfl(static_cast<int>(my));
-  // a positive velocity moves the samples towards lower coordinates (retreat)
-  const int need_lx = vx > 0.f ? gx : 1, need_hx = vx > 0.f ? 1 : gx;
-  const int need_ly = vy > 0.f ? gy : 1, need_hy = vy > 0.f ? 1 : gy;
-  const bool near = force || lo8 < need_lx * 8 || hi8 > (C::kW - 2 - need_hx) * 8 || loy < need_ly || hiy > C::kH - 2 - need_hy;
+  const bool near = force || lo4 < W.lo_x4 || hi4 > W.hi_x4 || loy < W.lo_y || hiy > W.hi_y;
   if (lane == 0) {
     if (near) ctl[C::kCtlFlag / 4 + phase] = 1;
-    ctl[wave * 4 + 0] = lo8;
-    ctl[wave * 4 + 1] = hi8;
-    ctl[wave * 4 + 2] = loy;
-    ctl[wave * 4 + 3] = hiy;
-    if (wave == 0) {
-      ctl[C::kCtlVel / 4 + 0] = __float_as_int(vx);
-      ctl[C::kCtlVel / 4 + 1] = __float_as_int(vy);
-      ctl[C::kCtlFlag / 4 + (phase == 2 ? 0 : phase + 1)] = 0;
-    }
+    if (wave == 0) ctl[C::kCtlFlag / 4 + (phase == 2 ? 0 : phase + 1)] = 0;
   }
   win_barrier();
   if (rfl(ctl[C::kCtlFlag / 4 + phase]) == 0) return;
-  int ulo8 = 0x7fffffff, uhi8 = -0x7fffffff, uloy = 0x7fffffff, uhiy = -0x7fffffff;
+  // somebody asked: everybody publishes the box of its corner samples, wave 0 its direction of travel
+  if (lane == 0) {
+    ctl[wave * 4 + 0] = lo4;
+    ctl[wave * 4 + 1] = hi4;
+    ctl[wave * 4 + 2] = loy;
+    ctl[wave * 4 + 3] = hiy;
+    if (wave == 0) {
+      ctl[C::kCtlVel / 4 + 0] = __float_as_int(vx_lane);
+      ctl[C::kCtlVel / 4 + 1] = __float_as_int(vy_lane);
+    }
+  }
+  win_barrier();
+  int ulo4 = 0x7fffffff, uhi4 = -0x7fffffff, uloy = 0x7fffffff, uhiy = -0x7fffffff;
 #pragma unroll
   for (int w = 0; w < C::kWaves; ++w) {
-    ulo8 = min(ulo8, ctl[w * 4 + 0]);
-    uhi8 = max(uhi8, ctl[w * 4 + 1]);
+    ulo4 = min(ulo4, ctl[w * 4 + 0]);
+    uhi4 = max(uhi4, ctl[w * 4 + 1]);
     uloy = min(uloy, ctl[w * 4 + 2]);
     uhiy = max(uhiy, ctl[w * 4 + 3]);
   }
   const float wvx = __int_as_float(ctl[C::kCtlVel / 4 + 0]), wvy = __int_as_float(ctl[C::kCtlVel / 4 + 1]);
   // first and last texel the tile touches now (right / lower tap included), relative to the current origin
-  const int bx0 = ulo8 >> 3, bx1 = (uhi8 >> 3) + 1, by0 = uloy, by1 = uhiy + 1;
+  const int bx0 = ulo4 >> 2, bx1 = (uhi4 >> 2) + 1, by0 = uloy, by1 = uhiy + 1;
   const int slack_x = max(C::kW - (bx1 - bx0 + 1), 0), slack_y = max(C::kH - (by1 - by0 + 1), 0);
-  // texels kept on the low side: all the slack but two where the motion goes that way, two where it comes
-  // from, half of it in calm air
+  // texels kept on the low side: all the slack but two where the motion goes that way (a positive velocity moves
+  // the samples towards lower coordinates), two where it comes from, half of it in calm air
   const int keep_x = wvx > 0.125f ? max(slack_x - 2, 0) : (wvx < -0.125f ? min(slack_x, 2) : slack_x / 2);
   const int keep_y = wvy > 0.125f ? max(slack_y - 2, 0) : (wvy < -0.125f ? min(slack_y, 2) : slack_y / 2);
-  const int nox = rfl(min(max((W.ox + bx0 - keep_x) & ~3, 0), n - C::kW));  // 16-byte aligned rows of both planes
+  const int nox = rfl(min(max((W.ox + bx0 - keep_x) & ~3, 0), n - C::kW));  // 16-byte aligned rows
   const int noy = rfl(min(max(W.oy + by0 - keep_y, 0), m - C::kH));
+  // the room a patch needs ahead of its corner samples before the next lead step (the distance one covers, + 25 % + 2);
+  // a lost trajectory (NaN) asks for nothing
+  const float mvx = fabsf(wvx) < 64.f ? fabsf(wvx) * move_scale + 2.f : 2.f, mvy = fabsf(wvy) < 64.f ? fabsf(wvy) * move_scale + 2.f : 2.f;
+  const int gx = rfl(static_cast<int>(mvx)), gy = rfl(static_cast<int>(mvy));
+  W.lo_x4 = (wvx > 0.f ? gx : 1) * 4;
+  W.hi_x4 = (C::kW - 2 - (wvx > 0.f ? 1 : gx)) * 4;
+  W.lo_y = wvy > 0.f ? gy : 1;
+  W.hi_y = C::kH - 2 - (wvy > 0.f ? 1 : gy);
   // (a tile parked at the image border keeps asking: the window it would get is the one it has)
   if (!force && nox == W.ox && noy == W.oy) return;
-  win_count(W, 2);
-  const int ddx8 = (nox - W.ox) * 8, ddy = noy - W.oy;
+  win2_count(W, 2);
+  const int ddx4 = (nox - W.ox) * 4, ddy = noy - W.oy;
 #pragma unroll
   for (int j = 0; j < kWinRows; ++j) {
-    dx8[j] -= ddx8;
+    dx4[j] -= ddx4;
     dy[j] -= ddy;
   }
   W.ox = nox;
   W.oy = noy;
-  // every wave is past the barrier: nobody reads the old window any more
+  // both barriers passed: nobody reads the old window any more
   int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));  // opaque: the item addresses below are not loop invariants worth 40 registers
-  constexpr int kRoundsUV = (C::kItemsUV + C::kThreads - 1) / C::kThreads, kRoundsP = (C::kItemsP + C::kThreads - 1) / C::kThreads;
+  asm volatile("" : "+v"(tid));  // opaque: the item addresses below are not loop invariants worth their registers
+  constexpr int kRounds = (C::kItems + C::kThreads - 1) / C::kThreads;
   // (threads past the last item repeat it: the same bytes to the same place, and no exec-masked rounds)
-  u32x4 buv[kRoundsUV], bp[kRoundsP];
+  u32x4 bu[kRounds], bv[kRounds], bp[kRounds];
   const unsigned org = static_cast<unsigned>(noy) * static_cast<unsigned>(n) + static_cast<unsigned>(nox);
 #pragma unroll
-  for (int k = 0; k < kRoundsUV; ++k) {
-    const int item = min(tid + C::kThreads * k, C::kItemsUV - 1);
-    const int row = item / (C::kW / 2), c = item - row * (C::kW / 2);
-    buv[k] = __builtin_amdgcn_raw_buffer_load_b128(F.ruv, static_cast<int>((org + row * n + 2 * c) << 3), 0, 0);
-  }
-#pragma unroll
-  for (int k = 0; k < kRoundsP; ++k) {
-    const int item = min(tid + C::kThreads * k, C::kItemsP - 1);
+  for (int k = 0; k < kRounds; ++k) {
+    const int item = min(tid + C::kThreads * k, C::kItems - 1);
     const int row = item / (C::kW / 4), c = item - row * (C::kW / 4);
-    bp[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rp, static_cast<int>((org + row * n + 4 * c) << 2), 0, 0);
+    const int off = static_cast<int>((org + row * n + 4 * c) << 2);
+    bu[k] = __builtin_amdgcn_raw_buffer_load_b128(F.ru, off, 0, 0);
+    bv[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rv, off, 0, 0);
+    bp[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rp, off, 0, 0);
   }
 #pragma unroll
-  for (int k = 0; k < kRoundsUV; ++k)
-    *(lds_u32x4 *)(size_t)(W.uv + 16u * min(tid + C::kThreads * k, C::kItemsUV - 1)) = buv[k];
-#pragma unroll
-  for (int k = 0; k < kRoundsP; ++k)
-    *(lds_u32x4 *)(size_t)(W.p + 16u * min(tid + C::kThreads * k, C::kItemsP - 1)) = bp[k];
+  for (int k = 0; k < kRounds; ++k) {
+    const unsigned l = 16u * min(tid + C::kThreads * k, C::kItems - 1);
+    *(lds_u32x4 *)(size_t)(W.u + l) = bu[k];
+    *(lds_u32x4 *)(size_t)(W.v + l) = bv[k];
+    *(lds_u32x4 *)(size_t)(W.p + l) = bp[k];
+  }
   win_barrier();
 }
 
-// retreat() on the pre-scaled column offset (8 bytes per pixel): same t, same floor, same fraction
-__device__ __forceinline__ void retreat8(int &P8, float &f, float w) {
-  const float t = f - w;
-  int k;
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k) : "v"(t));
-  P8 += k * 8;
-  f = __builtin_amdgcn_fractf(t);
-}
-
 template <class C, bool GEN>
-__global__ __launch_bounds__(C::kThreads, C::kWaves == 4 ? 3 : 4) void semilag_window(
-    const float *__restrict__ precip, const float *__restrict__ vel, const float *__restrict__ vel_packed,
-    float *__restrict__ out, double *__restrict__ disp, const float *__restrict__ scale, float first_scale, int m,
-    int n, int T, int n_iter, int resume, float outval, int row0, int rows, int bmode, int tiles_x, int n_tiles,
-    int tiles_per_xcd, unsigned long long *__restrict__ stats) {
+__global__ __launch_bounds__(C::kThreads, 4) void semilag_window2(
+    const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out, double *__restrict__ disp,
+    const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume, float outval,
+    int row0, int rows, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd, float guard,
+    unsigned long long *__restrict__ stats) {
   const int b = blockIdx.x;
   const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
   if (tile >= n_tiles) return;  // the whole workgroup
@@ -1028,115 +883,125 @@ __global__ __launch_bounds__(C::kThreads, C::kWaves == 4 ? 3 : 4) void semilag_w
   F.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel), 0, plane_bytes, 0x00020000);
   F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
   F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(precip), 0, plane_bytes, 0x00020000);
-  F.ruv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel_packed), 0, 2 * plane_bytes, 0x00020000);
-  F.rpp = F.ruv;  // (no row-pair field plane in this kernel)
+  F.ruv = F.ru;  // (no packed planes in this kernel: the fallback is the one-plane-per-component gather path)
+  F.rpp = F.ru;
   F.row_bytes = n * static_cast<int>(sizeof(float));
   F.coef = nullptr;
   F.cpad = 0;
   F.minval = 0.f;
   F.bmode = bmode;
 
-  __shared__ __attribute__((aligned(16))) float win_uv[C::kW * C::kH * 2];
-  __shared__ __attribute__((aligned(16))) float win_p[C::kW * C::kH];
+  __shared__ __attribute__((aligned(16))) float win_planes[3 * C::kW * C::kH];
   __shared__ __attribute__((aligned(16))) int win_ctl[C::kCtlWords];
-  Window W;
-  W.uv = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_uv));
-  W.p = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_p));
+  Window2 W;
+  W.u = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_planes));
+  W.v = W.u + C::kPlaneBytes;
+  W.p = W.v + C::kPlaneBytes;
   W.ctl = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_ctl));
   W.ox = W.oy = 0;
+  W.lo_x4 = W.lo_y = 0;
+  W.hi_x4 = W.hi_y = 0;
   W.stats = stats;
   if (threadIdx.x < 3) win_ctl[C::kCtlFlag / 4 + threadIdx.x] = 0;
 
-  int y[kWinRows], dx8[kWinRows], dy[kWinRows];
-  float fx[kWinRows], fy[kWinRows], vix[kWinRows], viy[kWinRows], su[kWinRows], sv[kWinRows], sp[kWinRows];
+  int y[kWinRows], dx4[kWinRows], dy[kWinRows];
+  f32x2 fx[kWinPairs], fy[kWinPairs], vix[kWinPairs], viy[kWinPairs], su[kWinPairs], sv[kWinPairs], sp[kWinPairs];
   bool live[kWinRows];
   unsigned opix[kWinRows];
+  float ifx[kWinRows], ify[kWinRows], ivx[kWinRows], ivy[kWinRows];
 #pragma unroll
   for (int j = 0; j < kWinRows; ++j) {
     live[j] = xt < n && yt + j < row0 + rows;
     y[j] = min(yt + j, m - 1);
     opix[j] = static_cast<unsigned>(__mul24(y[j] - row0, n) + x) << 2;
     int px = x, py = y[j];
-    fx[j] = fy[j] = sp[j] = 0.f;
+    ifx[j] = ify[j] = 0.f;
     if (resume) {
-      split_displacement(disp[static_cast<size_t>(y[j]) * n + x], px, fx[j]);
-      split_displacement(disp[plane + static_cast<size_t>(y[j]) * n + x], py, fy[j]);
+      split_displacement(disp[static_cast<size_t>(y[j]) * n + x], px, ifx[j]);
+      split_displacement(disp[plane + static_cast<size_t>(y[j]) * n + x], py, ify[j]);
     }
-    dx8[j] = px * 8;  // relative to the origin (0, 0) until the first window is placed
+    dx4[j] = px * 4;  // relative to the origin (0, 0) until the first window is placed
     dy[j] = py;
-    vix[j] = viy[j] = 0.f;
-  }
-  const float move_scale = 2.5f * static_cast<float>(n_iter);  // lead step = n_iter sub-steps of two half increments, + 25 %
-  if (!resume) {
-    // first increment is NOT divided by n_iter (semilagrangian.py:202)
-#pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
+    ivx[j] = ivy[j] = 0.f;
+    if (!resume) {
+      // first increment is NOT divided by n_iter (semilagrangian.py:202)
       const unsigned pix = static_cast<unsigned>(__mul24(y[j], n) + x) << 2;
-      vix[j] = ld(F.u0, pix) * first_scale;
-      viy[j] = ld(F.v0, pix) * first_scale;
+      ivx[j] = ld(F.u0, pix) * first_scale;
+      ivy[j] = ld(F.v0, pix) * first_scale;
     }
   }
+#pragma unroll
+  for (int q = 0; q < kWinPairs; ++q) {
+    fx[q] = f32x2{ifx[2 * q], ifx[2 * q + 1]};
+    fy[q] = f32x2{ify[2 * q], ify[2 * q + 1]};
+    vix[q] = f32x2{ivx[2 * q], ivx[2 * q + 1]};
+    viy[q] = f32x2{ivy[2 * q], ivy[2 * q + 1]};
+    sp[q] = f32x2{0.f, 0.f};
+  }
+  const float move_scale = guard * static_cast<float>(n_iter);  // lead step = n_iter sub-steps of two half increments, + 25 %
   __syncthreads();  // the flag words are cleared
   int phase = 0;
-  win_update<C>(F, W, phase, true, dx8, dy, 0.5f * vix[0], 0.5f * viy[0], move_scale, m, n);
+  win2_update<C>(F, W, phase, true, dx4, dy, 0.5f * vix[0].x, 0.5f * viy[0].x, move_scale, m, n);
   phase = 1;
   if (resume) {
-    win_sample<C, kVel, GEN>(F, W, dx8, dy, fx, fy, m, n, outval, su, sv, sp);
+    win2_sample<C, kVel, GEN>(F, W, dx4, dy, fx, fy, m, n, outval, su, sv, sp);
     const float s0 = scale[0];
 #pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
-      vix[j] = su[j] * s0;
-      viy[j] = sv[j] * s0;
+    for (int q = 0; q < kWinPairs; ++q) {
+      vix[q] = su[q] * s0;
+      viy[q] = sv[q] * s0;
     }
   }
   const float lostval = (bmode == kModeNearest || bmode == kModeGridConstant) ? __builtin_nanf("") : outval;
   // the increment is only ever used halved (midpoint rule): carry Vi / 2 (exact)
 #pragma unroll
-  for (int j = 0; j < kWinRows; ++j) {
-    vix[j] *= 0.5f;
-    viy[j] *= 0.5f;
+  for (int q = 0; q < kWinPairs; ++q) {
+    vix[q] = vix[q] * 0.5f;
+    viy[q] = viy[q] * 0.5f;
   }
 
   for (int t = 0; t < T; ++t) {
     const float s = scale[t];
     const float half_s = 0.5f * s;
     for (int k = 0; k < n_iter; ++k) {
-      int mx8[kWinRows], my[kWinRows];
-      float gx[kWinRows], gy[kWinRows];
+      int mx4[kWinRows], my[kWinRows];
+      f32x2 gx[kWinPairs], gy[kWinPairs];
 #pragma unroll
-      for (int j = 0; j < kWinRows; ++j) {
-        mx8[j] = dx8[j];
-        my[j] = dy[j];
-        gx[j] = fx[j];
-        gy[j] = fy[j];
-        retreat8(mx8[j], gx[j], vix[j]);  // midpoint rule (:213), vix = Vi / 2
-        retreat(my[j], gy[j], viy[j]);
+      for (int q = 0; q < kWinPairs; ++q) {
+        mx4[2 * q] = dx4[2 * q], mx4[2 * q + 1] = dx4[2 * q + 1];
+        my[2 * q] = dy[2 * q], my[2 * q + 1] = dy[2 * q + 1];
+        gx[q] = fx[q];
+        gy[q] = fy[q];
+        retreat2<2>(mx4[2 * q], mx4[2 * q + 1], gx[q], vix[q]);  // midpoint rule (:213), vix = Vi / 2
+        retreat2<0>(my[2 * q], my[2 * q + 1], gy[q], viy[q]);
       }
-      win_sample<C, kVel, GEN>(F, W, mx8, my, gx, gy, m, n, outval, su, sv, sp);
+      win2_sample<C, kVel, GEN>(F, W, mx4, my, gx, gy, m, n, outval, su, sv, sp);
 #pragma unroll
-      for (int j = 0; j < kWinRows; ++j) {
-        retreat8(dx8[j], fx[j], su[j] * s);
-        retreat(dy[j], fy[j], sv[j] * s);
+      for (int q = 0; q < kWinPairs; ++q) {
+        retreat2<2>(dx4[2 * q], dx4[2 * q + 1], fx[q], su[q] * s);
+        retreat2<0>(dy[2 * q], dy[2 * q + 1], fy[q], sv[q] * s);
       }
       if (k == n_iter - 1) {
-        win_sample<C, kVel | kPrecip, GEN>(F, W, dx8, dy, fx, fy, m, n, outval, su, sv, sp);
+        win2_sample<C, kVel | kPrecip, GEN>(F, W, dx4, dy, fx, fy, m, n, outval, su, sv, sp);
       } else {
-        win_sample<C, kVel, GEN>(F, W, dx8, dy, fx, fy, m, n, outval, su, sv, sp);
+        win2_sample<C, kVel, GEN>(F, W, dx4, dy, fx, fy, m, n, outval, su, sv, sp);
       }
 #pragma unroll
-      for (int j = 0; j < kWinRows; ++j) {
-        vix[j] = su[j] * half_s;
-        viy[j] = sv[j] * half_s;
+      for (int q = 0; q < kWinPairs; ++q) {
+        vix[q] = su[q] * half_s;
+        viy[q] = sv[q] * half_s;
       }
     }
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
-      sp[j] = lost(fx[j], fy[j]) ? lostval : sp[j];
-      if (live[j]) __builtin_nontemporal_store(sp[j], reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
+      const float fxs = (j & 1) ? fx[j / 2].y : fx[j / 2].x, fys = (j & 1) ? fy[j / 2].y : fy[j / 2].x;
+      float val = (j & 1) ? sp[j / 2].y : sp[j / 2].x;
+      val = lost(fxs, fys) ? lostval : val;
+      if (live[j]) __builtin_nontemporal_store(val, reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
     }
     out += static_cast<size_t>(rows) * n;
     if (t + 1 < T) {
-      win_update<C>(F, W, phase, false, dx8, dy, vix[0], viy[0], move_scale, m, n);
+      win2_update<C>(F, W, phase, false, dx4, dy, vix[0].x, viy[0].x, move_scale, m, n);
       phase = phase == 2 ? 0 : phase + 1;
     }
   }
@@ -1145,51 +1010,50 @@ __global__ __launch_bounds__(C::kThreads, C::kWaves == 4 ? 3 : 4) void semilag_w
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
       if (!live[j]) continue;
-      disp[static_cast<size_t>(y[j]) * n + x] =
-          static_cast<double>(W.ox + (dx8[j] >> 3) - x) + static_cast<double>(fx[j]);
-      disp[plane + static_cast<size_t>(y[j]) * n + x] =
-          static_cast<double>(W.oy + dy[j] - y[j]) + static_cast<double>(fy[j]);
+      const float fxs = (j & 1) ? fx[j / 2].y : fx[j / 2].x, fys = (j & 1) ? fy[j / 2].y : fy[j / 2].x;
+      disp[static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.ox + (dx4[j] >> 2) - x) + static_cast<double>(fxs);
+      disp[plane + static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.oy + dy[j] - y[j]) + static_cast<double>(fys);
     }
   }
 }
 
-bool semilag_window_eligible(const SemilagArgs &a) {
-  return a.precip != nullptr && a.vel_packed != nullptr && a.order == 1 && a.n_iter >= 1 && a.n % 4 == 0 &&
-         a.n >= Win8::kW && a.m >= Win8::kH && reinterpret_cast<uintptr_t>(a.vel_packed) % 16 == 0 &&
-         reinterpret_cast<uintptr_t>(a.precip) % 16 == 0;
+// the planar window kernel needs no packed copy of anything
+bool semilag_window2_eligible(const SemilagArgs &a) {
+  return a.precip != nullptr && a.order == 1 && a.n_iter >= 1 && a.n % 4 == 0 && a.n >= Win2x8::kW && a.m >= Win2x8::kH &&
+         reinterpret_cast<uintptr_t>(a.vel) % 16 == 0 && reinterpret_cast<uintptr_t>(a.precip) % 16 == 0 &&
+         (static_cast<size_t>(a.m) * a.n) % 4 == 0;
 }
 
-// debug counters of the window kernels (PYSTEPS_HIP_SL_STATS=1): printed after every launch, which then waits
-static unsigned long long *g_win_stats = nullptr;
-
 template <class C>
-static hipError_t launch_window(const SemilagArgs &a, hipStream_t stream) {
+static hipError_t launch_window2(const SemilagArgs &a, hipStream_t stream) {
   const int tiles_x = (a.n + kTileX - 1) / kTileX;
   const int tiles_y = (a.rows + C::kTileY - 1) / C::kTileY;
   const int n_tiles = tiles_x * tiles_y;
   const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
   const dim3 grid(tiles_per_xcd * kNumXcd), block(C::kThreads);
   static const bool want_stats = std::getenv("PYSTEPS_HIP_SL_STATS") != nullptr;
+  // room asked for ahead of the samples, in units of the distance the last lead step covered (development knob)
+  static const float guard = std::getenv("PYSTEPS_HIP_SL_GUARD") ? static_cast<float>(std::atof(std::getenv("PYSTEPS_HIP_SL_GUARD"))) : 2.5f;
   if (want_stats) {
     if (g_win_stats == nullptr && hipMalloc(&g_win_stats, 4 * sizeof(unsigned long long)) != hipSuccess) g_win_stats = nullptr;
     if (g_win_stats != nullptr) (void)hipMemsetAsync(g_win_stats, 0, 4 * sizeof(unsigned long long), stream);
   }
   if (a.bmode != 0) {
-    hipLaunchKernelGGL((semilag_window<C, true>), grid, block, 0, stream, a.precip, a.vel, a.vel_packed, a.out, a.disp,
-                       a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x,
-                       n_tiles, tiles_per_xcd, g_win_stats);
+    hipLaunchKernelGGL((semilag_window2<C, true>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
+                       a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
+                       tiles_per_xcd, guard, g_win_stats);
   } else {
-    hipLaunchKernelGGL((semilag_window<C, false>), grid, block, 0, stream, a.precip, a.vel, a.vel_packed, a.out, a.disp,
-                       a.scale, a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x,
-                       n_tiles, tiles_per_xcd, g_win_stats);
+    hipLaunchKernelGGL((semilag_window2<C, false>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
+                       a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
+                       tiles_per_xcd, guard, g_win_stats);
   }
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess && want_stats && g_win_stats != nullptr) {
     unsigned long long h[4] = {0, 0, 0, 0};
     if (hipMemcpyAsync(h, g_win_stats, sizeof(h), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipStreamSynchronize(stream) == hipSuccess)
-      std::fprintf(stderr, "semilag_window<%d waves>: %dx%d T=%d: wave-passes through the window %llu, through the gathers %llu, "
-                   "window fills %llu (of %d workgroups x %d lead steps)\n", C::kWaves, a.m, a.n, a.T, h[0], h[1], h[2],
+      std::fprintf(stderr, "semilag_window2<%d waves>: %dx%d T=%d: wave-passes through the window %llu, through the gathers %llu, "
+                   "window fills (per wave) %llu (%d workgroups x %d lead steps)\n", C::kWaves, a.m, a.n, a.T, h[0], h[1], h[2],
                    n_tiles, a.T);
   }
   return e;
@@ -1197,7 +1061,7 @@ static hipError_t launch_window(const SemilagArgs &a, hipStream_t stream) {
 
 template <int NPX, int MODE>
 static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
-  constexpr int kWaves = waves_of<MODE>();
+  constexpr int kWaves = kDirectWaves;
   const int tile_y = kWaves * NPX;
   const int tiles_x = (a.n + kTileX - 1) / kTileX;
   const int tiles_y = (a.rows + tile_y - 1) / tile_y;
@@ -1235,9 +1099,12 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
 
 }  // namespace
 
-// 0 (default): velocity gathered from a packed {u,v} plane and the field from a row-pair plane (dwordx4 gathers);
-// 5: packed velocity only; 1: one plane per component with DPP column sharing (what short calls take anyway);
-// 8: per-wave LDS staging of the packed planes; 9 / 10: workgroup window kept in LDS across lead steps.
+// semilag_variant: 0 (default) = the workgroup-window kernel wherever it applies (bilinear resampling of a field,
+// n_iter >= 1, images of at least 96 x 64 pixels with n % 4 == 0, at least kWindowMinPasses sampling steps), the gather
+// kernels elsewhere; 12 = the window kernel for every eligible call, however short; 7 = gather kernels only: velocity
+// from a packed {u,v} plane and the field from a row-pair plane (the default of rounds 2 - 4); 5 = packed velocity
+// only; 1 = one plane per component with DPP column sharing (what calls of fewer than 8 sampling steps take among the
+// gather kernels).  All of them give bit-identical results (tests/test_semilag_gpu.py, tools/sl_bitcheck.py).
 static int g_semilag_variant = [] {
   const char *e = std::getenv("PYSTEPS_HIP_SL_VARIANT");
   return e ? std::atoi(e) : 0;
@@ -1245,37 +1112,37 @@ static int g_semilag_variant = [] {
 
 void set_semilag_variant(int v) { g_semilag_variant = v; }
 
+static const bool g_window_pipe = std::getenv("PYSTEPS_HIP_SL_PIPE") != nullptr;  // development knob
+
+// the first window costs one fill before anything is sampled: calls of one or two sampling steps keep the gathers
+constexpr long long kWindowMinPasses = 3;
+
+bool semilag_uses_window(const SemilagArgs &a) {
+  if (!semilag_window2_eligible(a)) return false;
+  if (g_semilag_variant == 12) return true;
+  return g_semilag_variant == 0 && static_cast<long long>(a.T) * a.n_iter >= kWindowMinPasses;
+}
+
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
-  // LDS staging needs 16-byte aligned rows (n % 4 == 0)
-  const bool aligned = (a.n % 4 == 0) && (reinterpret_cast<uintptr_t>(a.vel) % 16 == 0) &&
-                       (a.precip == nullptr || reinterpret_cast<uintptr_t>(a.precip) % 16 == 0);
-  if (g_semilag_variant == 9 && semilag_window_eligible(a)) return launch_window<Win4>(a, stream);
-  if (g_semilag_variant == 10 && semilag_window_eligible(a)) return launch_window<Win8>(a, stream);
-  if (g_semilag_variant == 11 && semilag_window_eligible(a)) return launch_window<Win8Raw>(a, stream);
+  if (semilag_uses_window(a)) return g_window_pipe ? launch_window2<Win2x8Pipe>(a, stream) : launch_window2<Win2x8>(a, stream);
   if (a.vel_packed != nullptr && a.field_pairs != nullptr && a.order == 1) return launch_variant<1, kModePacked2>(a, stream);
-  // variant 8: per-wave LDS staging of the packed velocity plane and the plain field plane
-  if (a.vel_packed != nullptr && g_semilag_variant == 8 && a.order == 1 && aligned &&
-      reinterpret_cast<uintptr_t>(a.vel_packed) % 16 == 0)
-    return launch_variant<4, kModeWave>(a, stream);
   if (a.vel_packed != nullptr) return launch_variant<1, kModePacked>(a, stream);
   return launch_variant<1, kModeDirect>(a, stream);
 }
 
-// variant 0 (default) samples the velocity from a packed {u,v} plane when the caller provides one;
-// variant 1 = the one-plane-per-component kernel with DPP column sharing (round 1 default)
-// The layout passes cost one sweep over the planes each (0.04 ms at 4096^2) and save ~4 us per
-// sampling pass of a 4096^2 step: they pay off from ~8 sampling steps on.  Shorter calls - the
-// single-step calls of a generic nowcast loop - take the planar kernel (bit-identical results).
+// The gather kernels sample the velocity from a packed {u,v} plane when the call is long enough to pay for the
+// layout pass (one sweep over the planes, 0.04 ms at 4096^2, saves ~4 us per sampling pass of a 4096^2 step: from ~8
+// sampling steps on) - unless the caller hands the packed plane over (psh_semilag_uv_dev).  Shorter calls - the
+// single-step calls of a generic nowcast loop - take the one-plane-per-component kernel.  The window kernel needs
+// no second layout of anything.
 bool semilag_wants_packed(const SemilagArgs &a) {
-  return (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 8 || g_semilag_variant >= 9) &&
+  return !semilag_uses_window(a) && (g_semilag_variant == 0 || g_semilag_variant == 5 || g_semilag_variant == 7) &&
          static_cast<uint64_t>(a.m) * static_cast<uint64_t>(a.n) < (1ull << 29) &&
          static_cast<long long>(a.T) * (a.n_iter > 0 ? a.n_iter : 1) >= 8;
 }
-// variant 0 also samples the field from a row-pair plane (one dwordx4 per sample); 5 = packed
-// velocity only (two dwordx2 for the field), kept for comparison; variant 8 stages the plain field
-// plane through LDS and needs no second copy of it
+// ... and the field from a row-pair plane (one dwordx4 per sample); 5 = packed velocity only (two dwordx2 for the field)
 bool semilag_wants_field_pairs(const SemilagArgs &a) {
-  return g_semilag_variant == 0 && semilag_wants_packed(a) && a.precip != nullptr &&
+  return (g_semilag_variant == 0 || g_semilag_variant == 7) && semilag_wants_packed(a) && a.precip != nullptr &&
          a.order == 1 && a.T >= 8;
 }
 

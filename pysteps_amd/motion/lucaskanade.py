@@ -36,6 +36,9 @@ _N_STATS = 8
 # set to False to run the stage-by-stage Python loop instead of psh_dense_lk_dev (same results;
 # used by the tests to keep both orchestrations honest)
 USE_NATIVE_ORCHESTRATION = True
+# a resident motion field also as (m, n, 2) {u, v} pairs (DeviceArray.uv_pairs): the layout of the extrapolator's gather
+# kernels (semilag_variant 7 / 5); the default window kernel samples the planes
+WRITE_UV_TWIN = False
 # one corner request (launch -> finish) is in flight per process: callers on several threads
 # (the reference is re-entrant and gets called from dask workers) take turns here
 _corner_lock = threading.Lock()
@@ -195,9 +198,10 @@ def _dense_lk_native(frames, on_device, dense, size_opening, buffer_mask, max_co
         field = DeviceArray((2, m, n), np.float32)
         # resident frames in, resident field out: the call only queues kernels (no count asked for,
         # so nothing waits for the device); host callers get the sample count with the field
-        # (a resident field also gets its {u, v}-interleaved twin, written by the interpolation kernel: the
-        # extrapolator gathers from that layout and would otherwise interleave the planes on every call)
-        pairs = DeviceArray((m, n, 2), np.float32) if on_device else None
+        # (WRITE_UV_TWIN: a resident field also gets its {u, v}-interleaved twin, written by the interpolation kernel:
+        # the layout the extrapolator's GATHER kernels sample, which would otherwise interleave the planes on every
+        # call; the window kernel - the default - reads the planes, so the twin's 128 MB of stores are not spent)
+        pairs = DeviceArray((m, n, 2), np.float32) if on_device and WRITE_UV_TWIN else None
         rc = lib.psh_dense_lk_uv_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), field.ptr,
                                      None if pairs is None else pairs.ptr, None, None, 0,
                                      None if on_device else ctypes.byref(count))
@@ -205,7 +209,8 @@ def _dense_lk_native(frames, on_device, dense, size_opening, buffer_mask, max_co
             return None
         _lib.check(rc, "psh_dense_lk_uv_dev")
         if on_device:
-            field.uv_pairs = pairs
+            if pairs is not None:
+                field.uv_pairs = pairs
             return field
         if count.value == 0:
             return np.zeros((2, m, n))

@@ -376,11 +376,11 @@ def test_device_resident_path(extrapolate):
     assert np.array_equal(dev_disp.to_host(), host_disp)  # displacement_prev untouched
 
 
-@pytest.mark.parametrize("variant", [1, 5, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 5, 7, 12])
 def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
-    """Every other kernel of the extrapolator is bit-identical to the default one (packed {u,v} plane and row-pair
-    field plane, dwordx4 gathers): one plane per component with DPP column sharing (1, what short calls take), packed
-    velocity only (5), per-wave LDS staging (8), and the workgroup windows kept in LDS across lead steps (9, 10)."""
+    """Every kernel of the extrapolator gives the bytes the default selection gives (the workgroup-window kernel where
+    it applies): one plane per component with DPP column sharing (1, what short calls take), packed velocity (5),
+    packed velocity + row-pair field plane (7, the default of rounds 2 - 4), the window kernel for every eligible call (12)."""
     from pysteps_amd import _lib
     from tools import synth
 
@@ -630,24 +630,35 @@ def test_input_checks_run_on_the_device_with_the_reference_messages(extrapolate)
 
 
 @pytest.mark.gpu
-def test_interleaved_motion_field_twin_is_the_field_and_gives_the_same_advection():
-    """dense_lucaskanade on resident frames returns the motion field with its {u, v}-interleaved twin (written by
-    the interpolation kernel); the twin holds the same numbers, and extrapolate() gathering from it gives the
-    bytes it gives from the planes."""
+def test_interleaved_motion_field_twin_is_the_field_and_gives_the_same_advection(extrapolate, monkeypatch):
+    """dense_lucaskanade on resident frames can hand the motion field over twice: as (2, m, n) planes and, written by
+    the same interpolation kernel, as (m, n, 2) {u, v} pairs - the layout the GATHER kernels of the extrapolator sample
+    (``lucaskanade.WRITE_UV_TWIN``; the window kernel, the default since round 5, reads the planes and the twin is
+    not written any more).  The twin must hold the same numbers, and advecting with it (gather kernels,
+    ``semilag_variant`` 7) must give the bytes the default kernel gives from the planes."""
+    from pysteps_amd import _lib
     from pysteps_amd.device import DeviceArray
-    from pysteps_amd.extrapolation.semilagrangian import extrapolate
-    from pysteps_amd.motion.lucaskanade import dense_lucaskanade
+    from pysteps_amd.motion import get_method, lucaskanade
     from tools import synth
 
-    for m, n in ((256, 320), (130, 203)):
-        frames = synth.steps_frames(m, n, 2).astype(np.float32)
-        V = dense_lucaskanade(DeviceArray.from_host(frames))
+    dense_lk = get_method("LK")
+    lib = _lib.lib()
+    for m, n in ((512, 512), (130, 203)):  # (the second shape is not one the window kernel takes)
+        frames = synth.steps_frames(m, n, 2)
+        monkeypatch.setattr(lucaskanade, "WRITE_UV_TWIN", False)
+        assert getattr(dense_lk(DeviceArray.from_host(frames)), "uv_pairs", None) is None  # the default: no second layout
+        monkeypatch.setattr(lucaskanade, "WRITE_UV_TWIN", True)
+        V = dense_lk(DeviceArray.from_host(frames))
         assert V.uv_pairs is not None and V.uv_pairs.shape == (m, n, 2)
         planes, pairs = V.to_host(), V.uv_pairs.to_host()
-        np.testing.assert_array_equal(pairs[..., 0], planes[0])
-        np.testing.assert_array_equal(pairs[..., 1], planes[1])
-        R = DeviceArray.from_host(frames[-1])
-        with_twin = extrapolate(R, V, 4).to_host()
-        V.uv_pairs = None
-        without = extrapolate(R, V, 4).to_host()
-        np.testing.assert_array_equal(with_twin, without)
+        assert np.array_equal(pairs[..., 0], planes[0]) and np.array_equal(pairs[..., 1], planes[1])
+        p = DeviceArray.from_host(frames[-1])
+        want = extrapolate(p, V, 12, outval=-15.0).to_host()  # the default kernel, from the planes
+        _lib.check(lib.psh_set_option(b"semilag_variant", 7))
+        try:
+            with_twin = extrapolate(p, V, 12, outval=-15.0).to_host()
+            V.uv_pairs = None
+            without = extrapolate(p, V, 12, outval=-15.0).to_host()
+        finally:
+            _lib.check(lib.psh_set_option(b"semilag_variant", 0))
+        assert np.array_equal(with_twin, want, equal_nan=True) and np.array_equal(without, want, equal_nan=True)
