@@ -620,10 +620,9 @@ static unsigned long long *g_win_stats = nullptr;
 // pixels of a lane: same operations, same order, same rounding per pixel (no contraction in this file) -
 // bit-identical - at about half the instructions.  The once-per-lead-step agreement is reduced to eight
 // v_readlane and scalar compares; boxes are exchanged only when a wave asked for a new window.
-template <int WAVES, int WW, int WH, bool PIPE = false>
+template <int WAVES, int WW, int WH>
 struct Win2Cfg {
   static constexpr int kWaves = WAVES, kW = WW, kH = WH;
-  static constexpr bool kPipe = PIPE;  // blend the first pixel pair while the reads of the second are in flight
   static constexpr int kTileY = kWinRows * WAVES;
   static constexpr unsigned kPitch4 = WW * 4u;          // bytes per window row of one plane
   static constexpr unsigned kPlaneBytes = WW * WH * 4u;
@@ -633,7 +632,6 @@ struct Win2Cfg {
   static constexpr int kCtlWords = 4 * WAVES + 2 + 3 + 3;
 };
 using Win2x8 = Win2Cfg<8, 96, 64>;
-using Win2x8Pipe = Win2Cfg<8, 96, 64, true>;
 
 struct Window2 {
   unsigned u, v, p;  // LDS byte addresses of the three planes
@@ -696,29 +694,13 @@ __device__ __forceinline__ void win2_sample(const Fields &F, const Window2 &W, c
 #undef PSH_TAPS
     }
 #define PSH_TIE4(A, J) "+v"(A[J][0]), "+v"(A[J][1]), "+v"(A[J][2]), "+v"(A[J][3])
-    if (C::kPipe) {
-      // the LDS returns in order: once at most 15 reads are outstanding (the counter's range) the first pixel pair's
-      // 16 / 24 values are there; its blends run while the second pair's reads complete
-      if (kWithP) {
-        asm volatile("s_waitcnt lgkmcnt(15)" : PSH_TIE4(ru, 0), PSH_TIE4(ru, 1), PSH_TIE4(rv, 0), PSH_TIE4(rv, 1), PSH_TIE4(rp, 0), PSH_TIE4(rp, 1));
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(15)" : PSH_TIE4(ru, 0), PSH_TIE4(ru, 1), PSH_TIE4(rv, 0), PSH_TIE4(rv, 1));
-      }
-    } else {
     asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(ru, 0), PSH_TIE4(ru, 1), PSH_TIE4(ru, 2), PSH_TIE4(ru, 3), PSH_TIE4(rv, 0), PSH_TIE4(rv, 1));
     asm volatile("" : PSH_TIE4(rv, 2), PSH_TIE4(rv, 3));
     if (kWithP) asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1), PSH_TIE4(rp, 2), PSH_TIE4(rp, 3));
-    }
+    // (blending the first pixel pair while the second pair's reads were still in flight - waits of lgkmcnt(15) and
+    // lgkmcnt(0) - was measured: 1.217 against 1.206 ms, profiles/r05/d_window_default_knobs_short_calls.txt)
 #pragma unroll
     for (int q = 0; q < kWinPairs; ++q) {
-      if (C::kPipe && q == 1) {
-        if (kWithP) {
-          // (tied to the first pair's results as well: the wait stays behind their blends)
-          asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(ru, 2), PSH_TIE4(ru, 3), PSH_TIE4(rv, 2), PSH_TIE4(rv, 3), PSH_TIE4(rp, 2), PSH_TIE4(rp, 3), "+v"(su[0]), "+v"(sv[0]), "+v"(sp[0]));
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(ru, 2), PSH_TIE4(ru, 3), PSH_TIE4(rv, 2), PSH_TIE4(rv, 3), "+v"(su[0]), "+v"(sv[0]));
-        }
-      }
       f32x2 tu[4], tv[4], tp[4];  // [tap 00, 01, 10, 11], .x = pixel 2q, .y = pixel 2q+1
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -780,24 +762,23 @@ __device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int pha
   const int lo4 = smin(smin(xa, xb), smin(xc, xd)), hi4 = smax(smax(xa, xb), smax(xc, xd));
   const int loy = smin(smin(ya, yb), smin(yc, yd)), hiy = smax(smax(ya, yb), smax(yc, yd));
   const bool near = force || lo4 < W.lo_x4 || hi4 > W.hi_x4 || loy < W.lo_y || hiy > W.hi_y;
+  // every wave publishes the box of its corner samples (one 16-byte store of lane 0), wave 0 its direction of travel:
+  // if anybody asks for a new window, everything its placement needs is behind the same barrier
   if (lane == 0) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
+    *(lds_i32x4 *)(size_t)(W.ctl + 16u * wave) = i32x4{lo4, hi4, loy, hiy};
     if (near) ctl[C::kCtlFlag / 4 + phase] = 1;
-    if (wave == 0) ctl[C::kCtlFlag / 4 + (phase == 2 ? 0 : phase + 1)] = 0;
-  }
-  win_barrier();
-  if (rfl(ctl[C::kCtlFlag / 4 + phase]) == 0) return;
-  // somebody asked: everybody publishes the box of its corner samples, wave 0 its direction of travel
-  if (lane == 0) {
-    ctl[wave * 4 + 0] = lo4;
-    ctl[wave * 4 + 1] = hi4;
-    ctl[wave * 4 + 2] = loy;
-    ctl[wave * 4 + 3] = hiy;
     if (wave == 0) {
       ctl[C::kCtlVel / 4 + 0] = __float_as_int(vx_lane);
       ctl[C::kCtlVel / 4 + 1] = __float_as_int(vy_lane);
+      ctl[C::kCtlFlag / 4 + (phase == 2 ? 0 : phase + 1)] = 0;
     }
   }
   win_barrier();
+  if (rfl(ctl[C::kCtlFlag / 4 + phase]) == 0) return;
+  // (the boxes of this step are overwritten after the next barrier every wave passes - the one that ends the fill,
+  // or the next lead step's - and every wave has read them by then)
   int ulo4 = 0x7fffffff, uhi4 = -0x7fffffff, uloy = 0x7fffffff, uhiy = -0x7fffffff;
 #pragma unroll
   for (int w = 0; w < C::kWaves; ++w) {
@@ -816,7 +797,7 @@ __device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int pha
   const int keep_y = wvy > 0.125f ? max(slack_y - 2, 0) : (wvy < -0.125f ? min(slack_y, 2) : slack_y / 2);
   const int nox = rfl(min(max((W.ox + bx0 - keep_x) & ~3, 0), n - C::kW));  // 16-byte aligned rows
   const int noy = rfl(min(max(W.oy + by0 - keep_y, 0), m - C::kH));
-  // the room a patch needs ahead of its corner samples before the next lead step (the distance one covers, + 25 % + 2);
+  // the room a patch needs ahead of its corner samples before the next lead step (the distance the last one covered + 2);
   // a lost trajectory (NaN) asks for nothing
   const float mvx = fabsf(wvx) < 64.f ? fabsf(wvx) * move_scale + 2.f : 2.f, mvy = fabsf(wvy) < 64.f ? fabsf(wvy) * move_scale + 2.f : 2.f;
   const int gx = rfl(static_cast<int>(mvx)), gy = rfl(static_cast<int>(mvy));
@@ -824,8 +805,12 @@ __device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int pha
   W.hi_x4 = (C::kW - 2 - (wvx > 0.f ? 1 : gx)) * 4;
   W.lo_y = wvy > 0.f ? gy : 1;
   W.hi_y = C::kH - 2 - (wvy > 0.f ? 1 : gy);
-  // (a tile parked at the image border keeps asking: the window it would get is the one it has)
-  if (!force && nox == W.ox && noy == W.oy) return;
+  // (a tile parked at the image border keeps asking: the window it would get is the one it has.  The barrier keeps
+  // a wave that returns from overwriting its box while another one still reads this step's boxes)
+  if (!force && nox == W.ox && noy == W.oy) {
+    win_barrier();
+    return;
+  }
   win2_count(W, 2);
   const int ddx4 = (nox - W.ox) * 4, ddy = noy - W.oy;
 #pragma unroll
@@ -865,10 +850,24 @@ template <class C, bool GEN>
 __global__ __launch_bounds__(C::kThreads, 4) void semilag_window2(
     const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out, double *__restrict__ disp,
     const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume, float outval,
-    int row0, int rows, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd, float guard,
+    int row0, int rows, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd, float guard, int cells,
     unsigned long long *__restrict__ stats) {
+  // Block b runs on XCD b % 8.  How long a workgroup takes depends on how fast its tile's samples travel (window
+  // fills), and motion fields vary smoothly across the image: with one contiguous band of tiles per XCD the XCD
+  // that owns the fastest band finishes last.  `cells`: the tile grid is cut into 8 x 8 cells and XCD k owns the
+  // cells (cx + cy) % 8 == k - one in every row band and every column band - each cell still a compact block of
+  // tiles for its L2.  (Tile grids that do not divide by 8 keep the bands.)
   const int b = blockIdx.x;
-  const int tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
+  int tile;
+  if (cells) {
+    const int xcd = b % kNumXcd, l = b / kNumXcd;
+    const int cw = tiles_x / kNumXcd, ch = (n_tiles / tiles_x) / kNumXcd, per_cell = cw * ch;
+    const int cy = l / per_cell, r = l - cy * per_cell;
+    const int cx = (xcd + kNumXcd - cy) & (kNumXcd - 1);
+    tile = (cy * ch + r / cw) * tiles_x + cx * cw + r % cw;
+  } else {
+    tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
+  }
   if (tile >= n_tiles) return;  // the whole workgroup
   const int lane = threadIdx.x & (kTileX - 1);
   const int xt = (tile % tiles_x) * kTileX + lane;
@@ -938,7 +937,7 @@ __global__ __launch_bounds__(C::kThreads, 4) void semilag_window2(
     viy[q] = f32x2{ivy[2 * q], ivy[2 * q + 1]};
     sp[q] = f32x2{0.f, 0.f};
   }
-  const float move_scale = guard * static_cast<float>(n_iter);  // lead step = n_iter sub-steps of two half increments, + 25 %
+  const float move_scale = guard * static_cast<float>(n_iter);  // lead step = n_iter sub-steps of two half increments
   __syncthreads();  // the flag words are cleared
   int phase = 0;
   win2_update<C>(F, W, phase, true, dx4, dy, 0.5f * vix[0].x, 0.5f * viy[0].x, move_scale, m, n);
@@ -1032,8 +1031,11 @@ static hipError_t launch_window2(const SemilagArgs &a, hipStream_t stream) {
   const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
   const dim3 grid(tiles_per_xcd * kNumXcd), block(C::kThreads);
   static const bool want_stats = std::getenv("PYSTEPS_HIP_SL_STATS") != nullptr;
-  // room asked for ahead of the samples, in units of the distance the last lead step covered (development knob)
-  static const float guard = std::getenv("PYSTEPS_HIP_SL_GUARD") ? static_cast<float>(std::atof(std::getenv("PYSTEPS_HIP_SL_GUARD"))) : 2.5f;
+  // room asked for ahead of the corner samples, in half increments per sub-step: 2.0 = the distance the last lead step
+  // covered (+ 2 pixels); measured 2.0 / 2.2 / 2.5 / 3.0: 1.184 / 1.190 / 1.206 / 1.209 ms (development knob)
+  static const float guard = std::getenv("PYSTEPS_HIP_SL_GUARD") ? static_cast<float>(std::atof(std::getenv("PYSTEPS_HIP_SL_GUARD"))) : 2.0f;
+  static const bool want_cells = std::getenv("PYSTEPS_HIP_SL_CELLS") == nullptr || std::atoi(std::getenv("PYSTEPS_HIP_SL_CELLS")) != 0;
+  const int cells = (want_cells && tiles_x % kNumXcd == 0 && tiles_y % kNumXcd == 0) ? 1 : 0;
   if (want_stats) {
     if (g_win_stats == nullptr && hipMalloc(&g_win_stats, 4 * sizeof(unsigned long long)) != hipSuccess) g_win_stats = nullptr;
     if (g_win_stats != nullptr) (void)hipMemsetAsync(g_win_stats, 0, 4 * sizeof(unsigned long long), stream);
@@ -1041,11 +1043,11 @@ static hipError_t launch_window2(const SemilagArgs &a, hipStream_t stream) {
   if (a.bmode != 0) {
     hipLaunchKernelGGL((semilag_window2<C, true>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
                        a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
-                       tiles_per_xcd, guard, g_win_stats);
+                       tiles_per_xcd, guard, cells, g_win_stats);
   } else {
     hipLaunchKernelGGL((semilag_window2<C, false>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
                        a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
-                       tiles_per_xcd, guard, g_win_stats);
+                       tiles_per_xcd, guard, cells, g_win_stats);
   }
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess && want_stats && g_win_stats != nullptr) {
@@ -1100,7 +1102,7 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
 }  // namespace
 
 // semilag_variant: 0 (default) = the workgroup-window kernel wherever it applies (bilinear resampling of a field,
-// n_iter >= 1, images of at least 96 x 64 pixels with n % 4 == 0, at least kWindowMinPasses sampling steps), the gather
+// n_iter >= 1, images of at least 96 x 64 pixels with n % 4 == 0, at least two sampling steps), the gather
 // kernels elsewhere; 12 = the window kernel for every eligible call, however short; 7 = gather kernels only: velocity
 // from a packed {u,v} plane and the field from a row-pair plane (the default of rounds 2 - 4); 5 = packed velocity
 // only; 1 = one plane per component with DPP column sharing (what calls of fewer than 8 sampling steps take among the
@@ -1112,10 +1114,10 @@ static int g_semilag_variant = [] {
 
 void set_semilag_variant(int v) { g_semilag_variant = v; }
 
-static const bool g_window_pipe = std::getenv("PYSTEPS_HIP_SL_PIPE") != nullptr;  // development knob
-
-// the first window costs one fill before anything is sampled: calls of one or two sampling steps keep the gathers
-constexpr long long kWindowMinPasses = 3;
+// the first window costs one fill before anything is sampled: a call of a single sampling step keeps the gathers
+// (4096^2, n_iter 1, T = 1 / 2 / 3 / 4 / 8: window 0.106 / 0.143 / 0.180 / 0.217 / 0.403 ms, gathers 0.100 / 0.153 / 0.205 /
+// 0.262 / 0.597 ms - profiles/r05/d_window_default_knobs_short_calls.txt)
+constexpr long long kWindowMinPasses = 2;
 
 bool semilag_uses_window(const SemilagArgs &a) {
   if (!semilag_window2_eligible(a)) return false;
@@ -1124,7 +1126,7 @@ bool semilag_uses_window(const SemilagArgs &a) {
 }
 
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
-  if (semilag_uses_window(a)) return g_window_pipe ? launch_window2<Win2x8Pipe>(a, stream) : launch_window2<Win2x8>(a, stream);
+  if (semilag_uses_window(a)) return launch_window2<Win2x8>(a, stream);
   if (a.vel_packed != nullptr && a.field_pairs != nullptr && a.order == 1) return launch_variant<1, kModePacked2>(a, stream);
   if (a.vel_packed != nullptr) return launch_variant<1, kModePacked>(a, stream);
   return launch_variant<1, kModeDirect>(a, stream);
