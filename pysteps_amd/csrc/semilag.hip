@@ -749,36 +749,38 @@ __device__ __forceinline__ void win2_sample(const Fields &F, const Window2 &W, c
   }
 }
 
-template <class C>
-__device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int phase, bool force, int (&dx4)[kWinRows],
-                                            int (&dy)[kWinRows], float vx_lane, float vy_lane, float move_scale, int m,
-                                            int n) {
-  const int lane = threadIdx.x & 63, wave = rfl(static_cast<int>(threadIdx.x >> 6));
-  lds_int *ctl = (lds_int *)(size_t)W.ctl;
+// the box of a patch's corner samples (window-relative, pre-scaled columns / rows): eight v_readlane, scalar min / max
+struct WinBox {
+  int lo4, hi4, loy, hiy;
+};
+__device__ __forceinline__ WinBox win2_corners(const int (&dx4)[kWinRows], const int (&dy)[kWinRows]) {
   const int xa = __builtin_amdgcn_readlane(dx4[0], 0), xb = __builtin_amdgcn_readlane(dx4[0], 63);
   const int xc = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 0), xd = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 63);
   const int ya = __builtin_amdgcn_readlane(dy[0], 0), yb = __builtin_amdgcn_readlane(dy[0], 63);
   const int yc = __builtin_amdgcn_readlane(dy[kWinRows - 1], 0), yd = __builtin_amdgcn_readlane(dy[kWinRows - 1], 63);
-  const int lo4 = smin(smin(xa, xb), smin(xc, xd)), hi4 = smax(smax(xa, xb), smax(xc, xd));
-  const int loy = smin(smin(ya, yb), smin(yc, yd)), hiy = smax(smax(ya, yb), smax(yc, yd));
-  const bool near = force || lo4 < W.lo_x4 || hi4 > W.hi_x4 || loy < W.lo_y || hiy > W.hi_y;
-  // every wave publishes the box of its corner samples (one 16-byte store of lane 0), wave 0 its direction of travel:
-  // if anybody asks for a new window, everything its placement needs is behind the same barrier
-  if (lane == 0) {
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
-    *(lds_i32x4 *)(size_t)(W.ctl + 16u * wave) = i32x4{lo4, hi4, loy, hiy};
-    if (near) ctl[C::kCtlFlag / 4 + phase] = 1;
-    if (wave == 0) {
-      ctl[C::kCtlVel / 4 + 0] = __float_as_int(vx_lane);
-      ctl[C::kCtlVel / 4 + 1] = __float_as_int(vy_lane);
-      ctl[C::kCtlFlag / 4 + (phase == 2 ? 0 : phase + 1)] = 0;
-    }
+  return {smin(smin(xa, xb), smin(xc, xd)), smax(smax(xa, xb), smax(xc, xd)), smin(smin(ya, yb), smin(yc, yd)),
+          smax(smax(ya, yb), smax(yc, yd))};
+}
+
+// lane 0: the wave's box (one 16-byte store), wave 0 also its direction of travel
+template <class C>
+__device__ __forceinline__ void win2_publish(const Window2 &W, int wave, const WinBox &bx, float vx_lane, float vy_lane) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
+  lds_int *ctl = (lds_int *)(size_t)W.ctl;
+  *(lds_i32x4 *)(size_t)(W.ctl + 16u * wave) = i32x4{bx.lo4, bx.hi4, bx.loy, bx.hiy};
+  if (wave == 0) {
+    ctl[C::kCtlVel / 4 + 0] = __float_as_int(vx_lane);
+    ctl[C::kCtlVel / 4 + 1] = __float_as_int(vy_lane);
   }
-  win_barrier();
-  if (rfl(ctl[C::kCtlFlag / 4 + phase]) == 0) return;
-  // (the boxes of this step are overwritten after the next barrier every wave passes - the one that ends the fill,
-  // or the next lead step's - and every wave has read them by then)
+}
+
+// Every wave of the workgroup, with every wave's box published and nobody reading the window any more: place the
+// new window ahead of the motion, re-base the offsets, fill it.  (The caller orders the LDS writes before the next reader.)
+template <class C>
+__device__ __forceinline__ void win2_place_and_fill(const Fields &F, Window2 &W, bool force, int (&dx4)[kWinRows],
+                                                    int (&dy)[kWinRows], float move_scale, int m, int n) {
+  lds_int *ctl = (lds_int *)(size_t)W.ctl;
   int ulo4 = 0x7fffffff, uhi4 = -0x7fffffff, uloy = 0x7fffffff, uhiy = -0x7fffffff;
 #pragma unroll
   for (int w = 0; w < C::kWaves; ++w) {
@@ -805,12 +807,8 @@ __device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int pha
   W.hi_x4 = (C::kW - 2 - (wvx > 0.f ? 1 : gx)) * 4;
   W.lo_y = wvy > 0.f ? gy : 1;
   W.hi_y = C::kH - 2 - (wvy > 0.f ? 1 : gy);
-  // (a tile parked at the image border keeps asking: the window it would get is the one it has.  The barrier keeps
-  // a wave that returns from overwriting its box while another one still reads this step's boxes)
-  if (!force && nox == W.ox && noy == W.oy) {
-    win_barrier();
-    return;
-  }
+  // (a tile parked at the image border keeps asking: the window it would get is the one it has)
+  if (!force && nox == W.ox && noy == W.oy) return;
   win2_count(W, 2);
   const int ddx4 = (nox - W.ox) * 4, ddy = noy - W.oy;
 #pragma unroll
@@ -820,7 +818,6 @@ __device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int pha
   }
   W.ox = nox;
   W.oy = noy;
-  // both barriers passed: nobody reads the old window any more
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));  // opaque: the item addresses below are not loop invariants worth their registers
   constexpr int kRounds = (C::kItems + C::kThreads - 1) / C::kThreads;
@@ -843,8 +840,38 @@ __device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int pha
     *(lds_u32x4 *)(size_t)(W.v + l) = bv[k];
     *(lds_u32x4 *)(size_t)(W.p + l) = bp[k];
   }
+}
+
+// Once per lead step, every wave of the workgroup: publish the box of the patch's corner samples, ask for a new
+// window if they are about to leave this one, agree at ONE barrier, and if anybody asked: place, re-base, fill,
+// second barrier.  `phase` cycles through three flag words so that clearing the next one never races with a wave
+// that still has to read it.
+template <class C>
+__device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int phase, bool force, int (&dx4)[kWinRows],
+                                            int (&dy)[kWinRows], float vx_lane, float vy_lane, float move_scale, int m,
+                                            int n) {
+  const int lane = threadIdx.x & 63, wave = rfl(static_cast<int>(threadIdx.x >> 6));
+  lds_int *ctl = (lds_int *)(size_t)W.ctl;
+  const WinBox bx = win2_corners(dx4, dy);
+  const bool near = force || bx.lo4 < W.lo_x4 || bx.hi4 > W.hi_x4 || bx.loy < W.lo_y || bx.hiy > W.hi_y;
+  if (lane == 0) {
+    win2_publish<C>(W, wave, bx, vx_lane, vy_lane);
+    if (near) ctl[C::kCtlFlag / 4 + phase] = 1;
+    if (wave == 0) ctl[C::kCtlFlag / 4 + (phase == 2 ? 0 : phase + 1)] = 0;
+  }
+  win_barrier();
+  if (rfl(ctl[C::kCtlFlag / 4 + phase]) == 0) return;
+  // every wave is past the barrier: nobody reads the old window any more.  The boxes of this step are overwritten
+  // after the barrier below - every wave has read them by then
+  win2_place_and_fill<C>(F, W, force, dx4, dy, move_scale, m, n);
   win_barrier();
 }
+
+// (Round 5 also built the same agreement WITHOUT the per-lead-step barrier - waves running free, a wave that needs a
+// new window raising an epoch flag and waiting at an LDS-counter rendezvous the others join when they finish their own
+// lead step: bit-identical, but 1.220 against 1.172 ms - waves that drift a step or two apart spread their samples over
+// a larger box, the window's slack shrinks and it is refilled twice as often (9.6 instead of 5 fills per workgroup;
+// profiles/r05/f_window_free_running_timings.txt).  The barrier is what keeps the window economical.)
 
 template <class C, bool GEN>
 __global__ __launch_bounds__(C::kThreads, 4) void semilag_window2(

@@ -1,5 +1,5 @@
 """Copy the judged summaries of a gpurun_out/<tag> session into profiles/<round>/ and refresh
-profiles/pmc_traffic.json (HBM bytes per launch of semilag_fused; FETCH_SIZE is doubled: gfx950
+profiles/pmc_traffic.json (HBM bytes per launch of the extrapolation kernel; FETCH_SIZE is doubled: gfx950
 reports exactly half of a coalesced read stream, see tools/calib_copy.py / DESIGN.md section 6)."""
 import csv, glob, json, os, shutil, sys
 
@@ -69,13 +69,14 @@ def mean_counter(sub, counter, kernel):
     vals = [v for v in vals if v[1] > 500000]  # full-size launches only (not the input synthesis)
     return (sum(v[0] for v in vals) / len(vals), sum(v[1] for v in vals) / len(vals) / 1e6, len(vals)) if vals else None
 
-fetch = mean_counter("pmc_fetch", "FETCH_SIZE", "semilag_fused")
-write = mean_counter("pmc_write", "WRITE_SIZE", "semilag_fused")
+SL_KERNEL = "semilag_window2"  # the extrapolator of the bench step (rounds 1-4: semilag_fused)
+fetch = mean_counter("pmc_fetch", "FETCH_SIZE", SL_KERNEL)
+write = mean_counter("pmc_write", "WRITE_SIZE", SL_KERNEL)
 if fetch and write:
     bench = json.load(open(os.path.join(src, "bench.json")))
     key = "semilag_4096x4096_T24_K1"
     rec = {
-        "kernel": "semilag_fused", "launches_averaged": fetch[2],
+        "kernel": SL_KERNEL, "launches_averaged": fetch[2],
         "FETCH_SIZE_KiB": fetch[0], "WRITE_SIZE_KiB": write[0],
         "fetch_correction": 2.0,
         "hbm_bytes_per_launch": (2.0 * fetch[0] + write[0]) * 1024.0,
