@@ -195,6 +195,10 @@ size_t lk_keepbits_bytes(int m, int n);
 size_t lk_slot_bytes();
 int lk_pyramids_beside(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m, int n, int win_w,
                        int win_h, int max_level, void **handle_out);
+int lk_pyramids_on_side(hipStream_t side, void *block, size_t block_bytes, const unsigned char *prev_u8_dev,
+                        const unsigned char *next_u8_dev, int m, int n, int win_w, int win_h, int max_level,
+                        void **handle_out);
+size_t lk_pyramids_bytes(int m, int n, int win_w, int win_h, int max_level);
 
 // ordered min-distance acceptance and the post-outlier-test stage on the device (lk_sparse.hip)
 int corner_order_max_corners();

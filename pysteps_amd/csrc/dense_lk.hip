@@ -144,31 +144,37 @@ extern "C" int psh_dense_lk_uv_dev(const float *frames_dev, int nframes, int m, 
   float *d_pts = reinterpret_cast<float *>(corners.as<char>() + 256);
   for (int t = 0; t + 1 < nframes; ++t) {
     // side stream: the next frame's passes, then the pyramids of the pair (they only need the uint8
-    // renderings); main stream: the corner chain of this frame; joined before the tracker
+    // renderings); main stream: the corner chain of this frame; joined before the tracker.  The corner chain is
+    // QUEUED first: its first kernel follows the frame passes on the main stream directly, and the ~10 launches of
+    // the side stream cost the host more time than those passes run (round 4's timeline had the main stream idle
+    // for 13 us in front of lk_corner_response_cols while the host was still queueing the side stream)
     hipStream_t side = nullptr;
     if (int rc = psh::side_begin(&side)) return rc;
-    if (int rc = prepare(t + 1, side, ws_side.p)) {
+    // (the pyramids' storage is taken NOW: a block the allocator hands out after the corner chain is queued may be
+    // one that chain just gave back, and the side stream does not wait for the chain)
+    const size_t pyr_bytes = psh::lk_pyramids_bytes(m, n, prm->win_w, prm->win_h, prm->max_level);
+    void *pyr_block = nullptr;
+    if (int rc = psh_malloc(&pyr_block, pyr_bytes)) {
       (void)psh::side_end();
       return rc;
     }
-    struct Fork {
-      const unsigned char *prev, *next;
-      int m, n, win_w, win_h, max_level;
-      void *pyr;
-      int rc;
-    } fork{trk[t].as<unsigned char>(), trk[t + 1].as<unsigned char>(), m, n, prm->win_w, prm->win_h, prm->max_level,
-           nullptr, PSH_OK};
-    auto build_pyramids = [](void *arg) -> int {
-      Fork *f = static_cast<Fork *>(arg);
-      f->rc = psh::lk_pyramids_beside(f->prev, f->next, f->m, f->n, f->win_w, f->win_h, f->max_level, &f->pyr);
-      return f->rc;
-    };
     int walk_stats[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    (void)build_pyramids(&fork);  // queued behind the frame passes on the side stream
     const int rc1 = psh::lk_corners_resident(feat[t].as<unsigned char>(), nan_pattern(t),
                                              stats[t].as<float>(), m, n, prm->block_size, prm->buffer_mask,
                                              prm->quality_level, prm->min_distance, prm->max_corners, d_pts, d_npts,
                                              nullptr, nullptr, trace ? walk_stats : nullptr, frame_slots(t));
+    if (int rc = prepare(t + 1, side, ws_side.p)) {
+      (void)psh::side_end();
+      (void)psh_free(pyr_block);
+      return rc;
+    }
+    struct Fork {
+      void *pyr;
+      int rc;
+    } fork{nullptr, PSH_OK};
+    // queued behind the frame passes on the side stream (forked above, after this frame's passes on the main stream)
+    fork.rc = psh::lk_pyramids_on_side(side, pyr_block, pyr_bytes, trk[t].as<unsigned char>(), trk[t + 1].as<unsigned char>(),
+                                       m, n, prm->win_w, prm->win_h, prm->max_level, &fork.pyr);
     const int rcj = psh::side_end();
     void *pyr = fork.pyr;
     if (trace)

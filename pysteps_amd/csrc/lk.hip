@@ -2355,12 +2355,13 @@ struct PyramidSet {
 }  // namespace
 
 static int lk_pyramids_on(hipStream_t stream, const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev,
-                          int m, int n, int win_w, int win_h, int max_level, void **handle_out);
+                          int m, int n, int win_w, int win_h, int max_level, void **handle_out, void *block_in,
+                          size_t block_in_bytes);
 
 int psh_lk_pyramids_dev(const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev, int m,
                         int n, int win_w, int win_h, int max_level, void **handle_out) {
   PSH_REQUIRE_INIT();
-  return lk_pyramids_on(ctx().stream, prev_u8_dev, next_u8_dev, m, n, win_w, win_h, max_level, handle_out);
+  return lk_pyramids_on(ctx().stream, prev_u8_dev, next_u8_dev, m, n, win_w, win_h, max_level, handle_out, nullptr, 0);
 }
 
 extern "C++" {
@@ -2373,13 +2374,44 @@ int lk_pyramids_beside(const unsigned char *prev_u8_dev, const unsigned char *ne
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   hipStream_t side = nullptr;
   if (int rc = side_begin(&side)) return rc;
-  return lk_pyramids_on(side, prev_u8_dev, next_u8_dev, m, n, win_w, win_h, max_level, handle_out);
+  return lk_pyramids_on(side, prev_u8_dev, next_u8_dev, m, n, win_w, win_h, max_level, handle_out, nullptr, 0);
+}
+// ... on a side stream the caller has forked already (no new fork: the pyramids then wait for what the side stream
+// waits for, not for whatever the main stream was given in the meantime).  `block` (lk_pyramids_bytes() bytes, from
+// psh_malloc) has to be taken BEFORE the caller queues anything else on the main stream after the fork: the allocator
+// is ordered on the main stream, a block it hands out later may still be in use by that work, which the side stream
+// does not wait for.  The pyramid set owns the block from here on (also when the call fails).
+int lk_pyramids_on_side(hipStream_t side, void *block, size_t block_bytes, const unsigned char *prev_u8_dev,
+                        const unsigned char *next_u8_dev, int m, int n, int win_w, int win_h, int max_level,
+                        void **handle_out) {
+  Context &c = ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  const int rc = lk_pyramids_on(side, prev_u8_dev, next_u8_dev, m, n, win_w, win_h, max_level, handle_out, block, block_bytes);
+  if (rc != PSH_OK && (handle_out == nullptr || *handle_out == nullptr) && block) (void)psh_free(block);
+  return rc;
+}
+size_t lk_pyramids_bytes(int m, int n, int win_w, int win_h, int max_level) {
+  if (max_level >= kMaxLevels) max_level = kMaxLevels - 1;
+  const bool need_deriv = win_w > kRowsMaxWin;
+  size_t bytes = 0;
+  int r = m, q = n;
+  if (need_deriv) bytes += (static_cast<size_t>(r) * q * sizeof(short2) + 255) & ~static_cast<size_t>(255);
+  for (int l = 1; l <= max_level; ++l) {
+    r = (r + 1) / 2;
+    q = (q + 1) / 2;
+    if (q <= win_w || r <= win_h) break;
+    const size_t px = (static_cast<size_t>(r) * q + 255) & ~static_cast<size_t>(255);
+    bytes += 2 * px;
+    if (need_deriv) bytes += (static_cast<size_t>(r) * q * sizeof(short2) + 255) & ~static_cast<size_t>(255);
+  }
+  return bytes ? bytes : 256;
 }
 }  // namespace psh
 }  // extern "C++"
 
 static int lk_pyramids_on(hipStream_t stream, const unsigned char *prev_u8_dev, const unsigned char *next_u8_dev,
-                          int m, int n, int win_w, int win_h, int max_level, void **handle_out) {
+                          int m, int n, int win_w, int win_h, int max_level, void **handle_out, void *block_in,
+                          size_t block_in_bytes) {
   PSH_REQUIRE_INIT();
   if (!handle_out) return fail(PSH_EINVAL, "lk_pyramids: NULL handle pointer");
   *handle_out = nullptr;
@@ -2421,7 +2453,14 @@ static int lk_pyramids_on(hipStream_t stream, const unsigned char *prev_u8_dev, 
   }
   if (bytes == 0) bytes = 256;  // single level, no gradient image: nothing to store
   PyramidSet *ps = new PyramidSet();
-  if (int rc = psh_malloc(&ps->block, bytes)) {
+  if (block_in != nullptr) {
+    // a block the caller took from the allocator earlier (before it queued other work on the main stream); the set owns it
+    if (block_in_bytes < bytes) {
+      delete ps;
+      return fail(PSH_EINVAL, "lk_pyramids: the block handed in holds %zu bytes, %zu are needed", block_in_bytes, bytes);
+    }
+    ps->block = block_in;
+  } else if (int rc = psh_malloc(&ps->block, bytes)) {
     delete ps;
     return rc;
   }

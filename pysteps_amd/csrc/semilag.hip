@@ -620,9 +620,12 @@ static unsigned long long *g_win_stats = nullptr;
 // pixels of a lane: same operations, same order, same rounding per pixel (no contraction in this file) -
 // bit-identical - at about half the instructions.  The once-per-lead-step agreement is reduced to eight
 // v_readlane and scalar compares; boxes are exchanged only when a wave asked for a new window.
-template <int WAVES, int WW, int WH>
+template <int WAVES, int WW, int WH, bool UV = false>
 struct Win2Cfg {
   static constexpr int kWaves = WAVES, kW = WW, kH = WH;
+  // UV: u and v interleaved as {u,v} pairs in ONE window plane (8-byte texels, column offsets pre-scaled by 8)
+  static constexpr bool kUV = UV;
+  static constexpr int kXShift = UV ? 3 : 2;
   static constexpr int kTileY = kWinRows * WAVES;
   static constexpr unsigned kPitch4 = WW * 4u;          // bytes per window row of one plane
   static constexpr unsigned kPlaneBytes = WW * WH * 4u;
@@ -632,6 +635,7 @@ struct Win2Cfg {
   static constexpr int kCtlWords = 4 * WAVES + 2 + 3 + 3;
 };
 using Win2x8 = Win2Cfg<8, 96, 64>;
+using Win3x8 = Win2Cfg<8, 96, 64, true>;
 
 struct Window2 {
   unsigned u, v, p;  // LDS byte addresses of the three planes
@@ -791,7 +795,7 @@ __device__ __forceinline__ void win2_place_and_fill(const Fields &F, Window2 &W,
   }
   const float wvx = __int_as_float(ctl[C::kCtlVel / 4 + 0]), wvy = __int_as_float(ctl[C::kCtlVel / 4 + 1]);
   // first and last texel the tile touches now (right / lower tap included), relative to the current origin
-  const int bx0 = ulo4 >> 2, bx1 = (uhi4 >> 2) + 1, by0 = uloy, by1 = uhiy + 1;
+  const int bx0 = ulo4 >> C::kXShift, bx1 = (uhi4 >> C::kXShift) + 1, by0 = uloy, by1 = uhiy + 1;
   const int slack_x = max(C::kW - (bx1 - bx0 + 1), 0), slack_y = max(C::kH - (by1 - by0 + 1), 0);
   // texels kept on the low side: all the slack but two where the motion goes that way (a positive velocity moves
   // the samples towards lower coordinates), two where it comes from, half of it in calm air
@@ -803,14 +807,14 @@ __device__ __forceinline__ void win2_place_and_fill(const Fields &F, Window2 &W,
   // a lost trajectory (NaN) asks for nothing
   const float mvx = fabsf(wvx) < 64.f ? fabsf(wvx) * move_scale + 2.f : 2.f, mvy = fabsf(wvy) < 64.f ? fabsf(wvy) * move_scale + 2.f : 2.f;
   const int gx = rfl(static_cast<int>(mvx)), gy = rfl(static_cast<int>(mvy));
-  W.lo_x4 = (wvx > 0.f ? gx : 1) * 4;
-  W.hi_x4 = (C::kW - 2 - (wvx > 0.f ? 1 : gx)) * 4;
+  W.lo_x4 = (wvx > 0.f ? gx : 1) << C::kXShift;
+  W.hi_x4 = (C::kW - 2 - (wvx > 0.f ? 1 : gx)) << C::kXShift;
   W.lo_y = wvy > 0.f ? gy : 1;
   W.hi_y = C::kH - 2 - (wvy > 0.f ? 1 : gy);
   // (a tile parked at the image border keeps asking: the window it would get is the one it has)
   if (!force && nox == W.ox && noy == W.oy) return;
   win2_count(W, 2);
-  const int ddx4 = (nox - W.ox) * 4, ddy = noy - W.oy;
+  const int ddx4 = (nox - W.ox) << C::kXShift, ddy = noy - W.oy;
 #pragma unroll
   for (int j = 0; j < kWinRows; ++j) {
     dx4[j] -= ddx4;
@@ -836,8 +840,14 @@ __device__ __forceinline__ void win2_place_and_fill(const Fields &F, Window2 &W,
 #pragma unroll
   for (int k = 0; k < kRounds; ++k) {
     const unsigned l = 16u * min(tid + C::kThreads * k, C::kItems - 1);
-    *(lds_u32x4 *)(size_t)(W.u + l) = bu[k];
-    *(lds_u32x4 *)(size_t)(W.v + l) = bv[k];
+    if (C::kUV) {
+      // W.u is the {u,v} plane (W.v is not used): four pixels = two 16-byte items
+      *(lds_u32x4 *)(size_t)(W.u + 2u * l) = u32x4{bu[k].x, bv[k].x, bu[k].y, bv[k].y};
+      *(lds_u32x4 *)(size_t)(W.u + 2u * l + 16u) = u32x4{bu[k].z, bv[k].z, bu[k].w, bv[k].w};
+    } else {
+      *(lds_u32x4 *)(size_t)(W.u + l) = bu[k];
+      *(lds_u32x4 *)(size_t)(W.v + l) = bv[k];
+    }
     *(lds_u32x4 *)(size_t)(W.p + l) = bp[k];
   }
 }
@@ -1043,6 +1053,231 @@ __global__ __launch_bounds__(C::kThreads, 4) void semilag_window2(
   }
 }
 
+// ---- hybrid window (experiment): {u,v} interleaved in LDS, x / y-paired arithmetic ------------------------
+// Same window, same protocol; the velocity taps are ds_read_b64 {u,v} pairs (8 LDS reads per pixel and lead step for
+// the velocity instead of 16), the trajectory update and the weights run as v_pk_*_f32 on the (x, y) pair of ONE
+// pixel, the velocity blend on the (u, v) pair with the weights broadcast by op_sel, the field blend as four scalar
+// FMAs: 12 LDS reads and ~51 VALU instructions per pixel and lead step against 21 and 54.
+template <class C, int WHAT, bool GEN>
+__device__ __forceinline__ void win3_sample(const Fields &F, const Window2 &W, const int (&dx8)[kWinRows],
+                                            const int (&dy)[kWinRows], const f32x2 (&f)[kWinRows], int m, int n,
+                                            float outval, f32x2 (&s_uv)[kWinRows], float (&sp)[kWinRows]) {
+  constexpr bool kWithP = (WHAT & kPrecip) != 0;
+  unsigned mx = static_cast<unsigned>(dx8[0]), my = static_cast<unsigned>(dy[0]);
+#pragma unroll
+  for (int j = 1; j < kWinRows; ++j) {
+    mx = max(mx, static_cast<unsigned>(dx8[j]));
+    my = max(my, static_cast<unsigned>(dy[j]));
+  }
+  const bool ok = mx <= (C::kW - 2) * 8u && my <= static_cast<unsigned>(C::kH - 2);
+  if (__builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true)) {
+    win2_count(W, 0);
+    f32x2 t[kWinRows][4];
+    float rp[kWinRows][4];
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      const unsigned a = __umul24(static_cast<unsigned>(dy[j]), 2u * C::kPitch4) + static_cast<unsigned>(dx8[j]) + W.u;
+      asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:%c5\n\t"
+                   "ds_read_b64 %3, %4 offset:%c6"
+                   : "=&v"(t[j][0]), "=&v"(t[j][1]), "=&v"(t[j][2]), "=&v"(t[j][3])
+                   : "v"(a), "i"(2u * C::kPitch4), "i"(2u * C::kPitch4 + 8u));
+      if (kWithP) {
+        const unsigned ap = ((a - W.u) >> 1) + W.p;
+        asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:%c5\n\t"
+                     "ds_read_b32 %3, %4 offset:%c6"
+                     : "=&v"(rp[j][0]), "=&v"(rp[j][1]), "=&v"(rp[j][2]), "=&v"(rp[j][3])
+                     : "v"(ap), "i"(C::kPitch4), "i"(C::kPitch4 + 4u));
+      }
+    }
+#define PSH_TIE4(A, J) "+v"(A[J][0]), "+v"(A[J][1]), "+v"(A[J][2]), "+v"(A[J][3])
+    asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(t, 0), PSH_TIE4(t, 1), PSH_TIE4(t, 2), PSH_TIE4(t, 3));
+    if (kWithP) asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1), PSH_TIE4(rp, 2), PSH_TIE4(rp, 3));
+#undef PSH_TIE4
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      // make_weights(): gx = 1 - fx, gy = 1 - fy; {gy gx, gy fx, fy gx, fy fx} (products commute bit for bit)
+      const f32x2 g = 1.f - f[j];
+      const f32x2 w00 = g * g.yx;        // (gx gy, gy gx): w00 in both halves
+      const f32x2 wmid = f[j] * g.yx;    // (fx gy, fy gx) = (w01, w10)
+      const f32x2 w11 = f[j] * f[j].yx;  // (fx fy, fy fx): w11 in both halves
+      f32x2 acc = t[j][0] * f32x2{w00.x, w00.x};  // the order of sample_interior_packed
+      acc = __builtin_elementwise_fma(f32x2{wmid.x, wmid.x}, t[j][1], acc);
+      acc = __builtin_elementwise_fma(f32x2{wmid.y, wmid.y}, t[j][2], acc);
+      acc = __builtin_elementwise_fma(f32x2{w11.x, w11.x}, t[j][3], acc);
+      s_uv[j] = acc;
+      if (kWithP) sp[j] = fmaf(w11.x, rp[j][3], fmaf(wmid.y, rp[j][2], fmaf(wmid.x, rp[j][1], w00.x * rp[j][0])));
+    }
+  } else {
+    win2_count(W, 1);
+    int X[kWinRows], Y[kWinRows];
+    float sfx[kWinRows], sfy[kWinRows], ssu[kWinRows], ssv[kWinRows], ssp[kWinRows];
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      X[j] = W.ox + (dx8[j] >> 3);
+      Y[j] = W.oy + dy[j];
+      sfx[j] = f[j].x;
+      sfy[j] = f[j].y;
+      ssp[j] = 0.f;
+    }
+    sample_at<kWinRows, 1, WHAT, kModeDirect, GEN>(F, X, Y, sfx, sfy, m, n, outval, ssu, ssv, ssp);
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      s_uv[j] = f32x2{ssu[j], ssv[j]};
+      if (kWithP) sp[j] = ssp[j];
+    }
+  }
+}
+
+// one pixel's trajectory, both axes in one packed subtraction: P -= floor stuff exactly as retreat()
+__device__ __forceinline__ void retreat_xy(int &PX8, int &PY, f32x2 &f, f32x2 w) {
+  const f32x2 t = f - w;
+  int kx, ky;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(kx) : "v"(t.x));
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ky) : "v"(t.y));
+  PX8 += kx << 3;
+  PY += ky;
+  f = f32x2{__builtin_amdgcn_fractf(t.x), __builtin_amdgcn_fractf(t.y)};
+}
+
+template <class C, bool GEN>
+__global__ __launch_bounds__(C::kThreads, 4) void semilag_window3(
+    const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out, double *__restrict__ disp,
+    const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume, float outval,
+    int row0, int rows, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd, float guard, int cells,
+    unsigned long long *__restrict__ stats) {
+  const int b = blockIdx.x;
+  int tile;
+  if (cells) {
+    const int xcd = b % kNumXcd, l = b / kNumXcd;
+    const int cw = tiles_x / kNumXcd, ch = (n_tiles / tiles_x) / kNumXcd, per_cell = cw * ch;
+    const int cy = l / per_cell, r = l - cy * per_cell;
+    const int cx = (xcd + kNumXcd - cy) & (kNumXcd - 1);
+    tile = (cy * ch + r / cw) * tiles_x + cx * cw + r % cw;
+  } else {
+    tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
+  }
+  if (tile >= n_tiles) return;  // the whole workgroup
+  const int lane = threadIdx.x & (kTileX - 1);
+  const int xt = (tile % tiles_x) * kTileX + lane;
+  const int yt = row0 + (tile / tiles_x) * C::kTileY + static_cast<int>(threadIdx.x / kTileX) * kWinRows;
+  const int x = min(xt, n - 1);
+  const size_t plane = static_cast<size_t>(m) * n;
+  Fields F;
+  F.u0 = vel;
+  F.v0 = vel + plane;
+  F.p0 = precip;
+  const int plane_bytes = static_cast<int>(plane * sizeof(float));
+  F.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel), 0, plane_bytes, 0x00020000);
+  F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
+  F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(precip), 0, plane_bytes, 0x00020000);
+  F.ruv = F.ru;
+  F.rpp = F.ru;
+  F.row_bytes = n * static_cast<int>(sizeof(float));
+  F.coef = nullptr;
+  F.cpad = 0;
+  F.minval = 0.f;
+  F.bmode = bmode;
+
+  __shared__ __attribute__((aligned(16))) float win_planes[3 * C::kW * C::kH];
+  __shared__ __attribute__((aligned(16))) int win_ctl[C::kCtlWords];
+  Window2 W;
+  W.u = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_planes));  // {u,v} pairs: two planes' worth
+  W.v = W.u;
+  W.p = W.u + 2u * C::kPlaneBytes;
+  W.ctl = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_ctl));
+  W.ox = W.oy = 0;
+  W.lo_x4 = W.lo_y = 0;
+  W.hi_x4 = W.hi_y = 0;
+  W.stats = stats;
+  if (threadIdx.x < 3) win_ctl[C::kCtlFlag / 4 + threadIdx.x] = 0;
+
+  int y[kWinRows], dx8[kWinRows], dy[kWinRows];
+  f32x2 f[kWinRows], vi[kWinRows], s_uv[kWinRows];
+  float sp[kWinRows];
+  bool live[kWinRows];
+  unsigned opix[kWinRows];
+#pragma unroll
+  for (int j = 0; j < kWinRows; ++j) {
+    live[j] = xt < n && yt + j < row0 + rows;
+    y[j] = min(yt + j, m - 1);
+    opix[j] = static_cast<unsigned>(__mul24(y[j] - row0, n) + x) << 2;
+    int px = x, py = y[j];
+    float ifx = 0.f, ify = 0.f, ivx = 0.f, ivy = 0.f;
+    if (resume) {
+      split_displacement(disp[static_cast<size_t>(y[j]) * n + x], px, ifx);
+      split_displacement(disp[plane + static_cast<size_t>(y[j]) * n + x], py, ify);
+    } else {
+      const unsigned pix = static_cast<unsigned>(__mul24(y[j], n) + x) << 2;
+      ivx = ld(F.u0, pix) * first_scale;  // first increment is NOT divided by n_iter (semilagrangian.py:202)
+      ivy = ld(F.v0, pix) * first_scale;
+    }
+    dx8[j] = px * 8;
+    dy[j] = py;
+    f[j] = f32x2{ifx, ify};
+    vi[j] = f32x2{ivx, ivy};
+    sp[j] = 0.f;
+  }
+  const float move_scale = guard * static_cast<float>(n_iter);
+  __syncthreads();
+  int phase = 0;
+  win2_update<C>(F, W, phase, true, dx8, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
+  phase = 1;
+  if (resume) {
+    win3_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+    const float s0 = scale[0];
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * s0;
+  }
+  const float lostval = (bmode == kModeNearest || bmode == kModeGridConstant) ? __builtin_nanf("") : outval;
+#pragma unroll
+  for (int j = 0; j < kWinRows; ++j) vi[j] = vi[j] * 0.5f;  // the increment is only ever used halved (exact)
+
+  for (int t = 0; t < T; ++t) {
+    const float s = scale[t];
+    const float half_s = 0.5f * s;
+    for (int k = 0; k < n_iter; ++k) {
+      int mx8[kWinRows], my[kWinRows];
+      f32x2 g[kWinRows];
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) {
+        mx8[j] = dx8[j];
+        my[j] = dy[j];
+        g[j] = f[j];
+        retreat_xy(mx8[j], my[j], g[j], vi[j]);  // midpoint rule (:213), vi = Vi / 2
+      }
+      win3_sample<C, kVel, GEN>(F, W, mx8, my, g, m, n, outval, s_uv, sp);
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) retreat_xy(dx8[j], dy[j], f[j], s_uv[j] * s);
+      if (k == n_iter - 1) {
+        win3_sample<C, kVel | kPrecip, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+      } else {
+        win3_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+      }
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * half_s;
+    }
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      const float val = lost(f[j].x, f[j].y) ? lostval : sp[j];
+      if (live[j]) __builtin_nontemporal_store(val, reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
+    }
+    out += static_cast<size_t>(rows) * n;
+    if (t + 1 < T) {
+      win2_update<C>(F, W, phase, false, dx8, dy, vi[0].x, vi[0].y, move_scale, m, n);
+      phase = phase == 2 ? 0 : phase + 1;
+    }
+  }
+
+  if (disp != nullptr) {
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      if (!live[j]) continue;
+      disp[static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.ox + (dx8[j] >> 3) - x) + static_cast<double>(f[j].x);
+      disp[plane + static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.oy + dy[j] - y[j]) + static_cast<double>(f[j].y);
+    }
+  }
+}
+
 // the planar window kernel needs no packed copy of anything
 bool semilag_window2_eligible(const SemilagArgs &a) {
   return a.precip != nullptr && a.order == 1 && a.n_iter >= 1 && a.n % 4 == 0 && a.n >= Win2x8::kW && a.m >= Win2x8::kH &&
@@ -1067,6 +1302,17 @@ static hipError_t launch_window2(const SemilagArgs &a, hipStream_t stream) {
     if (g_win_stats == nullptr && hipMalloc(&g_win_stats, 4 * sizeof(unsigned long long)) != hipSuccess) g_win_stats = nullptr;
     if (g_win_stats != nullptr) (void)hipMemsetAsync(g_win_stats, 0, 4 * sizeof(unsigned long long), stream);
   }
+  if constexpr (C::kUV) {
+    if (a.bmode != 0) {
+      hipLaunchKernelGGL((semilag_window3<C, true>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
+                         a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x,
+                         n_tiles, tiles_per_xcd, guard, cells, g_win_stats);
+    } else {
+      hipLaunchKernelGGL((semilag_window3<C, false>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
+                         a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x,
+                         n_tiles, tiles_per_xcd, guard, cells, g_win_stats);
+    }
+  } else {
   if (a.bmode != 0) {
     hipLaunchKernelGGL((semilag_window2<C, true>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
                        a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
@@ -1075,6 +1321,7 @@ static hipError_t launch_window2(const SemilagArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL((semilag_window2<C, false>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
                        a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
                        tiles_per_xcd, guard, cells, g_win_stats);
+  }
   }
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess && want_stats && g_win_stats != nullptr) {
@@ -1153,7 +1400,8 @@ bool semilag_uses_window(const SemilagArgs &a) {
 }
 
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
-  if (semilag_uses_window(a)) return launch_window2<Win2x8>(a, stream);
+  static const bool hybrid = std::getenv("PYSTEPS_HIP_SL_HYBRID") != nullptr;  // development knob
+  if (semilag_uses_window(a)) return hybrid ? launch_window2<Win3x8>(a, stream) : launch_window2<Win2x8>(a, stream);
   if (a.vel_packed != nullptr && a.field_pairs != nullptr && a.order == 1) return launch_variant<1, kModePacked2>(a, stream);
   if (a.vel_packed != nullptr) return launch_variant<1, kModePacked>(a, stream);
   return launch_variant<1, kModeDirect>(a, stream);
