@@ -793,7 +793,7 @@ def main():
         "roofline": {
             # the extrapolation call between two HIP events on the library stream: ONE kernel since round 5
             # (the workgroup-window kernel reads the planes as they are; rounds 2-4: kernel + two layout passes)
-            "kernel": "semilag_window2",
+            "kernel": "semilag_window",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -1116,7 +1116,7 @@ def main_config5(args, dist):
                             "extrapolation" % len(rows),
                 "rccl_ranks": dist.world,
             },
-            "roofline": {"kernel": "semilag_window2 (row band of rank 0)", "bound": "hbm", "achieved": alg_bytes / (sl_ms * 1e-3) / 1e9,
+            "roofline": {"kernel": "semilag_window (row band of rank 0)", "bound": "hbm", "achieved": alg_bytes / (sl_ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / (sl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "alg_bytes_per_launch": alg_bytes, "kernel_ms": sl_ms, "traffic": None,
                          "note": "kernel_ms brackets the band's extrapolation call (velocity / field packing passes included)"},

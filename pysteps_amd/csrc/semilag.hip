@@ -584,9 +584,7 @@ __global__ __launch_bounds__(kTileX *kDirectWaves) void semilag_fused(
 //    next step covers.  The new window is placed with its slack AHEAD of the motion (it then lasts
 //    slack / speed lead steps: ~5 at 6 px per step), filled by coalesced dwordx4 loads + ds_write_b128,
 //    and the lanes re-base their offsets.
-// What round 5 measured on the way (profiles/r05/): an interleaved {u,v} window with the arithmetic of the
-// gather kernel (variants 9 - 11: 73 VALU instructions per pixel and lead step, SIMDs 70 % busy) ran at the
-// gather kernel's speed; the planar window with pair-packed arithmetic below is the one that is kept.
+//  * XCD cells, guards, what bounds the kernel now and everything round 5 measured on the way: DESIGN.md 3.1 / 9.
 constexpr int kWinRows = 4;   // image rows per lane
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -613,19 +611,12 @@ __device__ __forceinline__ int smax(int a, int b) {
 // debug counters of the window kernel (PYSTEPS_HIP_SL_STATS=1): printed after every launch, which then waits
 static unsigned long long *g_win_stats = nullptr;
 
-// ---- planar window, two pixels per packed instruction ---------------------------------------------
-// The window holds u, v and the field as three planes of
-// identical geometry (one LDS address per tap for all of them) and every floating-point operation of the
-// trajectory update, the weights and the three blends runs as ONE v_pk_*_f32 on the two vertically adjacent
-// pixels of a lane: same operations, same order, same rounding per pixel (no contraction in this file) -
-// bit-identical - at about half the instructions.  The once-per-lead-step agreement is reduced to eight
-// v_readlane and scalar compares; boxes are exchanged only when a wave asked for a new window.
-template <int WAVES, int WW, int WH, bool UV = false>
-struct Win2Cfg {
+// ---- the window's geometry and control block ----------------------------------------------------------
+template <int WAVES, int WW, int WH>
+struct WinCfg {
   static constexpr int kWaves = WAVES, kW = WW, kH = WH;
-  // UV: u and v interleaved as {u,v} pairs in ONE window plane (8-byte texels, column offsets pre-scaled by 8)
-  static constexpr bool kUV = UV;
-  static constexpr int kXShift = UV ? 3 : 2;
+  // u and v are interleaved as {u,v} pairs in ONE window plane (8-byte texels): column offsets are pre-scaled by 8
+  static constexpr int kXShift = 3;
   static constexpr int kTileY = kWinRows * WAVES;
   static constexpr unsigned kPitch4 = WW * 4u;          // bytes per window row of one plane
   static constexpr unsigned kPlaneBytes = WW * WH * 4u;
@@ -634,11 +625,10 @@ struct Win2Cfg {
   static constexpr unsigned kCtlVel = 16u * WAVES, kCtlFlag = kCtlVel + 8u;  // byte offsets in the control block
   static constexpr int kCtlWords = 4 * WAVES + 2 + 3 + 3;
 };
-using Win2x8 = Win2Cfg<8, 96, 64>;
-using Win3x8 = Win2Cfg<8, 96, 64, true>;
+using Win8 = WinCfg<8, 96, 64>;
 
-struct Window2 {
-  unsigned u, v, p;  // LDS byte addresses of the three planes
+struct Window {
+  unsigned uv, p;    // LDS byte addresses of the {u,v} plane and of the field plane
   unsigned ctl;
   int ox, oy;        // image position of the window's first texel (uniform over the workgroup)
   // where the corner samples of a patch may be without asking for a new window (pre-scaled columns / rows):
@@ -647,117 +637,15 @@ struct Window2 {
   unsigned long long *stats;
 };
 
-__device__ __forceinline__ void win2_count(const Window2 &W, int which) {
+__device__ __forceinline__ void win_count(const Window &W, int which) {
   if (W.stats != nullptr && (threadIdx.x & 63) == 0) atomicAdd(W.stats + which, 1ull);
-}
-
-// two trajectories of a lane (pixels 2q and 2q+1) along one axis: P -= floor stuff exactly as retreat()
-template <int SHIFT>
-__device__ __forceinline__ void retreat2(int &P0, int &P1, f32x2 &f, f32x2 w) {
-  const f32x2 t = f - w;
-  int k0, k1;
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k0) : "v"(t.x));
-  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k1) : "v"(t.y));
-  P0 += k0 << SHIFT;
-  P1 += k1 << SHIFT;
-  f = f32x2{__builtin_amdgcn_fractf(t.x), __builtin_amdgcn_fractf(t.y)};
-}
-
-constexpr int kWinPairs = kWinRows / 2;
-
-template <class C, int WHAT, bool GEN>
-__device__ __forceinline__ void win2_sample(const Fields &F, const Window2 &W, const int (&dx4)[kWinRows],
-                                            const int (&dy)[kWinRows], const f32x2 (&fx)[kWinPairs],
-                                            const f32x2 (&fy)[kWinPairs], int m, int n, float outval,
-                                            f32x2 (&su)[kWinPairs], f32x2 (&sv)[kWinPairs], f32x2 (&sp)[kWinPairs]) {
-  constexpr bool kWithP = (WHAT & kPrecip) != 0;
-  unsigned mx = static_cast<unsigned>(dx4[0]), my = static_cast<unsigned>(dy[0]);
-#pragma unroll
-  for (int j = 1; j < kWinRows; ++j) {
-    mx = max(mx, static_cast<unsigned>(dx4[j]));
-    my = max(my, static_cast<unsigned>(dy[j]));
-  }
-  const bool ok = mx <= (C::kW - 2) * 4u && my <= static_cast<unsigned>(C::kH - 2);
-  if (__builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true)) {
-    win2_count(W, 0);
-    // Taps by single-address ds_read_b32 (2 LDS cycles per wave-instruction; the compiler would merge the taps of
-    // one pixel into ds_read2_b32 and then move every value into the pixel-pair registers the packed blends want).
-    // The reads are invisible to the compiler's counters: one s_waitcnt, with every destination tied to it.
-    float ru[kWinRows][4], rv[kWinRows][4], rp[kWinRows][4];
-#pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
-      const unsigned a = __umul24(static_cast<unsigned>(dy[j]), C::kPitch4) + static_cast<unsigned>(dx4[j]) + W.u;
-#define PSH_TAPS(DST, BASE)                                                                                          \
-  asm volatile("ds_read_b32 %0, %4 offset:%c5\n\tds_read_b32 %1, %4 offset:%c6\n\tds_read_b32 %2, %4 offset:%c7\n\t" \
-               "ds_read_b32 %3, %4 offset:%c8"                                                                       \
-               : "=&v"(DST[j][0]), "=&v"(DST[j][1]), "=&v"(DST[j][2]), "=&v"(DST[j][3])                              \
-               : "v"(a), "i"(BASE), "i"(BASE + 4u), "i"(BASE + C::kPitch4), "i"(BASE + C::kPitch4 + 4u))
-      PSH_TAPS(ru, 0u);
-      PSH_TAPS(rv, C::kPlaneBytes);
-      if (kWithP) PSH_TAPS(rp, 2u * C::kPlaneBytes);
-#undef PSH_TAPS
-    }
-#define PSH_TIE4(A, J) "+v"(A[J][0]), "+v"(A[J][1]), "+v"(A[J][2]), "+v"(A[J][3])
-    asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(ru, 0), PSH_TIE4(ru, 1), PSH_TIE4(ru, 2), PSH_TIE4(ru, 3), PSH_TIE4(rv, 0), PSH_TIE4(rv, 1));
-    asm volatile("" : PSH_TIE4(rv, 2), PSH_TIE4(rv, 3));
-    if (kWithP) asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1), PSH_TIE4(rp, 2), PSH_TIE4(rp, 3));
-    // (blending the first pixel pair while the second pair's reads were still in flight - waits of lgkmcnt(15) and
-    // lgkmcnt(0) - was measured: 1.217 against 1.206 ms, profiles/r05/d_window_default_knobs_short_calls.txt)
-#pragma unroll
-    for (int q = 0; q < kWinPairs; ++q) {
-      f32x2 tu[4], tv[4], tp[4];  // [tap 00, 01, 10, 11], .x = pixel 2q, .y = pixel 2q+1
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        tu[k] = f32x2{ru[2 * q][k], ru[2 * q + 1][k]};
-        tv[k] = f32x2{rv[2 * q][k], rv[2 * q + 1][k]};
-        if (kWithP) tp[k] = f32x2{rp[2 * q][k], rp[2 * q + 1][k]};
-      }
-      // make_weights() and blend() on two pixels at once
-      const f32x2 gx = 1.f - fx[q], gy = 1.f - fy[q];
-      const f32x2 w00 = gy * gx, w01 = gy * fx[q], w10 = fy[q] * gx, w11 = fy[q] * fx[q];
-      f32x2 au = w00 * tu[0];
-      au = __builtin_elementwise_fma(w01, tu[1], au);
-      au = __builtin_elementwise_fma(w10, tu[2], au);
-      su[q] = __builtin_elementwise_fma(w11, tu[3], au);
-      f32x2 av = w00 * tv[0];
-      av = __builtin_elementwise_fma(w01, tv[1], av);
-      av = __builtin_elementwise_fma(w10, tv[2], av);
-      sv[q] = __builtin_elementwise_fma(w11, tv[3], av);
-      if (kWithP) {
-        f32x2 ap = w00 * tp[0];
-        ap = __builtin_elementwise_fma(w01, tp[1], ap);
-        ap = __builtin_elementwise_fma(w10, tp[2], ap);
-        sp[q] = __builtin_elementwise_fma(w11, tp[3], ap);
-      }
-    }
-#undef PSH_TIE4
-  } else {
-    win2_count(W, 1);
-    int X[kWinRows], Y[kWinRows];
-    float sfx[kWinRows], sfy[kWinRows], ssu[kWinRows], ssv[kWinRows], ssp[kWinRows];
-#pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
-      X[j] = W.ox + (dx4[j] >> 2);
-      Y[j] = W.oy + dy[j];
-      sfx[j] = (j & 1) ? fx[j / 2].y : fx[j / 2].x;
-      sfy[j] = (j & 1) ? fy[j / 2].y : fy[j / 2].x;
-      ssp[j] = 0.f;
-    }
-    sample_at<kWinRows, 1, WHAT, kModeDirect, GEN>(F, X, Y, sfx, sfy, m, n, outval, ssu, ssv, ssp);
-#pragma unroll
-    for (int q = 0; q < kWinPairs; ++q) {
-      su[q] = f32x2{ssu[2 * q], ssu[2 * q + 1]};
-      sv[q] = f32x2{ssv[2 * q], ssv[2 * q + 1]};
-      if (kWithP) sp[q] = f32x2{ssp[2 * q], ssp[2 * q + 1]};
-    }
-  }
 }
 
 // the box of a patch's corner samples (window-relative, pre-scaled columns / rows): eight v_readlane, scalar min / max
 struct WinBox {
   int lo4, hi4, loy, hiy;
 };
-__device__ __forceinline__ WinBox win2_corners(const int (&dx4)[kWinRows], const int (&dy)[kWinRows]) {
+__device__ __forceinline__ WinBox win_corners(const int (&dx4)[kWinRows], const int (&dy)[kWinRows]) {
   const int xa = __builtin_amdgcn_readlane(dx4[0], 0), xb = __builtin_amdgcn_readlane(dx4[0], 63);
   const int xc = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 0), xd = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 63);
   const int ya = __builtin_amdgcn_readlane(dy[0], 0), yb = __builtin_amdgcn_readlane(dy[0], 63);
@@ -768,7 +656,7 @@ __device__ __forceinline__ WinBox win2_corners(const int (&dx4)[kWinRows], const
 
 // lane 0: the wave's box (one 16-byte store), wave 0 also its direction of travel
 template <class C>
-__device__ __forceinline__ void win2_publish(const Window2 &W, int wave, const WinBox &bx, float vx_lane, float vy_lane) {
+__device__ __forceinline__ void win_publish(const Window &W, int wave, const WinBox &bx, float vx_lane, float vy_lane) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
   lds_int *ctl = (lds_int *)(size_t)W.ctl;
@@ -782,7 +670,7 @@ __device__ __forceinline__ void win2_publish(const Window2 &W, int wave, const W
 // Every wave of the workgroup, with every wave's box published and nobody reading the window any more: place the
 // new window ahead of the motion, re-base the offsets, fill it.  (The caller orders the LDS writes before the next reader.)
 template <class C>
-__device__ __forceinline__ void win2_place_and_fill(const Fields &F, Window2 &W, bool force, int (&dx4)[kWinRows],
+__device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, bool force, int (&dx4)[kWinRows],
                                                     int (&dy)[kWinRows], float move_scale, int m, int n) {
   lds_int *ctl = (lds_int *)(size_t)W.ctl;
   int ulo4 = 0x7fffffff, uhi4 = -0x7fffffff, uloy = 0x7fffffff, uhiy = -0x7fffffff;
@@ -813,7 +701,7 @@ __device__ __forceinline__ void win2_place_and_fill(const Fields &F, Window2 &W,
   W.hi_y = C::kH - 2 - (wvy > 0.f ? 1 : gy);
   // (a tile parked at the image border keeps asking: the window it would get is the one it has)
   if (!force && nox == W.ox && noy == W.oy) return;
-  win2_count(W, 2);
+  win_count(W, 2);
   const int ddx4 = (nox - W.ox) << C::kXShift, ddy = noy - W.oy;
 #pragma unroll
   for (int j = 0; j < kWinRows; ++j) {
@@ -840,14 +728,9 @@ __device__ __forceinline__ void win2_place_and_fill(const Fields &F, Window2 &W,
 #pragma unroll
   for (int k = 0; k < kRounds; ++k) {
     const unsigned l = 16u * min(tid + C::kThreads * k, C::kItems - 1);
-    if (C::kUV) {
-      // W.u is the {u,v} plane (W.v is not used): four pixels = two 16-byte items
-      *(lds_u32x4 *)(size_t)(W.u + 2u * l) = u32x4{bu[k].x, bv[k].x, bu[k].y, bv[k].y};
-      *(lds_u32x4 *)(size_t)(W.u + 2u * l + 16u) = u32x4{bu[k].z, bv[k].z, bu[k].w, bv[k].w};
-    } else {
-      *(lds_u32x4 *)(size_t)(W.u + l) = bu[k];
-      *(lds_u32x4 *)(size_t)(W.v + l) = bv[k];
-    }
+    // four pixels of the {u,v} plane = two 16-byte items
+    *(lds_u32x4 *)(size_t)(W.uv + 2u * l) = u32x4{bu[k].x, bv[k].x, bu[k].y, bv[k].y};
+    *(lds_u32x4 *)(size_t)(W.uv + 2u * l + 16u) = u32x4{bu[k].z, bv[k].z, bu[k].w, bv[k].w};
     *(lds_u32x4 *)(size_t)(W.p + l) = bp[k];
   }
 }
@@ -857,15 +740,15 @@ __device__ __forceinline__ void win2_place_and_fill(const Fields &F, Window2 &W,
 // second barrier.  `phase` cycles through three flag words so that clearing the next one never races with a wave
 // that still has to read it.
 template <class C>
-__device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int phase, bool force, int (&dx4)[kWinRows],
+__device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase, bool force, int (&dx4)[kWinRows],
                                             int (&dy)[kWinRows], float vx_lane, float vy_lane, float move_scale, int m,
                                             int n) {
   const int lane = threadIdx.x & 63, wave = rfl(static_cast<int>(threadIdx.x >> 6));
   lds_int *ctl = (lds_int *)(size_t)W.ctl;
-  const WinBox bx = win2_corners(dx4, dy);
+  const WinBox bx = win_corners(dx4, dy);
   const bool near = force || bx.lo4 < W.lo_x4 || bx.hi4 > W.hi_x4 || bx.loy < W.lo_y || bx.hiy > W.hi_y;
   if (lane == 0) {
-    win2_publish<C>(W, wave, bx, vx_lane, vy_lane);
+    win_publish<C>(W, wave, bx, vx_lane, vy_lane);
     if (near) ctl[C::kCtlFlag / 4 + phase] = 1;
     if (wave == 0) ctl[C::kCtlFlag / 4 + (phase == 2 ? 0 : phase + 1)] = 0;
   }
@@ -873,7 +756,7 @@ __device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int pha
   if (rfl(ctl[C::kCtlFlag / 4 + phase]) == 0) return;
   // every wave is past the barrier: nobody reads the old window any more.  The boxes of this step are overwritten
   // after the barrier below - every wave has read them by then
-  win2_place_and_fill<C>(F, W, force, dx4, dy, move_scale, m, n);
+  win_place_and_fill<C>(F, W, force, dx4, dy, move_scale, m, n);
   win_barrier();
 }
 
@@ -883,183 +766,19 @@ __device__ __forceinline__ void win2_update(const Fields &F, Window2 &W, int pha
 // a larger box, the window's slack shrinks and it is refilled twice as often (9.6 instead of 5 fills per workgroup;
 // profiles/r05/f_window_free_running_timings.txt).  The barrier is what keeps the window economical.)
 
-template <class C, bool GEN>
-__global__ __launch_bounds__(C::kThreads, 4) void semilag_window2(
-    const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out, double *__restrict__ disp,
-    const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume, float outval,
-    int row0, int rows, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd, float guard, int cells,
-    unsigned long long *__restrict__ stats) {
-  // Block b runs on XCD b % 8.  How long a workgroup takes depends on how fast its tile's samples travel (window
-  // fills), and motion fields vary smoothly across the image: with one contiguous band of tiles per XCD the XCD
-  // that owns the fastest band finishes last.  `cells`: the tile grid is cut into 8 x 8 cells and XCD k owns the
-  // cells (cx + cy) % 8 == k - one in every row band and every column band - each cell still a compact block of
-  // tiles for its L2.  (Tile grids that do not divide by 8 keep the bands.)
-  const int b = blockIdx.x;
-  int tile;
-  if (cells) {
-    const int xcd = b % kNumXcd, l = b / kNumXcd;
-    const int cw = tiles_x / kNumXcd, ch = (n_tiles / tiles_x) / kNumXcd, per_cell = cw * ch;
-    const int cy = l / per_cell, r = l - cy * per_cell;
-    const int cx = (xcd + kNumXcd - cy) & (kNumXcd - 1);
-    tile = (cy * ch + r / cw) * tiles_x + cx * cw + r % cw;
-  } else {
-    tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
-  }
-  if (tile >= n_tiles) return;  // the whole workgroup
-  const int lane = threadIdx.x & (kTileX - 1);
-  const int xt = (tile % tiles_x) * kTileX + lane;
-  const int yt = row0 + (tile / tiles_x) * C::kTileY + static_cast<int>(threadIdx.x / kTileX) * kWinRows;
-  const int x = min(xt, n - 1);
-  const size_t plane = static_cast<size_t>(m) * n;
-  Fields F;
-  F.u0 = vel;
-  F.v0 = vel + plane;
-  F.p0 = precip;
-  const int plane_bytes = static_cast<int>(plane * sizeof(float));
-  F.ru = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel), 0, plane_bytes, 0x00020000);
-  F.rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(vel + plane), 0, plane_bytes, 0x00020000);
-  F.rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(precip), 0, plane_bytes, 0x00020000);
-  F.ruv = F.ru;  // (no packed planes in this kernel: the fallback is the one-plane-per-component gather path)
-  F.rpp = F.ru;
-  F.row_bytes = n * static_cast<int>(sizeof(float));
-  F.coef = nullptr;
-  F.cpad = 0;
-  F.minval = 0.f;
-  F.bmode = bmode;
-
-  __shared__ __attribute__((aligned(16))) float win_planes[3 * C::kW * C::kH];
-  __shared__ __attribute__((aligned(16))) int win_ctl[C::kCtlWords];
-  Window2 W;
-  W.u = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_planes));
-  W.v = W.u + C::kPlaneBytes;
-  W.p = W.v + C::kPlaneBytes;
-  W.ctl = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_ctl));
-  W.ox = W.oy = 0;
-  W.lo_x4 = W.lo_y = 0;
-  W.hi_x4 = W.hi_y = 0;
-  W.stats = stats;
-  if (threadIdx.x < 3) win_ctl[C::kCtlFlag / 4 + threadIdx.x] = 0;
-
-  int y[kWinRows], dx4[kWinRows], dy[kWinRows];
-  f32x2 fx[kWinPairs], fy[kWinPairs], vix[kWinPairs], viy[kWinPairs], su[kWinPairs], sv[kWinPairs], sp[kWinPairs];
-  bool live[kWinRows];
-  unsigned opix[kWinRows];
-  float ifx[kWinRows], ify[kWinRows], ivx[kWinRows], ivy[kWinRows];
-#pragma unroll
-  for (int j = 0; j < kWinRows; ++j) {
-    live[j] = xt < n && yt + j < row0 + rows;
-    y[j] = min(yt + j, m - 1);
-    opix[j] = static_cast<unsigned>(__mul24(y[j] - row0, n) + x) << 2;
-    int px = x, py = y[j];
-    ifx[j] = ify[j] = 0.f;
-    if (resume) {
-      split_displacement(disp[static_cast<size_t>(y[j]) * n + x], px, ifx[j]);
-      split_displacement(disp[plane + static_cast<size_t>(y[j]) * n + x], py, ify[j]);
-    }
-    dx4[j] = px * 4;  // relative to the origin (0, 0) until the first window is placed
-    dy[j] = py;
-    ivx[j] = ivy[j] = 0.f;
-    if (!resume) {
-      // first increment is NOT divided by n_iter (semilagrangian.py:202)
-      const unsigned pix = static_cast<unsigned>(__mul24(y[j], n) + x) << 2;
-      ivx[j] = ld(F.u0, pix) * first_scale;
-      ivy[j] = ld(F.v0, pix) * first_scale;
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < kWinPairs; ++q) {
-    fx[q] = f32x2{ifx[2 * q], ifx[2 * q + 1]};
-    fy[q] = f32x2{ify[2 * q], ify[2 * q + 1]};
-    vix[q] = f32x2{ivx[2 * q], ivx[2 * q + 1]};
-    viy[q] = f32x2{ivy[2 * q], ivy[2 * q + 1]};
-    sp[q] = f32x2{0.f, 0.f};
-  }
-  const float move_scale = guard * static_cast<float>(n_iter);  // lead step = n_iter sub-steps of two half increments
-  __syncthreads();  // the flag words are cleared
-  int phase = 0;
-  win2_update<C>(F, W, phase, true, dx4, dy, 0.5f * vix[0].x, 0.5f * viy[0].x, move_scale, m, n);
-  phase = 1;
-  if (resume) {
-    win2_sample<C, kVel, GEN>(F, W, dx4, dy, fx, fy, m, n, outval, su, sv, sp);
-    const float s0 = scale[0];
-#pragma unroll
-    for (int q = 0; q < kWinPairs; ++q) {
-      vix[q] = su[q] * s0;
-      viy[q] = sv[q] * s0;
-    }
-  }
-  const float lostval = (bmode == kModeNearest || bmode == kModeGridConstant) ? __builtin_nanf("") : outval;
-  // the increment is only ever used halved (midpoint rule): carry Vi / 2 (exact)
-#pragma unroll
-  for (int q = 0; q < kWinPairs; ++q) {
-    vix[q] = vix[q] * 0.5f;
-    viy[q] = viy[q] * 0.5f;
-  }
-
-  for (int t = 0; t < T; ++t) {
-    const float s = scale[t];
-    const float half_s = 0.5f * s;
-    for (int k = 0; k < n_iter; ++k) {
-      int mx4[kWinRows], my[kWinRows];
-      f32x2 gx[kWinPairs], gy[kWinPairs];
-#pragma unroll
-      for (int q = 0; q < kWinPairs; ++q) {
-        mx4[2 * q] = dx4[2 * q], mx4[2 * q + 1] = dx4[2 * q + 1];
-        my[2 * q] = dy[2 * q], my[2 * q + 1] = dy[2 * q + 1];
-        gx[q] = fx[q];
-        gy[q] = fy[q];
-        retreat2<2>(mx4[2 * q], mx4[2 * q + 1], gx[q], vix[q]);  // midpoint rule (:213), vix = Vi / 2
-        retreat2<0>(my[2 * q], my[2 * q + 1], gy[q], viy[q]);
-      }
-      win2_sample<C, kVel, GEN>(F, W, mx4, my, gx, gy, m, n, outval, su, sv, sp);
-#pragma unroll
-      for (int q = 0; q < kWinPairs; ++q) {
-        retreat2<2>(dx4[2 * q], dx4[2 * q + 1], fx[q], su[q] * s);
-        retreat2<0>(dy[2 * q], dy[2 * q + 1], fy[q], sv[q] * s);
-      }
-      if (k == n_iter - 1) {
-        win2_sample<C, kVel | kPrecip, GEN>(F, W, dx4, dy, fx, fy, m, n, outval, su, sv, sp);
-      } else {
-        win2_sample<C, kVel, GEN>(F, W, dx4, dy, fx, fy, m, n, outval, su, sv, sp);
-      }
-#pragma unroll
-      for (int q = 0; q < kWinPairs; ++q) {
-        vix[q] = su[q] * half_s;
-        viy[q] = sv[q] * half_s;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
-      const float fxs = (j & 1) ? fx[j / 2].y : fx[j / 2].x, fys = (j & 1) ? fy[j / 2].y : fy[j / 2].x;
-      float val = (j & 1) ? sp[j / 2].y : sp[j / 2].x;
-      val = lost(fxs, fys) ? lostval : val;
-      if (live[j]) __builtin_nontemporal_store(val, reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
-    }
-    out += static_cast<size_t>(rows) * n;
-    if (t + 1 < T) {
-      win2_update<C>(F, W, phase, false, dx4, dy, vix[0].x, viy[0].x, move_scale, m, n);
-      phase = phase == 2 ? 0 : phase + 1;
-    }
-  }
-
-  if (disp != nullptr) {
-#pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
-      if (!live[j]) continue;
-      const float fxs = (j & 1) ? fx[j / 2].y : fx[j / 2].x, fys = (j & 1) ? fy[j / 2].y : fy[j / 2].x;
-      disp[static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.ox + (dx4[j] >> 2) - x) + static_cast<double>(fxs);
-      disp[plane + static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.oy + dy[j] - y[j]) + static_cast<double>(fys);
-    }
-  }
-}
-
-// ---- hybrid window (experiment): {u,v} interleaved in LDS, x / y-paired arithmetic ------------------------
-// Same window, same protocol; the velocity taps are ds_read_b64 {u,v} pairs (8 LDS reads per pixel and lead step for
-// the velocity instead of 16), the trajectory update and the weights run as v_pk_*_f32 on the (x, y) pair of ONE
-// pixel, the velocity blend on the (u, v) pair with the weights broadcast by op_sel, the field blend as four scalar
-// FMAs: 12 LDS reads and ~51 VALU instructions per pixel and lead step against 21 and 54.
+// ---- sampling from the window -------------------------------------------------------------------------
+// The velocity taps are ds_read_b64 {u,v} pairs, the field taps ds_read_b32 - single-address reads (2 LDS cycles per
+// wave-instruction; the two-address forms the compiler would merge them into take 8 / 4), invisible to the compiler's
+// counters: one s_waitcnt with every destination tied to it.  The trajectory update and the weights run as
+// v_pk_*_f32 on the (x, y) pair of a pixel, the velocity blend on its (u, v) pair with the weights broadcast by
+// op_sel, same operations, same order, same rounding per component (no contraction in this file) - bit-identical
+// with the gather kernels - at 12 LDS reads and ~54 VALU instructions per pixel and lead step.
+// (Round 5 measured two other forms of the same window: u, v and the field as three planes with every
+// floating-point operation packed over the two vertically adjacent pixels of a lane - 21 LDS reads, 54 VALU:
+// 1.200 against 1.158 ms - and the gather kernel's arithmetic on a {u,v} window - 73 VALU: 1.28 ms;
+// profiles/r05/g_window_hybrid_timings.txt, b_*, c_*.)
 template <class C, int WHAT, bool GEN>
-__device__ __forceinline__ void win3_sample(const Fields &F, const Window2 &W, const int (&dx8)[kWinRows],
+__device__ __forceinline__ void win_sample(const Fields &F, const Window &W, const int (&dx8)[kWinRows],
                                             const int (&dy)[kWinRows], const f32x2 (&f)[kWinRows], int m, int n,
                                             float outval, f32x2 (&s_uv)[kWinRows], float (&sp)[kWinRows]) {
   constexpr bool kWithP = (WHAT & kPrecip) != 0;
@@ -1071,18 +790,18 @@ __device__ __forceinline__ void win3_sample(const Fields &F, const Window2 &W, c
   }
   const bool ok = mx <= (C::kW - 2) * 8u && my <= static_cast<unsigned>(C::kH - 2);
   if (__builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true)) {
-    win2_count(W, 0);
+    win_count(W, 0);
     f32x2 t[kWinRows][4];
     float rp[kWinRows][4];
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
-      const unsigned a = __umul24(static_cast<unsigned>(dy[j]), 2u * C::kPitch4) + static_cast<unsigned>(dx8[j]) + W.u;
+      const unsigned a = __umul24(static_cast<unsigned>(dy[j]), 2u * C::kPitch4) + static_cast<unsigned>(dx8[j]) + W.uv;
       asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:%c5\n\t"
                    "ds_read_b64 %3, %4 offset:%c6"
                    : "=&v"(t[j][0]), "=&v"(t[j][1]), "=&v"(t[j][2]), "=&v"(t[j][3])
                    : "v"(a), "i"(2u * C::kPitch4), "i"(2u * C::kPitch4 + 8u));
       if (kWithP) {
-        const unsigned ap = ((a - W.u) >> 1) + W.p;
+        const unsigned ap = ((a - W.uv) >> 1) + W.p;
         asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:%c5\n\t"
                      "ds_read_b32 %3, %4 offset:%c6"
                      : "=&v"(rp[j][0]), "=&v"(rp[j][1]), "=&v"(rp[j][2]), "=&v"(rp[j][3])
@@ -1108,7 +827,7 @@ __device__ __forceinline__ void win3_sample(const Fields &F, const Window2 &W, c
       if (kWithP) sp[j] = fmaf(w11.x, rp[j][3], fmaf(wmid.y, rp[j][2], fmaf(wmid.x, rp[j][1], w00.x * rp[j][0])));
     }
   } else {
-    win2_count(W, 1);
+    win_count(W, 1);
     int X[kWinRows], Y[kWinRows];
     float sfx[kWinRows], sfy[kWinRows], ssu[kWinRows], ssv[kWinRows], ssp[kWinRows];
 #pragma unroll
@@ -1140,7 +859,7 @@ __device__ __forceinline__ void retreat_xy(int &PX8, int &PY, f32x2 &f, f32x2 w)
 }
 
 template <class C, bool GEN>
-__global__ __launch_bounds__(C::kThreads, 4) void semilag_window3(
+__global__ __launch_bounds__(C::kThreads, 4) void semilag_window(
     const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out, double *__restrict__ disp,
     const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume, float outval,
     int row0, int rows, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd, float guard, int cells,
@@ -1180,10 +899,9 @@ __global__ __launch_bounds__(C::kThreads, 4) void semilag_window3(
 
   __shared__ __attribute__((aligned(16))) float win_planes[3 * C::kW * C::kH];
   __shared__ __attribute__((aligned(16))) int win_ctl[C::kCtlWords];
-  Window2 W;
-  W.u = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_planes));  // {u,v} pairs: two planes' worth
-  W.v = W.u;
-  W.p = W.u + 2u * C::kPlaneBytes;
+  Window W;
+  W.uv = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_planes));  // 8-byte texels
+  W.p = W.uv + 2u * C::kPlaneBytes;
   W.ctl = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_ctl));
   W.ox = W.oy = 0;
   W.lo_x4 = W.lo_y = 0;
@@ -1220,10 +938,10 @@ __global__ __launch_bounds__(C::kThreads, 4) void semilag_window3(
   const float move_scale = guard * static_cast<float>(n_iter);
   __syncthreads();
   int phase = 0;
-  win2_update<C>(F, W, phase, true, dx8, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
+  win_update<C>(F, W, phase, true, dx8, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
   phase = 1;
   if (resume) {
-    win3_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+    win_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
     const float s0 = scale[0];
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * s0;
@@ -1245,13 +963,13 @@ __global__ __launch_bounds__(C::kThreads, 4) void semilag_window3(
         g[j] = f[j];
         retreat_xy(mx8[j], my[j], g[j], vi[j]);  // midpoint rule (:213), vi = Vi / 2
       }
-      win3_sample<C, kVel, GEN>(F, W, mx8, my, g, m, n, outval, s_uv, sp);
+      win_sample<C, kVel, GEN>(F, W, mx8, my, g, m, n, outval, s_uv, sp);
 #pragma unroll
       for (int j = 0; j < kWinRows; ++j) retreat_xy(dx8[j], dy[j], f[j], s_uv[j] * s);
       if (k == n_iter - 1) {
-        win3_sample<C, kVel | kPrecip, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+        win_sample<C, kVel | kPrecip, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
       } else {
-        win3_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+        win_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
       }
 #pragma unroll
       for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * half_s;
@@ -1263,7 +981,7 @@ __global__ __launch_bounds__(C::kThreads, 4) void semilag_window3(
     }
     out += static_cast<size_t>(rows) * n;
     if (t + 1 < T) {
-      win2_update<C>(F, W, phase, false, dx8, dy, vi[0].x, vi[0].y, move_scale, m, n);
+      win_update<C>(F, W, phase, false, dx8, dy, vi[0].x, vi[0].y, move_scale, m, n);
       phase = phase == 2 ? 0 : phase + 1;
     }
   }
@@ -1278,15 +996,15 @@ __global__ __launch_bounds__(C::kThreads, 4) void semilag_window3(
   }
 }
 
-// the planar window kernel needs no packed copy of anything
-bool semilag_window2_eligible(const SemilagArgs &a) {
-  return a.precip != nullptr && a.order == 1 && a.n_iter >= 1 && a.n % 4 == 0 && a.n >= Win2x8::kW && a.m >= Win2x8::kH &&
+// the window kernel reads the planes as they are: no packed copy of anything
+bool semilag_window_eligible(const SemilagArgs &a) {
+  return a.precip != nullptr && a.order == 1 && a.n_iter >= 1 && a.n % 4 == 0 && a.n >= Win8::kW && a.m >= Win8::kH &&
          reinterpret_cast<uintptr_t>(a.vel) % 16 == 0 && reinterpret_cast<uintptr_t>(a.precip) % 16 == 0 &&
          (static_cast<size_t>(a.m) * a.n) % 4 == 0;
 }
 
 template <class C>
-static hipError_t launch_window2(const SemilagArgs &a, hipStream_t stream) {
+static hipError_t launch_window(const SemilagArgs &a, hipStream_t stream) {
   const int tiles_x = (a.n + kTileX - 1) / kTileX;
   const int tiles_y = (a.rows + C::kTileY - 1) / C::kTileY;
   const int n_tiles = tiles_x * tiles_y;
@@ -1302,33 +1020,21 @@ static hipError_t launch_window2(const SemilagArgs &a, hipStream_t stream) {
     if (g_win_stats == nullptr && hipMalloc(&g_win_stats, 4 * sizeof(unsigned long long)) != hipSuccess) g_win_stats = nullptr;
     if (g_win_stats != nullptr) (void)hipMemsetAsync(g_win_stats, 0, 4 * sizeof(unsigned long long), stream);
   }
-  if constexpr (C::kUV) {
-    if (a.bmode != 0) {
-      hipLaunchKernelGGL((semilag_window3<C, true>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
-                         a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x,
-                         n_tiles, tiles_per_xcd, guard, cells, g_win_stats);
-    } else {
-      hipLaunchKernelGGL((semilag_window3<C, false>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
-                         a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x,
-                         n_tiles, tiles_per_xcd, guard, cells, g_win_stats);
-    }
-  } else {
   if (a.bmode != 0) {
-    hipLaunchKernelGGL((semilag_window2<C, true>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
+    hipLaunchKernelGGL((semilag_window<C, true>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
                        a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
                        tiles_per_xcd, guard, cells, g_win_stats);
   } else {
-    hipLaunchKernelGGL((semilag_window2<C, false>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
+    hipLaunchKernelGGL((semilag_window<C, false>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
                        a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
                        tiles_per_xcd, guard, cells, g_win_stats);
-  }
   }
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess && want_stats && g_win_stats != nullptr) {
     unsigned long long h[4] = {0, 0, 0, 0};
     if (hipMemcpyAsync(h, g_win_stats, sizeof(h), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipStreamSynchronize(stream) == hipSuccess)
-      std::fprintf(stderr, "semilag_window2<%d waves>: %dx%d T=%d: wave-passes through the window %llu, through the gathers %llu, "
+      std::fprintf(stderr, "semilag_window<%d waves>: %dx%d T=%d: wave-passes through the window %llu, through the gathers %llu, "
                    "window fills (per wave) %llu (%d workgroups x %d lead steps)\n", C::kWaves, a.m, a.n, a.T, h[0], h[1], h[2],
                    n_tiles, a.T);
   }
@@ -1394,14 +1100,13 @@ void set_semilag_variant(int v) { g_semilag_variant = v; }
 constexpr long long kWindowMinPasses = 2;
 
 bool semilag_uses_window(const SemilagArgs &a) {
-  if (!semilag_window2_eligible(a)) return false;
+  if (!semilag_window_eligible(a)) return false;
   if (g_semilag_variant == 12) return true;
   return g_semilag_variant == 0 && static_cast<long long>(a.T) * a.n_iter >= kWindowMinPasses;
 }
 
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {
-  static const bool hybrid = std::getenv("PYSTEPS_HIP_SL_HYBRID") != nullptr;  // development knob
-  if (semilag_uses_window(a)) return hybrid ? launch_window2<Win3x8>(a, stream) : launch_window2<Win2x8>(a, stream);
+  if (semilag_uses_window(a)) return launch_window<Win8>(a, stream);
   if (a.vel_packed != nullptr && a.field_pairs != nullptr && a.order == 1) return launch_variant<1, kModePacked2>(a, stream);
   if (a.vel_packed != nullptr) return launch_variant<1, kModePacked>(a, stream);
   return launch_variant<1, kModeDirect>(a, stream);

@@ -419,6 +419,52 @@ def test_kernel_variants_match_default(extrapolate, semilag_golden, variant):
         _lib.check(lib.psh_set_option(b"semilag_variant", 0))
 
 
+@pytest.mark.parametrize("field", ["vortex", "sink", "source", "jets", "fast"])
+def test_window_kernel_on_hard_motion_fields(extrapolate, field):
+    """The workgroup-window kernel (the default) against the gather kernels (``semilag_variant`` 7) bit for bit on motion
+    fields that stress what is new in it: a vortex (the tile's samples travel in different directions: boxes that do not
+    fit, waves falling back pass by pass), a sink and a source (tiles that shrink / grow over the lead steps), opposite jets
+    (a shear line through tiles), and motion too fast for the window's guard (16 px per step).  With a NaN hole in the
+    motion field, a NaN border in the advected field, a resumed displacement and a row band on top."""
+    from pysteps_amd import _lib, parallel
+    from pysteps_amd.device import DeviceArray
+    from tools import synth
+
+    m, n = 416, 608
+    y, x = np.mgrid[0:m, 0:n].astype(np.float64)
+    cy, cx = (m - 1) / 2.0, (n - 1) / 2.0
+    r = np.hypot(x - cx, y - cy) + 1e-9
+    if field == "vortex":
+        v = np.stack([-(y - cy) / 30.0, (x - cx) / 30.0])
+    elif field == "sink":
+        v = np.stack([(x - cx) / 40.0, (y - cy) / 40.0])  # positive velocity: samples travel towards lower coordinates
+    elif field == "source":
+        v = np.stack([-(x - cx) / 40.0, -(y - cy) / 40.0])
+    elif field == "jets":
+        v = np.stack([7.0 * np.tanh((y - cy) / 3.0), 0.5 * np.sin(x / 20.0)])
+    else:
+        v = np.stack([16.0 + 0.0 * x, -11.0 + 2.0 * np.sin(r / 25.0)])
+    v = v.astype(np.float32)
+    v[:, 200:204, 300:309] = np.nan
+    p = synth.rain_field_db(m, n, seed=9)
+    p[synth.border_nan_mask(m, n, 0.08)] = np.nan
+    lib = _lib.lib()
+    runs = {}
+    for variant in (7, 0):
+        _lib.check(lib.psh_set_option(b"semilag_variant", variant))
+        try:
+            a, da = extrapolate(p, v, 9, n_iter=1, outval=-15.0, allow_nonfinite_values=True, return_displacement=True)
+            b, db = extrapolate(p, v, [0.5, 1.5, 2.0], n_iter=2, allow_nonfinite_values=True, return_displacement=True,
+                                displacement_prev=da)
+            dp, dv = DeviceArray.from_host(p), DeviceArray.from_host(v)
+            rows, band = parallel.tiled_extrapolate(dp, dv, 6, 1, 3, n_iter=1)
+            runs[variant] = (a, da, b, db, band.to_host())
+        finally:
+            _lib.check(lib.psh_set_option(b"semilag_variant", 0))
+    for got, want in zip(runs[0], runs[7]):
+        assert np.array_equal(got, want, equal_nan=True)
+
+
 def test_config3_4096_full_size_vs_oracle(extrapolate):
     """BASELINE config 3 (the bench workload): 4096^2, 24 lead times, n_iter=1, against the
     multi-threaded C oracle at full size; device-resident so only the results cross PCIe."""

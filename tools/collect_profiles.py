@@ -69,7 +69,7 @@ def mean_counter(sub, counter, kernel):
     vals = [v for v in vals if v[1] > 500000]  # full-size launches only (not the input synthesis)
     return (sum(v[0] for v in vals) / len(vals), sum(v[1] for v in vals) / len(vals) / 1e6, len(vals)) if vals else None
 
-SL_KERNEL = "semilag_window2"  # the extrapolator of the bench step (rounds 1-4: semilag_fused)
+SL_KERNEL = "semilag_window"  # the extrapolator of the bench step (rounds 1-4: semilag_fused)
 fetch = mean_counter("pmc_fetch", "FETCH_SIZE", SL_KERNEL)
 write = mean_counter("pmc_write", "WRITE_SIZE", SL_KERNEL)
 if fetch and write:

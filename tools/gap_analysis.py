@@ -5,8 +5,8 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 def nm(r):
     n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]); n = re.sub(r"^void ", "", n)
     return n.split("(")[0].replace("psh::", "")[:26]
-# find the last full step: from a lk_stats1 to the following extrapolation kernel (semilag_window2; semilag_fused before round 5)
-idx = [i for i, r in enumerate(rows) if (nm(r).startswith("semilag_window2") or nm(r).startswith("semilag_fused<1, 1, true, 4"))]
+# find the last full step: from a lk_stats1 to the following extrapolation kernel (semilag_window; semilag_fused before round 5)
+idx = [i for i, r in enumerate(rows) if (nm(r).startswith("semilag_window") or nm(r).startswith("semilag_fused<1, 1, true, 4"))]
 end = idx[-1]; start = idx[-2] + 1
 prev_end = int(rows[idx[-2]]["End_Timestamp"])
 busy = 0; total_gap = 0

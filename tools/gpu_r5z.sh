@@ -34,3 +34,6 @@ timeout 900 python bench.py --workload config5 --steps 3 --warmup 1 2>$OUT/confi
   echo "== pip"; python -m pip list 2>/dev/null | grep -i -E "opencv|cv2" || echo "(no opencv package)"
   echo "== /opt/conda scikit-image"; /opt/conda/bin/python3.9 -c "import skimage; print(skimage.__version__)" 2>&1 | tail -1; } > $OUT/cv2_probe.txt 2>&1
 du -sh $OUT
+# the extrapolator's tests once more with the window kernel forced onto every eligible call (single-step calls too)
+( PYSTEPS_HIP_SL_VARIANT=12 timeout 600 python -m pytest tests/test_semilag_gpu.py tests/test_callers_gpu.py tests/test_nowcast_gpu.py -q -m gpu -k "not config5 and not config3" ) > $OUT/pytest_window_forced.txt 2>&1
+grep -E "passed|failed|error" $OUT/pytest_window_forced.txt | tail -2
