@@ -1470,7 +1470,7 @@ __global__ __launch_bounds__(256) void lk_track_rows(Pyramid pyr, const float2 *
   bool ok = true, suspect = false;
   const int row_first = wave * ROWS;                          // window rows of this wave
   const int row_count = min(ROWS, win_h - row_first);         // may be <= 0 for the last waves
-  const bool sample_lane = lane < win_w, load_lane = lane <= win_w;
+  const bool sample_lane = lane < win_w;
 
   for (int level = pyr.top; level >= 0; --level) {
     const PyrLevel L = pyr.lv[level];
