@@ -772,10 +772,10 @@ __device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase
 // counters: one s_waitcnt with every destination tied to it.  The trajectory update and the weights run as
 // v_pk_*_f32 on the (x, y) pair of a pixel, the velocity blend on its (u, v) pair with the weights broadcast by
 // op_sel, same operations, same order, same rounding per component (no contraction in this file) - bit-identical
-// with the gather kernels - at 12 LDS reads and ~54 VALU instructions per pixel and lead step.
+// with the gather kernels - at 13 LDS reads and 63 VALU instructions per pixel and lead step (54.5 in this fast path).
 // (Round 5 measured two other forms of the same window: u, v and the field as three planes with every
-// floating-point operation packed over the two vertically adjacent pixels of a lane - 21 LDS reads, 54 VALU:
-// 1.200 against 1.158 ms - and the gather kernel's arithmetic on a {u,v} window - 73 VALU: 1.28 ms;
+// floating-point operation packed over the two vertically adjacent pixels of a lane - 21 LDS reads, 54 VALU, but
+// three times the LDS-issue stalls: 1.200 against 1.158 ms - and the gather kernel's arithmetic on a {u,v} window - 73 VALU: 1.28 ms;
 // profiles/r05/g_window_hybrid_timings.txt, b_*, c_*.)
 template <class C, int WHAT, bool GEN>
 __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, const int (&dx8)[kWinRows],
