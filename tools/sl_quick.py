@@ -18,6 +18,12 @@ def main():
     vel = synth.true_velocity(m, n)
     if len(sys.argv) > 4 and sys.argv[4] == "uniform":  # rigid translation: no integer crossings inside a wave
         vel[0], vel[1] = 4.3, -3.1
+    if len(sys.argv) > 4 and sys.argv[4] == "calm":  # nearly at rest: no window fills, no samples leaving the image
+        vel[0], vel[1] = 0.23, -0.17
+    if len(sys.argv) > 4 and sys.argv[4] == "inward":  # the uniform field's speeds, every sample stays inside the image
+        yy, xx = np.mgrid[0:m, 0:n]
+        vel[0] = np.where(xx < n // 2, -4.3, 4.3)
+        vel[1] = np.where(yy < m // 2, -3.1, 3.1)
     if len(sys.argv) > 5:
         vel *= 24.0 / T  # same total displacement as the 24-step workload
     v = DeviceArray.from_host(vel)
