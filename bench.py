@@ -569,7 +569,7 @@ def spectral_leg(m, n):
         pm_ms = e5.elapsed_ms(e6) / reps
         out["probmatch_cdf_ms"] = pm_ms
         # round 4: the forecast's side runs without device-scope atomics (two partition passes with LDS histograms,
-        # DESIGN.md 3.8); what bounds it now is bytes - the wet pixels travel as 16-byte records through two
+        # docs/history.md 3.8); what bounds it now is bytes - the wet pixels travel as 16-byte records through two
         # scatters and the ranked values go back to their pixels as scattered 8-byte stores
         out["probmatch_bound"] = {"bound": "hbm", "min_bytes_per_call": 24.0 * m * n,
                                   "hbm_frac_of_min_bytes": 24.0 * m * n / (pm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -605,7 +605,7 @@ def steps_loop_leg(precip_d, vel_d, members, T, K, dist, with_stock):
     # roofline of the member update (HBM): algorithmic bytes = every array of the update read or written once
     # per stage that has to see it whole - L (p + 1) half spectra of the AR history, white field, noise
     # spectrum, recomposed spectrum, field, masked field (each written + read), matched field written, mask
-    # read + written: 8 (L (p + 1) + 13) B per pixel; `traffic` is the PMC measurement
+    # read + written: 8 (L (p + 1) + 13) B per pixel (docs/history.md 3.12); `traffic` is the PMC measurement
     levels, order = int(info["cascade_levels"]), int(info["ar_order"])
     alg = 8.0 * (levels * (order + 1) + 13) * m * n
     upd_s = out["ms_per_member_update"] * 1e-3

@@ -21,7 +21,7 @@
 //    pass (4 points per thread and pass: half the LDS traffic and barriers of plain radix 2),
 //    twiddles exp(-2 pi i k / N) from a table computed once per length on the host in long double.
 // FP64 vector rate on MI355X equals FP32 (78 TFLOP/s); a 4096^2 rfft2 is ~0.5 GFLOP: the transform
-// is bound by HBM / LDS traffic, not arithmetic.
+// is bound by HBM / LDS traffic, not arithmetic (docs/history.md 3.6).
 //
 // Sides that are NOT powers of two (radar composites: 640 x 710, 1226 x 760 ...; the reference's FFT
 // object takes any shape, pysteps/utils/fft.py:20-37) go through Bluestein's chirp-z identity inside

@@ -7,7 +7,7 @@
 //     w = (d / res + dist_offset)^-power, normalised (:95-103), out = sum w*uv (:106-109).
 // This is the dominant cost of the reference's dense LK (109 s at 4096^2).
 //
-// Design (DESIGN.md "idw_knn"): selection-bound FP32 VALU work, no MFMA, almost no
+// Design (docs/history.md 3.2 "idw_coarse + idw_fine3"): selection-bound FP32 VALU work, no MFMA, almost no
 // HBM traffic (8 B written per pixel).
 //  * one 256-thread workgroup per 16x16-pixel tile.  A tile-level pre-pass brackets the
 //    k-th nearest distance R of the tile centre c from an LDS histogram of centre

@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(256) void lk_track(Pyramid pyr, const float2 *__res
 // ---- row-structured tracker (windows up to 63 columns) ---------------------------------------
 // Same arithmetic as lk_track; what changes is how the window reaches the registers.  A vector
 // memory instruction costs the CU's address pipeline the same whether it gathers bytes or
-// dwords, and lk_track issues four byte gathers per window sample and pass.
+// dwords (docs/history.md 3.1), and lk_track issues four byte gathers per window sample and pass.
 // Here a lane owns a window COLUMN and a wave a band of ROWS window rows: every image row of
 // the band is loaded once (column x by lane x - x0; lane win_w fetches the extra column), the
 // right-hand tap comes from the next lane by DPP and the lower tap row is the next row's upper

@@ -5,7 +5,8 @@
 // order-0/1 scipy.ndimage.map_coordinates resampling it calls (:185-190 with
 // mode="nearest", :225-232 with mode="constant").
 //
-// Design (see DESIGN.md "sl_fused"):
+// Design of the gather kernels (their history: docs/history.md 3.1) - the window kernel, the default
+// since round 5, is described where it starts below and in DESIGN.md 3.1:
 //  * A pixel's trajectory depends only on gathers from the constant velocity
 //    field, so one thread owns one pixel for ALL T lead steps and keeps the
 //    displacement D and the increment Vi in registers.  Nothing but the T output
@@ -15,7 +16,7 @@
 //    weights therefore keep full fp32 precision however far the trajectory has
 //    travelled, and the "advected from outside" test of map_coordinates
 //    (coord < 0 or coord > len-1, strict) becomes an integer comparison.
-//  * 64x4-pixel workgroups of 4 waves, one image row per wave, one pixel per lane (two rows
+//  * 64x8-pixel workgroups of 8 waves, one image row per wave, one pixel per lane (two rows
 //    per thread were measured equal).  A wave reads 64 consecutive floats per tap row
 //    (coalesced up to the sub-row shift).  The block index is remapped so that each XCD
 //    (block b runs on XCD b % 8) owns one contiguous horizontal band of the image and its
@@ -24,8 +25,8 @@
 //    them) take a clamp-free path: buffer loads with one lane offset for every plane (+1 row
 //    = scalar offset), the right-hand column of each lane's 2x2 footprint taken from lane
 //    i+1 by DPP (v_cndmask_b32_dpp) unless the neighbour's trajectory sits elsewhere.
-//  * No LDS (default variant), no MFMA: the gather footprint moves with D and there is no
-//    dense contraction.  The kernel is bound by the CU's vector-memory pipeline.
+//  * No LDS in the gather kernels, no MFMA anywhere: the gather footprint moves with D and there is no
+//    dense contraction.  The kernel is bound by the CU's vector-memory pipeline (docs/history.md 3.1).
 #include <cstdio>
 #include <cstdlib>
 
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(kTileX *kDirectWaves) void semilag_fused(
 
 // ---- workgroup window ------------------------------------------------------------------------------
 // The gather kernels above are bound by the CU's vector-memory pipeline: five wave64 dwordx4 gathers per
-// pixel and lead step return 80 B per lane through a 64 B/clk path, whatever the caches
+// pixel and lead step return 80 B per lane through a 64 B/clk path (docs/history.md 3.1), whatever the caches
 // hold.  The window kernel below takes that pipeline out of the inner loop.  A workgroup of eight waves
 // owns a 64 x 32 tile (four rows per lane) and keeps a WINDOW of the motion field and of the advected
 // field - 96 x 64 texels around the tile's current sample positions - in LDS ACROSS lead steps: a sampling

@@ -1,4 +1,4 @@
-"""Timing of the HIP FFTs (development aid / DESIGN.md 3.6): resident transforms by HIP events,
+"""Timing of the HIP FFTs (development aid / docs/history.md 3.6): resident transforms by HIP events,
 the NumPy-in / NumPy-out path by the wall clock, numpy.fft (pocketfft) beside them.
 
     python tools/fft_quick.py [size | rowsxcols ...]      e.g.  2048 4096 640x710 1226x760

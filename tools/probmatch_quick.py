@@ -1,4 +1,4 @@
-"""Timing of the device probability matching (development aid / DESIGN.md 3.8): resident calls by HIP
+"""Timing of the device probability matching (development aid / docs/history.md 3.8): resident calls by HIP
 events, the NumPy-in / NumPy-out path and the oracle (two host sorts, like the reference) by the wall
 clock; the result is checked against the oracle.
 
