@@ -30,6 +30,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# VALU issue peak of the chip in wave64 instructions per second: 256 CUs x 4 SIMDs, one wave64 VALU instruction occupies
+# its SIMD for 4 cycles (measured for fp32 / fp64 / packed / DPP, profiles/r04/a_valu_probe.txt), 2.4 GHz max clock
+# (MI355X_MICROARCH.md; the chip sustains 2.1-2.2 GHz under this kernel, so a frac of ~0.9 is the practical ceiling)
+N_SIMD = 1024
+VALU_PEAK_GINST = N_SIMD * 2.4 / 4.0
+# the sources whose kernels the committed counter files describe: tools/collect_profiles.py stores their git blob
+# hashes beside the counters, and a line whose sources differ reports `traffic: null, traffic_stale: true` instead of
+# counters of a kernel that is no longer the one being timed
+SL_SOURCES = ("pysteps_amd/csrc/semilag.hip", "pysteps_amd/csrc/semilag_device.h", "pysteps_amd/csrc/common.h")
+LK_SOURCES = ("pysteps_amd/csrc/lk.hip", "pysteps_amd/csrc/lk_sparse.hip", "pysteps_amd/csrc/sparse_qc.hip",
+              "pysteps_amd/csrc/idw.hip", "pysteps_amd/csrc/dense_lk.hip", "pysteps_amd/csrc/common.h")
+
+
+def blob_hash(relpath):
+    """git's blob hash of a file of the working tree (what `git hash-object` prints)."""
+    import hashlib
+
+    try:
+        with open(os.path.join(ROOT, relpath), "rb") as fh:
+            data = fh.read()
+    except OSError:
+        return None
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def sources_match(recorded, sources):
+    """True if the blob hashes stored with a counter file are those of the tree's sources."""
+    return bool(recorded) and all(recorded.get(src) == blob_hash(src) for src in sources)
 
 
 def parse_args():
@@ -52,6 +80,9 @@ def parse_args():
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
     ap.add_argument("--workload", choices=("default", "config5"), default="default",
                     help="config5: 8192^2 x 36 lead times, row bands over the ranks (banded LK + tiled semilag, RCCL collectives)")
+    ap.add_argument("--config5-lk", choices=("replicated", "banded"), default="replicated",
+                    help="config5: the motion estimate on every rank (default: no collective in the step) or in row bands "
+                         "(host-driven stage loop with 5 small collectives per estimate)")
     ap.add_argument("--no-steps-loop", action="store_true", help="skip the STEPS member-loop leg of the N = 1 line")
     ap.add_argument("--no-steps-stock", action="store_true", help="skip the sampled stock nowcasts.steps run (oracle/_ref) of steps_e2e")
     ap.add_argument("--advection-only", action="store_true",
@@ -241,18 +272,21 @@ def host_path(frames_d, vel_d, T, K, reps=3):
                 m, n, T, reps, moved / 1e9)}
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if it matches."""
+def pmc_counters(workload):
+    """(record, stale) of the extrapolation kernel from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json:
+    HBM bytes per launch, SQ_INSTS_VALU, GRBM_GUI_ACTIVE, all per launch of the SAME workload); stale = the kernel's
+    sources are not the ones the counters were taken from."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
-            table = json.load(fh)
-        return table.get(workload, {}).get("hbm_bytes_per_launch")
+            rec = json.load(fh).get(workload)
     except Exception:
-        return None
+        rec = None
+    if not rec:
+        return None, False
+    return rec, not sources_match(rec.get("source_hashes"), SL_SOURCES)
 
 
-N_SIMD = 1024  # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles (profiles/r04/a_valu_probe.txt)
 # algorithmic bytes per pixel of the streaming image passes of the motion estimate (what each pass has
 # to read and write once): float32 frame in / keep bits / uint8 renderings / float32 response
 LK_PASS_BYTES = {
@@ -286,7 +320,9 @@ def roofline_lk(frames_d, m, n, pairs):
     except Exception:
         return None
     counters = prof.get("counters", {})
-    out = {"source": prof.get("source"), "counter_source": prof.get("counter_source")}
+    out = {"source": prof.get("source"), "counter_source": prof.get("counter_source"),
+           "stale": not sources_match(prof.get("source_hashes"), LK_SOURCES),
+           "stale_note": "true = the LK sources changed after these kernel times / counters were taken (tools/collect_profiles.py)"}
     passes = {}
     total_ns = total_bytes = 0.0
     for name, (bpp, what) in LK_PASS_BYTES.items():
@@ -317,6 +353,54 @@ def roofline_lk(frames_d, m, n, pairs):
                              "a wave64 VALU instruction occupies its SIMD for 4 cycles whatever its type (fp32, fp64, packed, DPP), "
                              "transcendentals for 8 (profiles/r04/a_valu_probe.txt): a lower bound of the VALU busy share", "per_kernel": valu}
     return out
+
+
+def semilag_roofline(m, n, T, K, sl_ms, alg_bytes):
+    """The roofline block of the extrapolation leg.  `kernel_ms` is measured live (HIP events on the library stream
+    around the ONE kernel of the leg).  The kernel that runs by default - the workgroup window - serves every tap from
+    LDS, so the roof that binds it is VALU ISSUE, not HBM: `achieved` = wave64 VALU instructions per second
+    (SQ_INSTS_VALU per launch, from the committed counter pass of this very workload, over the live kernel time),
+    `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles per instruction, `frac` their ratio.  `traffic` = HBM bytes per launch from
+    the FETCH_SIZE / WRITE_SIZE passes (gfx950 correction applied, tools/calib_copy.py).  The HBM reading the contract
+     prescribes - ALGORITHMIC bytes / time / 8 TB/s - is kept under `hbm`: it prices every tap as a byte
+    from memory, exceeds 1 for this kernel and says nothing about its distance from any bound; `hbm.hbm_frac`
+    (counter bytes) and `hbm.kernel_over_floor` are the physical figures.  Counters are static per source revision:
+    when the kernel's sources differ from the ones the counters were taken from, they are withheld."""
+    from pysteps_amd import _lib
+
+    choice = _lib.load().psh_semilag_kernel(m, n, T, K, 1, 1)
+    kernel = {12: "semilag_window"}.get(choice, "semilag_fused (gather mode %d)" % choice)
+    rec, stale = pmc_counters("semilag_%dx%d_T%d_K%d" % (m, n, T, K))
+    if rec is not None and rec.get("kernel") != kernel.split(" ")[0]:
+        rec, stale = None, False  # counters of another kernel
+    use = rec if (rec is not None and not stale) else {}
+    traffic = use.get("hbm_bytes_per_launch")
+    insts = use.get("SQ_INSTS_VALU")
+    floor_ms = compulsory_bytes(m, n, T, K) / (HBM_PEAK_GBS * 1e9) * 1e3
+    alg_gbs = alg_bytes / (sl_ms * 1e-3) / 1e9
+    hbm = {
+        "alg_bytes_per_launch": alg_bytes, "alg_achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "alg_frac": alg_gbs / HBM_PEAK_GBS,
+        "alg_frac_note": "the contract's figure (algorithmic bytes / time / 8 TB/s); saturated for a kernel that serves its taps "
+                         "from LDS - north_star's 40 % target is met by construction, read hbm_frac and kernel_over_floor",
+        "hbm_frac": (traffic / (sl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "floor_ms": floor_ms, "kernel_over_floor": sl_ms / floor_ms,
+    }
+    rf = {"kernel": kernel, "kernel_ms": sl_ms, "traffic": traffic, "traffic_stale": bool(stale), "hbm": hbm,
+          "counter_source": rec.get("source") if rec else None}
+    if choice == 12:
+        achieved = (insts / (sl_ms * 1e-3) / 1e9) if insts else None
+        rf.update({"bound": "valu issue", "achieved": achieved, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s",
+                   "frac": (achieved / VALU_PEAK_GINST) if achieved else None,
+                   "valu_insts_per_launch": insts,
+                   "frac_at_measured_clock": (insts * 4.0 / (N_SIMD * use["GRBM_GUI_ACTIVE"] / 8.0))
+                   if insts and use.get("GRBM_GUI_ACTIVE") else None,
+                   "frac_note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x cycles): `frac` takes the cycles of kernel_ms at the "
+                                "2.4 GHz maximum, frac_at_measured_clock the GRBM_GUI_ACTIVE / 8 of the counter pass itself"})
+    else:
+        # the gather kernels move their taps through the vector-memory path: the contract's HBM reading applies
+        rf.update({"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_gbs / HBM_PEAK_GBS})
+    return rf
 
 
 def compulsory_bytes(m, n, T, K):
@@ -790,29 +874,9 @@ def main():
             "semilag_only_mpx_leadsteps_s": m * n * T / (sl_ms * 1e-3) / 1e6,
             "lk_ms_per_step": (ms_per_step - sl_ms) if have_lk else None,
         },
-        "roofline": {
-            # the extrapolation call between two HIP events on the library stream: ONE kernel since round 5
-            # (the workgroup-window kernel reads the planes as they are; rounds 2-4: kernel + two layout passes)
-            "kernel": "semilag_window",
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "alg_bytes_per_launch": alg_bytes,
-            "kernel_ms": sl_ms,
-            "traffic": pmc_traffic("semilag_%dx%d_T%d_K%d" % (m, n, T, K)),
-        },
+        "roofline": None,
     }
-    # the contract's `frac` prices ALGORITHMIC bytes (every tap of every sampling pass as a byte from
-    # memory).  The window kernel serves the taps from LDS, so `frac` saturates - it can exceed 1 - and says nothing
-    # about how far the kernel is from its bound.  The working metrics are beside it: counter traffic over the same
-    # duration (`hbm_frac`), the time the compulsory stream alone would need at peak (`floor_ms`) and their ratio.
-    rf = line["roofline"]
-    rf["hbm_frac"] = (rf["traffic"] / (sl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rf["traffic"] else None
-    rf["floor_ms"] = compulsory_bytes(m, n, T, K) / (HBM_PEAK_GBS * 1e9) * 1e3
-    rf["kernel_over_floor"] = sl_ms / rf["floor_ms"]
-    rf["frac_note"] = "algorithmic bytes / time / 8 TB/s; saturated (the taps come from an LDS window): read kernel_over_floor and hbm_frac"
+    line["roofline"] = semilag_roofline(m, n, T, K, sl_ms, alg_bytes)
     if have_lk:
         line["roofline_lk"] = roofline_lk(frames_d, m, n, args.frames - 1)
     if not args.no_host_path:
@@ -919,11 +983,22 @@ def main_members(args, dist, dense_lk):
     t0 = time.perf_counter()
     ok = 1.0
     err = None
+    comm_init_s = bcast_ms = None
     try:
         with stdout_to_stderr():
             comm = parallel.Communicator(dist.rank, dist.world, dist.broadcast_bytes)
-            comm.broadcast(pack, root=0)
             synchronize()
+            comm_init_s = time.perf_counter() - t0  # unique id over the control plane + ncclCommInitRank
+            # the data path's ONE collective, by HIP events on the library stream: a first, untimed broadcast brings the
+            # rings / channels up (RCCL connects lazily), the second one is the transfer itself
+            comm.broadcast(pack, root=0)
+            synchronize()  # (the first broadcast also lines the ranks up: no control-plane barrier inside this try block)
+            b0, b1 = Event(), Event()
+            b0.record()
+            comm.broadcast(pack, root=0)
+            b1.record()
+            synchronize()
+            bcast_ms = b0.elapsed_ms(b1)
     except Exception as exc:
         ok, err = 0.0, exc
     if dist.max(1.0 - ok) > 0.0:
@@ -1002,7 +1077,14 @@ def main_members(args, dist, dense_lk):
                             "motion field from %s on rank 0, [precip|u|v] in ONE RCCL broadcast before the timed region, no "
                             "data-path collective" % ("dense LK" if dense_lk is not None else "the synthetic truth"),
                 "rccl_ranks": dist.world,
-                "broadcast_s": bcast_s,
+                "comm_init_s": comm_init_s,
+                "broadcast_ms": bcast_ms,
+                "broadcast_gbs": (pack.nbytes / (bcast_ms * 1e-3) / 1e9) if bcast_ms else None,
+                "broadcast_note": "comm_init_s = communicator bring-up (unique id + ncclCommInitRank, host clock, rank 0); "
+                                  "broadcast_ms = the [precip | u | v] broadcast alone between two HIP events on the library "
+                                  "stream of rank 0 (second of two: RCCL connects its channels on the first); "
+                                  "collective_phase_s = both + the warm-up broadcast + barriers",
+                "collective_phase_s": bcast_s,
                 "broadcast_bytes": pack.nbytes,
                 "member_loop": info,
                 "compare_with": "single_gpu_base (same run, same per-GPU workload); the --gpus 1 line is BASELINE config 3 "
@@ -1027,9 +1109,10 @@ def main_members(args, dist, dense_lk):
 
 def main_config5(args, dist):
     """--workload config5 (BASELINE configs[4]): 8192^2, 2 frames, 36 lead times tiled over the ranks.
-    Every rank holds the frames (ONE RCCL broadcast), the dense Lucas-Kanade image passes run on row
-    bands (global ranges by allreduce MIN / MAX / SUM, corner candidates and tracked vectors by
-    allgather: pysteps_amd/motion/banded.py) and every rank integrates the rows of its band
+    Every rank holds the frames (ONE RCCL broadcast before the timed region), runs the whole dense Lucas-Kanade
+    estimate itself (deterministic: every rank gets the same field, no collective in the step; --config5-lk banded:
+    the image passes on row bands with global ranges by allreduce MIN / MAX / SUM and corner candidates / tracked
+    vectors by allgather, pysteps_amd/motion/banded.py) and integrates the rows of its band
     (parallel.tiled_extrapolate, no halo exchange: the scheme has no inter-pixel dependency).  Strong
     scaling: the total work is fixed; rank 0 times the whole step alone first (single_gpu_base)."""
     from pysteps_amd import _lib, extrapolation, motion, parallel
@@ -1082,8 +1165,12 @@ def main_config5(args, dist):
 
     marks = []
 
+    plan = parallel.config5_plan(m, dist.world, dist.rank, args.config5_lk)
+    dense_lk_whole = motion.get_method("LK")
+
     def step():
-        v = parallel.banded_dense_lucaskanade(frames_d, comm)
+        # (parallel.config5_step, opened up for the event pair around the band's extrapolation)
+        v = parallel.banded_dense_lucaskanade(frames_d, comm) if plan["lk"] == "banded" else dense_lk_whole(frames_d)
         e0 = Event().record()
         out = parallel.tiled_extrapolate(precip_d, v, T, dist.rank, dist.world, outval=-15.0, n_iter=K)
         marks.append((e0, Event().record()))
@@ -1109,11 +1196,15 @@ def main_config5(args, dist):
             "data": "synthetic", "single_gpu_base": base, "strong_scaling_speedup": value / base["value"],
             "strong_scaling_efficiency": value / base["value"] / dist.world,
             "config": {
-                "workload": "%dx%d fp32, %d input frames, banded dense LK + tiled semilag %d leadtimes n_iter=%d (BASELINE "
-                            "config 5)" % (m, n, args.frames, T, K),
-                "sharding": "row bands: %d rows per rank; frames in ONE RCCL broadcast; per estimate allreduce MIN/MAX/SUM of "
-                            "<= 6 floats x 3, allgather of corner keys and of tracked vectors; no halo exchange for the "
-                            "extrapolation" % len(rows),
+                "workload": "%dx%d fp32, %d input frames, %s dense LK + tiled semilag %d leadtimes n_iter=%d (BASELINE "
+                            "config 5)" % (m, n, args.frames, plan["lk"], T, K),
+                "sharding": "row bands of the extrapolation: %d rows per rank, no halo exchange; frames in ONE RCCL broadcast "
+                            "before the timed region; motion estimate %s" % (len(rows), (
+                                "replicated on every rank (deterministic: bit-identical fields, NO collective in the step)"
+                                if plan["lk"] == "replicated" else
+                                "in row bands: per estimate allreduce MIN/MAX/SUM of <= 6 floats x 3, allgather of corner "
+                                "keys and of tracked vectors")),
+                "config5_plan": plan,
                 "rccl_ranks": dist.world,
             },
             "roofline": {"kernel": "semilag_window (row band of rank 0)", "bound": "hbm", "achieved": alg_bytes / (sl_ms * 1e-3) / 1e9,

@@ -142,6 +142,16 @@ int psh_semilag_uv_dev(const float *precip_dev, const float *velocity_dev, const
                        const double *steps_host, int T, int n_iter, int interp_order, float outval, double *disp_dev,
                        int resume, float *out_dev);
 
+/* 1 if the workgroup-window kernel (the default extrapolator for bilinear resampling of a field with n_iter >= 1;
+ * it samples the velocity PLANES) takes (m, n) images, 0 if such images go to the gather kernels, which sample
+ * {u, v} pairs - a caller that produces motion fields for them (psh_dense_lk_uv_dev) then writes the pair layout too
+ * instead of leaving the interleaving to every extrapolation call.  Pure function: needs no device. */
+int psh_semilag_window_shape(int m, int n);
+/* Which kernel a call of this shape takes under the current "semilag_variant" (16-byte aligned planes assumed):
+ * 12 the workgroup-window kernel (semilag_window), 7 / 5 / 1 the gather kernel (semilag_fused) on packed velocity +
+ * row-pair field planes / packed velocity / one plane per component.  Pure function: needs no device. */
+int psh_semilag_kernel(int m, int n, int T, int n_iter, int interp_order, int has_field);
+
 /* Row-band form for output tiling across GPUs (BASELINE config 5: every rank holds the whole
  * input - it is tiny next to 288 GB - and advects only its band): pixels of rows
  * [row_begin, row_begin + row_count) are integrated and written to out (T,row_count,n);

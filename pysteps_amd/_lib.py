@@ -158,6 +158,8 @@ SIGNATURES = {
     "psh_semilag_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p]),
     "psh_semilag_uv_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
                                    c_void_p]),
+    "psh_semilag_window_shape": (c_int, [c_int, c_int]),
+    "psh_semilag_kernel": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "psh_semilag_rows_dev": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_semilag_host": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),
 }

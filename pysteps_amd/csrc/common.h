@@ -114,6 +114,8 @@ hipError_t launch_pack_velocity(const float *vel, float *uv, size_t plane, hipSt
 bool semilag_wants_field_pairs(const SemilagArgs &a);
 hipError_t launch_pack_field_rows(const float *precip, float *pairs, int m, int n, hipStream_t stream);
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream);
+bool semilag_window_shape(int m, int n);
+int semilag_kernel_choice(int m, int n, int T, int n_iter, int order, bool has_field);
 void set_semilag_variant(int v);
 void set_members_variant(int v);
 hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream, int kind = 0,

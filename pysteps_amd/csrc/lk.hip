@@ -2380,14 +2380,19 @@ int lk_pyramids_beside(const unsigned char *prev_u8_dev, const unsigned char *ne
 // waits for, not for whatever the main stream was given in the meantime).  `block` (lk_pyramids_bytes() bytes, from
 // psh_malloc) has to be taken BEFORE the caller queues anything else on the main stream after the fork: the allocator
 // is ordered on the main stream, a block it hands out later may still be in use by that work, which the side stream
-// does not wait for.  The pyramid set owns the block from here on (also when the call fails).
+// does not wait for.  The pyramid set owns the block once the call has succeeded; when it fails - whichever check or
+// launch failed - lk_pyramids_on leaves a caller's block alone and it is released HERE, once, before the error that
+// lk_pyramids_on recorded can be overwritten by anything.
 int lk_pyramids_on_side(hipStream_t side, void *block, size_t block_bytes, const unsigned char *prev_u8_dev,
                         const unsigned char *next_u8_dev, int m, int n, int win_w, int win_h, int max_level,
                         void **handle_out) {
   Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   const int rc = lk_pyramids_on(side, prev_u8_dev, next_u8_dev, m, n, win_w, win_h, max_level, handle_out, block, block_bytes);
-  if (rc != PSH_OK && (handle_out == nullptr || *handle_out == nullptr) && block) (void)psh_free(block);
+  if (rc != PSH_OK && block) {
+    // (psh_free of a block of the allocator succeeds and leaves psh_last_error() alone)
+    (void)psh_free(block);
+  }
   return rc;
 }
 size_t lk_pyramids_bytes(int m, int n, int win_w, int win_h, int max_level) {
@@ -2454,7 +2459,7 @@ static int lk_pyramids_on(hipStream_t stream, const unsigned char *prev_u8_dev, 
   if (bytes == 0) bytes = 256;  // single level, no gradient image: nothing to store
   PyramidSet *ps = new PyramidSet();
   if (block_in != nullptr) {
-    // a block the caller took from the allocator earlier (before it queued other work on the main stream); the set owns it
+    // a block the caller took from the allocator earlier (before it queued other work on the main stream)
     if (block_in_bytes < bytes) {
       delete ps;
       return fail(PSH_EINVAL, "lk_pyramids: the block handed in holds %zu bytes, %zu are needed", block_in_bytes, bytes);
@@ -2494,7 +2499,8 @@ static int lk_pyramids_on(hipStream_t stream, const unsigned char *prev_u8_dev, 
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
-    (void)psh_free(ps->block);
+    // a block the caller handed in stays the caller's on every failure path (lk_pyramids_on_side releases it): one owner
+    if (block_in == nullptr) (void)psh_free(ps->block);
     delete ps;
     return fail(PSH_EHIP, "lk_pyramids launch failed: %s", hipGetErrorString(e));
   }

@@ -474,6 +474,12 @@ static int semilag_rows(const float *precip_dev, const float *velocity_dev, cons
                         const double *steps_host, int T, int n_iter, int interp_order, float outval, double *disp_dev,
                         int resume, int row_begin, int row_count, float *out_dev);
 
+int psh_semilag_window_shape(int m, int n) { return psh::semilag_window_shape(m, n) ? 1 : 0; }
+
+int psh_semilag_kernel(int m, int n, int T, int n_iter, int interp_order, int has_field) {
+  return psh::semilag_kernel_choice(m, n, T, n_iter, interp_order, has_field != 0);
+}
+
 int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int m, int n,
                          const double *steps_host, int T, int n_iter, int interp_order,
                          float outval, double *disp_dev, int resume, int row_begin, int row_count,

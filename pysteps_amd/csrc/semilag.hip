@@ -27,8 +27,10 @@
 //    i+1 by DPP (v_cndmask_b32_dpp) unless the neighbour's trajectory sits elsewhere.
 //  * No LDS in the gather kernels, no MFMA anywhere: the gather footprint moves with D and there is no
 //    dense contraction.  The kernel is bound by the CU's vector-memory pipeline (docs/history.md 3.1).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 
@@ -586,7 +588,6 @@ __global__ __launch_bounds__(kTileX *kDirectWaves) void semilag_fused(
 //    slack / speed lead steps: ~5 at 6 px per step), filled by coalesced dwordx4 loads + ds_write_b128,
 //    and the lanes re-base their offsets.
 //  * XCD cells, guards, what bounds the kernel now and everything round 5 measured on the way: DESIGN.md 3.1 / 9.
-constexpr int kWinRows = 4;   // image rows per lane
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(3))) float lds_f32;
@@ -613,20 +614,28 @@ __device__ __forceinline__ int smax(int a, int b) {
 static unsigned long long *g_win_stats = nullptr;
 
 // ---- the window's geometry and control block ----------------------------------------------------------
-template <int WAVES, int WW, int WH>
+template <int WAVES, int WW, int WH, int ROWS = 4, int OCC = 4>
 struct WinCfg {
   static constexpr int kWaves = WAVES, kW = WW, kH = WH;
+  static constexpr int kRows = ROWS;  // image rows per lane
+  static constexpr int kOcc = OCC;    // waves per SIMD the register budget is cut for (two workgroups of 8 waves: 4)
   // u and v are interleaved as {u,v} pairs in ONE window plane (8-byte texels): column offsets are pre-scaled by 8
   static constexpr int kXShift = 3;
-  static constexpr int kTileY = kWinRows * WAVES;
+  static constexpr int kTileY = ROWS * WAVES;
   static constexpr unsigned kPitch4 = WW * 4u;          // bytes per window row of one plane
   static constexpr unsigned kPlaneBytes = WW * WH * 4u;
   static constexpr int kItems = WH * (WW / 4);          // 16-byte items per plane
   static constexpr int kThreads = kTileX * WAVES;
   static constexpr unsigned kCtlVel = 16u * WAVES, kCtlFlag = kCtlVel + 8u;  // byte offsets in the control block
+  static constexpr unsigned kCtlTile = kCtlFlag + 12u;  // the tile a persistent workgroup works on
   static constexpr int kCtlWords = 4 * WAVES + 2 + 3 + 3;
 };
 using Win8 = WinCfg<8, 96, 64>;
+// (Round 6 measured two rows per lane at six waves per SIMD on the same box: twelve waves on a 64 x 24 tile with a
+// 96 x 56 window, two workgroups per CU - WinCfg<12, 96, 56, 2, 6> - 1.29 / 1.23 ms (sheared / uniform field), eight
+// waves on a 64 x 16 tile with a 96 x 42 window, three per CU - WinCfg<8, 96, 42, 2, 6> - 1.21 / 1.13, against 1.145 /
+// 1.077 for this one: more waves do not buy what the smaller tiles' extra fills, barriers and per-wave scalar work
+// cost - the kernel is not short of latency hiding.  profiles/r06/a_window_order_persist_ab.txt)
 
 struct Window {
   unsigned uv, p;    // LDS byte addresses of the {u,v} plane and of the field plane
@@ -646,6 +655,7 @@ __device__ __forceinline__ void win_count(const Window &W, int which) {
 struct WinBox {
   int lo4, hi4, loy, hiy;
 };
+template <int kWinRows>
 __device__ __forceinline__ WinBox win_corners(const int (&dx4)[kWinRows], const int (&dy)[kWinRows]) {
   const int xa = __builtin_amdgcn_readlane(dx4[0], 0), xb = __builtin_amdgcn_readlane(dx4[0], 63);
   const int xc = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 0), xd = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 63);
@@ -671,8 +681,9 @@ __device__ __forceinline__ void win_publish(const Window &W, int wave, const Win
 // Every wave of the workgroup, with every wave's box published and nobody reading the window any more: place the
 // new window ahead of the motion, re-base the offsets, fill it.  (The caller orders the LDS writes before the next reader.)
 template <class C>
-__device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, bool force, int (&dx4)[kWinRows],
-                                                    int (&dy)[kWinRows], float move_scale, int m, int n) {
+__device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, bool force, int (&dx4)[C::kRows],
+                                                    int (&dy)[C::kRows], float move_scale, int m, int n) {
+  constexpr int kWinRows = C::kRows;
   lds_int *ctl = (lds_int *)(size_t)W.ctl;
   int ulo4 = 0x7fffffff, uhi4 = -0x7fffffff, uloy = 0x7fffffff, uhiy = -0x7fffffff;
 #pragma unroll
@@ -741,8 +752,8 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
 // second barrier.  `phase` cycles through three flag words so that clearing the next one never races with a wave
 // that still has to read it.
 template <class C>
-__device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase, bool force, int (&dx4)[kWinRows],
-                                            int (&dy)[kWinRows], float vx_lane, float vy_lane, float move_scale, int m,
+__device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase, bool force, int (&dx4)[C::kRows],
+                                            int (&dy)[C::kRows], float vx_lane, float vy_lane, float move_scale, int m,
                                             int n) {
   const int lane = threadIdx.x & 63, wave = rfl(static_cast<int>(threadIdx.x >> 6));
   lds_int *ctl = (lds_int *)(size_t)W.ctl;
@@ -779,9 +790,11 @@ __device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase
 // three times the LDS-issue stalls: 1.200 against 1.158 ms - and the gather kernel's arithmetic on a {u,v} window - 73 VALU: 1.28 ms;
 // profiles/r05/g_window_hybrid_timings.txt, b_*, c_*.)
 template <class C, int WHAT, bool GEN>
-__device__ __forceinline__ void win_sample(const Fields &F, const Window &W, const int (&dx8)[kWinRows],
-                                            const int (&dy)[kWinRows], const f32x2 (&f)[kWinRows], int m, int n,
-                                            float outval, f32x2 (&s_uv)[kWinRows], float (&sp)[kWinRows]) {
+__device__ __forceinline__ void win_sample(const Fields &F, const Window &W, const int (&dx8)[C::kRows],
+                                            const int (&dy)[C::kRows], const f32x2 (&f)[C::kRows], int m, int n,
+                                            float outval, f32x2 (&s_uv)[C::kRows], float (&sp)[C::kRows]) {
+  constexpr int kWinRows = C::kRows;
+  static_assert(kWinRows == 2 || kWinRows == 4, "rows per lane");
   constexpr bool kWithP = (WHAT & kPrecip) != 0;
   unsigned mx = static_cast<unsigned>(dx8[0]), my = static_cast<unsigned>(dy[0]);
 #pragma unroll
@@ -810,8 +823,13 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
       }
     }
 #define PSH_TIE4(A, J) "+v"(A[J][0]), "+v"(A[J][1]), "+v"(A[J][2]), "+v"(A[J][3])
-    asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(t, 0), PSH_TIE4(t, 1), PSH_TIE4(t, 2), PSH_TIE4(t, 3));
-    if (kWithP) asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1), PSH_TIE4(rp, 2), PSH_TIE4(rp, 3));
+    if constexpr (kWinRows == 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(t, 0), PSH_TIE4(t, 1), PSH_TIE4(t, 2), PSH_TIE4(t, 3));
+      if (kWithP) asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1), PSH_TIE4(rp, 2), PSH_TIE4(rp, 3));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(t, 0), PSH_TIE4(t, 1));
+      if (kWithP) asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1));
+    }
 #undef PSH_TIE4
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
@@ -848,39 +866,69 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
   }
 }
 
-// one pixel's trajectory, both axes in one packed subtraction: P -= floor stuff exactly as retreat()
+// one pixel's trajectory, both axes in one packed subtraction: P -= floor stuff exactly as retreat().
+// The column offset is pre-scaled by 8, so an integer step of 2^28 pixels and more - a garbage or sentinel
+// velocity such as 1e20, which v_cvt_flr saturates to INT_MAX - would wrap back INTO the window where the gather
+// kernels' positions (which wrap at 2^31) are outside the image: the step is limited to +-2^27 pixels, which
+// leaves every window and every image (tests/test_semilag_gpu.py::test_window_kernel_on_sentinel_velocities).
+// (MED3: one v_med3_i32 with one of the two bounds in a VGPR - a VALU instruction of gfx9 reads one SGPR; the
+// boundary-mode instantiation, which has no register to spare, takes v_max_i32 + v_min_i32 with literals.)
+template <bool MED3>
 __device__ __forceinline__ void retreat_xy(int &PX8, int &PY, f32x2 &f, f32x2 w) {
   const f32x2 t = f - w;
   int kx, ky;
   asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(kx) : "v"(t.x));
   asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ky) : "v"(t.y));
-  PX8 += kx << 3;
+#ifndef PSH_SL_NO_STEP_CLAMP
+  if constexpr (MED3) {
+    asm("v_med3_i32 %0, %0, %1, %2" : "+v"(kx) : "s"(-(1 << 27)), "v"(1 << 27));
+  } else {
+    kx = min(max(kx, -(1 << 27)), 1 << 27);
+  }
+#endif
+  PX8 += static_cast<int>(static_cast<unsigned>(kx) << 3);
   PY += ky;
   f = f32x2{__builtin_amdgcn_fractf(t.x), __builtin_amdgcn_fractf(t.y)};
 }
 
-template <class C, bool GEN>
-__global__ __launch_bounds__(C::kThreads, 4) void semilag_window(
-    const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out, double *__restrict__ disp,
-    const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume, float outval,
-    int row0, int rows, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd, float guard, int cells,
-    unsigned long long *__restrict__ stats) {
-  const int b = blockIdx.x;
-  int tile;
-  if (cells) {
-    const int xcd = b % kNumXcd, l = b / kNumXcd;
-    const int cw = tiles_x / kNumXcd, ch = (n_tiles / tiles_x) / kNumXcd, per_cell = cw * ch;
-    const int cy = l / per_cell, r = l - cy * per_cell;
-    const int cx = (xcd + kNumXcd - cy) & (kNumXcd - 1);
-    tile = (cy * ch + r / cw) * tiles_x + cx * cw + r % cw;
-  } else {
-    tile = (b % kNumXcd) * tiles_per_xcd + b / kNumXcd;
+// ---- which tile a workgroup takes ----------------------------------------------------------------------
+// `order` lists the tiles in the sequence they are to be STARTED (slot s belongs to XCD s % 8: block b of a launch runs
+// on XCD b % 8; -1 pads the XCDs' lists to one length).  Tiles are not equally expensive: the ones near the image
+// border take their sampling passes through the gather path once their trajectories leave the image (three times
+// the cost of a window pass) - and in image order the last ones to start would be the bottom rows, on their own
+// at the end of the launch while the rest of the chip is idle.  The host builds the table (launch_window): rings
+// of 32 pixels from the border inwards first, the interior in XCD cells (one cell per row band and column band for
+// every XCD, each still a compact block for its L2).
+//  * PERSIST = false (the default): one tile per workgroup, tile = order[blockIdx.x]; the hardware dispatcher starts the
+//    next workgroup of an XCD wherever a slot frees up.
+//  * PERSIST = true (PYSTEPS_HIP_SL_PERSIST=1, kept for measurements): two workgroups per CU stay, each pulling slots
+//    from the list of its own XCD with one atomic per tile and, when that is exhausted, from the other XCDs' lists.
+//    queue[0..7] are the lists' cursors, queue[8] counts the workgroups that are done; the last one out clears all nine
+//    for the next launch on the stream.  Measured on one box against the same table without it (profiles/r06/
+//    a_window_order_persist_ab.txt): 1.160 against 1.145 ms (sheared field), 1.09 against 1.077 (uniform) - the
+//    dispatcher already balances workgroups of unequal length inside an XCD, the XCDs' lists are equal by
+//    construction (cells), and the queue adds a barrier and an atomic round trip per tile.  What pays is the ORDER:
+//    image order 1.185 / 1.117 ms, border rings first 1.145 / 1.077.
+__device__ __attribute__((noinline)) int win_next_slot(unsigned *queue, int home, int tiles_per_xcd, const int *order) {
+  for (int i = 0; i < kNumXcd; ++i) {
+    const int k = (home + i) & (kNumXcd - 1);
+    if (__hip_atomic_load(queue + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= static_cast<unsigned>(tiles_per_xcd)) continue;
+    const unsigned l = __hip_atomic_fetch_add(queue + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (l < static_cast<unsigned>(tiles_per_xcd)) {
+      const int t = order[l * kNumXcd + k];
+      if (t >= 0) return t;
+    }
   }
-  if (tile >= n_tiles) return;  // the whole workgroup
-  const int lane = threadIdx.x & (kTileX - 1);
-  const int xt = (tile % tiles_x) * kTileX + lane;
-  const int yt = row0 + (tile / tiles_x) * C::kTileY + static_cast<int>(threadIdx.x / kTileX) * kWinRows;
-  const int x = min(xt, n - 1);
+  return -1;
+}
+
+template <class C, bool GEN, bool PERSIST>
+__global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
+    const float *__restrict__ precip, const float *__restrict__ vel, float *__restrict__ out_base, double *__restrict__ disp,
+    const float *__restrict__ scale, float first_scale, int m, int n, int T, int n_iter, int resume, float outval,
+    int row0, int rows, int bmode, int tiles_x, int n_tiles, int tiles_per_xcd, float guard,
+    const int *__restrict__ order, unsigned *__restrict__ queue, unsigned long long *__restrict__ stats) {
+  constexpr int kWinRows = C::kRows;
   const size_t plane = static_cast<size_t>(m) * n;
   Fields F;
   F.u0 = vel;
@@ -900,108 +948,212 @@ __global__ __launch_bounds__(C::kThreads, 4) void semilag_window(
 
   __shared__ __attribute__((aligned(16))) float win_planes[3 * C::kW * C::kH];
   __shared__ __attribute__((aligned(16))) int win_ctl[C::kCtlWords];
-  Window W;
-  W.uv = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_planes));  // 8-byte texels
-  W.p = W.uv + 2u * C::kPlaneBytes;
-  W.ctl = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_ctl));
-  W.ox = W.oy = 0;
-  W.lo_x4 = W.lo_y = 0;
-  W.hi_x4 = W.hi_y = 0;
-  W.stats = stats;
-  if (threadIdx.x < 3) win_ctl[C::kCtlFlag / 4 + threadIdx.x] = 0;
-
-  int y[kWinRows], dx8[kWinRows], dy[kWinRows];
-  f32x2 f[kWinRows], vi[kWinRows], s_uv[kWinRows];
-  float sp[kWinRows];
-  bool live[kWinRows];
-  unsigned opix[kWinRows];
-#pragma unroll
-  for (int j = 0; j < kWinRows; ++j) {
-    live[j] = xt < n && yt + j < row0 + rows;
-    y[j] = min(yt + j, m - 1);
-    opix[j] = static_cast<unsigned>(__mul24(y[j] - row0, n) + x) << 2;
-    int px = x, py = y[j];
-    float ifx = 0.f, ify = 0.f, ivx = 0.f, ivy = 0.f;
-    if (resume) {
-      split_displacement(disp[static_cast<size_t>(y[j]) * n + x], px, ifx);
-      split_displacement(disp[plane + static_cast<size_t>(y[j]) * n + x], py, ify);
-    } else {
-      const unsigned pix = static_cast<unsigned>(__mul24(y[j], n) + x) << 2;
-      ivx = ld(F.u0, pix) * first_scale;  // first increment is NOT divided by n_iter (semilagrangian.py:202)
-      ivy = ld(F.v0, pix) * first_scale;
-    }
-    dx8[j] = px * 8;
-    dy[j] = py;
-    f[j] = f32x2{ifx, ify};
-    vi[j] = f32x2{ivx, ivy};
-    sp[j] = 0.f;
-  }
+  const int lane = threadIdx.x & (kTileX - 1);
   const float move_scale = guard * static_cast<float>(n_iter);
-  __syncthreads();
-  int phase = 0;
-  win_update<C>(F, W, phase, true, dx8, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
-  phase = 1;
-  if (resume) {
-    win_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
-    const float s0 = scale[0];
-#pragma unroll
-    for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * s0;
-  }
   const float lostval = (bmode == kModeNearest || bmode == kModeGridConstant) ? __builtin_nanf("") : outval;
-#pragma unroll
-  for (int j = 0; j < kWinRows; ++j) vi[j] = vi[j] * 0.5f;  // the increment is only ever used halved (exact)
+  const int home = static_cast<int>(blockIdx.x) & (kNumXcd - 1);
+  int tile = PERSIST ? -1 : order[blockIdx.x];
+  int next = -1;
+  if (PERSIST && threadIdx.x == 0) next = win_next_slot(queue, home, tiles_per_xcd, order);
 
-  for (int t = 0; t < T; ++t) {
-    const float s = scale[t];
-    const float half_s = 0.5f * s;
-    for (int k = 0; k < n_iter; ++k) {
-      int mx8[kWinRows], my[kWinRows];
-      f32x2 g[kWinRows];
+  for (;;) {
+    if (PERSIST) {
+      // thread 0 hands the tile it pulled while the last one was running to the workgroup; nobody is inside the last
+      // tile's window any more once every wave is here
+      if (threadIdx.x == 0) win_ctl[C::kCtlTile / 4] = next;
+      __syncthreads();
+      tile = rfl(win_ctl[C::kCtlTile / 4]);
+    }
+    if (tile < 0) break;  // the whole workgroup
+    if (PERSIST && threadIdx.x == 0) next = win_next_slot(queue, home, tiles_per_xcd, order);  // in flight behind this tile
+    const int xt = (tile % tiles_x) * kTileX + lane;
+    const int yt = row0 + (tile / tiles_x) * C::kTileY + static_cast<int>(threadIdx.x / kTileX) * kWinRows;
+    const int x = min(xt, n - 1);
+    float *out = out_base;
+    Window W;
+    W.uv = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_planes));  // 8-byte texels
+    W.p = W.uv + 2u * C::kPlaneBytes;
+    W.ctl = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_ctl));
+    W.ox = W.oy = 0;
+    W.lo_x4 = W.lo_y = 0;
+    W.hi_x4 = W.hi_y = 0;
+    W.stats = stats;
+    if (threadIdx.x < 3) win_ctl[C::kCtlFlag / 4 + threadIdx.x] = 0;
+
+    int y[kWinRows], dx8[kWinRows], dy[kWinRows];
+    f32x2 f[kWinRows], vi[kWinRows], s_uv[kWinRows];
+    float sp[kWinRows];
+    bool live[kWinRows];
+    unsigned opix[kWinRows];
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) {
+      live[j] = xt < n && yt + j < row0 + rows;
+      y[j] = min(yt + j, m - 1);
+      opix[j] = static_cast<unsigned>(__mul24(y[j] - row0, n) + x) << 2;
+      int px = x, py = y[j];
+      float ifx = 0.f, ify = 0.f, ivx = 0.f, ivy = 0.f;
+      if (resume) {
+        split_displacement(disp[static_cast<size_t>(y[j]) * n + x], px, ifx);
+        split_displacement(disp[plane + static_cast<size_t>(y[j]) * n + x], py, ify);
+      } else {
+        const unsigned pix = static_cast<unsigned>(__mul24(y[j], n) + x) << 2;
+        ivx = ld(F.u0, pix) * first_scale;  // first increment is NOT divided by n_iter (semilagrangian.py:202)
+        ivy = ld(F.v0, pix) * first_scale;
+      }
+      dx8[j] = px * 8;
+      dy[j] = py;
+      f[j] = f32x2{ifx, ify};
+      vi[j] = f32x2{ivx, ivy};
+      sp[j] = 0.f;
+    }
+    __syncthreads();
+    int phase = 0;
+    win_update<C>(F, W, phase, true, dx8, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
+    phase = 1;
+    if (resume) {
+      win_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+      const float s0 = scale[0];
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * s0;
+    }
+#pragma unroll
+    for (int j = 0; j < kWinRows; ++j) vi[j] = vi[j] * 0.5f;  // the increment is only ever used halved (exact)
+
+    for (int t = 0; t < T; ++t) {
+      const float s = scale[t];
+      const float half_s = 0.5f * s;
+      for (int k = 0; k < n_iter; ++k) {
+        int mx8[kWinRows], my[kWinRows];
+        f32x2 g[kWinRows];
+#pragma unroll
+        for (int j = 0; j < kWinRows; ++j) {
+          mx8[j] = dx8[j];
+          my[j] = dy[j];
+          g[j] = f[j];
+          retreat_xy<!GEN>(mx8[j], my[j], g[j], vi[j]);  // midpoint rule (:213), vi = Vi / 2
+        }
+        win_sample<C, kVel, GEN>(F, W, mx8, my, g, m, n, outval, s_uv, sp);
+#pragma unroll
+        for (int j = 0; j < kWinRows; ++j) retreat_xy<!GEN>(dx8[j], dy[j], f[j], s_uv[j] * s);
+        if (k == n_iter - 1) {
+          win_sample<C, kVel | kPrecip, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+        } else {
+          win_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+        }
+#pragma unroll
+        for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * half_s;
+      }
 #pragma unroll
       for (int j = 0; j < kWinRows; ++j) {
-        mx8[j] = dx8[j];
-        my[j] = dy[j];
-        g[j] = f[j];
-        retreat_xy(mx8[j], my[j], g[j], vi[j]);  // midpoint rule (:213), vi = Vi / 2
+        const float val = lost(f[j].x, f[j].y) ? lostval : sp[j];
+        if (live[j]) __builtin_nontemporal_store(val, reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
       }
-      win_sample<C, kVel, GEN>(F, W, mx8, my, g, m, n, outval, s_uv, sp);
-#pragma unroll
-      for (int j = 0; j < kWinRows; ++j) retreat_xy(dx8[j], dy[j], f[j], s_uv[j] * s);
-      if (k == n_iter - 1) {
-        win_sample<C, kVel | kPrecip, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
-      } else {
-        win_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+      out += static_cast<size_t>(rows) * n;
+      if (t + 1 < T) {
+        win_update<C>(F, W, phase, false, dx8, dy, vi[0].x, vi[0].y, move_scale, m, n);
+        phase = phase == 2 ? 0 : phase + 1;
       }
-#pragma unroll
-      for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * half_s;
     }
-#pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
-      const float val = lost(f[j].x, f[j].y) ? lostval : sp[j];
-      if (live[j]) __builtin_nontemporal_store(val, reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
-    }
-    out += static_cast<size_t>(rows) * n;
-    if (t + 1 < T) {
-      win_update<C>(F, W, phase, false, dx8, dy, vi[0].x, vi[0].y, move_scale, m, n);
-      phase = phase == 2 ? 0 : phase + 1;
-    }
-  }
 
-  if (disp != nullptr) {
+    if (disp != nullptr) {
 #pragma unroll
-    for (int j = 0; j < kWinRows; ++j) {
-      if (!live[j]) continue;
-      disp[static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.ox + (dx8[j] >> 3) - x) + static_cast<double>(f[j].x);
-      disp[plane + static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.oy + dy[j] - y[j]) + static_cast<double>(f[j].y);
+      for (int j = 0; j < kWinRows; ++j) {
+        if (!live[j]) continue;
+        disp[static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.ox + (dx8[j] >> 3) - x) + static_cast<double>(f[j].x);
+        disp[plane + static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.oy + dy[j] - y[j]) + static_cast<double>(f[j].y);
+      }
+    }
+    if (!PERSIST) return;
+  }
+  // persistent launch: the last workgroup out rewinds the cursors (the next launch on the stream starts from zero)
+  if (PERSIST && threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(queue + kNumXcd, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+      for (int i = 0; i <= kNumXcd; ++i) __hip_atomic_store(queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
 
 // the window kernel reads the planes as they are: no packed copy of anything
+static bool window_shape(int m, int n) { return n % 4 == 0 && n >= Win8::kW && m >= Win8::kH; }
+
 bool semilag_window_eligible(const SemilagArgs &a) {
-  return a.precip != nullptr && a.order == 1 && a.n_iter >= 1 && a.n % 4 == 0 && a.n >= Win8::kW && a.m >= Win8::kH &&
+  return a.precip != nullptr && a.order == 1 && a.n_iter >= 1 && window_shape(a.m, a.n) &&
          reinterpret_cast<uintptr_t>(a.vel) % 16 == 0 && reinterpret_cast<uintptr_t>(a.precip) % 16 == 0 &&
          (static_cast<size_t>(a.m) * a.n) % 4 == 0;
+}
+
+// ---- the order the tiles are started in (see win_next_slot) ----------------------------------------------
+// One table per tile grid, built on the host and kept on the device.  Slot s belongs to XCD s % 8.
+struct WinOrder {
+  int tiles_x = 0, tiles_y = 0, tile_h = 0, mode = -1;
+  int *dev = nullptr;
+};
+static WinOrder g_win_orders[8];
+static int g_win_orders_next = 0;
+static unsigned *g_win_queue = nullptr;  // kQueueRing x 16 words: the cursors of persistent launches
+static unsigned g_win_queue_turn = 0;
+constexpr int kQueueRing = 16;
+
+// mode bit 0: XCD cells (else one band of tiles per XCD), bit 1: border rings first
+static std::vector<int> win_order_table(int tiles_x, int tiles_y, int tile_h, int mode) {
+  const int n_tiles = tiles_x * tiles_y, per = (n_tiles + kNumXcd - 1) / kNumXcd;
+  const bool cells = (mode & 1) && tiles_x % kNumXcd == 0 && tiles_y % kNumXcd == 0;
+  std::vector<int> table(static_cast<size_t>(per) * kNumXcd, -1);
+  for (int k = 0; k < kNumXcd; ++k) {
+    std::vector<int> mine;
+    for (int l = 0; l < per; ++l) {
+      int tile;
+      if (cells) {
+        const int cw = tiles_x / kNumXcd, ch = tiles_y / kNumXcd, per_cell = cw * ch;
+        const int cy = l / per_cell, r = l - cy * per_cell;
+        const int cx = (k + kNumXcd - cy) & (kNumXcd - 1);
+        tile = (cy * ch + r / cw) * tiles_x + cx * cw + r % cw;
+      } else {
+        tile = k * per + l;
+      }
+      if (tile < n_tiles) mine.push_back(tile);
+    }
+    if (mode & 2) {
+      // pixels between the tile and the nearest image border, in rings of 32 up to 192 (beyond: the interior)
+      auto ring = [&](int tile) {
+        const int tx = tile % tiles_x, ty = tile / tiles_x;
+        const int d = std::min(std::min(tx, tiles_x - 1 - tx) * kTileX, std::min(ty, tiles_y - 1 - ty) * tile_h);
+        return std::min(d, 192) / 32;
+      };
+      std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return ring(a) < ring(b); });
+    }
+    for (size_t l = 0; l < mine.size(); ++l) table[l * kNumXcd + k] = mine[l];
+  }
+  return table;
+}
+
+static const int *win_order(int tiles_x, int tiles_y, int tile_h, int mode, hipStream_t stream) {
+  for (const WinOrder &o : g_win_orders)
+    if (o.dev != nullptr && o.tiles_x == tiles_x && o.tiles_y == tiles_y && o.tile_h == tile_h && o.mode == mode) return o.dev;
+  WinOrder &o = g_win_orders[g_win_orders_next];
+  g_win_orders_next = (g_win_orders_next + 1) % 8;
+  const std::vector<int> table = win_order_table(tiles_x, tiles_y, tile_h, mode);
+  if (o.dev != nullptr) {
+    (void)hipStreamSynchronize(stream);  // a launch in flight may still read the table this slot held
+    (void)hipFree(o.dev);
+    o.dev = nullptr;
+  }
+  if (hipMalloc(&o.dev, table.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(o.dev, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(o.dev);
+    o.dev = nullptr;
+    return nullptr;
+  }
+  o.tiles_x = tiles_x;
+  o.tiles_y = tiles_y;
+  o.tile_h = tile_h;
+  o.mode = mode;
+  return o.dev;
+}
+
+static int env_int(const char *name, int fallback) {
+  const char *e = std::getenv(name);
+  return e ? std::atoi(e) : fallback;
 }
 
 template <class C>
@@ -1010,34 +1162,52 @@ static hipError_t launch_window(const SemilagArgs &a, hipStream_t stream) {
   const int tiles_y = (a.rows + C::kTileY - 1) / C::kTileY;
   const int n_tiles = tiles_x * tiles_y;
   const int tiles_per_xcd = (n_tiles + kNumXcd - 1) / kNumXcd;
-  const dim3 grid(tiles_per_xcd * kNumXcd), block(C::kThreads);
   static const bool want_stats = std::getenv("PYSTEPS_HIP_SL_STATS") != nullptr;
   // room asked for ahead of the corner samples, in half increments per sub-step: 2.0 = the distance the last lead step
   // covered (+ 2 pixels); measured 2.0 / 2.2 / 2.5 / 3.0: 1.184 / 1.190 / 1.206 / 1.209 ms (development knob)
   static const float guard = std::getenv("PYSTEPS_HIP_SL_GUARD") ? static_cast<float>(std::atof(std::getenv("PYSTEPS_HIP_SL_GUARD"))) : 2.0f;
-  static const bool want_cells = std::getenv("PYSTEPS_HIP_SL_CELLS") == nullptr || std::atoi(std::getenv("PYSTEPS_HIP_SL_CELLS")) != 0;
-  const int cells = (want_cells && tiles_x % kNumXcd == 0 && tiles_y % kNumXcd == 0) ? 1 : 0;
+  // development knobs: PYSTEPS_HIP_SL_CELLS=0: one band of tiles per XCD; PYSTEPS_HIP_SL_RINGS=0: image order instead of
+  // border rings first; PYSTEPS_HIP_SL_PERSIST=1: persistent workgroups on a tile queue (N > 1: N workgroups)
+  static const int order_mode = (env_int("PYSTEPS_HIP_SL_CELLS", 1) ? 1 : 0) | (env_int("PYSTEPS_HIP_SL_RINGS", 1) ? 2 : 0);
+  static const int persist = env_int("PYSTEPS_HIP_SL_PERSIST", 0);
+  const int *order = win_order(tiles_x, tiles_y, C::kTileY, order_mode, stream);
+  if (order == nullptr) return hipErrorOutOfMemory;
+  unsigned *queue = nullptr;
+  // workgroups the chip holds at once: kOcc waves per SIMD
+  // (PYSTEPS_HIP_SL_PERSIST > 1: that many workgroups, whatever the grid - the tests' way to a queue on small images)
+  const int resident = persist > 1 ? persist : psh::ctx().cu_count * (4 * C::kOcc / C::kWaves);
+  int grid_x = tiles_per_xcd * kNumXcd;
+  if (persist && (grid_x > resident || persist > 1)) {
+    if (g_win_queue == nullptr) {
+      if (hipMalloc(&g_win_queue, kQueueRing * 16 * sizeof(unsigned)) != hipSuccess) return hipErrorOutOfMemory;
+      if (hipMemset(g_win_queue, 0, kQueueRing * 16 * sizeof(unsigned)) != hipSuccess) return hipErrorUnknown;
+    }
+    queue = g_win_queue + 16 * (g_win_queue_turn++ % kQueueRing);
+    grid_x = resident;
+  }
+  const dim3 grid(grid_x), block(C::kThreads);
   if (want_stats) {
     if (g_win_stats == nullptr && hipMalloc(&g_win_stats, 4 * sizeof(unsigned long long)) != hipSuccess) g_win_stats = nullptr;
     if (g_win_stats != nullptr) (void)hipMemsetAsync(g_win_stats, 0, 4 * sizeof(unsigned long long), stream);
   }
+#define PSH_WIN_LAUNCH(GEN, PERSIST)                                                                               \
+  hipLaunchKernelGGL((semilag_window<C, GEN, PERSIST>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale, \
+                     a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x,      \
+                     n_tiles, tiles_per_xcd, guard, order, queue, g_win_stats)
   if (a.bmode != 0) {
-    hipLaunchKernelGGL((semilag_window<C, true>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
-                       a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
-                       tiles_per_xcd, guard, cells, g_win_stats);
+    if (queue != nullptr) PSH_WIN_LAUNCH(true, true); else PSH_WIN_LAUNCH(true, false);
   } else {
-    hipLaunchKernelGGL((semilag_window<C, false>), grid, block, 0, stream, a.precip, a.vel, a.out, a.disp, a.scale,
-                       a.first_scale, a.m, a.n, a.T, a.n_iter, a.resume, a.outval, a.row0, a.rows, a.bmode, tiles_x, n_tiles,
-                       tiles_per_xcd, guard, cells, g_win_stats);
+    if (queue != nullptr) PSH_WIN_LAUNCH(false, true); else PSH_WIN_LAUNCH(false, false);
   }
+#undef PSH_WIN_LAUNCH
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess && want_stats && g_win_stats != nullptr) {
     unsigned long long h[4] = {0, 0, 0, 0};
     if (hipMemcpyAsync(h, g_win_stats, sizeof(h), hipMemcpyDeviceToHost, stream) == hipSuccess &&
         hipStreamSynchronize(stream) == hipSuccess)
-      std::fprintf(stderr, "semilag_window<%d waves>: %dx%d T=%d: wave-passes through the window %llu, through the gathers %llu, "
-                   "window fills (per wave) %llu (%d workgroups x %d lead steps)\n", C::kWaves, a.m, a.n, a.T, h[0], h[1], h[2],
-                   n_tiles, a.T);
+      std::fprintf(stderr, "semilag_window<%d waves x %d rows>: %dx%d T=%d: wave-passes through the window %llu, through the gathers %llu, "
+                   "window fills (per wave) %llu (%d tiles on %d workgroups x %d lead steps)\n", C::kWaves, C::kRows, a.m, a.n, a.T,
+                   h[0], h[1], h[2], n_tiles, grid_x, a.T);
   }
   return e;
 }
@@ -1104,6 +1274,26 @@ bool semilag_uses_window(const SemilagArgs &a) {
   if (!semilag_window_eligible(a)) return false;
   if (g_semilag_variant == 12) return true;
   return g_semilag_variant == 0 && static_cast<long long>(a.T) * a.n_iter >= kWindowMinPasses;
+}
+
+bool semilag_window_shape(int m, int n) { return window_shape(m, n); }
+
+// which kernel a call of this shape takes under the current "semilag_variant" (16-byte aligned planes assumed):
+// 12 the window kernel, 7 / 5 / 1 the gather modes (psh_semilag_kernel: bench.py labels its roofline with it)
+int semilag_kernel_choice(int m, int n, int T, int n_iter, int order, bool has_field) {
+  SemilagArgs a{};
+  static float dummy[4] __attribute__((aligned(16)));
+  a.precip = has_field ? dummy : nullptr;
+  a.vel = dummy;
+  a.m = m;
+  a.n = n;
+  a.T = T;
+  a.n_iter = n_iter;
+  a.order = order;
+  if (semilag_uses_window(a)) return 12;
+  if (semilag_wants_field_pairs(a)) return 7;
+  if (semilag_wants_packed(a)) return 5;
+  return 1;
 }
 
 hipError_t launch_semilag(const SemilagArgs &a, hipStream_t stream) {

@@ -37,8 +37,11 @@ _N_STATS = 8
 # used by the tests to keep both orchestrations honest)
 USE_NATIVE_ORCHESTRATION = True
 # a resident motion field also as (m, n, 2) {u, v} pairs (DeviceArray.uv_pairs): the layout of the extrapolator's gather
-# kernels (semilag_variant 7 / 5); the default window kernel samples the planes
-WRITE_UV_TWIN = False
+# kernels (semilag_variant 7 / 5).  None (default): decided per field - the window kernel samples the planes, so the
+# twin's stores are only spent for shapes it does not take (psh_semilag_window_shape: n % 4 != 0, n < 96 or m < 64 - a
+# 640 x 710 composite, say), where every long extrapolation call would otherwise interleave the planes again.
+# True / False: always / never
+WRITE_UV_TWIN = None
 # one corner request (launch -> finish) is in flight per process: callers on several threads
 # (the reference is re-entrant and gets called from dask workers) take turns here
 _corner_lock = threading.Lock()
@@ -201,7 +204,8 @@ def _dense_lk_native(frames, on_device, dense, size_opening, buffer_mask, max_co
         # (WRITE_UV_TWIN: a resident field also gets its {u, v}-interleaved twin, written by the interpolation kernel:
         # the layout the extrapolator's GATHER kernels sample, which would otherwise interleave the planes on every
         # call; the window kernel - the default - reads the planes, so the twin's 128 MB of stores are not spent)
-        pairs = DeviceArray((m, n, 2), np.float32) if on_device and WRITE_UV_TWIN else None
+        want_twin = (not lib.psh_semilag_window_shape(m, n)) if WRITE_UV_TWIN is None else bool(WRITE_UV_TWIN)
+        pairs = DeviceArray((m, n, 2), np.float32) if on_device and want_twin else None
         rc = lib.psh_dense_lk_uv_dev(frames.ptr, nr_fields, m, n, ctypes.byref(prm), field.ptr,
                                      None if pairs is None else pairs.ptr, None, None, 0,
                                      None if on_device else ctypes.byref(count))

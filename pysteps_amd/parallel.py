@@ -152,6 +152,42 @@ def banded_dense_lucaskanade(frames, comm, **kwargs):
     return banded.run(banded.band_lucaskanade(frames, comm.rank, comm.world_size, **kwargs), comm)
 
 
+def config5_plan(m, world_size, rank, lk="replicated"):
+    """What ``rank`` does in one step of the row-band nowcast (BASELINE config 5) - no device needed.
+
+    ``lk="replicated"`` (the default): every rank runs the WHOLE dense Lucas-Kanade estimate on the frames it holds.
+    The estimate is deterministic (integer image passes, ordered corner walk, fixed-order k-NN sums), so all ranks
+    arrive at the same field bit for bit and the step has NO data-path collective: the estimate costs 1.5 ms at
+    8192^2 on one MI355X, less than moving its 512 MiB result over xGMI would (>= 3 ms at the links' 153 GB/s), and a
+    row-band estimate cannot pay either - its sequential stages (corner walk, vector QC) do not shrink with the band
+    and each needs a collective (``lk="banded"``: 3 small allreduces + 2 allgathers per estimate,
+    :mod:`pysteps_amd.motion.banded`).  Only the extrapolation (5.5 ms at 8192^2 x 36 lead times) is worth tiling:
+    expected time per rank ~ 1.5 + 5.5 / world_size ms."""
+    if lk not in ("replicated", "banded"):
+        raise ValueError("lk must be 'replicated' or 'banded'")
+    rows = partition(m, world_size, rank)
+    return {"rows": (rows.start, rows.stop), "lk": lk,
+            "collectives_per_step": 0 if lk == "replicated" else 5,
+            "expected_ms_8192": 1.5 + 5.5 / world_size if lk == "replicated" else None}
+
+
+def config5_step(frames, timesteps, rank, world_size, comm=None, lk="replicated", lk_kwargs=None, **kwargs):
+    """One step of the row-band nowcast on frames every rank holds (one broadcast, outside the step): the motion
+    field (see :func:`config5_plan` for the two ways), then this rank's row band of the extrapolation of the last
+    frame.  Returns ``(rows, out)`` as :func:`tiled_extrapolate` does; the bands of all ranks concatenate to the
+    single-device result bit for bit (tests/test_semilag_gpu.py, tests/test_lk_banded_gpu.py)."""
+    from .motion import get_method
+
+    plan = config5_plan(frames.shape[1], world_size, rank, lk)
+    if plan["lk"] == "banded":
+        if comm is None:
+            raise ValueError("lk='banded' needs the communicator its collectives run on")
+        v = banded_dense_lucaskanade(frames, comm, **(lk_kwargs or {}))
+    else:
+        v = get_method("LK")(frames, **(lk_kwargs or {}))
+    return tiled_extrapolate(frames.view(frames.shape[0] - 1), v, timesteps, rank, world_size, **kwargs)
+
+
 def tiled_extrapolate(precip, velocity, timesteps, rank, world_size, outval=float("nan"), n_iter=1,
                       interp_order=1):
     """Output-tiled nowcast for domains shared by several GPUs (BASELINE config 5).

@@ -30,8 +30,10 @@ def main():
     eps = [p["eps_par"] for p in steps_perturbators(n_total, 42, 1.0, 5.0)[shard.start:shard.stop]]
     # ... and the random streams of its members (the first draw of each identifies the stream)
     first_draws = [float(rs.standard_normal()) for rs in steps_noise_generators(n_total, 42)[shard.start:shard.stop]]
+    # config 5: row bands of the extrapolation, the motion estimate replicated (no collective in the step)
+    plan = parallel.config5_plan(8192, dist.world, dist.rank)
     with open(os.path.join(out_dir, "rank%d.json" % dist.rank), "w") as fh:
-        json.dump({"rank": dist.rank, "max": slowest, "token_len": len(token), "mine": mine,
+        json.dump({"rank": dist.rank, "max": slowest, "token_len": len(token), "mine": mine, "config5": plan,
                    "owners": owners, "shard": list(shard), "eps_par": eps, "first_draws": first_draws}, fh)
     dist.barrier()
     dist.close()

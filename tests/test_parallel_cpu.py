@@ -45,6 +45,10 @@ def test_two_rank_gloo_control_plane(tmp_path):
     assert [r["token_len"] for r in res] == [128, 128]    # rank-0 payload reached rank 1
     assert res[0]["mine"] == list(range(24)) and res[1]["mine"] == list(range(24, 48))
     assert res[0]["owners"] == [0] * 24 and res[1]["owners"] == [1] * 24
+    # config 5: the ranks' row bands tile the 8192 rows, the default plan has no collective in the step
+    assert [tuple(r["config5"]["rows"]) for r in res] == [(0, 4096), (4096, 8192)]
+    assert all(r["config5"]["lk"] == "replicated" and r["config5"]["collectives_per_step"] == 0 for r in res)
+    assert parallel.config5_plan(8192, 8, 3, lk="banded")["collectives_per_step"] == 5
     # the member shards of bench.py's N > 1 leg (6 per GPU): disjoint, complete, and the perturbators
     # each rank derives from the ensemble seed are the slices of ONE seed chain
     from pysteps_amd.extrapolation.ensemble import steps_perturbators

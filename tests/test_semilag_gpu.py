@@ -465,6 +465,44 @@ def test_window_kernel_on_hard_motion_fields(extrapolate, field):
         assert np.array_equal(got, want, equal_nan=True)
 
 
+@pytest.mark.parametrize("sentinel", [1e20, -1e20, 1e9, -3e9])
+def test_window_kernel_on_sentinel_velocities(extrapolate, sentinel):
+    """Finite garbage in the motion field (a sentinel such as 1e20 in a patch): a trajectory that samples it leaves every
+    image for good - the reference's float64 positions do, the gather kernels' integer positions do (they wrap at 2^31
+    pixels), and the window kernel's pre-scaled column offset, which would wrap back INTO the window at 2^28, limits the
+    integer step to +-2^27 pixels (retreat_xy).  Fields of the window kernel, the gather kernels and the oracle agree;
+    displacements are compared where the oracle's are not astronomical."""
+    from oracle import semilag as osl
+    from pysteps_amd import _lib
+    from tools import synth
+
+    m, n = 256, 384
+    v = synth.true_velocity(m, n)
+    v[0, 100:108, 200:212] = sentinel
+    v[1, 140:150, 90:100] = -sentinel
+    p = synth.rain_field_db(m, n, seed=4)
+    lib = _lib.lib()
+    runs = {}
+    for variant in (7, 12):
+        _lib.check(lib.psh_set_option(b"semilag_variant", variant))
+        try:
+            runs[variant] = extrapolate(p, v, 6, n_iter=1, outval=-15.0, return_displacement=True)
+        finally:
+            _lib.check(lib.psh_set_option(b"semilag_variant", 0))
+    assert np.array_equal(runs[12][0], runs[7][0], equal_nan=True)
+    with np.errstate(all="ignore"):
+        want, wdisp = osl.extrapolate(p, v, 6, n_iter=1, outval=-15.0, return_displacement=True)
+    assert np.array_equal(np.isnan(runs[12][0]), np.isnan(want))
+    ok = np.isfinite(want)
+    assert np.linalg.norm(runs[12][0][ok] - want[ok]) / np.linalg.norm(want[ok]) < 1e-4
+    sane = np.all(np.abs(wdisp) < 1e6, axis=0)
+    assert sane.mean() > 0.9 and (~sane).sum() > 50  # the sentinel patch was sampled
+    for variant in (7, 12):
+        assert np.max(np.abs(runs[variant][1][:, sane] - wdisp[:, sane])) < 1e-4
+        far = np.abs(wdisp) >= 1e6
+        assert np.all(np.abs(runs[variant][1][far]) > 1e6)
+
+
 def test_config3_4096_full_size_vs_oracle(extrapolate):
     """BASELINE config 3 (the bench workload): 4096^2, 24 lead times, n_iter=1, against the
     multi-threaded C oracle at full size; device-resident so only the results cross PCIe."""
@@ -679,8 +717,8 @@ def test_input_checks_run_on_the_device_with_the_reference_messages(extrapolate)
 def test_interleaved_motion_field_twin_is_the_field_and_gives_the_same_advection(extrapolate, monkeypatch):
     """dense_lucaskanade on resident frames can hand the motion field over twice: as (2, m, n) planes and, written by
     the same interpolation kernel, as (m, n, 2) {u, v} pairs - the layout the GATHER kernels of the extrapolator sample
-    (``lucaskanade.WRITE_UV_TWIN``; the window kernel, the default since round 5, reads the planes and the twin is
-    not written any more).  The twin must hold the same numbers, and advecting with it (gather kernels,
+    (``lucaskanade.WRITE_UV_TWIN``; the window kernel, the default since round 5, reads the planes, so the twin is
+    only written for the shapes that kernel does not take).  The twin must hold the same numbers, and advecting with it (gather kernels,
     ``semilag_variant`` 7) must give the bytes the default kernel gives from the planes."""
     from pysteps_amd import _lib
     from pysteps_amd.device import DeviceArray
@@ -691,8 +729,13 @@ def test_interleaved_motion_field_twin_is_the_field_and_gives_the_same_advection
     lib = _lib.lib()
     for m, n in ((512, 512), (130, 203)):  # (the second shape is not one the window kernel takes)
         frames = synth.steps_frames(m, n, 2)
+        # the default (None) decides per field: no second layout where the window kernel samples the planes, the twin
+        # for shapes it does not take (they would interleave the planes on every long call otherwise)
+        monkeypatch.setattr(lucaskanade, "WRITE_UV_TWIN", None)
+        auto = getattr(dense_lk(DeviceArray.from_host(frames)), "uv_pairs", None)
+        assert (auto is None) == bool(lib.psh_semilag_window_shape(m, n)) == (n == 512)
         monkeypatch.setattr(lucaskanade, "WRITE_UV_TWIN", False)
-        assert getattr(dense_lk(DeviceArray.from_host(frames)), "uv_pairs", None) is None  # the default: no second layout
+        assert getattr(dense_lk(DeviceArray.from_host(frames)), "uv_pairs", None) is None
         monkeypatch.setattr(lucaskanade, "WRITE_UV_TWIN", True)
         V = dense_lk(DeviceArray.from_host(frames))
         assert V.uv_pairs is not None and V.uv_pairs.shape == (m, n, 2)

@@ -1,7 +1,19 @@
 """Copy the judged summaries of a gpurun_out/<tag> session into profiles/<round>/ and refresh
 profiles/pmc_traffic.json (HBM bytes per launch of the extrapolation kernel; FETCH_SIZE is doubled: gfx950
 reports exactly half of a coalesced read stream, see tools/calib_copy.py / DESIGN.md section 6)."""
-import csv, glob, json, os, shutil, sys
+import csv, glob, hashlib, json, os, shutil, sys
+
+
+def blob_hash(path):
+    """git's blob hash of a working-tree file: bench.py compares these with the tree it runs from and withholds the
+    counters (`traffic_stale` / `roofline_lk.stale`) when a kernel source changed after they were taken"""
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+SL_SOURCES = ("pysteps_amd/csrc/semilag.hip", "pysteps_amd/csrc/semilag_device.h", "pysteps_amd/csrc/common.h")
+LK_SOURCES = ("pysteps_amd/csrc/lk.hip", "pysteps_amd/csrc/lk_sparse.hip", "pysteps_amd/csrc/sparse_qc.hip",
+              "pysteps_amd/csrc/idw.hip", "pysteps_amd/csrc/dense_lk.hip", "pysteps_amd/csrc/common.h")
 
 tag, rnd, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
 src = os.path.join("gpurun_out", tag)
@@ -55,6 +67,7 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
         counter_source = "profiles/%s/%s_pmc_kernels.csv" % (rnd, prefix)
     json.dump({"source": "profiles/%s/%s_rocprofv3_kernel_stats.csv" % (rnd, prefix), "steps_traced": STEPS_TRACED,
                "workload": "4096x4096", "counters": counters, "counter_source": counter_source,
+               "source_hashes": {src: blob_hash(src) for src in LK_SOURCES},
                "note": "ns_per_step also spreads the input synthesis launches of semilag_fused over the steps; "
                        "LK kernels only run inside steps", "kernels": table},
               open(os.path.join("profiles", "kernel_stats_latest.json"), "w"), indent=1)
@@ -83,7 +96,17 @@ if fetch and write:
         "kernel_ms_under_pmc": fetch[1],
         "alg_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
         "source": "gpurun_out/%s pmc_fetch + pmc_write (rocprofv3 --pmc, separate passes)" % tag,
+        "source_hashes": {src: blob_hash(src) for src in SL_SOURCES},
     }
+    # VALU instructions and chip cycles of the same launch (the roofline that binds the window kernel: VALU issue)
+    stats = json.load(open(os.path.join("profiles", "kernel_stats_latest.json"))) if os.path.exists(
+        os.path.join("profiles", "kernel_stats_latest.json")) else {}
+    c = stats.get("counters", {}).get(SL_KERNEL, {})
+    for name in ("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_LDS"):
+        if name in c:
+            rec[name] = c[name]
+    if "SQ_INSTS_VALU" in c:
+        rec["source"] += "; SQ_* / GRBM_* from %s" % stats.get("counter_source")
     path = os.path.join("profiles", "pmc_traffic.json")
     table = json.load(open(path)) if os.path.exists(path) else {}
     table[key] = rec
