@@ -563,15 +563,15 @@ __global__ __launch_bounds__(kTileX *kDirectWaves) void semilag_fused(
     for (int j = 0; j < NPX; ++j) {
       if (!live[j]) continue;
       disp[static_cast<size_t>(y[j]) * n + x] =
-          static_cast<double>(px[j] - x) + static_cast<double>(fx[j]);
+          static_cast<double>(px[j]) - static_cast<double>(x) + static_cast<double>(fx[j]);
       disp[plane + static_cast<size_t>(y[j]) * n + x] =
-          static_cast<double>(py[j] - y[j]) + static_cast<double>(fy[j]);
+          static_cast<double>(py[j]) - static_cast<double>(y[j]) + static_cast<double>(fy[j]);
     }
   }
 }
 
 // ---- workgroup window ------------------------------------------------------------------------------
-// The gather kernels above are bound by the CU's vector-memory pipeline: five wave64 dwordx4 gathers per
+// The gather kernels above are bound by the CU's vector-memory pipeline: five wave64 dwordxw gathers per
 // pixel and lead step return 80 B per lane through a 64 B/clk path (docs/history.md 3.1), whatever the caches
 // hold.  The window kernel below takes that pipeline out of the inner loop.  A workgroup of eight waves
 // owns a 64 x 32 tile (four rows per lane) and keeps a WINDOW of the motion field and of the advected
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kTileX *kDirectWaves) void semilag_fused(
 //  * Once per lead step the waves agree (one s_barrier) on whether the window has to move: a wave asks
 //    for it when the corner samples of its patch come closer to the window's edge than the distance the
 //    next step covers.  The new window is placed with its slack AHEAD of the motion (it then lasts
-//    slack / speed lead steps: ~5 at 6 px per step), filled by coalesced dwordx4 loads + ds_write_b128,
+//    slack / speed lead steps: ~5 at 6 px per step), filled by coalesced dwordxw loads + ds_write_b128,
 //    and the lanes re-base their offsets.
 //  * XCD cells, guards, what bounds the kernel now and everything round 5 measured on the way: DESIGN.md 3.1 / 9.
 
@@ -619,8 +619,7 @@ struct WinCfg {
   static constexpr int kWaves = WAVES, kW = WW, kH = WH;
   static constexpr int kRows = ROWS;  // image rows per lane
   static constexpr int kOcc = OCC;    // waves per SIMD the register budget is cut for (two workgroups of 8 waves: 4)
-  // u and v are interleaved as {u,v} pairs in ONE window plane (8-byte texels): column offsets are pre-scaled by 8
-  static constexpr int kXShift = 3;
+  // u and v are interleaved as {u,v} pairs in ONE window plane (8-byte texels)
   static constexpr int kTileY = ROWS * WAVES;
   static constexpr unsigned kPitch4 = WW * 4u;          // bytes per window row of one plane
   static constexpr unsigned kPlaneBytes = WW * WH * 4u;
@@ -643,7 +642,7 @@ struct Window {
   int ox, oy;        // image position of the window's first texel (uniform over the workgroup)
   // where the corner samples of a patch may be without asking for a new window (pre-scaled columns / rows):
   // set when a window is placed, from the direction and speed of travel
-  int lo_x4, hi_x4, lo_y, hi_y;
+  int lo_x, hi_x, lo_y, hi_y;
   unsigned long long *stats;
 };
 
@@ -653,12 +652,12 @@ __device__ __forceinline__ void win_count(const Window &W, int which) {
 
 // the box of a patch's corner samples (window-relative, pre-scaled columns / rows): eight v_readlane, scalar min / max
 struct WinBox {
-  int lo4, hi4, loy, hiy;
+  int lox, hix, loy, hiy;
 };
 template <int kWinRows>
-__device__ __forceinline__ WinBox win_corners(const int (&dx4)[kWinRows], const int (&dy)[kWinRows]) {
-  const int xa = __builtin_amdgcn_readlane(dx4[0], 0), xb = __builtin_amdgcn_readlane(dx4[0], 63);
-  const int xc = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 0), xd = __builtin_amdgcn_readlane(dx4[kWinRows - 1], 63);
+__device__ __forceinline__ WinBox win_corners(const int (&dxw)[kWinRows], const int (&dy)[kWinRows]) {
+  const int xa = __builtin_amdgcn_readlane(dxw[0], 0), xb = __builtin_amdgcn_readlane(dxw[0], 63);
+  const int xc = __builtin_amdgcn_readlane(dxw[kWinRows - 1], 0), xd = __builtin_amdgcn_readlane(dxw[kWinRows - 1], 63);
   const int ya = __builtin_amdgcn_readlane(dy[0], 0), yb = __builtin_amdgcn_readlane(dy[0], 63);
   const int yc = __builtin_amdgcn_readlane(dy[kWinRows - 1], 0), yd = __builtin_amdgcn_readlane(dy[kWinRows - 1], 63);
   return {smin(smin(xa, xb), smin(xc, xd)), smax(smax(xa, xb), smax(xc, xd)), smin(smin(ya, yb), smin(yc, yd)),
@@ -671,7 +670,7 @@ __device__ __forceinline__ void win_publish(const Window &W, int wave, const Win
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
   lds_int *ctl = (lds_int *)(size_t)W.ctl;
-  *(lds_i32x4 *)(size_t)(W.ctl + 16u * wave) = i32x4{bx.lo4, bx.hi4, bx.loy, bx.hiy};
+  *(lds_i32x4 *)(size_t)(W.ctl + 16u * wave) = i32x4{bx.lox, bx.hix, bx.loy, bx.hiy};
   if (wave == 0) {
     ctl[C::kCtlVel / 4 + 0] = __float_as_int(vx_lane);
     ctl[C::kCtlVel / 4 + 1] = __float_as_int(vy_lane);
@@ -681,21 +680,21 @@ __device__ __forceinline__ void win_publish(const Window &W, int wave, const Win
 // Every wave of the workgroup, with every wave's box published and nobody reading the window any more: place the
 // new window ahead of the motion, re-base the offsets, fill it.  (The caller orders the LDS writes before the next reader.)
 template <class C>
-__device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, bool force, int (&dx4)[C::kRows],
+__device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, bool force, int (&dxw)[C::kRows],
                                                     int (&dy)[C::kRows], float move_scale, int m, int n) {
   constexpr int kWinRows = C::kRows;
   lds_int *ctl = (lds_int *)(size_t)W.ctl;
-  int ulo4 = 0x7fffffff, uhi4 = -0x7fffffff, uloy = 0x7fffffff, uhiy = -0x7fffffff;
+  int ulox = 0x7fffffff, uhix = -0x7fffffff, uloy = 0x7fffffff, uhiy = -0x7fffffff;
 #pragma unroll
   for (int w = 0; w < C::kWaves; ++w) {
-    ulo4 = min(ulo4, ctl[w * 4 + 0]);
-    uhi4 = max(uhi4, ctl[w * 4 + 1]);
+    ulox = min(ulox, ctl[w * 4 + 0]);
+    uhix = max(uhix, ctl[w * 4 + 1]);
     uloy = min(uloy, ctl[w * 4 + 2]);
     uhiy = max(uhiy, ctl[w * 4 + 3]);
   }
   const float wvx = __int_as_float(ctl[C::kCtlVel / 4 + 0]), wvy = __int_as_float(ctl[C::kCtlVel / 4 + 1]);
   // first and last texel the tile touches now (right / lower tap included), relative to the current origin
-  const int bx0 = ulo4 >> C::kXShift, bx1 = (uhi4 >> C::kXShift) + 1, by0 = uloy, by1 = uhiy + 1;
+  const int bx0 = ulox, bx1 = uhix + 1, by0 = uloy, by1 = uhiy + 1;
   const int slack_x = max(C::kW - (bx1 - bx0 + 1), 0), slack_y = max(C::kH - (by1 - by0 + 1), 0);
   // texels kept on the low side: all the slack but two where the motion goes that way (a positive velocity moves
   // the samples towards lower coordinates), two where it comes from, half of it in calm air
@@ -707,18 +706,18 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
   // a lost trajectory (NaN) asks for nothing
   const float mvx = fabsf(wvx) < 64.f ? fabsf(wvx) * move_scale + 2.f : 2.f, mvy = fabsf(wvy) < 64.f ? fabsf(wvy) * move_scale + 2.f : 2.f;
   const int gx = rfl(static_cast<int>(mvx)), gy = rfl(static_cast<int>(mvy));
-  W.lo_x4 = (wvx > 0.f ? gx : 1) << C::kXShift;
-  W.hi_x4 = (C::kW - 2 - (wvx > 0.f ? 1 : gx)) << C::kXShift;
+  W.lo_x = wvx > 0.f ? gx : 1;
+  W.hi_x = C::kW - 2 - (wvx > 0.f ? 1 : gx);
   W.lo_y = wvy > 0.f ? gy : 1;
   W.hi_y = C::kH - 2 - (wvy > 0.f ? 1 : gy);
   // (a tile parked at the image border keeps asking: the window it would get is the one it has)
   if (!force && nox == W.ox && noy == W.oy) return;
   win_count(W, 2);
-  const int ddx4 = (nox - W.ox) << C::kXShift, ddy = noy - W.oy;
+  const int ddx = nox - W.ox, ddy = noy - W.oy;
 #pragma unroll
   for (int j = 0; j < kWinRows; ++j) {
-    dx4[j] -= ddx4;
-    dy[j] -= ddy;
+    dxw[j] = sat_sub(dxw[j], ddx);  // (a trajectory that left for good stays at the end of the number line)
+    dy[j] = sat_sub(dy[j], ddy);
   }
   W.ox = nox;
   W.oy = noy;
@@ -752,13 +751,13 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
 // second barrier.  `phase` cycles through three flag words so that clearing the next one never races with a wave
 // that still has to read it.
 template <class C>
-__device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase, bool force, int (&dx4)[C::kRows],
+__device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase, bool force, int (&dxw)[C::kRows],
                                             int (&dy)[C::kRows], float vx_lane, float vy_lane, float move_scale, int m,
                                             int n) {
   const int lane = threadIdx.x & 63, wave = rfl(static_cast<int>(threadIdx.x >> 6));
   lds_int *ctl = (lds_int *)(size_t)W.ctl;
-  const WinBox bx = win_corners(dx4, dy);
-  const bool near = force || bx.lo4 < W.lo_x4 || bx.hi4 > W.hi_x4 || bx.loy < W.lo_y || bx.hiy > W.hi_y;
+  const WinBox bx = win_corners(dxw, dy);
+  const bool near = force || bx.lox < W.lo_x || bx.hix > W.hi_x || bx.loy < W.lo_y || bx.hiy > W.hi_y;
   if (lane == 0) {
     win_publish<C>(W, wave, bx, vx_lane, vy_lane);
     if (near) ctl[C::kCtlFlag / 4 + phase] = 1;
@@ -768,7 +767,7 @@ __device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase
   if (rfl(ctl[C::kCtlFlag / 4 + phase]) == 0) return;
   // every wave is past the barrier: nobody reads the old window any more.  The boxes of this step are overwritten
   // after the barrier below - every wave has read them by then
-  win_place_and_fill<C>(F, W, force, dx4, dy, move_scale, m, n);
+  win_place_and_fill<C>(F, W, force, dxw, dy, move_scale, m, n);
   win_barrier();
 }
 
@@ -790,32 +789,34 @@ __device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase
 // three times the LDS-issue stalls: 1.200 against 1.158 ms - and the gather kernel's arithmetic on a {u,v} window - 73 VALU: 1.28 ms;
 // profiles/r05/g_window_hybrid_timings.txt, b_*, c_*.)
 template <class C, int WHAT, bool GEN>
-__device__ __forceinline__ void win_sample(const Fields &F, const Window &W, const int (&dx8)[C::kRows],
+__device__ __forceinline__ void win_sample(const Fields &F, const Window &W, const int (&dxw)[C::kRows],
                                             const int (&dy)[C::kRows], const f32x2 (&f)[C::kRows], int m, int n,
                                             float outval, f32x2 (&s_uv)[C::kRows], float (&sp)[C::kRows]) {
   constexpr int kWinRows = C::kRows;
   static_assert(kWinRows == 2 || kWinRows == 4, "rows per lane");
   constexpr bool kWithP = (WHAT & kPrecip) != 0;
-  unsigned mx = static_cast<unsigned>(dx8[0]), my = static_cast<unsigned>(dy[0]);
+  unsigned mx = static_cast<unsigned>(dxw[0]), my = static_cast<unsigned>(dy[0]);
 #pragma unroll
   for (int j = 1; j < kWinRows; ++j) {
-    mx = max(mx, static_cast<unsigned>(dx8[j]));
+    mx = max(mx, static_cast<unsigned>(dxw[j]));
     my = max(my, static_cast<unsigned>(dy[j]));
   }
-  const bool ok = mx <= (C::kW - 2) * 8u && my <= static_cast<unsigned>(C::kH - 2);
+  const bool ok = mx <= static_cast<unsigned>(C::kW - 2) && my <= static_cast<unsigned>(C::kH - 2);
   if (__builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true)) {
     win_count(W, 0);
     f32x2 t[kWinRows][4];
     float rp[kWinRows][4];
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
-      const unsigned a = __umul24(static_cast<unsigned>(dy[j]), 2u * C::kPitch4) + static_cast<unsigned>(dx8[j]) + W.uv;
+      // texel index in the window (one v_mad_u32_u24), scaled to the 8-byte {u,v} texels and the 4-byte field texels
+      const unsigned tx = __umul24(static_cast<unsigned>(dy[j]), static_cast<unsigned>(C::kW)) + static_cast<unsigned>(dxw[j]);
+      const unsigned a = (tx << 3) + W.uv;
       asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:%c5\n\t"
                    "ds_read_b64 %3, %4 offset:%c6"
                    : "=&v"(t[j][0]), "=&v"(t[j][1]), "=&v"(t[j][2]), "=&v"(t[j][3])
                    : "v"(a), "i"(2u * C::kPitch4), "i"(2u * C::kPitch4 + 8u));
       if (kWithP) {
-        const unsigned ap = ((a - W.uv) >> 1) + W.p;
+        const unsigned ap = (tx << 2) + W.p;
         asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:%c5\n\t"
                      "ds_read_b32 %3, %4 offset:%c6"
                      : "=&v"(rp[j][0]), "=&v"(rp[j][1]), "=&v"(rp[j][2]), "=&v"(rp[j][3])
@@ -851,8 +852,8 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
     float sfx[kWinRows], sfy[kWinRows], ssu[kWinRows], ssv[kWinRows], ssp[kWinRows];
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
-      X[j] = W.ox + (dx8[j] >> 3);
-      Y[j] = W.oy + dy[j];
+      X[j] = sat_add(W.ox, dxw[j]);
+      Y[j] = sat_add(W.oy, dy[j]);
       sfx[j] = f[j].x;
       sfy[j] = f[j].y;
       ssp[j] = 0.f;
@@ -866,28 +867,19 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
   }
 }
 
-// one pixel's trajectory, both axes in one packed subtraction: P -= floor stuff exactly as retreat().
-// The column offset is pre-scaled by 8, so an integer step of 2^28 pixels and more - a garbage or sentinel
-// velocity such as 1e20, which v_cvt_flr saturates to INT_MAX - would wrap back INTO the window where the gather
-// kernels' positions (which wrap at 2^31) are outside the image: the step is limited to +-2^27 pixels, which
-// leaves every window and every image (tests/test_semilag_gpu.py::test_window_kernel_on_sentinel_velocities).
-// (MED3: one v_med3_i32 with one of the two bounds in a VGPR - a VALU instruction of gfx9 reads one SGPR; the
-// boundary-mode instantiation, which has no register to spare, takes v_max_i32 + v_min_i32 with literals.)
-template <bool MED3>
-__device__ __forceinline__ void retreat_xy(int &PX8, int &PY, f32x2 &f, f32x2 w) {
+// one pixel's trajectory, both axes in one packed subtraction: P -= floor stuff exactly as retreat() - the integer
+// parts by SATURATING adds (sat_add, semilag_device.h): a garbage or sentinel velocity such as 1e20, which v_cvt_flr
+// turns into INT_MAX / INT_MIN, sends the trajectory to the end of the number line, where it stays - as the reference's
+// float64 position does - instead of wrapping around to the other side of the image or back into it
+// (tests/test_semilag_gpu.py::test_window_kernel_on_sentinel_velocities).  (Round 5 carried the column pre-scaled by
+// the texel size - one multiply-add less per LDS address - which wraps at 2^28 pixels, inside the window again.)
+__device__ __forceinline__ void retreat_xy(int &PX, int &PY, f32x2 &f, f32x2 w) {
   const f32x2 t = f - w;
   int kx, ky;
   asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(kx) : "v"(t.x));
   asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ky) : "v"(t.y));
-#ifndef PSH_SL_NO_STEP_CLAMP
-  if constexpr (MED3) {
-    asm("v_med3_i32 %0, %0, %1, %2" : "+v"(kx) : "s"(-(1 << 27)), "v"(1 << 27));
-  } else {
-    kx = min(max(kx, -(1 << 27)), 1 << 27);
-  }
-#endif
-  PX8 += static_cast<int>(static_cast<unsigned>(kx) << 3);
-  PY += ky;
+  PX = sat_add(PX, kx);
+  PY = sat_add(PY, ky);
   f = f32x2{__builtin_amdgcn_fractf(t.x), __builtin_amdgcn_fractf(t.y)};
 }
 
@@ -975,12 +967,12 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
     W.p = W.uv + 2u * C::kPlaneBytes;
     W.ctl = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_ctl));
     W.ox = W.oy = 0;
-    W.lo_x4 = W.lo_y = 0;
-    W.hi_x4 = W.hi_y = 0;
+    W.lo_x = W.lo_y = 0;
+    W.hi_x = W.hi_y = 0;
     W.stats = stats;
     if (threadIdx.x < 3) win_ctl[C::kCtlFlag / 4 + threadIdx.x] = 0;
 
-    int y[kWinRows], dx8[kWinRows], dy[kWinRows];
+    int y[kWinRows], dxw[kWinRows], dy[kWinRows];
     f32x2 f[kWinRows], vi[kWinRows], s_uv[kWinRows];
     float sp[kWinRows];
     bool live[kWinRows];
@@ -1000,7 +992,7 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
         ivx = ld(F.u0, pix) * first_scale;  // first increment is NOT divided by n_iter (semilagrangian.py:202)
         ivy = ld(F.v0, pix) * first_scale;
       }
-      dx8[j] = px * 8;
+      dxw[j] = px;
       dy[j] = py;
       f[j] = f32x2{ifx, ify};
       vi[j] = f32x2{ivx, ivy};
@@ -1008,10 +1000,10 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
     }
     __syncthreads();
     int phase = 0;
-    win_update<C>(F, W, phase, true, dx8, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
+    win_update<C>(F, W, phase, true, dxw, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
     phase = 1;
     if (resume) {
-      win_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+      win_sample<C, kVel, GEN>(F, W, dxw, dy, f, m, n, outval, s_uv, sp);
       const float s0 = scale[0];
 #pragma unroll
       for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * s0;
@@ -1023,22 +1015,22 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
       const float s = scale[t];
       const float half_s = 0.5f * s;
       for (int k = 0; k < n_iter; ++k) {
-        int mx8[kWinRows], my[kWinRows];
+        int mxw[kWinRows], my[kWinRows];
         f32x2 g[kWinRows];
 #pragma unroll
         for (int j = 0; j < kWinRows; ++j) {
-          mx8[j] = dx8[j];
+          mxw[j] = dxw[j];
           my[j] = dy[j];
           g[j] = f[j];
-          retreat_xy<!GEN>(mx8[j], my[j], g[j], vi[j]);  // midpoint rule (:213), vi = Vi / 2
+          retreat_xy(mxw[j], my[j], g[j], vi[j]);  // midpoint rule (:213), vi = Vi / 2
         }
-        win_sample<C, kVel, GEN>(F, W, mx8, my, g, m, n, outval, s_uv, sp);
+        win_sample<C, kVel, GEN>(F, W, mxw, my, g, m, n, outval, s_uv, sp);
 #pragma unroll
-        for (int j = 0; j < kWinRows; ++j) retreat_xy<!GEN>(dx8[j], dy[j], f[j], s_uv[j] * s);
+        for (int j = 0; j < kWinRows; ++j) retreat_xy(dxw[j], dy[j], f[j], s_uv[j] * s);
         if (k == n_iter - 1) {
-          win_sample<C, kVel | kPrecip, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+          win_sample<C, kVel | kPrecip, GEN>(F, W, dxw, dy, f, m, n, outval, s_uv, sp);
         } else {
-          win_sample<C, kVel, GEN>(F, W, dx8, dy, f, m, n, outval, s_uv, sp);
+          win_sample<C, kVel, GEN>(F, W, dxw, dy, f, m, n, outval, s_uv, sp);
         }
 #pragma unroll
         for (int j = 0; j < kWinRows; ++j) vi[j] = s_uv[j] * half_s;
@@ -1050,7 +1042,7 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
       }
       out += static_cast<size_t>(rows) * n;
       if (t + 1 < T) {
-        win_update<C>(F, W, phase, false, dx8, dy, vi[0].x, vi[0].y, move_scale, m, n);
+        win_update<C>(F, W, phase, false, dxw, dy, vi[0].x, vi[0].y, move_scale, m, n);
         phase = phase == 2 ? 0 : phase + 1;
       }
     }
@@ -1059,8 +1051,8 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
 #pragma unroll
       for (int j = 0; j < kWinRows; ++j) {
         if (!live[j]) continue;
-        disp[static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.ox + (dx8[j] >> 3) - x) + static_cast<double>(f[j].x);
-        disp[plane + static_cast<size_t>(y[j]) * n + x] = static_cast<double>(W.oy + dy[j] - y[j]) + static_cast<double>(f[j].y);
+        disp[static_cast<size_t>(y[j]) * n + x] = static_cast<double>(sat_add(W.ox, dxw[j])) - static_cast<double>(x) + static_cast<double>(f[j].x);
+        disp[plane + static_cast<size_t>(y[j]) * n + x] = static_cast<double>(sat_add(W.oy, dy[j])) - static_cast<double>(y[j]) + static_cast<double>(f[j].y);
       }
     }
     if (!PERSIST) return;

@@ -21,11 +21,26 @@ __device__ __forceinline__ float ld(const float *base, unsigned byte_off, int el
 // Position along one axis is an integer pixel index P plus a fraction f in [0,1).
 // Subtract w: |rounding| <= ulp(|f - w|)/2 ~ 5e-7 px for |w| < 8, independent of
 // how far the trajectory has travelled.
+// Integer positions are moved by SATURATING adds (v_add_i32 / v_sub_i32 with the clamp bit, the cost of a plain add):
+// a step the conversion saturated - a sentinel velocity such as 1e20 - parks the trajectory at INT_MAX / INT_MIN, far
+// outside every image on the side it left on, instead of wrapping to the other side or, after a few such steps, back
+// inside; the reference's float64 position behaves the same way.
+__device__ __forceinline__ int sat_add(int a, int b) {
+  int r;
+  asm("v_add_i32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ int sat_sub(int a, int b) {
+  int r;
+  asm("v_sub_i32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ void retreat(int &P, float &f, float w) {
   const float t = f - w;
   int k;
   asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k) : "v"(t));  // (int)floor(t), one instruction
-  P += k;
+  P = sat_add(P, k);
   // v_fract_f32 = min(t - floor(t), 0x1.fffffep-1): (-1e-9) - (-1) would round to 1.0f, the
   // instruction keeps f < 1 (checked on the device by tests/test_semilag_gpu.py::test_fraction_clamp)
   f = __builtin_amdgcn_fractf(t);
@@ -39,7 +54,7 @@ __device__ __forceinline__ void retreat(int &P, float &f, float w) {
 __device__ __forceinline__ void split_displacement(double d, int &P, float &f) {
   const bool ok = fabs(d) < 1e300;  // false for NaN and +-inf
   const double fl = ok ? floor(d) : 0.0;
-  P += static_cast<int>(fl);
+  P = sat_add(P, static_cast<int>(fmin(fmax(fl, -2147483648.0), 2147483647.0)));
   f = ok ? fminf(static_cast<float>(d - fl), kMaxFrac) : __builtin_nanf("");
 }
 __device__ __forceinline__ bool lost(float fx, float fy) { return fx != fx || fy != fy; }

@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256) void semilag_members(
       *record = make_uint4(static_cast<unsigned>(px - xc), static_cast<unsigned>(py - yc), __float_as_uint(fx),
                            __float_as_uint(fy));
     } else {
-      dplane[pix] = static_cast<double>(px - xc) + static_cast<double>(fx);
-      dplane[plane + pix] = static_cast<double>(py - yc) + static_cast<double>(fy);
+      dplane[pix] = static_cast<double>(px) - static_cast<double>(xc) + static_cast<double>(fx);
+      dplane[plane + pix] = static_cast<double>(py) - static_cast<double>(yc) + static_cast<double>(fy);
     }
   }
 }
