@@ -91,6 +91,9 @@ int psh_db_transform_dev(const float *in_dev, float *out_dev, size_t n, double t
  * the float64 arrays pysteps works with cross the bus as they are instead of being narrowed /
  * widened by a host pass. */
 int psh_convert_dev(const void *in_dev, void *out_dev, size_t n, int to_f64);
+/* dst[i] += alpha * src[i] on float64 device arrays (queued on the library stream): base-position offsets of a custom
+ * xy_coords grid added to / taken off a displacement field */
+int psh_axpy_f64_dev(double *dst_dev, const double *src_dev, double alpha, size_t n);
 /* pysteps/utils/check_norain.py:40-50 on a resident field: number of values > threshold (NaN never
  * counts) and np.nanmin of the field; a NaN threshold means "the minimum of the field"
  * (precip_thr=None).  Synchronous. */
@@ -113,14 +116,15 @@ int psh_field_stats_dev(const float *in_dev, size_t n, double *min_out, double *
  *  steps_host  T doubles, HOST memory: lead-time increments / vel_timestep
  *              (timestep_diff / vel_timestep of semilagrangian.py:165,198)
  *  n_iter      >= 0 (0 = no midpoint rule, :215-219)
- *  interp_order 0, 1 or 3 for the precip resampling (:85-90); 3 = cubic B-spline incl. the
+ *  interp_order 0 .. 5 for the precip resampling (:85-90); 2 .. 5 = B-spline of that order incl. the
  *              spline prefilter and the two mask warps of :146-157,234-253 (outside -> NaN).
  *              The boundary mode of that resampling (map_coordinates_mode, :91-96,225-232) rides in
  *              the second byte: interp_order | PSH_MODE_* << 8 (outval is then the cval of
  *              "grid-constant"); with interp_order 3 the spline filter takes the mode's boundary
  *              condition and "nearest" / "grid-constant" are padded by 12 samples first, like SciPy.
  *  outval      value for pixels advected from outside the domain (may be NaN)
- *  disp        (2,m,n) float64 or NULL; if resume != 0 it holds displacement_prev
+ *  disp        (2,m,n) float64 or NULL; resume = 1: it holds displacement_prev; resume = 2 (PSH_SL_RESUME_BASE): it
+ *              holds the base positions of a custom xy_coords grid relative to the integer grid (see PSH_SL_BASE_IN_DISP)
  *              on entry (:203-207); if non-NULL it receives the final displacement
  *  out         (T,m,n) float32, required iff precip != NULL
  */
@@ -179,6 +183,12 @@ int psh_semilag_rows_dev(const float *precip_dev, const float *velocity_dev, int
 #define PSH_SL_PRECIP_F64 4
 #define PSH_SL_VELOCITY_F64 8
 #define PSH_SL_OUT_F64 16
+/* disp_prev holds the BASE positions of a custom xy_coords grid relative to the integer grid (xy_coords - meshgrid,
+ * semilagrangian.py:174-179), not a previous displacement: trajectories start there, the first increment is the
+ * grid's own velocity (:203) and disp_out is relative to the integer grid too (the caller subtracts the offsets).
+ * The *_dev entry points take the same through resume = 2 (PSH_SL_RESUME_BASE); resume = 1 is displacement_prev. */
+#define PSH_SL_BASE_IN_DISP 32
+#define PSH_SL_RESUME_BASE 2
 #define PSH_SL_ST_PRECIP_NONFINITE 1
 #define PSH_SL_ST_PRECIP_ALL_NONFINITE 2
 #define PSH_SL_ST_VELOCITY_NONFINITE 4
@@ -514,6 +524,13 @@ int psh_probmatch_planned_dev(const void *plan, const double *initial_dev, size_
  *      with the reference (NaN everywhere if nothing is set, like 0 / 0 in NumPy).  Asynchronous. */
 int psh_dilated_mask_dev(const unsigned char *mask_dev, int m, int n, const unsigned char *kr_host, int kh, int kw,
                          int r, double *out_dev);
+/* `field >= threshold` (nowcasts/steps.py:1211) and psh_dilated_mask_dev of the result in one entry point, on bit
+ * masks: one pass over the float64 field (m, n) -> one bit per pixel, then one kernel for the structure's dilation,
+ * the r cross dilations and the float64 mask (a wave per tile, rows as lanes, columns as bits of a 64-bit word).
+ * Bit-identical with psh_ge_mask_dev + psh_dilated_mask_dev.  PSH_EUNSUPPORTED (take those two): a structure
+ * without its centre element, r + the structure's reach above 24 pixels. */
+int psh_steps_incremental_mask_dev(const double *field_dev, int m, int n, double threshold,
+                                   const unsigned char *kr_host, int kh, int kw, int r, double *out_dev);
 
 /* ---- element-wise half of one STEPS member update (csrc/steps_loop.hip) ------------ *
  * pysteps/nowcasts/steps.py:1057-1219 `__update_state` between the spectral operators, the CDF

@@ -74,57 +74,81 @@ _PREFILTER_KIND = {"constant": "mirror", "mirror": "mirror", "wrap": "mirror", "
 _PREFILTER_PAD = {"nearest": 12, "grid-constant": 12}
 
 
-def _spline_prefilter(field, kind="mirror"):
-    """Cubic B-spline coefficients along both axes, float64 (scipy.ndimage.spline_filter(order=3); ni_splines.c:
-    gain 6, pole z = sqrt(3) - 2, _init_causal_* / _init_anticausal_* of the boundary kind)."""
-    z = np.sqrt(3.0) - 2.0
+def _spline_poles(order):
+    """Poles of the B-spline prefilter (ni_splines.c get_filter_poles; order 3: the one of the cubic case)."""
+    if order == 2:
+        return [np.sqrt(8.0) - 3.0]
+    if order == 3:
+        return [np.sqrt(3.0) - 2.0]
+    if order == 4:
+        return [np.sqrt(664.0 - np.sqrt(438976.0)) + np.sqrt(304.0) - 19.0,
+                np.sqrt(664.0 + np.sqrt(438976.0)) - np.sqrt(304.0) - 19.0]
+    if order == 5:
+        return [np.sqrt(67.5 - np.sqrt(4436.25)) + np.sqrt(26.25) - 6.5,
+                np.sqrt(67.5 + np.sqrt(4436.25)) - np.sqrt(26.25) - 6.5]
+    raise NotImplementedError("spline order %r" % (order,))
+
+
+def _spline_prefilter(field, kind="mirror", order=3):
+    """B-spline coefficients of order 2 .. 5 along both axes, float64 (scipy.ndimage.spline_filter; ni_splines.c
+    apply_filter: the gain prod (1 - z)(1 - 1/z) over the poles on the whole line first - 6 for the cubic case -, then
+    per pole _init_causal_* / causal recursion / _init_anticausal_* / anticausal recursion of the boundary kind)."""
+    poles = _spline_poles(order)
+    gain = 1.0
+    for z in poles:
+        gain *= (1.0 - z) * (1.0 - 1.0 / z)
     c = np.array(field, dtype=np.float64)
     for axis in (0, 1):
         c = np.moveaxis(c, axis, 0).copy()
         n = c.shape[0]
         if n > 1:
-            c *= 6.0
-            if kind == "mirror":
-                zn1 = z ** (n - 1)
-                acc = c[0] + zn1 * c[n - 1]
-                zi = z
-                for i in range(1, n - 1):
-                    acc = acc + zi * (c[i] + zn1 * c[n - 1 - i])
-                    zi *= z
-                c[0] = acc / (1.0 - zn1 * zn1)
-            elif kind == "reflect":
-                zn = z**n
-                first = c[0].copy()
-                acc = c[0] + zn * c[n - 1]
-                zi = z
-                for i in range(1, n):
-                    acc = acc + zi * (c[i] + zn * c[n - 1 - i])
-                    zi *= z
-                c[0] = acc * (z / (1.0 - zn * zn)) + first
-            else:  # wrap
-                acc = c[0].copy()
-                zi = z
-                for i in range(1, n):
-                    acc = acc + zi * c[n - i]
-                    zi *= z
-                c[0] = acc / (1.0 - zi)
-            for i in range(1, n):
-                c[i] += z * c[i - 1]
-            if kind == "mirror":
-                c[n - 1] = (z * c[n - 2] + c[n - 1]) * z / (z * z - 1.0)
-            elif kind == "reflect":
-                c[n - 1] = c[n - 1] * (z / (z - 1.0))
-            else:
-                acc = c[n - 1].copy()
-                zi = z
-                for i in range(0, n - 1):
-                    acc = acc + zi * c[i]
-                    zi *= z
-                c[n - 1] = acc * (z / (zi - 1.0))
-            for i in range(n - 2, -1, -1):
-                c[i] = z * (c[i + 1] - c[i])
+            c *= gain
+            for z in poles:
+                _spline_pole_pass(c, n, z, kind)
         c = np.moveaxis(c, 0, axis)
     return c
+
+
+def _spline_pole_pass(c, n, z, kind):
+    if kind == "mirror":
+        zn1 = z ** (n - 1)
+        acc = c[0] + zn1 * c[n - 1]
+        zi = z
+        for i in range(1, n - 1):
+            acc = acc + zi * (c[i] + zn1 * c[n - 1 - i])
+            zi *= z
+        c[0] = acc / (1.0 - zn1 * zn1)
+    elif kind == "reflect":
+        zn = z**n
+        first = c[0].copy()
+        acc = c[0] + zn * c[n - 1]
+        zi = z
+        for i in range(1, n):
+            acc = acc + zi * (c[i] + zn * c[n - 1 - i])
+            zi *= z
+        c[0] = acc * (z / (1.0 - zn * zn)) + first
+    else:  # wrap
+        acc = c[0].copy()
+        zi = z
+        for i in range(1, n):
+            acc = acc + zi * c[n - i]
+            zi *= z
+        c[0] = acc / (1.0 - zi)
+    for i in range(1, n):
+        c[i] += z * c[i - 1]
+    if kind == "mirror":
+        c[n - 1] = (z * c[n - 2] + c[n - 1]) * z / (z * z - 1.0)
+    elif kind == "reflect":
+        c[n - 1] = c[n - 1] * (z / (z - 1.0))
+    else:
+        acc = c[n - 1].copy()
+        zi = z
+        for i in range(0, n - 1):
+            acc = acc + zi * c[i]
+            zi *= z
+        c[n - 1] = acc * (z / (zi - 1.0))
+    for i in range(n - 2, -1, -1):
+        c[i] = z * (c[i + 1] - c[i])
 
 
 def _spline_prefilter_mirror(field):
@@ -143,19 +167,50 @@ def _bspline3_weights(t):
     return [(1 - t) ** 3 / 6, (3 * t**3 - 6 * t**2 + 4) / 6, (-3 * t**3 + 3 * t**2 + 3 * t + 1) / 6, t**3 / 6]
 
 
-def _cubic(field, row, col, cval):
-    """order-3 map_coordinates, mode="constant": strict inside test on the coordinate, 4x4 taps
-    around floor(c) with mirrored indices, coefficients from the mirror prefilter."""
+def _bspline_basis(x, order):
+    """Centred cardinal B-spline of the given order at distance x (the closed piecewise polynomials)."""
+    a = np.abs(x)
+    if order == 2:
+        return np.where(a <= 0.5, 0.75 - a * a, np.where(a <= 1.5, 0.5 * (1.5 - a) ** 2, 0.0))
+    if order == 3:
+        return np.where(a <= 1.0, 2.0 / 3.0 - a * a + 0.5 * a**3, np.where(a <= 2.0, (2.0 - a) ** 3 / 6.0, 0.0))
+    if order == 4:
+        return np.where(a <= 0.5, 115.0 / 192.0 - 0.625 * a * a + 0.25 * a**4,
+                        np.where(a <= 1.5, 55.0 / 96.0 + a * (5.0 / 24.0 + a * (-1.25 + a * (5.0 / 6.0 - a / 6.0))),
+                                 np.where(a <= 2.5, (2.5 - a) ** 4 / 24.0, 0.0)))
+    if order == 5:
+        return np.where(a <= 1.0, 0.55 + a * a * (-0.5 + a * a * (0.25 - a / 12.0)),
+                        np.where(a <= 2.0, 0.425 + a * (0.625 + a * (-1.75 + a * (1.25 + a * (-0.375 + a / 24.0)))),
+                                 np.where(a <= 3.0, (3.0 - a) ** 5 / 120.0, 0.0)))
+    raise NotImplementedError("spline order %r" % (order,))
+
+
+def _spline_taps(c, order):
+    """(first tap index, list of the order + 1 weights) of map_coordinates for coordinates c: odd orders start at
+    floor(c) - order // 2, even ones at floor(c + 0.5) - order // 2 (ni_interpolation.c); the weights are the
+    B-spline at the taps' distances (SciPy sets the last one to 1 - sum of the others: equal to rounding)."""
+    base = np.floor(c) if order & 1 else np.floor(c + 0.5)
+    start = base.astype(np.int64) - order // 2
+    return start, [_bspline_basis(c - (start + k), order) for k in range(order + 1)]
+
+
+def _cubic(field, row, col, cval, order=3):
+    """order-2 .. 5 map_coordinates, mode="constant": strict inside test on the coordinate, (order + 1)^2 taps with
+    mirrored indices, coefficients from the mirror prefilter."""
     m, n = field.shape
-    coef = _spline_prefilter_mirror(field)
+    coef = _spline_prefilter(field, "mirror", order)
     outside = (row < 0.0) | (row > m - 1.0) | (col < 0.0) | (col > n - 1.0)
     rr, cc = np.where(outside, 0.0, row), np.where(outside, 0.0, col)
-    iy, ix = np.floor(rr).astype(np.int64), np.floor(cc).astype(np.int64)
-    wy, wx = _bspline3_weights(rr - iy), _bspline3_weights(cc - ix)
+    if order == 3:
+        iy, ix = np.floor(rr).astype(np.int64) - 1, np.floor(cc).astype(np.int64) - 1
+        wy, wx = _bspline3_weights(rr - iy - 1), _bspline3_weights(cc - ix - 1)
+    else:
+        iy, wy = _spline_taps(rr, order)
+        ix, wx = _spline_taps(cc, order)
     acc = np.zeros(row.shape)
-    for a in range(4):
-        for b in range(4):
-            acc += wy[a] * wx[b] * coef[_mirror_index(iy - 1 + a, m), _mirror_index(ix - 1 + b, n)]
+    for a in range(order + 1):
+        for b in range(order + 1):
+            acc += wy[a] * wx[b] * coef[_mirror_index(iy + a, m), _mirror_index(ix + b, n)]
     return np.where(outside, cval, acc)
 
 
@@ -232,11 +287,11 @@ def _fold_tap(i, length, mode):
     return np.where(i < 0, neg, np.where(i >= length, pos, i)), no
 
 
-def _cubic_mode(field, row, col, mode, cval):
-    """order-3 map_coordinates with a boundary mode other than "constant": the array is padded for the
+def _cubic_mode(field, row, col, mode, cval, order=3):
+    """order-2 .. 5 map_coordinates with a boundary mode other than "constant": the array is padded for the
     two modes the filter has no boundary condition for, filtered with the mode's boundary kind, the
     coordinate folded like for the lower orders (on the ORIGINAL length) and shifted by the padding, the
-    4 x 4 taps around floor(c) folded index by index on the padded length ("grid-constant": cval)."""
+    (order + 1)^2 taps folded index by index on the padded length ("grid-constant": cval)."""
     m, n = field.shape
     npad = _PREFILTER_PAD.get(mode, 0)
     if mode == "nearest":
@@ -245,17 +300,21 @@ def _cubic_mode(field, row, col, mode, cval):
         padded = np.pad(field, npad, mode="constant", constant_values=cval)
     else:
         padded = field
-    coef = _spline_prefilter(padded, _PREFILTER_KIND[mode])
+    coef = _spline_prefilter(padded, _PREFILTER_KIND[mode], order)
     rr = _fold_coordinate(row, m, mode) + npad
     cc = _fold_coordinate(col, n, mode) + npad
     big_m, big_n = padded.shape
-    iy, ix = np.floor(rr).astype(np.int64), np.floor(cc).astype(np.int64)
-    wy, wx = _bspline3_weights(rr - iy), _bspline3_weights(cc - ix)
+    if order == 3:
+        iy, ix = np.floor(rr).astype(np.int64) - 1, np.floor(cc).astype(np.int64) - 1
+        wy, wx = _bspline3_weights(rr - iy - 1), _bspline3_weights(cc - ix - 1)
+    else:
+        iy, wy = _spline_taps(rr, order)
+        ix, wx = _spline_taps(cc, order)
     acc = np.zeros(np.shape(row))
-    for a in range(4):
-        ri, rcv = _fold_tap(iy - 1 + a, big_m, mode)
-        for b in range(4):
-            ci, ccv = _fold_tap(ix - 1 + b, big_n, mode)
+    for a in range(order + 1):
+        ri, rcv = _fold_tap(iy + a, big_m, mode)
+        for b in range(order + 1):
+            ci, ccv = _fold_tap(ix + b, big_n, mode)
             acc = acc + wy[a] * wx[b] * np.where(rcv | ccv, cval, coef[ri, ci])
     return acc
 
@@ -299,8 +358,8 @@ def _numpy_sample(field, row, col, mode, cval, order):
             raise NotImplementedError("non-finite coordinates are restated for modes constant / nearest only")
         val = _numpy_sample(field, np.where(bad, 0.0, row), np.where(bad, 0.0, col), mode, cval, order)
         return np.where(bad, lost, val)
-    if mode != "constant" and order == 3:
-        return _cubic_mode(field.astype(np.float64), row, col, mode, cval)
+    if mode != "constant" and order in (2, 3, 4, 5):
+        return _cubic_mode(field.astype(np.float64), row, col, mode, cval, order)
     if mode != "constant" and order in (0, 1) and not (mode == "nearest" and np.all(np.isfinite(field))):
         return _numpy_sample_mode(field, row, col, mode, cval, order)
     if mode == "nearest":
@@ -315,10 +374,10 @@ def _numpy_sample(field, row, col, mode, cval, order):
     else:
         raise NotImplementedError("numpy backend restates order 3 for mode constant only")
 
-    if order == 3:
+    if order in (2, 3, 4, 5):
         if mode != "constant":
-            raise NotImplementedError("numpy backend restates order 3 for mode constant only")
-        return _cubic(field.astype(np.float64), row, col, cval)
+            raise NotImplementedError("numpy backend restates the spline orders for mode constant here")
+        return _cubic(field.astype(np.float64), row, col, cval, order)
     if order == 1:
         val = _bilinear(field, rr, cc)
     elif order == 0:
@@ -328,7 +387,7 @@ def _numpy_sample(field, row, col, mode, cval, order):
             np.clip(ri, 0, m - 1), np.clip(ci, 0, n - 1)
         ]
     else:
-        raise NotImplementedError("numpy backend restates interpolation order 0/1/3 only")
+        raise NotImplementedError("numpy backend restates interpolation orders 0 .. 5")
 
     if outside is not None:
         val = np.where(outside, cval, val)

@@ -57,6 +57,7 @@ SIGNATURES = {
     "psh_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_size_t]),
     "psh_memcpy_d2h_async": (c_int, [c_void_p, c_void_p, c_size_t]),
     "psh_convert_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
+    "psh_axpy_f64_dev": (c_int, [c_void_p, c_void_p, ctypes.c_double, c_size_t]),
     "psh_count_above_dev": (c_int, [c_void_p, c_size_t, c_double, POINTER(c_double), POINTER(c_double)]),
     "psh_host_alloc": (c_int, [POINTER(c_void_p), c_size_t]),
     "psh_host_free": (c_int, [c_void_p]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "psh_probmatch_plan_destroy": (c_int, [c_void_p]),
     "psh_probmatch_planned_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "psh_dilated_mask_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "psh_steps_incremental_mask_dev": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_ar_iterate_dev": (c_int, [c_void_p, c_int, c_size_t, POINTER(c_double), c_int, c_void_p, c_void_p]),
     "psh_steps_ar_recompose_dev": (c_int, [c_void_p, c_int, c_int, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]),

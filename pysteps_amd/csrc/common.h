@@ -105,6 +105,7 @@ struct SemilagArgs {
   int coef_pad = 0;     // samples the coefficient plane is padded by ("nearest", "grid-constant": 12)
   float minval;         // interp_order 3: minimum over the finite values of precip
   int bmode = 0;        // boundary mode of the field resampling (PSH_MODE_*), interp_order 0/1
+  int spline_order = 3; // order == 3 stands for "B-spline resampling": 2, 3, 4 or 5 (interp_order of the call)
   const float *vel_packed = nullptr;  // (m,n,2) {u,v} interleaved copy of vel (launch_pack_velocity) or nullptr
   const float *field_pairs = nullptr;  // (m,n,2) {p(y,x), p(y+1,x)} row-pair copy of precip (launch_pack_field_rows)
 };
@@ -119,7 +120,7 @@ int semilag_kernel_choice(int m, int n, int T, int n_iter, int order, bool has_f
 void set_semilag_variant(int v);
 void set_members_variant(int v);
 hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream, int kind = 0,
-                            int npad = 0, int pad_edge = 0, float cval = 0.f);
+                            int npad = 0, int pad_edge = 0, float cval = 0.f, int order = 3);
 
 // sample count and interpolator preamble kept in device memory (written by vectors_finish,
 // lk_sparse.hip): the IDW kernels read L / reach from here instead of their launch arguments, so

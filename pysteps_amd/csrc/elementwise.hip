@@ -307,6 +307,28 @@ extern "C" int psh_count_above_dev(const float *in_dev, size_t n, double thresho
   return PSH_OK;
 }
 
+namespace psh {
+namespace {
+__global__ __launch_bounds__(256) void axpy_f64(double *__restrict__ dst, const double *__restrict__ src, double alpha, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += alpha * src[i];
+}
+}  // namespace
+}  // namespace psh
+
+extern "C" int psh_axpy_f64_dev(double *dst_dev, const double *src_dev, double alpha, size_t n) {
+  PSH_REQUIRE_INIT();
+  if (n == 0) return PSH_OK;
+  if (!dst_dev || !src_dev) return psh::fail(PSH_EINVAL, "axpy: NULL pointer");
+  psh::Context &c = psh::ctx();
+  std::lock_guard<std::recursive_mutex> lock(c.mu);
+  PSH_HIP(hipSetDevice(c.device));
+  const unsigned blocks = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, static_cast<size_t>(c.cu_count) * 16));
+  hipLaunchKernelGGL(psh::axpy_f64, dim3(blocks), dim3(256), 0, c.stream, dst_dev, src_dev, alpha, n);
+  PSH_HIP(hipGetLastError());
+  return PSH_OK;
+}
+
 extern "C" int psh_convert_dev(const void *in_dev, void *out_dev, size_t n, int to_f64) {
   PSH_REQUIRE_INIT();
   if (n == 0) return PSH_OK;

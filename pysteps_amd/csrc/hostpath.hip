@@ -355,8 +355,8 @@ int psh_semilag_host(const void *precip, const void *velocity, int m, int n, con
       return fail(PSH_EINPUT, "semilag: non-finite input values (status 0x%x)", status);
     }
   }
-  PSH_TRY_RC(psh_semilag_dev(d_p, d_v, m, n, steps, T, n_iter, interp_order, outval, d_disp, disp_prev != nullptr,
-                             d_out));
+  PSH_TRY_RC(psh_semilag_dev(d_p, d_v, m, n, steps, T, n_iter, interp_order, outval, d_disp,
+                             disp_prev == nullptr ? 0 : ((flags & PSH_SL_BASE_IN_DISP) ? PSH_SL_RESUME_BASE : 1), d_out));
   const size_t out_elems = static_cast<size_t>(T) * plane;
   if (precip && o64)
     PSH_TRY_HIP(psh::launch_convert_f32_f64(d_out, static_cast<double *>(d_out64), out_elems, c.stream));

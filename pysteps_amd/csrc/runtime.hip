@@ -130,8 +130,8 @@ int check_semilag(int m, int n, int T, int n_iter, int order_and_mode) {
     return fail(PSH_EUNSUPPORTED, "semilag: m*n must be < 2^30 pixels (32-bit byte offsets)");
   if (T <= 0) return fail(PSH_EINVAL, "semilag: T must be positive (got %d)", T);
   if (n_iter < 0) return fail(PSH_EINVAL, "semilag: n_iter must be >= 0 (got %d)", n_iter);
-  if (order != 0 && order != 1 && order != 3)
-    return fail(PSH_EUNSUPPORTED, "semilag: interp_order %d not implemented (0, 1 or 3)", order);
+  if (order < 0 || order > 5)
+    return fail(PSH_EUNSUPPORTED, "semilag: interp_order %d not implemented (0 .. 5)", order);
   return PSH_OK;
 }
 
@@ -564,6 +564,10 @@ static int semilag_rows(const float *precip_dev, const float *velocity_dev, cons
   a.order = interp_order & 0xff;
   a.bmode = (interp_order >> 8) & 0xff;
   interp_order &= 0xff;
+  if (interp_order >= 2 && interp_order <= 5) {  // B-spline resampling: one kernel instantiation, the order as data
+    a.spline_order = interp_order;
+    a.order = interp_order = 3;
+  }
   a.resume = resume;
   a.row0 = row_begin;
   a.rows = row_count;
@@ -585,7 +589,8 @@ static int semilag_rows(const float *precip_dev, const float *velocity_dev, cons
       if (int rc = psh_malloc(&spline_blk, 2 * plane_bytes)) return rc;
       float *coef = static_cast<float *>(spline_blk);
       float *tmp = coef + plane_bytes / sizeof(float);
-      e = psh::spline_prefilter(precip_dev, coef, tmp, m, n, c.stream, kind, npad, mode == PSH_MODE_NEAREST, outval);
+      e = psh::spline_prefilter(precip_dev, coef, tmp, m, n, c.stream, kind, npad, mode == PSH_MODE_NEAREST, outval,
+                                a.spline_order);
       a.coef = coef;
       a.coef_pad = npad;
     }

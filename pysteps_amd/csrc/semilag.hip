@@ -66,6 +66,7 @@ struct Fields {
   const float *coef;  // cubic B-spline coefficients of the field (interp_order 3 only)
   int cpad;           // ... padded by this many samples (boundary modes "nearest", "grid-constant")
   float minval;       // minimum over its finite values (interp_order 3 only)
+  int sorder;         // ... and which B-spline the coefficients belong to: 2, 3, 4 or 5
   int bmode;          // boundary mode of the field resampling (semilag_device.h kMode*)
 };
 
@@ -316,8 +317,8 @@ __device__ __forceinline__ float sample_precip_off_fast(const float *p, int X, i
 template <bool GEN>
 __device__ __forceinline__ float sample_cubic(const Fields &F, int X, int Y, float fx, float fy, int m, int n,
                                               float outval) {
-  if (GEN) return sample_precip_cubic_mode(F.coef, F.p0, X, Y, fx, fy, m, n, F.minval, outval, F.bmode, F.cpad);
-  return sample_precip_cubic(F.coef, F.p0, X, Y, fx, fy, m, n, F.minval);
+  if (GEN) return sample_precip_cubic_mode(F.coef, F.p0, X, Y, fx, fy, m, n, F.minval, outval, F.bmode, F.cpad, F.sorder);
+  return sample_precip_cubic(F.coef, F.p0, X, Y, fx, fy, m, n, F.minval, F.sorder);
 }
 
 // What to sample at the NPX positions of a thread
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(kTileX *kDirectWaves) void semilag_fused(
                                             2 * plane_bytes, 0x00020000);
   F.row_bytes = n * static_cast<int>(sizeof(float));
   F.coef = coef;
-  F.cpad = coef_pad;
+  F.cpad = coef_pad & 0xff;  // (the B-spline's order rides in the second byte: launch_variant)
+  F.sorder = (coef_pad >> 8) != 0 ? (coef_pad >> 8) : 3;
   F.minval = minval;
   F.bmode = bmode;
 
@@ -435,14 +437,20 @@ __global__ __launch_bounds__(kTileX *kDirectWaves) void semilag_fused(
       split_displacement(dx, px[j], fx[j]);
       split_displacement(dy, py[j], fy[j]);
     }
-    sample_at<NPX, ORDER, kVel, MODE, GEN>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
-    const float s0 = scale[0];
+    // resume == 1: a displacement_prev in the reference's sense - the increment is sampled where the trajectory
+    // stands (:204-207).  resume == 2: the buffer holds the BASE positions of a custom xy_coords grid relative to the
+    // integer grid (:174-179, :221), no previous displacement: the increment starts as the grid's own velocity (:203)
+    if (resume == 1) {
+      sample_at<NPX, ORDER, kVel, MODE, GEN>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
+      const float s0 = scale[0];
 #pragma unroll
-    for (int j = 0; j < NPX; ++j) {
-      vix[j] = su[j] * s0;
-      viy[j] = sv[j] * s0;
+      for (int j = 0; j < NPX; ++j) {
+        vix[j] = su[j] * s0;
+        viy[j] = sv[j] * s0;
+      }
     }
-  } else {
+  }
+  if (resume != 1) {
     // first increment is NOT divided by n_iter (semilagrangian.py:202)
 #pragma unroll
     for (int j = 0; j < NPX; ++j) {
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(kTileX *kDirectWaves) void semilag_fused(
         }
       }
     } else {
-      if (t > 0 || resume) {
+      if (t > 0 || resume == 1) {  // (:216: ti > 0 or a displacement_prev; base positions alone do not count)
         sample_at<NPX, ORDER, kVel, MODE, GEN>(F, px, py, fx, fy, m, n, outval, su, sv, sp);
 #pragma unroll
         for (int j = 0; j < NPX; ++j) {
@@ -935,6 +943,7 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
   F.row_bytes = n * static_cast<int>(sizeof(float));
   F.coef = nullptr;
   F.cpad = 0;
+  F.sorder = 3;
   F.minval = 0.f;
   F.bmode = bmode;
 
@@ -987,7 +996,8 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
       if (resume) {
         split_displacement(disp[static_cast<size_t>(y[j]) * n + x], px, ifx);
         split_displacement(disp[plane + static_cast<size_t>(y[j]) * n + x], py, ify);
-      } else {
+      }
+      if (resume != 1) {  // (2: base positions of a custom grid in the buffer, the increment starts as the grid's velocity)
         const unsigned pix = static_cast<unsigned>(__mul24(y[j], n) + x) << 2;
         ivx = ld(F.u0, pix) * first_scale;  // first increment is NOT divided by n_iter (semilagrangian.py:202)
         ivy = ld(F.v0, pix) * first_scale;
@@ -1002,7 +1012,7 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
     int phase = 0;
     win_update<C>(F, W, phase, true, dxw, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
     phase = 1;
-    if (resume) {
+    if (resume == 1) {
       win_sample<C, kVel, GEN>(F, W, dxw, dy, f, m, n, outval, s_uv, sp);
       const float s0 = scale[0];
 #pragma unroll
@@ -1217,7 +1227,7 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
   hipLaunchKernelGGL((semilag_fused<NPX, ORDER, HASP, MODE, GEN>), grid, block, 0, stream,      \
                      a.precip, a.vel, a.vel_packed, a.field_pairs, a.out, a.disp, a.scale, a.first_scale, a.m, a.n, \
                      a.T,                                                                                  \
-                     a.n_iter, a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, a.bmode, a.coef_pad,  \
+                     a.n_iter, a.resume, a.outval, a.row0, a.rows, a.coef, a.minval, a.bmode, a.coef_pad | (a.spline_order << 8),  \
                      tiles_x, n_tiles, tiles_per_xcd)
   if (a.precip == nullptr) {
     PSH_SL_LAUNCH(1, false, false);

@@ -266,9 +266,37 @@ __device__ __forceinline__ void bspline3(float t, float (&w)[4]) {
   w[3] = t * t * t * (1.f / 6.f);
 }
 
+// ---- interp_order 2, 4, 5: the same machinery with the other B-splines ----------------------------------
+// Centred cardinal B-spline of order 2 / 4 / 5 at distance a >= 0 (closed piecewise polynomials; SciPy evaluates the
+// same functions in double and sets the last weight to 1 - sum of the others: equal to float32 rounding).
+__device__ __forceinline__ float bspline_basis(float a, int order) {
+  if (order == 2) return a <= 0.5f ? 0.75f - a * a : (a <= 1.5f ? 0.5f * (1.5f - a) * (1.5f - a) : 0.f);
+  if (order == 4) {
+    if (a <= 0.5f) return (115.f / 192.f) + a * a * (-0.625f + 0.25f * a * a);
+    if (a <= 1.5f) return (55.f / 96.f) + a * ((5.f / 24.f) + a * (-1.25f + a * ((5.f / 6.f) - a * (1.f / 6.f))));
+    const float u = 2.5f - a;
+    return a <= 2.5f ? u * u * u * u * (1.f / 24.f) : 0.f;
+  }
+  // order 5
+  if (a <= 1.f) return 0.55f + a * a * (-0.5f + a * a * (0.25f - a * (1.f / 12.f)));
+  if (a <= 2.f) return 0.425f + a * (0.625f + a * (-1.75f + a * (1.25f + a * (-0.375f + a * (1.f / 24.f)))));
+  const float u = 3.f - a;
+  return a <= 3.f ? u * u * u * u * u * (1.f / 120.f) : 0.f;
+}
+// first tap of the order + 1 taps along one axis for the coordinate X + f and their weights (ni_interpolation.c: odd
+// orders start at floor(c) - order / 2, even ones at floor(c + 0.5) - order / 2); w[k] for k > order is not set
+__device__ __forceinline__ int spline_taps(int X, float f, int order, float (&w)[6]) {
+  const int up = ((order & 1) == 0 && f >= 0.5f) ? 1 : 0;  // even order: the nearest sample is the centre tap
+  const float t = f - static_cast<float>(up) + static_cast<float>(order / 2);  // distance of the coordinate from tap 0
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    if (k <= order) w[k] = bspline_basis(fabsf(t - static_cast<float>(k)), order);
+  return X + up - order / 2;
+}
+
 __device__ __forceinline__ float sample_precip_cubic(const float *coef, const float *p, int X, int Y,
                                                      float fx, float fy, int m, int n,
-                                                     float minval) {
+                                                     float minval, int sorder = 3) {
   const bool outside = X < 0 || Y < 0 || X > n - 1 || Y > m - 1 || (X == n - 1 && fx > 0.f) ||
                        (Y == m - 1 && fy > 0.f);
   if (outside) return __builtin_nanf("");
@@ -284,6 +312,22 @@ __device__ __forceinline__ float sample_precip_cubic(const float *coef, const fl
   const float above = blend(w, v00 > minval ? 1.f : 0.f, v01 > minval ? 1.f : 0.f,
                             v10 > minval ? 1.f : 0.f, v11 > minval ? 1.f : 0.f);
   if (above < 0.5f) return minval;
+  if (sorder != 3) {  // (uniform) orders 2, 4, 5: (order + 1)^2 taps, mirrored indices
+    float gx[6], gy[6];
+    const int x0 = spline_taps(X, fx, sorder, gx), y0 = spline_taps(Y, fy, sorder, gy);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (a > sorder) break;
+      const unsigned row = static_cast<unsigned>(__mul24(mirror101(y0 + a, m), n));
+      float line = 0.f;
+#pragma unroll
+      for (int b = 0; b < 6; ++b)
+        if (b <= sorder) line = fmaf(gx[b], ld(coef, (row + mirror101(x0 + b, n)) << 2), line);
+      acc = fmaf(gy[a], line, acc);
+    }
+    return acc;
+  }
   float wx[4], wy[4];
   bspline3(fx, wx);
   bspline3(fy, wy);
@@ -308,7 +352,7 @@ __device__ __forceinline__ float sample_precip_cubic(const float *coef, const fl
 // cval was padded in and the filter's recursion carried it everywhere - every coefficient is NaN.
 __device__ __forceinline__ float sample_precip_cubic_mode(const float *coef, const float *p, int X, int Y, float fx,
                                                           float fy, int m, int n, float minval, float cval, int mode,
-                                                          int npad) {
+                                                          int npad, int sorder = 3) {
   fold_coord(X, fx, n, mode);
   fold_coord(Y, fy, m, mode);
   {
@@ -329,6 +373,34 @@ __device__ __forceinline__ float sample_precip_cubic_mode(const float *coef, con
   }
   if (coef == nullptr) return __builtin_nanf("");
   const int big_m = m + 2 * npad, big_n = n + 2 * npad;
+  if (sorder != 3) {  // (uniform) orders 2, 4, 5
+    float gx[6], gy[6];
+    const int x0 = spline_taps(X + npad, fx, sorder, gx), y0 = spline_taps(Y + npad, fy, sorder, gy);
+    int gi[6];
+    bool gc[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      gc[b] = false;
+      gi[b] = b <= sorder ? fold_tap(x0 + b, big_n, mode, &gc[b]) : 0;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      if (a > sorder) break;
+      bool yc = false;
+      const unsigned row = static_cast<unsigned>(__mul24(fold_tap(y0 + a, big_m, mode, &yc), big_n));
+      float line = 0.f;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        if (b <= sorder) {
+          const float v = ld(coef, (row + gi[b]) << 2);
+          line = fmaf(gx[b], (yc || gc[b]) ? cval : v, line);
+        }
+      }
+      acc = fmaf(gy[a], line, acc);
+    }
+    return acc;
+  }
   float wx[4], wy[4];
   bspline3(fx, wx);
   bspline3(fy, wy);

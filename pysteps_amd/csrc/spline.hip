@@ -1,4 +1,7 @@
-// Cubic B-spline prefilter for interp_order=3 of the semi-Lagrangian extrapolator (gfx950).
+// B-spline prefilter for interp_order 2 .. 5 of the semi-Lagrangian extrapolator (gfx950); written for the cubic
+// case (one pole, gain 6), the other orders pass their poles and the gain of all of them through the same kernels
+// (ni_splines.c get_filter_poles / apply_filter: order 2 one pole sqrt(8) - 3; orders 4 and 5 two poles each - one
+// causal / anticausal pair per pole, the gain prod (1 - z)(1 - 1/z) on the first).
 //
 // pysteps/extrapolation/semilagrangian.py:225-232 calls scipy.ndimage.map_coordinates(order=3,
 // prefilter=True, mode="constant"); SciPy first turns the samples into B-spline coefficients
@@ -17,6 +20,8 @@
 // samples early: 8-16x more parallelism at ~10 % redundant work, results identical to fp32
 // rounding.  Rows are filtered as columns of the transposed image (LDS-tiled transposes), so
 // every memory access of the recursions is coalesced.
+#include <cmath>
+
 #include "common.h"
 
 #pragma clang fp contract(off)
@@ -26,7 +31,7 @@ namespace {
 
 constexpr int kSeg = 512;   // samples owned by one thread
 constexpr int kWarm = 40;   // recursion warm-up before the owned segment
-constexpr float kPole = -0.2679491924311227f;  // sqrt(3) - 2
+// (the warm-up is sized for the slowest pole, order 5's 0.4306: |z|^40 = 2e-15 - far below float32 rounding)
 
 __global__ __launch_bounds__(256) void spline_zero_nonfinite(const float *__restrict__ in,
                                                              float *__restrict__ out, size_t n) {
@@ -39,9 +44,9 @@ __global__ __launch_bounds__(256) void spline_zero_nonfinite(const float *__rest
 
 enum : int { kKindMirror = 0, kKindReflect = 1, kKindWrap = 2 };
 
-// z^k as a float (0 once it underflows: |z|^64 ~ 1e-37)
-__device__ __forceinline__ float pole_pow(int k) {
-  return powf(-kPole, static_cast<float>(k)) * ((k & 1) ? -1.f : 1.f);
+// z^k as a float for a negative pole z (0 once it underflows)
+__device__ __forceinline__ float pole_pow(float z, int k) {
+  return powf(-z, static_cast<float>(k)) * ((k & 1) ? -1.f : 1.f);
 }
 
 // zero-padded / edge-padded copy with the missing values zeroed: out (m + 2 npad, n + 2 npad)
@@ -62,13 +67,13 @@ __global__ __launch_bounds__(256) void spline_pad(const float *__restrict__ in, 
   }
 }
 
-// causal pass along axis 0 of a (len, width) row-major array: dst[i] = 6 src[i] + z dst[i-1]
+// causal pass along axis 0 of a (len, width) row-major array: dst[i] = gain src[i] + z dst[i-1]
 __global__ __launch_bounds__(64) void spline_causal(const float *__restrict__ src,
-                                                    float *__restrict__ dst, int len, int width, int kind) {
+                                                    float *__restrict__ dst, int len, int width, int kind, float z,
+                                                    float gain) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   if (x >= width) return;
   const int s0 = blockIdx.y * kSeg, s1 = min(len, s0 + kSeg);
-  const float z = kPole;
   float c;
   int i;
   if (s0 <= kWarm) {
@@ -78,48 +83,48 @@ __global__ __launch_bounds__(64) void spline_causal(const float *__restrict__ sr
       return;
     }
     if (kind == kKindMirror) {
-      const float zn1 = pole_pow(len - 1);
-      float acc = 6.f * src[x] + zn1 * 6.f * src[static_cast<size_t>(len - 1) * width + x];
+      const float zn1 = pole_pow(z, len - 1);
+      float acc = gain * src[x] + zn1 * gain * src[static_cast<size_t>(len - 1) * width + x];
       float zi = z;
       const int horizon = min(len - 2, 64);  // |z|^64 ~ 1e-37
       for (int k = 1; k <= horizon; ++k) {
-        float term = 6.f * src[static_cast<size_t>(k) * width + x];
-        if (zn1 != 0.f) term += zn1 * 6.f * src[static_cast<size_t>(len - 1 - k) * width + x];
+        float term = gain * src[static_cast<size_t>(k) * width + x];
+        if (zn1 != 0.f) term += zn1 * gain * src[static_cast<size_t>(len - 1 - k) * width + x];
         acc += zi * term;
         zi *= z;
       }
       c = acc / (1.f - zn1 * zn1);
     } else if (kind == kKindReflect) {  // _init_causal_reflect
-      const float zn = pole_pow(len), first = 6.f * src[x];
-      float acc = first + zn * 6.f * src[static_cast<size_t>(len - 1) * width + x];
+      const float zn = pole_pow(z, len), first = gain * src[x];
+      float acc = first + zn * gain * src[static_cast<size_t>(len - 1) * width + x];
       float zi = z;
       const int horizon = min(len - 1, 64);
       for (int k = 1; k <= horizon; ++k) {
-        float term = 6.f * src[static_cast<size_t>(k) * width + x];
-        if (zn != 0.f) term += zn * 6.f * src[static_cast<size_t>(len - 1 - k) * width + x];
+        float term = gain * src[static_cast<size_t>(k) * width + x];
+        if (zn != 0.f) term += zn * gain * src[static_cast<size_t>(len - 1 - k) * width + x];
         acc += zi * term;
         zi *= z;
       }
       c = acc * (z / (1.f - zn * zn)) + first;
     } else {  // _init_causal_wrap
-      float acc = 6.f * src[x];
+      float acc = gain * src[x];
       float zi = z;
       const int horizon = min(len - 1, 64);
       for (int k = 1; k <= horizon; ++k) {
-        acc += zi * 6.f * src[static_cast<size_t>(len - k) * width + x];
+        acc += zi * gain * src[static_cast<size_t>(len - k) * width + x];
         zi *= z;
       }
-      c = acc / (1.f - pole_pow(len));
+      c = acc / (1.f - pole_pow(z, len));
     }
     if (s0 == 0) dst[x] = c;
     i = 1;
   } else {
     i = s0 - kWarm;
-    c = 6.f * src[static_cast<size_t>(i) * width + x];  // any start value: forgotten after kWarm steps
+    c = gain * src[static_cast<size_t>(i) * width + x];  // any start value: forgotten after kWarm steps
     ++i;
   }
   for (; i < s1; ++i) {
-    c = 6.f * src[static_cast<size_t>(i) * width + x] + z * c;
+    c = gain * src[static_cast<size_t>(i) * width + x] + z * c;
     if (i >= s0) dst[static_cast<size_t>(i) * width + x] = c;
   }
 }
@@ -127,14 +132,13 @@ __global__ __launch_bounds__(64) void spline_causal(const float *__restrict__ sr
 // anticausal pass: dst[i] = z (dst[i+1] - cp[i]) with cp the causal result
 __global__ __launch_bounds__(64) void spline_anticausal(const float *__restrict__ cp,
                                                         float *__restrict__ dst, int len,
-                                                        int width, int kind) {
+                                                        int width, int kind, float z) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   if (x >= width || len == 1) {
     if (x < width && blockIdx.y == 0) dst[x] = cp[x];
     return;
   }
   const int s0 = blockIdx.y * kSeg, s1 = min(len, s0 + kSeg);
-  const float z = kPole;
   float c;
   int i;
   if (s1 + kWarm >= len) {
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(64) void spline_anticausal(const float *__restrict_
         acc += zi * cp[static_cast<size_t>(k) * width + x];
         zi *= z;
       }
-      c = acc * (z / (pole_pow(len) - 1.f));
+      c = acc * (z / (pole_pow(z, len) - 1.f));
     }
     if (s1 == len) dst[static_cast<size_t>(len - 1) * width + x] = c;
     i = len - 2;
@@ -185,10 +189,25 @@ __global__ __launch_bounds__(256) void transpose32(const float *__restrict__ in,
 
 }  // namespace
 
-// coef <- cubic B-spline coefficients of precip (NaN/Inf -> 0) padded by `npad` samples (edge values
+// coef <- B-spline coefficients (order 2 .. 5) of precip (NaN/Inf -> 0) padded by `npad` samples (edge values
 // or `cval`), boundary kind 0 mirror / 1 reflect / 2 wrap; coef and tmp: (m + 2 npad, n + 2 npad) planes.
 hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream, int kind,
-                            int npad, int pad_edge, float cval) {
+                            int npad, int pad_edge, float cval, int order) {
+  double poles[2] = {std::sqrt(3.0) - 2.0, 0.0};
+  int npoles = 1;
+  if (order == 2) {
+    poles[0] = std::sqrt(8.0) - 3.0;
+  } else if (order == 4) {
+    poles[0] = std::sqrt(664.0 - std::sqrt(438976.0)) + std::sqrt(304.0) - 19.0;
+    poles[1] = std::sqrt(664.0 + std::sqrt(438976.0)) - std::sqrt(304.0) - 19.0;
+    npoles = 2;
+  } else if (order == 5) {
+    poles[0] = std::sqrt(67.5 - std::sqrt(4436.25)) + std::sqrt(26.25) - 6.5;
+    poles[1] = std::sqrt(67.5 + std::sqrt(4436.25)) - std::sqrt(26.25) - 6.5;
+    npoles = 2;
+  }
+  double gain = 1.0;
+  for (int k = 0; k < npoles; ++k) gain *= (1.0 - poles[k]) * (1.0 - 1.0 / poles[k]);
   if (npad > 0) {
     hipLaunchKernelGGL(spline_pad, dim3(2048), dim3(256), 0, stream, precip, coef, m, n, npad, pad_edge, cval);
     m += 2 * npad;
@@ -196,15 +215,21 @@ hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m,
   } else {
     hipLaunchKernelGGL(spline_zero_nonfinite, dim3(2048), dim3(256), 0, stream, precip, coef, static_cast<size_t>(m) * n);
   }
-  // axis 0 (columns of the image)
+  // axis 0 (columns of the image): one causal / anticausal pair per pole, coef -> tmp -> coef
   dim3 g0((n + 63) / 64, (m + kSeg - 1) / kSeg);
-  hipLaunchKernelGGL(spline_causal, g0, dim3(64), 0, stream, coef, tmp, m, n, kind);
-  hipLaunchKernelGGL(spline_anticausal, g0, dim3(64), 0, stream, tmp, coef, m, n, kind);
-  // axis 1 (rows) as columns of the transpose
+  for (int k = 0; k < npoles; ++k) {
+    const float z = static_cast<float>(poles[k]);
+    hipLaunchKernelGGL(spline_causal, g0, dim3(64), 0, stream, coef, tmp, m, n, kind, z, k == 0 ? static_cast<float>(gain) : 1.f);
+    hipLaunchKernelGGL(spline_anticausal, g0, dim3(64), 0, stream, tmp, coef, m, n, kind, z);
+  }
+  // axis 1 (rows) as columns of the transpose: tmp -> coef -> tmp per pole
   hipLaunchKernelGGL(transpose32, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, stream, coef, tmp, m, n);
   dim3 g1((m + 63) / 64, (n + kSeg - 1) / kSeg);
-  hipLaunchKernelGGL(spline_causal, g1, dim3(64), 0, stream, tmp, coef, n, m, kind);
-  hipLaunchKernelGGL(spline_anticausal, g1, dim3(64), 0, stream, coef, tmp, n, m, kind);
+  for (int k = 0; k < npoles; ++k) {
+    const float z = static_cast<float>(poles[k]);
+    hipLaunchKernelGGL(spline_causal, g1, dim3(64), 0, stream, tmp, coef, n, m, kind, z, k == 0 ? static_cast<float>(gain) : 1.f);
+    hipLaunchKernelGGL(spline_anticausal, g1, dim3(64), 0, stream, coef, tmp, n, m, kind, z);
+  }
   hipLaunchKernelGGL(transpose32, dim3((m + 31) / 32, (n + 31) / 32), dim3(256), 0, stream, tmp, coef, n, m);
   return hipGetLastError();
 }

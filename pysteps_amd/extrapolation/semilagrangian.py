@@ -12,8 +12,8 @@ Differences, all documented in DESIGN.md:
 * arithmetic is float32 on device (the reference computes in float64 inside
   SciPy); the advected field is within 1e-4 relative L2 of the reference (measured
   ~1e-6) and the returned displacement is float64 like the reference's;
-* options the kernel does not implement (``interp_order`` other than 0/1/3, custom ``xy_coords``) are delegated to the reference implementation when pysteps is
-  importable and raise ``NotImplementedError`` otherwise;
+* a custom ``xy_coords`` grid (:174-179) rides into the kernel as base-position offsets in the displacement buffer
+  (``_grid_offsets``); every ``interp_order`` scipy.ndimage accepts (0 .. 5) and every boundary mode is native;
 * ``precip``/``velocity``/``displacement_prev`` may also be
   :class:`pysteps_amd.device.DeviceArray` objects; then nothing crosses PCIe and
   the results are DeviceArrays too (used by the resident nowcast loop and bench).
@@ -34,6 +34,7 @@ __all__ = ["extrapolate"]
 
 # psh_semilag_host flags / input status bits (include/pysteps_hip.h PSH_SL_*)
 _FLAG_ALLOW_NONFINITE, _FLAG_OUTVAL_MIN, _FLAG_PRECIP_F64, _FLAG_VELOCITY_F64, _FLAG_OUT_F64 = 1, 2, 4, 8, 16
+_FLAG_BASE_IN_DISP = 32
 _ST_PRECIP_NONFINITE, _ST_PRECIP_ALL_NONFINITE, _ST_VELOCITY_NONFINITE, _ST_VELOCITY_ALL_NONFINITE = 1, 2, 4, 8
 
 # scipy.ndimage boundary modes of the field resampling -> PSH_MODE_* (include/pysteps_hip.h)
@@ -103,6 +104,19 @@ def _is_default_grid(xy_coords, m, n):
         except TypeError:
             pass  # not weak-referenceable (a list): verified every time
     return ok
+
+
+def _grid_offsets(xy_coords, m, n):
+    """``xy_coords - meshgrid`` as float64 (2, m, n): where the trajectories of a custom grid start, relative to the
+    integer grid the kernels index (reference :174-179, :182, :221: every coordinate is ``xy_coords + displacement``).
+    The kernels split it into integer position + float32 fraction (6e-8 px), as they split a displacement_prev."""
+    xy = np.asarray(xy_coords, dtype=np.float64)
+    if xy.shape != (2, m, n):
+        raise ValueError("xy_coords must have shape (2, %d, %d)" % (m, n))
+    off = np.empty((2, m, n), dtype=np.float64)
+    np.subtract(xy[0], np.arange(n, dtype=np.float64)[None, :], out=off[0])
+    np.subtract(xy[1], np.arange(m, dtype=np.float64)[:, None], out=off[1])
+    return off
 
 
 def _step_increments(timesteps, vel_timestep):
@@ -181,14 +195,18 @@ def extrapolate(
         raise ValueError("precip and velocity have incompatible shapes")
 
     # ---- options outside the kernel's contract -------------------------
-    if interp_order not in (0, 1, 3):
+    if interp_order not in (0, 1, 2, 3, 4, 5):  # (what scipy.ndimage accepts; anything else is the reference's error to raise)
         return _unsupported("interp_order=%r" % (interp_order,), call_args, call_kwargs)
     if map_coordinates_mode not in _BOUNDARY_MODES:
         raise RuntimeError("boundary mode not supported")  # what scipy.ndimage raises
     # the boundary mode rides in the second byte of the interp_order word (include/pysteps_hip.h)
     interp_order = int(interp_order) | (_BOUNDARY_MODES[map_coordinates_mode] << 8)
+    # a custom grid: its base positions relative to the integer grid go where a displacement_prev would (the kernels
+    # start every trajectory at integer position + fraction anyway); the displacement that comes back is made
+    # relative to xy_coords again
+    grid_off = None
     if xy_coords is not None and not _is_default_grid(xy_coords, m, n):
-        return _unsupported("a non-default xy_coords grid", call_args, call_kwargs)
+        grid_off = _grid_offsets(xy_coords, m, n)
     if n_iter < 0:
         n_iter = 0  # the reference treats any n_iter <= 0 as "no midpoint rule" (:211-219)
 
@@ -201,7 +219,7 @@ def extrapolate(
 
     if on_device:
         result = _run_device(lib, precip, velocity, steps, outval, displacement_prev, n_iter,
-                             return_displacement, interp_order)
+                             return_displacement, interp_order, grid_off)
     else:
         flags = _FLAG_ALLOW_NONFINITE if allow_nonfinite_values else 0
         if isinstance(outval, str):
@@ -233,6 +251,12 @@ def extrapolate(
             dprev = np.ascontiguousarray(displacement_prev, dtype=np.float64)
             if dprev.shape != (2, m, n):
                 raise ValueError("displacement_prev must have shape (2, m, n)")
+        if grid_off is not None:
+            if dprev is None:
+                dprev = grid_off
+                flags |= _FLAG_BASE_IN_DISP  # no previous displacement: the first increment is the grid's velocity (:203)
+            else:
+                dprev = dprev + grid_off
         # results on pinned blocks of the library's pool: the device-to-host copies land in the
         # arrays the caller receives (csrc/hostpath.hip)
         out = None
@@ -258,6 +282,8 @@ def extrapolate(
                 raise ValueError("precip contains only non-finite values")
             raise ValueError("velocity contains only non-finite values")
         _lib.check(rc, "psh_semilag_host")
+        if grid_off is not None and disp is not None:
+            np.subtract(disp, grid_off, out=disp)
         if out is not None and out.dtype != out_dtype and np.issubdtype(out_dtype, np.floating):
             out = out.astype(out_dtype)  # float16 / longdouble inputs
         if precip is None:
@@ -273,7 +299,7 @@ def extrapolate(
 
 
 def _run_device(lib, precip, velocity, steps, outval, displacement_prev, n_iter,
-                return_displacement, interp_order):
+                return_displacement, interp_order, grid_off=None):
     """All operands resident in HBM; asynchronous on the library stream."""
     m, n = velocity.shape[1:]
     T = int(steps.size)
@@ -297,8 +323,17 @@ def _run_device(lib, precip, velocity, steps, outval, displacement_prev, n_iter,
         disp = DeviceArray((2, m, n), np.float64)  # inputs are never mutated (:205)
         _lib.check(lib.psh_memcpy_d2d(disp.ptr, displacement_prev.ptr, disp.nbytes), "d2d")
         resume = 1
-    elif return_displacement:
+    elif return_displacement or grid_off is not None:
         disp = DeviceArray((2, m, n), np.float64)
+    off_d = None
+    if grid_off is not None:
+        # base positions of a custom xy_coords grid: into the displacement buffer (added to a displacement_prev)
+        off_d = DeviceArray.from_host(grid_off)
+        if resume:
+            _lib.check(lib.psh_axpy_f64_dev(disp.ptr, off_d.ptr, 1.0, disp.size), "psh_axpy_f64_dev")
+        else:
+            _lib.check(lib.psh_memcpy_d2d(disp.ptr, off_d.ptr, disp.nbytes), "d2d")
+            resume = 2  # PSH_SL_RESUME_BASE: positions from the buffer, the first increment from the grid's velocity
     out = None if precip is None else DeviceArray((T, m, n), np.float32)
     # a motion field that comes with its {u, v}-interleaved twin (dense_lucaskanade on resident frames) is
     # gathered from that twin directly
@@ -311,6 +346,11 @@ def _run_device(lib, precip, velocity, steps, outval, displacement_prev, n_iter,
         None if disp is None else disp.ptr, resume, None if out is None else out.ptr,
     )
     _lib.check(rc, "psh_semilag_uv_dev")
+    if off_d is not None:
+        if return_displacement or precip is None:
+            _lib.check(lib.psh_axpy_f64_dev(disp.ptr, off_d.ptr, -1.0, disp.size), "psh_axpy_f64_dev")
+        else:
+            disp = None
     if precip is None:
         return None, disp
     return (out, disp) if return_displacement else out

@@ -350,6 +350,7 @@ class ResidentSteps:
             masks = state["mask_prec"]
             self.struct = np.ascontiguousarray(np.asarray(p["struct"]) != 0, dtype=np.uint8)
             self.rim = int(p["mask_rim"])
+            self._bit_mask = os.environ.get("PYSTEPS_HIP_BIT_MASK", "1") != "0"  # (development switch)
             if self.struct.ndim != 2 or not 0 <= self.rim <= 254 or int(self.struct.sum()) > 1024 or self.thr is None:
                 raise _Declined
             if isinstance(masks, DeviceArray):
@@ -530,11 +531,19 @@ class ResidentSteps:
         """steps.py:1209-1217: the member's incremental mask from its new field, the domain mask."""
         lib, m, n, plane = self._lib, self.m, self.n, self.plane
         if self.grey is not None:
-            _lib.check(lib.psh_ge_mask_dev(field.ptr, plane, self.thr, self.wet.ptr), "psh_ge_mask_dev")
-            _lib.check(
-                lib.psh_dilated_mask_dev(self.wet.ptr, m, n, self.struct.ctypes.data_as(ctypes.c_void_p), int(self.struct.shape[0]),
-                                         int(self.struct.shape[1]), self.rim, self.grey.view(j).ptr),
-                "psh_dilated_mask_dev")
+            kr = self.struct.ctypes.data_as(ctypes.c_void_p)
+            kh, kw = int(self.struct.shape[0]), int(self.struct.shape[1])
+            # threshold + dilations on bit masks in two kernels; structures that entry point does not take (no centre
+            # element, a rim wider than its tiles' halo) go through the byte masks
+            rc = lib.psh_steps_incremental_mask_dev(field.ptr, m, n, self.thr, kr, kh, kw, self.rim, self.grey.view(j).ptr) \
+                if self._bit_mask else _lib.PSH_EUNSUPPORTED
+            if rc == _lib.PSH_EUNSUPPORTED:
+                self._bit_mask = False
+                _lib.check(lib.psh_ge_mask_dev(field.ptr, plane, self.thr, self.wet.ptr), "psh_ge_mask_dev")
+                _lib.check(lib.psh_dilated_mask_dev(self.wet.ptr, m, n, kr, kh, kw, self.rim, self.grey.view(j).ptr),
+                           "psh_dilated_mask_dev")
+            else:
+                _lib.check(rc, "psh_steps_incremental_mask_dev")
         if self.domain_mask is not None:
             _lib.check(lib.psh_nan_where_dev(field.ptr, self.domain_mask.ptr, plane), "psh_nan_where_dev")
 

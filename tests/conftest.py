@@ -75,6 +75,18 @@ def semilag_o3_golden():
 
 
 @pytest.fixture(scope="session")
+def semilag_orders_golden():
+    """interp_order 2 / 4 / 5, from the unmodified reference (tools/make_golden.py semilag_spline_orders)."""
+    return GoldenCases(os.path.join(GOLDEN, "semilag_spline_orders.npz"))
+
+
+@pytest.fixture(scope="session")
+def semilag_xy_golden():
+    """custom xy_coords grids, from the unmodified reference (tools/make_golden.py semilag_xy)."""
+    return GoldenCases(os.path.join(GOLDEN, "semilag_xy_coords.npz"))
+
+
+@pytest.fixture(scope="session")
 def ref_pysteps():
     """The REAL reference package, imported from oracle/_ref (built by ``python -m oracle.build_ref``
     from /root/reference; ships to the GPU box with the snapshot).  Test infrastructure only."""

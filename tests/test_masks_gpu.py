@@ -73,3 +73,60 @@ def test_resident_small_empty_and_numeric_masks(ref_pysteps):
     assert np.array_equal(compute_dilated_mask(mask, big, 2), ref(mask, big, 2))
     with pytest.raises(NotImplementedError):
         compute_dilated_mask(DeviceArray.from_host(mask.astype(np.uint8)), big, 2)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (70, 130), (257, 255), (1024, 1024), (40, 41), (1, 77)])
+def test_bit_mask_entry_point_is_bit_exact_with_the_reference(ref_pysteps, shape):
+    """psh_steps_incremental_mask_dev - `field >= thr` and the dilated mask in two kernels on bit masks (what the
+    resident STEPS update calls per member) - against the reference's compute_dilated_mask of the thresholded field:
+    structures with their centre element, rims up to the tile halo; NaNs in the field; empty and full masks; and the
+    structures / rims the entry point declines (PSH_EUNSUPPORTED: the byte-mask kernels answer those)."""
+    import ctypes
+
+    from pysteps.nowcasts.utils import compute_dilated_mask as ref
+
+    from pysteps_amd import _lib
+    from pysteps_amd.device import DeviceArray
+
+    lib = _lib.lib()
+    m, n = shape
+    structures = _structures()
+    rng = np.random.default_rng(m * 1000 + n)
+
+    def run(field, kr, r, thr):
+        kr8 = np.ascontiguousarray(np.asarray(kr) != 0, dtype=np.uint8)
+        out = DeviceArray((m, n), np.float64)
+        rc = lib.psh_steps_incremental_mask_dev(DeviceArray.from_host(field).ptr, m, n, float(thr),
+                                                kr8.ctypes.data_as(ctypes.c_void_p), kr8.shape[0], kr8.shape[1], int(r), out.ptr)
+        return rc, out
+
+    from scipy.ndimage import gaussian_filter
+
+    for it, (fraction, r) in enumerate([(0.2, 10), (0.02, 3), (0.5, 0), (0.001, 20), (0.2, 1), (0.05, 14), (0.3, 4)]):
+        g = gaussian_filter(rng.standard_normal(shape), 3.0) if min(shape) > 8 else rng.standard_normal(shape)
+        thr = np.quantile(g, 1.0 - fraction)
+        field = g.astype(np.float64)
+        field[rng.random(shape) < 0.01] = np.nan  # NaN >= thr is False
+        kr = structures[it % len(structures)]
+        rc, out = run(field, kr, r, thr)
+        has_centre = bool(np.asarray(kr)[kr.shape[0] // 2, kr.shape[1] // 2])
+        reach = max(kr.shape[0] // 2, kr.shape[1] // 2, (kr.shape[0] - 1) - kr.shape[0] // 2, (kr.shape[1] - 1) - kr.shape[1] // 2)
+        if not has_centre:
+            assert rc == _lib.PSH_EUNSUPPORTED
+            continue
+        _lib.check(rc, "psh_steps_incremental_mask_dev")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = ref(field >= thr, kr, r)
+        assert np.array_equal(out.to_host(), want, equal_nan=True), (it, r, reach)
+    cross = structures[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # 0 / 0
+        rc, out = run(np.zeros(shape), cross, 10, 1.0)
+        _lib.check(rc, "empty")
+        assert np.isnan(out.to_host()).all()
+    rc, out = run(np.ones(shape), cross, 10, 1.0)
+    _lib.check(rc, "full")
+    assert np.array_equal(out.to_host(), ref(np.ones(shape, bool), cross, 10))
+    rc, _ = run(np.ones(shape), cross, 24, 1.0)  # rim + reach = 25 > 24
+    assert rc == _lib.PSH_EUNSUPPORTED

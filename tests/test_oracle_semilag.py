@@ -84,6 +84,64 @@ def test_displacement_only(semilag_golden, backend):
     np.testing.assert_allclose(disp, c["disp"], rtol=0, atol=1e-11)
 
 
+GOLDEN_XY = ["sl_xy_warp", "sl_xy_warp_resume", "sl_xy_half_K0", "sl_xy_warp_o0", "sl_xy_warp_o3"]
+
+
+@pytest.mark.parametrize("backend", ["numpy", "scipy"])
+@pytest.mark.parametrize("name", GOLDEN_XY)
+def test_oracle_custom_grid_matches_reference_golden(semilag_xy_golden, backend, name):
+    """custom xy_coords (reference :174-179): the oracle against outputs of the unmodified reference"""
+    c = semilag_xy_golden.case(name)
+    out, disp = _run(backend, c)
+    assert out.shape == c["out"].shape and out.dtype == c["out"].dtype
+    assert nan_mismatch(out, c["out"]) == 0
+    np.testing.assert_allclose(disp, c["disp"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out, c["out"], rtol=0, atol=2e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("backend,atol", [("scipy", 1e-11), ("numpy", 2e-7)])
+def test_oracle_custom_grid_displacement_only(semilag_xy_golden, backend, atol):
+    """(float32 velocity: SciPy rounds every interpolated velocity sample to float32, the NumPy restatement keeps
+    float64 - 8e-8 px over two lead steps)"""
+    c = semilag_xy_golden.case("sl_xy_disp_only")
+    none, disp = osl.extrapolate(None, c["velocity"], [0.7, 1.9], return_displacement=True, n_iter=1, xy_coords=c["xy_coords"],
+                                 backend=backend)
+    assert none is None
+    np.testing.assert_allclose(disp, c["disp"], rtol=0, atol=atol)
+
+
+GOLDEN_ORDERS = ["sl_o2", "sl_o2_nan", "sl_o2_reflect", "sl_o4", "sl_o4_nan", "sl_o4_nearest", "sl_o4_gridconstant_nan",
+                 "sl_o5", "sl_o5_nan", "sl_o5_gridwrap"]
+
+
+@pytest.mark.parametrize("backend", ["numpy", "scipy"])
+@pytest.mark.parametrize("name", GOLDEN_ORDERS)
+def test_oracle_spline_orders_match_reference_golden(semilag_orders_golden, backend, name):
+    """interp_order 2 / 4 / 5: the restated prefilter poles, tap geometry (even orders start at floor(c + 0.5) -
+    order // 2) and B-spline weights against outputs of the unmodified reference"""
+    c = semilag_orders_golden.case(name)
+    out, disp = _run(backend, c)
+    assert out.shape == c["out"].shape and out.dtype == c["out"].dtype
+    assert nan_mismatch(out, c["out"]) == 0
+    np.testing.assert_allclose(disp, c["disp"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out, c["out"], rtol=0, atol=5e-5, equal_nan=True)
+
+
+@pytest.mark.parametrize("order", [2, 4, 5])
+def test_spline_restatement_equals_scipy(order):
+    """prefilter and sampler of the NumPy backend against scipy.ndimage itself, every boundary mode"""
+    from scipy.ndimage import map_coordinates, spline_filter
+
+    rng = np.random.default_rng(order)
+    f = rng.standard_normal((37, 53))
+    for kind, mode in (("mirror", "mirror"), ("reflect", "reflect"), ("wrap", "grid-wrap")):
+        np.testing.assert_allclose(osl._spline_prefilter(f, kind, order), spline_filter(f, order=order, mode=mode), rtol=0, atol=1e-10)
+    row, col = rng.uniform(-3, 40, 3000), rng.uniform(-3, 56, 3000)
+    for mode in ("constant", "nearest", "reflect", "mirror", "wrap", "grid-wrap", "grid-constant"):
+        np.testing.assert_allclose(osl._numpy_sample(f, row, col, mode, -7.0, order),
+                                   map_coordinates(f, [row, col], order=order, mode=mode, cval=-7.0), rtol=0, atol=1e-11)
+
+
 def test_oracle_error_behaviour():
     p = np.ones((8, 8))
     v = np.ones((2, 8, 8))

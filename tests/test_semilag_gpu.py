@@ -168,6 +168,82 @@ def test_matches_reference_golden(extrapolate, semilag_golden, name):
         _field_bar(rel_l2(out, c["out"]))
 
 
+GOLDEN_ORDERS = ["sl_o2", "sl_o2_nan", "sl_o2_reflect", "sl_o4", "sl_o4_nan", "sl_o4_nearest", "sl_o4_gridconstant_nan",
+                 "sl_o5", "sl_o5_nan", "sl_o5_gridwrap"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_ORDERS)
+def test_spline_orders_match_reference_golden(extrapolate, semilag_orders_golden, name):
+    """interp_order 2, 4 and 5 natively (reference :85-90, :146-157: the prefilter with that order's poles - two
+    causal / anticausal pairs for orders 4 and 5 -, (order + 1)^2 taps, even orders centred on the nearest sample) against
+    outputs of the unmodified reference; the tolerance of the float32 spline path (see sl_order3)."""
+    import warnings
+
+    c = semilag_orders_golden.case(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # a delegation to the reference implementation would warn
+        out, disp = extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **c["kw"])
+    want = c["out"]
+    assert out.shape == want.shape and out.dtype == want.dtype
+    _disp_bar(np.max(np.abs(disp - c["disp"])), bar=DISP_TOL)
+    assert nan_mismatch(out, want) <= 1e-3 * out.size  # masks thresholded at exactly 0.5 (see the order-3 tests)
+    both = np.isfinite(out) & np.isfinite(want)
+    assert both.any()
+    # isolated pixels on the other side of a 0.5 mask threshold carry the minimum instead of a value (order-3 tests)
+    scale = max(float(np.ptp(want[both])), 1.0)
+    off = np.abs(out - want)[both] > 2e-3 * scale
+    assert off.mean() < 2e-3, off.mean()
+    _field_bar(rel_l2(out[both][~off], want[both][~off]), bar=REL_L2_TOL)
+
+
+GOLDEN_XY = ["sl_xy_warp", "sl_xy_warp_resume", "sl_xy_half_K0", "sl_xy_warp_o0", "sl_xy_warp_o3"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_XY)
+@pytest.mark.parametrize("resident", [False, True])
+def test_custom_grid_matches_reference_golden(extrapolate, semilag_xy_golden, name, resident):
+    """Custom ``xy_coords`` (reference :174-179: a deformed / staggered grid of start positions) natively: the base
+    positions ride into the kernels as offsets in the displacement buffer (``resume = 2``); NumPy arrays through
+    psh_semilag_host and DeviceArrays through psh_semilag_uv_dev, against outputs of the unmodified reference."""
+    import warnings
+
+    from pysteps_amd.device import DeviceArray
+
+    c = semilag_xy_golden.case(name)
+    kw = dict(c["kw"])
+    p, v = c["precip"], c["velocity"]
+    if resident:
+        if kw.get("allow_nonfinite_values") or p.dtype != np.float32:
+            p = p.astype(np.float32)
+        kw.pop("allow_nonfinite_values", None)
+        p, v = DeviceArray.from_host(p), DeviceArray.from_host(v.astype(np.float32))
+        if "displacement_prev" in kw:
+            kw["displacement_prev"] = DeviceArray.from_host(np.ascontiguousarray(kw["displacement_prev"], dtype=np.float64))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # a delegation to the reference implementation would warn
+        out, disp = extrapolate(p, v, c["timesteps"], return_displacement=True, **kw)
+    if resident:
+        out, disp = out.to_host(), disp.to_host()
+    want = c["out"]
+    assert out.shape == want.shape
+    _disp_bar(np.max(np.abs(disp - c["disp"])), bar=DISP_TOL)
+    if name.endswith("_o3"):
+        assert nan_mismatch(out, want) <= 2e-4 * out.size
+    else:
+        assert nan_mismatch(out, want) == 0
+    if name.endswith("_o0"):
+        assert np.count_nonzero(out != want) <= 1e-4 * out.size
+    else:
+        _field_bar(rel_l2(out, want), bar=REL_L2_TOL)
+
+
+def test_custom_grid_displacement_only(extrapolate, semilag_xy_golden):
+    c = semilag_xy_golden.case("sl_xy_disp_only")
+    none, disp = extrapolate(None, c["velocity"], [0.7, 1.9], return_displacement=True, n_iter=1, xy_coords=c["xy_coords"])
+    assert none is None
+    _disp_bar(np.max(np.abs(disp - c["disp"])), bar=DISP_TOL)
+
+
 O3_MODES = ("nearest", "reflect", "mirror", "wrap", "grid-wrap", "grid-constant")
 GOLDEN_O3 = (["sl_o3_%s%s" % (m.replace("-", ""), suffix) for m in O3_MODES for suffix in ("", "_nan")]
              + ["sl_o3_gridconstant_nancval"])

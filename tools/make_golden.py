@@ -133,6 +133,83 @@ def make_semilag_order3_modes():
     print("semilag order 3 x modes:", len(semilag_order3_mode_cases()), "cases")
 
 
+def semilag_spline_order_cases():
+    """interp_order 2, 4 and 5 (reference :85-90, :146-157, :225-253: B-spline prefilter of that order + the two
+    order-1 mask warps), mode "constant" with and without missing values, and one other boundary mode each."""
+    base = semilag_cases()
+    P, Vs, Pn, V = base["sl_order3"]["precip"], base["sl_order3"]["velocity"], base["sl_order3_nan"]["precip"], base["sl_order3_nan"]["velocity"]
+    cases = {}
+    for order, mode in ((2, "reflect"), (4, "nearest"), (5, "grid-wrap")):
+        cases["sl_o%d" % order] = dict(precip=P, velocity=Vs, timesteps=3, kw=dict(interp_order=order, outval=-15.0))
+        cases["sl_o%d_nan" % order] = dict(precip=Pn, velocity=V, timesteps=2, kw=dict(interp_order=order, allow_nonfinite_values=True))
+        cases["sl_o%d_%s" % (order, mode.replace("-", ""))] = dict(
+            precip=P, velocity=Vs, timesteps=[2.0, 10.0, 40.0], kw=dict(interp_order=order, map_coordinates_mode=mode, outval=-15.0))
+    cases["sl_o4_gridconstant_nan"] = dict(precip=Pn, velocity=Vs, timesteps=[3.0, 12.0],
+                                           kw=dict(interp_order=4, map_coordinates_mode="grid-constant", allow_nonfinite_values=True, n_iter=2))
+    return cases
+
+
+def make_semilag_spline_orders():
+    ref = ref_loader.load("pysteps.extrapolation.semilagrangian")
+    blob = {}
+    for name, c in semilag_spline_order_cases().items():
+        kw = dict(c["kw"])
+        out, disp = ref.extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **kw)
+        blob[name + "/precip"] = c["precip"]
+        blob[name + "/velocity"] = c["velocity"]
+        blob[name + "/timesteps"] = np.asarray(c["timesteps"])
+        blob[name + "/timesteps_is_int"] = np.asarray(isinstance(c["timesteps"], int))
+        for k, v in kw.items():
+            blob[name + "/kw/" + k] = np.asarray(v)
+        blob[name + "/out"] = out
+        blob[name + "/disp"] = disp
+    np.savez_compressed(os.path.join(OUT, "semilag_spline_orders.npz"), **blob)
+    print("semilag spline orders 2 / 4 / 5:", len(semilag_spline_order_cases()), "cases")
+
+
+def semilag_xy_cases():
+    """Custom ``xy_coords`` (reference :68-72, :174-179: the positions the trajectories start from - callers pass a
+    sub-grid or, as here, a deformed grid): a smooth sub-pixel deformation, the same with a displacement_prev, a
+    staggered half-pixel grid without the midpoint rule, interp_order 0 and a displacement-only call."""
+    base = semilag_cases()
+    P, Vs, Pn = base["sl_shear_K3"]["precip"], base["sl_shear_K3"]["velocity"], base["sl_nan_nan"]["precip"]
+    m, n = P.shape
+    y, x = np.mgrid[0:m, 0:n].astype(np.float64)
+    warp = np.stack([x + 1.7 * np.sin(y / 9.0) + 0.3, y + 2.2 * np.cos(x / 11.0) - 0.6])
+    half = np.stack([x + 0.5, y + 0.5])
+    D0 = base["sl_resume"]["kw"]["displacement_prev"]
+    return {
+        "sl_xy_warp": dict(precip=P, velocity=Vs, timesteps=3, kw=dict(xy_coords=warp, outval=-15.0)),
+        "sl_xy_warp_resume": dict(precip=P, velocity=Vs, timesteps=[0.5, 2.0], kw=dict(xy_coords=warp, displacement_prev=D0, n_iter=2)),
+        "sl_xy_half_K0": dict(precip=Pn, velocity=Vs, timesteps=[1.0, 2.5], kw=dict(xy_coords=half, n_iter=0, allow_nonfinite_values=True)),
+        "sl_xy_warp_o0": dict(precip=P, velocity=Vs, timesteps=2, kw=dict(xy_coords=warp, interp_order=0, outval=-15.0)),
+        "sl_xy_warp_o3": dict(precip=P, velocity=Vs, timesteps=2, kw=dict(xy_coords=warp, interp_order=3, outval=-15.0)),
+    }
+
+
+def make_semilag_xy():
+    ref = ref_loader.load("pysteps.extrapolation.semilagrangian")
+    blob = {}
+    for name, c in semilag_xy_cases().items():
+        kw = dict(c["kw"])
+        out, disp = ref.extrapolate(c["precip"], c["velocity"], c["timesteps"], return_displacement=True, **kw)
+        blob[name + "/precip"] = c["precip"]
+        blob[name + "/velocity"] = c["velocity"]
+        blob[name + "/timesteps"] = np.asarray(c["timesteps"])
+        blob[name + "/timesteps_is_int"] = np.asarray(isinstance(c["timesteps"], int))
+        for k, v in kw.items():
+            blob[name + "/kw/" + k] = np.asarray(v)
+        blob[name + "/out"] = out
+        blob[name + "/disp"] = disp
+    c = semilag_xy_cases()["sl_xy_warp"]
+    _, disp = ref.extrapolate(None, c["velocity"], [0.7, 1.9], return_displacement=True, n_iter=1, xy_coords=c["kw"]["xy_coords"])
+    blob["sl_xy_disp_only/velocity"] = c["velocity"]
+    blob["sl_xy_disp_only/xy_coords"] = c["kw"]["xy_coords"]
+    blob["sl_xy_disp_only/disp"] = disp
+    np.savez_compressed(os.path.join(OUT, "semilag_xy_coords.npz"), **blob)
+    print("semilag xy_coords:", len(semilag_xy_cases()) + 1, "cases")
+
+
 def sparse_vectors(L, m, n, seed, outliers=True):
     """LK-like sparse vectors: integer feature positions, smooth motion + noise (+ planted outliers)."""
     rng = np.random.default_rng(seed)
@@ -206,8 +283,8 @@ def main():
         sys.exit("reference not available")
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for name, fn in (("semilag", make_semilag), ("semilag_order3_modes", make_semilag_order3_modes), ("sparse", make_sparse),
-                     ("probmatch", make_probmatch)):
+    for name, fn in (("semilag", make_semilag), ("semilag_order3_modes", make_semilag_order3_modes),
+                     ("semilag_xy", make_semilag_xy), ("semilag_spline_orders", make_semilag_spline_orders), ("sparse", make_sparse), ("probmatch", make_probmatch)):
         if not only or name in only:
             fn()
 
