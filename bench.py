@@ -39,6 +39,8 @@ VALU_PEAK_GINST = N_SIMD * 2.4 / 4.0
 # hashes beside the counters, and a line whose sources differ reports `traffic: null, traffic_stale: true` instead of
 # counters of a kernel that is no longer the one being timed
 SL_SOURCES = ("pysteps_amd/csrc/semilag.hip", "pysteps_amd/csrc/semilag_device.h", "pysteps_amd/csrc/common.h")
+MU_SOURCES = ("pysteps_amd/csrc/steps_loop.hip", "pysteps_amd/csrc/fft.hip", "pysteps_amd/csrc/probmatch.hip",
+              "pysteps_amd/csrc/mask.hip", "pysteps_amd/csrc/cascade.hip", "pysteps_amd/csrc/common.h")
 LK_SOURCES = ("pysteps_amd/csrc/lk.hip", "pysteps_amd/csrc/lk_sparse.hip", "pysteps_amd/csrc/sparse_qc.hip",
               "pysteps_amd/csrc/idw.hip", "pysteps_amd/csrc/dense_lk.hip", "pysteps_amd/csrc/common.h")
 
@@ -693,17 +695,20 @@ def steps_loop_leg(precip_d, vel_d, members, T, K, dist, with_stock):
     levels, order = int(info["cascade_levels"]), int(info["ar_order"])
     alg = 8.0 * (levels * (order + 1) + 13) * m * n
     upd_s = out["ms_per_member_update"] * 1e-3
-    traffic = None
+    traffic, stale = None, False
     try:
         with open(os.path.join(ROOT, "profiles", "member_update_traffic.json")) as fh:
             rec = json.load(fh)
         if rec.get("workload", "").startswith("%dx%d" % (m, n)):
-            traffic = rec["hbm_bytes_per_member_update"]
+            # (counters of another revision of the update's kernels are withheld: tools/member_traffic.py stores the hashes)
+            stale = not sources_match(rec.get("source_hashes"), MU_SOURCES)
+            traffic = None if stale else rec["hbm_bytes_per_member_update"]
     except Exception:
-        pass
+        stale = False
     out["roofline"] = {"kernel": "member update (all kernels of one update)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                        "alg_bytes_per_member_update": alg, "achieved": alg / upd_s / 1e9, "frac": alg / upd_s / 1e9 / HBM_PEAK_GBS,
-                       "traffic": traffic, "hbm_frac": (traffic / upd_s / 1e9 / HBM_PEAK_GBS) if traffic else None}
+                       "traffic": traffic, "traffic_stale": bool(stale),
+                       "hbm_frac": (traffic / upd_s / 1e9 / HBM_PEAK_GBS) if traffic else None}
     del step
     e2e = None
     try:

@@ -11,7 +11,8 @@ import threading
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libpysteps_hip.so")
+# PYSTEPS_HIP_LIB: another build of the library (the assertion build of `python -m pysteps_amd.build --debug`)
+LIB_PATH = os.environ.get("PYSTEPS_HIP_LIB") or os.path.join(_PKG, "lib", "libpysteps_hip.so")
 
 PSH_OK = 0
 PSH_EINVAL = -1

@@ -1,6 +1,12 @@
 """Build libpysteps_hip.so in-tree with hipcc for gfx950.
 
-    python -m pysteps_amd.build [--force] [--verbose]
+    python -m pysteps_amd.build [--force] [--verbose] [--debug]
+
+--debug builds pysteps_amd/lib/libpysteps_hip_debug.so beside the product (-O1 -g -DPSH_DEBUG: the device-side
+assertions of common.h PSH_DASSERT - window and tile bounds of the extrapolator's window kernel, list / segment bounds
+of the interpolation and probability-matching kernels - are compiled in and trap the kernel that violates one);
+PYSTEPS_HIP_LIB=<path> makes the package load it (tools/gpu_debug_build.sh runs the SL + LK suites under it once per
+round, the log is kept under profiles/).
 
 The shared object lands in pysteps_amd/lib/ (git-ignored, but it travels to the
 GPU box with the gpurun snapshot).  hipcc cross-compiles without a GPU.
@@ -36,15 +42,22 @@ def _deps():
     return glob.glob(os.path.join(SRC_DIR, "*.h")) + [HEADER]
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ_DIR, exist_ok=True)
+DEBUG_LIB_PATH = os.path.join(LIB_DIR, "libpysteps_hip_debug.so")
+
+
+def build(force=False, verbose=False, debug=False):
+    obj_dir = os.path.join(LIB_DIR, "obj_debug") if debug else OBJ_DIR
+    lib_path = DEBUG_LIB_PATH if debug else LIB_PATH
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     dep_mtime = max(os.path.getmtime(p) for p in _deps())
     objs, rebuilt = [], False
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    if debug:
+        flags = ["--offload-arch=" + ARCH, "-O1", "-g", "-DPSH_DEBUG", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
     procs = []
     for src in sources():
-        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if (
             not force
@@ -60,13 +73,13 @@ def build(force=False, verbose=False):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
-    if rebuilt or not os.path.exists(LIB_PATH):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
+    if rebuilt or not os.path.exists(lib_path):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv, debug="--debug" in sys.argv))

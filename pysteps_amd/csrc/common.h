@@ -12,6 +12,15 @@
 
 #include "../../include/pysteps_hip.h"
 
+// Device-side assertions of the debug build (python -m pysteps_amd.build --debug: -O1 -g -DPSH_DEBUG): compiled out
+// of the product.  A violated one prints file:line and traps the kernel; the host sees the launch fail.
+#ifdef PSH_DEBUG
+#include <cassert>
+#define PSH_DASSERT(cond) assert(cond)
+#else
+#define PSH_DASSERT(cond) ((void)0)
+#endif
+
 namespace psh {
 
 constexpr int kNumXcd = 8;  // MI355X: 8 XCDs, block b is dispatched to XCD b % 8

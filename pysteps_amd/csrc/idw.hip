@@ -365,6 +365,7 @@ __global__ __launch_bounds__(kThreads) void idw_knn(const float2 *__restrict__ x
               keep = pass == 0 ? sure : !sure;
             }
             const unsigned long long mask = __ballot(keep);
+            PSH_DASSERT(!keep || at + __popcll(mask & ((1ull << tid) - 1ull)) < kCandCap);
             if (keep) s_cand[at + __popcll(mask & ((1ull << tid) - 1ull))] = cnd;
             at += __popcll(mask);
           }
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(64) void idw_fine3(const float2 *__restrict__ xy, c
         if (j < chunks) {
           const bool sure = (sure_mask[j] >> lane) & 1ull, ring = (ring_mask[j] >> lane) & 1ull;
           const int slot = sure ? at_sure + __popcll(sure_mask[j] & lt) : at_ring + __popcll(ring_mask[j] & lt);
+          PSH_DASSERT(!(sure || ring) || (slot >= 0 && slot < kFineCap));  // the classified list fits its LDS block
           if (sure || ring) s_cand[slot] = c[j];
           at_sure += __popcll(sure_mask[j]);
           at_ring += __popcll(ring_mask[j]);

@@ -947,10 +947,27 @@ __host__ __device__ inline CornerKey make_corner_key(float val, unsigned addr) {
   return (static_cast<CornerKey>(bits) << 32) | addr;
 }
 
-constexpr int kSelRows = 64;  // 4 waves x 16 rows: the row unit of lk_corner_select (x kSelGroups per workgroup)
-
-constexpr int kSelCols = 62;    // columns per wave: 64 lanes minus one halo column on each side
-constexpr int kSelGroups = 4;   // 16-row groups a wave works through: a workgroup covers 62 x 256 pixels
+// A workgroup of kSelWaves waves covers 256 rows x 62 columns (kSelWide = 0: the waves stacked vertically) or 64 rows x
+// 248 columns (kSelWide = 1: side by side - a workgroup's row loads are 1 KiB of consecutive addresses instead of four
+// 256-byte pieces 64 rows apart); every wave works through kSelGroups groups of 16 rows; one reservation of output per
+// workgroup (see below).  Round 6 measured 16 waves x 1 group at the same coverage (four times the loads in flight):
+// 68 us against 54 at 4096^2, LK leg 0.596 against 0.580 ms (profiles/r06/g_select_16x1_ab.txt) - the pass is not
+// short of loads in flight.
+#ifndef PSH_SEL_WAVES
+#define PSH_SEL_WAVES 4
+#endif
+#ifndef PSH_SEL_GROUPS
+#define PSH_SEL_GROUPS 4
+#endif
+#ifndef PSH_SEL_WIDE
+#define PSH_SEL_WIDE 1
+#endif
+constexpr int kSelWaves = PSH_SEL_WAVES;
+constexpr int kSelGroups = PSH_SEL_GROUPS;   // 16-row groups a wave works through
+constexpr bool kSelWide = PSH_SEL_WIDE != 0;
+constexpr int kSelCols = 62;                 // columns per wave: 64 lanes minus one halo column on each side
+constexpr int kSelWgRows = kSelWide ? 16 * kSelGroups : 16 * kSelGroups * kSelWaves;  // rows / columns of a workgroup
+constexpr int kSelWgCols = kSelWide ? kSelCols * kSelWaves : kSelCols;
 
 // A wave owns 62 columns and works through four groups of 16 rows: for each it loads the 18 rows
 // of the response it needs (all loads in flight together), takes the left / right neighbours from
@@ -959,23 +976,23 @@ constexpr int kSelGroups = 4;   // 16-row groups a wave works through: a workgro
 // output range with ONE atomic: a single global counter takes ~90 atomics per microsecond, which is
 // what bounded the kernel while a workgroup covered 64 x 64 pixels (4096 atomics = 46 us at 4096^2,
 // whatever the kernel did otherwise).
-__global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict__ eig,
+__global__ __launch_bounds__(64 * kSelWaves) void lk_corner_select(const float *__restrict__ eig,
                                                         const float *__restrict__ clean, int m,
                                                         int n, int buffer_mask, float quality,
                                                         float *__restrict__ stats,
                                                         CornerKey *__restrict__ out, int cap,
                                                         int *__restrict__ count, Band band,
                                                         const unsigned *__restrict__ slots) {
-  constexpr int kRows = kSelRows / 4;  // rows per group
-  __shared__ unsigned long long s_mask[4][kSelGroups * kRows];
-  __shared__ int wave_count[4];
+  constexpr int kRows = 16;  // rows per group
+  __shared__ unsigned long long s_mask[kSelWaves][kSelGroups * kRows];
+  __shared__ int wave_count[kSelWaves];
   __shared__ int block_base;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // lane l LOADS column x0 - 1 + l and JUDGES the column to its right, xc = x0 + l: its own value is the
   // left neighbour, the centre and the right neighbour come from lanes l + 1 and l + 2 (DPP wave_shl
   // moves, 4 cycles each; the ds_bpermute behind __shfl_up / __shfl_down costs 24)
-  const int x = blockIdx.x * kSelCols - 1 + lane, xc = x + 1;
-  const int y_wave = (blockIdx.y * 4 + wave) * (kSelGroups * kRows);
+  const int x = (kSelWide ? (blockIdx.x * kSelWaves + wave) : blockIdx.x) * kSelCols - 1 + lane, xc = x + 1;
+  const int y_wave = (kSelWide ? blockIdx.y : (blockIdx.y * kSelWaves + wave)) * (kSelGroups * kRows);
   // slots != nullptr: the maximum response comes from the statistic slots (the response pass wrote them)
   // and workgroup (0, 0) writes it into stats[] for the ordering kernels
   const float eig_max = slots ? slots_max(slots, kSlEig) : stats[kEigMax];
@@ -1020,7 +1037,8 @@ __global__ __launch_bounds__(256) void lk_corner_select(const float *__restrict_
   if (lane == 0) wave_count[wave] = mine;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    int total = 0;
+    for (int w = 0; w < kSelWaves; ++w) total += wave_count[w];
     block_base = total > 0 ? atomicAdd(count, total) : 0;
   }
   __syncthreads();
@@ -1987,8 +2005,8 @@ int psh_lk_band_select_dev(const float *eig_dev, const float *clean_dev, int m, 
   const size_t off = static_cast<size_t>(e0) * n;
   PSH_HIP(hipMemsetAsync(count_dev, 0, sizeof(int), c.stream));
   PSH_HIP(hipMemsetAsync(keys_dev, 0, static_cast<size_t>(cap) * sizeof(psh::CornerKey), c.stream));
-  const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (ms + psh::kSelRows * psh::kSelGroups - 1) / (psh::kSelRows * psh::kSelGroups));
-  hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig_dev + off, clean_dev + off, ms, n,
+  const dim3 sgrid((n + psh::kSelWgCols - 1) / psh::kSelWgCols, (ms + psh::kSelWgRows - 1) / psh::kSelWgRows);
+  hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(64 * psh::kSelWaves), 0, c.stream, eig_dev + off, clean_dev + off, ms, n,
                      buffer_mask, static_cast<float>(quality_level), const_cast<float *>(stats_dev), keys_dev, cap, count_dev,
                      psh::Band{e0, r0 - e0, r1 - e0}, static_cast<const unsigned *>(nullptr));
   PSH_HIP(hipGetLastError());
@@ -2112,8 +2130,8 @@ int corner_candidates(const CornerWs &w, void *ws, const unsigned char *feature_
     hipLaunchKernelGGL(psh::lk_max_final, dim3(1), dim3(psh::kFinalThreads), 0, c.stream, part, w.nb, stats_dev,
                        static_cast<int>(psh::kEigMax), cnt, 1, ord, ord_ints);
   }
-  const dim3 sgrid((n + psh::kSelCols - 1) / psh::kSelCols, (m + psh::kSelRows * psh::kSelGroups - 1) / (psh::kSelRows * psh::kSelGroups));
-  hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(256), 0, c.stream, eig, clean_dev, m, n, buffer_mask,
+  const dim3 sgrid((n + psh::kSelWgCols - 1) / psh::kSelWgCols, (m + psh::kSelWgRows - 1) / psh::kSelWgRows);
+  hipLaunchKernelGGL(psh::lk_corner_select, sgrid, dim3(64 * psh::kSelWaves), 0, c.stream, eig, clean_dev, m, n, buffer_mask,
                      static_cast<float>(quality_level), stats_dev, raw, w.cap, cnt, psh::Band{0, 0, m},
                      static_cast<const unsigned *>(eig_slots));
   PSH_HIP(hipGetLastError());

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(kThreads) void pm_scatter_target(const double *__re
 __device__ __forceinline__ void pm_emit(const PmHeader *__restrict__ h, size_t n, const double *__restrict__ tw,
                                         double *__restrict__ out, unsigned pixel, unsigned rank_wet) {
   const size_t r = (n - h->wet[0]) + rank_wet, zeros_trg = n - h->wet[1];
+  PSH_DASSERT(pixel < n && rank_wet < h->wet[0] && r < n);  // a rank outside the wet block / a pixel outside the grid
   double val = r < zeros_trg ? h->z[1] : tw[r - zeros_trg];
   if (h->adjust && val < h->p) val = h->z[1];  // :108
   out[pixel] = val;
@@ -685,6 +686,7 @@ __global__ __launch_bounds__(kRefineThreads) void pm2_refine(PmHeader *h, const 
         const unsigned f = bin_i(r[k].v, z, scale) & (kFine - 1);
         const unsigned at = atomicAdd(&s_cur[f], 1u), cnt = s_cnt[f];
         r[k].tag = cnt > kSmallBin ? kCrowded : ((at << 8) | (cnt - 1u));
+        PSH_DASSERT(at < cnt && s_start[f] + at >= seg0 && s_start[f] + at < seg1);  // inside the fine bucket's segment
         rec_out[s_start[f] + at] = r[k];
       }
     }

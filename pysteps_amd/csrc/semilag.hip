@@ -710,6 +710,7 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
   const int keep_y = wvy > 0.125f ? max(slack_y - 2, 0) : (wvy < -0.125f ? min(slack_y, 2) : slack_y / 2);
   const int nox = rfl(min(max((W.ox + bx0 - keep_x) & ~3, 0), n - C::kW));  // 16-byte aligned rows
   const int noy = rfl(min(max(W.oy + by0 - keep_y, 0), m - C::kH));
+  PSH_DASSERT(nox >= 0 && nox + C::kW <= n && (nox & 3) == 0 && noy >= 0 && noy + C::kH <= m);  // the window lies in the image
   // the room a patch needs ahead of its corner samples before the next lead step (the distance the last one covered + 2);
   // a lost trajectory (NaN) asks for nothing
   const float mvx = fabsf(wvx) < 64.f ? fabsf(wvx) * move_scale + 2.f : 2.f, mvy = fabsf(wvy) < 64.f ? fabsf(wvy) * move_scale + 2.f : 2.f;
@@ -809,8 +810,10 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
     mx = max(mx, static_cast<unsigned>(dxw[j]));
     my = max(my, static_cast<unsigned>(dy[j]));
   }
-  const bool ok = mx <= static_cast<unsigned>(C::kW - 2) && my <= static_cast<unsigned>(C::kH - 2);
-  if (__builtin_amdgcn_ballot_w64(ok) == __builtin_amdgcn_ballot_w64(true)) {
+  // (two ballots and a scalar AND: the compiler turns the ballot of `a && b` into a select and a second compare)
+  const unsigned long long okx = __builtin_amdgcn_ballot_w64(mx <= static_cast<unsigned>(C::kW - 2));
+  const unsigned long long oky = __builtin_amdgcn_ballot_w64(my <= static_cast<unsigned>(C::kH - 2));
+  if ((okx & oky) == __builtin_amdgcn_ballot_w64(true)) {
     win_count(W, 0);
     f32x2 t[kWinRows][4];
     float rp[kWinRows][4];
@@ -818,6 +821,9 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
     for (int j = 0; j < kWinRows; ++j) {
       // texel index in the window (one v_mad_u32_u24), scaled to the 8-byte {u,v} texels and the 4-byte field texels
       const unsigned tx = __umul24(static_cast<unsigned>(dy[j]), static_cast<unsigned>(C::kW)) + static_cast<unsigned>(dxw[j]);
+      // fast path only: all four taps of the pixel inside the window's planes
+      PSH_DASSERT(static_cast<unsigned>(dxw[j]) <= static_cast<unsigned>(C::kW - 2) && static_cast<unsigned>(dy[j]) <= static_cast<unsigned>(C::kH - 2) &&
+                  tx + C::kW + 1 < static_cast<unsigned>(C::kW * C::kH));
       const unsigned a = (tx << 3) + W.uv;
       asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:%c5\n\t"
                    "ds_read_b64 %3, %4 offset:%c6"
@@ -967,6 +973,7 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
     }
     if (tile < 0) break;  // the whole workgroup
     if (PERSIST && threadIdx.x == 0) next = win_next_slot(queue, home, tiles_per_xcd, order);  // in flight behind this tile
+    PSH_DASSERT(tile < n_tiles);  // the order table names tiles of this launch's grid
     const int xt = (tile % tiles_x) * kTileX + lane;
     const int yt = row0 + (tile / tiles_x) * C::kTileY + static_cast<int>(threadIdx.x / kTileX) * kWinRows;
     const int x = min(xt, n - 1);

@@ -21,6 +21,7 @@ dst = os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 for name in ("bench.json", "pytest_gpu.txt", "gaps.txt", "lk_timeline.txt", "fft_quick.json", "other_shapes.jsonl",
              "bench_members_world1.json", "bench_members_advection_world1.json", "bench_config5_world1.json",
+             "bench_config5_banded_world1.json", "pytest_window_forced.txt", "debug_build.txt",
              "steps_quick.jsonl", "rng_quick.json", "ensemble_quick.txt", "cv2_probe.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (prefix, name)))
