@@ -59,6 +59,9 @@ int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hb
  * 1 one pre-pass per 16x16 tile;
  * "members_variant": members per thread of the member-batched step on packed planes: 2 (default: the two
  * trajectories' gathers overlap) or 1;
+ * "lk_fused_nms": 1 = the resident dense Lucas-Kanade estimate computes the Shi-Tomasi response, the 3x3 maxima and the
+ * candidate list in ONE pass without writing the response plane (lk_corner_response_nms), 0 (default) = response pass +
+ * selection pass: same corners bit for bit; the fused pass measured slower;
  * "trim_cache": release the device blocks cached by psh_free (value ignored) */
 int psh_set_option(const char *key, int value);
 

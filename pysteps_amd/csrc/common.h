@@ -128,6 +128,7 @@ bool semilag_window_shape(int m, int n);
 int semilag_kernel_choice(int m, int n, int T, int n_iter, int order, bool has_field);
 void set_semilag_variant(int v);
 void set_members_variant(int v);
+void set_lk_fused_nms(int v);
 hipError_t spline_prefilter(const float *precip, float *coef, float *tmp, int m, int n, hipStream_t stream, int kind = 0,
                             int npad = 0, int pad_edge = 0, float cval = 0.f, int order = 3);
 
@@ -220,7 +221,8 @@ hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw
                                const float *eig_max_dev, float quality, int n, double min_distance,
                                int max_corners, void *ws_dev, float *points_dev, int *npoints_dev,
                                hipStream_t stream, int (*before_walk)(void *), void *before_walk_arg,
-                               bool ws_is_cleared);
+                               bool ws_is_cleared, const unsigned *eig_slots_dev = nullptr, int count_bias = 0,
+                               float *eig_max_out_dev = nullptr);
 size_t corner_order_clear_bytes();  // leading bytes of the workspace that have to be zero (histogram, header)
 size_t corner_order_walk_stats_offset();  // byte offset of the int[3] walk statistics inside the workspace
 hipError_t launch_vectors_finish(const double *pool_xy_dev, const double *pool_uv_dev,

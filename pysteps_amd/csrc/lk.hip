@@ -49,7 +49,8 @@ constexpr int kRedBlocks = 1024;
 // between orders the two.  Floats are kept as order-preserving unsigned keys; minima as the complement
 // of the key, so that every word is a maximum and zero-filled memory is the identity.
 constexpr int kSlots = 64;
-enum SlotKind : int { kSlMin = 0, kSlNan, kSlMaxAll, kSlMinFeat, kSlMaxFeat, kSlEig, kSlotKinds };
+// (kSlCand: word 0 = number of corner candidates, word 1 = workgroups of the fused response pass that are done)
+enum SlotKind : int { kSlMin = 0, kSlNan, kSlMaxAll, kSlMinFeat, kSlMaxFeat, kSlEig, kSlCand, kSlotKinds };
 constexpr size_t kSlotBytes = sizeof(unsigned) * kSlots * kSlotKinds;  // per frame; cleared before the first pass
 
 __device__ __forceinline__ unsigned float_key(float f) {
@@ -917,6 +918,185 @@ __global__ __launch_bounds__(256) void lk_corner_response_cols(
   }
 }
 
+// ---- response + 3x3 non-maximum suppression + compaction in ONE pass (the resident estimate) ---------------
+// lk_corner_response_cols writes the response plane (64 MiB at 4096^2) and lk_corner_select reads it back to find
+// the local maxima above quality x maximum - 70 + 50 us of the estimate's critical path.  The 3x3 test does not
+// need the maximum: max3x3(threshold(e)) == e and e > thr  <=>  e is a 3x3 maximum and e > thr (the threshold is
+// monotone).  So the column walk judges its own rows - the last three response rows live in registers, the
+// horizontal neighbours come from the adjacent lanes -, emits every positive 3x3 maximum that the NaN buffer
+// allows as a candidate key, and the ordering kernels, which bin the keys by value anyway, drop what is not above
+// the threshold (key_range: strictly above).  The response plane is never written.
+//  * geometry: a wave computes the response for crn_cols(BS) columns and ROWS + 2 rows and judges the inner
+//    crn_cols - 2 columns and ROWS rows (strip stride crn_cols - 2: 3.5 % more columns, 6 % more rows);
+//  * weak maxima are dropped on the way: a candidate has to exceed quality x (the largest response the wave knows of:
+//    what the finished workgroups have published in the slots when it starts, and its own strip's maximum, folded
+//    over the lanes every 8 rows) - a lower bound of the final threshold, so nothing that counts is lost;
+//  * no counter in the common case: wave w of the launch owns kNmsKeys slots of the output, fills them with its keys
+//    and ZERO keys (which every consumer ignores: they lie below any key range) - the consumers read
+//    gridDim x 4 x kNmsKeys slots (+ the overflow count: a wave with more candidates appends the rest behind the fixed
+//    part through the counter word of the frame's statistic slots);
+//  * the maximum goes through the kSlEig slots as before; the ordering kernels fold them themselves
+//    (lk_sparse.hip load_eig_max) and corner_order writes stats[kEigMax] (lk_corner_select did that).
+constexpr int kNmsKeys = 64;  // output slots per wave
+
+using CornerKeyT = unsigned long long;
+__device__ __forceinline__ CornerKeyT nms_key(float val, unsigned addr) {
+  return (static_cast<CornerKeyT>(__float_as_uint(val)) << 32) | addr;
+}
+__device__ __forceinline__ float prev_lane_f(float v) {  // lane i gets lane i - 1's value (lane 0: 0)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+
+template <int BS, int ROWS>
+__global__ __launch_bounds__(256) void lk_corner_response_nms(
+    const unsigned char *__restrict__ u8, const float *__restrict__ clean, int m, int n, int buffer_mask,
+    const float *__restrict__ stats, float quality, CornerKeyT *__restrict__ out, int cap, Band band,
+    unsigned *__restrict__ slots, int *__restrict__ zero_b, int count_b) {
+  constexpr int r = BS / 2, H = r + 1, W = crn_cols(BS);
+  if (blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i < count_b; i += 256) zero_b[i] = 0;  // scratch of the ordering kernels
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int *over_count = reinterpret_cast<int *>(slots + kSlCand * kSlots);
+  const int fixed_total = static_cast<int>(gridDim.x * gridDim.y) * 4 * kNmsKeys;  // slots owned by the waves
+  const int my_slots = (static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * kNmsKeys;
+  const int x0 = blockIdx.x * (W - 2) - 1;            // first response column of the strip
+  const int yj = (blockIdx.y * 4 + wave) * ROWS;       // first JUDGED row of the wave
+  const int yb = yj - 1;                               // first response row
+  float best = 0.f;
+  // what the finished workgroups know of the maximum (the slots hold order-preserving keys; zero = nothing yet)
+  float known = fmaxf(slots_max(slots, kSlEig), 0.f);
+  int held = 0;  // keys this wave has written to its slots (uniform)
+  if (yj < m) {
+    const float s = 1.0f / (4.0f * static_cast<float>(BS) * 255.0f), s2 = 2.f * s;
+    const int xl = x0 - H + lane;  // column this lane loads; its products belong to column xl + 1
+    const bool neg_x = walk_mirrored(xl + 1, n);
+    const float sx = neg_x ? -s : s, sx2 = neg_x ? -s2 : s2;
+    const unsigned char *col = u8 + reflect101(xl, n);
+    const bool few_rows = m < 2 * H + 4;
+    auto row_of = [&](int y) -> int {
+      if (few_rows) return reflect101(y, m);
+      y = y < 0 ? -y : y;
+      return y >= m ? 2 * m - 2 - y : y;
+    };
+    auto load_row = [&](int i) -> int { return col[static_cast<size_t>(row_of(yb - H + i)) * n]; };
+    auto row_terms = [&](int raw, float &hd, float &g) {
+      const float a = static_cast<float>(raw);
+      const float c = next_lane_f(a);
+      const float b = next_lane_f(c);
+      hd = b - a;
+      g = (a + b) * s + c * s2;
+    };
+    const bool any_nan = stats[kNanCount] > 0.f;
+    const int x = x0 + lane;  // response column of the lane
+    const bool in_image_col = lane < W && x >= 0 && x < n;
+    const bool judged_col = lane >= 1 && lane < W - 1 && x >= 1 && x < n - 1;
+    const int rows_e = min(ROWS + 2, m - yb);  // response rows yb .. yb + rows_e - 1 (row m is never needed)
+    const int last_p = rows_e + BS - 1;
+    double ring[3][BS], V[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < BS; ++j) ring[0][j] = ring[1][j] = ring[2][j] = 0.0;
+    int raw[BS];
+    const int raw0 = load_row(0), raw1 = load_row(1);
+#pragma unroll
+    for (int j = 0; j < BS; ++j) raw[j] = load_row(2 + j);
+    float hd_m, hd_0, g_m, g_0;
+    row_terms(raw0, hd_m, g_m);
+    row_terms(raw1, hd_0, g_0);
+    // the two response rows above the newest one: value, max(left, right), max of the three
+    float c1 = 0.f, h1 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int base = 1; base <= last_p; base += BS) {
+      int nxt[BS];
+#pragma unroll
+      for (int j = 0; j < BS; ++j) nxt[j] = load_row(base + BS + 1 + j);
+#pragma unroll
+      for (int j = 0; j < BS; ++j) {
+        const int p = base + j;
+        if (p > last_p) break;  // (uniform)
+        constexpr int kRingBase = 1;
+        const int slot = (kRingBase + j) % BS;
+        float hd_p, g_p;
+        row_terms(raw[j], hd_p, g_p);
+        const float dx = (hd_m + hd_p) * sx + hd_0 * sx2;
+        float dy = g_p - g_m;
+        const int y_seq = yb - H + p;
+        const bool row_mirrored = few_rows ? walk_mirrored(y_seq, m) : (y_seq < 0 || y_seq >= m);
+        const unsigned row_sign = row_mirrored ? 0x80000000u : 0u;
+        dy = __uint_as_float(__float_as_uint(dy) ^ row_sign);
+        const double pxx = static_cast<double>(dx * dx), pxy = static_cast<double>(dx * dy);
+        const double pyy = static_cast<double>(dy * dy);
+        V[0] += pxx - ring[0][slot];
+        V[1] += pxy - ring[1][slot];
+        V[2] += pyy - ring[2][slot];
+        ring[0][slot] = pxx;
+        ring[1][slot] = pxy;
+        ring[2][slot] = pyy;
+        hd_m = hd_0;
+        hd_0 = hd_p;
+        g_m = g_0;
+        g_0 = g_p;
+        if (p >= BS) {
+          double w0 = V[0], w1 = V[1], w2 = V[2];
+          double q0 = V[0], q1 = V[1], q2 = V[2];
+#pragma unroll
+          for (int c = 0; c < 2 * r; ++c) {
+            q0 = next_lane_d(q0);
+            q1 = next_lane_d(q1);
+            q2 = next_lane_d(q2);
+            w0 += q0;
+            w1 += q1;
+            w2 += q2;
+          }
+          const int y = yb + p - BS;  // response row (>= -1)
+          const float a = static_cast<float>(w0) * 0.5f, b = static_cast<float>(w1);
+          const float c = static_cast<float>(w2) * 0.5f;
+          const float e = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+          if (in_image_col && y >= 0 && y >= band.lo && y < band.hi && px_allowed(clean, m, n, x, y, buffer_mask, any_nan))
+            best = fmaxf(best, fmaxf(e, 0.f));
+          if ((p & 7) == 0) known = fmaxf(known, wave_max(best));  // (uniform) the strip's maximum so far
+          // the row's horizontal neighbours, and the judgement of the row ABOVE it (y - 1) now that its three rows are here
+          const float h0 = fmaxf(prev_lane_f(e), next_lane_f(e)), t0 = fmaxf(e, h0);
+          const int yr = y - 1;
+          if (p >= BS + 2 && yr >= yj) {  // (uniform) response rows y - 2, y - 1, y of this wave exist
+            bool keep = judged_col && yr >= 1 && yr < m - 1 && yr >= band.lo && yr < band.hi;
+            keep = keep && c1 > 0.f && c1 > known * quality;          // (> the final threshold is the ordering kernels' test)
+            keep = keep && !(fmaxf(h1, fmaxf(t2, t0)) > c1);          // the 3x3 maximum
+            keep = keep && px_allowed(clean, m, n, x, yr, buffer_mask, any_nan);
+            const unsigned long long mask = __ballot(keep);
+            if (mask != 0ull) {  // (uniform)
+              const int cnt = __popcll(mask);
+              int at = held + __popcll(mask & ((1ull << lane) - 1ull));
+              if (held + cnt > kNmsKeys) {  // (uniform, rare) what does not fit the wave's slots goes behind the fixed part
+                int base = 0;
+                const int spill = held + cnt - max(held, kNmsKeys);
+                if (lane == 0) base = atomicAdd(over_count, spill);
+                base = __shfl(base, 0);
+                if (at >= kNmsKeys) at = fixed_total + base + (at - max(held, kNmsKeys)) - my_slots;
+              }
+              if (keep && my_slots + at < cap) out[my_slots + at] = nms_key(c1, static_cast<unsigned>(yr + band.y_org) * n + x);
+              held += cnt;
+            }
+          }
+          t2 = t1;
+          t1 = t0;
+          h1 = h0;
+          c1 = e;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < BS; ++j) raw[j] = nxt[j];
+    }
+  }
+  // the rest of the wave's slots: zero keys
+  for (int i = min(held, kNmsKeys) + lane; i < kNmsKeys; i += 64)
+    if (my_slots + i < cap) out[my_slots + i] = 0ull;
+  best = wave_max(best);
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    slot_max(slots, kSlEig, blockIdx.y * gridDim.x + blockIdx.x, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
 // (zero_a / zero_b: counters and scratch the NEXT kernels expect cleared - done here, by a kernel
 // that is a single idle-ish block anyway, instead of one 5 us fill launch each)
 __global__ __launch_bounds__(kFinalThreads) void lk_max_final(const float *__restrict__ partial,
@@ -1725,6 +1905,29 @@ dim3 lk_response_grid(int m, int n, int block_size) {
   const int w = crn_cols(block_size), rows = 4 * kCrnRows;
   return dim3((n + w - 1) / w, (m + rows - 1) / rows);
 }
+dim3 lk_response_nms_grid(int m, int n, int block_size) {
+  const int w = crn_cols(block_size) - 2, rows = 4 * kCrnRows;
+  return dim3((n + w - 1) / w, (m + rows - 1) / rows);
+}
+// slots of the candidate list the waves of that grid own (the overflow count of the slots' counter word is added to it)
+int lk_response_nms_fixed_keys(dim3 grid) { return static_cast<int>(grid.x * grid.y) * 4 * kNmsKeys; }
+void launch_lk_response_nms(dim3 grid, hipStream_t stream, int block_size, const unsigned char *u8, const float *clean, int m,
+                            int n, int buffer_mask, const float *stats, float quality, CornerKeyT *out, int cap, Band band,
+                            unsigned *slots, int *zero_b, int count_b) {
+#define PSH_NMS_LAUNCH(BS)                                                                                             \
+  hipLaunchKernelGGL((lk_corner_response_nms<BS, kCrnRows>), grid, dim3(256), 0, stream, u8, clean, m, n, buffer_mask, \
+                     stats, quality, out, cap, band, slots, zero_b, count_b)
+  if (block_size == 1) {
+    PSH_NMS_LAUNCH(1);
+  } else if (block_size == 3) {
+    PSH_NMS_LAUNCH(3);
+  } else if (block_size == 5) {
+    PSH_NMS_LAUNCH(5);
+  } else {
+    PSH_NMS_LAUNCH(7);
+  }
+#undef PSH_NMS_LAUNCH
+}
 // slots != nullptr: the maximum goes to the statistic slots (and zero_a / zero_b are cleared by the first
 // workgroup); otherwise one partial maximum per workgroup goes to part[]
 void launch_lk_response(dim3 grid, hipStream_t stream, int block_size, const unsigned char *u8, const float *clean, int m,
@@ -2087,6 +2290,22 @@ struct GreedyGrid {
 // response image, its maximum, candidate keys (threshold + 3x3 maxima) of one frame: queued on the
 // library stream into the block `ws` (layout below); lock held by the caller
 namespace {
+// psh_set_option("lk_fused_nms", v) / PYSTEPS_HIP_LK_FUSED_NMS: 1 = the resident estimate takes lk_corner_response_nms
+// (response + 3x3 maxima + compaction in one pass).  Off by default: on one box, library unchanged, the LK leg measured
+// 0.598 ms with it against 0.580 ms without (profiles/r06/j_fused_nms_ab.txt) - the response pass is bound by VALU issue
+// (0.88), so the judging, the 10 % of extra strip overlap and the lost occupancy (100 against 90 registers) cost more
+// than the response plane's round trip through the memory-side cache saves.  Bit-identical corners either way.
+static int g_lk_fused_nms = [] {
+  const char *e = std::getenv("PYSTEPS_HIP_LK_FUSED_NMS");
+  return e ? std::atoi(e) : 0;
+}();
+}  // namespace
+extern "C++" {
+namespace psh {
+void set_lk_fused_nms(int v) { g_lk_fused_nms = v; }
+}  // namespace psh
+}
+namespace {
 struct CornerWs {
   size_t off_part, off_cnt, off_raw, off_ord, bytes;
   int cap, nb;
@@ -2097,6 +2316,8 @@ struct CornerWs {
     nb = rgrid.x * rgrid.y;
     // every pixel can be a candidate (plateaus of equal response pass the 3x3 test): no overflow
     cap = static_cast<int>(std::min<size_t>(npx, 0x7fffffffu));
+    // ... and the fused response pass gives every wave of its grid kNmsKeys slots (tiny images: more slots than pixels)
+    cap = std::max(cap, psh::lk_response_nms_fixed_keys(psh::lk_response_nms_grid(m, n, block_size)));
     auto up = [](size_t v) { return (v + 255) & ~static_cast<size_t>(255); };
     off_part = up(npx * sizeof(float));
     off_cnt = up(off_part + static_cast<size_t>(nb) * sizeof(float));
@@ -2109,9 +2330,11 @@ struct CornerWs {
 // eig_slots != nullptr (cleared statistic slots of the frame): the maximum response travels through
 // them - the response pass clears the candidate counter and the ordering scratch, the selection pass reads
 // the maximum back: two launches; otherwise lk_max_final sits in between
+// (count_dev_out: where the number of candidates lives - the workspace's counter, or, for the fused pass of the
+// resident estimate, the counter word of the frame's statistic slots)
 int corner_candidates(const CornerWs &w, void *ws, const unsigned char *feature_u8_dev, const float *clean_dev,
                       float *stats_dev, int m, int n, int block_size, int buffer_mask, double quality_level,
-                      unsigned *eig_slots = nullptr) {
+                      unsigned *eig_slots = nullptr, const int **count_dev_out = nullptr, int *count_bias_out = nullptr) {
   psh::Context &c = ctx();
   char *base = static_cast<char *>(ws);
   float *eig = reinterpret_cast<float *>(base);
@@ -2120,6 +2343,17 @@ int corner_candidates(const CornerWs &w, void *ws, const unsigned char *feature_
   psh::CornerKey *raw = reinterpret_cast<psh::CornerKey *>(base + w.off_raw);
   int *ord = reinterpret_cast<int *>(base + w.off_ord);
   const int ord_ints = static_cast<int>(psh::corner_order_clear_bytes() / sizeof(int));
+  if (count_dev_out) *count_dev_out = cnt;
+  if (eig_slots && count_dev_out && count_bias_out && g_lk_fused_nms) {
+    // response + 3x3 maxima + compaction in one pass: no response plane, no selection pass (lk_corner_response_nms)
+    const dim3 ngrid = psh::lk_response_nms_grid(m, n, block_size);
+    psh::launch_lk_response_nms(ngrid, c.stream, block_size, feature_u8_dev, clean_dev, m, n, buffer_mask, stats_dev,
+                                static_cast<float>(quality_level), raw, w.cap, psh::Band{0, 0, m}, eig_slots, ord, ord_ints);
+    *count_dev_out = reinterpret_cast<const int *>(eig_slots + psh::kSlCand * psh::kSlots);  // the overflow count
+    *count_bias_out = psh::lk_response_nms_fixed_keys(ngrid);
+    PSH_HIP(hipGetLastError());
+    return PSH_OK;
+  }
   if (eig_slots) {
     psh::launch_lk_response(w.rgrid, c.stream, block_size, feature_u8_dev, clean_dev, m, n, buffer_mask, stats_dev, eig,
                             part, psh::Band{0, 0, m}, eig_slots, cnt, 1, ord, ord_ints);
@@ -2168,14 +2402,17 @@ int lk_corners_resident(const unsigned char *feature_u8_dev, const float *clean_
   const CornerWs w(m, n, block_size);
   void *ws = nullptr;
   if (int rc = psh_malloc(&ws, w.bytes)) return rc;  // stream-ordered caching allocator
+  const int *count_dev = nullptr;
+  int count_bias = 0;
   int rc = corner_candidates(w, ws, feature_u8_dev, clean_dev, stats_dev, m, n, block_size, buffer_mask, quality_level,
-                             slots_cleared);
+                             slots_cleared, &count_dev, &count_bias);
   if (rc == PSH_OK) {
     char *base = static_cast<char *>(ws);
     const hipError_t e = launch_corner_order(
-        reinterpret_cast<const CornerKey *>(base + w.off_raw), reinterpret_cast<const int *>(base + w.off_cnt), w.cap,
+        reinterpret_cast<const CornerKey *>(base + w.off_raw), count_dev, w.cap,
         stats_dev + kEigMax, static_cast<float>(quality_level), n, min_distance, max_corners, base + w.off_ord,
-        points_dev, npoints_dev, c.stream, before_walk, before_walk_arg, /*ws_is_cleared=*/true);
+        points_dev, npoints_dev, c.stream, before_walk, before_walk_arg, /*ws_is_cleared=*/true,
+        count_bias ? slots_cleared + psh::kSlEig * psh::kSlots : nullptr, count_bias, count_bias ? stats_dev + kEigMax : nullptr);
     if (e != hipSuccess) rc = fail(PSH_EHIP, "corner_order launch failed: %s", hipGetErrorString(e));
     if (rc == PSH_OK && walk_stats_host) {
       if (hipMemcpyAsync(walk_stats_host, base + w.off_ord + corner_order_walk_stats_offset(), 13 * sizeof(int),

@@ -78,13 +78,28 @@ __device__ __forceinline__ int next_pow2(int v) {
   return p;
 }
 
-// The keys of a frame's candidates lie in [key_lo, key_hi): every response exceeds
-// thr = max * quality (lk_corner_select) and none exceeds the maximum.
+// The keys of a frame's candidates that count lie in [key_lo, key_hi): responses above thr = max * quality
+// (lk_corner_select sends only those; lk_corner_response_nms also sends weaker 3x3 maxima) up to the maximum.
 __device__ __forceinline__ void key_range(float eig_max, float quality, CornerKey &key_lo, CornerKey &key_hi) {
   const float top = fmaxf(eig_max, 0.f);
   const float thr = fmaxf(top * quality, 0.f);
-  key_lo = static_cast<CornerKey>(__float_as_uint(thr)) << 32;
+  // STRICTLY above the threshold (THRESH_TOZERO keeps values > thr; responses are positive, so the next bit pattern is
+  // the next value): lk_corner_select sends nothing else, the fused response pass sends every positive 3x3 maximum
+  key_lo = (static_cast<CornerKey>(__float_as_uint(thr)) + 1ull) << 32;
   key_hi = (static_cast<CornerKey>(__float_as_uint(top)) + 1ull) << 32;
+}
+// The maximum response: from stats[] (eig_max), or - the fused response pass of the resident estimate, which has no
+// finishing step - folded here from the 64 words of the frame's statistic slots (eig_slots: order-preserving keys,
+// lk.hip slot_max); every wave does the fold itself.
+__device__ __forceinline__ float load_eig_max(const float *eig_max, const unsigned *eig_slots) {
+  if (eig_slots == nullptr) return *eig_max;
+  unsigned v = eig_slots[threadIdx.x & 63];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned o = static_cast<unsigned>(__shfl_xor(static_cast<int>(v), d));
+    v = o > v ? o : v;
+  }
+  return __uint_as_float((v >> 31) ? (v & 0x7fffffffu) : ~v);
 }
 __device__ __forceinline__ int bin_shift(CornerKey rlo, CornerKey rhi) {
   int sh = 0;
@@ -146,13 +161,14 @@ constexpr int kPreThreads = 256;
 __global__ __launch_bounds__(kPreThreads) void corner_hist(const CornerKey *__restrict__ raw,
                                                            const int *__restrict__ raw_count, int cap,
                                                            const float *__restrict__ eig_max, float quality,
-                                                           int *__restrict__ hist) {
+                                                           int *__restrict__ hist, const unsigned *__restrict__ eig_slots,
+                                                           int count_bias) {
   __shared__ int s_hist[kOrdBins];
   for (int i = threadIdx.x; i < kOrdBins; i += kPreThreads) s_hist[i] = 0;
   __syncthreads();
-  const int nkeys = min(max(*raw_count, 0), cap);
+  const int nkeys = min(max(*raw_count, 0) + count_bias, cap);
   CornerKey key_lo, key_hi;
-  key_range(*eig_max, quality, key_lo, key_hi);
+  key_range(load_eig_max(eig_max, eig_slots), quality, key_lo, key_hi);
   const int sh = bin_shift(key_lo, key_hi);
   for (int i = blockIdx.x * kPreThreads + threadIdx.x; i < nkeys; i += gridDim.x * kPreThreads) {
     const CornerKey k = raw[i];
@@ -168,13 +184,14 @@ __global__ __launch_bounds__(kPreThreads) void corner_gather(const CornerKey *__
                                                              const float *__restrict__ eig_max, float quality,
                                                              const int *__restrict__ hist,
                                                              CornerKey *__restrict__ head,
-                                                             OrderHeader *__restrict__ hdr, int ccap) {
+                                                             OrderHeader *__restrict__ hdr, int ccap,
+                                                             const unsigned *__restrict__ eig_slots, int count_bias) {
   __shared__ int s_suffix[kOrdBins + 1];  // candidates in bins >= c
   __shared__ int s_cut[kHeadSegs + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nkeys = min(max(*raw_count, 0), cap);
+  const int nkeys = min(max(*raw_count, 0) + count_bias, cap);
   CornerKey key_lo, key_hi;
-  key_range(*eig_max, quality, key_lo, key_hi);
+  key_range(load_eig_max(eig_max, eig_slots), quality, key_lo, key_hi);
   const int sh = bin_shift(key_lo, key_hi);
   // ---- suffix counts of the histogram (every workgroup repeats this small computation) ----------
   if (wave == 0) {
@@ -311,7 +328,9 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
                                                             const CornerKey *__restrict__ head,
                                                             OrderHeader *__restrict__ hdr, int n, int cell,
                                                             unsigned md2_ceil, int use_grid, int max_corners, int ccap,
-                                                            float2 *__restrict__ points, int *__restrict__ npoints) {
+                                                            float2 *__restrict__ points, int *__restrict__ npoints,
+                                                            const unsigned *__restrict__ eig_slots, int count_bias,
+                                                            float *__restrict__ eig_max_out) {
   __shared__ CornerKey s_keys[kChunkCap];
   __shared__ int s_hist[kOrdBins];
   // the block's own candidates by cell (fixed point of the acceptance among the survivors)
@@ -338,9 +357,11 @@ __global__ __launch_bounds__(kOrdThreads) void corner_order(const CornerKey *__r
   __shared__ int s_wcount[kOrdWaves];
   __shared__ int s_fill, s_over, s_fits, s_nsurv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nkeys = min(max(*raw_count, 0), cap);
+  const int nkeys = min(max(*raw_count, 0) + count_bias, cap);
   CornerKey key_lo, upper;  // candidates not yet walked lie in [key_lo, upper)
-  key_range(*eig_max, quality, key_lo, upper);
+  const float top_response = load_eig_max(eig_max, eig_slots);
+  if (eig_max_out != nullptr && tid == 0) *eig_max_out = top_response;  // (the fused response pass leaves stats[] to this kernel)
+  key_range(top_response, quality, key_lo, upper);
   for (int i = tid; i < kHashSlots; i += kOrdThreads) s_hhead[i] = -1;
   int nacc = 0;
   int remaining = nkeys;
@@ -948,7 +969,7 @@ hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw
                                const float *eig_max_dev, float quality, int n, double min_distance,
                                int max_corners, void *ws_dev, float *points_dev, int *npoints_dev,
                                hipStream_t stream, int (*before_walk)(void *), void *before_walk_arg,
-                               bool ws_is_cleared) {
+                               bool ws_is_cleared, const unsigned *eig_slots_dev, int count_bias, float *eig_max_out_dev) {
   const int cell = static_cast<int>(std::lrint(min_distance)) > 1 ? static_cast<int>(std::lrint(min_distance)) : 1;
   const double md2 = std::ceil(min_distance * min_distance);
   const unsigned md2_ceil = md2 >= 2147483647.0 ? 2147483647u : static_cast<unsigned>(md2);
@@ -963,18 +984,18 @@ hipError_t launch_corner_order(const unsigned long long *raw_dev, const int *raw
   // the list is streamed by up to 128 workgroups (its length is only known on the device)
   const int groups = std::max(1, std::min(128, (cap + 4 * kPreThreads - 1) / (4 * kPreThreads)));
   hipLaunchKernelGGL(corner_hist, dim3(groups), dim3(kPreThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
-                     quality, hist);
+                     quality, hist, eig_slots_dev, count_bias);
   // candidates ordered at a time: the walk rarely needs more than ~2 x max_corners of them, and a chunk
   // that covers a narrower key range is ordered faster (finer bins of the counting sort)
   int ccap = 1024;
   while (ccap < 2 * max_corners && ccap < kChunkCap) ccap <<= 1;
   hipLaunchKernelGGL(corner_gather, dim3(groups), dim3(kPreThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
-                     quality, hist, head, hdr, ccap);
+                     quality, hist, head, hdr, ccap, eig_slots_dev, count_bias);
   // the walk is a single workgroup: whatever the caller can run beside it is forked off here
   if (before_walk != nullptr && before_walk(before_walk_arg) != 0) return hipErrorUnknown;
   hipLaunchKernelGGL(corner_order, dim3(1), dim3(kOrdThreads), 0, stream, raw_dev, raw_count_dev, cap, eig_max_dev,
                      quality, head, hdr, n, cell, md2_ceil, min_distance >= 1.0 ? 1 : 0, max_corners, ccap,
-                     reinterpret_cast<float2 *>(points_dev), npoints_dev);
+                     reinterpret_cast<float2 *>(points_dev), npoints_dev, eig_slots_dev, count_bias, eig_max_out_dev);
   return hipGetLastError();
 }
 

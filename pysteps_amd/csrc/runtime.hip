@@ -272,6 +272,11 @@ int psh_set_option(const char *key, int value) {
     psh::set_idw_variant(value);
     return PSH_OK;
   }
+  if (std::strcmp(key, "lk_fused_nms") == 0) {
+    if (value != 0 && value != 1) return fail(PSH_EINVAL, "lk_fused_nms must be 0 (response + selection passes, default) or 1 (one fused pass)");
+    psh::set_lk_fused_nms(value);
+    return PSH_OK;
+  }
   if (std::strcmp(key, "trim_cache") == 0) {  // give the cached device blocks back to the driver
     psh::Context &c = ctx();
     std::lock_guard<std::recursive_mutex> lock(c.mu);
