@@ -274,6 +274,27 @@ int psh_idw_host(const double *xy, const double *values, int L, int m, int n, do
 int psh_rbf_eval_dev(const double *xy_dev, const double *weights_dev, int N, int m, int n, double x0, double dx,
                      double y0, double dy, int function, double epsilon, double *out_dev);
 
+/* ---- scale-space blob detection: the `fd_method="blob"` feature detector (csrc/blob.hip) ---------------------- *
+ * pysteps/feature/blob.py:32-140 -> scikit-image blob_log / blob_dog [third party] -> scipy.ndimage.gaussian_laplace /
+ * gaussian_filter per scale, a 3 x 3 x 3 maximum_filter over the scale cube, peak mask.  SciPy's arithmetic operation
+ * by operation (correlate1d's symmetric form in double, stored in the image's dtype after every pass, mode "reflect";
+ * maximum_filter1d's ring of (value, death) pairs, which decides what the filter returns next to NaNs).
+ *  psh_blob_cube_dev    image (m, n) float32 / float64 -> cube (K, m, n) float64:
+ *      method 0 (LoG): cube[k] = -gaussian_laplace(image, sigma_k) * sigma_k^2,  K = nsig
+ *      method 1 (DoG): cube[k] = (G(sigma_k) - G(sigma_k+1)) image * sigma_k,    K = nsig - 1
+ *      radius_host[k] = int(4 sigma_k + 0.5); weights_host: per scale 2 (radius + 1) doubles - centre and distances
+ *      1 .. radius of the smoothing kernel, then of the second-derivative kernel (scipy's _gaussian_kernel1d, evaluated
+ *      by the caller with NumPy like SciPy does).  Asynchronous.
+ *  psh_blob_peaks_dev   skimage peak_local_max(cube, threshold_abs, footprint ones(3,3,3), exclude_border False) as
+ *      blob_log calls it: coords_host (capacity, 3) int32 (row, column, scale index) and their values, unordered;
+ *      *count_host = number of peaks (above capacity: call again with more room).  Waits.
+ *  psh_blob_gather_dev  values of one (m, n) float64 plane at `count` (row, column) pixels.  Waits. */
+int psh_blob_cube_dev(const void *image_dev, int image_is_f32, int m, int n, int method, const double *sigmas_host, int nsig,
+                      const int *radius_host, const double *weights_host, double *cube_dev);
+int psh_blob_peaks_dev(const double *cube_dev, int K, int m, int n, double threshold, int capacity, int *coords_host,
+                       double *values_host, int *count_host);
+int psh_blob_gather_dev(const double *plane_dev, int m, int n, const int *yx_host, int count, double *values_host);
+
 /* ---- dense Lucas-Kanade: image front end ----------------------------------- *
  * The NumPy + OpenCV stages of pysteps/motion/lucaskanade.py:205-242, per frame /
  * frame pair.  OpenCV is a third-party dependency of the reference (not in its
@@ -517,6 +538,13 @@ int psh_order_statistic_dev(const double *field_dev, size_t count, size_t index,
 int psh_probmatch_plan_create(const double *target_dev, size_t count, void **plan_out);
 int psh_probmatch_plan_destroy(void *plan);
 int psh_probmatch_planned_dev(const void *plan, const double *initial_dev, size_t count, double *out_dev, int *status_dev);
+/* psh_steps_mask_dev(field, count, grey, keep, min_key) followed by psh_probmatch_planned_dev(plan, field, count, out,
+ * status_dev) (nowcasts/steps.py:1221-1240, then :1198-1201) with the mask applied by the matching's own first sweep over
+ * the field (the one that takes its statistics): one pass less, identical results; field_dev holds the masked field
+ * afterwards; out_dev must be another array */
+int psh_steps_mask_probmatch_dev(const void *plan, double *field_dev, size_t count, const double *grey_mask_dev,
+                                 const unsigned char *keep_mask_dev, const unsigned long long *min_key_dev,
+                                 double *out_dev, int *status_dev);
 
 /* ---- incremental precipitation mask of the member loops (csrc/mask.hip) -------- *
  *  psh_dilated_mask_dev  pysteps/nowcasts/utils.py:69-101, compute_dilated_mask(input_mask, kr, r) (nowcasts/

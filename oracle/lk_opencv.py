@@ -407,8 +407,9 @@ def track_features(prev_img, next_img, prev_valid, next_valid, points, winsize=(
 # motion/lucaskanade.py:182-279  sparse vectors of dense_lucaskanade
 # --------------------------------------------------------------------------
 def sparse_lucaskanade(frames, size_opening=3, buffer_mask=5, max_corners=1000, quality_level=0.01,
-                       min_distance=10, block_size=5, winsize=(50, 50), nr_levels=3, min_eig_thr=1e-4):
-    """Pooled (xy, uv) before outlier removal (lucaskanade.py:205-242)."""
+                       min_distance=10, block_size=5, winsize=(50, 50), nr_levels=3, min_eig_thr=1e-4, detector=None):
+    """Pooled (xy, uv) before outlier removal (lucaskanade.py:205-242).  `detector`: another feature detection
+    method (lucaskanade.py:191,230: called with the frame after the opening, missing pixels NaN) -> (p, 2) points."""
     xy = np.empty((0, 2))
     uv = np.empty((0, 2))
     for t in range(frames.shape[0] - 1):
@@ -417,7 +418,10 @@ def sparse_lucaskanade(frames, size_opening=3, buffer_mask=5, max_corners=1000, 
         if size_opening > 0:
             prev = morph_opening(prev, pv, prev[pv].min(), size_opening)
             nxt = morph_opening(nxt, nv, nxt[nv].min(), size_opening)
-        pts = shitomasi_detection(prev, pv, max_corners, quality_level, min_distance, block_size, buffer_mask)
+        if detector is not None:
+            pts = np.asarray(detector(prev)).astype(np.float32)
+        else:
+            pts = shitomasi_detection(prev, pv, max_corners, quality_level, min_distance, block_size, buffer_mask)
         if pts.shape[0] == 0:
             continue
         xy_, uv_ = track_features(prev, nxt, pv, nv, pts, winsize, nr_levels, 10, 0.0, min_eig_thr)

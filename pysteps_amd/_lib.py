@@ -88,6 +88,10 @@ SIGNATURES = {
     "psh_probmatch_plan_create": (c_int, [c_void_p, c_size_t, c_void_p]),
     "psh_probmatch_plan_destroy": (c_int, [c_void_p]),
     "psh_probmatch_planned_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "psh_blob_cube_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "psh_blob_peaks_dev": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p, c_void_p]),
+    "psh_blob_gather_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "psh_steps_mask_probmatch_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "psh_dilated_mask_dev": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_steps_incremental_mask_dev": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_int, c_int, c_int, c_void_p]),
     "psh_ar_iterate_dev": (c_int, [c_void_p, c_int, c_size_t, POINTER(c_double), c_int, c_void_p, c_void_p]),

@@ -37,6 +37,9 @@ struct Context {
   // small persistent device scratch (per-step scale factors etc.)
   void *scratch = nullptr;
   size_t scratch_bytes = 0;
+  // "a wet pixel was seen" word of psh_steps_incremental_mask_dev and the generation number its launches stamp it with
+  int *mask_any = nullptr;
+  int mask_generation = 0;
   // pinned staging buffer for pageable host copies
   void *pinned = nullptr;
   size_t pinned_bytes = 0;

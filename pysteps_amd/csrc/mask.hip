@@ -186,10 +186,16 @@ __global__ __launch_bounds__(kThreads) void mask_rim(const unsigned char *__rest
 //                   the stores are coalesced rows.
 // Same small integers and the same one division as above: bit-identical.
 constexpr int kBitsWaves = 4;  // waves (tiles) per workgroup
+constexpr int kBitsMaxTaps = 96;  // set elements of the structure that travel as a kernel argument (no copy to queue)
+struct BitTaps {
+  short2 t[kBitsMaxTaps];
+};
 
+// `any`: a word that lives as long as the library; a launch that saw a wet pixel stores ITS generation number there
+// (unique per call, never 0), the mask kernel behind it compares - no clearing launch in front of every call
 __global__ __launch_bounds__(256) void wet_bits(const double *__restrict__ field, int m, int n, double thr,
                                                 unsigned long long *__restrict__ bits, int words_per_row,
-                                                int *__restrict__ any) {
+                                                int *__restrict__ any, int generation) {
   // one wave per 64-pixel word: a lane per pixel, the word by ballot
   const int lane = threadIdx.x & 63;
   const size_t wave = (static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256) void wet_bits(const double *__restrict__ field
       }
     }
   }
-  if (seen && lane == 0) *any = 1;
+  if (seen && lane == 0) *any = generation;
 }
 
 __device__ __forceinline__ unsigned long long lane_word(unsigned long long v, int src_lane) {  // lane i gets lane src's word (0 outside the wave)
@@ -227,8 +233,8 @@ __device__ __forceinline__ unsigned long long lane_word(unsigned long long v, in
 
 template <int PLANES>
 __global__ __launch_bounds__(64 * kBitsWaves) void mask_from_bits(const unsigned long long *__restrict__ bits, int words_per_row,
-                                                                  int m, int n, const short2 *__restrict__ taps, int ntaps,
-                                                                  int halo, int r, const int *__restrict__ any,
+                                                                  int m, int n, const BitTaps taps, int ntaps,
+                                                                  int halo, int r, const int *__restrict__ any, int generation,
                                                                   double *__restrict__ out, int tiles_x, int n_tiles) {
   __shared__ unsigned long long s_planes[kBitsWaves][PLANES + 1][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(64 * kBitsWaves) void mask_from_bits(const unsigned
   // ---- mask0 = OR over the taps (dy, dx) of in[y - dy][x - dx]
   unsigned long long M = 0ull;
   for (int t = 0; t < ntaps; ++t) {
-    const int dy = taps[t].x, dx = taps[t].y;
+    const int dy = taps.t[t].x, dx = taps.t[t].y;
     const unsigned long long w = lane_word(in, lane - dy);
     M |= dx >= 0 ? (w << dx) : (w >> (-dx));
   }
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(64 * kBitsWaves) void mask_from_bits(const unsigned
   }
   __builtin_amdgcn_wave_barrier();
   const int cap = r + 1;
-  const double top = *any ? static_cast<double>(cap) : 0.0;
+  const double top = *any == generation ? static_cast<double>(cap) : 0.0;
   const int x = x0 + lane;
   const bool col_ok = lane >= halo && lane < 64 - halo && x < n;
   for (int row = halo; row < 64 - halo; ++row) {
@@ -377,50 +383,54 @@ extern "C" int psh_steps_incremental_mask_dev(const double *field_dev, int m, in
   Context &c = ctx();
   std::lock_guard<std::recursive_mutex> lock(c.mu);
   PSH_HIP(hipSetDevice(c.device));
-  constexpr int kMaxTaps = static_cast<int>(kConstSlotFloats * sizeof(float) / sizeof(short2));
-  float *slot_host = nullptr;
-  const float *slot_dev = nullptr;
-  if (int rc = const_slot(&slot_host, &slot_dev)) return rc;
-  short2 *taps_host = reinterpret_cast<short2 *>(slot_host);
+  BitTaps taps;
   int ntaps = 0, reach = 0;
   bool centre = false;
   for (int y = 0; y < kh; ++y) {
     for (int x = 0; x < kw; ++x) {
       if (!kr_host[static_cast<size_t>(y) * kw + x]) continue;
-      if (ntaps == kMaxTaps) return fail(PSH_EUNSUPPORTED, "incremental_mask: more than %d set elements in the structure", kMaxTaps);
-      taps_host[ntaps].x = static_cast<short>(y - kh / 2);
-      taps_host[ntaps].y = static_cast<short>(x - kw / 2);
+      if (ntaps == kBitsMaxTaps) return fail(PSH_EUNSUPPORTED, "incremental_mask: more than %d set elements in the structure", kBitsMaxTaps);
+      taps.t[ntaps].x = static_cast<short>(y - kh / 2);
+      taps.t[ntaps].y = static_cast<short>(x - kw / 2);
       reach = std::max(reach, std::max(std::abs(x - kw / 2), std::abs(y - kh / 2)));
       centre |= (y == kh / 2 && x == kw / 2);
       ++ntaps;
     }
   }
+  for (int t = ntaps; t < kBitsMaxTaps; ++t) taps.t[t] = make_short2(0, 0);
   // (with the centre element mask0 contains the input: "anything set in mask0" = "anything wet")
   if (!centre) return fail(PSH_EUNSUPPORTED, "incremental_mask: the structure lacks its centre element");
   const int halo = r + reach;
   if (halo > 24) return fail(PSH_EUNSUPPORTED, "incremental_mask: rim + structure reach %d pixels (at most 24)", halo);
   const int words_per_row = (n + 63) / 64;
   const size_t bit_bytes = static_cast<size_t>(m) * words_per_row * sizeof(unsigned long long);
+  // the "anything wet" word and its generation counter (see wet_bits)
+  if (!c.mask_any) {
+    PSH_HIP(hipMalloc(reinterpret_cast<void **>(&c.mask_any), sizeof(int)));
+    PSH_HIP(hipMemsetAsync(c.mask_any, 0, sizeof(int), c.stream));  // once, in stream order
+    c.mask_generation = 0;
+  }
+  c.mask_generation = c.mask_generation == 0x7fffffff ? 1 : c.mask_generation + 1;
+  int *any = c.mask_any;
+  const int generation = c.mask_generation;
   void *blk = nullptr;
-  if (int rc = psh_malloc(&blk, 256 + bit_bytes)) return rc;
-  int *any = static_cast<int *>(blk);
-  unsigned long long *bits = reinterpret_cast<unsigned long long *>(static_cast<char *>(blk) + 256);
+  if (int rc = psh_malloc(&blk, bit_bytes)) return rc;
+  unsigned long long *bits = static_cast<unsigned long long *>(blk);
   auto run = [&]() -> int {
     hipStream_t s = c.stream;
-    PSH_HIP(hipMemcpyAsync(const_cast<float *>(slot_dev), slot_host, static_cast<size_t>(ntaps) * sizeof(short2),
-                           hipMemcpyHostToDevice, s));
-    PSH_HIP(hipMemsetAsync(any, 0, sizeof(int), s));
     const size_t words = static_cast<size_t>(m) * words_per_row;
     const int wgrid = static_cast<int>(std::min<size_t>((words + 15) / 16, static_cast<size_t>(c.cu_count) * 16));
-    hipLaunchKernelGGL(wet_bits, dim3(std::max(wgrid, 1)), dim3(256), 0, s, field_dev, m, n, threshold, bits, words_per_row, any);
+    hipLaunchKernelGGL(wet_bits, dim3(std::max(wgrid, 1)), dim3(256), 0, s, field_dev, m, n, threshold, bits, words_per_row, any,
+                       generation);
     const int side = 64 - 2 * halo;
     const int tiles_x = (n + side - 1) / side, tiles_y = (m + side - 1) / side, n_tiles = tiles_x * tiles_y;
     const dim3 grid((n_tiles + kBitsWaves - 1) / kBitsWaves), block(64 * kBitsWaves);
-    const short2 *taps_dev = reinterpret_cast<const short2 *>(slot_dev);
     if (r + 1 < 16) {
-      hipLaunchKernelGGL(mask_from_bits<4>, grid, block, 0, s, bits, words_per_row, m, n, taps_dev, ntaps, halo, r, any, out_dev, tiles_x, n_tiles);
+      hipLaunchKernelGGL(mask_from_bits<4>, grid, block, 0, s, bits, words_per_row, m, n, taps, ntaps, halo, r, any, generation, out_dev,
+                         tiles_x, n_tiles);
     } else {
-      hipLaunchKernelGGL(mask_from_bits<8>, grid, block, 0, s, bits, words_per_row, m, n, taps_dev, ntaps, halo, r, any, out_dev, tiles_x, n_tiles);
+      hipLaunchKernelGGL(mask_from_bits<8>, grid, block, 0, s, bits, words_per_row, m, n, taps, ntaps, halo, r, any, generation, out_dev,
+                         tiles_x, n_tiles);
     }
     PSH_HIP(hipGetLastError());
     return PSH_OK;

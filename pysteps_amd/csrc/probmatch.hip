@@ -68,7 +68,7 @@ __device__ __forceinline__ unsigned bin_of(double v, double z, double scale) {
   return f >= static_cast<double>(kBins - 1) ? kBins - 1 : static_cast<unsigned>(f);
 }
 
-__global__ void pm_init(PmHeader *h) {
+__device__ __forceinline__ void pm_init(PmHeader *h) {
   for (int y = 0; y < 2; ++y) {
     h->n_nan[y] = h->n_inf[y] = h->wet[y] = h->n_large[y] = h->max_bin[y] = 0u;
     h->z[y] = h->scale[y] = 0.0;
@@ -76,6 +76,13 @@ __global__ void pm_init(PmHeader *h) {
   h->status = kStOk;
   h->adjust = 0;
   h->p = 0.0;
+}
+
+// 64-bit key of a double whose unsigned order is the doubles' order (steps_loop.hip min_key / from_min_key)
+__device__ __forceinline__ double pm_from_min_key(unsigned long long k) {
+  if (k == 0ull) return __longlong_as_double(0x7ff8000000000000ll);  // NaN
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double(static_cast<long long>(b));
 }
 
 __global__ __launch_bounds__(kThreads) void pm_stats(const double *__restrict__ a0, const double *__restrict__ a1,
@@ -122,12 +129,79 @@ __global__ __launch_bounds__(kThreads) void pm_stats(const double *__restrict__ 
   }
 }
 
+// steps.py:1221-1240 (the precipitation mask of the member loop, psh_steps_mask_dev's arithmetic) applied to the
+// initial array IN PLACE, and the statistics of the masked values in the same sweep: the matching's first pass
+// over the array is the mask's own
+__global__ __launch_bounds__(kThreads) void pm_mask_stats(double *__restrict__ a, size_t n, const double *__restrict__ grey,
+                                                          const unsigned char *__restrict__ keep,
+                                                          const unsigned long long *__restrict__ min_key_in,
+                                                          PmPartial *__restrict__ part) {
+#pragma clang fp contract(off)
+  const double base = pm_from_min_key(*min_key_in);
+  double mn = INFINITY, mx = -INFINITY;
+  unsigned nn = 0, ni = 0;
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += kLoads * stride) {
+    double v[kLoads], g[kLoads];
+    unsigned char kp[kLoads];
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const size_t j = i + k * stride;
+      v[k] = j < n ? a[j] : 0.0;
+      g[k] = (grey && j < n) ? grey[j] : 0.0;
+      kp[k] = (keep && j < n) ? keep[j] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kLoads; ++k) {
+      const size_t j = i + k * stride;
+      if (j >= n) continue;
+      double w = v[k];
+      if (grey) {
+        const double d = w - base;
+        const double s = d * g[k];
+        w = base + s;
+        if (!(w > base)) w = base;
+      } else if (!kp[k]) {
+        w = base;
+      }
+      a[j] = w;
+      const bool nan = w != w;
+      nn += nan ? 1u : 0u;
+      ni += (w == INFINITY || w == -INFINITY) ? 1u : 0u;
+      mn = w < mn ? w : mn;  // false for NaN
+      mx = w > mx ? w : mx;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const double omn = __shfl_xor(mn, d), omx = __shfl_xor(mx, d);
+    mn = omn < mn ? omn : mn;
+    mx = omx > mx ? omx : mx;
+    nn += __shfl_xor(nn, d);
+    ni += __shfl_xor(ni, d);
+  }
+  __shared__ PmPartial s_part[kThreads / 64];
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = PmPartial{mn, mx, nn, ni};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PmPartial r = s_part[0];
+    for (int w = 1; w < kThreads / 64; ++w) {
+      r.mn = s_part[w].mn < r.mn ? s_part[w].mn : r.mn;
+      r.mx = s_part[w].mx > r.mx ? s_part[w].mx : r.mx;
+      r.n_nan += s_part[w].n_nan;
+      r.n_inf += s_part[w].n_inf;
+    }
+    part[blockIdx.x] = r;
+  }
+}
+
 // one workgroup: finishes the statistics and fixes the bucket mapping.  `only` < 0: both arrays;
 // 1: the target alone (a plan is being made: nothing is known about an initial array yet);
 // 0: the initial array alone, the target's side of the header comes from `plan`
 __global__ __launch_bounds__(kThreads) void pm_prepare(PmHeader *h, size_t n, const PmPartial *__restrict__ part,
                                                        int nparts, int only, const PmHeader *__restrict__ plan) {
   __shared__ PmPartial s_part[kThreads / 64];
+  if (threadIdx.x == 0) pm_init(h);  // (thread 0 is the header's only writer in this kernel)
   for (int y = 0; y < 2; ++y) {
     if (only >= 0 && y != only) continue;  // uniform
     double mn = INFINITY, mx = -INFINITY;
@@ -564,23 +638,71 @@ __global__ __launch_bounds__(kThreads) void pm2_sums(const unsigned *__restrict_
   if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void pm2_scan_sums(unsigned *__restrict__ sums, unsigned nsums, PmHeader *h) {
-  __shared__ unsigned s_wave[16];
-  unsigned carry = 0;
-  for (unsigned b0 = 0; b0 < nsums; b0 += 1024) {  // (uniform trip count)
-    const unsigned i = b0 + threadIdx.x;
-    const unsigned v = i < nsums ? sums[i] : 0u;
-    unsigned total;
-    const unsigned incl = block_incl_scan<16>(v, s_wave, &total);
-    if (i < nsums) sums[i] = carry + incl - v;
-    carry += total;
+// :104-108: the wet area of the target above that of the initial array -> p = np.percentile(target,
+// 100 * (1 - war)), method "linear" (numpy/lib/_function_base_impl.py: virtual index (n - 1) * q,
+// _get_indexes, _lerp), every operation in numpy's order and unfused
+__device__ __forceinline__ void pm_threshold(PmHeader *h, size_t n, const double *__restrict__ tw, unsigned wi) {
+#pragma clang fp contract(off)
+  if (h->status != kStOk) return;
+  const unsigned wt = h->wet[1];
+  if (wt <= wi) return;
+  const size_t zeros_trg = n - wt;
+  const double war = static_cast<double>(wi) / static_cast<double>(n);
+  const double one_minus = 1.0 - war;
+  const double percent = 100.0 * one_minus;
+  const double q = percent / 100.0;
+  const double last = static_cast<double>(n - 1);
+  const double virt = last * q;
+  size_t ia, ib;
+  double t;
+  if (virt >= last) {  // _get_indexes: both -1, gamma = virt - (-1)
+    ia = ib = n - 1;
+    t = virt + 1.0;
+  } else {
+    const double fl = floor(virt);
+    ia = static_cast<size_t>(fl);
+    ib = ia + 1;
+    t = virt - fl;
   }
-  if (threadIdx.x == 0) h->wet[0] = carry;
+  const double a = ia < zeros_trg ? h->z[1] : tw[ia - zeros_trg];
+  const double b = ib < zeros_trg ? h->z[1] : tw[ib - zeros_trg];
+  const double diff = b - a;
+  double p = a + diff * t;
+  if (t >= 0.5) p = b - diff * (1.0 - t);
+  h->p = p;
+  h->adjust = 1;
 }
 
+// offsets written back in place; every workgroup adds the sums in front of its own chunk itself (a few hundred
+// words) - no scan kernel of the sums -, workgroup 0 also the total = wet count of the initial array, with which
+// its first thread fixes the wet-area threshold (no kernel of its own either)
 __global__ __launch_bounds__(kThreads) void pm2_offsets(unsigned *__restrict__ H, size_t nent,
-                                                        const unsigned *__restrict__ sums) {
+                                                        const unsigned *__restrict__ sums, unsigned nsums, PmHeader *h,
+                                                        size_t n, const double *__restrict__ tw) {
   __shared__ unsigned s_wave[kThreads / 64];
+  __shared__ unsigned s_before, s_all;
+  unsigned before = 0, all = 0;
+  for (unsigned j = threadIdx.x; j < nsums; j += kThreads) {
+    const unsigned v = sums[j];
+    before += j < blockIdx.x ? v : 0u;
+    all += v;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    before += __shfl_xor(before, d);
+    all += __shfl_xor(all, d);
+  }
+  if (threadIdx.x == 0) s_before = s_all = 0u;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&s_before, before);  // (integers: the order does not matter)
+    atomicAdd(&s_all, all);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    h->wet[0] = s_all;
+    pm_threshold(h, n, tw, s_all);
+  }
   constexpr unsigned kPer = kScanChunk / kThreads;
   const size_t base = static_cast<size_t>(blockIdx.x) * kScanChunk + static_cast<size_t>(threadIdx.x) * kPer;
   unsigned v[kPer], mine = 0;
@@ -591,7 +713,7 @@ __global__ __launch_bounds__(kThreads) void pm2_offsets(unsigned *__restrict__ H
   }
   unsigned total;
   const unsigned incl = block_incl_scan<kThreads / 64>(mine, s_wave, &total);
-  unsigned run = sums[blockIdx.x] + incl - mine;
+  unsigned run = s_before + incl - mine;
 #pragma unroll
   for (unsigned k = 0; k < kPer; ++k) {
     if (base + k < nent) H[base + k] = run;
@@ -696,12 +818,35 @@ __global__ __launch_bounds__(kRefineThreads) void pm2_refine(PmHeader *h, const 
 // position inside the bucket = number of smaller (value, pixel) pairs; the bucket's members are found
 // from the record's tag.  Two records per thread side by side: the kernel is a chain of dependent loads
 // (record -> bucket members), a second chain fills the waiting time of the first.
-__global__ __launch_bounds__(kThreads) void pm2_rank_small(const PmHeader *__restrict__ h, size_t n,
-                                                           const PmRec *__restrict__ rec, const double *__restrict__ tw,
-                                                           double *__restrict__ out) {
+// The workgroups behind the first `small_blocks` take the crowded buckets (more than kSmallBin values), one bucket
+// per workgroup and turn (what pm2_rank_large was as a launch of its own; as a rule there is none).
+__global__ __launch_bounds__(kThreads) void pm2_rank(PmHeader *h, size_t n, const PmRec *__restrict__ rec,
+                                                     const double *__restrict__ tw, double *__restrict__ out,
+                                                     unsigned small_blocks, const uint2 *__restrict__ large,
+                                                     unsigned large_cap) {
   if (h->status != kStOk) return;
+  if (blockIdx.x >= small_blocks) {
+    const unsigned n_large = h->n_large[0] < large_cap ? h->n_large[0] : large_cap;
+    for (unsigned li = blockIdx.x - small_blocks; li < n_large; li += gridDim.x - small_blocks) {
+      const unsigned st = large[li].x, c = large[li].y;
+      if (c > kLargeLimit) {
+        if (threadIdx.x == 0) atomicExch(&h->status, kStTies);
+        continue;
+      }
+      for (unsigned e = threadIdx.x; e < c; e += kThreads) {
+        const PmRec me = rec[st + e];
+        unsigned less = 0;
+        for (unsigned j = st; j < st + c; ++j) {
+          const PmRec o = rec[j];
+          less += (o.v < me.v || (o.v == me.v && o.idx < me.idx)) ? 1u : 0u;
+        }
+        pm_emit(h, n, tw, out, me.idx, st + less);
+      }
+    }
+    return;
+  }
   const unsigned wet = h->wet[0];
-  const unsigned stride = gridDim.x * kThreads;
+  const unsigned stride = small_blocks * kThreads;
   for (unsigned s0 = blockIdx.x * kThreads + threadIdx.x; s0 < wet; s0 += 2 * stride) {
     const unsigned s1 = s0 + stride;
     const bool two = s1 < wet;
@@ -728,65 +873,6 @@ __global__ __launch_bounds__(kThreads) void pm2_rank_small(const PmHeader *__res
     if (n0) pm_emit(h, n, tw, out, me0.idx, st0 + less0);
     if (n1) pm_emit(h, n, tw, out, me1.idx, st1 + less1);
   }
-}
-
-// the crowded buckets (more than kSmallBin values), one workgroup each
-__global__ __launch_bounds__(kThreads) void pm2_rank_large(PmHeader *h, size_t n, const uint2 *__restrict__ large,
-                                                           unsigned large_cap, const PmRec *__restrict__ rec,
-                                                           const double *__restrict__ tw, double *__restrict__ out) {
-  if (h->status != kStOk) return;
-  const unsigned n_large = h->n_large[0] < large_cap ? h->n_large[0] : large_cap;
-  for (unsigned li = blockIdx.x; li < n_large; li += gridDim.x) {
-    const unsigned st = large[li].x, c = large[li].y;
-    if (c > kLargeLimit) {
-      if (threadIdx.x == 0) atomicExch(&h->status, kStTies);
-      continue;
-    }
-    for (unsigned e = threadIdx.x; e < c; e += kThreads) {
-      const PmRec me = rec[st + e];
-      unsigned less = 0;
-      for (unsigned j = st; j < st + c; ++j) {
-        const PmRec o = rec[j];
-        less += (o.v < me.v || (o.v == me.v && o.idx < me.idx)) ? 1u : 0u;
-      }
-      pm_emit(h, n, tw, out, me.idx, st + less);
-    }
-  }
-}
-
-// :104-108: the wet area of the target above that of the initial array -> p = np.percentile(target,
-// 100 * (1 - war)), method "linear" (numpy/lib/_function_base_impl.py: virtual index (n - 1) * q,
-// _get_indexes, _lerp), every operation in numpy's order and unfused
-__global__ void pm_threshold(PmHeader *h, size_t n, const double *__restrict__ tw) {
-#pragma clang fp contract(off)
-  if (h->status != kStOk) return;
-  const unsigned wi = h->wet[0], wt = h->wet[1];
-  if (wt <= wi) return;
-  const size_t zeros_trg = n - wt;
-  const double war = static_cast<double>(wi) / static_cast<double>(n);
-  const double one_minus = 1.0 - war;
-  const double percent = 100.0 * one_minus;
-  const double q = percent / 100.0;
-  const double last = static_cast<double>(n - 1);
-  const double virt = last * q;
-  size_t ia, ib;
-  double t;
-  if (virt >= last) {  // _get_indexes: both -1, gamma = virt - (-1)
-    ia = ib = n - 1;
-    t = virt + 1.0;
-  } else {
-    const double fl = floor(virt);
-    ia = static_cast<size_t>(fl);
-    ib = ia + 1;
-    t = virt - fl;
-  }
-  const double a = ia < zeros_trg ? h->z[1] : tw[ia - zeros_trg];
-  const double b = ib < zeros_trg ? h->z[1] : tw[ib - zeros_trg];
-  const double diff = b - a;
-  double p = a + diff * t;
-  if (t >= 0.5) p = b - diff * (1.0 - t);
-  h->p = p;
-  h->adjust = 1;
 }
 
 }  // namespace
@@ -820,8 +906,15 @@ struct PmPlan {
 
 // plan == nullptr, make == nullptr: one complete call.  make: only the target's half, kept in *make.
 // plan: only the initial array's half against the plan.
+struct PmMask {  // psh_steps_mask_probmatch_dev: exactly one of grey / keep
+  const double *grey;
+  const unsigned char *keep;
+  const unsigned long long *min_key;
+};
+
 static int probmatch_run(const double *initial_dev, const double *target_dev, size_t count, double *out_dev,
-                         int *status_dev, const PmPlan *plan = nullptr, PmPlan *make = nullptr) {
+                         int *status_dev, const PmPlan *plan = nullptr, PmPlan *make = nullptr,
+                         const PmMask *mask = nullptr) {
   using namespace psh;
   PSH_REQUIRE_INIT();
   if ((!make && (!initial_dev || !out_dev)) || (!plan && !target_dev)) return fail(PSH_EINVAL, "probmatch: NULL pointer");
@@ -881,10 +974,17 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
     const int halves = plan ? 1 : 2;
     hipStream_t s = c.stream;
     if (!plan) PSH_HIP(hipMemsetAsync(cnt + kBins, 0, table_bytes / 2, s));  // the target's bucket counts
-    hipLaunchKernelGGL(pm_init, dim3(1), dim3(1), 0, s, h);
-    hipLaunchKernelGGL(pm_stats, dim3(grid, halves), dim3(kThreads), 0, s, make ? target_dev : initial_dev, target_dev, count,
-                       part);
-    hipLaunchKernelGGL(pm_prepare, dim3(1), dim3(kThreads), 0, s, h, count, part, grid, plan ? 0 : (make ? 1 : -1),
+    // (the header is reset by pm_prepare; nothing before it reads one)
+    int nparts = grid;
+    if (mask) {  // the member loop's precipitation mask in place + the statistics of what it leaves, one sweep
+      nparts = kGrid;
+      hipLaunchKernelGGL(pm_mask_stats, dim3(nparts), dim3(kThreads), 0, s, const_cast<double *>(initial_dev), count, mask->grey,
+                         mask->keep, mask->min_key, part);
+    } else {
+      hipLaunchKernelGGL(pm_stats, dim3(grid, halves), dim3(kThreads), 0, s, make ? target_dev : initial_dev, target_dev, count,
+                         part);
+    }
+    hipLaunchKernelGGL(pm_prepare, dim3(1), dim3(kThreads), 0, s, h, count, part, nparts, plan ? 0 : (make ? 1 : -1),
                        plan ? plan->header() : static_cast<const PmHeader *>(nullptr));
     if (!plan) {  // target: bucket counts, bucket starts, sorted wet values
       hipLaunchKernelGGL(pm_hist_target, dim3(grid), dim3(kThreads), 0, s, target_dev, count, h, cnt + kBins);
@@ -906,14 +1006,11 @@ static int probmatch_run(const double *initial_dev, const double *target_dev, si
     // initial: two partition passes (LDS atomics only), ranks inside the buckets -> output
     hipLaunchKernelGGL(pm2_count, dim3(nblk), dim3(kThreads), 0, s, initial_dev, count, h, H, nblk);
     hipLaunchKernelGGL(pm2_sums, dim3(nsums), dim3(kThreads), 0, s, H, nent, hsums);
-    hipLaunchKernelGGL(pm2_scan_sums, dim3(1), dim3(1024), 0, s, hsums, nsums, h);
-    hipLaunchKernelGGL(pm2_offsets, dim3(nsums), dim3(kThreads), 0, s, H, nent, hsums);
-    hipLaunchKernelGGL(pm_threshold, dim3(1), dim3(1), 0, s, h, count, tw);
+    hipLaunchKernelGGL(pm2_offsets, dim3(nsums), dim3(kThreads), 0, s, H, nent, hsums, nsums, h, count, tw);
     hipLaunchKernelGGL(pm2_scatter, dim3(nblk), dim3(kThreads), 0, s, initial_dev, count, h, H, nblk, rec_a, out_dev);
     hipLaunchKernelGGL(pm2_refine, dim3(kCoarse), dim3(kRefineThreads), 0, s, h, H, nblk, rec_a, rec_b, large2, large_cap);
-    hipLaunchKernelGGL(pm2_rank_small, dim3(grid), dim3(kThreads), 0, s, h, count, rec_b, tw, out_dev);
-    hipLaunchKernelGGL(pm2_rank_large, dim3(grid_large), dim3(kThreads), 0, s, h, count, large2, large_cap, rec_b, tw,
-                       out_dev);
+    hipLaunchKernelGGL(pm2_rank, dim3(grid + grid_large), dim3(kThreads), 0, s, h, count, rec_b, tw, out_dev,
+                       static_cast<unsigned>(grid), large2, large_cap);
     PSH_HIP(hipGetLastError());
     if (status_dev) {  // the caller reads the status later (resident member loop: one wait per time step)
       PSH_HIP(hipMemcpyAsync(status_dev, &h->status, sizeof(int), hipMemcpyDeviceToDevice, s));
@@ -973,6 +1070,22 @@ extern "C" int psh_probmatch_planned_dev(const void *plan_handle, const double *
   if (!plan || !plan->blk) return psh::fail(PSH_EINVAL, "probmatch_planned: NULL plan");
   if (count != plan->count) return psh::fail(PSH_EINVAL, "probmatch_planned: the plan was made for %zu values, not %zu", plan->count, count);
   return probmatch_run(initial_dev, nullptr, count, out_dev, status_dev, plan, nullptr);
+}
+
+// psh_steps_mask_dev(field, ...) followed by psh_probmatch_planned_dev(plan, field, ...) with the mask applied by the
+// matching's own first sweep (field_dev holds the masked field afterwards, as after psh_steps_mask_dev)
+extern "C" int psh_steps_mask_probmatch_dev(const void *plan_handle, double *field_dev, size_t count,
+                                            const double *grey_mask_dev, const unsigned char *keep_mask_dev,
+                                            const unsigned long long *min_key_dev, double *out_dev, int *status_dev) {
+  const PmPlan *plan = static_cast<const PmPlan *>(plan_handle);
+  if (!plan || !plan->blk) return psh::fail(PSH_EINVAL, "steps_mask_probmatch: NULL plan");
+  if (count != plan->count)
+    return psh::fail(PSH_EINVAL, "steps_mask_probmatch: the plan was made for %zu values, not %zu", plan->count, count);
+  if (!field_dev || !min_key_dev || (!grey_mask_dev == !keep_mask_dev))
+    return psh::fail(PSH_EINVAL, "steps_mask_probmatch: field, minimum and exactly one of the two masks are required");
+  if (field_dev == out_dev) return psh::fail(PSH_EINVAL, "steps_mask_probmatch: the matched field needs an array of its own");
+  const PmMask mask{grey_mask_dev, keep_mask_dev, min_key_dev};
+  return probmatch_run(field_dev, nullptr, count, out_dev, status_dev, plan, nullptr, &mask);
 }
 
 // The k-th smallest value of a field without NaNs (0-based) - what compute_percentile_mask

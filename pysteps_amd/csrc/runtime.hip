@@ -232,6 +232,8 @@ int psh_shutdown(void) {
   psh::release_persistent_pinned();
   psh::fft_release();
   if (c.scratch) (void)hipFree(c.scratch);
+  if (c.mask_any) (void)hipFree(c.mask_any);
+  c.mask_any = nullptr;
   ++psh::g_scratch_generation;
   if (c.pinned) (void)hipHostFree(c.pinned);
   (void)hipStreamDestroy(c.stream);

@@ -12,10 +12,12 @@ thousand) are quality-controlled on the host exactly like the reference
 float64 ndarray like the reference) or a float32
 :class:`pysteps_amd.device.DeviceArray` (result stays in HBM as float32).
 
-Only the reference's default detector/interpolator pair is implemented natively
-(``fd_method="shitomasi"``, ``interp_method="idwinterp2d"``; any other ``interp_method`` gets the
-HIP sparse stage followed by the reference's interpolation function); other choices are
-delegated to the reference when pysteps is importable, else NotImplementedError.
+The reference's default detector/interpolator pair (``fd_method="shitomasi"``, ``interp_method="idwinterp2d"``)
+runs as ONE queued chain (``csrc/dense_lk.hip``); ``fd_method="blob"`` (``pysteps_amd.feature.blob``: scale-space
+maxima, ``csrc/blob.hip``) and ``interp_method="rbfinterp2d"`` run stage by stage on the device; any other
+``interp_method`` gets the HIP sparse stage followed by the reference's interpolation function; other choices
+(``fd_method="tstorm"``, the Harris response) are delegated to the reference when pysteps is importable, else
+NotImplementedError.
 """
 
 import ctypes
@@ -230,6 +232,28 @@ def _dense_lk_native(frames, on_device, dense, size_opening, buffer_mask, max_co
     return xy[: count.value].copy(), uv[: count.value].copy()
 
 
+_BLOB_KWARGS = {"max_num_features", "method", "threshold", "min_sigma", "max_sigma", "overlap", "num_sigma", "log_scale",
+                "sigma_ratio"}
+
+
+def _blob_points(prep, host_frame, fd_kwargs):
+    """``feature.blob.detection`` on the cleaned frame -> (p, 2) float32 (x, y) (lucaskanade.py:230).  The reference
+    detects on the frame in ITS dtype: for float64 host frames the cleaned frame is put together again in float64
+    (the pixels the opening removed are those whose float32 rendering changed: they hold the frame's minimum)."""
+    from ..feature.blob import detection  # noqa: PLC0415
+
+    kwargs = {k: v for k, v in fd_kwargs.items() if k != "return_sigmas"}
+    if host_frame is not None and np.asarray(host_frame).dtype == np.float64:
+        orig = np.asarray(np.ma.filled(host_frame, np.nan) if isinstance(host_frame, np.ma.MaskedArray) else host_frame)
+        clean32 = prep.clean.to_host()
+        removed = np.isfinite(orig) & (clean32 != orig.astype(np.float32))
+        image = np.where(removed, np.nanmin(orig), orig)
+        image[~np.isfinite(orig)] = np.nan
+    else:
+        image = prep.clean
+    return detection(image, **kwargs).astype(np.float32)
+
+
 def _reference_dense_lk():
     try:
         from pysteps.motion.lucaskanade import dense_lucaskanade as ref  # noqa: PLC0415
@@ -238,7 +262,7 @@ def _reference_dense_lk():
     return None if ref is dense_lucaskanade else ref
 
 
-def _dense_with_reference_interpolator(input_images, lk_kwargs, fd_kwargs, interp_method, interp_kwargs,
+def _dense_with_reference_interpolator(input_images, lk_kwargs, fd_method, fd_kwargs, interp_method, interp_kwargs,
                                        nr_std_outlier, k_outlier, size_opening, decl_scale, verbose):
     """Another interpolation method: the sparse stage - features, tracking, outlier removal - runs on the HIP
     path, the vectors are declustered here and handed to the interpolation function, exactly as
@@ -261,7 +285,7 @@ def _dense_with_reference_interpolator(input_images, lk_kwargs, fd_kwargs, inter
             ) from exc
         interpolation_method = ref_utils.get_method(interp_method)  # ValueError for unknown names, as the reference
     xy, uv = dense_lucaskanade(
-        input_images, lk_kwargs, "shitomasi", fd_kwargs, "idwinterp2d", None, False, nr_std_outlier, k_outlier,
+        input_images, lk_kwargs, fd_method, fd_kwargs, "idwinterp2d", None, False, nr_std_outlier, k_outlier,
         size_opening, decl_scale, verbose,
     )
     domain_size = input_images.shape[1:]
@@ -323,9 +347,12 @@ def dense_lucaskanade(
     interp_kwargs = dict(interp_kwargs or {})
 
     unsupported = None
-    if fd_method != "shitomasi":
+    fd_name = fd_method.lower() if isinstance(fd_method, str) else fd_method
+    if fd_name not in ("shitomasi", "blob"):
         unsupported = "fd_method=%r" % (fd_method,)
-    elif fd_kwargs.get("use_harris", False):
+    elif fd_name == "blob" and (fd_kwargs.get("method", "log") == "doh" or set(fd_kwargs) - _BLOB_KWARGS):
+        unsupported = "fd_method='blob' with fd_kwargs %r" % (sorted(fd_kwargs),)
+    elif fd_name == "shitomasi" and fd_kwargs.get("use_harris", False):
         unsupported = "use_harris=True"
     elif lk_kwargs.get("flags", 0) != 0:
         unsupported = "flags=%r" % (lk_kwargs.get("flags"),)
@@ -334,7 +361,7 @@ def dense_lucaskanade(
     else:
         # limits of the kernels (csrc/lk.hip kMaxBlockR / kMaxWin, csrc/idw.hip top-k registers):
         # checked HERE so that such calls reach the reference instead of failing in the library
-        bs = fd_kwargs.get("block_size", 5)
+        bs = fd_kwargs.get("block_size", 5) if fd_name == "shitomasi" else 5
         win = lk_kwargs.get("winsize", (50, 50))
         ik, ipow = interp_kwargs.get("k", 20), interp_kwargs.get("power", 0.5)
         if not (isinstance(bs, (int, np.integer)) and 1 <= bs <= 7 and bs % 2 == 1):
@@ -358,7 +385,7 @@ def dense_lucaskanade(
 
     if dense and interp_method != "idwinterp2d":
         return _dense_with_reference_interpolator(
-            input_images, lk_kwargs, fd_kwargs, interp_method, interp_kwargs, nr_std_outlier, k_outlier,
+            input_images, lk_kwargs, fd_name, fd_kwargs, interp_method, interp_kwargs, nr_std_outlier, k_outlier,
             size_opening, decl_scale, verbose,
         )
 
@@ -380,7 +407,7 @@ def dense_lucaskanade(
     min_eig_thr = lk_kwargs.get("min_eig_thr", 1e-4)
 
     # ---- fast path: the whole estimate in one C-ABI call (csrc/dense_lk.hip) ----------------
-    native = _dense_lk_native(
+    native = None if fd_name != "shitomasi" else _dense_lk_native(
         frames, on_device, dense, size_opening, buffer_mask, max_corners, quality_level, min_distance,
         block_size, winsize, nr_levels, criteria, min_eig_thr, nr_std_outlier, k_outlier, decl_scale,
         interp_kwargs,
@@ -391,7 +418,7 @@ def dense_lucaskanade(
         return native
 
     prepared = [
-        PreparedFrame(frames.view(t), size_opening, buffer_mask, want_features=t < nr_fields - 1)
+        PreparedFrame(frames.view(t), size_opening, buffer_mask, want_features=fd_name == "shitomasi" and t < nr_fields - 1)
         for t in range(nr_fields)
     ]
 
@@ -400,12 +427,17 @@ def dense_lucaskanade(
     for t in range(nr_fields - 1):
         # corner kernels first, then the pyramids of the pair: the device builds them while
         # the host runs the ordered min-distance pass over the candidates
-        with _corner_lock:
-            token = launch_corners(prepared[t], max_corners, quality_level, min_distance, block_size)
+        if fd_name == "blob":
+            # lucaskanade.py:230: the detector sees the frame after the opening, missing pixels still NaN
             pyramids = PyramidPair(prepared[t], prepared[t + 1], winsize, nr_levels)
-            points = finish_corners(token)
-        if fd_kwargs.get("verbose", False):
-            print(f"--- {points.shape[0]} good features to track detected ---")
+            points = _blob_points(prepared[t], None if on_device else input_images[t], fd_kwargs)
+        else:
+            with _corner_lock:
+                token = launch_corners(prepared[t], max_corners, quality_level, min_distance, block_size)
+                pyramids = PyramidPair(prepared[t], prepared[t + 1], winsize, nr_levels)
+                points = finish_corners(token)
+            if fd_kwargs.get("verbose", False):
+                print(f"--- {points.shape[0]} good features to track detected ---")
         if points.shape[0] == 0:
             pyramids.close()
             continue

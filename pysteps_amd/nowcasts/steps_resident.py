@@ -499,6 +499,17 @@ class ResidentSteps:
                                                        self._phi_p, self.eps.ptr, self.eps_stats.ptr, self._noise_std_p,
                                                        self.mu[j].ctypes.data, self.sigma[j].ctypes.data, field.ptr, self.min_key.ptr),
                     "psh_steps_ar_recompose_raw_dev")
+            masked = self.grey is not None or self.keep is not None
+            if masked and self.pm_method == "cdf" and field.ptr != result.ptr:
+                # steps.py:1221-1240 + 1198-1201: the matching's first sweep (statistics of the initial array) applies
+                # the mask on its way - one pass over the field less than the two calls below; the outcome is read
+                # after the last member
+                _lib.check(lib.psh_steps_mask_probmatch_dev(
+                    self.pm_plan, field.ptr, plane, None if self.grey is None else self.grey.view(j).ptr,
+                    None if self.grey is not None else self.keep.ptr, self.min_key.ptr, result.ptr, self.pm_status.ptr + 4 * j),
+                    "psh_steps_mask_probmatch_dev")
+                self._finish_member(j, result)
+                continue
             if self.grey is not None:  # steps.py:1221-1240
                 _lib.check(lib.psh_steps_mask_dev(field.ptr, plane, self.grey.view(j).ptr, None, self.min_key.ptr), "psh_steps_mask_dev")
             elif self.keep is not None:

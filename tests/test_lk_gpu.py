@@ -505,17 +505,18 @@ def test_lk_option_matrix(dense_lk, dense, nr_std_outlier, k_outlier, size_openi
             assert len(d) >= 0.95 * len(want[0]) and max(d) < 1e-2
 
 
-@pytest.mark.parametrize("fd_method", ["blob", "tstorm"])
-def test_other_feature_detectors_are_delegated(dense_lk, fd_method):
-    """Detectors other than Shi-Tomasi are not part of the path: they go to the reference when it
-    is importable and fail loudly otherwise (no silent substitution)."""
+@pytest.mark.parametrize("fd_method,fd_kwargs", [("tstorm", None), ("blob", {"method": "doh"})])
+def test_other_feature_detectors_are_delegated(dense_lk, fd_method, fd_kwargs):
+    """The thunderstorm-cell detector and determinant-of-Hessian blobs are not part of the path (Shi-Tomasi and LoG / DoG
+    blobs are: tests/test_blob_gpu.py): they go to the reference when it is importable and fail loudly otherwise (no
+    silent substitution)."""
     frames, _ = _advected_frames(128, 128, 2, seed=5)
     try:  # with oracle/_ref importable the reference raises its own MissingOptionalDependency (skimage)
         from pysteps.exceptions import MissingOptionalDependency as missing
     except Exception:
         missing = NotImplementedError
     with pytest.raises((NotImplementedError, ImportError, ModuleNotFoundError, missing)):
-        dense_lk(frames, fd_method=fd_method)
+        dense_lk(frames, fd_method=fd_method, fd_kwargs=fd_kwargs)
 
 
 def test_other_interpolation_method_runs_on_the_hip_sparse_stage(dense_lk, ref_pysteps):

@@ -95,7 +95,7 @@ if fetch and write:
         "fetch_correction": 2.0,
         "hbm_bytes_per_launch": (2.0 * fetch[0] + write[0]) * 1024.0,
         "kernel_ms_under_pmc": fetch[1],
-        "alg_bytes_per_launch": bench["roofline"]["alg_bytes_per_launch"],
+        "alg_bytes_per_launch": (bench["roofline"].get("hbm") or bench["roofline"])["alg_bytes_per_launch"],
         "source": "gpurun_out/%s pmc_fetch + pmc_write (rocprofv3 --pmc, separate passes)" % tag,
         "source_hashes": {src: blob_hash(src) for src in SL_SOURCES},
     }
