@@ -837,6 +837,24 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
                      : "v"(ap), "i"(C::kPitch4), "i"(C::kPitch4 + 4u));
       }
     }
+    // make_weights(): gx = 1 - fx, gy = 1 - fy; {gy gx, gy fx, fy gx, fy fx} (products commute bit for bit).  They only
+    // need the fractions: computed while the reads are in flight (round 6: 0.98 -> 0.945 ms in the bench's leg,
+    // profiles/r06/n_window_early_weights_ab.txt).  The two scalar products as asm: left to the compiler the eight of a
+    // lane's four pixels become packed multiplies fed by a dozen register moves; an empty volatile asm that reads the
+    // pair keeps everything in front of the wait.  (Not in the instantiation for the other boundary modes, which has no
+    // registers to spare during the wait: two would spill.)
+    f32x2 w_mid[kWinRows];  // (fx gy, fy gx) = (w01, w10)
+    float w_00[kWinRows], w_11[kWinRows];
+    if constexpr (!GEN) {
+#pragma unroll
+      for (int j = 0; j < kWinRows; ++j) {
+        const f32x2 g = 1.f - f[j];
+        w_mid[j] = f[j] * g.yx;
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(w_00[j]) : "v"(g.x), "v"(g.y));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(w_11[j]) : "v"(f[j].x), "v"(f[j].y));
+        asm volatile("" ::"v"(w_mid[j]));
+      }
+    }
 #define PSH_TIE4(A, J) "+v"(A[J][0]), "+v"(A[J][1]), "+v"(A[J][2]), "+v"(A[J][3])
     if constexpr (kWinRows == 4) {
       asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(t, 0), PSH_TIE4(t, 1), PSH_TIE4(t, 2), PSH_TIE4(t, 3));
@@ -848,11 +866,17 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
 #undef PSH_TIE4
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
-      // make_weights(): gx = 1 - fx, gy = 1 - fy; {gy gx, gy fx, fy gx, fy fx} (products commute bit for bit)
-      const f32x2 g = 1.f - f[j];
-      const f32x2 w00 = g * g.yx;        // (gx gy, gy gx): w00 in both halves
-      const f32x2 wmid = f[j] * g.yx;    // (fx gy, fy gx) = (w01, w10)
-      const f32x2 w11 = f[j] * f[j].yx;  // (fx fy, fy fx): w11 in both halves
+      f32x2 w00, wmid, w11;
+      if constexpr (GEN) {
+        const f32x2 g = 1.f - f[j];
+        w00 = g * g.yx;        // (gx gy, gy gx): w00 in both halves
+        wmid = f[j] * g.yx;    // (fx gy, fy gx) = (w01, w10)
+        w11 = f[j] * f[j].yx;  // (fx fy, fy fx): w11 in both halves
+      } else {
+        w00 = f32x2{w_00[j], w_00[j]};
+        wmid = w_mid[j];
+        w11 = f32x2{w_11[j], w_11[j]};
+      }
       f32x2 acc = t[j][0] * f32x2{w00.x, w00.x};  // the order of sample_interior_packed
       acc = __builtin_elementwise_fma(f32x2{wmid.x, wmid.x}, t[j][1], acc);
       acc = __builtin_elementwise_fma(f32x2{wmid.y, wmid.y}, t[j][2], acc);

@@ -18,6 +18,7 @@ NOISE_NAMES = {"parametric_hip": "parametric", "nonparametric_hip": "nonparametr
 BPS_NAME = "bps_hip"  # vel_pert_method: the reference's generate_bps behind an initialiser that shares the unit fields
 EXTRAPOLATION_NAMES = ("semilagrangian_hip",)
 MOTION_NAMES = ("lk_hip", "lucaskanade_hip")
+FEATURE_NAMES = {"blob_hip": "blob", "shitomasi_hip": "shitomasi"}  # pysteps.feature.get_method(...)
 _STOCK_EXTRAPOLATION = ("semilagrangian",)
 _STOCK_MOTION = ("lk", "lucaskanade")
 
@@ -110,6 +111,25 @@ def register_spectral():
 
     noise_if._noise_methods[BPS_NAME] = (initialize_bps, noise_if._noise_methods["bps"][1])
     added.append("noise:" + BPS_NAME)
+    return added
+
+
+def register_features(override=False):
+    """Insert the HIP feature detectors into the reference's table (pysteps/feature/interface.py:26-29
+    ``_detection_methods``) as ``"blob_hip"`` / ``"shitomasi_hip"`` (and under the stock names with ``override``):
+    ``pysteps.feature.get_method("blob_hip")``, and through it ``dense_lucaskanade(fd_method="blob_hip")`` of the
+    REFERENCE's Lucas-Kanade routine, then run the scale-space / corner kernels.  (``pysteps_amd``'s own
+    ``dense_lucaskanade`` takes ``fd_method="blob"`` / ``"shitomasi"`` directly.)"""
+    import pysteps.feature.interface as feat_if  # noqa: PLC0415
+
+    from .feature import blob, shitomasi  # noqa: PLC0415
+
+    added = []
+    for name, stock in FEATURE_NAMES.items():
+        fn = blob.detection if stock == "blob" else shitomasi.detection
+        for key in (name,) + ((stock,) if override else ()):
+            feat_if._detection_methods[key] = fn
+            added.append("feature:" + key)
     return added
 
 
@@ -222,6 +242,10 @@ def register(override=False, patch_main_loop=False, fft=True, probmatching=False
     import pysteps.motion.interface as mot_if  # noqa: PLC0415
 
     added = register_into(mot_if._methods, ext_if._extrapolation_methods, override=override)
+    try:
+        added += register_features(override=override)
+    except ImportError:
+        pass  # pysteps.feature needs none of its optional dependencies at import time; a stripped-down install may lack it
     if fft:
         added += register_fft()
         added += register_spectral()

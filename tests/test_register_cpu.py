@@ -85,3 +85,25 @@ def test_fft_method_name_resolves_through_the_reference_lookup(ref_pysteps):
     assert not hasattr(interface.get_method, "_pysteps_amd_reference")
     with pytest.raises(ValueError):
         utils.get_method("hip", shape=(64, 64))
+
+
+def test_feature_detectors_resolve_through_the_reference_lookup(ref_pysteps):
+    """register() adds "blob_hip" / "shitomasi_hip" to pysteps.feature's table (feature/interface.py:26-29); the stock
+    names keep the reference's functions unless override is asked for."""
+    import pysteps.feature.interface as feat_if
+    from pysteps import feature
+
+    from pysteps_amd.feature import blob, shitomasi
+
+    saved = dict(feat_if._detection_methods)
+    try:
+        added = register.register_features()
+        assert set(added) == {"feature:blob_hip", "feature:shitomasi_hip"}
+        assert feature.get_method("blob_hip") is blob.detection and feature.get_method("Shitomasi_HIP") is shitomasi.detection
+        assert feature.get_method("blob") is saved["blob"] and feature.get_method("shitomasi") is saved["shitomasi"]
+        register.register_features(override=True)
+        assert feature.get_method("blob") is blob.detection and feature.get_method("shitomasi") is shitomasi.detection
+        assert feature.get_method("tstorm") is saved["tstorm"]
+    finally:
+        feat_if._detection_methods.clear()
+        feat_if._detection_methods.update(saved)

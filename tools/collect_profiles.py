@@ -61,7 +61,7 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
             counters.setdefault(kernel, {})[counter] = float(value)  # per instantiation (names cut at 40 characters)
         for k in list(counters):
             base = k.split("<")[0]
-            chosen = table.get(base, {}).get("instantiation", base)[:40]
+            chosen = table.get(base, {}).get("instantiation", base)[:40].strip()
             if "<" in k and k == chosen:
                 counters[base] = dict(counters[k])  # the base name carries its dominant instantiation's counters
         shutil.copy(summary, os.path.join(dst, "%s_pmc_kernels.csv" % prefix))
