@@ -845,6 +845,38 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
     // registers to spare during the wait: two would spill.)
     f32x2 w_mid[kWinRows];  // (fx gy, fy gx) = (w01, w10)
     float w_00[kWinRows], w_11[kWinRows];
+#ifndef PSH_WIN_NO_PAIR_WEIGHTS
+    // the sample that also reads the field: every weight as a register PAIR over two vertically adjacent pixels - what
+    // the packed blend of the field's taps multiplies with (the compiler packs that blend itself and otherwise builds
+    // these pairs by eight register moves BEHIND the wait); the velocity blends pick their half by op_sel
+    constexpr bool kPairs = !GEN && kWithP && kWinRows == 4;
+    f32x2 q00[2], q01[2], q10[2], q11[2];
+    if constexpr (kPairs) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const f32x2 fa = f[2 * pr], fb = f[2 * pr + 1];
+        const f32x2 ga = 1.f - fa, gb = 1.f - fb;
+        float a00, b00, a01, b01, a10, b10, a11, b11;
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a00) : "v"(ga.x), "v"(ga.y));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(b00) : "v"(gb.x), "v"(gb.y));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a01) : "v"(fa.x), "v"(ga.y));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(b01) : "v"(fb.x), "v"(gb.y));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a10) : "v"(fa.y), "v"(ga.x));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(b10) : "v"(fb.y), "v"(gb.x));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a11) : "v"(fa.x), "v"(fa.y));
+        asm volatile("v_mul_f32 %0, %1, %2" : "=v"(b11) : "v"(fb.x), "v"(fb.y));
+        q00[pr] = f32x2{a00, b00};
+        q01[pr] = f32x2{a01, b01};
+        q10[pr] = f32x2{a10, b10};
+        q11[pr] = f32x2{a11, b11};
+        // (in-out: behind this the pairs are opaque two-element values, so the velocity blends of the second pixel take
+        // their half by op_sel instead of a register move)
+        asm volatile("" : "+v"(q00[pr]), "+v"(q01[pr]), "+v"(q10[pr]), "+v"(q11[pr]));
+      }
+    } else
+#else
+    constexpr bool kPairs = false;
+#endif
     if constexpr (!GEN) {
 #pragma unroll
       for (int j = 0; j < kWinRows; ++j) {
@@ -856,6 +888,19 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
       }
     }
 #define PSH_TIE4(A, J) "+v"(A[J][0]), "+v"(A[J][1]), "+v"(A[J][2]), "+v"(A[J][3])
+#ifndef PSH_WIN_NO_STAGED_WAIT
+    if constexpr (kWinRows == 4 && !GEN) {
+      // LDS answers in order: the first pixel pair's taps are there once at most the second pair's reads are
+      // outstanding (the counter has four bits: of 32 reads the first 17 are the least that can be waited for)
+      if (kWithP) {
+        asm volatile("s_waitcnt lgkmcnt(15)" : PSH_TIE4(t, 0), PSH_TIE4(t, 1));
+        asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(8)" : PSH_TIE4(t, 0), PSH_TIE4(t, 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else
+#endif
     if constexpr (kWinRows == 4) {
       asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(t, 0), PSH_TIE4(t, 1), PSH_TIE4(t, 2), PSH_TIE4(t, 3));
       if (kWithP) asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1), PSH_TIE4(rp, 2), PSH_TIE4(rp, 3));
@@ -863,9 +908,50 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
       asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(t, 0), PSH_TIE4(t, 1));
       if (kWithP) asm volatile("" : PSH_TIE4(rp, 0), PSH_TIE4(rp, 1));
     }
-#undef PSH_TIE4
+#ifndef PSH_WIN_NO_PAIR_WEIGHTS
+    if constexpr (kPairs) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int a = 2 * pr, b = 2 * pr + 1;
+#ifndef PSH_WIN_NO_STAGED_WAIT
+        if (pr == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(t, 2), PSH_TIE4(t, 3));
+          asm volatile("" : PSH_TIE4(rp, 2), PSH_TIE4(rp, 3));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+        f32x2 acc = t[a][0] * f32x2{q00[pr].x, q00[pr].x};  // the order of sample_interior_packed
+        acc = __builtin_elementwise_fma(f32x2{q01[pr].x, q01[pr].x}, t[a][1], acc);
+        acc = __builtin_elementwise_fma(f32x2{q10[pr].x, q10[pr].x}, t[a][2], acc);
+        acc = __builtin_elementwise_fma(f32x2{q11[pr].x, q11[pr].x}, t[a][3], acc);
+        s_uv[a] = acc;
+        acc = t[b][0] * f32x2{q00[pr].y, q00[pr].y};
+        acc = __builtin_elementwise_fma(f32x2{q01[pr].y, q01[pr].y}, t[b][1], acc);
+        acc = __builtin_elementwise_fma(f32x2{q10[pr].y, q10[pr].y}, t[b][2], acc);
+        acc = __builtin_elementwise_fma(f32x2{q11[pr].y, q11[pr].y}, t[b][3], acc);
+        s_uv[b] = acc;
+        f32x2 ps = q00[pr] * f32x2{rp[a][0], rp[b][0]};
+        ps = __builtin_elementwise_fma(q01[pr], f32x2{rp[a][1], rp[b][1]}, ps);
+        ps = __builtin_elementwise_fma(q10[pr], f32x2{rp[a][2], rp[b][2]}, ps);
+        ps = __builtin_elementwise_fma(q11[pr], f32x2{rp[a][3], rp[b][3]}, ps);
+        sp[a] = ps.x;
+        sp[b] = ps.y;
+      }
+    } else
+#endif
 #pragma unroll
     for (int j = 0; j < kWinRows; ++j) {
+#ifndef PSH_WIN_NO_STAGED_WAIT
+      if constexpr (kWinRows == 4 && !GEN) {
+        if (j == 2) {
+          __builtin_amdgcn_sched_barrier(0);  // the first pair's blends stay in front of the second wait
+          asm volatile("s_waitcnt lgkmcnt(0)" : PSH_TIE4(t, 2), PSH_TIE4(t, 3));
+          if (kWithP) asm volatile("" : PSH_TIE4(rp, 2), PSH_TIE4(rp, 3));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#endif
       f32x2 w00, wmid, w11;
       if constexpr (GEN) {
         const f32x2 g = 1.f - f[j];
@@ -884,6 +970,7 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
       s_uv[j] = acc;
       if (kWithP) sp[j] = fmaf(w11.x, rp[j][3], fmaf(wmid.y, rp[j][2], fmaf(wmid.x, rp[j][1], w00.x * rp[j][0])));
     }
+#undef PSH_TIE4
   } else {
     win_count(W, 1);
     int X[kWinRows], Y[kWinRows];
@@ -1002,6 +1089,9 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
     const int yt = row0 + (tile / tiles_x) * C::kTileY + static_cast<int>(threadIdx.x / kTileX) * kWinRows;
     const int x = min(xt, n - 1);
     float *out = out_base;
+#ifndef PSH_WIN_MASKED_STORES
+    const int out_plane_bytes = static_cast<int>(static_cast<unsigned>(__mul24(rows, n)) * 4u);  // (< 0xfffffff0: semilag_window_eligible)
+#endif
     Window W;
     W.uv = static_cast<unsigned>(reinterpret_cast<size_t>((lds_void *)win_planes));  // 8-byte texels
     W.p = W.uv + 2u * C::kPlaneBytes;
@@ -1022,6 +1112,9 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
       live[j] = xt < n && yt + j < row0 + rows;
       y[j] = min(yt + j, m - 1);
       opix[j] = static_cast<unsigned>(__mul24(y[j] - row0, n) + x) << 2;
+#ifndef PSH_WIN_MASKED_STORES
+      if (!live[j]) opix[j] = 0xfffffff0u;
+#endif
       int px = x, py = y[j];
       float ifx = 0.f, ify = 0.f, ivx = 0.f, ivy = 0.f;
       if (resume) {
@@ -1079,7 +1172,15 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
 #pragma unroll
       for (int j = 0; j < kWinRows; ++j) {
         const float val = lost(f[j].x, f[j].y) ? lostval : sp[j];
+#ifndef PSH_WIN_MASKED_STORES
+        // one plane of the output as a buffer whose base moves (scalar adds) from lead step to lead step: the lane's
+        // offset is all the address arithmetic, and the pixels outside the image or the band sit behind the buffer's
+        // end, where the hardware drops the store - no exec mask, no branch
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), __builtin_amdgcn_make_buffer_rsrc(out, 0, out_plane_bytes, 0x00020000),
+                                              static_cast<int>(opix[j]), 0, 2 /* nt */);
+#else
         if (live[j]) __builtin_nontemporal_store(val, reinterpret_cast<float *>(reinterpret_cast<char *>(out) + opix[j]));
+#endif
       }
       out += static_cast<size_t>(rows) * n;
       if (t + 1 < T) {
@@ -1110,7 +1211,9 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
 static bool window_shape(int m, int n) { return n % 4 == 0 && n >= Win8::kW && m >= Win8::kH; }
 
 bool semilag_window_eligible(const SemilagArgs &a) {
+  // (a plane of the output below 0xfffffff0 bytes: the lanes without a pixel store to that offset, behind the buffer's end)
   return a.precip != nullptr && a.order == 1 && a.n_iter >= 1 && window_shape(a.m, a.n) &&
+         static_cast<size_t>(a.m) * a.n * sizeof(float) < 0xfffffff0ull &&
          reinterpret_cast<uintptr_t>(a.vel) % 16 == 0 && reinterpret_cast<uintptr_t>(a.precip) % 16 == 0 &&
          (static_cast<size_t>(a.m) * a.n) % 4 == 0;
 }

@@ -2,8 +2,8 @@
 ``s_waitcnt lgkmcnt(0)`` behind them is tied to their destinations through "+v" constraints only.  A compiler
 upgrade that put a copy or a spill of such a destination between a read and the wait would read the register before
 the LDS has answered - silently wrong numbers.  This test compiles ``csrc/semilag.hip`` to gfx950 assembly (no GPU
-needed) and fails if, anywhere in a ``semilag_window`` kernel, an instruction between an asm ``ds_read`` and the next
-``s_waitcnt lgkmcnt(0)`` touches a register one of the pending reads writes, if a basic block ends with reads pending,
+needed) and fails if, anywhere in a ``semilag_window`` kernel, an instruction touches a register a read still in flight
+writes (reads complete in order: ``s_waitcnt lgkmcnt(N)`` leaves the N youngest pending), if a basic block ends with reads pending,
 or if the default kernel uses scratch memory (a VGPR spill inside the 128-register budget of four waves per SIMD)."""
 import os
 import re
@@ -48,7 +48,7 @@ def test_no_instruction_touches_a_pending_lds_destination(window_asm):
     assert len(kernels) >= 2, list(kernels)
     groups = 0
     for name, body in kernels.items():
-        pending, in_asm = set(), False
+        pending, in_asm = [], False  # destination sets of the reads in flight, oldest first (the LDS answers in order)
         for line in body.splitlines():
             code = line.split(";")[0].strip() if not line.lstrip().startswith(";;#") else line.strip()
             if code.startswith(";;#ASMSTART"):
@@ -66,17 +66,24 @@ def test_no_instruction_touches_a_pending_lds_destination(window_asm):
                 continue
             if in_asm and code.startswith("ds_read"):
                 dest = code.split(",")[0]
-                pending |= _regs(dest)
+                pending.append(_regs(dest))
                 continue
-            if "s_waitcnt" in code and "lgkmcnt(0)" in code:
-                if pending:
+            waited = re.search(r"s_waitcnt.*lgkmcnt\((\d+)\)", code)
+            if waited:
+                # at most N operations outstanding afterwards: everything but the N youngest reads has landed (the
+                # counter saturates at 15 - more reads than that cannot be in flight, the sequencer stalls the issue)
+                keep = int(waited.group(1))
+                if pending and keep == 0:
                     groups += 1
-                pending = set()
+                pending = pending[len(pending) - keep:] if keep < len(pending) else pending
+                if keep == 0:
+                    pending = []
                 continue
             if pending:
+                in_flight = set().union(*pending)
                 assert not code.startswith(("s_cbranch", "s_branch", "s_endpgm")), (name, line)
-                assert not code.startswith(("scratch_", "buffer_store")) or not (_regs(code) & pending), (name, line)
-                hit = _regs(code) & pending
+                assert not code.startswith(("scratch_", "buffer_store")) or not (_regs(code) & in_flight), (name, line)
+                hit = _regs(code) & in_flight
                 assert not hit, "%s: `%s` touches v%s while its ds_read is in flight" % (name, code, sorted(hit))
     assert groups >= 6  # three sampling passes per kernel at least
 
