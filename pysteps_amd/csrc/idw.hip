@@ -617,33 +617,31 @@ __device__ __forceinline__ void idw_accumulate2(const float4 c, const float2v px
   sv = __builtin_elementwise_fma(w, float2v{c.w, c.w}, sv);
 }
 
-// the `need` nearest of a ring of <= 8 vectors: every member ranks itself among the others (ties: lower index
+// the `need` nearest of a ring of NR <= 8 vectors: every member ranks itself among the others (ties: lower index
 // first, as the second sweep of add_nearest takes them) - for the lane's TWO pixels: distances and weights in packed instructions, the ranks per component (a
-// compare has no packed form); a vector that is not among a pixel's `need` nearest enters its sums with weight zero
-template <bool HALF>
-__device__ __forceinline__ void idw_small_ring2(const float4 *ring, int n_ring, int need, const float2v px, float py,
+// compare has no packed form); a vector that is not among a pixel's `need` nearest enters its sums with weight zero.
+// One instantiation per ring size (the ring is tile-uniform): NR (NR - 1) comparisons per pixel instead of the 56 of
+// an eight-slot ring padded with +inf - a ring holds four or five vectors as a rule.
+template <bool HALF, int NR>
+__device__ __forceinline__ void idw_small_ring2(const float4 *ring, int need, const float2v px, float py,
                                                 float inv_res, float power, float offset, float2v &sw, float2v &su,
                                                 float2v &sv) {
-  float2v d2[8];
+  float2v d2[NR];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    d2[j] = float2v{INFINITY, INFINITY};
-    if (j < n_ring) {  // (uniform)
-      const float4 c = ring[j];
-      const float2v dx = float2v{c.x, c.x} - px;
-      const float dy = c.y - py;
-      const float dy2 = dy * dy;
-      d2[j] = __builtin_elementwise_fma(dx, dx, float2v{dy2, dy2});  // = dist2() per component
-    }
+  for (int j = 0; j < NR; ++j) {
+    const float4 c = ring[j];
+    const float2v dx = float2v{c.x, c.x} - px;
+    const float dy = c.y - py;
+    const float dy2 = dy * dy;
+    d2[j] = __builtin_elementwise_fma(dx, dx, float2v{dy2, dy2});  // = dist2() per component
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j >= n_ring) break;  // (uniform)
+  for (int j = 0; j < NR; ++j) {
     int rank_a = 0, rank_b = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NR; ++i) {
       if (i == j) continue;
-      // (missing members: +inf; ties go to the lower index)
+      // (ties go to the lower index)
       rank_a += (i < j ? d2[i].x <= d2[j].x : d2[i].x < d2[j].x) ? 1 : 0;
       rank_b += (i < j ? d2[i].y <= d2[j].y : d2[i].y < d2[j].y) ? 1 : 0;
     }
@@ -661,6 +659,29 @@ __device__ __forceinline__ void idw_small_ring2(const float4 *ring, int n_ring, 
     sw += w;
     su = __builtin_elementwise_fma(w, float2v{c.z, c.z}, su);
     sv = __builtin_elementwise_fma(w, float2v{c.w, c.w}, sv);
+  }
+}
+
+template <bool HALF>
+__device__ __forceinline__ void idw_small_ring2(const float4 *ring, int n_ring, int need, const float2v px, float py,
+                                                float inv_res, float power, float offset, float2v &sw, float2v &su,
+                                                float2v &sv) {
+  switch (n_ring) {  // (uniform)
+#define PSH_RING_CASE(NR)                                                                      \
+  case NR:                                                                                     \
+    idw_small_ring2<HALF, NR>(ring, need, px, py, inv_res, power, offset, sw, su, sv);         \
+    break;
+    PSH_RING_CASE(1)
+    PSH_RING_CASE(2)
+    PSH_RING_CASE(3)
+    PSH_RING_CASE(4)
+    PSH_RING_CASE(5)
+    PSH_RING_CASE(6)
+    PSH_RING_CASE(7)
+    PSH_RING_CASE(8)
+#undef PSH_RING_CASE
+    default:
+      break;
   }
 }
 
