@@ -284,7 +284,7 @@ int psh_rbf_eval_dev(const double *xy_dev, const double *weights_dev, int N, int
  *      method 1 (DoG): cube[k] = (G(sigma_k) - G(sigma_k+1)) image * sigma_k,    K = nsig - 1
  *      radius_host[k] = int(4 sigma_k + 0.5); weights_host: per scale 2 (radius + 1) doubles - centre and distances
  *      1 .. radius of the smoothing kernel, then of the second-derivative kernel (scipy's _gaussian_kernel1d, evaluated
- *      by the caller with NumPy like SciPy does).  Asynchronous.
+ *      by the caller with NumPy like SciPy does).  The kernels are queued; the host arrays may go when the call returns.
  *  psh_blob_peaks_dev   skimage peak_local_max(cube, threshold_abs, footprint ones(3,3,3), exclude_border False) as
  *      blob_log calls it: coords_host (capacity, 3) int32 (row, column, scale index) and their values, unordered;
  *      *count_host = number of peaks (above capacity: call again with more room).  Waits.

@@ -225,8 +225,10 @@ int blob_cube(const T *image, int m, int n, int method, const double *sigmas, in
   T *tmp_a = reinterpret_cast<T *>(base + wbytes), *tmp_b = reinterpret_cast<T *>(base + wbytes + pbytes);
   T *g_prev = reinterpret_cast<T *>(base + wbytes + 2 * pbytes), *g_cur = reinterpret_cast<T *>(base + wbytes + 3 * pbytes);
   auto run = [&]() -> int {
-    // (pageable source: the copy is staged by the runtime before it returns, the caller's array may go)
+    // (the caller's array may go once this call returns: the copy is waited for - a detection is not a launch chain
+    // anybody queues behind)
     PSH_HIP(hipMemcpyAsync(w_dev, weights, wtotal * sizeof(double), hipMemcpyHostToDevice, stream));
+    PSH_HIP(hipStreamSynchronize(stream));
     const dim3 grid0((n + 63) / 64, (m + 3) / 4), grid1((n + kBlobThreads - 1) / kBlobThreads, m);
     const size_t lds = 2 * static_cast<size_t>(kBlobThreads + 2 * rmax) * sizeof(double);
     if (lds > 64 * 1024) PSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blob_corr_axis1<T>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));

@@ -651,6 +651,9 @@ struct Window {
   // where the corner samples of a patch may be without asking for a new window (pre-scaled columns / rows):
   // set when a window is placed, from the direction and speed of travel
   int lo_x, hi_x, lo_y, hi_y;
+  // the window reaches beyond the image (uniform): its texels out there hold what the border rules read - the motion
+  // field's edge values replicated, the advected field's mirror texel at index len - and a field sample may lie outside
+  int edge;
   unsigned long long *stats;
 };
 
@@ -687,7 +690,7 @@ __device__ __forceinline__ void win_publish(const Window &W, int wave, const Win
 
 // Every wave of the workgroup, with every wave's box published and nobody reading the window any more: place the
 // new window ahead of the motion, re-base the offsets, fill it.  (The caller orders the LDS writes before the next reader.)
-template <class C>
+template <class C, bool GEN>
 __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, bool force, int (&dxw)[C::kRows],
                                                     int (&dy)[C::kRows], float move_scale, int m, int n) {
   constexpr int kWinRows = C::kRows;
@@ -708,9 +711,18 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
   // the samples towards lower coordinates), two where it comes from, half of it in calm air
   const int keep_x = wvx > 0.125f ? max(slack_x - 2, 0) : (wvx < -0.125f ? min(slack_x, 2) : slack_x / 2);
   const int keep_y = wvy > 0.125f ? max(slack_y - 2, 0) : (wvy < -0.125f ? min(slack_y, 2) : slack_y / 2);
-  const int nox = rfl(min(max((W.ox + bx0 - keep_x) & ~3, 0), n - C::kW));  // 16-byte aligned rows
-  const int noy = rfl(min(max(W.oy + by0 - keep_y, 0), m - C::kH));
-  PSH_DASSERT(nox >= 0 && nox + C::kW <= n && (nox & 3) == 0 && noy >= 0 && noy + C::kH <= m);  // the window lies in the image
+  // 16-byte aligned rows.  With the "constant" rule for the advected field (every instantiation but GEN) the window
+  // FOLLOWS the samples out of the image: out there its texels are filled with what the border rules read (below), so
+  // a tile whose trajectories leave the image keeps sampling from LDS instead of taking every pass through the gathers
+  // (round 6; 6 % of the kernel's time at 4096^2).  The other boundary modes keep the window inside the image: their
+  // samples out there go through sample_at<>.
+  constexpr int kFar = 1 << 27;  // (a saturated box - a trajectory at the end of the number line - places the window nowhere useful)
+  const int want_x = min(max(sat_add(W.ox, sat_sub(bx0, keep_x)), -kFar), kFar) & ~3;
+  const int want_y = min(max(sat_add(W.oy, sat_sub(by0, keep_y)), -kFar), kFar);
+  const int nox = rfl(GEN ? min(max(want_x, 0), n - C::kW) : want_x);
+  const int noy = rfl(GEN ? min(max(want_y, 0), m - C::kH) : want_y);
+  const bool edge = !GEN && (nox < 0 || nox + C::kW > n || noy < 0 || noy + C::kH > m);  // (uniform)
+  PSH_DASSERT((nox & 3) == 0 && (edge || (nox >= 0 && nox + C::kW <= n && noy >= 0 && noy + C::kH <= m)));  // the window lies in the image
   // the room a patch needs ahead of its corner samples before the next lead step (the distance the last one covered + 2);
   // a lost trajectory (NaN) asks for nothing
   const float mvx = fabsf(wvx) < 64.f ? fabsf(wvx) * move_scale + 2.f : 2.f, mvy = fabsf(wvy) < 64.f ? fabsf(wvy) * move_scale + 2.f : 2.f;
@@ -730,20 +742,54 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
   }
   W.ox = nox;
   W.oy = noy;
+  W.edge = edge ? 1 : 0;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));  // opaque: the item addresses below are not loop invariants worth their registers
   constexpr int kRounds = (C::kItems + C::kThreads - 1) / C::kThreads;
   // (threads past the last item repeat it: the same bytes to the same place, and no exec-masked rounds)
   u32x4 bu[kRounds], bv[kRounds], bp[kRounds];
-  const unsigned org = static_cast<unsigned>(noy) * static_cast<unsigned>(n) + static_cast<unsigned>(nox);
+  if (!edge) {
+    const unsigned org = static_cast<unsigned>(noy) * static_cast<unsigned>(n) + static_cast<unsigned>(nox);
 #pragma unroll
-  for (int k = 0; k < kRounds; ++k) {
-    const int item = min(tid + C::kThreads * k, C::kItems - 1);
-    const int row = item / (C::kW / 4), c = item - row * (C::kW / 4);
-    const int off = static_cast<int>((org + row * n + 4 * c) << 2);
-    bu[k] = __builtin_amdgcn_raw_buffer_load_b128(F.ru, off, 0, 0);
-    bv[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rv, off, 0, 0);
-    bp[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rp, off, 0, 0);
+    for (int k = 0; k < kRounds; ++k) {
+      const int item = min(tid + C::kThreads * k, C::kItems - 1);
+      const int row = item / (C::kW / 4), c = item - row * (C::kW / 4);
+      const int off = static_cast<int>((org + row * n + 4 * c) << 2);
+      bu[k] = __builtin_amdgcn_raw_buffer_load_b128(F.ru, off, 0, 0);
+      bv[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rv, off, 0, 0);
+      bp[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rp, off, 0, 0);
+    }
+  } else {
+    // A window that reaches beyond the image.  Motion field, mode "nearest" (sample_velocity_border): every tap index is
+    // clamped on its own - texel (r, x) holds the value at (clamp r, clamp x).  Advected field, mode "constant"
+    // (sample_precip_border): a sample outside [0, len - 1] is outval whatever the taps are (win_sample decides that
+    // from the position), and the one in-range sample that touches index len - coordinate len - 1 exactly, weight 0 -
+    // reads the MIRROR texel len - 2 (0 x NaN matters): texel len holds the value at len - 2.  n % 4 == 0 and the
+    // window's columns start at a multiple of 4, so a 16-byte item lies inside the image's columns or outside as a whole.
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+      const int item = min(tid + C::kThreads * k, C::kItems - 1);
+      const int row = item / (C::kW / 4), c = item - row * (C::kW / 4);
+      const int r = noy + row, x = nox + 4 * c;
+      const int rv = min(max(r, 0), m - 1), rq = r == m ? m - 2 : rv;
+      const int xi = min(max(x, 0), n - 4);
+      const int off_v = static_cast<int>(static_cast<unsigned>(__mul24(rv, n) + xi) << 2);
+      const int off_q = static_cast<int>(static_cast<unsigned>(__mul24(rq, n) + xi) << 2);
+      u32x4 tu = __builtin_amdgcn_raw_buffer_load_b128(F.ru, off_v, 0, 0);
+      u32x4 tv = __builtin_amdgcn_raw_buffer_load_b128(F.rv, off_v, 0, 0);
+      u32x4 tq = __builtin_amdgcn_raw_buffer_load_b128(F.rp, off_q, 0, 0);
+      if (x < 0) {  // left of the image: column 0
+        tu = u32x4{tu.x, tu.x, tu.x, tu.x};
+        tv = u32x4{tv.x, tv.x, tv.x, tv.x};
+      } else if (x >= n) {  // right of it: column n - 1 for the motion field, n - 2 (the mirror of n) for the advected field
+        tu = u32x4{tu.w, tu.w, tu.w, tu.w};
+        tv = u32x4{tv.w, tv.w, tv.w, tv.w};
+        tq = u32x4{tq.z, tq.z, tq.z, tq.z};
+      }
+      bu[k] = tu;
+      bv[k] = tv;
+      bp[k] = tq;
+    }
   }
 #pragma unroll
   for (int k = 0; k < kRounds; ++k) {
@@ -759,7 +805,7 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
 // window if they are about to leave this one, agree at ONE barrier, and if anybody asked: place, re-base, fill,
 // second barrier.  `phase` cycles through three flag words so that clearing the next one never races with a wave
 // that still has to read it.
-template <class C>
+template <class C, bool GEN>
 __device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase, bool force, int (&dxw)[C::kRows],
                                             int (&dy)[C::kRows], float vx_lane, float vy_lane, float move_scale, int m,
                                             int n) {
@@ -776,7 +822,7 @@ __device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase
   if (rfl(ctl[C::kCtlFlag / 4 + phase]) == 0) return;
   // every wave is past the barrier: nobody reads the old window any more.  The boxes of this step are overwritten
   // after the barrier below - every wave has read them by then
-  win_place_and_fill<C>(F, W, force, dxw, dy, move_scale, m, n);
+  win_place_and_fill<C, GEN>(F, W, force, dxw, dy, move_scale, m, n);
   win_barrier();
 }
 
@@ -971,6 +1017,16 @@ __device__ __forceinline__ void win_sample(const Fields &F, const Window &W, con
       if (kWithP) sp[j] = fmaf(w11.x, rp[j][3], fmaf(wmid.y, rp[j][2], fmaf(wmid.x, rp[j][1], w00.x * rp[j][0])));
     }
 #undef PSH_TIE4
+    if constexpr (kWithP && !GEN) {
+      if (W.edge) {  // (uniform) sample_precip_border's rule: outside [0, len - 1] the sample is outval
+#pragma unroll
+        for (int j = 0; j < kWinRows; ++j) {
+          const int X = sat_add(W.ox, dxw[j]), Y = sat_add(W.oy, dy[j]);
+          const bool outside = X < 0 || Y < 0 || X > n - 1 || Y > m - 1 || (X == n - 1 && f[j].x > 0.f) || (Y == m - 1 && f[j].y > 0.f);
+          sp[j] = outside ? outval : sp[j];
+        }
+      }
+    }
   } else {
     win_count(W, 1);
     int X[kWinRows], Y[kWinRows];
@@ -1099,6 +1155,7 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
     W.ox = W.oy = 0;
     W.lo_x = W.lo_y = 0;
     W.hi_x = W.hi_y = 0;
+    W.edge = 0;
     W.stats = stats;
     if (threadIdx.x < 3) win_ctl[C::kCtlFlag / 4 + threadIdx.x] = 0;
 
@@ -1134,7 +1191,7 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
     }
     __syncthreads();
     int phase = 0;
-    win_update<C>(F, W, phase, true, dxw, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
+    win_update<C, GEN>(F, W, phase, true, dxw, dy, 0.5f * vi[0].x, 0.5f * vi[0].y, move_scale, m, n);
     phase = 1;
     if (resume == 1) {
       win_sample<C, kVel, GEN>(F, W, dxw, dy, f, m, n, outval, s_uv, sp);
@@ -1184,7 +1241,7 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
       }
       out += static_cast<size_t>(rows) * n;
       if (t + 1 < T) {
-        win_update<C>(F, W, phase, false, dxw, dy, vi[0].x, vi[0].y, move_scale, m, n);
+        win_update<C, GEN>(F, W, phase, false, dxw, dy, vi[0].x, vi[0].y, move_scale, m, n);
         phase = phase == 2 ? 0 : phase + 1;
       }
     }

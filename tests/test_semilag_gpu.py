@@ -541,6 +541,53 @@ def test_window_kernel_on_hard_motion_fields(extrapolate, field):
         assert np.array_equal(got, want, equal_nan=True)
 
 
+@pytest.mark.parametrize("flow", ["out_right_down", "out_left_up", "diverging", "still_edges"])
+def test_window_follows_the_samples_out_of_the_image(extrapolate, flow):
+    """Since round 6 the window kernel's window leaves the image with the samples: its texels out there hold what the border
+    rules read - the motion field's edge values replicated (mode "nearest": every tap index clamped on its own), the
+    advected field's mirror texel at index len (the one in-range sample that touches it has weight 0 there, and 0 x NaN
+    matters) - and samples outside [0, len - 1] become outval.  Against the gather kernels (``semilag_variant`` 7) bit for
+    bit and against the oracle, on flows that carry whole tiles hundreds of pixels out of the image, with NaNs in the
+    advected field's last two columns / rows and a motion field at rest along the edges (coordinate len - 1 exactly)."""
+    from oracle import semilag_cport as ocl
+    from pysteps_amd import _lib
+    from tools import synth
+
+    m, n = 352, 480
+    y, x = np.mgrid[0:m, 0:n].astype(np.float64)
+    if flow == "out_right_down":
+        v = np.stack([-23.0 - 0.01 * y, -17.0 + 0.02 * x])  # negative velocity: samples travel towards higher coordinates
+    elif flow == "out_left_up":
+        v = np.stack([31.0 + 0.0 * x, 19.0 + 2.0 * np.sin(x / 40.0)])
+    elif flow == "diverging":
+        v = np.stack([-(x - n / 2.0) / 6.0, -(y - m / 2.0) / 6.0])
+    else:
+        v = np.stack([3.0 * np.sin(np.pi * x / (n - 1)) ** 2, -2.0 * np.sin(np.pi * y / (m - 1)) ** 2])
+        v[:, :, -1] = v[:, -1, :] = v[:, :, 0] = v[:, 0, :] = 0.0  # exactly at rest on the edges
+    v = v.astype(np.float32)
+    p = synth.rain_field_db(m, n, seed=12)
+    p[5:40, n - 2] = np.nan  # the mirror texels of column n
+    p[m - 2, 100:160] = np.nan
+    p[60:70, n - 1] = np.nan
+    lib = _lib.lib()
+    runs = {}
+    for variant in (7, 12):
+        _lib.check(lib.psh_set_option(b"semilag_variant", variant))
+        try:
+            runs[variant] = extrapolate(p, v, 12, n_iter=1, outval=-15.0, allow_nonfinite_values=True, return_displacement=True)
+        finally:
+            _lib.check(lib.psh_set_option(b"semilag_variant", 0))
+    assert np.array_equal(runs[12][0], runs[7][0], equal_nan=True)
+    assert np.array_equal(runs[12][1], runs[7][1], equal_nan=True)
+    want = ocl.extrapolate(p, v, 12, outval=-15.0)
+    got = runs[12][0]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isfinite(want)
+    assert np.linalg.norm(got[ok] - want[ok]) / np.linalg.norm(want[ok]) < 1e-4
+    if flow != "still_edges":
+        assert (got[-1] == -15.0).mean() > 0.3  # most of the last field came from outside
+
+
 @pytest.mark.parametrize("sentinel", [1e20, -1e20, 1e9, -3e9])
 def test_window_kernel_on_sentinel_velocities(extrapolate, sentinel):
     """Finite garbage in the motion field (a sentinel such as 1e20 in a patch): a trajectory that samples it leaves every
