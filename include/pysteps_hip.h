@@ -50,7 +50,7 @@ int psh_device_info(int *device_id, int *cu_count, size_t *hbm_total, size_t *hb
 
 /* knobs; "semilag_variant": 0 (default) the workgroup-window kernel - the motion field and the advected field of
  * a 64 x 32 tile's neighbourhood kept in LDS across lead steps - wherever it applies (interp_order 1 with a field,
- * n_iter >= 1, images >= 96 x 64 with n % 4 == 0, at least two sampling steps) and the gather kernels elsewhere;
+ * n_iter >= 1, images >= 96 x 64, at least two sampling steps) and the gather kernels elsewhere;
  * 12 the window kernel for every eligible call; 7 gather kernels only: velocity from a packed {u,v} plane and the field
  * from a row-pair plane with dwordx4 loads (the default of rounds 2 - 4); 5 the same without the row-pair plane;
  * 1 one plane per component with DPP column sharing (what calls of fewer than 8 sampling steps take among the gather

@@ -654,6 +654,8 @@ struct Window {
   // the window reaches beyond the image (uniform): its texels out there hold what the border rules read - the motion
   // field's edge values replicated, the advected field's mirror texel at index len - and a field sample may lie outside
   int edge;
+  // rows of the planes start on 16-byte boundaries (n % 4 == 0, 16-byte aligned planes): the fills move dwordx4 items
+  int fill16;
   unsigned long long *stats;
 };
 
@@ -719,10 +721,10 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
   constexpr int kFar = 1 << 27;  // (a saturated box - a trajectory at the end of the number line - places the window nowhere useful)
   const int want_x = min(max(sat_add(W.ox, sat_sub(bx0, keep_x)), -kFar), kFar) & ~3;
   const int want_y = min(max(sat_add(W.oy, sat_sub(by0, keep_y)), -kFar), kFar);
-  const int nox = rfl(GEN ? min(max(want_x, 0), n - C::kW) : want_x);
+  const int nox = rfl(GEN ? min(max(want_x, 0), n - C::kW) : want_x);  // (n - kW is a multiple of 4 where n is)
   const int noy = rfl(GEN ? min(max(want_y, 0), m - C::kH) : want_y);
   const bool edge = !GEN && (nox < 0 || nox + C::kW > n || noy < 0 || noy + C::kH > m);  // (uniform)
-  PSH_DASSERT((nox & 3) == 0 && (edge || (nox >= 0 && nox + C::kW <= n && noy >= 0 && noy + C::kH <= m)));  // the window lies in the image
+  PSH_DASSERT((W.fill16 == 0 || (nox & 3) == 0) && (edge || (nox >= 0 && nox + C::kW <= n && noy >= 0 && noy + C::kH <= m)));  // the window lies in the image
   // the room a patch needs ahead of its corner samples before the next lead step (the distance the last one covered + 2);
   // a lost trajectory (NaN) asks for nothing
   const float mvx = fabsf(wvx) < 64.f ? fabsf(wvx) * move_scale + 2.f : 2.f, mvy = fabsf(wvy) < 64.f ? fabsf(wvy) * move_scale + 2.f : 2.f;
@@ -749,6 +751,8 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
   // (threads past the last item repeat it: the same bytes to the same place, and no exec-masked rounds)
   u32x4 bu[kRounds], bv[kRounds], bp[kRounds];
   if (!edge) {
+    // (rows that do not start on 16-byte boundaries - n % 4 != 0 - load their items from dword-aligned addresses: a
+    // dwordx4 needs no more; round 6, such shapes took the gather kernels before)
     const unsigned org = static_cast<unsigned>(noy) * static_cast<unsigned>(n) + static_cast<unsigned>(nox);
 #pragma unroll
     for (int k = 0; k < kRounds; ++k) {
@@ -758,6 +762,31 @@ __device__ __forceinline__ void win_place_and_fill(const Fields &F, Window &W, b
       bu[k] = __builtin_amdgcn_raw_buffer_load_b128(F.ru, off, 0, 0);
       bv[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rv, off, 0, 0);
       bp[k] = __builtin_amdgcn_raw_buffer_load_b128(F.rp, off, 0, 0);
+    }
+  } else if (!W.fill16) {
+    // A window that reaches beyond an image whose rows do not start on 16-byte boundaries (n % 4 != 0: a 640 x 710
+    // composite, say): texel by texel, every one with its own clamped / mirrored column - the rules of the branch below,
+    // which here also cover an item that straddles the image's edge.  Twelve dword loads per item instead of three
+    // dwordx4, in border tiles only.
+#pragma unroll
+    for (int k = 0; k < kRounds; ++k) {
+      const int item = min(tid + C::kThreads * k, C::kItems - 1);
+      const int row = item / (C::kW / 4), c = item - row * (C::kW / 4);
+      const int r = noy + row, x0 = nox + 4 * c;
+      const int rv = min(max(r, 0), m - 1), rq = r == m ? m - 2 : rv;
+      const unsigned base_v = static_cast<unsigned>(__mul24(rv, n)), base_q = static_cast<unsigned>(__mul24(rq, n));
+      unsigned tu[4], tv[4], tq[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = x0 + e;
+        const int xv = min(max(x, 0), n - 1), xq = x == n ? n - 2 : xv;
+        tu[e] = __builtin_amdgcn_raw_buffer_load_b32(F.ru, static_cast<int>((base_v + xv) << 2), 0, 0);
+        tv[e] = __builtin_amdgcn_raw_buffer_load_b32(F.rv, static_cast<int>((base_v + xv) << 2), 0, 0);
+        tq[e] = __builtin_amdgcn_raw_buffer_load_b32(F.rp, static_cast<int>((base_q + xq) << 2), 0, 0);
+      }
+      bu[k] = u32x4{tu[0], tu[1], tu[2], tu[3]};
+      bv[k] = u32x4{tv[0], tv[1], tv[2], tv[3]};
+      bp[k] = u32x4{tq[0], tq[1], tq[2], tq[3]};
     }
   } else {
     // A window that reaches beyond the image.  Motion field, mode "nearest" (sample_velocity_border): every tap index is
@@ -1156,6 +1185,10 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
     W.lo_x = W.lo_y = 0;
     W.hi_x = W.hi_y = 0;
     W.edge = 0;
+    W.fill16 = ((n & 3) == 0 && (plane & 3) == 0 &&
+                ((reinterpret_cast<uintptr_t>(vel) | reinterpret_cast<uintptr_t>(precip)) & 15) == 0)
+                   ? 1
+                   : 0;
     W.stats = stats;
     if (threadIdx.x < 3) win_ctl[C::kCtlFlag / 4 + threadIdx.x] = 0;
 
@@ -1265,14 +1298,12 @@ __global__ __launch_bounds__(C::kThreads, C::kOcc) void semilag_window(
 }
 
 // the window kernel reads the planes as they are: no packed copy of anything
-static bool window_shape(int m, int n) { return n % 4 == 0 && n >= Win8::kW && m >= Win8::kH; }
+static bool window_shape(int m, int n) { return n >= Win8::kW && m >= Win8::kH; }
 
 bool semilag_window_eligible(const SemilagArgs &a) {
   // (a plane of the output below 0xfffffff0 bytes: the lanes without a pixel store to that offset, behind the buffer's end)
   return a.precip != nullptr && a.order == 1 && a.n_iter >= 1 && window_shape(a.m, a.n) &&
-         static_cast<size_t>(a.m) * a.n * sizeof(float) < 0xfffffff0ull &&
-         reinterpret_cast<uintptr_t>(a.vel) % 16 == 0 && reinterpret_cast<uintptr_t>(a.precip) % 16 == 0 &&
-         (static_cast<size_t>(a.m) * a.n) % 4 == 0;
+         static_cast<size_t>(a.m) * a.n * sizeof(float) < 0xfffffff0ull;
 }
 
 // ---- the order the tiles are started in (see win_next_slot) ----------------------------------------------
@@ -1446,7 +1477,7 @@ static hipError_t launch_variant(const SemilagArgs &a, hipStream_t stream) {
 }  // namespace
 
 // semilag_variant: 0 (default) = the workgroup-window kernel wherever it applies (bilinear resampling of a field,
-// n_iter >= 1, images of at least 96 x 64 pixels with n % 4 == 0, at least two sampling steps), the gather
+// n_iter >= 1, images of at least 96 x 64 pixels, at least two sampling steps), the gather
 // kernels elsewhere; 12 = the window kernel for every eligible call, however short; 7 = gather kernels only: velocity
 // from a packed {u,v} plane and the field from a row-pair plane (the default of rounds 2 - 4); 5 = packed velocity
 // only; 1 = one plane per component with DPP column sharing (what calls of fewer than 8 sampling steps take among the

@@ -40,8 +40,8 @@ _N_STATS = 8
 USE_NATIVE_ORCHESTRATION = True
 # a resident motion field also as (m, n, 2) {u, v} pairs (DeviceArray.uv_pairs): the layout of the extrapolator's gather
 # kernels (semilag_variant 7 / 5).  None (default): decided per field - the window kernel samples the planes, so the
-# twin's stores are only spent for shapes it does not take (psh_semilag_window_shape: n % 4 != 0, n < 96 or m < 64 - a
-# 640 x 710 composite, say), where every long extrapolation call would otherwise interleave the planes again.
+# twin's stores are only spent for shapes it does not take (psh_semilag_window_shape: n < 96 or m < 64), where every
+# long extrapolation call would otherwise interleave the planes again.
 # True / False: always / never
 WRITE_UV_TWIN = None
 # one corner request (launch -> finish) is in flight per process: callers on several threads

@@ -68,10 +68,11 @@ def test_product_never_imports_oracle():
 
 def test_window_shape_rule_needs_no_device():
     """psh_semilag_window_shape is a pure function (the LK shim asks it whether a motion field also needs its
-    {u, v}-pair layout): images of at least 96 x 64 pixels with a row length divisible by four."""
+    {u, v}-pair layout): images of at least 96 x 64 pixels (since round 6 whatever the row length: rows that are not
+    16-byte aligned are filled texel by texel)."""
     from pysteps_amd import _lib
 
     lib = _lib.load()
     assert lib.psh_semilag_window_shape(4096, 4096) == 1 and lib.psh_semilag_window_shape(64, 96) == 1
-    assert lib.psh_semilag_window_shape(640, 710) == 0  # n % 4 != 0
+    assert lib.psh_semilag_window_shape(640, 710) == 1  # n % 4 != 0: taken too
     assert lib.psh_semilag_window_shape(63, 4096) == 0 and lib.psh_semilag_window_shape(4096, 92) == 0

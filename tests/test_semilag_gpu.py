@@ -588,6 +588,43 @@ def test_window_follows_the_samples_out_of_the_image(extrapolate, flow):
         assert (got[-1] == -15.0).mean() > 0.3  # most of the last field came from outside
 
 
+@pytest.mark.parametrize("shape", [(640, 710), (130, 99), (257, 1001), (64, 96)])
+def test_window_kernel_on_rows_that_are_not_16_byte_aligned(extrapolate, shape):
+    """n % 4 != 0 (the 640 x 710 composite of the reference's example data): since round 6 the window kernel takes such
+    shapes too - its fills go texel by texel - instead of leaving them to the gather kernels.  Bit for bit against those
+    (``semilag_variant`` 7) with samples leaving the image, NaNs at the far edges and a resumed displacement; against the
+    oracle; and the default selection does pick the window kernel."""
+    from oracle import semilag_cport as ocl
+    from pysteps_amd import _lib
+    from tools import synth
+
+    m, n = shape
+    v = synth.true_velocity(m, n) * 2.5
+    v[0] -= 6.0  # towards higher columns: the right edge is crossed
+    p = synth.rain_field_db(m, n, seed=m + n)
+    p[m // 3: m // 3 + 9, n - 2] = np.nan
+    p[m - 2, n // 4: n // 2] = np.nan
+    lib = _lib.lib()
+    assert lib.psh_semilag_window_shape(m, n) == 1
+    runs = {}
+    for variant in (7, 0):
+        _lib.check(lib.psh_set_option(b"semilag_variant", variant))
+        try:
+            a, da = extrapolate(p, v, 7, n_iter=1, outval=-15.0, allow_nonfinite_values=True, return_displacement=True)
+            b, db = extrapolate(p, v, [1.0, 2.5], n_iter=2, outval=-15.0, allow_nonfinite_values=True, return_displacement=True,
+                                displacement_prev=da)
+            runs[variant] = (a, da, b, db)
+        finally:
+            _lib.check(lib.psh_set_option(b"semilag_variant", 0))
+    for got, want in zip(runs[0], runs[7]):
+        assert np.array_equal(got, want, equal_nan=True)
+    want = ocl.extrapolate(p, v, 7, outval=-15.0)
+    got = runs[0][0]
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = np.isfinite(want)
+    assert np.linalg.norm(got[ok] - want[ok]) / np.linalg.norm(want[ok]) < 1e-4
+
+
 @pytest.mark.parametrize("sentinel", [1e20, -1e20, 1e9, -3e9])
 def test_window_kernel_on_sentinel_velocities(extrapolate, sentinel):
     """Finite garbage in the motion field (a sentinel such as 1e20 in a patch): a trajectory that samples it leaves every
@@ -850,7 +887,7 @@ def test_interleaved_motion_field_twin_is_the_field_and_gives_the_same_advection
 
     dense_lk = get_method("LK")
     lib = _lib.lib()
-    for m, n in ((512, 512), (130, 203)):  # (the second shape is not one the window kernel takes)
+    for m, n in ((512, 512), (130, 92)):  # (the second shape is not one the window kernel takes: fewer than 96 columns)
         frames = synth.steps_frames(m, n, 2)
         # the default (None) decides per field: no second layout where the window kernel samples the planes, the twin
         # for shapes it does not take (they would interleave the planes on every long call otherwise)
