@@ -867,7 +867,12 @@ __device__ __forceinline__ void win_update(const Fields &F, Window &W, int phase
 // counters: one s_waitcnt with every destination tied to it.  The trajectory update and the weights run as
 // v_pk_*_f32 on the (x, y) pair of a pixel, the velocity blend on its (u, v) pair with the weights broadcast by
 // op_sel, same operations, same order, same rounding per component (no contraction in this file) - bit-identical
-// with the gather kernels - at 13 LDS reads and 63 VALU instructions per pixel and lead step (54.5 in this fast path).
+// with the gather kernels - at 13 LDS reads and 58 VALU instructions per pixel and lead step (round 5: 63).
+// Round 6: everything that does not depend on the taps runs between the issue of the reads and the wait
+// (the weights; as register pairs over two pixels in the pass that also reads the field), the first pixel pair is
+// blended once ITS taps are back, the output goes through a buffer descriptor.  Build-time knobs for same-box A/B runs
+// (tools/build_variant.sh ... -D<knob>): PSH_WIN_NO_PAIR_WEIGHTS, PSH_WIN_NO_STAGED_WAIT, PSH_WIN_MASKED_STORES switch
+// the three steps off again (profiles/r06/q_window_pairs_staged_buffer_ab.txt); all forms are bit-identical.
 // (Round 5 measured two other forms of the same window: u, v and the field as three planes with every
 // floating-point operation packed over the two vertically adjacent pixels of a lane - 21 LDS reads, 54 VALU, but
 // three times the LDS-issue stalls: 1.200 against 1.158 ms - and the gather kernel's arithmetic on a {u,v} window - 73 VALU: 1.28 ms;
